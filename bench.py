@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py — volume-pairs/s of the TransMF_AD train step (fwd + bwd + Adam) on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = the reference's train_step (kfold_train_adversarial.py:101-136) on one synthetic
+batch already resident in HBM: zero_grad, forward of model_ad(dim=128, depth=3, heads=4,
+dim_head=32, mlp_dim=512), CE + adversarial CE, backward, (gradient all-reduce over RCCL when
+N > 1), Adam step.  Workload (BASELINE.json configs[1]): batch 8 per GPU of 1x96^3 MRI+PET pairs,
+fp32.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU x 2.4 GHz
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_flops_per_pair(size, dim=128):
+    """Algorithmic conv FLOPs fwd+bwd per MRI+PET pair: 6*sum(F_l) - 2*F_conv1 per
+    stream... summed over both streams; no dgrad for conv1."""
+    q, h, d, d2 = dim // 4, dim // 2, dim, dim * 2
+    layers = [(1, q, 3, 1), (q, q, 3, 2), (q, h, 3, 2), (h, h, 3, 4), (h, d, 3, 4), (d, d2, 3, 8), (d2, d, 1, 8)]
+    tot = 0.0
+    for i, (ci, co, k, div) in enumerate(layers):
+        s = size // div
+        f = 2.0 * ci * co * k ** 3 * s ** 3
+        tot += f * (2 if i == 0 else 3)
+    return 2 * tot
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="pairs per GPU")
+    ap.add_argument("--size", type=int, default=96)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=2, help="pairs in the bounded CPU sample")
+    args = ap.parse_args()
+
+    from transmf_ad_amd import model_ad, ops, _lib
+    from transmf_ad_amd.parallel import GradAllReduce, init_from_env
+
+    rank, local, world = init_from_env()
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    torch.manual_seed(0)
+    net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to(dev)
+    if world > 1:
+        net = GradAllReduce(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    crit = nn.CrossEntropyLoss()
+    B, S = args.batch, args.size
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    mri = torch.rand((B, 1, S, S, S), device=dev, generator=g)
+    pet = torch.rand((B, 1, S, S, S), device=dev, generator=g)
+    label = (torch.arange(B, device=dev) % 2).long()
+    ones = torch.ones(B, dtype=torch.int64, device=dev)
+    zeros = torch.zeros(B, dtype=torch.int64, device=dev)
+
+    def step():
+        net.train()
+        opt.zero_grad()
+        lo, dm, dp = net(mri, pet)
+        loss = (crit(dm, ones) + crit(dp, zeros)) / 2 + crit(lo, label)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = loss.item()
+    assert final_loss == final_loss, "loss is NaN"
+
+    ms_per_step = dt / args.steps * 1e3
+    pairs_per_s = world * B * args.steps / dt
+
+    # ---- roofline of the dominant kernel: conv3d_fwd_kernel (forward + data-gradient = 2/3 of
+    # the MFMA work) at its largest launch, conv2.3 (32 -> 64 channels at (S/2)^3), timed live
+    # with HIP events on the stream the kernel is launched on ----
+    roof = None
+    if rank == 0:
+        s2 = S // 2
+        x = torch.randn((B, s2, s2, s2, 32), device=dev)
+        w = torch.randn((27, 32, 64), device=dev) * 0.03
+        for _ in range(3):
+            ops.conv3d_raw(x, w, 32, 64, 3, True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        z = torch.empty((B, s2, s2, s2, 64), device=dev)
+        nblk = _lib.query("tmf_conv3d_stat_blocks", B, s2, s2, s2, 32, 64, 3)
+        part = torch.empty((nblk, 2, 64), device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            _lib.call("tmf_conv3d_fwd", x.data_ptr(), w.data_ptr(), z.data_ptr(), part.data_ptr(),
+                      B, s2, s2, s2, 32, 64, 3, st)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / reps
+        flops = 2.0 * 27 * 32 * 64 * B * s2 ** 3
+        ach = flops / (k_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": "conv3d_fwd_kernel<L64,k3,cin32> @conv2.3", "achieved": round(ach, 2),
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                "traffic": None, "launch_ms": round(k_ms, 4), "flops_per_launch": flops}
+        del x, w, z, part
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import tmf_oracle as O         # test infrastructure, used ONLY as the timed CPU baseline
+        sec, threads = O.cpu_train_step_seconds(args.cpu_batch, S, steps=1, warmup=1, threads=os.cpu_count())
+        cpu = {"value": round(args.cpu_batch / sec, 4), "unit": "volume-pairs/s", "cores": threads, "kind": "port",
+               "sample": f"oracle model_ad train-mode fwd+bwd, batch {args.cpu_batch} of 1x{S}^3 pairs "
+                         f"(1/{max(1, B // args.cpu_batch)} of one batch-{B} step), 1 warm-up + 1 timed step, "
+                         f"{sec:.2f} s/step, host cpu_count={os.cpu_count()}"}
+
+    if rank == 0:
+        gf = conv_flops_per_pair(S)
+        out = {
+            "metric": "volume-pairs/sec fwd+bwd(+Adam), 96^3 MRI+PET batch=8 per GPU",
+            "value": round(pairs_per_s, 3), "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512) train step, "
+                                   f"batch {B} pairs of 1x{S}^3 per GPU, fp32 (BASELINE configs[1])",
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       "step": "zero_grad+fwd+loss+bwd+allreduce+Adam"},
+            "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
+            "loss": round(final_loss, 6),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,157 @@
+/*
+ * tmf_hip.h — C ABI of libtmf_hip.so: the MI355X (gfx950) kernels behind the
+ * TransMF_AD forward/backward hot path.
+ *
+ * The reference (Kateridge/TransMF_AD) has no FFI of its own: the whole path is a
+ * sequence of ATen calls issued by Python nn.Modules.  Each entry point below
+ * therefore replaces a group of ATen calls at a cited reference call site; the
+ * Python package `transmf_ad_amd` binds them with ctypes (transmf_ad_amd/_lib.py)
+ * from torch.autograd.Functions, and INTEGRATION.md shows the binding a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers (hipMalloc'd / torch.Tensor.data_ptr()),
+ *    fp32 unless stated; all buffers, including workspaces, are caller-allocated.
+ *  - Activations are channels-last:  x[b][d][h][w][c]  ("NDHWC").
+ *  - 3x3x3 weights are tap-major:    w[kd*9+kh*3+kw][cin][cout]; 1x1x1: w[cin][cout].
+ *  - `stream` is a hipStream_t passed as void*; every call is asynchronous on it,
+ *    never synchronises, never allocates, never throws.  Stateless and re-entrant.
+ *  - Return: 0 = launched; <0 = TMF_E_* argument error (nothing launched);
+ *    >0 = hipError_t from the launch.  tmf_last_error_string() describes the last
+ *    non-zero return on the calling thread.
+ */
+#ifndef TMF_HIP_H
+#define TMF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMF_OK              0
+#define TMF_E_NULL         -1   /* a required pointer is NULL */
+#define TMF_E_SHAPE        -2   /* unsupported / inconsistent shape */
+#define TMF_E_ALIGN        -3   /* pointer not 16-byte aligned */
+#define TMF_E_WORKSPACE    -4   /* workspace smaller than *_workspace_bytes() */
+#define TMF_E_ARG          -5   /* bad enum / scalar argument */
+
+#define TMF_POOL_NONE 0
+#define TMF_POOL_MAX2 1        /* MaxPool3d(2, stride=2), floor mode */
+#define TMF_POOL_AVG2 2        /* AvgPool3d(2, stride=2), floor mode */
+
+int         tmf_version(void);                 /* ABI version, currently 1 */
+const char* tmf_last_error_string(void);
+
+/* ------------------------------------------------------------------------------
+ * 3-D convolution, stride 1, "same" zero padding, cross-correlation, NO bias
+ * (a bias ahead of BatchNorm is folded into the BN shift / running mean by
+ * tmf_bn_finalize).  Replaces F.conv3d at networks.py:22,28,31,37,40,46,49.
+ *
+ * ksize = 3 or 1.  fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32 (exact fp32).
+ * If `stat_partial` != NULL the kernel also writes per-workgroup partial sums
+ * [nblk][2][cout] (sum z, sum z^2) for the BatchNorm statistics, nblk =
+ * tmf_conv3d_stat_blocks(); reduce them with tmf_bn_finalize.
+ * The data-gradient of the layer is the SAME entry called on dz with the weight
+ * tensor flipped and transposed (w'[26-t][co][ci] = w[t][ci][co]).
+ * ---------------------------------------------------------------------------- */
+int  tmf_conv3d_fwd(const float* x, const float* w, float* z, float* stat_partial,
+                    int B, int D, int H, int W, int cin, int cout, int ksize, void* stream);
+int  tmf_conv3d_stat_blocks(int B, int D, int H, int W, int cin, int cout, int ksize);
+
+/* Weight gradient: dw[t][ci][co] = sum_{b,pos} x[b,pos+t-1][ci] * dz[b,pos][co].
+ * Two stages: split-K partial slabs into `workspace`, then a deterministic reduce.
+ * Replaces the weight half of aten::convolution_backward for the call sites above. */
+size_t tmf_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int cin, int cout, int ksize);
+int    tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
+                        int B, int D, int H, int W, int cin, int cout, int ksize, void* stream);
+
+/* First layer, cin == 1 (networks.py:22): x[b][d][h][w], w[27][cout]. */
+int    tmf_conv3d_c1_fwd(const float* x, const float* w, float* z, float* stat_partial,
+                         int B, int D, int H, int W, int cout, void* stream);
+int    tmf_conv3d_c1_stat_blocks(int B, int D, int H, int W, int cout);
+size_t tmf_conv3d_c1_wgrad_workspace_bytes(int B, int D, int H, int W, int cout);
+int    tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
+                           int B, int D, int H, int W, int cout, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * BatchNorm3d (training statistics) + LeakyReLU + 2x2x2 pool, two passes.
+ * Replaces F.batch_norm / leaky_relu / max_pool3d / avg_pool3d at
+ * networks.py:23-25,29-30,32-34,38-39,41-43,47-48,50-52.
+ * ---------------------------------------------------------------------------- */
+
+/* Reduce the conv's partial sums -> per-channel mean / invstd / scale / shift and
+ * update the running buffers (momentum, unbiased running_var, torch semantics).
+ * conv_bias (may be NULL) is added to the mean that goes into running_mean.
+ * count = B*D*H*W.  running_* may be NULL (no update). */
+int tmf_bn_finalize(const float* stat_partial, int nblk, int C, double count,
+                    const float* gamma, const float* beta, const float* conv_bias,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    float* mean, float* invstd, float* scale, float* shift, void* stream);
+
+/* Eval mode: scale/shift from the running statistics (and the folded conv bias). */
+int tmf_bn_eval_coeffs(const float* gamma, const float* beta, const float* conv_bias,
+                       const float* running_mean, const float* running_var, float eps, int C,
+                       float* scale, float* shift, void* stream);
+
+/* out = pool(leaky_relu(z*scale + shift, slope)); out dims are floor(D/2).. for pools. */
+int tmf_bn_act_pool_fwd(const float* z, const float* scale, const float* shift, float* out,
+                        int B, int D, int H, int W, int C, int pool, float slope, void* stream);
+
+/* Backward pass 1: per-workgroup partials [nblk][2][C] of sum(dy) and sum(dy*xhat),
+ * dy = d(loss)/d(BN output) obtained from `dout` through pool and LeakyReLU. */
+int tmf_bn_act_pool_bwd_blocks(int B, int D, int H, int W, int C, int pool);
+int tmf_bn_act_pool_bwd_reduce(const float* z, const float* dout, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, float* partial,
+                               int B, int D, int H, int W, int C, int pool, float slope, void* stream);
+/* Reduce partials -> dgamma, dbeta and the two per-channel constants the apply pass needs
+ * (coef[0][c] = sum(dy)/count, coef[1][c] = sum(dy*xhat)/count). */
+int tmf_bn_bwd_finalize(const float* partial, int nblk, int C, double count,
+                        float* dgamma, float* dbeta, float* coef, void* stream);
+/* Backward pass 2: dz = scale * (dy - coef0 - xhat*coef1). */
+int tmf_bn_act_pool_bwd_apply(const float* z, const float* dout, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, const float* coef, float* dz,
+                              int B, int D, int H, int W, int C, int pool, float slope, void* stream);
+
+/* Sum `nblk` partial rows of `ncol` floats (fp64 accumulation) into out[ncol]. */
+int tmf_colsum_finalize(const float* partial, int nblk, int ncol, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * Fused multi-head cross attention:  out = softmax(q k^T * scale) v
+ * (networks.py:169-173: einsum -> softmax -> einsum, plus the two rearranges).
+ * q: [B][N][*] rows of stride q_stride floats, head h at columns [h*dh, (h+1)*dh);
+ * k, v: [B][M][*] rows of stride kv_stride (so they can alias the to_kv output);
+ * out: [B][N][heads*dh] ('b n (h d)'); lse: [B][heads][N] log-sum-exp (saved for bwd).
+ * dh must be 8, 16, 32 or 64.
+ * ---------------------------------------------------------------------------- */
+int tmf_xattn_fwd(const float* q, const float* k, const float* v, float* out, float* lse,
+                  int B, int heads, int N, int M, int dh, int q_stride, int kv_stride, float scale,
+                  void* stream);
+/* dq: [B][N][heads*dh] (stride heads*dh); dk, dv: rows of stride dkv_stride. */
+int tmf_xattn_bwd(const float* q, const float* k, const float* v, const float* out, const float* lse,
+                  const float* dout, float* dq, float* dk, float* dv,
+                  int B, int heads, int N, int M, int dh, int q_stride, int kv_stride, int dkv_stride,
+                  float scale, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * LayerNorm over the last dim (networks.py:117,219) and the token pooling of
+ * CrossTransformer_MOD_AVG.forward (networks.py:276-281).
+ * ---------------------------------------------------------------------------- */
+int tmf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                      float* mean, float* rstd, int rows, int dim, float eps, void* stream);
+int tmf_layernorm_bwd_blocks(int rows, int dim);
+/* partial: [nblk][2][dim] (dgamma, dbeta partials; reduce with tmf_colsum_finalize, ncol = 2*dim). */
+int tmf_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
+                      const float* dy, float* dx, float* partial, int rows, int dim, void* stream);
+
+/* cls[b] = [mean_n mri | mean_n pet | max_n mri | max_n pet]  (4*dim); argmax: int32 [B][2][dim]. */
+int tmf_token_pool_fwd(const float* mri, const float* pet, float* cls, int32_t* argmax,
+                       int B, int N, int dim, void* stream);
+int tmf_token_pool_bwd(const float* dcls, const int32_t* argmax, float* dmri, float* dpet,
+                       int B, int N, int dim, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMF_HIP_H */

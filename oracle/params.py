@@ -1,0 +1,81 @@
+"""Regenerable inputs and parameters for the golden fixtures (TEST INFRASTRUCTURE).
+
+Nothing here depends on the reference or on torch's RNG: every array comes from
+numpy's frozen legacy MT19937 stream (``np.random.RandomState``), so the 16.7 MB
+of weights and the volumes never need to be stored — only the seeds do
+(SURVEY.md §8c "Fixture recipe").
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _fan(shape):
+    """(fan_in, fan_out) as torch.nn.init computes them."""
+    if len(shape) < 2:
+        return shape[0], shape[0]
+    rf = int(np.prod(shape[2:])) if len(shape) > 2 else 1
+    return shape[1] * rf, shape[0] * rf
+
+
+def init_arrays(spec, seed: int = 7) -> dict:
+    """Per-tensor fill in ``spec`` (state_dict) order.
+
+    conv weights   ~ N(0, sqrt(2/fan_out))   (same scale as kaiming_normal_(fan_out, relu),
+                                              mymodel.py:195-199)
+    other weights  ~ N(0, 1/sqrt(fan_in))
+    conv / linear biases ~ N(0, 0.1)
+    norm gammas    = 1 + 0.1 n,  norm betas = 0.1 n         (n ~ N(0,1))
+    running_mean   = 0.1 n,  running_var = 1 + 0.1 |n|,  num_batches_tracked = 0
+    """
+    rs = np.random.RandomState(seed)
+    out = {}
+    for name, (kind, shape) in spec.items():
+        if name.endswith("num_batches_tracked"):
+            out[name] = np.zeros((), np.int64)
+            continue
+        n = rs.standard_normal(shape).astype(np.float64)
+        is_norm = len(shape) == 1 and (".norm." in name or _is_bn_key(name, spec))
+        if name.endswith("running_mean"):
+            a = 0.1 * n
+        elif name.endswith("running_var"):
+            a = 1.0 + 0.1 * np.abs(n)
+        elif is_norm:
+            a = 1.0 + 0.1 * n if name.endswith("weight") else 0.1 * n
+        elif len(shape) == 5:
+            a = n * np.sqrt(2.0 / _fan(shape)[1])
+        elif len(shape) == 2:
+            a = n / np.sqrt(_fan(shape)[0])
+        else:                       # biases
+            a = 0.1 * n
+        out[name] = a.astype(np.float32)
+    return out
+
+
+def _is_bn_key(name: str, spec) -> bool:
+    """A 1-d '.weight'/'.bias' belongs to a BatchNorm iff its prefix also owns a running_mean."""
+    prefix = name.rsplit(".", 1)[0]
+    return (prefix + ".running_mean") in spec
+
+
+def make_inputs(batch: int, size, seed: int = 1234):
+    """MRI first, then PET, from one stream, uniform [0,1) (the range ScaleIntensityd
+    produces, datasets/ADNI.py:64); labels arange(B) % 2."""
+    rs = np.random.RandomState(seed)
+    shape = (batch, 1) + tuple(size)
+    mri = rs.rand(*shape).astype(np.float32)
+    pet = rs.rand(*shape).astype(np.float32)
+    y = (np.arange(batch) % 2).astype(np.int64)
+    return mri, pet, y
+
+
+def make_masks(batch: int, seed: int = 99):
+    """Keep-masks for the two Dropout(0.5) layers of model_ad.fc_cls (mymodel.py:190-191)."""
+    rs = np.random.RandomState(seed)
+    return rs.rand(batch, 512) >= 0.5, rs.rand(batch, 64) >= 0.5
+
+
+def probe_indices(numel: int, k: int = 16, seed: int = 5):
+    """Fixed flat indices at which tensors are sampled into the fixtures."""
+    rs = np.random.RandomState(seed + (numel % 9973))
+    return rs.randint(0, numel, size=min(k, numel)).astype(np.int64)

@@ -1,0 +1,20 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: CPU test that takes more than ~20 s")
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests fail loudly (not skip) when selected without a GPU: a silent skip would
+    look like a pass.  They are deselected by `-m "not gpu"` on the CPU box."""
+    return

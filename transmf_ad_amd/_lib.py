@@ -1,0 +1,92 @@
+"""ctypes binding of libtmf_hip.so (C ABI: include/tmf_hip.h).
+
+There is NO fallback: if the library is missing, or a call returns non-zero, this
+module raises.  The product path never routes around the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtmf_hip.so")
+
+POOL_NONE, POOL_MAX2, POOL_AVG2 = 0, 1, 2
+_POOL = {None: POOL_NONE, "none": POOL_NONE, "max": POOL_MAX2, "avg": POOL_AVG2}
+
+_p = C.c_void_p
+_i = C.c_int
+_f = C.c_float
+_d = C.c_double
+_z = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/tmf_hip.h declaration by declaration
+PROTOTYPES = {
+    "tmf_version": (_i, []),
+    "tmf_last_error_string": (C.c_char_p, []),
+    "tmf_conv3d_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tmf_conv3d_stat_blocks": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "tmf_conv3d_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
+    "tmf_conv3d_wgrad": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tmf_conv3d_c1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "tmf_conv3d_c1_stat_blocks": (_i, [_i, _i, _i, _i, _i]),
+    "tmf_conv3d_c1_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "tmf_conv3d_c1_wgrad": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
+    "tmf_bn_finalize": (_i, [_p, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
+    "tmf_bn_eval_coeffs": (_i, [_p, _p, _p, _p, _p, _f, _i, _p, _p, _p]),
+    "tmf_bn_act_pool_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "tmf_bn_act_pool_bwd_blocks": (_i, [_i, _i, _i, _i, _i, _i]),
+    "tmf_bn_act_pool_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "tmf_bn_bwd_finalize": (_i, [_p, _i, _i, _d, _p, _p, _p, _p]),
+    "tmf_bn_act_pool_bwd_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "tmf_colsum_finalize": (_i, [_p, _i, _i, _p, _p]),
+    "tmf_xattn_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "tmf_xattn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
+    "tmf_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "tmf_layernorm_bwd_blocks": (_i, [_i, _i]),
+    "tmf_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "tmf_token_pool_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+    "tmf_token_pool_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+class TmfError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libtmf_hip.so (once) and attach prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise TmfError(
+            f"{LIB_PATH} is missing: build it with `python -m transmf_ad_amd.build` "
+            "(hipcc --offload-arch=gfx950). transmf_ad_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def pool_code(pool):
+    return _POOL[pool]
+
+
+def call(name, *args):
+    """Call an int-returning entry point; raise TmfError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.tmf_last_error_string()
+        raise TmfError(f"{name} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def query(name, *args):
+    """Call a size/count query (no error code)."""
+    return getattr(load(), name)(*args)

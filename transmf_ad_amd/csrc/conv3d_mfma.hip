@@ -1,0 +1,878 @@
+// conv3d_mfma.hip — im2col-free fp32 MFMA 3-D convolution for gfx950 (MI355X).
+//
+// Forward / data-gradient:  z[pos][co] = sum_{tap,ci} x[pos + tap - 1][ci] * w[tap][ci][co]
+// as an implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32, 157 TF peak):
+//   * a workgroup owns a TD x TH x TW brick of output voxels and NB output channels;
+//   * the (TD+2)(TH+2)(TW+2) x CINC input halo is staged ONCE per input-channel chunk in
+//     LDS (channels-last rows, 16-B padded) and re-used by all 27 taps -> no im2col,
+//     HBM/L2 sees each input voxel ~2.3x instead of 27x;
+//   * weights stream through a double-buffered LDS ring, one (kd,kh) row of 3 taps per
+//     stage, prefetched into registers while the previous stage computes (one barrier
+//     per stage);
+//   * A operand (voxels x cin) is read with one ds_read_b128 per 4 MFMAs using a
+//     K-permutation: within a group of 8 input channels lanes 0-31 take channels 0-3
+//     and lanes 32-63 channels 4-7 (the GEMM K order is free as long as B agrees);
+//   * epilogue: 128-B row segments of NDHWC output per half-wave + per-workgroup
+//     sum / sum-of-squares partials for the BatchNorm statistics.
+//
+// Weight-gradient: dw[tap][ci][co] = sum_pos x[pos+tap-1][ci] dz[pos][co] with
+// M = ci, N = co, K = voxels; the 27 taps are spread over the 4 waves (7 accumulators
+// each), the workgroup walks a contiguous range of bricks (split-K) and writes one
+// partial slab; a second kernel reduces the slabs deterministically.
+//
+// Replaces aten::conv3d / convolution_backward at /root/reference/models/networks.py:
+// 22,28,31,37,40,46,49.
+#include "tmf_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------
+// forward / dgrad
+// ------------------------------------------------------------------------------------
+template <int KS_, int CINC_, int MT_, int NT_, int WM_, int WN_, int TD_, int TH_, int TW_, int TPS_>
+struct FwdCfg {
+    static constexpr int KS = KS_, CINC = CINC_, MT = MT_, NT = NT_, WM = WM_, WN = WN_;
+    static constexpr int TD = TD_, TH = TH_, TW = TW_, TPS = TPS_;
+    static constexpr int PAD = KS / 2;
+    static constexpr int HD = TD + 2 * PAD, HH = TH + 2 * PAD, HW = TW + 2 * PAD;
+    static constexpr int NHALO = HD * HH * HW;
+    static constexpr int CP = CINC + 4;                  // padded halo row (floats), keeps 16-B alignment
+    static constexpr int NPOS = TD * TH * TW;
+    static constexpr int NB = 32 * NT * WN;              // output channels per workgroup
+    static constexpr int NTAPS = KS * KS * KS;
+    static constexpr int NSTAGES = NTAPS / TPS;
+    static constexpr int BSTAGE = TPS * CINC * NB;       // floats per weight stage
+    static constexpr int BV = (BSTAGE / 4 + 255) / 256;  // float4 prefetch registers per thread
+    static constexpr int RED = 4 * 32 * NT * 2;          // cross-wave stat scratch (floats)
+    static constexpr size_t LDS_BYTES = (size_t)(NHALO * CP + 2 * BSTAGE + RED) * 4;
+    static_assert(NPOS == 32 * MT * WM, "brick must be MT*WM tiles of 32 voxels");
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(CINC % 8 == 0, "cin chunk is a multiple of 8");
+    static_assert(NTAPS % TPS == 0, "taps per stage must divide the tap count");
+    static_assert(KS == 1 || TPS == 1 || TPS == 3, "stage = 1 tap or one kw row");
+};
+
+template <class C, bool VEC>
+__global__ __launch_bounds__(256) void conv3d_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
+    float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
+    int tilesD, int tilesH, int tilesW, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;
+    float* Bs = smem + C::NHALO * C::CP;
+    float* red = Bs + 2 * C::BSTAGE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hsel = lane >> 5;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+
+    const int tile = xcd_contiguous(blockIdx.x, ntiles);
+    int t = tile;
+    const int tw = t % tilesW; t /= tilesW;
+    const int th = t % tilesH; t /= tilesH;
+    const int td = t % tilesD;
+    const int b = t / tilesD;
+    const int d0 = td * C::TD, h0 = th * C::TH, w0 = tw * C::TW;
+    const int n0 = blockIdx.y * C::NB;
+    const bool wave_active = (n0 + wn * C::NT * 32) < Cout;
+
+    // per-lane halo float index of the voxel this lane feeds to M-tile i (tap (0,0,0))
+    int a_lane[C::MT];
+#pragma unroll
+    for (int i = 0; i < C::MT; ++i) {
+        const int p = (wm * C::MT + i) * 32 + l31;
+        const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
+        a_lane[i] = ((pd * C::HH + ph) * C::HW + pw) * C::CP + hsel * 4;
+    }
+    const int b_lane = hsel * 4 * C::NB + wn * C::NT * 32 + l31;
+
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* xb = x + (size_t)b * D * H * W * Cin;
+
+    for (int c0 = 0; c0 < Cin; c0 += C::CINC) {
+        if (c0 > 0) __syncthreads();   // everyone is done with the previous halo and weight ring
+        // ---- stage the input halo for channels [c0, c0+CINC) ----
+        constexpr int C4 = C::CINC / 4;
+        for (int e = tid; e < C::NHALO * C4; e += 256) {
+            const int hp = e / C4, c4 = e % C4;
+            const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
+            const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
+            const int c = c0 + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
+                const float* src = xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c;
+                if (VEC) {
+                    if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c + q < Cin) v[q] = src[q];
+                }
+            }
+            *reinterpret_cast<f32x4*>(&halo[hp * C::CP + c4 * 4]) = v;
+        }
+
+        // ---- weight stage loader: element e -> (row = tap_in_stage*CINC + ci, 4 couts) ----
+        f32x4 breg[C::BV];
+        auto load_b = [&](int st) {
+#pragma unroll
+            for (int q = 0; q < C::BV; ++q) {
+                const int e = tid + q * 256;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (e < C::BSTAGE / 4) {
+                    const int row = e / (C::NB / 4), col = (e % (C::NB / 4)) * 4;
+                    const int tap = st * C::TPS + row / C::CINC;
+                    const int ci = c0 + row % C::CINC;
+                    const int co = n0 + col;
+                    if (ci < Cin) {
+                        const float* src = w + ((size_t)tap * Cin + ci) * Cout + co;
+                        if (VEC) {
+                            if (co < Cout) v = *reinterpret_cast<const f32x4*>(src);
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (co + u < Cout) v[u] = src[u];
+                        }
+                    }
+                }
+                breg[q] = v;
+            }
+        };
+        auto store_b = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < C::BV; ++q) {
+                const int e = tid + q * 256;
+                if (e < C::BSTAGE / 4)
+                    *reinterpret_cast<f32x4*>(&Bs[buf * C::BSTAGE + e * 4]) = breg[q];
+            }
+        };
+
+        load_b(0);
+        for (int st = 0; st < C::NSTAGES; ++st) {
+            const int buf = st & 1;
+            store_b(buf);
+            __syncthreads();
+            if (st + 1 < C::NSTAGES) load_b(st + 1);   // in flight while this stage computes
+            if (wave_active) {
+                // halo offset of this stage's first tap
+                int stage_off;
+                if (C::KS == 1) stage_off = 0;
+                else if (C::TPS == 3) stage_off = ((st / 3) * C::HH + (st % 3)) * C::HW * C::CP;
+                else stage_off = (((st / 9) * C::HH + (st / 3) % 3) * C::HW + st % 3) * C::CP;
+                const float* bs = Bs + buf * C::BSTAGE + b_lane;
+#pragma unroll
+                for (int tp = 0; tp < C::TPS; ++tp) {
+#pragma unroll
+                    for (int g = 0; g < C::CINC / 8; ++g) {
+                        f32x4 a[C::MT];
+#pragma unroll
+                        for (int i = 0; i < C::MT; ++i)
+                            a[i] = *reinterpret_cast<const f32x4*>(&halo[a_lane[i] + stage_off + tp * C::CP + g * 8]);
+#pragma unroll
+                        for (int j = 0; j < C::NT; ++j) {
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) {
+                                const float bv = bs[(tp * C::CINC + g * 8 + s) * C::NB + j * 32];
+#pragma unroll
+                                for (int i = 0; i < C::MT; ++i)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], bv, acc[i][j], 0, 0, 0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: NDHWC store (+ BatchNorm statistic partials) ----
+    // C/D fragment: column = lane & 31 (output channel), row r -> voxel (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float s1[C::NT], s2[C::NT];
+#pragma unroll
+    for (int j = 0; j < C::NT; ++j) s1[j] = s2[j] = 0.f;
+    float* zb = z + (size_t)b * D * H * W * Cout;
+#pragma unroll
+    for (int i = 0; i < C::MT; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = (wm * C::MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+            const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
+            const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+            const bool pv = gd < D && gh < H && gw < W;
+            float* dst = zb + ((size_t)(gd * H + gh) * W + gw) * Cout;
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j) {
+                const int co = n0 + (wn * C::NT + j) * 32 + l31;
+                if (pv && co < Cout) {
+                    const float v = acc[i][j][r];
+                    dst[co] = v;
+                    s1[j] += v;
+                    s2[j] += v * v;
+                }
+            }
+        }
+    }
+    if (stat_partial != nullptr) {
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+        }
+        // red[wave][j*32 + l31][2]
+        if (hsel == 0) {
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j) {
+                red[(wave * C::NT * 32 + j * 32 + l31) * 2 + 0] = s1[j];
+                red[(wave * C::NT * 32 + j * 32 + l31) * 2 + 1] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < C::NB) {
+            const int wn_t = tid / (C::NT * 32), col = tid % (C::NT * 32);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < C::WM; ++m) {
+                const int wv = m * C::WN + wn_t;
+                a1 += red[(wv * C::NT * 32 + col) * 2 + 0];
+                a2 += red[(wv * C::NT * 32 + col) * 2 + 1];
+            }
+            const int co = n0 + tid;
+            if (co < Cout) {
+                stat_partial[((size_t)tile * 2 + 0) * Cout + co] = a1;
+                stat_partial[((size_t)tile * 2 + 1) * Cout + co] = a2;
+            }
+        }
+    }
+}
+
+// Config table.  Names: <brick><NB>.
+//  L32 / L64 : 4x8x8 brick (256 voxels), 32 / 64 output channels per workgroup, 3 taps per weight stage
+//  S128      : 4x4x4 brick (64 voxels), 128 output channels, 1 tap per stage (deep, small layers)
+template <int KS, int CINC> using CfgL32 = FwdCfg<KS, CINC, 2, 1, 4, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
+template <int KS, int CINC> using CfgL64 = FwdCfg<KS, CINC, 2, 2, 4, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
+template <int KS, int CINC> using CfgS128 = FwdCfg<KS, CINC, 1, 2, 2, 2, 4, 4, 4, 1>;
+
+struct FwdPlan {
+    int cfg;      // 0 = L32, 1 = L64, 2 = S128
+    int cinc;     // 8, 16, 32
+    int tilesD, tilesH, tilesW, ntiles, nby;
+};
+
+FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks) {
+    FwdPlan p;
+    p.cinc = cin <= 8 ? 8 : (cin <= 16 ? 16 : 32);
+    const int mind = D < H ? (D < W ? D : W) : (H < W ? H : W);
+    int td, th, tw, nb;
+    if (mind >= 16 || (long)D * H * W >= 4096) {
+        if (cout <= 32) { p.cfg = 0; nb = 32; } else { p.cfg = 1; nb = 64; }
+        td = 4; th = 8; tw = 8;
+    } else {
+        p.cfg = 2; nb = 128; td = 4; th = 4; tw = 4;
+    }
+    (void)ks;
+    p.tilesD = tmf_cdiv(D, td); p.tilesH = tmf_cdiv(H, th); p.tilesW = tmf_cdiv(W, tw);
+    p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
+    p.nby = tmf_cdiv(cout, nb);
+    return p;
+}
+
+template <class C>
+int launch_fwd_cfg(const FwdPlan& p, const float* x, const float* w, float* z, float* sp,
+                   int D, int H, int W, int cin, int cout, hipStream_t s) {
+    const bool vec = (cin % 4 == 0) && (cout % 4 == 0);
+    dim3 grid(p.ntiles, p.nby), block(256);
+    int rc;
+    if (vec) {
+        auto k = conv3d_fwd_kernel<C, true>;
+        if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
+        hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+    } else {
+        auto k = conv3d_fwd_kernel<C, false>;
+        if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
+        hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+    }
+    return tmf_launch_result("tmf_conv3d_fwd");
+}
+
+template <int KS>
+int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float* sp,
+               int D, int H, int W, int cin, int cout, hipStream_t s) {
+#define TMF_FWD_CASE(CFG, CINC)                                                                   \
+    if (p.cinc == CINC) return launch_fwd_cfg<CFG<KS, CINC>>(p, x, w, z, sp, D, H, W, cin, cout, s);
+    if (p.cfg == 0) { TMF_FWD_CASE(CfgL32, 8) TMF_FWD_CASE(CfgL32, 16) TMF_FWD_CASE(CfgL32, 32) }
+    if (p.cfg == 1) { TMF_FWD_CASE(CfgL64, 8) TMF_FWD_CASE(CfgL64, 16) TMF_FWD_CASE(CfgL64, 32) }
+    if (p.cfg == 2) { TMF_FWD_CASE(CfgS128, 8) TMF_FWD_CASE(CfgS128, 16) TMF_FWD_CASE(CfgS128, 32) }
+#undef TMF_FWD_CASE
+    tmf_set_error("tmf_conv3d_fwd: no kernel for plan cfg=%d cinc=%d", p.cfg, p.cinc);
+    return TMF_E_SHAPE;
+}
+
+// ------------------------------------------------------------------------------------
+// weight gradient, 3x3x3
+// ------------------------------------------------------------------------------------
+template <int NT_, int TD_, int TH_, int TW_>
+struct WgCfg {
+    static constexpr int NT = NT_, TD = TD_, TH = TH_, TW = TW_;
+    static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+    static constexpr int NHALO = HD * HH * HW;
+    static constexpr int CI = 32;                 // input channels per workgroup (one MFMA M-tile)
+    static constexpr int NB = 32 * NT;            // output channels per workgroup
+    static constexpr int NPOS = TD * TH * TW;
+    static constexpr int TPW = 7;                 // taps per wave (4 waves x 7 >= 27)
+    static constexpr size_t LDS_BYTES = (size_t)(NHALO * CI + NPOS * NB) * 4;
+    static_assert(TW % 2 == 0, "voxel pairs must not straddle a row");
+};
+
+template <class C, bool VEC>
+__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
+    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles,
+    int tiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xh = smem;                       // [NHALO][32]
+    float* dzs = smem + C::NHALO * C::CI;   // [NPOS][NB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int hsel = lane >> 5;
+    const int split = blockIdx.x;
+    const int ci0 = blockIdx.y * C::CI;
+    const int co0 = blockIdx.z * C::NB;
+
+    // halo float offset of each of this wave's taps (clamped; surplus taps are not written)
+    int tapoff[C::TPW];
+#pragma unroll
+    for (int t = 0; t < C::TPW; ++t) {
+        int tap = wave * C::TPW + t;
+        tap = tap > 26 ? 26 : tap;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        tapoff[t] = ((kd * C::HH + kh) * C::HW + kw + hsel) * C::CI + l31;
+    }
+    const int b_lane = hsel * C::NB + l31;
+
+    f32x16 acc[C::TPW][C::NT];
+#pragma unroll
+    for (int t = 0; t < C::TPW; ++t)
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
+
+    const int tile_begin = split * tiles_per_split;
+    int tile_end = tile_begin + tiles_per_split;
+    if (tile_end > ntiles) tile_end = ntiles;
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        int tt = tile;
+        const int tw = tt % tilesW; tt /= tilesW;
+        const int th = tt % tilesH; tt /= tilesH;
+        const int td = tt % tilesD;
+        const int b = tt / tilesD;
+        const int d0 = td * C::TD, h0 = th * C::TH, w0 = tw * C::TW;
+        const float* xb = x + (size_t)b * D * H * W * Cin;
+        const float* dzb = dz + (size_t)b * D * H * W * Cout;
+
+        __syncthreads();   // previous brick fully consumed
+        for (int e = tid; e < C::NHALO * 8; e += 256) {
+            const int hp = e >> 3, c4 = e & 7;
+            const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
+            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+            const int c = ci0 + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
+                const float* src = xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c;
+                if (VEC) {
+                    if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c + q < Cin) v[q] = src[q];
+                }
+            }
+            *reinterpret_cast<f32x4*>(&xh[hp * C::CI + c4 * 4]) = v;
+        }
+        for (int e = tid; e < C::NPOS * (C::NB / 4); e += 256) {
+            const int p = e / (C::NB / 4), c4 = e % (C::NB / 4);
+            const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
+            const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+            const int c = co0 + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gd < D && gh < H && gw < W) {
+                const float* src = dzb + ((size_t)(gd * H + gh) * W + gw) * Cout + c;
+                if (VEC) {
+                    if (c < Cout) v = *reinterpret_cast<const f32x4*>(src);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (c + q < Cout) v[q] = src[q];
+                }
+            }
+            *reinterpret_cast<f32x4*>(&dzs[p * C::NB + c4 * 4]) = v;
+        }
+        __syncthreads();
+
+        // K loop over voxel pairs: row = (pd, ph), pairs along w
+        for (int row = 0; row < C::TD * C::TH; ++row) {
+            const int rowoff = ((row / C::TH) * C::HH + (row % C::TH)) * C::HW * C::CI;
+            const float* bsrc = dzs + b_lane + row * C::TW * C::NB;
+#pragma unroll
+            for (int q = 0; q < C::TW / 2; ++q) {
+                float bv[C::NT];
+#pragma unroll
+                for (int j = 0; j < C::NT; ++j) bv[j] = bsrc[2 * q * C::NB + j * 32];
+#pragma unroll
+                for (int t = 0; t < C::TPW; ++t) {
+                    const float av = xh[tapoff[t] + rowoff + 2 * q * C::CI];
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j)
+                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[t][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // partial[split][tap][ci][co];  D fragment: row = ci, column = co
+#pragma unroll
+    for (int t = 0; t < C::TPW; ++t) {
+        const int tap = wave * C::TPW + t;
+        if (tap < 27) {
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j) {
+                const int co = co0 + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                    if (ci < Cin && co < Cout)
+                        partial[(((size_t)split * 27 + tap) * Cin + ci) * Cout + co] = acc[t][j][r];
+                }
+            }
+        }
+    }
+}
+
+// 1x1x1 weight gradient: dw[ci][co] = sum_pos x[pos][ci] dz[pos][co]; the 4 waves split the
+// voxels of each 256-voxel slab and own one partial slab each (split index = block*4 + wave).
+template <int NT>
+__global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
+    long npos, int Cin, int Cout, int slabs_per_block) {
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int ci = blockIdx.y * 32 + l31;
+    const int co0 = blockIdx.z * 32 * NT;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const long p_begin = ((long)blockIdx.x * slabs_per_block) * 256 + wave * 64;
+    for (int sl = 0; sl < slabs_per_block; ++sl) {
+        const long pb = p_begin + (long)sl * 256;
+#pragma unroll 8
+        for (int q = 0; q < 32; ++q) {
+            const long p = pb + 2 * q + hsel;
+            const bool pv = p < npos;
+            const float av = (pv && ci < Cin) ? x[p * Cin + ci] : 0.f;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = co0 + j * 32 + l31;
+                const float bv = (pv && co < Cout) ? dz[p * Cout + co] : 0.f;
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+        }
+    }
+    const int split = blockIdx.x * 4 + wave;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int co = co0 + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cr = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+            if (cr < Cin && co < Cout) partial[((size_t)split * Cin + cr) * Cout + co] = acc[j][r];
+        }
+    }
+}
+
+// out[e] = sum_s partial[s][e]  (fixed order -> deterministic)
+__global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                   int nsplit, long n) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    float a = 0.f;
+    for (int s = 0; s < nsplit; ++s) a += partial[(size_t)s * n + e];
+    out[e] = a;
+}
+
+struct WgPlan {
+    int nt, tilesD, tilesH, tilesW, ntiles, tps, nsplit, gy, gz;
+    int small;   // 1 = 4x4x4 bricks
+};
+
+WgPlan plan_wgrad(int B, int D, int H, int W, int cin, int cout) {
+    WgPlan p;
+    const int mind = D < H ? (D < W ? D : W) : (H < W ? H : W);
+    p.small = !(mind >= 16 || (long)D * H * W >= 4096);
+    const int td = 4, th = p.small ? 4 : 8, tw = p.small ? 4 : 8;
+    p.nt = cout <= 32 ? 1 : 2;
+    p.tilesD = tmf_cdiv(D, td); p.tilesH = tmf_cdiv(H, th); p.tilesW = tmf_cdiv(W, tw);
+    p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
+    p.gy = tmf_cdiv(cin, 32);
+    p.gz = tmf_cdiv(cout, 32 * p.nt);
+    const int groups = p.gy * p.gz;
+    int want = 512 / groups;             // ~2 workgroups per CU in total
+    if (want < 1) want = 1;
+    if (want > p.ntiles) want = p.ntiles;
+    p.tps = tmf_cdiv(p.ntiles, want);
+    p.nsplit = tmf_cdiv(p.ntiles, p.tps);
+    return p;
+}
+
+struct Wg1Plan { int nt, gy, gz, spb, nblk, nsplit; };
+Wg1Plan plan_wgrad1(long npos, int cin, int cout) {
+    Wg1Plan p;
+    p.nt = cout <= 32 ? 1 : 2;
+    p.gy = tmf_cdiv(cin, 32);
+    p.gz = tmf_cdiv(cout, 32 * p.nt);
+    const long slabs = (npos + 255) / 256;
+    int want = 1024 / (p.gy * p.gz);
+    if (want < 1) want = 1;
+    if (want > slabs) want = (int)slabs;
+    p.spb = (int)((slabs + want - 1) / want);
+    p.nblk = (int)((slabs + p.spb - 1) / p.spb);
+    p.nsplit = p.nblk * 4;
+    return p;
+}
+
+// ------------------------------------------------------------------------------------
+// first layer: cin == 1
+// ------------------------------------------------------------------------------------
+// z[pos][co] = sum_tap x[pos+tap-1] w[tap][co]:  A[i = voxel][k = tap] read from a scalar halo
+// brick in LDS, B[k = tap][j = co] held in 14 registers (28 taps, the 28th is zero).
+constexpr int C1_TD = 4, C1_TH = 8, C1_TW = 8;
+constexpr int C1_HD = C1_TD + 2, C1_HH = C1_TH + 2, C1_HW = C1_TW + 2;
+constexpr int C1_NHALO = C1_HD * C1_HH * C1_HW;
+
+__device__ __forceinline__ constexpr int c1_tapoff(int tap) {
+    return tap >= 27 ? 0 : ((tap / 9) * C1_HH + (tap / 3) % 3) * C1_HW + tap % 3;
+}
+
+__global__ __launch_bounds__(256) void conv3d_c1_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
+    float* __restrict__ stat_partial, int D, int H, int W, int Cout,
+    int tilesD, int tilesH, int tilesW, int ntiles) {
+    __shared__ float halo[C1_NHALO];
+    __shared__ float red[4 * 32 * 2];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int tile = xcd_contiguous(blockIdx.x, ntiles);
+    int t = tile;
+    const int tw = t % tilesW; t /= tilesW;
+    const int th = t % tilesH; t /= tilesH;
+    const int td = t % tilesD;
+    const int b = t / tilesD;
+    const int d0 = td * C1_TD, h0 = th * C1_TH, w0 = tw * C1_TW;
+    const int n0 = blockIdx.y * 32;
+    const int co = n0 + l31;
+
+    const float* xb = x + (size_t)b * D * H * W;
+    for (int e = tid; e < C1_NHALO; e += 256) {
+        const int hw = e % C1_HW, hh = (e / C1_HW) % C1_HH, hd = e / (C1_HW * C1_HH);
+        const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+        float v = 0.f;
+        if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+            v = xb[(size_t)(gd * H + gh) * W + gw];
+        halo[e] = v;
+    }
+    float bw[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int tap = 2 * s + hsel;
+        bw[s] = (tap < 27 && co < Cout) ? w[tap * Cout + co] : 0.f;
+    }
+    __syncthreads();
+
+    f32x16 acc[2];
+    int abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        const int p = (wave * 2 + i) * 32 + l31;
+        const int pw = p % C1_TW, ph = (p / C1_TW) % C1_TH, pd = p / (C1_TW * C1_TH);
+        abase[i] = (pd * C1_HH + ph) * C1_HW + pw;
+    }
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int off = hsel ? c1_tapoff(2 * s + 1) : c1_tapoff(2 * s);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[abase[i] + off], bw[s], acc[i], 0, 0, 0);
+    }
+
+    float s1 = 0.f, s2 = 0.f;
+    float* zb = z + (size_t)b * D * H * W * Cout;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = (wave * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+            const int pw = p % C1_TW, ph = (p / C1_TW) % C1_TH, pd = p / (C1_TW * C1_TH);
+            const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+            if (gd < D && gh < H && gw < W && co < Cout) {
+                const float v = acc[i][r];
+                zb[((size_t)(gd * H + gh) * W + gw) * Cout + co] = v;
+                s1 += v;
+                s2 += v * v;
+            }
+        }
+    }
+    if (stat_partial != nullptr) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (hsel == 0) {
+            red[(wave * 32 + l31) * 2 + 0] = s1;
+            red[(wave * 32 + l31) * 2 + 1] = s2;
+        }
+        __syncthreads();
+        if (tid < 32 && n0 + tid < Cout) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                a1 += red[(m * 32 + tid) * 2 + 0];
+                a2 += red[(m * 32 + tid) * 2 + 1];
+            }
+            stat_partial[((size_t)tile * 2 + 0) * Cout + n0 + tid] = a1;
+            stat_partial[((size_t)tile * 2 + 1) * Cout + n0 + tid] = a2;
+        }
+    }
+}
+
+// dw[tap][co] = sum_pos x[pos+tap-1] dz[pos][co]:  A[i = tap (27 of 32)][k = voxel], B[k = voxel][j = co].
+// The 4 waves split the brick's voxels; partial[split*4 + wave][27][Cout].
+__global__ __launch_bounds__(256) void conv3d_c1_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
+    int D, int H, int W, int Cout, int tilesD, int tilesH, int tilesW, int ntiles, int tiles_per_split) {
+    constexpr int NPOS = C1_TD * C1_TH * C1_TW;
+    __shared__ float halo[C1_NHALO];
+    extern __shared__ __attribute__((aligned(16))) float dzs[];   // [NPOS][32]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int n0 = blockIdx.y * 32;
+    const int tapo = c1_tapoff(l31) + hsel;   // lanes >= 27 read tap 0's voxels; their rows are dropped
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int tile_begin = blockIdx.x * tiles_per_split;
+    int tile_end = tile_begin + tiles_per_split;
+    if (tile_end > ntiles) tile_end = ntiles;
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        int t = tile;
+        const int tw = t % tilesW; t /= tilesW;
+        const int th = t % tilesH; t /= tilesH;
+        const int td = t % tilesD;
+        const int b = t / tilesD;
+        const int d0 = td * C1_TD, h0 = th * C1_TH, w0 = tw * C1_TW;
+        const float* xb = x + (size_t)b * D * H * W;
+        const float* dzb = dz + (size_t)b * D * H * W * Cout;
+        __syncthreads();
+        for (int e = tid; e < C1_NHALO; e += 256) {
+            const int hw = e % C1_HW, hh = (e / C1_HW) % C1_HH, hd = e / (C1_HW * C1_HH);
+            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+            float v = 0.f;
+            if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                v = xb[(size_t)(gd * H + gh) * W + gw];
+            halo[e] = v;
+        }
+        for (int e = tid; e < NPOS * 32; e += 256) {
+            const int p = e >> 5, c = e & 31;
+            const int pw = p % C1_TW, ph = (p / C1_TW) % C1_TH, pd = p / (C1_TW * C1_TH);
+            const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+            float v = 0.f;
+            if (gd < D && gh < H && gw < W && n0 + c < Cout)
+                v = dzb[((size_t)(gd * H + gh) * W + gw) * Cout + n0 + c];
+            dzs[e] = v;
+        }
+        __syncthreads();
+        // this wave's voxels: pd = wave (C1_TD == 4 waves), all (ph, pw)
+#pragma unroll 4
+        for (int ph = 0; ph < C1_TH; ++ph) {
+#pragma unroll
+            for (int q = 0; q < C1_TW / 2; ++q) {
+                const int hp = (wave * C1_HH + ph) * C1_HW + 2 * q;
+                const int p = (wave * C1_TH + ph) * C1_TW + 2 * q + hsel;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[hp + tapo], dzs[p * 32 + l31], acc, 0, 0, 0);
+            }
+        }
+    }
+    const int split = blockIdx.x * 4 + wave;
+    const int co = n0 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int tap = (r & 3) + 8 * (r >> 2) + 4 * hsel;
+        if (tap < 27 && co < Cout) partial[((size_t)split * 27 + tap) * Cout + co] = acc[r];
+    }
+}
+
+struct C1Plan { int tilesD, tilesH, tilesW, ntiles, nby, tps, nblk; };
+C1Plan plan_c1(int B, int D, int H, int W, int cout) {
+    C1Plan p;
+    p.tilesD = tmf_cdiv(D, C1_TD); p.tilesH = tmf_cdiv(H, C1_TH); p.tilesW = tmf_cdiv(W, C1_TW);
+    p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
+    p.nby = tmf_cdiv(cout, 32);
+    int want = 2048 / p.nby;
+    if (want > p.ntiles) want = p.ntiles;
+    p.tps = tmf_cdiv(p.ntiles, want);
+    p.nblk = tmf_cdiv(p.ntiles, p.tps);
+    return p;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------
+extern "C" int tmf_conv3d_stat_blocks(int B, int D, int H, int W, int cin, int cout, int ksize) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
+    return plan_fwd(B, D, H, W, cin, cout, ksize).ntiles;
+}
+
+extern "C" int tmf_conv3d_fwd(const float* x, const float* w, float* z, float* stat_partial,
+                              int B, int D, int H, int W, int cin, int cout, int ksize, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(z);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
+                "tmf_conv3d_fwd: non-positive dimension (B=%d D=%d H=%d W=%d cin=%d cout=%d)", B, D, H, W, cin, cout);
+    TMF_REQUIRE(ksize == 1 || ksize == 3, TMF_E_ARG, "tmf_conv3d_fwd: ksize must be 1 or 3, got %d", ksize);
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
+                "tmf_conv3d_fwd: one sample exceeds 2^31 elements");
+    TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w); TMF_REQUIRE_ALIGNED(z);
+    const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize);
+    hipStream_t s = (hipStream_t)stream;
+    return ksize == 3 ? launch_fwd<3>(p, x, w, z, stat_partial, D, H, W, cin, cout, s)
+                      : launch_fwd<1>(p, x, w, z, stat_partial, D, H, W, cin, cout, s);
+}
+
+extern "C" size_t tmf_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int cin, int cout, int ksize) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
+    if (ksize == 3) {
+        const WgPlan p = plan_wgrad(B, D, H, W, cin, cout);
+        return (size_t)p.nsplit * 27 * cin * cout * 4;
+    }
+    const Wg1Plan p = plan_wgrad1((long)B * D * H * W, cin, cout);
+    return (size_t)p.nsplit * cin * cout * 4;
+}
+
+extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void* workspace,
+                                size_t workspace_bytes, int B, int D, int H, int W, int cin, int cout,
+                                int ksize, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(dz); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
+                "tmf_conv3d_wgrad: non-positive dimension");
+    TMF_REQUIRE(ksize == 1 || ksize == 3, TMF_E_ARG, "tmf_conv3d_wgrad: ksize must be 1 or 3, got %d", ksize);
+    TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(dz); TMF_REQUIRE_ALIGNED(dw); TMF_REQUIRE_ALIGNED(workspace);
+    const size_t need = tmf_conv3d_wgrad_workspace_bytes(B, D, H, W, cin, cout, ksize);
+    TMF_REQUIRE(workspace_bytes >= need, TMF_E_WORKSPACE, "tmf_conv3d_wgrad: workspace %zu B < required %zu B",
+                workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const bool vec = (cin % 4 == 0) && (cout % 4 == 0);
+    int rc;
+    long nelem;
+    int nsplit;
+    if (ksize == 3) {
+        const WgPlan p = plan_wgrad(B, D, H, W, cin, cout);
+        dim3 grid(p.nsplit, p.gy, p.gz), block(256);
+#define TMF_WG_LAUNCH(CFG, V)                                                                       \
+    do {                                                                                            \
+        auto k = conv3d_wgrad_kernel<CFG, V>;                                                       \
+        if ((rc = tmf_allow_lds(k, CFG::LDS_BYTES, "tmf_conv3d_wgrad"))) return rc;                 \
+        hipLaunchKernelGGL(k, grid, block, CFG::LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,   \
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);                          \
+    } while (0)
+        using L1 = WgCfg<1, 4, 8, 8>;
+        using L2 = WgCfg<2, 4, 8, 8>;
+        using S1 = WgCfg<1, 4, 4, 4>;
+        using S2 = WgCfg<2, 4, 4, 4>;
+        if (!p.small && p.nt == 1) { if (vec) TMF_WG_LAUNCH(L1, true); else TMF_WG_LAUNCH(L1, false); }
+        else if (!p.small)         { if (vec) TMF_WG_LAUNCH(L2, true); else TMF_WG_LAUNCH(L2, false); }
+        else if (p.nt == 1)        { if (vec) TMF_WG_LAUNCH(S1, true); else TMF_WG_LAUNCH(S1, false); }
+        else                       { if (vec) TMF_WG_LAUNCH(S2, true); else TMF_WG_LAUNCH(S2, false); }
+#undef TMF_WG_LAUNCH
+        if ((rc = tmf_launch_result("tmf_conv3d_wgrad"))) return rc;
+        nelem = 27L * cin * cout;
+        nsplit = p.nsplit;
+    } else {
+        const long npos = (long)B * D * H * W;
+        const Wg1Plan p = plan_wgrad1(npos, cin, cout);
+        dim3 grid(p.nblk, p.gy, p.gz), block(256);
+        if (p.nt == 1) hipLaunchKernelGGL(conv1x1_wgrad_kernel<1>, grid, block, 0, s, x, dz, partial, npos, cin, cout, p.spb);
+        else           hipLaunchKernelGGL(conv1x1_wgrad_kernel<2>, grid, block, 0, s, x, dz, partial, npos, cin, cout, p.spb);
+        if ((rc = tmf_launch_result("tmf_conv3d_wgrad(1x1)"))) return rc;
+        nelem = (long)cin * cout;
+        nsplit = p.nsplit;
+    }
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(tmf_cdiv(nelem, 256)), dim3(256), 0, s, partial, dw, nsplit, nelem);
+    return tmf_launch_result("tmf_conv3d_wgrad(reduce)");
+}
+
+extern "C" int tmf_conv3d_c1_stat_blocks(int B, int D, int H, int W, int cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cout <= 0) return 0;
+    return plan_c1(B, D, H, W, cout).ntiles;
+}
+
+extern "C" int tmf_conv3d_c1_fwd(const float* x, const float* w, float* z, float* stat_partial,
+                                 int B, int D, int H, int W, int cout, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(z);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cout > 0, TMF_E_SHAPE, "tmf_conv3d_c1_fwd: non-positive dimension");
+    TMF_REQUIRE((long)D * H * W * cout < (1L << 31), TMF_E_SHAPE, "tmf_conv3d_c1_fwd: one sample exceeds 2^31 elements");
+    const C1Plan p = plan_c1(B, D, H, W, cout);
+    hipLaunchKernelGGL(conv3d_c1_fwd_kernel, dim3(p.ntiles, p.nby), dim3(256), 0, (hipStream_t)stream,
+                       x, w, z, stat_partial, D, H, W, cout, p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+    return tmf_launch_result("tmf_conv3d_c1_fwd");
+}
+
+extern "C" size_t tmf_conv3d_c1_wgrad_workspace_bytes(int B, int D, int H, int W, int cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cout <= 0) return 0;
+    const C1Plan p = plan_c1(B, D, H, W, cout);
+    return (size_t)p.nblk * 4 * 27 * cout * 4;
+}
+
+extern "C" int tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* workspace,
+                                   size_t workspace_bytes, int B, int D, int H, int W, int cout, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(dz); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cout > 0, TMF_E_SHAPE, "tmf_conv3d_c1_wgrad: non-positive dimension");
+    const size_t need = tmf_conv3d_c1_wgrad_workspace_bytes(B, D, H, W, cout);
+    TMF_REQUIRE(workspace_bytes >= need, TMF_E_WORKSPACE, "tmf_conv3d_c1_wgrad: workspace %zu B < required %zu B",
+                workspace_bytes, need);
+    const C1Plan p = plan_c1(B, D, H, W, cout);
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const size_t lds = (size_t)C1_TD * C1_TH * C1_TW * 32 * 4;
+    hipLaunchKernelGGL(conv3d_c1_wgrad_kernel, dim3(p.nblk, p.nby), dim3(256), lds, s, x, dz, partial,
+                       D, H, W, cout, p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);
+    int rc;
+    if ((rc = tmf_launch_result("tmf_conv3d_c1_wgrad"))) return rc;
+    const long nelem = 27L * cout;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(tmf_cdiv(nelem, 256)), dim3(256), 0, s, partial, dw, p.nblk * 4, nelem);
+    return tmf_launch_result("tmf_conv3d_c1_wgrad(reduce)");
+}

@@ -1,0 +1,215 @@
+// token_ops.hip — LayerNorm (fwd/bwd) and the token pooling head of
+// CrossTransformer_MOD_AVG, plus the library-level entry points.  gfx950.
+//
+// LayerNorm: one wavefront per token row (dim <= 2048), wave-level shuffles only, no LDS in
+// the forward; the backward also accumulates the dgamma / dbeta column sums in registers and
+// reduces them once per workgroup.
+// Replaces F.layer_norm at /root/reference/models/networks.py:117,219 and
+// AdaptiveAvgPool1d/AdaptiveMaxPool1d + cat at :264-269, 276-281.
+#include "tmf_common.h"
+
+static thread_local char g_err[512] = "";
+
+void tmf_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int tmf_version(void) { return 1; }
+extern "C" const char* tmf_last_error_string(void) { return g_err; }
+
+namespace {
+
+constexpr int LN_MAXV = 8;   // float4 groups per lane: dim <= 64*4*8 = 2048
+
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int rows, int dim, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * dim;
+    float s = 0.f;
+    for (int i = lane * VEC; i < dim; i += 64 * VEC) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) s += xr[i + q];
+    }
+    const float mu = wave_sum(s) / dim;
+    float v = 0.f;
+    for (int i = lane * VEC; i < dim; i += 64 * VEC) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) { const float d = xr[i + q] - mu; v += d * d; }
+    }
+    const float rs = 1.f / sqrtf(wave_sum(v) / dim + eps);
+    float* yr = y + (size_t)row * dim;
+    for (int i = lane * VEC; i < dim; i += 64 * VEC) {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) yr[i + q] = (xr[i + q] - mu) * rs * gamma[i + q] + beta[i + q];
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma
+// partial[blk][0][c] = sum_rows dy*xhat, partial[blk][1][c] = sum_rows dy
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const float* __restrict__ dy, float* __restrict__ dx,
+    float* __restrict__ partial, int rows, int dim, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float red[];   // [4][2][dim]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ag[LN_MAXV * VEC], ab[LN_MAXV * VEC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV * VEC; ++i) { ag[i] = 0.f; ab[i] = 0.f; }
+    const int r0 = blockIdx.x * rows_per_block;
+    int r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float* xr = x + (size_t)row * dim;
+        const float* gr = dy + (size_t)row * dim;
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < LN_MAXV; ++u) {
+            const int i = (u * 64 + lane) * VEC;
+            if (i < dim) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const float xh = (xr[i + q] - mu) * rs;
+                    const float g = gr[i + q] * gamma[i + q];
+                    s1 += g;
+                    s2 += g * xh;
+                    ag[u * VEC + q] += gr[i + q] * xh;
+                    ab[u * VEC + q] += gr[i + q];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / dim;
+        s2 = wave_sum(s2) / dim;
+        float* dr = dx + (size_t)row * dim;
+#pragma unroll
+        for (int u = 0; u < LN_MAXV; ++u) {
+            const int i = (u * 64 + lane) * VEC;
+            if (i < dim) {
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const float xh = (xr[i + q] - mu) * rs;
+                    dr[i + q] = rs * (gr[i + q] * gamma[i + q] - s1 - xh * s2);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < LN_MAXV; ++u) {
+        const int i = (u * 64 + lane) * VEC;
+        if (i < dim) {
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                red[(wave * 2 + 0) * dim + i + q] = ag[u * VEC + q];
+                red[(wave * 2 + 1) * dim + i + q] = ab[u * VEC + q];
+            }
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * dim; e += 256) {
+        const float a = red[e] + red[2 * dim + e] + red[4 * dim + e] + red[6 * dim + e];
+        partial[(size_t)blockIdx.x * 2 * dim + e] = a;
+    }
+}
+
+// cls[b] = [mean_n mri | mean_n pet | max_n mri | max_n pet]; one thread per (b, modality, channel)
+__global__ void token_pool_fwd_kernel(const float* __restrict__ mri, const float* __restrict__ pet,
+                                      float* __restrict__ cls, int32_t* __restrict__ argmax, int B, int N, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * 2 * dim) return;
+    const int c = i % dim, mod = (i / dim) % 2, b = i / (2 * dim);
+    const float* src = (mod == 0 ? mri : pet) + (size_t)b * N * dim + c;
+    float s = 0.f, mx = -INFINITY;
+    int am = 0;
+    for (int n = 0; n < N; ++n) {
+        const float v = src[(size_t)n * dim];
+        s += v;
+        if (v > mx) { mx = v; am = n; }      // first maximum, as AdaptiveMaxPool1d
+    }
+    cls[(size_t)b * 4 * dim + mod * dim + c] = s / N;
+    cls[(size_t)b * 4 * dim + (2 + mod) * dim + c] = mx;
+    argmax[i] = am;
+}
+
+__global__ void token_pool_bwd_kernel(const float* __restrict__ dcls, const int32_t* __restrict__ argmax,
+                                      float* __restrict__ dmri, float* __restrict__ dpet, int B, int N, int dim) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * 2 * N * dim;
+    if (i >= total) return;
+    const int c = i % dim;
+    const int n = (i / dim) % N;
+    const int mod = (i / ((long)dim * N)) % 2;
+    const int b = i / ((long)dim * N * 2);
+    const float gavg = dcls[(size_t)b * 4 * dim + mod * dim + c];
+    const float gmax = dcls[(size_t)b * 4 * dim + (2 + mod) * dim + c];
+    const int am = argmax[((size_t)b * 2 + mod) * dim + c];
+    float* dst = (mod == 0 ? dmri : dpet);
+    dst[((size_t)b * N + n) * dim + c] = gavg / N + (n == am ? gmax : 0.f);
+}
+
+}  // namespace
+
+extern "C" int tmf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                                 float* mean, float* rstd, int rows, int dim, float eps, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(gamma); TMF_REQUIRE_PTR(beta); TMF_REQUIRE_PTR(y);
+    TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(rstd);
+    TMF_REQUIRE(rows > 0 && dim > 0, TMF_E_SHAPE, "tmf_layernorm_fwd: rows=%d dim=%d", rows, dim);
+    dim3 grid(tmf_cdiv(rows, 4)), block(256);
+    if (dim % 4 == 0) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, dim, eps);
+    else              hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, block, 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, dim, eps);
+    return tmf_launch_result("tmf_layernorm_fwd");
+}
+
+static int ln_rows_per_block(int rows) {
+    int rpb = tmf_cdiv(rows, 512);
+    if (rpb < 4) rpb = 4;
+    return rpb;
+}
+
+extern "C" int tmf_layernorm_bwd_blocks(int rows, int dim) {
+    (void)dim;
+    if (rows <= 0) return 0;
+    return tmf_cdiv(rows, ln_rows_per_block(rows));
+}
+
+extern "C" int tmf_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
+                                 const float* dy, float* dx, float* partial, int rows, int dim, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(gamma); TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(rstd);
+    TMF_REQUIRE_PTR(dy); TMF_REQUIRE_PTR(dx); TMF_REQUIRE_PTR(partial);
+    TMF_REQUIRE(rows > 0 && dim > 0, TMF_E_SHAPE, "tmf_layernorm_bwd: rows=%d dim=%d", rows, dim);
+    const int vec = dim % 4 == 0 ? 4 : 1;
+    TMF_REQUIRE(dim <= 64 * vec * LN_MAXV, TMF_E_SHAPE, "tmf_layernorm_bwd: dim=%d exceeds %d", dim, 64 * vec * LN_MAXV);
+    const int rpb = ln_rows_per_block(rows);
+    dim3 grid(tmf_cdiv(rows, rpb)), block(256);
+    const size_t lds = (size_t)8 * dim * 4;
+    if (vec == 4) hipLaunchKernelGGL(layernorm_bwd_kernel<4>, grid, block, lds, (hipStream_t)stream, x, gamma, mean, rstd, dy, dx, partial, rows, dim, rpb);
+    else          hipLaunchKernelGGL(layernorm_bwd_kernel<1>, grid, block, lds, (hipStream_t)stream, x, gamma, mean, rstd, dy, dx, partial, rows, dim, rpb);
+    return tmf_launch_result("tmf_layernorm_bwd");
+}
+
+extern "C" int tmf_token_pool_fwd(const float* mri, const float* pet, float* cls, int32_t* argmax,
+                                  int B, int N, int dim, void* stream) {
+    TMF_REQUIRE_PTR(mri); TMF_REQUIRE_PTR(pet); TMF_REQUIRE_PTR(cls); TMF_REQUIRE_PTR(argmax);
+    TMF_REQUIRE(B > 0 && N > 0 && dim > 0, TMF_E_SHAPE, "tmf_token_pool_fwd: B=%d N=%d dim=%d", B, N, dim);
+    hipLaunchKernelGGL(token_pool_fwd_kernel, dim3(tmf_cdiv((long)B * 2 * dim, 64)), dim3(64), 0, (hipStream_t)stream,
+                       mri, pet, cls, argmax, B, N, dim);
+    return tmf_launch_result("tmf_token_pool_fwd");
+}
+
+extern "C" int tmf_token_pool_bwd(const float* dcls, const int32_t* argmax, float* dmri, float* dpet,
+                                  int B, int N, int dim, void* stream) {
+    TMF_REQUIRE_PTR(dcls); TMF_REQUIRE_PTR(argmax); TMF_REQUIRE_PTR(dmri); TMF_REQUIRE_PTR(dpet);
+    TMF_REQUIRE(B > 0 && N > 0 && dim > 0, TMF_E_SHAPE, "tmf_token_pool_bwd: B=%d N=%d dim=%d", B, N, dim);
+    const long total = (long)B * 2 * N * dim;
+    hipLaunchKernelGGL(token_pool_bwd_kernel, dim3(tmf_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dcls, argmax, dmri, dpet, B, N, dim);
+    return tmf_launch_result("tmf_token_pool_bwd");
+}

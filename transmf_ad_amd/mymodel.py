@@ -1,0 +1,98 @@
+"""Drop-in model classes (reference: models/mymodel.py): same constructor arguments, forward
+signatures, return tuples, attribute names and state_dict keys as the reference's ``model_ad``
+(:182-222), ``model_CNN_ad`` (:144-179) and ``model_single`` (:13-37), computed by the MI355X
+HIP kernels.  ``kfold_train_adversarial.py``'s train_step/val_step run unchanged on them.
+
+The small dense heads (``D``, ``fc_cls``, ``fc``: (B, <=512) matrices) stay on stock torch ops.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .gradient_reversal import revgrad
+from .networks import CrossTransformer_MOD_AVG, sNet
+
+
+def _init_like_reference(module: nn.Module) -> None:
+    """mymodel.py:195-202: kaiming-normal(fan_out, relu) conv weights, BN3d gamma=1, beta=0."""
+    for m in module.modules():
+        if isinstance(m, nn.Conv3d):
+            nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        elif isinstance(m, nn.BatchNorm3d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+def _tokens(emb):
+    """'b d x y z -> b (x y z) d' (mymodel.py:218).  sNet returns a (B, C, d, h, w) VIEW of its
+    channels-last buffer, so this is a reshape of strides only — no transpose kernel, no copy."""
+    return emb.flatten(2).transpose(1, 2)
+
+
+class _Flatten5(nn.Module):
+    """'b c x y z -> b (c x y z)' (stands in for the einops layer of the reference's ``gap``)."""
+
+    def forward(self, x):
+        return x.flatten(1)
+
+
+def _discriminator(dim):
+    return nn.Sequential(nn.Linear(dim, 128), nn.BatchNorm1d(128), nn.ReLU(), nn.Linear(128, 2))
+
+
+class model_single(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.cnn = sNet(dim)
+        self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
+        self.fc = nn.Sequential(nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 2))
+        _init_like_reference(self)
+
+    def forward(self, img):
+        return self.fc(_tokens(self.cnn(img)).mean(dim=1))
+
+
+class model_CNN_ad(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.mri_cnn = sNet(dim)
+        self.pet_cnn = sNet(dim)
+        self.fc_cls = nn.Sequential(nn.Linear(dim * 2, 128), nn.ReLU(), nn.Linear(128, 2))
+        self.gap = nn.Sequential(nn.AdaptiveAvgPool3d(1), _Flatten5())
+        self.D = _discriminator(dim)
+        _init_like_reference(self)
+
+    def forward(self, mri, pet):
+        mri_feat = _tokens(self.mri_cnn(mri)).mean(dim=1)       # == AdaptiveAvgPool3d(1) + flatten
+        pet_feat = _tokens(self.pet_cnn(pet)).mean(dim=1)
+        D_MRI_logits = self.D(revgrad(mri_feat, 2.0))
+        D_PET_logits = self.D(revgrad(pet_feat, 2.0))
+        output_logits = self.fc_cls(torch.cat([mri_feat, pet_feat], dim=1))
+        return output_logits, D_MRI_logits, D_PET_logits
+
+
+class model_ad(nn.Module):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout):
+        super().__init__()
+        self.mri_cnn = sNet(dim)
+        self.pet_cnn = sNet(dim)
+        self.fuse_transformer = CrossTransformer_MOD_AVG(dim, depth, heads, dim_head, mlp_dim, dropout)
+        self.fc_cls = nn.Sequential(nn.Linear(dim * 4, 512), nn.BatchNorm1d(512), nn.ReLU(), nn.Dropout(0.5),
+                                    nn.Linear(512, 64), nn.BatchNorm1d(64), nn.ReLU(), nn.Dropout(0.5),
+                                    nn.Linear(64, 2))
+        self.gap = nn.Sequential(nn.AdaptiveAvgPool3d(1), _Flatten5())
+        self.D = _discriminator(dim)
+        _init_like_reference(self)
+
+    def forward_features(self, mri, pet):
+        """-> (cls (B, 4*dim), D_MRI_logits, D_PET_logits); everything ahead of fc_cls."""
+        mri_tok = _tokens(self.mri_cnn(mri))               # (B, V, dim)
+        pet_tok = _tokens(self.pet_cnn(pet))
+        D_MRI_logits = self.D(revgrad(mri_tok.mean(dim=1), 2.0))
+        D_PET_logits = self.D(revgrad(pet_tok.mean(dim=1), 2.0))
+        return self.fuse_transformer(mri_tok, pet_tok), D_MRI_logits, D_PET_logits
+
+    def forward(self, mri, pet):
+        cls, D_MRI_logits, D_PET_logits = self.forward_features(mri, pet)
+        return self.fc_cls(cls), D_MRI_logits, D_PET_logits

@@ -1,0 +1,149 @@
+"""MI355X-native network blocks with the reference's constructor / forward signatures and
+state_dict keys (reference: models/networks.py).
+
+Each class keeps stock ``nn.Conv3d`` / ``nn.BatchNorm3d`` / ``nn.Linear`` / ``nn.LayerNorm``
+sub-modules at the reference's attribute paths purely as PARAMETER HOLDERS — that is what makes
+``state_dict()``, ``load_state_dict(strict=True)``, ``.to(device)`` and init loops such as
+``isinstance(m, nn.Conv3d)`` behave exactly like the reference.  Their own ``forward`` is
+never called: the compute goes through the HIP kernels in ``transmf_ad_amd.ops``.
+
+Internal activation layout is channels-last (B, D, H, W, C); ``sNet.forward`` returns the
+reference's (B, C, D, H, W) *view* of it (no copy); flattening that view to tokens
+(mymodel.py:218 'b d x y z -> b (x y z) d') is then free as well.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+
+
+# ---------------------------------------------------------------------------------------
+# sNet                                                         reference: networks.py:18-61
+# ---------------------------------------------------------------------------------------
+
+def _conv_block(cin, cout, k):
+    return [nn.Conv3d(cin, cout, kernel_size=(k, k, k), padding=k // 2), nn.BatchNorm3d(cout), nn.LeakyReLU()]
+
+
+class sNet(nn.Module):
+    """Seven Conv3d-BatchNorm3d-LeakyReLU blocks, 2x2x2 pools after blocks 1, 3, 5 (max) and 7 (avg).
+
+    forward(vol: (B, 1, D, H, W)) -> (B, dim, D//16, H//16, W//16)
+    """
+
+    # (sequential name, index of the conv inside it, pool that follows the block)
+    _PLAN = (("conv1", 0, "max"), ("conv2", 0, None), ("conv2", 3, "max"), ("conv3", 0, None),
+             ("conv3", 3, "max"), ("conv4", 0, None), ("conv4", 3, "avg"))
+
+    def __init__(self, dim) -> None:
+        super().__init__()
+        q, h = dim // 4, dim // 2
+        self.conv1 = nn.Sequential(*_conv_block(1, q, 3), nn.MaxPool3d(2, stride=2))
+        self.conv2 = nn.Sequential(*_conv_block(q, q, 3), *_conv_block(q, h, 3), nn.MaxPool3d(2, stride=2))
+        self.conv3 = nn.Sequential(*_conv_block(h, h, 3), *_conv_block(h, dim, 3), nn.MaxPool3d(2, stride=2))
+        self.conv4 = nn.Sequential(*_conv_block(dim, dim * 2, 3), *_conv_block(dim * 2, dim, 1),
+                                   nn.AvgPool3d(2, stride=2))
+
+    def forward_channels_last(self, vol):
+        if vol.dim() != 5 or vol.shape[1] != 1:
+            raise ValueError(f"sNet expects (B, 1, D, H, W), got {tuple(vol.shape)}")
+        B, _, D, H, W = vol.shape
+        x = vol.reshape(B, D, H, W, 1)          # C == 1: NCDHW and NDHWC are the same bytes
+        for seq_name, i, pool in self._PLAN:
+            seq = getattr(self, seq_name)
+            conv, bn, act = seq[i], seq[i + 1], seq[i + 2]
+            if self.training and bn.track_running_stats:
+                bn.num_batches_tracked += 1
+            x = ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                     bn.running_var, self.training or not bn.track_running_stats,
+                                     momentum=bn.momentum, eps=bn.eps, slope=act.negative_slope, pool=pool)
+        return x                                 # (B, d, h, w, dim)
+
+    def forward(self, mri):
+        return self.forward_channels_last(mri).permute(0, 4, 1, 2, 3)
+
+
+# ---------------------------------------------------------------------------------------
+# transformer blocks                                    reference: networks.py:114-175, 215-230
+# ---------------------------------------------------------------------------------------
+
+class PreNorm(nn.Module):
+    """LayerNorm on x only; keyword arguments (the attention context) pass through un-normalised."""
+
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x, **kwargs):
+        return self.fn(ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps), **kwargs)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, dropout=0.):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(dim, hidden_dim), nn.GELU(), nn.Dropout(dropout),
+                                 nn.Linear(hidden_dim, dim), nn.Dropout(dropout))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class Attention(nn.Module):
+    """Multi-head attention; q from x, k/v from ``context`` (default x).  QK^T, softmax and AV run
+    as one fused HIP kernel straight on the to_q / to_kv outputs."""
+
+    def __init__(self, dim, heads=4, dim_head=64, dropout=0.):
+        super().__init__()
+        inner_dim = dim_head * heads
+        self.heads = heads
+        self.scale = dim_head ** -0.5
+        self.attend = nn.Softmax(dim=-1)          # kept for attribute parity; has no parameters
+        self.to_q = nn.Linear(dim, inner_dim, bias=False)
+        self.to_kv = nn.Linear(dim, inner_dim * 2, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
+
+    def forward(self, x, context=None, kv_include_self=False):
+        context = x if context is None else context
+        if kv_include_self:
+            context = torch.cat((x, context), dim=1)
+        out = ops.cross_attention(self.to_q(x), self.to_kv(context), self.heads, self.scale)
+        return self.to_out(out)
+
+
+class Transformer(nn.Module):
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout=0.):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        self.norm = nn.LayerNorm(dim)
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([
+                PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
+                PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))]))
+
+    def forward(self, x, context=None):
+        for attn, ff in self.layers:
+            x = attn(x, context=context) + x
+            x = ff(x) + x
+        return ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+
+
+class CrossTransformer_MOD_AVG(nn.Module):
+    """``depth`` x [mri <- Transformer(mri | pet) + mri ; pet <- Transformer(pet | NEW mri) + pet], then
+    cat[mean, mean, max, max] over tokens -> (B, 4*dim).   reference: networks.py:255-281"""
+
+    def __init__(self, dim, depth, heads, dim_head, mlp_dim, dropout):
+        super().__init__()
+        self.layers = nn.ModuleList([])
+        for _ in range(depth):
+            self.layers.append(nn.ModuleList([Transformer(dim, 1, heads, dim_head, mlp_dim, dropout=dropout),
+                                              Transformer(dim, 1, heads, dim_head, mlp_dim, dropout=dropout)]))
+
+    def forward(self, mri_tokens, pet_tokens):
+        for mri_enc, pet_enc in self.layers:
+            mri_tokens = mri_enc(mri_tokens, context=pet_tokens) + mri_tokens
+            pet_tokens = pet_enc(pet_tokens, context=mri_tokens) + pet_tokens
+        return ops.token_pool(mri_tokens, pet_tokens)

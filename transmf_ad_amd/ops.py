@@ -1,0 +1,295 @@
+"""torch.autograd.Functions over the C ABI of libtmf_hip.so.
+
+PyTorch is plumbing here (device memory, the current HIP stream, autograd graph);
+every numeric step of the hot path is a hand-written gfx950 kernel.  All tensors are
+fp32, contiguous, on a HIP device; activations are channels-last (B, D, H, W, C).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+_f32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.TmfError(
+            f"{name} is on {t.device}: transmf_ad_amd runs only on a HIP device (MI355X); there is no CPU fallback")
+    if t.dtype != _f32:
+        raise _lib.TmfError(f"{name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------------------
+# conv3d (+ folded bias) -> BatchNorm3d -> LeakyReLU -> pool      (networks.py:21-53)
+# --------------------------------------------------------------------------------------
+
+def pack_weight(weight: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, k, k, k) reference layout -> tap-major [k^3][Cin][Cout]."""
+    return weight.permute(2, 3, 4, 1, 0).contiguous()
+
+
+def pack_weight_dgrad(weight: torch.Tensor) -> torch.Tensor:
+    """Weights of the data-gradient convolution: w'[26-t][co][ci] = w[t][ci][co]."""
+    return weight.flip(2, 3, 4).permute(2, 3, 4, 0, 1).contiguous()
+
+
+def unpack_wgrad(dw: torch.Tensor, cout: int, cin: int, k: int) -> torch.Tensor:
+    """tap-major [k^3][Cin][Cout] gradient -> reference (Cout, Cin, k, k, k)."""
+    return dw.view(k, k, k, cin, cout).permute(4, 3, 0, 1, 2).contiguous()
+
+
+def conv3d_raw(x, w_packed, cin, cout, ksize, want_stats):
+    """z = conv(x, w) on NDHWC x; returns (z, stat_partial or None, nblk)."""
+    B, D, H, W = x.shape[:4]
+    z = torch.empty((B, D, H, W, cout), device=x.device, dtype=_f32)
+    part, nblk = None, 0
+    if cin == 1 and ksize == 3:
+        if want_stats:
+            nblk = _lib.query("tmf_conv3d_c1_stat_blocks", B, D, H, W, cout)
+            part = torch.empty((nblk, 2, cout), device=x.device, dtype=_f32)
+        _lib.call("tmf_conv3d_c1_fwd", x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(part),
+                  B, D, H, W, cout, _stream())
+    else:
+        if want_stats:
+            nblk = _lib.query("tmf_conv3d_stat_blocks", B, D, H, W, cin, cout, ksize)
+            part = torch.empty((nblk, 2, cout), device=x.device, dtype=_f32)
+        _lib.call("tmf_conv3d_fwd", x.data_ptr(), w_packed.data_ptr(), z.data_ptr(), _ptr(part),
+                  B, D, H, W, cin, cout, ksize, _stream())
+    return z, part, nblk
+
+
+def conv3d_wgrad(x, dz, cin, cout, ksize):
+    """tap-major weight gradient [k^3][cin][cout]."""
+    B, D, H, W = x.shape[:4]
+    dw = torch.empty((ksize ** 3, cin, cout), device=x.device, dtype=_f32)
+    if cin == 1 and ksize == 3:
+        nbytes = _lib.query("tmf_conv3d_c1_wgrad_workspace_bytes", B, D, H, W, cout)
+        ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=_f32)
+        _lib.call("tmf_conv3d_c1_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
+                  B, D, H, W, cout, _stream())
+    else:
+        nbytes = _lib.query("tmf_conv3d_wgrad_workspace_bytes", B, D, H, W, cin, cout, ksize)
+        ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=_f32)
+        _lib.call("tmf_conv3d_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
+                  B, D, H, W, cin, cout, ksize, _stream())
+    return dw
+
+
+class ConvBnActPool(torch.autograd.Function):
+    """One sNet block: Conv3d(k, same padding) -> BatchNorm3d -> LeakyReLU -> {none,max,avg} 2x2x2 pool.
+
+    The conv bias is never added to the activations: ahead of BatchNorm it only shifts the
+    batch mean, so it is folded into running_mean (train) or into the BN shift (eval).
+    Its train-mode gradient is exactly zero in exact arithmetic (the reference returns
+    rounding noise there); we return zeros.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var,
+                training, momentum, eps, slope, pool):
+        x = _chk(x, "x")
+        cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+        B, D, H, W, C = x.shape
+        if C != cin:
+            raise _lib.TmfError(f"conv expects {cin} input channels, got {C}")
+        wp = pack_weight(_chk(weight, "weight"))
+        dev = x.device
+        mean = torch.empty(cout, device=dev, dtype=_f32)
+        invstd = torch.empty(cout, device=dev, dtype=_f32)
+        scale = torch.empty(cout, device=dev, dtype=_f32)
+        shift = torch.empty(cout, device=dev, dtype=_f32)
+        s = _stream()
+        pc = _lib.pool_code(pool)
+        if training:
+            z, part, nblk = conv3d_raw(x, wp, cin, cout, k, True)
+            _lib.call("tmf_bn_finalize", part.data_ptr(), nblk, cout, float(B * D * H * W),
+                      gamma.data_ptr(), beta.data_ptr(), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                      float(momentum), float(eps), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                      shift.data_ptr(), s)
+        else:
+            z, _, _ = conv3d_raw(x, wp, cin, cout, k, False)
+            _lib.call("tmf_bn_eval_coeffs", gamma.data_ptr(), beta.data_ptr(), _ptr(bias), running_mean.data_ptr(),
+                      running_var.data_ptr(), float(eps), cout, scale.data_ptr(), shift.data_ptr(), s)
+            # xhat = (z + bias - running_mean) * invstd, written as (z - mean) * invstd
+            invstd = torch.rsqrt(running_var + eps)
+            mean = running_mean - bias if bias is not None else running_mean.clone()
+        if pc == _lib.POOL_NONE:
+            out = torch.empty((B, D, H, W, cout), device=dev, dtype=_f32)
+        else:
+            out = torch.empty((B, D // 2, H // 2, W // 2, cout), device=dev, dtype=_f32)
+        if out.numel() > 0:
+            _lib.call("tmf_bn_act_pool_fwd", z.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                      B, D, H, W, cout, pc, float(slope), s)
+        ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd)
+        ctx.cfg = (training, float(slope), pc, cin, cout, k, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, z, scale, shift, mean, invstd = ctx.saved_tensors
+        training, slope, pc, cin, cout, k, has_bias = ctx.cfg
+        B, D, H, W, _ = x.shape
+        dev = x.device
+        s = _stream()
+        dout = _chk(dout, "grad_output")
+        nblk = _lib.query("tmf_bn_act_pool_bwd_blocks", B, D, H, W, cout, pc)
+        part = torch.empty((nblk, 2, cout), device=dev, dtype=_f32)
+        _lib.call("tmf_bn_act_pool_bwd_reduce", z.data_ptr(), dout.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), B, D, H, W, cout, pc, slope, s)
+        dgamma = torch.empty(cout, device=dev, dtype=_f32)
+        dbeta = torch.empty(cout, device=dev, dtype=_f32)
+        coef = torch.empty((2, cout), device=dev, dtype=_f32)
+        _lib.call("tmf_bn_bwd_finalize", part.data_ptr(), nblk, cout, float(B * D * H * W),
+                  dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), s)
+        if training:
+            dbias = torch.zeros(cout, device=dev, dtype=_f32) if has_bias else None
+        else:
+            coef.zero_()                      # eval-mode BN is affine: dz = scale * dy
+            dbias = scale * dbeta if has_bias else None
+        dz = torch.empty_like(z)
+        _lib.call("tmf_bn_act_pool_bwd_apply", z.data_ptr(), dout.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dz.data_ptr(), B, D, H, W, cout, pc, slope, s)
+        dweight = None
+        if ctx.needs_input_grad[1]:
+            dweight = unpack_wgrad(conv3d_wgrad(x, dz, cin, cout, k), cout, cin, k)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx, _, _ = conv3d_raw(dz, pack_weight_dgrad(weight), cout, cin, k, False)
+        return (dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
+
+
+def conv_bn_act_pool(x, weight, bias, gamma, beta, running_mean, running_var, training,
+                     momentum=0.1, eps=1e-5, slope=0.01, pool=None):
+    return ConvBnActPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
+                               training, momentum, eps, slope, pool)
+
+
+# --------------------------------------------------------------------------------------
+# fused cross attention                                               (networks.py:166-174)
+# --------------------------------------------------------------------------------------
+
+class CrossAttention(torch.autograd.Function):
+    """out[b, n, (h d)] = softmax(q k^T * scale) v with q: (B, N, h*d), kv: (B, M, 2*h*d)
+    (the raw to_q / to_kv outputs: no rearrange, no chunk copy)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, heads, scale):
+        q, kv = _chk(q, "q"), _chk(kv, "kv")
+        B, N, inner = q.shape
+        M = kv.shape[1]
+        if kv.shape[2] != 2 * inner or inner % heads:
+            raise _lib.TmfError(f"attention shapes: q {tuple(q.shape)} kv {tuple(kv.shape)} heads {heads}")
+        dh = inner // heads
+        out = torch.empty((B, N, inner), device=q.device, dtype=_f32)
+        lse = torch.empty((B, heads, N), device=q.device, dtype=_f32)
+        _lib.call("tmf_xattn_fwd", q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 4, out.data_ptr(),
+                  lse.data_ptr(), B, heads, N, M, dh, inner, 2 * inner, float(scale), _stream())
+        ctx.save_for_backward(q, kv, out, lse)
+        ctx.cfg = (heads, float(scale))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse = ctx.saved_tensors
+        heads, scale = ctx.cfg
+        B, N, inner = q.shape
+        M = kv.shape[1]
+        dh = inner // heads
+        dout = _chk(dout, "grad_output")
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        _lib.call("tmf_xattn_bwd", q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 4, out.data_ptr(),
+                  lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), dkv.data_ptr() + inner * 4,
+                  B, heads, N, M, dh, inner, 2 * inner, 2 * inner, scale, _stream())
+        return dq, dkv, None, None
+
+
+def cross_attention(q, kv, heads, scale):
+    return CrossAttention.apply(q, kv, heads, scale)
+
+
+# --------------------------------------------------------------------------------------
+# LayerNorm                                                          (networks.py:117,219)
+# --------------------------------------------------------------------------------------
+
+class LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x = _chk(x, "x")
+        dim = x.shape[-1]
+        rows = x.numel() // dim
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=_f32)
+        rstd = torch.empty(rows, device=x.device, dtype=_f32)
+        _lib.call("tmf_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+                  mean.data_ptr(), rstd.data_ptr(), rows, dim, float(eps), _stream())
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dim = x.shape[-1]
+        rows = x.numel() // dim
+        dy = _chk(dy, "grad_output")
+        dx = torch.empty_like(x)
+        nblk = _lib.query("tmf_layernorm_bwd_blocks", rows, dim)
+        part = torch.empty((nblk, 2, dim), device=x.device, dtype=_f32)
+        s = _stream()
+        _lib.call("tmf_layernorm_bwd", x.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                  dy.data_ptr(), dx.data_ptr(), part.data_ptr(), rows, dim, s)
+        gb = torch.empty((2, dim), device=x.device, dtype=_f32)
+        _lib.call("tmf_colsum_finalize", part.data_ptr(), nblk, 2 * dim, gb.data_ptr(), s)
+        return dx, gb[0], gb[1], None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNorm.apply(x, gamma, beta, eps)
+
+
+# --------------------------------------------------------------------------------------
+# token pooling head                                                (networks.py:276-281)
+# --------------------------------------------------------------------------------------
+
+class TokenPool(torch.autograd.Function):
+    """cat[mean_n mri, mean_n pet, max_n mri, max_n pet] -> (B, 4*dim)."""
+
+    @staticmethod
+    def forward(ctx, mri, pet):
+        mri, pet = _chk(mri, "mri_tokens"), _chk(pet, "pet_tokens")
+        B, N, dim = mri.shape
+        if pet.shape != mri.shape:
+            raise _lib.TmfError(f"token shapes differ: {tuple(mri.shape)} vs {tuple(pet.shape)}")
+        cls = torch.empty((B, 4 * dim), device=mri.device, dtype=_f32)
+        arg = torch.empty((B, 2, dim), device=mri.device, dtype=torch.int32)
+        _lib.call("tmf_token_pool_fwd", mri.data_ptr(), pet.data_ptr(), cls.data_ptr(), arg.data_ptr(),
+                  B, N, dim, _stream())
+        ctx.save_for_backward(arg)
+        ctx.shape = (B, N, dim)
+        return cls
+
+    @staticmethod
+    def backward(ctx, dcls):
+        (arg,) = ctx.saved_tensors
+        B, N, dim = ctx.shape
+        dcls = _chk(dcls, "grad_output")
+        dm = torch.empty((B, N, dim), device=dcls.device, dtype=_f32)
+        dp = torch.empty((B, N, dim), device=dcls.device, dtype=_f32)
+        _lib.call("tmf_token_pool_bwd", dcls.data_ptr(), arg.data_ptr(), dm.data_ptr(), dp.data_ptr(),
+                  B, N, dim, _stream())
+        return dm, dp
+
+
+def token_pool(mri, pet):
+    return TokenPool.apply(mri, pet)

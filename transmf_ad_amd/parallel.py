@@ -1,0 +1,165 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU, gradients
+all-reduced with RCCL (torch.distributed backend "nccl" on ROCm) over xGMI.
+
+The reference is single-process / single-GPU (no DDP, no NCCL anywhere), so
+there is no call pattern to mirror; this is sized for the path itself:
+
+  * the replica is whole (4.17 M parameters = 16.7 MB of fp32 gradients for model_ad), each rank
+    runs the reference batch of 8 pairs, BatchNorm statistics stay per replica (reference
+    semantics at batch 8 — no SyncBN);
+  * gradients are packed into a few flat buckets in REVERSE registration order — the order
+    backward produces them: heads and fusion transformer first, then conv4 ... conv1 — and
+    each bucket's all-reduce is launched asynchronously from a post-accumulate-grad hook the
+    moment its last gradient lands, so the transfers ride under the long conv2/conv1
+    backward kernels.  xGMI is point-to-point (≈153 GB/s per link): a ring over 8 GPUs moves
+    2*(7/8)*16.7 MB ≈ 29 MB per GPU per step (≈0.2 ms on one link) — few, large buckets keep
+    that bandwidth-bound rather than latency-bound;
+  * a queued autograd callback waits for the buckets, averages, and scatters the result back
+    into ``param.grad`` before ``optimizer.step()`` — the reference's train_step is unchanged.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class _Bucket:
+    def __init__(self, params: List[nn.Parameter]):
+        self.params = params
+        self.numel = sum(p.numel() for p in params)
+        self.offsets = []
+        o = 0
+        for p in params:
+            self.offsets.append(o)
+            o += p.numel()
+        p0 = params[0]
+        self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
+        self.pending = len(params)
+        self.filled = [False] * len(params)
+        self.work = None
+
+    def reset(self):
+        self.pending = len(self.params)
+        self.filled = [False] * len(self.params)
+        self.work = None
+
+
+class GradAllReduce(nn.Module):
+    """Wrap a module so that ``loss.backward()`` leaves rank-averaged gradients in ``.grad``.
+
+    >>> net = GradAllReduce(model_ad(...).to(device))      # after dist.init_process_group
+    >>> out = net(mri, pet); loss.backward(); optimizer.step()
+    """
+
+    def __init__(self, module: nn.Module, process_group=None, bucket_mb: float = 6.0,
+                 broadcast_from_rank0: bool = True):
+        super().__init__()
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("GradAllReduce needs an initialised torch.distributed process group")
+        self.module = module
+        self.group = process_group
+        self.world = dist.get_world_size(process_group)
+        self._buckets: List[_Bucket] = []
+        self._where = {}
+        self._callback_queued = False
+        self.require_sync = True
+        params = [p for p in module.parameters() if p.requires_grad]
+        if broadcast_from_rank0 and self.world > 1:
+            with torch.no_grad():
+                for t in list(module.parameters()) + list(module.buffers()):
+                    dist.broadcast(t, 0, group=process_group)
+        cap = int(bucket_mb * (1 << 20))
+        cur, cur_bytes = [], 0
+        for p in reversed(params):
+            nbytes = p.numel() * p.element_size()
+            if cur and (cur_bytes + nbytes > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
+                self._add_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._add_bucket(cur)
+        for p in params:
+            p.register_post_accumulate_grad_hook(self._on_grad)
+
+    # -- construction ----------------------------------------------------------------------
+    def _add_bucket(self, params):
+        b = _Bucket(list(params))
+        for i, p in enumerate(b.params):
+            self._where[p] = (b, i)
+        self._buckets.append(b)
+
+    @property
+    def bucket_sizes_bytes(self):
+        return [b.numel * b.flat.element_size() for b in self._buckets]
+
+    # -- backward-time machinery -----------------------------------------------------------
+    def _on_grad(self, p: torch.Tensor):
+        if not self.require_sync or self.world == 1:
+            return
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        b, i = self._where[p]
+        if b.filled[i]:
+            return
+        n = p.numel()
+        b.flat[b.offsets[i]:b.offsets[i] + n].copy_(p.grad.reshape(-1))
+        b.filled[i] = True
+        b.pending -= 1
+        if b.pending == 0:
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _finalize(self):
+        self._callback_queued = False
+        for b in self._buckets:
+            if b.work is None:            # some parameter got no gradient this pass: send zeros for it
+                for i, p in enumerate(b.params):
+                    if not b.filled[i]:
+                        b.flat[b.offsets[i]:b.offsets[i] + p.numel()].zero_()
+                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self._buckets:
+            b.work.wait()
+            b.flat.div_(self.world)
+            for i, p in enumerate(b.params):
+                n = p.numel()
+                g = b.flat[b.offsets[i]:b.offsets[i] + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+            b.reset()
+
+    # -- nn.Module surface -------------------------------------------------------------------
+    def forward(self, *args, **kwargs):
+        return self.module(*args, **kwargs)
+
+    def state_dict(self, *args, **kwargs):          # checkpoints interchange with the bare module
+        return self.module.state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        return self.module.load_state_dict(*args, **kwargs)
+
+
+def init_from_env(backend: Optional[str] = None):
+    """Initialise the default process group from the torchrun environment
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world)."""
+    import os
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local, world
