@@ -43,6 +43,9 @@ extern "C" {
 
 int         tmf_version(void);                 /* ABI version, currently 1 */
 const char* tmf_last_error_string(void);
+/* Process-wide tuning knobs (never change results).  "conv_waves" = 4 | 8: wavefronts per
+ * convolution workgroup (8 = two per SIMD, the default). */
+int         tmf_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------
  * 3-D convolution, stride 1, "same" zero padding, cross-correlation, NO bias

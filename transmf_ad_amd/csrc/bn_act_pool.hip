@@ -329,14 +329,6 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
     }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int ncol, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= ncol) return;
-    double a = 0.0;
-    for (int i = 0; i < nblk; ++i) a += (double)part[(size_t)i * ncol + c];
-    out[c] = (float)a;
-}
-
 struct EwPlan { int vec, cq, rows, nblk; };
 EwPlan plan_ew(long nwork, int C) {
     EwPlan p;
@@ -461,7 +453,8 @@ extern "C" int tmf_bn_act_pool_bwd_apply(const float* z, const float* dout, cons
 extern "C" int tmf_colsum_finalize(const float* partial, int nblk, int ncol, float* out, void* stream) {
     TMF_REQUIRE_PTR(partial); TMF_REQUIRE_PTR(out);
     TMF_REQUIRE(nblk > 0 && ncol > 0, TMF_E_SHAPE, "tmf_colsum_finalize: nblk=%d ncol=%d", nblk, ncol);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3(tmf_cdiv(ncol, 256)), dim3(256), 0, (hipStream_t)stream,
-                       partial, nblk, ncol, out);
+    const dim3 block(64 * TMF_RED_LANES);
+    hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(tmf_cdiv(ncol, 64), 1), block, 0, (hipStream_t)stream,
+                       partial, out, nblk, (long)ncol, nblk);
     return tmf_launch_result("tmf_colsum_finalize");
 }

@@ -42,18 +42,20 @@ struct FwdCfg {
     static constexpr int NTAPS = KS * KS * KS;
     static constexpr int NSTAGES = NTAPS / TPS;
     static constexpr int BSTAGE = TPS * CINC * NB;       // floats per weight stage
-    static constexpr int BV = (BSTAGE / 4 + 255) / 256;  // float4 prefetch registers per thread
-    static constexpr int RED = 4 * 32 * NT * 2;          // cross-wave stat scratch (floats)
+    static constexpr int NW = WM * WN;                   // wavefronts per workgroup (4, or 8 = 2 per SIMD)
+    static constexpr int NTHR = 64 * NW;
+    static constexpr int BV = (BSTAGE / 4 + NTHR - 1) / NTHR;   // float4 prefetch registers per thread
+    static constexpr int RED = NW * 32 * NT * 2;         // cross-wave stat scratch (floats)
     static constexpr size_t LDS_BYTES = (size_t)(NHALO * CP + 2 * BSTAGE + RED) * 4;
     static_assert(NPOS == 32 * MT * WM, "brick must be MT*WM tiles of 32 voxels");
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(CINC % 8 == 0, "cin chunk is a multiple of 8");
     static_assert(NTAPS % TPS == 0, "taps per stage must divide the tap count");
     static_assert(KS == 1 || TPS == 1 || TPS == 3, "stage = 1 tap or one kw row");
 };
 
 template <class C, bool VEC>
-__global__ __launch_bounds__(256) void conv3d_fwd_kernel(
+__global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
     int tilesD, int tilesH, int tilesW, int ntiles) {
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(
         if (c0 > 0) __syncthreads();   // everyone is done with the previous halo and weight ring
         // ---- stage the input halo for channels [c0, c0+CINC) ----
         constexpr int C4 = C::CINC / 4;
-        for (int e = tid; e < C::NHALO * C4; e += 256) {
+        for (int e = tid; e < C::NHALO * C4; e += C::NTHR) {
             const int hp = e / C4, c4 = e % C4;
             const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
             const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(
         auto load_b = [&](int st) {
 #pragma unroll
             for (int q = 0; q < C::BV; ++q) {
-                const int e = tid + q * 256;
+                const int e = tid + q * C::NTHR;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (e < C::BSTAGE / 4) {
                     const int row = e / (C::NB / 4), col = (e % (C::NB / 4)) * 4;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(
         auto store_b = [&](int buf) {
 #pragma unroll
             for (int q = 0; q < C::BV; ++q) {
-                const int e = tid + q * 256;
+                const int e = tid + q * C::NTHR;
                 if (e < C::BSTAGE / 4)
                     *reinterpret_cast<f32x4*>(&Bs[buf * C::BSTAGE + e * 4]) = breg[q];
             }
@@ -260,9 +262,23 @@ __global__ __launch_bounds__(256) void conv3d_fwd_kernel(
 template <int KS, int CINC> using CfgL32 = FwdCfg<KS, CINC, 2, 1, 4, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgL64 = FwdCfg<KS, CINC, 2, 2, 4, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgS128 = FwdCfg<KS, CINC, 1, 2, 2, 2, 4, 4, 4, 1>;
+// 8-wave variants (two wavefronts per SIMD share the matrix pipe: one computes while the other waits on LDS)
+template <int KS, int CINC> using CfgL32w8 = FwdCfg<KS, CINC, 1, 1, 8, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
+template <int KS, int CINC> using CfgL64w8 = FwdCfg<KS, CINC, 1, 2, 8, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
+template <int KS, int CINC> using CfgS128w8 = FwdCfg<KS, CINC, 1, 1, 2, 4, 4, 4, 4, 1>;
+
+// tuning knob (tmf_set_option("conv_waves", 4|8) or TMF_CONV_WAVES): wavefronts per conv workgroup
+int g_conv_waves = 0;
+int conv_waves() {
+    if (g_conv_waves == 0) {
+        const char* e = getenv("TMF_CONV_WAVES");
+        g_conv_waves = (e && atoi(e) == 4) ? 4 : 8;
+    }
+    return g_conv_waves;
+}
 
 struct FwdPlan {
-    int cfg;      // 0 = L32, 1 = L64, 2 = S128
+    int cfg;      // 0 = L32, 1 = L64, 2 = S128  (+3: 8-wave variant)
     int cinc;     // 8, 16, 32
     int tilesD, tilesH, tilesW, ntiles, nby;
 };
@@ -279,6 +295,7 @@ FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks) {
         p.cfg = 2; nb = 128; td = 4; th = 4; tw = 4;
     }
     (void)ks;
+    if (p.cinc == 32 && conv_waves() == 8) p.cfg += 3;
     p.tilesD = tmf_cdiv(D, td); p.tilesH = tmf_cdiv(H, th); p.tilesW = tmf_cdiv(W, tw);
     p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
     p.nby = tmf_cdiv(cout, nb);
@@ -289,7 +306,7 @@ template <class C>
 int launch_fwd_cfg(const FwdPlan& p, const float* x, const float* w, float* z, float* sp,
                    int D, int H, int W, int cin, int cout, hipStream_t s) {
     const bool vec = (cin % 4 == 0) && (cout % 4 == 0);
-    dim3 grid(p.ntiles, p.nby), block(256);
+    dim3 grid(p.ntiles, p.nby), block(C::NTHR);
     int rc;
     if (vec) {
         auto k = conv3d_fwd_kernel<C, true>;
@@ -313,6 +330,9 @@ int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float
     if (p.cfg == 0) { TMF_FWD_CASE(CfgL32, 8) TMF_FWD_CASE(CfgL32, 16) TMF_FWD_CASE(CfgL32, 32) }
     if (p.cfg == 1) { TMF_FWD_CASE(CfgL64, 8) TMF_FWD_CASE(CfgL64, 16) TMF_FWD_CASE(CfgL64, 32) }
     if (p.cfg == 2) { TMF_FWD_CASE(CfgS128, 8) TMF_FWD_CASE(CfgS128, 16) TMF_FWD_CASE(CfgS128, 32) }
+    if (p.cfg == 3) { TMF_FWD_CASE(CfgL32w8, 32) }
+    if (p.cfg == 4) { TMF_FWD_CASE(CfgL64w8, 32) }
+    if (p.cfg == 5) { TMF_FWD_CASE(CfgS128w8, 32) }
 #undef TMF_FWD_CASE
     tmf_set_error("tmf_conv3d_fwd: no kernel for plan cfg=%d cinc=%d", p.cfg, p.cinc);
     return TMF_E_SHAPE;
@@ -321,21 +341,23 @@ int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float
 // ------------------------------------------------------------------------------------
 // weight gradient, 3x3x3
 // ------------------------------------------------------------------------------------
-template <int NT_, int TD_, int TH_, int TW_>
+template <int NT_, int TD_, int TH_, int TW_, int NW_ = 4>
 struct WgCfg {
-    static constexpr int NT = NT_, TD = TD_, TH = TH_, TW = TW_;
+    static constexpr int NT = NT_, TD = TD_, TH = TH_, TW = TW_, NW = NW_;
+    static constexpr int NTHR = 64 * NW;
     static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
     static constexpr int NHALO = HD * HH * HW;
     static constexpr int CI = 32;                 // input channels per workgroup (one MFMA M-tile)
     static constexpr int NB = 32 * NT;            // output channels per workgroup
     static constexpr int NPOS = TD * TH * TW;
-    static constexpr int TPW = 7;                 // taps per wave (4 waves x 7 >= 27)
+    // taps per wave: 4 waves x 7, or 8 waves as 4 SIMD pairs of (4 + 3) -> 7 taps per SIMD either way
+    static constexpr int TPW = NW == 4 ? 7 : 4;
     static constexpr size_t LDS_BYTES = (size_t)(NHALO * CI + NPOS * NB) * 4;
     static_assert(TW % 2 == 0, "voxel pairs must not straddle a row");
 };
 
 template <class C, bool VEC>
-__global__ __launch_bounds__(256) void conv3d_wgrad_kernel(
+__global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
     int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles,
     int tiles_per_split) {
@@ -352,11 +374,14 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(
     const int ci0 = blockIdx.y * C::CI;
     const int co0 = blockIdx.z * C::NB;
 
-    // halo float offset of each of this wave's taps (clamped; surplus taps are not written)
+    // This wave's taps.  Waves w and w+4 share a SIMD (dispatch order), each SIMD owns 7 consecutive taps.
+    const int tap_base = C::NW == 4 ? 7 * wave : 7 * (wave & 3) + 4 * (wave >> 2);
+    const int tap_cnt = C::NW == 4 ? 7 : (wave < 4 ? 4 : 3);
+    // halo float offset of each tap (clamped; surplus taps are neither computed nor written)
     int tapoff[C::TPW];
 #pragma unroll
     for (int t = 0; t < C::TPW; ++t) {
-        int tap = wave * C::TPW + t;
+        int tap = tap_base + t;
         tap = tap > 26 ? 26 : tap;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
         tapoff[t] = ((kd * C::HH + kh) * C::HW + kw + hsel) * C::CI + l31;
@@ -386,7 +411,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(
         const float* dzb = dz + (size_t)b * D * H * W * Cout;
 
         __syncthreads();   // previous brick fully consumed
-        for (int e = tid; e < C::NHALO * 8; e += 256) {
+        for (int e = tid; e < C::NHALO * 8; e += C::NTHR) {
             const int hp = e >> 3, c4 = e & 7;
             const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
             const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
@@ -404,7 +429,7 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(
             }
             *reinterpret_cast<f32x4*>(&xh[hp * C::CI + c4 * 4]) = v;
         }
-        for (int e = tid; e < C::NPOS * (C::NB / 4); e += 256) {
+        for (int e = tid; e < C::NPOS * (C::NB / 4); e += C::NTHR) {
             const int p = e / (C::NB / 4), c4 = e % (C::NB / 4);
             const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
             const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
@@ -435,10 +460,12 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(
                 for (int j = 0; j < C::NT; ++j) bv[j] = bsrc[2 * q * C::NB + j * 32];
 #pragma unroll
                 for (int t = 0; t < C::TPW; ++t) {
-                    const float av = xh[tapoff[t] + rowoff + 2 * q * C::CI];
+                    if (t < tap_cnt && tap_base + t < 27) {      // wave-uniform
+                        const float av = xh[tapoff[t] + rowoff + 2 * q * C::CI];
 #pragma unroll
-                    for (int j = 0; j < C::NT; ++j)
-                        acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[t][j], 0, 0, 0);
+                        for (int j = 0; j < C::NT; ++j)
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[t][j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -447,8 +474,8 @@ __global__ __launch_bounds__(256) void conv3d_wgrad_kernel(
     // partial[split][tap][ci][co];  D fragment: row = ci, column = co
 #pragma unroll
     for (int t = 0; t < C::TPW; ++t) {
-        const int tap = wave * C::TPW + t;
-        if (tap < 27) {
+        const int tap = tap_base + t;
+        if (t < tap_cnt && tap < 27) {
 #pragma unroll
             for (int j = 0; j < C::NT; ++j) {
                 const int co = co0 + j * 32 + l31;
@@ -506,16 +533,6 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(
             if (cr < Cin && co < Cout) partial[((size_t)split * Cin + cr) * Cout + co] = acc[j][r];
         }
     }
-}
-
-// out[e] = sum_s partial[s][e]  (fixed order -> deterministic)
-__global__ void slab_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                   int nsplit, long n) {
-    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n) return;
-    float a = 0.f;
-    for (int s = 0; s < nsplit; ++s) a += partial[(size_t)s * n + e];
-    out[e] = a;
 }
 
 struct WgPlan {
@@ -740,7 +757,8 @@ C1Plan plan_c1(int B, int D, int H, int W, int cout) {
     p.tilesD = tmf_cdiv(D, C1_TD); p.tilesH = tmf_cdiv(H, C1_TH); p.tilesW = tmf_cdiv(W, C1_TW);
     p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
     p.nby = tmf_cdiv(cout, 32);
-    int want = 2048 / p.nby;
+    int want = 1024 / p.nby;
+    if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tps = tmf_cdiv(p.ntiles, want);
     p.nblk = tmf_cdiv(p.ntiles, p.tps);
@@ -752,6 +770,17 @@ C1Plan plan_c1(int B, int D, int H, int W, int cout) {
 // ------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------
+extern "C" int tmf_set_option(const char* name, int value) {
+    TMF_REQUIRE_PTR(name);
+    if (strcmp(name, "conv_waves") == 0) {
+        TMF_REQUIRE(value == 4 || value == 8, TMF_E_ARG, "tmf_set_option: conv_waves must be 4 or 8, got %d", value);
+        g_conv_waves = value;
+        return TMF_OK;
+    }
+    tmf_set_error("tmf_set_option: unknown option '%s'", name);
+    return TMF_E_ARG;
+}
+
 extern "C" int tmf_conv3d_stat_blocks(int B, int D, int H, int W, int cin, int cout, int ksize) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
     return plan_fwd(B, D, H, W, cin, cout, ksize).ntiles;
@@ -776,10 +805,10 @@ extern "C" size_t tmf_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, i
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
     if (ksize == 3) {
         const WgPlan p = plan_wgrad(B, D, H, W, cin, cout);
-        return (size_t)p.nsplit * 27 * cin * cout * 4;
+        return (size_t)(p.nsplit + tmf_reduce_groups(p.nsplit)) * 27 * cin * cout * 4;
     }
     const Wg1Plan p = plan_wgrad1((long)B * D * H * W, cin, cout);
-    return (size_t)p.nsplit * cin * cout * 4;
+    return (size_t)(p.nsplit + tmf_reduce_groups(p.nsplit)) * cin * cout * 4;
 }
 
 extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void* workspace,
@@ -801,19 +830,30 @@ extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void
     int nsplit;
     if (ksize == 3) {
         const WgPlan p = plan_wgrad(B, D, H, W, cin, cout);
-        dim3 grid(p.nsplit, p.gy, p.gz), block(256);
+        dim3 grid(p.nsplit, p.gy, p.gz);
 #define TMF_WG_LAUNCH(CFG, V)                                                                       \
     do {                                                                                            \
         auto k = conv3d_wgrad_kernel<CFG, V>;                                                       \
         if ((rc = tmf_allow_lds(k, CFG::LDS_BYTES, "tmf_conv3d_wgrad"))) return rc;                 \
-        hipLaunchKernelGGL(k, grid, block, CFG::LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,   \
+        hipLaunchKernelGGL(k, grid, dim3(CFG::NTHR), CFG::LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,   \
                            p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);                          \
     } while (0)
         using L1 = WgCfg<1, 4, 8, 8>;
         using L2 = WgCfg<2, 4, 8, 8>;
         using S1 = WgCfg<1, 4, 4, 4>;
         using S2 = WgCfg<2, 4, 4, 4>;
-        if (!p.small && p.nt == 1) { if (vec) TMF_WG_LAUNCH(L1, true); else TMF_WG_LAUNCH(L1, false); }
+        using L1w8 = WgCfg<1, 4, 8, 8, 8>;
+        using L2w8 = WgCfg<2, 4, 8, 8, 8>;
+        using S1w8 = WgCfg<1, 4, 4, 4, 8>;
+        using S2w8 = WgCfg<2, 4, 4, 4, 8>;
+        const bool w8 = vec && conv_waves() == 8;
+        if (w8) {
+            if (!p.small && p.nt == 1) TMF_WG_LAUNCH(L1w8, true);
+            else if (!p.small)         TMF_WG_LAUNCH(L2w8, true);
+            else if (p.nt == 1)        TMF_WG_LAUNCH(S1w8, true);
+            else                       TMF_WG_LAUNCH(S2w8, true);
+        }
+        else if (!p.small && p.nt == 1) { if (vec) TMF_WG_LAUNCH(L1, true); else TMF_WG_LAUNCH(L1, false); }
         else if (!p.small)         { if (vec) TMF_WG_LAUNCH(L2, true); else TMF_WG_LAUNCH(L2, false); }
         else if (p.nt == 1)        { if (vec) TMF_WG_LAUNCH(S1, true); else TMF_WG_LAUNCH(S1, false); }
         else                       { if (vec) TMF_WG_LAUNCH(S2, true); else TMF_WG_LAUNCH(S2, false); }
@@ -831,8 +871,7 @@ extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void
         nelem = (long)cin * cout;
         nsplit = p.nsplit;
     }
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(tmf_cdiv(nelem, 256)), dim3(256), 0, s, partial, dw, nsplit, nelem);
-    return tmf_launch_result("tmf_conv3d_wgrad(reduce)");
+    return tmf_reduce_slabs(partial, nsplit, nelem, partial + (size_t)nsplit * nelem, dw, s, "tmf_conv3d_wgrad(reduce)");
 }
 
 extern "C" int tmf_conv3d_c1_stat_blocks(int B, int D, int H, int W, int cout) {
@@ -854,7 +893,7 @@ extern "C" int tmf_conv3d_c1_fwd(const float* x, const float* w, float* z, float
 extern "C" size_t tmf_conv3d_c1_wgrad_workspace_bytes(int B, int D, int H, int W, int cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cout <= 0) return 0;
     const C1Plan p = plan_c1(B, D, H, W, cout);
-    return (size_t)p.nblk * 4 * 27 * cout * 4;
+    return (size_t)(p.nblk * 4 + tmf_reduce_groups(p.nblk * 4)) * 27 * cout * 4;
 }
 
 extern "C" int tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* workspace,
@@ -873,6 +912,6 @@ extern "C" int tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, v
     int rc;
     if ((rc = tmf_launch_result("tmf_conv3d_c1_wgrad"))) return rc;
     const long nelem = 27L * cout;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(tmf_cdiv(nelem, 256)), dim3(256), 0, s, partial, dw, p.nblk * 4, nelem);
-    return tmf_launch_result("tmf_conv3d_c1_wgrad(reduce)");
+    return tmf_reduce_slabs(partial, p.nblk * 4, nelem, partial + (size_t)p.nblk * 4 * nelem, dw, s,
+                            "tmf_conv3d_c1_wgrad(reduce)");
 }

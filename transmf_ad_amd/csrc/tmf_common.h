@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include "../../include/tmf_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -58,6 +60,13 @@ static inline int tmf_allow_lds(K kernel, size_t bytes, const char* what) {
 
 static inline int tmf_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Two-stage slab reduction plan: `groups` first-stage groups (1 = single stage straight into `out`).
+static inline int tmf_reduce_groups(int nsplit) {
+    if (nsplit <= 64) return 1;
+    int g = nsplit / 16;
+    return g > 32 ? 32 : g;
+}
+
 #ifdef __HIPCC__
 // MI355X dispatches workgroup b to XCD b % 8 (speed hint only, MI355X_MICROARCH.md).
 // Map the launch index so that each XCD (= one private L2) walks a contiguous range
@@ -69,6 +78,39 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
     return start + idx;
 }
 
+// out[g][e] = sum over the slabs s of group g of partial[s][e]   (fixed order -> deterministic; fp64
+// accumulation: the sums cancel heavily).  Block = 64 consecutive elements x TMF_RED_LANES slab lanes.
+#define TMF_RED_LANES 16
+static __global__ __launch_bounds__(64 * TMF_RED_LANES) void tmf_slab_reduce_kernel(
+    const float* __restrict__ partial, float* __restrict__ out, int nsplit, long n, int slabs_per_group) {
+    __shared__ double red[TMF_RED_LANES][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long e = (long)blockIdx.x * 64 + tx;
+    const int g = blockIdx.y;
+    const int s0 = g * slabs_per_group;
+    int s1 = s0 + slabs_per_group;
+    if (s1 > nsplit) s1 = nsplit;
+    double a = 0.0;
+    if (e < n) {
+        int s = s0 + ty;
+        for (; s + 3 * TMF_RED_LANES < s1; s += 4 * TMF_RED_LANES) {
+            const float v0 = partial[(size_t)s * n + e];
+            const float v1 = partial[(size_t)(s + TMF_RED_LANES) * n + e];
+            const float v2 = partial[(size_t)(s + 2 * TMF_RED_LANES) * n + e];
+            const float v3 = partial[(size_t)(s + 3 * TMF_RED_LANES) * n + e];
+            a += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; s < s1; s += TMF_RED_LANES) a += (double)partial[(size_t)s * n + e];
+    }
+    red[ty][tx] = a;
+    __syncthreads();
+    if (ty == 0 && e < n) {
+#pragma unroll
+        for (int k = 1; k < TMF_RED_LANES; ++k) a += red[k][tx];
+        out[(size_t)g * n + e] = (float)a;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -78,5 +120,24 @@ __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
+}
+
+// Reduce `nsplit` slabs of `n` floats into out[n].  `scratch` (>= tmf_reduce_groups(nsplit)*n floats) is only
+// touched when the plan has two stages.
+static inline int tmf_reduce_slabs(const float* partial, int nsplit, long n, float* scratch, float* out,
+                                   hipStream_t s, const char* what) {
+    const int G = tmf_reduce_groups(nsplit);
+    const dim3 block(64 * TMF_RED_LANES);
+    const int gx = (int)((n + 63) / 64);
+    if (G == 1) {
+        hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, 1), block, 0, s, partial, out, nsplit, n, nsplit);
+        return tmf_launch_result(what);
+    }
+    const int spg = (nsplit + G - 1) / G;
+    hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, G), block, 0, s, partial, scratch, nsplit, n, spg);
+    int rc = tmf_launch_result(what);
+    if (rc) return rc;
+    hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, 1), block, 0, s, (const float*)scratch, out, G, n, G);
+    return tmf_launch_result(what);
 }
 #endif

@@ -169,7 +169,7 @@ extern "C" int tmf_layernorm_fwd(const float* x, const float* gamma, const float
 }
 
 static int ln_rows_per_block(int rows) {
-    int rpb = tmf_cdiv(rows, 512);
+    int rpb = tmf_cdiv(rows, 128);
     if (rpb < 4) rpb = 4;
     return rpb;
 }
