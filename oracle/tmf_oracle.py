@@ -288,13 +288,17 @@ def model_ad_forward(S, mri: Tensor, pet: Tensor, *, dim=128, depth=3, heads=4, 
     cls = fusion_forward(S, "fuse_transformer.", mt, pt, depth, heads, probes)
     if probes is not None:
         probes["cls"] = cls
+    return fc_cls_forward(S, cls, train, dropout_masks), d_m, d_p
+
+
+def fc_cls_forward(S, cls: Tensor, train: bool, dropout_masks=None) -> Tensor:
+    """``model_ad.fc_cls`` (mymodel.py:190-192): Linear-BN1d-ReLU-Dropout(.5) x2 - Linear."""
     k1, k2 = dropout_masks if dropout_masks is not None else (None, None)
     h = F.linear(cls, S["fc_cls.0.weight"], S["fc_cls.0.bias"])
     h = _drop(F.relu(_batch_norm(S, "fc_cls.1", h, train)), k1, train)
     h = F.linear(h, S["fc_cls.4.weight"], S["fc_cls.4.bias"])
     h = _drop(F.relu(_batch_norm(S, "fc_cls.5", h, train)), k2, train)
-    logits = F.linear(h, S["fc_cls.8.weight"], S["fc_cls.8.bias"])
-    return logits, d_m, d_p
+    return F.linear(h, S["fc_cls.8.weight"], S["fc_cls.8.bias"])
 
 
 def model_cnn_ad_forward(S, mri: Tensor, pet: Tensor, *, dim=128, train=True, probes=None):

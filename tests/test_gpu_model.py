@@ -11,11 +11,13 @@ from _golden import Golden, available, gprobe, probe, run_oracle, zero_grad_keys
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
-TOL = 5e-4      # north_star gate is 1e-3.  The batch-2 fixtures are the ill-conditioned ones: train-mode
-                # BatchNorm1d over TWO samples maps (x1-x2) -> +-1 with gain ~1/sqrt(eps) when the two are close,
-                # so fp32 noise of 1e-6 in `cls` shows up as 1e-4 in the logits (the reference's own fp32 run
-                # is 8e-5 away from its fp64 run on ad_full_b2).  The dropout/BN1d-free `cls` vector is held
-                # to 5e-5 separately.
+GATE = 1e-3     # north_star gate on logits / loss (fp32)
+TOL = 2e-4      # everything that is not behind the train-mode fc_cls head
+# Why the logits get the full gate: uniform-noise volumes give nearly IDENTICAL pooled features for every sample of
+# the batch (spread << sqrt(bn_eps)), so fc_cls's train-mode BatchNorm1d divides by ~sqrt(eps) and amplifies absolute
+# fp32 noise in `cls` by up to ~300x (the reference's own fp32 run sits 8e-5 from its fp64 run on ad_full_b2 for the
+# same reason).  The tests therefore also pin (a) the BN1d-free `cls` vector and sNet outputs to 5e-5 of the
+# reference's fp64 probes and (b) the head itself, evaluated by the oracle on OUR cls vector, to 1e-4.
 
 
 class FixedMaskDropout(nn.Module):
@@ -92,11 +94,18 @@ def test_train_step_matches_reference_golden(name):
     for k, t in seen.items():          # well-conditioned intermediate results vs the reference's fp64 probes
         ref = g[f"f64/probe/{k}"]
         assert np.abs(probe(t) - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), (k, probe(t) - ref)
+    if "cls" in seen:                  # the head on OUR cls vector, evaluated by the oracle in fp64
+        from oracle import tmf_oracle as O
+        S = O.to_state(g.arrays(), g.spec, dtype=torch.float64, requires_grad=False)
+        k1, k2 = (torch.from_numpy(m) for m in g.masks())
+        ref_head = O.fc_cls_forward(S, seen["cls"].detach().double().cpu(), True, (k1, k2))
+        assert (outs["logits"].detach().double().cpu() - ref_head).abs().max().item() <= 1e-4
     for k, v in outs.items():
         got = v.detach().double().cpu().numpy()
-        assert np.abs(got - g[f"f32/train/{k}"]).max() <= TOL, (k, "vs reference fp32")
-        assert np.abs(got - g[f"f64/train/{k}"]).max() <= TOL, (k, "vs reference fp64")
-    assert abs(loss.item() - float(g["f64/train/loss"])) <= TOL
+        tol = GATE if k == "logits" else TOL
+        assert np.abs(got - g[f"f32/train/{k}"]).max() <= tol, (k, "vs reference fp32")
+        assert np.abs(got - g[f"f64/train/{k}"]).max() <= tol, (k, "vs reference fp64")
+    assert abs(loss.item() - float(g["f64/train/loss"])) <= GATE
     # gradients against the reference's fp64 probes (its own fp32 grads are only good to ~2e-2 of max)
     zk = zero_grad_keys(g.spec, g.model)
     worst = 0.0
@@ -160,7 +169,8 @@ def test_activations_and_grads_match_oracle(name):
         err = (p.grad.double().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
         # conv weight gradients are 1e5..1e6-term fp32 sums with heavy cancellation: the reference's own fp32
         # run is 1e-3..2e-2 (of max) away from fp64 there; everything else is held to 5e-3
-        assert err <= (2e-2 if p.dim() == 5 else 5e-3), (k, err)
+        long_reduction = p.dim() == 5 or "_cnn.conv" in k        # conv weights and BatchNorm3d gamma/beta
+        assert err <= (2e-2 if long_reduction else 5e-3), (k, err)
 
 
 def test_reference_train_step_runs_unchanged_with_adam():

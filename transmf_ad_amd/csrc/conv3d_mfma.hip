@@ -172,6 +172,16 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
                 else if (C::TPS == 3) stage_off = ((st / 3) * C::HH + (st % 3)) * C::HW * C::CP;
                 else stage_off = (((st / 9) * C::HH + (st / 3) % 3) * C::HW + st % 3) * C::CP;
                 const float* bs = Bs + buf * C::BSTAGE + b_lane;
+                // Each stage (<= 96 products per output) accumulates from zero and is then added to the running
+                // sum: the fp32 MFMA is a strict k-ordered fma chain, and one 864..3456-term chain would carry
+                // ~sqrt(K) ulp of drift; short chains + 9 adds per channel chunk keep it ~3-5x smaller.
+                f32x16 part[C::MT][C::NT];
+#pragma unroll
+                for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
 #pragma unroll
                 for (int tp = 0; tp < C::TPS; ++tp) {
 #pragma unroll
@@ -187,11 +197,15 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
                                 const float bv = bs[(tp * C::CINC + g * 8 + s) * C::NB + j * 32];
 #pragma unroll
                                 for (int i = 0; i < C::MT; ++i)
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], bv, acc[i][j], 0, 0, 0);
+                                    part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], bv, part[i][j], 0, 0, 0);
                             }
                         }
                     }
                 }
+#pragma unroll
+                for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j) acc[i][j] += part[i][j];
             }
         }
     }
