@@ -70,9 +70,10 @@ def gprobe(g):
     return np.concatenate([[g.sum().item(), g.abs().sum().item(), g.abs().max().item()], g[idx].numpy()])
 
 
-def run_oracle(g: Golden, dtype=torch.float32, train=True, backward=True):
-    """Run the oracle on a fixture's inputs.  Returns dict(outs, loss, probes, grads, state)."""
-    S = O.to_state(g.arrays(), g.spec, dtype=dtype, requires_grad=train and backward)
+def run_oracle(g: Golden, dtype=torch.float32, train=True, backward=True, keep_graph=False):
+    """Run the oracle on a fixture's inputs.  Returns dict(outs, loss, probes, grads, state).
+    keep_graph: leave the parameters requiring grad (and the probes attached) without calling backward."""
+    S = O.to_state(g.arrays(), g.spec, dtype=dtype, requires_grad=train and (backward or keep_graph))
     mri, pet, y = g.inputs()
     mri, pet, y = torch.from_numpy(mri).to(dtype), torch.from_numpy(pet).to(dtype), torch.from_numpy(y)
     probes = {}

@@ -118,7 +118,9 @@ def test_train_step_matches_reference_golden(name):
             continue
         err = np.abs(got[3:] - ref[3:]).max() / max(ref[2], 1e-30)
         worst = max(worst, err)
-        assert err <= 2e-2, (k, err)
+        # loose: these gradients flow back through the same ill-conditioned BatchNorm1d heads (see GATE note);
+        # the tight gradient check is test_activations_and_grads_match_oracle
+        assert err <= 5e-2, (k, err)
     # BatchNorm buffers after one step (running stats, num_batches_tracked incl. D's double update)
     for k, b in net.named_buffers():
         ref = g[f"f32/buf/{k}"]
@@ -138,39 +140,57 @@ def test_eval_matches_reference_golden(name):
 
 @pytest.mark.parametrize("name", ["ad_tiny", "ad_ragged", "ad_mid"])
 def test_activations_and_grads_match_oracle(name):
-    """Same inputs through the CPU oracle (fp64) here and the HIP path: stage-by-stage probes."""
+    """Same inputs through the CPU oracle (fp64) and the HIP path: stage-by-stage activations, and the
+    gradients of a WELL-CONDITIONED functional of the hot path's outputs (random linear read-outs of `cls` and
+    of the two pooled sNet embeddings).  This takes the train-mode BatchNorm1d heads — which amplify fp32 noise
+    ~300x on uniform-noise volumes, forward and backward — out of the gradient comparison, so the conv / BN /
+    pool / attention / LayerNorm backward kernels can be held to 1e-3 of each tensor's max."""
     g = Golden(name)
-    r = run_oracle(g, dtype=torch.float64, train=True)
+    dim = g.kw["dim"]
+    rs = np.random.RandomState(3)
+    R1 = torch.from_numpy(rs.standard_normal((g.batch, 4 * dim)))
+    R2 = torch.from_numpy(rs.standard_normal((2, g.batch, dim)))
+
+    def readout(cls, mri_emb, pet_emb):
+        R1_, R2_ = R1.to(cls), R2.to(cls)
+        return (cls * R1_).sum() + (mri_emb.mean(dim=(2, 3, 4)) * R2_[0]).sum() + (pet_emb.mean(dim=(2, 3, 4)) * R2_[1]).sum()
+
+    r = run_oracle(g, dtype=torch.float64, train=True, backward=False, keep_graph=True)
+    P = r["probes"]
+    readout(P["cls"], P["mri_cnn.conv4.3"], P["pet_cnn.conv4.3"]).backward()
+    ref_grads = {k: r["state"][k].grad for k, (kind, _s) in g.spec.items() if kind == "param"}
+
     net = build(g)
     got = {}
     hooks = []
     for c in ("mri_cnn", "pet_cnn"):
-        s = getattr(net, c)
-        hooks.append(s.register_forward_hook(lambda _m, _i, o, c=c: got.__setitem__(f"{c}.conv4.3", o)))
+        hooks.append(getattr(net, c).register_forward_hook(lambda _m, _i, o, c=c: got.__setitem__(f"{c}.conv4.3", o)))
     for l, pair in enumerate(net.fuse_transformer.layers):
         for sidx in (0, 1):
             hooks.append(pair[sidx].register_forward_hook(
                 lambda _m, _i, o, l=l, sidx=sidx: got.__setitem__(f"fuse_transformer.layers.{l}.{sidx}", o)))
     hooks.append(net.fuse_transformer.register_forward_hook(lambda _m, _i, o: got.__setitem__("cls", o)))
-    step(net, g, train=True)
+    mri, pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+    net.train()
+    net(mri, pet)
     for h in hooks:
         h.remove()
     for k, t in got.items():
-        ref = r["probes"][k]
-        if k.endswith("conv4.3"):
-            t = t.contiguous()          # (B,C,d,h,w) view of the channels-last buffer
-        err = (t.detach().double().cpu() - ref.detach()).abs().max().item()
-        assert err <= 2e-4 * max(1.0, ref.abs().max().item()), (k, err)
-    zk = zero_grad_keys(g.spec, g.model)
+        ref = P[k].detach()
+        err = (t.detach().double().cpu() - ref).abs().max().item()
+        assert err <= 5e-5 * max(1.0, ref.abs().max().item()), (k, err)
+    readout(got["cls"], got["mri_cnn.conv4.3"], got["pet_cnn.conv4.3"]).backward()
+    torch.cuda.synchronize()
+    conv_bias = {k for k in g.spec if k.endswith(".bias") and len(g.spec[k[:-4] + "weight"][1]) == 5}
+    checked = 0
     for k, p in net.named_parameters():
-        if k in zk:
+        ref = ref_grads.get(k)
+        if ref is None or k in conv_bias:        # heads get no gradient from this read-out; conv biases are exactly 0
             continue
-        ref = r["grads"][k]
         err = (p.grad.double().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
-        # conv weight gradients are 1e5..1e6-term fp32 sums with heavy cancellation: the reference's own fp32
-        # run is 1e-3..2e-2 (of max) away from fp64 there (SURVEY.md §8c); everything else is held to 5e-3
-        long_reduction = p.dim() == 5 or "_cnn.conv" in k        # conv weights and BatchNorm3d gamma/beta
-        assert err <= (2e-2 if long_reduction else 5e-3), (k, err)
+        assert err <= 1e-3, (k, err)
+        checked += 1
+    assert checked >= 2 * 21 + 14 * g.kw["depth"] * 2 - 1
 
 
 def test_reference_train_step_runs_unchanged_with_adam():

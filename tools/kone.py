@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Launch ONE conv kernel variant a few times (for rocprofv3 --pmc passes).
+   python tools/kone.py fwd|dgrad|wgrad LAYER [--B 8 --S 96 --reps 5 --waves 8]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from transmf_ad_amd import _lib, ops          # noqa: E402
+from tools.kbench import LAYERS               # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("what")
+ap.add_argument("layer")
+ap.add_argument("--B", type=int, default=8)
+ap.add_argument("--S", type=int, default=96)
+ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--waves", type=int, default=8)
+a = ap.parse_args()
+_lib.call("tmf_set_option", b"conv_waves", a.waves)
+name, cin, cout, k, div, pool = [l for l in LAYERS if l[0] == a.layer][0]
+s = a.S // div
+dev = "cuda:0"
+x = torch.randn((a.B, s, s, s, cin), device=dev)
+w = torch.randn((cout, cin, k, k, k), device=dev) * (cin * k ** 3) ** -0.5
+dz = torch.randn((a.B, s, s, s, cout), device=dev)
+wp, wd = ops.pack_weight(w), ops.pack_weight_dgrad(w)
+for _ in range(a.reps):
+    if a.what == "fwd":
+        ops.conv3d_raw(x, wp, cin, cout, k, True)
+    elif a.what == "dgrad":
+        ops.conv3d_raw(dz, wd, cout, cin, k, False)
+    else:
+        ops.conv3d_wgrad(x, dz, cin, cout, k)
+torch.cuda.synchronize()
+print("done", a.what, a.layer)
