@@ -103,25 +103,30 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
 
     for (int c0 = 0; c0 < Cin; c0 += C::CINC) {
         if (c0 > 0) __syncthreads();   // everyone is done with the previous halo and weight ring
-        // ---- stage the input halo for channels [c0, c0+CINC) ----
+        // ---- stage the input halo for channels [c0, c0+CINC): issue every load first, then the LDS writes, so
+        //      the workgroup pays one memory latency instead of one per loop trip ----
         constexpr int C4 = C::CINC / 4;
-        for (int e = tid; e < C::NHALO * C4; e += C::NTHR) {
+        constexpr int HV = (C::NHALO * C4 + C::NTHR - 1) / C::NTHR;
+        f32x4 hreg[HV];
+#pragma unroll
+        for (int q = 0; q < HV; ++q) {
+            const int e = tid + q * C::NTHR;
             const int hp = e / C4, c4 = e % C4;
             const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
             const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
             const int c = c0 + c4 * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
+            if (e < C::NHALO * C4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
                 const float* src = xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c;
                 if (VEC) {
                     if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c + q < Cin) v[q] = src[q];
+                    for (int u = 0; u < 4; ++u)
+                        if (c + u < Cin) v[u] = src[u];
                 }
             }
-            *reinterpret_cast<f32x4*>(&halo[hp * C::CP + c4 * 4]) = v;
+            hreg[q] = v;
         }
 
         // ---- weight stage loader: element e -> (row = tap_in_stage*CINC + ci, 4 couts) ----
@@ -160,6 +165,11 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
         };
 
         load_b(0);
+#pragma unroll
+        for (int q = 0; q < HV; ++q) {
+            const int e = tid + q * C::NTHR;
+            if (e < C::NHALO * C4) *reinterpret_cast<f32x4*>(&halo[(e / C4) * C::CP + (e % C4) * 4]) = hreg[q];
+        }
         for (int st = 0; st < C::NSTAGES; ++st) {
             const int buf = st & 1;
             store_b(buf);
@@ -280,19 +290,25 @@ template <int KS, int CINC> using CfgS128 = FwdCfg<KS, CINC, 1, 2, 2, 2, 4, 4, 4
 template <int KS, int CINC> using CfgL32w8 = FwdCfg<KS, CINC, 1, 1, 8, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgL64w8 = FwdCfg<KS, CINC, 1, 2, 8, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgS128w8 = FwdCfg<KS, CINC, 1, 1, 2, 4, 4, 4, 4, 1>;
+// 4x4x8 bricks, 4 waves, <= 78 KiB of LDS: TWO workgroups per CU whose phases (halo staging, weight-stage
+// barriers, epilogue) are independent, so one computes while the other stages or stores
+template <int KS, int CINC> using CfgM32 = FwdCfg<KS, CINC, 1, 1, 4, 1, 4, 4, 8, (KS == 3 ? 3 : 1)>;
+template <int KS, int CINC> using CfgM64 = FwdCfg<KS, CINC, 1, 2, 4, 1, 4, 4, 8, 1>;
 
-// tuning knob (tmf_set_option("conv_waves", 4|8) or TMF_CONV_WAVES): wavefronts per conv workgroup
+// tuning knob (tmf_set_option("conv_waves", v) or TMF_CONV_WAVES): forward/dgrad workgroup shape for the large
+// layers: 4 = 4 waves, 1 workgroup per CU; 8 = 8 waves (two per SIMD); 2 = 4x4x8 bricks, two workgroups per CU
 int g_conv_waves = 0;
 int conv_waves() {
     if (g_conv_waves == 0) {
         const char* e = getenv("TMF_CONV_WAVES");
-        g_conv_waves = (e && atoi(e) == 4) ? 4 : 8;
+        const int v = e ? atoi(e) : 0;
+        g_conv_waves = (v == 4 || v == 2) ? v : 8;
     }
     return g_conv_waves;
 }
 
 struct FwdPlan {
-    int cfg;      // 0 = L32, 1 = L64, 2 = S128  (+3: 8-wave variant)
+    int cfg;      // 0 = L32, 1 = L64, 2 = S128  (+3: 8-wave variant); 6 = M32, 7 = M64
     int cinc;     // 8, 16, 32
     int tilesD, tilesH, tilesW, ntiles, nby;
 };
@@ -310,6 +326,10 @@ FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks) {
     }
     (void)ks;
     if (p.cinc == 32 && conv_waves() == 8) p.cfg += 3;
+    else if (p.cinc == 32 && conv_waves() == 2) {
+        if (p.cfg == 2) p.cfg = 5;
+        else { p.cfg += 6; th = 4; }
+    }
     p.tilesD = tmf_cdiv(D, td); p.tilesH = tmf_cdiv(H, th); p.tilesW = tmf_cdiv(W, tw);
     p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
     p.nby = tmf_cdiv(cout, nb);
@@ -347,6 +367,8 @@ int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float
     if (p.cfg == 3) { TMF_FWD_CASE(CfgL32w8, 32) }
     if (p.cfg == 4) { TMF_FWD_CASE(CfgL64w8, 32) }
     if (p.cfg == 5) { TMF_FWD_CASE(CfgS128w8, 32) }
+    if (p.cfg == 6) { TMF_FWD_CASE(CfgM32, 32) }
+    if (p.cfg == 7) { TMF_FWD_CASE(CfgM64, 32) }
 #undef TMF_FWD_CASE
     tmf_set_error("tmf_conv3d_fwd: no kernel for plan cfg=%d cinc=%d", p.cfg, p.cinc);
     return TMF_E_SHAPE;
@@ -414,54 +436,91 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
     int tile_end = tile_begin + tiles_per_split;
     if (tile_end > ntiles) tile_end = ntiles;
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
+    // Software pipeline over bricks: the NEXT brick's halo travels HBM -> registers while the current brick is
+    // being multiplied and is written to LDS after the compute phase (one barrier pair per brick); the dz rows
+    // (shorter, and the register file is full of accumulators) are fetched in one batch at the brick boundary.
+    constexpr int HV = (C::NHALO * 8 + C::NTHR - 1) / C::NTHR;
+    constexpr int DV = (C::NPOS * (C::NB / 4) + C::NTHR - 1) / C::NTHR;
+    f32x4 hreg[HV], dreg[DV];
+    auto locate = [&](int tile, int& b, int& d0, int& h0, int& w0) {
         int tt = tile;
         const int tw = tt % tilesW; tt /= tilesW;
         const int th = tt % tilesH; tt /= tilesH;
         const int td = tt % tilesD;
-        const int b = tt / tilesD;
-        const int d0 = td * C::TD, h0 = th * C::TH, w0 = tw * C::TW;
+        b = tt / tilesD;
+        d0 = td * C::TD; h0 = th * C::TH; w0 = tw * C::TW;
+    };
+    // slots [0, HVP) of the halo are prefetched a whole brick ahead, the rest rides with the dz batch
+    // (register budget: 2 waves per SIMD -> 256 VGPRs, half of them accumulators when NT == 2)
+    constexpr int HVP = (C::NW == 8 && C::NT == 2) ? (HV > 3 ? HV - 3 : 0) : HV;
+    auto fetch_halo = [&](int tile, const int q0, const int q1) {
+        int b, d0, h0, w0;
+        locate(tile, b, d0, h0, w0);
         const float* xb = x + (size_t)b * D * H * W * Cin;
-        const float* dzb = dz + (size_t)b * D * H * W * Cout;
-
-        __syncthreads();   // previous brick fully consumed
-        for (int e = tid; e < C::NHALO * 8; e += C::NTHR) {
+#pragma unroll
+        for (int q = q0; q < q1; ++q) {
+            const int e = tid + q * C::NTHR;
             const int hp = e >> 3, c4 = e & 7;
             const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
             const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
             const int c = ci0 + c4 * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
+            if (e < C::NHALO * 8 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
                 const float* src = xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c;
                 if (VEC) {
                     if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c + q < Cin) v[q] = src[q];
+                    for (int u = 0; u < 4; ++u)
+                        if (c + u < Cin) v[u] = src[u];
                 }
             }
-            *reinterpret_cast<f32x4*>(&xh[hp * C::CI + c4 * 4]) = v;
+            hreg[q] = v;
         }
-        for (int e = tid; e < C::NPOS * (C::NB / 4); e += C::NTHR) {
+    };
+    auto fetch_dz = [&](int tile) {
+        int b, d0, h0, w0;
+        locate(tile, b, d0, h0, w0);
+        const float* dzb = dz + (size_t)b * D * H * W * Cout;
+#pragma unroll
+        for (int q = 0; q < DV; ++q) {
+            const int e = tid + q * C::NTHR;
             const int p = e / (C::NB / 4), c4 = e % (C::NB / 4);
             const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
             const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
             const int c = co0 + c4 * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gd < D && gh < H && gw < W) {
+            if (e < C::NPOS * (C::NB / 4) && gd < D && gh < H && gw < W) {
                 const float* src = dzb + ((size_t)(gd * H + gh) * W + gw) * Cout + c;
                 if (VEC) {
                     if (c < Cout) v = *reinterpret_cast<const f32x4*>(src);
                 } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (c + q < Cout) v[q] = src[q];
+                    for (int u = 0; u < 4; ++u)
+                        if (c + u < Cout) v[u] = src[u];
                 }
             }
-            *reinterpret_cast<f32x4*>(&dzs[p * C::NB + c4 * 4]) = v;
+            dreg[q] = v;
+        }
+    };
+
+    if (tile_begin < tile_end) fetch_halo(tile_begin, 0, HVP);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        fetch_halo(tile, HVP, HV);
+        fetch_dz(tile);    // short-lived registers: issued here, landed by the time the halo is written
+        __syncthreads();   // previous brick fully consumed
+#pragma unroll
+        for (int q = 0; q < HV; ++q) {
+            const int e = tid + q * C::NTHR;
+            if (e < C::NHALO * 8) *reinterpret_cast<f32x4*>(&xh[e * 4]) = hreg[q];
+        }
+#pragma unroll
+        for (int q = 0; q < DV; ++q) {
+            const int e = tid + q * C::NTHR;
+            if (e < C::NPOS * (C::NB / 4)) *reinterpret_cast<f32x4*>(&dzs[e * 4]) = dreg[q];
         }
         __syncthreads();
+        if (tile + 1 < tile_end) fetch_halo(tile + 1, 0, HVP);   // in flight during the whole compute phase
 
         // K loop over voxel pairs: row = (pd, ph), pairs along w
         for (int row = 0; row < C::TD * C::TH; ++row) {
@@ -787,7 +846,8 @@ C1Plan plan_c1(int B, int D, int H, int W, int cout) {
 extern "C" int tmf_set_option(const char* name, int value) {
     TMF_REQUIRE_PTR(name);
     if (strcmp(name, "conv_waves") == 0) {
-        TMF_REQUIRE(value == 4 || value == 8, TMF_E_ARG, "tmf_set_option: conv_waves must be 4 or 8, got %d", value);
+        TMF_REQUIRE(value == 4 || value == 8 || value == 2, TMF_E_ARG,
+                    "tmf_set_option: conv_waves must be 2, 4 or 8, got %d", value);
         g_conv_waves = value;
         return TMF_OK;
     }
