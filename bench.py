@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2, help="pairs in the bounded CPU sample")
+    ap.add_argument("--cpu-threads", type=int, default=32)
     args = ap.parse_args()
 
     from transmf_ad_amd import model_ad, ops, _lib
@@ -144,7 +145,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tmf_oracle as O         # test infrastructure, used ONLY as the timed CPU baseline
-        sec, threads = O.cpu_train_step_seconds(args.cpu_batch, S, steps=1, warmup=1, threads=os.cpu_count())
+        # MKL-DNN conv3d scales poorly past a few dozen threads (256 SMT threads: 85 s/step vs ~8 s on 8): cap at 32
+        sec, threads = O.cpu_train_step_seconds(args.cpu_batch, S, steps=1, warmup=1,
+                                                threads=min(args.cpu_threads, os.cpu_count()))
         cpu = {"value": round(args.cpu_batch / sec, 4), "unit": "volume-pairs/s", "cores": threads, "kind": "port",
                "sample": f"oracle model_ad train-mode fwd+bwd, batch {args.cpu_batch} of 1x{S}^3 pairs "
                          f"(1/{max(1, B // args.cpu_batch)} of one batch-{B} step), 1 warm-up + 1 timed step, "

@@ -10,6 +10,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def pytest_configure(config):
+    import torch
+    # the host-side oracle (MKL-DNN conv3d) collapses when oversubscribed (256 SMT threads on the GPU box)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: CPU test that takes more than ~20 s")
 
