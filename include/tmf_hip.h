@@ -79,6 +79,28 @@ int    tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* wor
                            int B, int D, int H, int W, int cout, void* stream);
 
 /* ------------------------------------------------------------------------------
+ * Fused first block: Conv3d(1->C,3x3x3) -> BatchNorm3d -> LeakyReLU -> MaxPool3d(2) (networks.py:21-26)
+ * without materialising the conv output: every pass recomputes it from x (28 MB) instead of
+ * reading/writing the 906 MB tensor.  x[b][d][h][w], w[27][C], pooled/dpool [b][D/2][H/2][W/2][C].
+ *   tmf_c1_stats        -> stat_partial [tmf_c1_blocks()][2][C]  (reduce with tmf_bn_finalize)
+ *   tmf_c1_bn_pool_fwd  -> pooled
+ *   tmf_c1_bwd_reduce   -> partial [tmf_c1_blocks()][2][C]       (reduce with tmf_bn_bwd_finalize)
+ *   tmf_c1_bwd_wgrad    -> dw[27][C]   (coef from tmf_bn_bwd_finalize)
+ * ---------------------------------------------------------------------------- */
+int    tmf_c1_blocks(int B, int D, int H, int W, int C);
+int    tmf_c1_stats(const float* x, const float* w, float* stat_partial, int B, int D, int H, int W, int C, void* stream);
+int    tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* scale, const float* shift, float* pooled,
+                          int B, int D, int H, int W, int C, float slope, void* stream);
+int    tmf_c1_bwd_reduce(const float* x, const float* w, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, const float* dpool, float* partial,
+                         int B, int D, int H, int W, int C, float slope, void* stream);
+size_t tmf_c1_bwd_wgrad_workspace_bytes(int B, int D, int H, int W, int C);
+int    tmf_c1_bwd_wgrad(const float* x, const float* w, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* coef, const float* dpool,
+                        float* dw, void* workspace, size_t workspace_bytes,
+                        int B, int D, int H, int W, int C, float slope, void* stream);
+
+/* ------------------------------------------------------------------------------
  * BatchNorm3d (training statistics) + LeakyReLU + 2x2x2 pool, two passes.
  * Replaces F.batch_norm / leaky_relu / max_pool3d / avg_pool3d at
  * networks.py:23-25,29-30,32-34,38-39,41-43,47-48,50-52.

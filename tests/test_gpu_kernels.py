@@ -109,7 +109,10 @@ BLOCK_CASES = [
     (3, 7, 9, 5, 8, 8, 3, "max"),         # odd sizes: floor-mode pooling drops the last plane
     (2, 6, 6, 6, 16, 32, 3, None),
     (2, 4, 6, 5, 32, 16, 1, "avg"),
-    (2, 10, 9, 8, 1, 8, 3, "max"),        # first layer
+    (2, 10, 9, 8, 1, 8, 3, "max"),        # first layer (fused recompute path: conv output never stored)
+    (1, 13, 17, 11, 1, 32, 3, "max"),     # first layer, every brick ragged, odd pooling edges
+    (2, 8, 16, 24, 1, 40, 3, "max"),      # first layer, two channel tiles
+    (1, 6, 6, 6, 1, 8, 3, None),          # first layer without pool -> generic (stored-z) path
     (1, 5, 4, 3, 6, 10, 3, "max"),        # scalar channel path
     (2, 16, 16, 16, 32, 64, 3, "max"),
 ]

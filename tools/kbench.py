@@ -74,6 +74,30 @@ def main():
             r["bn_app_ms"] = timeit(lambda: _lib.call("tmf_bn_act_pool_bwd_apply", z.data_ptr(), out.data_ptr(), sc.data_ptr(),
                                                       sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), coef.data_ptr(),
                                                       dzo.data_ptr(), a.B, s, s, s, cout, pc, 0.01, st), a.reps)
+            if cin == 1:
+                xi = x.view(a.B, s, s, s)
+                wp1 = wp.view(27, cout)
+                nb1 = _lib.query("tmf_c1_blocks", a.B, s, s, s, cout)
+                p1 = torch.empty((nb1, 2, cout), device=dev)
+                dwo = torch.empty((27, cout), device=dev)
+                nby = _lib.query("tmf_c1_bwd_wgrad_workspace_bytes", a.B, s, s, s, cout)
+                ws1 = torch.empty((nby // 4,), device=dev)
+                f = {}
+                f["stats"] = timeit(lambda: _lib.call("tmf_c1_stats", xi.data_ptr(), wp1.data_ptr(), p1.data_ptr(),
+                                                      a.B, s, s, s, cout, st), a.reps)
+                f["fwd"] = timeit(lambda: _lib.call("tmf_c1_bn_pool_fwd", xi.data_ptr(), wp1.data_ptr(), sc.data_ptr(),
+                                                    sh.data_ptr(), out.data_ptr(), a.B, s, s, s, cout, 0.01, st), a.reps)
+                f["reduce"] = timeit(lambda: _lib.call("tmf_c1_bwd_reduce", xi.data_ptr(), wp1.data_ptr(), sc.data_ptr(),
+                                                       sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), out.data_ptr(),
+                                                       p1.data_ptr(), a.B, s, s, s, cout, 0.01, st), a.reps)
+                f["wgrad"] = timeit(lambda: _lib.call("tmf_c1_bwd_wgrad", xi.data_ptr(), wp1.data_ptr(), sc.data_ptr(),
+                                                      sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), coef.data_ptr(),
+                                                      out.data_ptr(), dwo.data_ptr(), ws1.data_ptr(), nby,
+                                                      a.B, s, s, s, cout, 0.01, st), a.reps)
+                r["fused_c1_ms"] = f
+                print(f"   fused conv1 block: stats {f['stats']:.3f} fwd {f['fwd']:.3f} reduce {f['reduce']:.3f} "
+                      f"wgrad {f['wgrad']:.3f}  sum {sum(f.values()):.3f} ms  (unfused sum "
+                      f"{r['fwd_ms'] + r['wgrad_ms'] + r['bn_fwd_ms'] + r['bn_red_ms'] + r['bn_app_ms']:.3f} ms)", flush=True)
             zb = z.numel() * 4 / 1e9
             r["fwd_tf"] = flops / r["fwd_ms"] / 1e9
             r["wgrad_tf"] = flops / r["wgrad_ms"] / 1e9

@@ -1,0 +1,318 @@
+// conv1_fused.hip — the first sNet block (Conv3d(1->C, 3x3x3) -> BatchNorm3d -> LeakyReLU -> MaxPool3d(2))
+// WITHOUT ever materialising the conv output in HBM.  gfx950.
+//
+// At B = 8, 96^3 the raw output z of this layer is 906 MB per stream and, stored, it is read or written six
+// times per training step (the layer is HBM-bound, AI = 13 flop/B).  The input is only 28 MB
+// and the 27-tap convolution costs 14 MFMAs per 32 voxels x 32 channels, so every pass RECOMPUTES z in
+// registers from an LDS halo brick instead:
+//   stats   : z -> per-workgroup sum / sum-of-squares partials                    (reads x)
+//   forward : z -> scale/shift -> LeakyReLU -> 2x2x2 max -> pooled output         (reads x, writes P)
+//   reduce  : z, dP -> dy (first-maximum routing, LeakyReLU mask) -> sum dy, sum dy*xhat partials
+//   wgrad   : z, dP -> dz = scale (dy - c0 - xhat c1) -> dw[tap][c] += x[voxel+tap] dz[voxel][c]  (MFMA)
+// z is bit-identical in all four (same instruction sequence), so the statistics, the forward activations and
+// the recomputed backward masks are mutually consistent.
+//
+// Fragment trick: the 32 voxels of an MFMA M-tile are a 2x4x4 block ordered so that the accumulator registers
+// of ONE lane hold two complete 2x2x2 pooling windows of one channel (row bits: w0,h0 | lane half = h1 | d0,w1):
+// pooling, its argmax and the BN algebra are per-lane register work, and in the wgrad pass the dz registers are
+// directly the MFMA B operand (k = lane half) — no LDS round trip, no shuffles.
+//
+// Replaces, for networks.py:21-26 (sNet.conv1): aten::conv3d, batch_norm, leaky_relu, max_pool3d and their
+// backward (weight gradient only: the network input needs no gradient, kfold_train_adversarial.py:106).
+#include "tmf_common.h"
+
+namespace {
+
+constexpr int TD = 4, TH = 8, TW = 8;
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+constexpr int NHALO = HD * HH * HW;
+
+enum { MODE_STATS = 0, MODE_FWD = 1, MODE_REDUCE = 2, MODE_WGRAD = 3 };
+
+__device__ __forceinline__ constexpr int tapoff(int tap) {
+    return tap >= 27 ? 0 : ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
+}
+// halo index (tap (0,0,0) corner) of M-tile t's origin, and of fragment row r (lane half 0) relative to it
+__device__ __forceinline__ constexpr int tile_org(int t) { return ((2 * (t >> 2)) * HH + 4 * ((t >> 1) & 1)) * HW + 4 * (t & 1); }
+__device__ __forceinline__ constexpr int row_off(int r) {   // r bits: b0 -> w0, b1 -> h0, b2 -> d0, b3 -> w1
+    return (((r >> 2) & 1) * HH + ((r >> 1) & 1)) * HW + 2 * ((r >> 3) & 1) + (r & 1);
+}
+
+struct Args {
+    const float* x;        // [B][D][H][W]
+    const float* w;        // [27][C]
+    const float* scale;    // [C]   (FWD, REDUCE, WGRAD)
+    const float* shift;
+    const float* mean;     // (REDUCE, WGRAD)
+    const float* invstd;
+    const float* coef;     // [2][C] (WGRAD)
+    const float* dpool;    // [B][D/2][H/2][W/2][C] (REDUCE, WGRAD)
+    float* pooled;         // (FWD)
+    float* partial;        // STATS/REDUCE: [nblk][2][C];  WGRAD: [nblk][27][C]
+    int D, H, W, C;
+    int tilesD, tilesH, tilesW, ntiles, tiles_per_block;
+    float slope;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
+    __shared__ float halo[NHALO];
+    __shared__ float red[4 * 32 * 32];      // cross-wave reduction scratch (16 KB)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int n0 = blockIdx.y * 32;
+    const int co = n0 + l31;
+    const bool cv = co < a.C;
+    const int OD = a.D / 2, OH = a.H / 2, OW = a.W / 2;
+
+    float bw[14];
+#pragma unroll
+    for (int s = 0; s < 14; ++s) {
+        const int tap = 2 * s + hsel;
+        bw[s] = (tap < 27 && cv) ? a.w[tap * a.C + co] : 0.f;
+    }
+    float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f, c0 = 0.f, c1 = 0.f;
+    if (MODE != MODE_STATS && cv) { sc = a.scale[co]; sh = a.shift[co]; }
+    if ((MODE == MODE_REDUCE || MODE == MODE_WGRAD) && cv) { mu = a.mean[co]; is = a.invstd[co]; }
+    if (MODE == MODE_WGRAD && cv) { c0 = a.coef[co]; c1 = a.coef[a.C + co]; }
+
+    float s1 = 0.f, s2 = 0.f;               // STATS: sum z, sum z^2;  REDUCE: sum dy, sum dy*xhat
+    f32x16 accw;                            // WGRAD: dw[tap = row][co = column]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+    const int a_tap = tapoff(l31);          // lanes >= 27 read tap 0's voxels; their rows are dropped
+
+    const int tile_begin = blockIdx.x * a.tiles_per_block;
+    int tile_end = tile_begin + a.tiles_per_block;
+    if (tile_end > a.ntiles) tile_end = a.ntiles;
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        int t = tile;
+        const int tw = t % a.tilesW; t /= a.tilesW;
+        const int th = t % a.tilesH; t /= a.tilesH;
+        const int td = t % a.tilesD;
+        const int b = t / a.tilesD;
+        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+        const float* xb = a.x + (size_t)b * a.D * a.H * a.W;
+        if (tile > tile_begin) __syncthreads();
+        for (int e = tid; e < NHALO; e += 256) {
+            const int hw = e % HW, hh = (e / HW) % HH, hd = e / (HW * HH);
+            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+            float v = 0.f;
+            if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
+                v = xb[(size_t)(gd * a.H + gh) * a.W + gw];
+            halo[e] = v;
+        }
+        __syncthreads();
+
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti) {
+            const int mt = wave * 2 + ti;                       // M-tile 0..7 of the brick (wave-uniform)
+            const int org = ((2 * (mt >> 2)) * HH + 4 * ((mt >> 1) & 1)) * HW + 4 * (mt & 1);
+            // ---- z = conv(x): A[i = voxel][k = tap], voxel i = lane & 31 in fragment-row order ----
+            const int i = l31;
+            const int a_vox = org + ((((i >> 3) & 1) * HH + 2 * ((i >> 2) & 1) + ((i >> 1) & 1)) * HW + 2 * ((i >> 4) & 1) + (i & 1));
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 14; ++s) {
+                const int off = hsel ? tapoff(2 * s + 1) : tapoff(2 * s);
+                z = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_vox + off], bw[s], z, 0, 0, 0);
+            }
+            // voxel coordinates of this lane's 16 rows: row r of lane half hsel
+            //   pd = 2*(mt>>2) + b2(r), ph = 4*((mt>>1)&1) + 2*hsel + b1(r), pw = 4*(mt&1) + 2*b3(r) + b0(r)
+            const int bd = d0 + 2 * (mt >> 2), bh = h0 + 4 * ((mt >> 1) & 1) + 2 * hsel, bwid = w0 + 4 * (mt & 1);
+
+            if (MODE == MODE_STATS) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gd = bd + ((r >> 2) & 1), gh = bh + ((r >> 1) & 1), gw = bwid + 2 * ((r >> 3) & 1) + (r & 1);
+                    if (gd < a.D && gh < a.H && gw < a.W) { s1 += z[r]; s2 += z[r] * z[r]; }
+                }
+                continue;
+            }
+
+            // ---- per pooling window q (= r >> 3): activation, first maximum ----
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int od = bd >> 1, oh = bh >> 1, ow = (bwid >> 1) + q;
+                const bool pooled = od < OD && oh < OH && ow < OW && cv;
+                float best = -INFINITY;
+                int arg = 0;
+                float lr[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {                   // k = 4*d0bit + 2*h0bit + w0bit: torch scan order
+                    const float y = z[8 * q + k] * sc + sh;
+                    const float act = y > 0.f ? y : y * a.slope;
+                    lr[k] = y > 0.f ? 1.f : a.slope;
+                    if (act > best) { best = act; arg = k; }
+                }
+                const size_t pidx = ((((size_t)b * OD + od) * OH + oh) * OW + ow) * a.C + co;
+                if (MODE == MODE_FWD) {
+                    if (pooled) a.pooled[pidx] = best;
+                    continue;
+                }
+                const float g = pooled ? a.dpool[pidx] : 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = 8 * q + k;
+                    const int gd = bd + ((r >> 2) & 1), gh = bh + ((r >> 1) & 1), gw = bwid + 2 * q + (r & 1);
+                    const bool vv = gd < a.D && gh < a.H && gw < a.W;
+                    const float dy = (k == arg) ? g * lr[k] : 0.f;
+                    const float xh = (z[r] - mu) * is;
+                    if (MODE == MODE_REDUCE) {
+                        if (vv) { s1 += dy; s2 += dy * xh; }
+                    } else {
+                        z[r] = (vv && cv) ? sc * (dy - c0 - xh * c1) : 0.f;        // dz, in place
+                    }
+                }
+            }
+            if (MODE == MODE_WGRAD) {
+                // dw[tap][co] += sum_voxel x[voxel + tap] * dz[voxel][co]:  A[i = tap][k = lane half], B = dz regs
+                const int a_row = org + hsel * 2 * HW + a_tap;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    accw = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_row + row_off(r)], z[r], accw, 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- workgroup reduction and partial slab ----
+    if (MODE == MODE_STATS || MODE == MODE_REDUCE) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        __syncthreads();
+        if (hsel == 0) { red[(wave * 32 + l31) * 2] = s1; red[(wave * 32 + l31) * 2 + 1] = s2; }
+        __syncthreads();
+        if (tid < 32 && n0 + tid < a.C) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { t1 += red[(m * 32 + tid) * 2]; t2 += red[(m * 32 + tid) * 2 + 1]; }
+            a.partial[((size_t)blockIdx.x * 2 + 0) * a.C + n0 + tid] = t1;
+            a.partial[((size_t)blockIdx.x * 2 + 1) * a.C + n0 + tid] = t2;
+        }
+    } else if (MODE == MODE_WGRAD) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int tap = (r & 3) + 8 * (r >> 2) + 4 * hsel;
+            red[(wave * 32 + tap) * 32 + l31] = accw[r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 27 * 32; e += 256) {
+            const int tap = e >> 5, c = e & 31;
+            if (n0 + c < a.C) {
+                const float v = red[(0 * 32 + tap) * 32 + c] + red[(1 * 32 + tap) * 32 + c] +
+                                red[(2 * 32 + tap) * 32 + c] + red[(3 * 32 + tap) * 32 + c];
+                a.partial[((size_t)blockIdx.x * 27 + tap) * a.C + n0 + c] = v;
+            }
+        }
+    }
+}
+
+struct Plan { int tilesD, tilesH, tilesW, ntiles, nby, tpb, nblk; };
+Plan make_plan(int B, int D, int H, int W, int C, int target_blocks) {
+    Plan p;
+    p.tilesD = tmf_cdiv(D, TD); p.tilesH = tmf_cdiv(H, TH); p.tilesW = tmf_cdiv(W, TW);
+    p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
+    p.nby = tmf_cdiv(C, 32);
+    int want = target_blocks / p.nby;
+    if (want < 1) want = 1;
+    if (want > p.ntiles) want = p.ntiles;
+    p.tpb = tmf_cdiv(p.ntiles, want);
+    p.nblk = tmf_cdiv(p.ntiles, p.tpb);
+    return p;
+}
+// STATS / REDUCE / WGRAD write one slab per workgroup: keep them few (8 per CU); FWD has no slab.
+constexpr int SLAB_BLOCKS = 2048;
+
+int check(const char* fn, int B, int D, int H, int W, int C) {
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, TMF_E_SHAPE, "%s: non-positive dimension", fn);
+    TMF_REQUIRE((long)D * H * W * C < (1L << 31), TMF_E_SHAPE, "%s: one sample exceeds 2^31 elements", fn);
+    return TMF_OK;
+}
+
+Args base_args(const float* x, const float* w, int D, int H, int W, int C, const Plan& p, float slope) {
+    Args a = {};
+    a.x = x; a.w = w; a.D = D; a.H = H; a.W = W; a.C = C;
+    a.tilesD = p.tilesD; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.ntiles = p.ntiles; a.tiles_per_block = p.tpb;
+    a.slope = slope;
+    return a;
+}
+
+}  // namespace
+
+extern "C" int tmf_c1_blocks(int B, int D, int H, int W, int C) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return make_plan(B, D, H, W, C, SLAB_BLOCKS).nblk;
+}
+
+extern "C" int tmf_c1_stats(const float* x, const float* w, float* stat_partial,
+                            int B, int D, int H, int W, int C, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(stat_partial);
+    int rc = check("tmf_c1_stats", B, D, H, W, C);
+    if (rc) return rc;
+    const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
+    Args a = base_args(x, w, D, H, W, C, p, 0.f);
+    a.partial = stat_partial;
+    hipLaunchKernelGGL(conv1_fused_kernel<MODE_STATS>, dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    return tmf_launch_result("tmf_c1_stats");
+}
+
+extern "C" int tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* scale, const float* shift,
+                                  float* pooled, int B, int D, int H, int W, int C, float slope, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(pooled);
+    int rc = check("tmf_c1_bn_pool_fwd", B, D, H, W, C);
+    if (rc) return rc;
+    const Plan p = make_plan(B, D, H, W, C, 1 << 30);     // one brick per workgroup
+    Args a = base_args(x, w, D, H, W, C, p, slope);
+    a.scale = scale; a.shift = shift; a.pooled = pooled;
+    hipLaunchKernelGGL(conv1_fused_kernel<MODE_FWD>, dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    return tmf_launch_result("tmf_c1_bn_pool_fwd");
+}
+
+extern "C" int tmf_c1_bwd_reduce(const float* x, const float* w, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, const float* dpool, float* partial,
+                                 int B, int D, int H, int W, int C, float slope, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift);
+    TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(invstd); TMF_REQUIRE_PTR(dpool); TMF_REQUIRE_PTR(partial);
+    int rc = check("tmf_c1_bwd_reduce", B, D, H, W, C);
+    if (rc) return rc;
+    const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
+    Args a = base_args(x, w, D, H, W, C, p, slope);
+    a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.dpool = dpool; a.partial = partial;
+    hipLaunchKernelGGL(conv1_fused_kernel<MODE_REDUCE>, dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    return tmf_launch_result("tmf_c1_bwd_reduce");
+}
+
+extern "C" size_t tmf_c1_bwd_wgrad_workspace_bytes(int B, int D, int H, int W, int C) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
+    return (size_t)(p.nblk + tmf_reduce_groups(p.nblk)) * 27 * C * 4;
+}
+
+extern "C" int tmf_c1_bwd_wgrad(const float* x, const float* w, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, const float* coef, const float* dpool,
+                                float* dw, void* workspace, size_t workspace_bytes,
+                                int B, int D, int H, int W, int C, float slope, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(mean);
+    TMF_REQUIRE_PTR(invstd); TMF_REQUIRE_PTR(coef); TMF_REQUIRE_PTR(dpool); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
+    int rc = check("tmf_c1_bwd_wgrad", B, D, H, W, C);
+    if (rc) return rc;
+    const size_t need = tmf_c1_bwd_wgrad_workspace_bytes(B, D, H, W, C);
+    TMF_REQUIRE(workspace_bytes >= need, TMF_E_WORKSPACE, "tmf_c1_bwd_wgrad: workspace %zu B < required %zu B",
+                workspace_bytes, need);
+    const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
+    Args a = base_args(x, w, D, H, W, C, p, slope);
+    a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.coef = coef; a.dpool = dpool;
+    a.partial = (float*)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(conv1_fused_kernel<MODE_WGRAD>, dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    if ((rc = tmf_launch_result("tmf_c1_bwd_wgrad"))) return rc;
+    const long n = 27L * C;
+    return tmf_reduce_slabs((const float*)workspace, p.nblk, n, (float*)workspace + (size_t)p.nblk * n, dw, s,
+                            "tmf_c1_bwd_wgrad(reduce)");
+}

@@ -169,8 +169,84 @@ class ConvBnActPool(torch.autograd.Function):
         return (dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
 
 
+class Conv1BnPool(torch.autograd.Function):
+    """First sNet block (Cin = 1, 3x3x3, max pool) with the conv output never written to HBM: the statistics,
+    forward, backward-reduce and weight-gradient passes each recompute it from the input volume."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+        x = _chk(x, "x")
+        B, D, H, W, _ = x.shape
+        C = weight.shape[0]
+        wp = pack_weight(_chk(weight, "weight")).view(27, C)
+        dev = x.device
+        mean = torch.empty(C, device=dev, dtype=_f32)
+        invstd = torch.empty(C, device=dev, dtype=_f32)
+        scale = torch.empty(C, device=dev, dtype=_f32)
+        shift = torch.empty(C, device=dev, dtype=_f32)
+        s = _stream()
+        if training:
+            nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
+            part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
+            _lib.call("tmf_c1_stats", x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
+            _lib.call("tmf_bn_finalize", part.data_ptr(), nblk, C, float(B * D * H * W),
+                      gamma.data_ptr(), beta.data_ptr(), _ptr(bias), _ptr(running_mean), _ptr(running_var),
+                      float(momentum), float(eps), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
+                      shift.data_ptr(), s)
+        else:
+            _lib.call("tmf_bn_eval_coeffs", gamma.data_ptr(), beta.data_ptr(), _ptr(bias), running_mean.data_ptr(),
+                      running_var.data_ptr(), float(eps), C, scale.data_ptr(), shift.data_ptr(), s)
+            invstd = torch.rsqrt(running_var + eps)
+            mean = running_mean - bias if bias is not None else running_mean.clone()
+        out = torch.empty((B, D // 2, H // 2, W // 2, C), device=dev, dtype=_f32)
+        if out.numel() > 0:
+            _lib.call("tmf_c1_bn_pool_fwd", x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                      out.data_ptr(), B, D, H, W, C, float(slope), s)
+        ctx.save_for_backward(x, wp, scale, shift, mean, invstd)
+        ctx.cfg = (training, float(slope), C, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wp, scale, shift, mean, invstd = ctx.saved_tensors
+        training, slope, C, has_bias = ctx.cfg
+        B, D, H, W, _ = x.shape
+        dev = x.device
+        s = _stream()
+        dout = _chk(dout, "grad_output")
+        nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
+        part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
+        _lib.call("tmf_c1_bwd_reduce", x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr(), dout.data_ptr(), part.data_ptr(), B, D, H, W, C, slope, s)
+        dgamma = torch.empty(C, device=dev, dtype=_f32)
+        dbeta = torch.empty(C, device=dev, dtype=_f32)
+        coef = torch.empty((2, C), device=dev, dtype=_f32)
+        _lib.call("tmf_bn_bwd_finalize", part.data_ptr(), nblk, C, float(B * D * H * W),
+                  dgamma.data_ptr(), dbeta.data_ptr(), coef.data_ptr(), s)
+        if training:
+            dbias = torch.zeros(C, device=dev, dtype=_f32) if has_bias else None
+        else:
+            coef.zero_()
+            dbias = scale * dbeta if has_bias else None
+        dweight = None
+        if ctx.needs_input_grad[1]:
+            nbytes = _lib.query("tmf_c1_bwd_wgrad_workspace_bytes", B, D, H, W, C)
+            ws = torch.empty((max(nbytes, 16) // 4,), device=dev, dtype=_f32)
+            dw = torch.empty((27, C), device=dev, dtype=_f32)
+            _lib.call("tmf_c1_bwd_wgrad", x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                      mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dout.data_ptr(), dw.data_ptr(),
+                      ws.data_ptr(), nbytes, B, D, H, W, C, slope, s)
+            dweight = unpack_wgrad(dw, C, 1, 3)
+        if ctx.needs_input_grad[0]:
+            raise _lib.TmfError("the fused first block has no data gradient (the network input needs none)")
+        return (None, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None)
+
+
 def conv_bn_act_pool(x, weight, bias, gamma, beta, running_mean, running_var, training,
                      momentum=0.1, eps=1e-5, slope=0.01, pool=None):
+    if (weight.shape[1] == 1 and weight.shape[2] == 3 and pool == "max" and not x.requires_grad):
+        return Conv1BnPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
+                                 training, momentum, eps, slope)
     return ConvBnActPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
                                training, momentum, eps, slope, pool)
 
