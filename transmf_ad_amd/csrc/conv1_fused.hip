@@ -88,6 +88,28 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
     int tile_end = tile_begin + a.tiles_per_block;
     if (tile_end > a.ntiles) tile_end = a.ntiles;
 
+    // halo brick: 600 scalars / 256 threads -> 3 registers per thread, fetched one brick ahead
+    constexpr int HVN = (NHALO + 255) / 256;
+    float hv[HVN];
+    auto fetch = [&](int tile) {
+        int t = tile;
+        const int tw = t % a.tilesW; t /= a.tilesW;
+        const int th = t % a.tilesH; t /= a.tilesH;
+        const int td = t % a.tilesD;
+        const int b = t / a.tilesD;
+        const float* xb = a.x + (size_t)b * a.D * a.H * a.W;
+#pragma unroll
+        for (int q = 0; q < HVN; ++q) {
+            const int e = tid + q * 256;
+            const int hw = e % HW, hh = (e / HW) % HH, hd = e / (HW * HH);
+            const int gd = td * TD + hd - 1, gh = th * TH + hh - 1, gw = tw * TW + hw - 1;
+            float v = 0.f;
+            if (e < NHALO && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
+                v = xb[(size_t)(gd * a.H + gh) * a.W + gw];
+            hv[q] = v;
+        }
+    };
+    if (tile_begin < tile_end) fetch(tile_begin);
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         int t = tile;
         const int tw = t % a.tilesW; t /= a.tilesW;
@@ -95,17 +117,14 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
         const int td = t % a.tilesD;
         const int b = t / a.tilesD;
         const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
-        const float* xb = a.x + (size_t)b * a.D * a.H * a.W;
         if (tile > tile_begin) __syncthreads();
-        for (int e = tid; e < NHALO; e += 256) {
-            const int hw = e % HW, hh = (e / HW) % HH, hd = e / (HW * HH);
-            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
-            float v = 0.f;
-            if (gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
-                v = xb[(size_t)(gd * a.H + gh) * a.W + gw];
-            halo[e] = v;
+#pragma unroll
+        for (int q = 0; q < HVN; ++q) {
+            const int e = tid + q * 256;
+            if (e < NHALO) halo[e] = hv[q];
         }
         __syncthreads();
+        if (tile + 1 < tile_end) fetch(tile + 1);
 
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
@@ -122,8 +141,8 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
                 const int off = hsel ? tapoff(2 * s + 1) : tapoff(2 * s);
                 z = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_vox + off], bw[s], z, 0, 0, 0);
             }
-            // voxel coordinates of this lane's 16 rows: row r of lane half hsel
-            //   pd = 2*(mt>>2) + b2(r), ph = 4*((mt>>1)&1) + 2*hsel + b1(r), pw = 4*(mt&1) + 2*b3(r) + b0(r)
+            // voxel coordinates of this lane's 16 rows (row r, lane half hsel), relative to the brick:
+            //   d = 2*(mt>>2) + r[2],  h = 4*((mt>>1)&1) + 2*hsel + r[1],  w = 4*(mt&1) + 2*r[3] + r[0]
             const int bd = d0 + 2 * (mt >> 2), bh = h0 + 4 * ((mt >> 1) & 1) + 2 * hsel, bwid = w0 + 4 * (mt & 1);
 
             if (MODE == MODE_STATS) {
@@ -267,7 +286,7 @@ extern "C" int tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* s
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(pooled);
     int rc = check("tmf_c1_bn_pool_fwd", B, D, H, W, C);
     if (rc) return rc;
-    const Plan p = make_plan(B, D, H, W, C, 1 << 30);     // one brick per workgroup
+    const Plan p = make_plan(B, D, H, W, C, 4 * SLAB_BLOCKS);     // a few bricks per workgroup (halo prefetch)
     Args a = base_args(x, w, D, H, W, C, p, slope);
     a.scale = scale; a.shift = shift; a.pooled = pooled;
     hipLaunchKernelGGL(conv1_fused_kernel<MODE_FWD>, dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);

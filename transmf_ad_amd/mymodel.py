@@ -24,6 +24,37 @@ def _init_like_reference(module: nn.Module) -> None:
             nn.init.constant_(m.bias, 0)
 
 
+def _two_streams(mri_fn, mri, pet_fn, pet):
+    """Run the two independent sNet encoders (mymodel.py:206-207) on two HIP streams of the same GPU.
+
+    The big convolutions of either encoder fill the chip on their own; what overlaps is everything that does
+    not: the deep 12^3 / 24^3 layers (1.7 workgroup rounds each), the finalize/reduce kernels, weight repacking.
+    Autograd replays each encoder's backward on the stream its forward ran on, so backward overlaps too.
+    TMF_STREAMS=1 disables it."""
+    import os
+    if os.environ.get("TMF_STREAMS", "2") == "1" or not mri.is_cuda:
+        return mri_fn(mri), pet_fn(pet)
+    cur = torch.cuda.current_stream(mri.device)
+    side = _side_stream(mri.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        pet_out = pet_fn(pet)
+    mri_out = mri_fn(mri)
+    cur.wait_stream(side)
+    pet_out.record_stream(cur)
+    return mri_out, pet_out
+
+
+_SIDE = {}
+
+
+def _side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
 def _tokens(emb):
     """'b d x y z -> b (x y z) d' (mymodel.py:218).  sNet returns a (B, C, d, h, w) VIEW of its
     channels-last buffer, so this is a reshape of strides only — no transpose kernel, no copy."""
@@ -64,8 +95,9 @@ class model_CNN_ad(nn.Module):
         _init_like_reference(self)
 
     def forward(self, mri, pet):
-        mri_feat = _tokens(self.mri_cnn(mri)).mean(dim=1)       # == AdaptiveAvgPool3d(1) + flatten
-        pet_feat = _tokens(self.pet_cnn(pet)).mean(dim=1)
+        mri_emb, pet_emb = _two_streams(self.mri_cnn, mri, self.pet_cnn, pet)
+        mri_feat = _tokens(mri_emb).mean(dim=1)                 # == AdaptiveAvgPool3d(1) + flatten
+        pet_feat = _tokens(pet_emb).mean(dim=1)
         D_MRI_logits = self.D(revgrad(mri_feat, 2.0))
         D_PET_logits = self.D(revgrad(pet_feat, 2.0))
         output_logits = self.fc_cls(torch.cat([mri_feat, pet_feat], dim=1))
@@ -87,8 +119,8 @@ class model_ad(nn.Module):
 
     def forward_features(self, mri, pet):
         """-> (cls (B, 4*dim), D_MRI_logits, D_PET_logits); everything ahead of fc_cls."""
-        mri_tok = _tokens(self.mri_cnn(mri))               # (B, V, dim)
-        pet_tok = _tokens(self.pet_cnn(pet))
+        mri_emb, pet_emb = _two_streams(self.mri_cnn, mri, self.pet_cnn, pet)
+        mri_tok, pet_tok = _tokens(mri_emb), _tokens(pet_emb)      # (B, V, dim)
         D_MRI_logits = self.D(revgrad(mri_tok.mean(dim=1), 2.0))
         D_PET_logits = self.D(revgrad(pet_tok.mean(dim=1), 2.0))
         return self.fuse_transformer(mri_tok, pet_tok), D_MRI_logits, D_PET_logits
