@@ -22,6 +22,7 @@
 //
 // Replaces aten::conv3d / convolution_backward at /root/reference/models/networks.py:
 // 22,28,31,37,40,46,49.
+#include <type_traits>
 #include "tmf_common.h"
 
 namespace {
@@ -297,6 +298,7 @@ template <int KS, int CINC> using CfgM64 = FwdCfg<KS, CINC, 1, 2, 4, 1, 4, 4, 8,
 
 // tuning knob (tmf_set_option("conv_waves", v) or TMF_CONV_WAVES): forward/dgrad workgroup shape for the large
 // layers: 4 = 4 waves, 1 workgroup per CU; 8 = 8 waves (two per SIMD); 2 = 4x4x8 bricks, two workgroups per CU
+int g_debug = 0;          // timing ablations only (tmf_set_option("debug", bits)); results are garbage when set
 int g_conv_waves = 0;
 int conv_waves() {
     if (g_conv_waves == 0) {
@@ -396,7 +398,7 @@ template <class C, bool VEC>
 __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
     const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
     int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles,
-    int tiles_per_split) {
+    int tiles_per_split, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xh = smem;                       // [NHALO][32]
     float* dzs = smem + C::NHALO * C::CI;   // [NPOS][NB]
@@ -506,6 +508,7 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
 
     if (tile_begin < tile_end) fetch_halo(tile_begin, 0, HVP);
     for (int tile = tile_begin; tile < tile_end; ++tile) {
+        if ((dbg & 1) && tile > tile_begin) goto compute;       // timing ablation: no staging after brick 0
         fetch_halo(tile, HVP, HV);
         fetch_dz(tile);    // short-lived registers: issued here, landed by the time the halo is written
         __syncthreads();   // previous brick fully consumed
@@ -522,26 +525,34 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
         __syncthreads();
         if (tile + 1 < tile_end) fetch_halo(tile + 1, 0, HVP);   // in flight during the whole compute phase
 
-        // K loop over voxel pairs: row = (pd, ph), pairs along w
-        for (int row = 0; row < C::TD * C::TH; ++row) {
-            const int rowoff = ((row / C::TH) * C::HH + (row % C::TH)) * C::HW * C::CI;
-            const float* bsrc = dzs + b_lane + row * C::TW * C::NB;
+    compute:
+        if (dbg & 2) continue;                                  // timing ablation: staging only
+        // K loop over voxel pairs: row = (pd, ph), pairs along w.  The tap count is a compile-time constant of
+        // the (wave-uniform) role, so the loop body is branch-free: all LDS reads of a voxel pair are issued
+        // before its MFMAs and the compiler pipelines them across pairs.
+        auto mma_bricks = [&](auto ntaps_c) {
+            constexpr int NTAPS = decltype(ntaps_c)::value;
+            for (int row = 0; row < C::TD * C::TH; ++row) {
+                const int rowoff = ((row / C::TH) * C::HH + (row % C::TH)) * C::HW * C::CI;
+                const float* bsrc = dzs + b_lane + row * C::TW * C::NB;
 #pragma unroll
-            for (int q = 0; q < C::TW / 2; ++q) {
-                float bv[C::NT];
+                for (int q = 0; q < C::TW / 2; ++q) {
+                    float bv[C::NT], av[NTAPS];
 #pragma unroll
-                for (int j = 0; j < C::NT; ++j) bv[j] = bsrc[2 * q * C::NB + j * 32];
+                    for (int j = 0; j < C::NT; ++j) bv[j] = bsrc[2 * q * C::NB + j * 32];
 #pragma unroll
-                for (int t = 0; t < C::TPW; ++t) {
-                    if (t < tap_cnt && tap_base + t < 27) {      // wave-uniform
-                        const float av = xh[tapoff[t] + rowoff + 2 * q * C::CI];
+                    for (int t = 0; t < NTAPS; ++t) av[t] = xh[tapoff[t] + rowoff + 2 * q * C::CI];
+#pragma unroll
+                    for (int t = 0; t < NTAPS; ++t)
 #pragma unroll
                         for (int j = 0; j < C::NT; ++j)
-                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[t][j], 0, 0, 0);
-                    }
+                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[j], acc[t][j], 0, 0, 0);
                 }
             }
-        }
+        };
+        if (C::NW == 4) mma_bricks(std::integral_constant<int, C::TPW>{});
+        else if (wave < 4) mma_bricks(std::integral_constant<int, 4>{});
+        else mma_bricks(std::integral_constant<int, 3>{});     // tap 27 (wave 7) is clamped: computed, not stored
     }
 
     // partial[split][tap][ci][co];  D fragment: row = ci, column = co
@@ -851,6 +862,7 @@ extern "C" int tmf_set_option(const char* name, int value) {
         g_conv_waves = value;
         return TMF_OK;
     }
+    if (strcmp(name, "debug") == 0) { g_debug = value; return TMF_OK; }
     tmf_set_error("tmf_set_option: unknown option '%s'", name);
     return TMF_E_ARG;
 }
@@ -910,7 +922,7 @@ extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void
         auto k = conv3d_wgrad_kernel<CFG, V>;                                                       \
         if ((rc = tmf_allow_lds(k, CFG::LDS_BYTES, "tmf_conv3d_wgrad"))) return rc;                 \
         hipLaunchKernelGGL(k, grid, dim3(CFG::NTHR), CFG::LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,   \
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);                          \
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps, g_debug);                 \
     } while (0)
         using L1 = WgCfg<1, 4, 8, 8>;
         using L2 = WgCfg<2, 4, 8, 8>;
