@@ -629,7 +629,10 @@ WgPlan plan_wgrad(int B, int D, int H, int W, int cin, int cout) {
     const int mind = D < H ? (D < W ? D : W) : (H < W ? H : W);
     p.small = !(mind >= 16 || (long)D * H * W >= 4096);
     const int td = 4, th = p.small ? 4 : 8, tw = p.small ? 4 : 8;
-    p.nt = cout <= 32 ? 1 : 2;
+    // 8-wave kernels: one 32-channel output tile per workgroup (64 accumulator registers) leaves room for the
+    // cross-brick halo prefetch; two tiles (128) spill.  Wider layers simply use more workgroup columns.
+    const bool w8 = (cin % 4 == 0) && (cout % 4 == 0) && conv_waves() == 8;
+    p.nt = (cout <= 32 || w8) ? 1 : 2;
     p.tilesD = tmf_cdiv(D, td); p.tilesH = tmf_cdiv(H, th); p.tilesW = tmf_cdiv(W, tw);
     p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
     p.gy = tmf_cdiv(cin, 32);
