@@ -17,3 +17,16 @@ for (cin, cout, s) in [(32, 64, 48), (32, 32, 48), (64, 64, 24), (128, 256, 12)]
         row.append(f"dbg{dbg}: {ms:.3f} ms ({fl / ms / 1e9:6.1f} TF)")
     _lib.call("tmf_set_option", b"debug", 0)
     print(f"wgrad {cin}->{cout} @{s}^3  " + " | ".join(row), flush=True)
+
+# forward / dgrad kernel: bits 2 = no MFMA loop, 4 = no output stores
+for (cin, cout, s_) in [(32, 64, 48), (32, 32, 48), (64, 32, 48), (64, 64, 24), (128, 256, 12)]:
+    x = torch.randn((8, s_, s_, s_, cin), device=dev)
+    w = torch.randn((27, cin, cout), device=dev) * 0.03
+    fl = 2.0 * 27 * cin * cout * 8 * s_ ** 3
+    row = []
+    for dbg in (0, 2, 4, 6):
+        _lib.call("tmf_set_option", b"debug", dbg)
+        ms = timeit(lambda: ops.conv3d_raw(x, w, cin, cout, 3, True), 10)
+        row.append(f"dbg{dbg}: {ms:.3f} ms ({fl / ms / 1e9:6.1f} TF)")
+    _lib.call("tmf_set_option", b"debug", 0)
+    print(f"fwd {cin}->{cout} @{s_}^3  " + " | ".join(row), flush=True)

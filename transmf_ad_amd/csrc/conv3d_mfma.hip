@@ -59,7 +59,7 @@ template <class C, bool VEC>
 __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
-    int tilesD, int tilesH, int tilesW, int ntiles) {
+    int tilesD, int tilesH, int tilesW, int ntiles, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;
     float* Bs = smem + C::NHALO * C::CP;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
             store_b(buf);
             __syncthreads();
             if (st + 1 < C::NSTAGES) load_b(st + 1);   // in flight while this stage computes
-            if (wave_active) {
+            if (wave_active && !(dbg & 2)) {
                 // halo offset of this stage's first tap
                 int stage_off;
                 if (C::KS == 1) stage_off = 0;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
                 const int co = n0 + (wn * C::NT + j) * 32 + l31;
                 if (pv && co < Cout) {
                     const float v = acc[i][j][r];
-                    dst[co] = v;
+                    if (!(dbg & 4)) dst[co] = v;
                     s1[j] += v;
                     s2[j] += v * v;
                 }
@@ -348,12 +348,12 @@ int launch_fwd_cfg(const FwdPlan& p, const float* x, const float* w, float* z, f
         auto k = conv3d_fwd_kernel<C, true>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug);
     } else {
         auto k = conv3d_fwd_kernel<C, false>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug);
     }
     return tmf_launch_result("tmf_conv3d_fwd");
 }
@@ -506,11 +506,15 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
         }
     };
 
-    if (tile_begin < tile_end) fetch_halo(tile_begin, 0, HVP);
+    constexpr bool DZ_AHEAD = C::NT == 1;      // 64 accumulator registers: room to carry the dz rows as well
+    if (tile_begin < tile_end) {
+        fetch_halo(tile_begin, 0, HVP);
+        if (DZ_AHEAD) fetch_dz(tile_begin);
+    }
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         if ((dbg & 1) && tile > tile_begin) goto compute;       // timing ablation: no staging after brick 0
         fetch_halo(tile, HVP, HV);
-        fetch_dz(tile);    // short-lived registers: issued here, landed by the time the halo is written
+        if (!DZ_AHEAD) fetch_dz(tile);   // short-lived registers: issued here, landed by the time the halo is written
         __syncthreads();   // previous brick fully consumed
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
@@ -523,7 +527,10 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
             if (e < C::NPOS * (C::NB / 4)) *reinterpret_cast<f32x4*>(&dzs[e * 4]) = dreg[q];
         }
         __syncthreads();
-        if (tile + 1 < tile_end) fetch_halo(tile + 1, 0, HVP);   // in flight during the whole compute phase
+        if (tile + 1 < tile_end) {                               // in flight during the whole compute phase
+            fetch_halo(tile + 1, 0, HVP);
+            if (DZ_AHEAD) fetch_dz(tile + 1);
+        }
 
     compute:
         if (dbg & 2) continue;                                  // timing ablation: staging only
