@@ -304,7 +304,7 @@ int conv_waves() {
     if (g_conv_waves == 0) {
         const char* e = getenv("TMF_CONV_WAVES");
         const int v = e ? atoi(e) : 0;
-        g_conv_waves = (v == 4 || v == 2) ? v : 8;
+        g_conv_waves = (v == 4 || v == 2 || v == 16) ? v : 8;
     }
     return g_conv_waves;
 }
@@ -327,7 +327,8 @@ FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks) {
         p.cfg = 2; nb = 128; td = 4; th = 4; tw = 4;
     }
     (void)ks;
-    if (p.cinc == 32 && conv_waves() == 8) p.cfg += 3;
+    if (p.cinc == 32 && conv_waves() == 16 && p.cfg < 2) { p.cfg += 8; p.cinc = 16; }
+    else if (p.cinc == 32 && conv_waves() >= 8) p.cfg += 3;
     else if (p.cinc == 32 && conv_waves() == 2) {
         if (p.cfg == 2) p.cfg = 5;
         else { p.cfg += 6; th = 4; }
@@ -369,6 +370,8 @@ int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float
     if (p.cfg == 3) { TMF_FWD_CASE(CfgL32w8, 32) }
     if (p.cfg == 4) { TMF_FWD_CASE(CfgL64w8, 32) }
     if (p.cfg == 5) { TMF_FWD_CASE(CfgS128w8, 32) }
+    if (p.cfg == 8) { TMF_FWD_CASE(CfgL32w8, 16) }     // 16-channel chunks: 77 KB of LDS -> two 8-wave workgroups per CU
+    if (p.cfg == 9) { TMF_FWD_CASE(CfgL64w8, 16) }
     if (p.cfg == 6) { TMF_FWD_CASE(CfgM32, 32) }
     if (p.cfg == 7) { TMF_FWD_CASE(CfgM64, 32) }
 #undef TMF_FWD_CASE
@@ -638,7 +641,7 @@ WgPlan plan_wgrad(int B, int D, int H, int W, int cin, int cout) {
     const int td = 4, th = p.small ? 4 : 8, tw = p.small ? 4 : 8;
     // 8-wave kernels: one 32-channel output tile per workgroup (64 accumulator registers) leaves room for the
     // cross-brick halo prefetch; two tiles (128) spill.  Wider layers simply use more workgroup columns.
-    const bool w8 = (cin % 4 == 0) && (cout % 4 == 0) && conv_waves() == 8;
+    const bool w8 = (cin % 4 == 0) && (cout % 4 == 0) && conv_waves() >= 8;
     p.nt = (cout <= 32 || w8) ? 1 : 2;
     p.tilesD = tmf_cdiv(D, td); p.tilesH = tmf_cdiv(H, th); p.tilesW = tmf_cdiv(W, tw);
     p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
@@ -867,8 +870,8 @@ C1Plan plan_c1(int B, int D, int H, int W, int cout) {
 extern "C" int tmf_set_option(const char* name, int value) {
     TMF_REQUIRE_PTR(name);
     if (strcmp(name, "conv_waves") == 0) {
-        TMF_REQUIRE(value == 4 || value == 8 || value == 2, TMF_E_ARG,
-                    "tmf_set_option: conv_waves must be 2, 4 or 8, got %d", value);
+        TMF_REQUIRE(value == 4 || value == 8 || value == 2 || value == 16, TMF_E_ARG,
+                    "tmf_set_option: conv_waves must be 2, 4, 8 or 16, got %d", value);
         g_conv_waves = value;
         return TMF_OK;
     }
@@ -942,7 +945,7 @@ extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void
         using L2w8 = WgCfg<2, 4, 8, 8, 8>;
         using S1w8 = WgCfg<1, 4, 4, 4, 8>;
         using S2w8 = WgCfg<2, 4, 4, 4, 8>;
-        const bool w8 = vec && conv_waves() == 8;
+        const bool w8 = vec && conv_waves() >= 8;
         if (w8) {
             if (!p.small && p.nt == 1) TMF_WG_LAUNCH(L1w8, true);
             else if (!p.small)         TMF_WG_LAUNCH(L2w8, true);
