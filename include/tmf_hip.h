@@ -43,8 +43,8 @@ extern "C" {
 
 int         tmf_version(void);                 /* ABI version, currently 1 */
 const char* tmf_last_error_string(void);
-/* Process-wide tuning knobs (never change results).  "conv_waves" = 4 | 8: wavefronts per
- * convolution workgroup (8 = two per SIMD, the default). */
+/* Process-wide tuning knobs (never change results).  "conv_waves" = 2 | 4 | 8 | 16: workgroup shape of the
+ * convolution kernels (16, the default: two 8-wave workgroups per CU).  "debug": timing ablations only. */
 int         tmf_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------
