@@ -26,6 +26,14 @@ import torch.distributed as dist
 from torch import nn
 
 
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
 class _Bucket:
     def __init__(self, params: List[nn.Parameter]):
         self.params = params
@@ -65,6 +73,7 @@ class GradAllReduce(nn.Module):
         self._buckets: List[_Bucket] = []
         self._where = {}
         self._callback_queued = False
+        self._streams = {}
         self.require_sync = True
         params = [p for p in module.parameters() if p.requires_grad]
         if broadcast_from_rank0 and self.world > 1:
@@ -97,6 +106,23 @@ class GradAllReduce(nn.Module):
         return [b.numel * b.flat.element_size() for b in self._buckets]
 
     # -- backward-time machinery -----------------------------------------------------------
+    # Gradients are produced on more than one HIP stream (the MRI and PET encoders run on two streams and
+    # autograd replays each backward on its forward stream).  All bucket traffic therefore goes through ONE
+    # staging stream per device: it waits for the producing stream, packs the gradient, and issues the
+    # collective; RCCL orders itself against that stream.
+    def _staging(self, device):
+        key = (device.type, device.index)
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(device=device)
+        return self._streams[key]
+
+    def _pack(self, b, i, p):
+        n = p.numel()
+        b.flat[b.offsets[i]:b.offsets[i] + n].copy_(p.grad.reshape(-1))
+
+    def _launch(self, b):
+        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def _on_grad(self, p: torch.Tensor):
         if not self.require_sync or self.world == 1:
             return
@@ -106,24 +132,42 @@ class GradAllReduce(nn.Module):
         b, i = self._where[p]
         if b.filled[i]:
             return
-        n = p.numel()
-        b.flat[b.offsets[i]:b.offsets[i] + n].copy_(p.grad.reshape(-1))
         b.filled[i] = True
         b.pending -= 1
-        if b.pending == 0:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if p.grad.is_cuda:
+            st = self._staging(p.device)
+            st.wait_stream(torch.cuda.current_stream(p.device))
+            with torch.cuda.stream(st):
+                self._pack(b, i, p)
+                p.grad.record_stream(st)
+                if b.pending == 0:
+                    self._launch(b)
+        else:
+            self._pack(b, i, p)
+            if b.pending == 0:
+                self._launch(b)
 
     def _finalize(self):
         self._callback_queued = False
+        dev = self._buckets[0].flat.device
+        cuda = dev.type == "cuda"
+        st = self._staging(dev) if cuda else None
+        ctx = torch.cuda.stream(st) if cuda else _NullCtx()
+        if cuda:
+            st.wait_stream(torch.cuda.current_stream(dev))
+        with ctx:
+            for b in self._buckets:
+                if b.work is None:        # some parameter got no gradient this pass: send zeros for it
+                    for i, p in enumerate(b.params):
+                        if not b.filled[i]:
+                            b.flat[b.offsets[i]:b.offsets[i] + p.numel()].zero_()
+                    self._launch(b)
+            for b in self._buckets:
+                b.work.wait()
+                b.flat.div_(self.world)
+        if cuda:
+            torch.cuda.current_stream(dev).wait_stream(st)
         for b in self._buckets:
-            if b.work is None:            # some parameter got no gradient this pass: send zeros for it
-                for i, p in enumerate(b.params):
-                    if not b.filled[i]:
-                        b.flat[b.offsets[i]:b.offsets[i] + p.numel()].zero_()
-                b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        for b in self._buckets:
-            b.work.wait()
-            b.flat.div_(self.world)
             for i, p in enumerate(b.params):
                 n = p.numel()
                 g = b.flat[b.offsets[i]:b.offsets[i] + n].view_as(p)
