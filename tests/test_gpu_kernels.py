@@ -299,3 +299,28 @@ def test_argument_errors_are_reported_not_launched():
     with pytest.raises(_lib.TmfError, match="dim_head"):
         _lib.call("tmf_xattn_fwd", x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
                   1, 1, 4, 4, 12, 12, 24, 1.0, None)
+
+
+def test_full_size_conv_properties():
+    """BASELINE-size layer (conv2.3: 8 x 48^3, 32 -> 64 channels) through size-independent properties, no oracle:
+    (i) exact homogeneity — scaling the input by a power of two scales every output bit-exactly;
+    (ii) adjointness — <dz, conv(x, w)> == <wgrad(x, dz), w> == <dgrad(dz, w), x> (the three kernels are mutually
+    consistent transposes of one bilinear map)."""
+    ops = _ops()
+    B, S, cin, cout = 8, 48, 32, 64
+    g = torch.Generator(device=DEV).manual_seed(7)
+    x = torch.randn((B, S, S, S, cin), device=DEV, generator=g)
+    dz = torch.randn((B, S, S, S, cout), device=DEV, generator=g)
+    w = torch.randn((cout, cin, 3, 3, 3), device=DEV, generator=g) * (27 * cin) ** -0.5
+    wp, wd = ops.pack_weight(w), ops.pack_weight_dgrad(w)
+    z, part, _ = ops.conv3d_raw(x, wp, cin, cout, 3, True)
+    z4, _, _ = ops.conv3d_raw(x * 4.0, wp, cin, cout, 3, False)
+    assert torch.equal(z4, z * 4.0)
+    assert torch.allclose(part[:, 0].double().sum(0), z.double().sum(dim=(0, 1, 2, 3)), rtol=1e-6, atol=1e-2)
+    dw = ops.unpack_wgrad(ops.conv3d_wgrad(x, dz, cin, cout, 3), cout, cin, 3)
+    dx, _, _ = ops.conv3d_raw(dz, wd, cout, cin, 3, False)
+    a = (dz.double() * z.double()).sum().item()
+    b = (dw.double() * w.double()).sum().item()
+    c = (dx.double() * x.double()).sum().item()
+    scale = (dz.double().abs() * z.double().abs()).sum().item()
+    assert abs(a - b) <= 1e-6 * scale and abs(a - c) <= 1e-6 * scale, (a, b, c, scale)

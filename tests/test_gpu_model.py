@@ -284,3 +284,52 @@ def test_full_size_properties_b8_96():
     # BN statistics property: the normalised pre-activation of conv1 has zero mean / unit variance
     s = net.mri_cnn
     assert int(s.conv1[1].num_batches_tracked.item()) == 1
+
+
+@pytest.mark.parametrize("which", ["model_CNN_ad", "model_single"])
+def test_config5_conv_only_models_b16_96(which):
+    """BASELINE config 5 (both readings): conv-only models at batch 16, 96^3 — shapes, finiteness,
+    run-to-run bitwise determinism, BatchNorm bookkeeping."""
+    import transmf_ad_amd as T
+    torch.manual_seed(0)
+    net = (T.model_CNN_ad(128) if which == "model_CNN_ad" else T.model_single(128)).to(DEV).train()
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.rand((16, 1, 96, 96, 96), device=DEV, generator=g)
+    y = (torch.arange(16, device=DEV) % 2).long()
+
+    def run():
+        net.zero_grad()
+        out = net(x, x.flip(0)) if which == "model_CNN_ad" else net(x)
+        lo = out[0] if isinstance(out, tuple) else out
+        nn.functional.cross_entropy(lo, y).backward()
+        torch.cuda.synchronize()
+        return lo.detach().clone(), [p.grad.clone() for p in net.parameters() if p.grad is not None]
+
+    lo1, g1 = run()
+    cnn = net.mri_cnn if which == "model_CNN_ad" else net.cnn
+    rm1 = cnn.conv1[1].running_mean.clone()
+    lo2, g2 = run()
+    assert lo1.shape == (16, 2) and torch.isfinite(lo1).all()
+    assert all(torch.isfinite(t).all() for t in g1)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))            # no atomics: bitwise reproducible
+    assert int(cnn.conv1[1].num_batches_tracked) == 2
+    assert not torch.equal(rm1, cnn.conv1[1].running_mean)            # momentum update happened again
+
+
+def test_128_cubed_tokens_512():
+    """BASELINE config 3 geometry in fp32: 128^3 volumes -> 8^3 = 512 tokens (the attention kernels' full LDS
+    super-block) — forward + backward finite, cls matches the oracle-free invariant mean(tokens) part."""
+    import transmf_ad_amd as T
+    torch.manual_seed(0)
+    net = T.model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to(DEV).train()
+    g = torch.Generator(device=DEV).manual_seed(6)
+    mri = torch.rand((2, 1, 128, 128, 128), device=DEV, generator=g)
+    pet = torch.rand((2, 1, 128, 128, 128), device=DEV, generator=g)
+    seen = {}
+    net.fuse_transformer.layers[2][1].register_forward_hook(lambda _m, i, o: seen.__setitem__("pet_in", i[0]))
+    net.fuse_transformer.register_forward_hook(lambda _m, i, o: seen.__setitem__("cls", o))
+    lo, dm, dp = net(mri, pet)
+    assert seen["pet_in"].shape == (2, 512, 128)
+    (lo.sum() + dm.sum() + dp.sum()).backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(lo).all() and all(torch.isfinite(p.grad).all() for p in net.parameters())

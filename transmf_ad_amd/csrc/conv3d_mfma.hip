@@ -650,7 +650,7 @@ WgPlan plan_wgrad(int B, int D, int H, int W, int cin, int cout) {
     p.gy = tmf_cdiv(cin, 32);
     p.gz = tmf_cdiv(cout, 32 * p.nt);
     const int groups = p.gy * p.gz;
-    int want = 512 / groups;             // ~2 workgroups per CU in total
+    int want = 256 / groups;             // one workgroup per CU in total: one round, half the partial slabs of two
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tps = tmf_cdiv(p.ntiles, want);
