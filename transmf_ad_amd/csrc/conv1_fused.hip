@@ -19,6 +19,7 @@
 //
 // Replaces, for networks.py:21-26 (sNet.conv1): aten::conv3d, batch_norm, leaky_relu, max_pool3d and their
 // backward (weight gradient only: the network input needs no gradient, kfold_train_adversarial.py:106).
+#include <type_traits>
 #include "tmf_common.h"
 
 namespace {
@@ -126,6 +127,8 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
         __syncthreads();
         if (tile + 1 < tile_end) fetch(tile + 1);
 
+        auto process = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;   // brick entirely inside the volume: no per-voxel checks
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int mt = wave * 2 + ti;                       // M-tile 0..7 of the brick (wave-uniform)
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int gd = bd + ((r >> 2) & 1), gh = bh + ((r >> 1) & 1), gw = bwid + 2 * ((r >> 3) & 1) + (r & 1);
-                    if (gd < a.D && gh < a.H && gw < a.W) { s1 += z[r]; s2 += z[r] * z[r]; }
+                    if (FULL || (gd < a.D && gh < a.H && gw < a.W)) { s1 += z[r]; s2 += z[r] * z[r]; }
                 }
                 continue;
             }
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int od = bd >> 1, oh = bh >> 1, ow = (bwid >> 1) + q;
-                const bool pooled = od < OD && oh < OH && ow < OW && cv;
+                const bool pooled = FULL ? cv : (od < OD && oh < OH && ow < OW && cv);
                 float best = -INFINITY;
                 int arg = 0;
                 float lr[8];
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
                 for (int k = 0; k < 8; ++k) {
                     const int r = 8 * q + k;
                     const int gd = bd + ((r >> 2) & 1), gh = bh + ((r >> 1) & 1), gw = bwid + 2 * q + (r & 1);
-                    const bool vv = gd < a.D && gh < a.H && gw < a.W;
+                    const bool vv = FULL || (gd < a.D && gh < a.H && gw < a.W);
                     const float dy = (k == arg) ? g * lr[k] : 0.f;
                     const float xh = (z[r] - mu) * is;
                     if (MODE == MODE_REDUCE) {
@@ -197,6 +200,11 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
                     accw = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_row + row_off(r)], z[r], accw, 0, 0, 0);
             }
         }
+        };
+        if (d0 + TD <= a.D && h0 + TH <= a.H && w0 + TW <= a.W && (a.D % 2 == 0) && (a.H % 2 == 0) && (a.W % 2 == 0))
+            process(std::true_type{});
+        else
+            process(std::false_type{});
     }
 
     // ---- workgroup reduction and partial slab ----

@@ -227,27 +227,34 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
 #pragma unroll
     for (int j = 0; j < C::NT; ++j) s1[j] = s2[j] = 0.f;
     float* zb = z + (size_t)b * D * H * W * Cout;
+    // 32-bit offsets inside the sample (checked < 2^31 on the host); a brick that lies inside the volume with a
+    // full channel tile takes the branch-free path (no per-voxel predicates around the stores)
+    auto epilogue = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-    for (int i = 0; i < C::MT; ++i) {
+        for (int i = 0; i < C::MT; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int p = (wm * C::MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-            const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
-            const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
-            const bool pv = gd < D && gh < H && gw < W;
-            float* dst = zb + ((size_t)(gd * H + gh) * W + gw) * Cout;
+            for (int r = 0; r < 16; ++r) {
+                const int p = (wm * C::MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
+                const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+                const bool pv = FULL || (gd < D && gh < H && gw < W);
+                const int off = ((gd * H + gh) * W + gw) * Cout;
 #pragma unroll
-            for (int j = 0; j < C::NT; ++j) {
-                const int co = n0 + (wn * C::NT + j) * 32 + l31;
-                if (pv && co < Cout) {
-                    const float v = acc[i][j][r];
-                    if (!(dbg & 4)) dst[co] = v;
-                    s1[j] += v;
-                    s2[j] += v * v;
+                for (int j = 0; j < C::NT; ++j) {
+                    const int co = n0 + (wn * C::NT + j) * 32 + l31;
+                    if (FULL || (pv && co < Cout)) {
+                        const float v = acc[i][j][r];
+                        if (!(dbg & 4)) zb[off + co] = v;
+                        s1[j] += v;
+                        s2[j] += v * v;
+                    }
                 }
             }
         }
-    }
+    };
+    if (d0 + C::TD <= D && h0 + C::TH <= H && w0 + C::TW <= W && n0 + C::NB <= Cout) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     if (stat_partial != nullptr) {
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) {
