@@ -129,21 +129,33 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
 
         auto process = [&](auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;   // brick entirely inside the volume: no per-voxel checks
+        // ---- z = conv(x) for BOTH M-tiles of this wave, interleaved (two independent MFMA chains) ----
+        //      A[i = voxel][k = tap], voxel i = lane & 31 in fragment-row order
+        f32x16 zt[2];
+        {
+            const int i = l31;
+            const int vox = (((i >> 3) & 1) * HH + 2 * ((i >> 2) & 1) + ((i >> 1) & 1)) * HW + 2 * ((i >> 4) & 1) + (i & 1);
+            int a_vox[2];
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti) {
+                const int mt = wave * 2 + ti;
+                a_vox[ti] = ((2 * (mt >> 2)) * HH + 4 * ((mt >> 1) & 1)) * HW + 4 * (mt & 1) + vox;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) zt[ti][r] = 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 14; ++s) {
+                const int off = hsel ? tapoff(2 * s + 1) : tapoff(2 * s);
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+                    zt[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_vox[ti] + off], bw[s], zt[ti], 0, 0, 0);
+            }
+        }
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti) {
             const int mt = wave * 2 + ti;                       // M-tile 0..7 of the brick (wave-uniform)
             const int org = ((2 * (mt >> 2)) * HH + 4 * ((mt >> 1) & 1)) * HW + 4 * (mt & 1);
-            // ---- z = conv(x): A[i = voxel][k = tap], voxel i = lane & 31 in fragment-row order ----
-            const int i = l31;
-            const int a_vox = org + ((((i >> 3) & 1) * HH + 2 * ((i >> 2) & 1) + ((i >> 1) & 1)) * HW + 2 * ((i >> 4) & 1) + (i & 1));
-            f32x16 z;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) z[r] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 14; ++s) {
-                const int off = hsel ? tapoff(2 * s + 1) : tapoff(2 * s);
-                z = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_vox + off], bw[s], z, 0, 0, 0);
-            }
+            f32x16& z = zt[ti];
             // voxel coordinates of this lane's 16 rows (row r, lane half hsel), relative to the brick:
             //   d = 2*(mt>>2) + r[2],  h = 4*((mt>>1)&1) + 2*hsel + r[1],  w = 4*(mt&1) + 2*r[3] + r[0]
             const int bd = d0 + 2 * (mt >> 2), bh = h0 + 4 * ((mt >> 1) & 1) + 2 * hsel, bwid = w0 + 4 * (mt & 1);
