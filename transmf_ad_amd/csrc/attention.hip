@@ -43,13 +43,33 @@ __device__ __forceinline__ void mma_cols(f32x16& acc, const float* lds, int row0
 }
 
 // Stage `nrows` rows (zero-filled past `limit`) of a [*, stride] matrix, columns [col0, col0+DH), into lds[(DH+1)].
+// 16-byte global loads, eight in flight per thread before the first LDS write (the whole K/V panel of a head is
+// two or three such batches: the staging is bandwidth- not latency-bound).  Needs stride % 4 == 0, col0 % 4 == 0.
 template <int DH>
 __device__ __forceinline__ void stage_rows(float* lds, const float* src, int stride, int col0, int first, int nrows,
                                            int limit, int tid, int nthreads) {
-    for (int e = tid; e < nrows * DH; e += nthreads) {
-        const int r = e / DH, d = e % DH;
-        const int g = first + r;
-        lds[r * (DH + 1) + d] = g < limit ? src[(size_t)g * stride + col0 + d] : 0.f;
+    constexpr int Q = DH / 4;                 // float4 per row
+    constexpr int BATCH = 8;
+    const int total = nrows * Q;
+    for (int base = 0; base < total; base += nthreads * BATCH) {
+        f32x4 v[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = base + u * nthreads + tid;
+            const int r = e / Q, c = (e % Q) * 4;
+            const int g = first + r;
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (e < total && g < limit) t = *reinterpret_cast<const f32x4*>(src + (size_t)g * stride + col0 + c);
+            v[u] = t;
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = base + u * nthreads + tid;
+            if (e < total) {
+                float* d = lds + (e / Q) * (DH + 1) + (e % Q) * 4;
+                d[0] = v[u][0]; d[1] = v[u][1]; d[2] = v[u][2]; d[3] = v[u][3];
+            }
+        }
     }
 }
 
@@ -289,7 +309,13 @@ __global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(
             float dl = 0.f, ls = 0.f;
             if (g < N) {
                 ls = lse[((size_t)b * heads + h) * N + g];
-                for (int d = 0; d < DH; ++d) dl += dob[(size_t)g * inner + h * DH + d] * ob[(size_t)g * inner + h * DH + d];
+                const f32x4* pa = reinterpret_cast<const f32x4*>(dob + (size_t)g * inner + h * DH);
+                const f32x4* pb = reinterpret_cast<const f32x4*>(ob + (size_t)g * inner + h * DH);
+#pragma unroll
+                for (int d = 0; d < DH / 4; ++d) {
+                    const f32x4 u = pa[d], w4 = pb[d];
+                    dl += u[0] * w4[0] + u[1] * w4[1] + u[2] * w4[2] + u[3] * w4[3];
+                }
             }
             lses[r] = ls;
             dels[r] = dl;
@@ -349,6 +375,7 @@ int check_attn(const char* fn, int B, int heads, int N, int M, int dh, int q_str
     TMF_REQUIRE(dh == 8 || dh == 16 || dh == 32 || dh == 64, TMF_E_SHAPE, "%s: dim_head %d not in {8,16,32,64}", fn, dh);
     TMF_REQUIRE(q_stride >= heads * dh && kv_stride >= heads * dh, TMF_E_SHAPE, "%s: row stride smaller than heads*dh", fn);
     TMF_REQUIRE(heads <= 65535 && B <= 65535, TMF_E_SHAPE, "%s: grid dimension overflow", fn);
+    TMF_REQUIRE(q_stride % 4 == 0 && kv_stride % 4 == 0, TMF_E_SHAPE, "%s: row strides must be multiples of 4 floats", fn);
     return TMF_OK;
 }
 
@@ -368,7 +395,7 @@ extern "C" int tmf_xattn_fwd(const float* q, const float* k, const float* v, flo
     TMF_REQUIRE_PTR(q); TMF_REQUIRE_PTR(k); TMF_REQUIRE_PTR(v); TMF_REQUIRE_PTR(out); TMF_REQUIRE_PTR(lse);
     int rc = check_attn("tmf_xattn_fwd", B, heads, N, M, dh, q_stride, kv_stride);
     if (rc) return rc;
-    TMF_REQUIRE_ALIGNED(out);
+    TMF_REQUIRE_ALIGNED(out); TMF_REQUIRE_ALIGNED(q); TMF_REQUIRE_ALIGNED(k); TMF_REQUIRE_ALIGNED(v);
     TMF_REQUIRE((heads * dh) % 4 == 0, TMF_E_SHAPE, "tmf_xattn_fwd: heads*dh must be a multiple of 4");
     const int sb = resident_rows(M, dh);
     const size_t lds = lds_two(sb, dh);
