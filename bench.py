@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2, help="pairs in the bounded CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--eager", action="store_true", help="do not capture the step in a hipGraph")
     args = ap.parse_args()
 
     from transmf_ad_amd import model_ad, ops, _lib
@@ -69,7 +70,7 @@ def main():
     net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to(dev)
     if world > 1:
         net = GradAllReduce(net)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=not args.eager and world == 1)
     crit = nn.CrossEntropyLoss()
     B, S = args.batch, args.size
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -87,6 +88,26 @@ def main():
         loss.backward()
         opt.step()
         return loss
+
+    mode = "eager"
+    if not args.eager:
+        # same kernels, same order, same numerics — replayed from a hipGraph instead of re-dispatched by Python
+        try:
+            from transmf_ad_amd.graphs import GraphedTrainStep
+
+            def loss_fn(out, lab):
+                lo, dm, dp = out
+                return (crit(dm, ones) + crit(dp, zeros)) / 2 + crit(lo, lab)
+
+            graphed = GraphedTrainStep(net, opt, loss_fn, (mri, pet, label))
+            eager_step = step
+
+            def step():                      # noqa: F811
+                return graphed(mri, pet, label)
+            mode = "hipgraph"
+        except Exception as e:               # capture unsupported: fall back to the eager step, and say so
+            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4)
 
     def fence():
         if world > 1:
@@ -163,7 +184,7 @@ def main():
             "config": {"workload": f"model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512) train step, "
                                    f"batch {B} pairs of 1x{S}^3 per GPU, fp32 (BASELINE configs[1])",
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "step": "zero_grad+fwd+loss+bwd+allreduce+Adam"},
+                       "step": "zero_grad+fwd+loss+bwd+allreduce+Adam", "dispatch": mode},
             "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
             "loss": round(final_loss, 6),
             "roofline": roof, "cpu_baseline": cpu,

@@ -333,3 +333,42 @@ def test_128_cubed_tokens_512():
     (lo.sum() + dm.sum() + dp.sum()).backward()
     torch.cuda.synchronize()
     assert torch.isfinite(lo).all() and all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_hipgraph_step_equals_eager_step():
+    """GraphedTrainStep replays exactly the eager train step: after two steps the loss and every parameter are
+    bitwise equal to two eager steps from the same start."""
+    from transmf_ad_amd.graphs import GraphedTrainStep
+    g = Golden("ad_tiny")
+    mri, pet, y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+    crit = nn.CrossEntropyLoss()
+
+    def loss_fn(out, lab):
+        lo, dm, dp = out
+        return (crit(dm, torch.ones_like(lab)) + crit(dp, torch.zeros_like(lab))) / 2 + crit(lo, lab)
+
+    nets, losses = [], []
+    for graphed in (False, True):
+        net = build(g).train()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
+        if graphed:
+            sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+            stepper = GraphedTrainStep(net, opt, loss_fn, (mri, pet, y), warmup=1)
+            net.load_state_dict(sd0)                       # undo the warm-up updates (weights and BN buffers)
+            opt.state.clear()
+            ls = [stepper(mri, pet, y).item() for _ in range(2)]
+        else:
+            ls = []
+            for _ in range(2):
+                opt.zero_grad()
+                loss = loss_fn(net(mri, pet), y)
+                loss.backward()
+                opt.step()
+                ls.append(loss.item())
+        nets.append(net)
+        losses.append(ls)
+    assert losses[0] == losses[1], losses
+    for (k, a), (_, b) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
+        if k.endswith("num_batches_tracked"):
+            continue
+        assert torch.equal(a, b), k

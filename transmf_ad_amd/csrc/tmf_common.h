@@ -49,12 +49,19 @@ static inline int tmf_launch_result(const char* what) {
 // Opt a kernel into > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU).
 template <typename K>
 static inline int tmf_allow_lds(K kernel, size_t bytes, const char* what) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    // once per kernel instantiation and size (K is a distinct function-pointer VALUE per call site, so key on it)
+    static thread_local const void* last_fn[8] = {};
+    static thread_local size_t last_sz[8] = {};
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    const unsigned slot = (unsigned)((reinterpret_cast<uintptr_t>(fn) >> 4) & 7u);
+    if (last_fn[slot] == fn && last_sz[slot] >= bytes) return TMF_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
         tmf_set_error("%s: cannot reserve %zu B of LDS: %s", what, bytes, hipGetErrorString(e));
         return (int)e;
     }
+    last_fn[slot] = fn;
+    last_sz[slot] = bytes;
     return TMF_OK;
 }
 

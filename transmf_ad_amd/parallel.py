@@ -177,6 +177,30 @@ class GradAllReduce(nn.Module):
                     p.grad.copy_(g)
             b.reset()
 
+    def reduce_gradients(self):
+        """Synchronous form (no overlap): all-reduce every bucket from the gradients currently in ``.grad``.
+        Used after a hipGraph replay of forward+backward, where the autograd hooks do not run."""
+        if self.world == 1:
+            return
+        for b in self._buckets:
+            for i, p in enumerate(b.params):
+                n = p.numel()
+                if p.grad is None:
+                    b.flat[b.offsets[i]:b.offsets[i] + n].zero_()
+                else:
+                    b.flat[b.offsets[i]:b.offsets[i] + n].copy_(p.grad.reshape(-1))
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        for b in self._buckets:
+            b.work.wait()
+            b.flat.div_(self.world)
+            for i, p in enumerate(b.params):
+                g = b.flat[b.offsets[i]:b.offsets[i] + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+            b.reset()
+
     # -- nn.Module surface -------------------------------------------------------------------
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
