@@ -355,7 +355,10 @@ def test_hipgraph_step_equals_eager_step():
             sd0 = {k: v.clone() for k, v in net.state_dict().items()}
             stepper = GraphedTrainStep(net, opt, loss_fn, (mri, pet, y), warmup=1)
             net.load_state_dict(sd0)                       # undo the warm-up updates (weights and BN buffers)
-            opt.state.clear()
+            for st in opt.state.values():                  # ... and Adam's moments / step counters, IN PLACE: the
+                for v in st.values():                      # graph holds pointers to these tensors
+                    if torch.is_tensor(v):
+                        v.zero_()
             ls = [stepper(mri, pet, y).item() for _ in range(2)]
         else:
             ls = []
