@@ -70,6 +70,14 @@ size_t tmf_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int cin, int
 int    tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
                         int B, int D, int H, int W, int cin, int cout, int ksize, void* stream);
 
+/* bf16 matrix-core variant (BASELINE configs[2]: "bf16 with MFMA 3D conv"), 3x3x3 only: fp32 tensors in HBM,
+ * operands rounded to bf16 (RNE) on the way into LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32
+ * output and statistics.  w_bf16: bf16 [27][cout][cin] (cin contiguous); cin % 8 == 0.  The data gradient is the
+ * same entry on dz with w'[26-t][ci][co] = w[t][co][ci].  stat_partial: [tmf_conv3d_bf16_stat_blocks()][2][cout]. */
+int  tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z, float* stat_partial,
+                         int B, int D, int H, int W, int cin, int cout, void* stream);
+int  tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W);
+
 /* First layer, cin == 1 (networks.py:22): x[b][d][h][w], w[27][cout]. */
 int    tmf_conv3d_c1_fwd(const float* x, const float* w, float* z, float* stat_partial,
                          int B, int D, int H, int W, int cout, void* stream);

@@ -324,3 +324,69 @@ def test_full_size_conv_properties():
     c = (dx.double() * x.double()).sum().item()
     scale = (dz.double().abs() * z.double().abs()).sum().item()
     assert abs(a - b) <= 1e-6 * scale and abs(a - c) <= 1e-6 * scale, (a, b, c, scale)
+
+
+BF16_SHAPES = [
+    # B, D, H, W, cin, cout
+    (2, 8, 8, 8, 8, 16),
+    (1, 5, 7, 9, 16, 32),          # ragged bricks
+    (2, 16, 16, 16, 32, 64),
+    (1, 12, 12, 12, 128, 256),     # 4 channel chunks, 4 output blocks
+    (1, 9, 8, 11, 40, 72),         # partial last chunk, partial output tile
+    (2, 24, 24, 24, 64, 32),
+]
+
+
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+def test_conv3d_bf16_mfma(shape):
+    """bf16 matrix-core convolution: with inputs and weights that ARE bf16 numbers the products are exact in fp32, so
+    the kernel must match an fp64 reference to fp32-accumulation accuracy (2e-6); with general fp32 inputs the
+    error is the bf16 rounding of the operands (<= 2^-8 each) — bounded at 1e-2 of max, typically 2e-3."""
+    ops = _ops()
+    B, D, H, W, cin, cout = shape
+    x = _rand(B, cin, D, H, W, seed=61)
+    w = _rand(cout, cin, 3, 3, 3, seed=62, scale=(cin * 27) ** -0.5)
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv3d(xb.double(), wb.double(), padding=1)
+    z, part, nblk = ops.conv3d_bf16_raw(_ndhwc(xb).to(DEV), ops.pack_weight_bf16(wb.to(DEV)), cin, cout, True)
+    torch.cuda.synchronize()
+    assert _relerr(_ncdhw(z.cpu()), ref) < 2e-6
+    s = part.double().sum(0).cpu()
+    r = ref.permute(1, 0, 2, 3, 4).reshape(cout, -1)
+    assert (s[0] - r.sum(1)).abs().max() <= 1e-4 * max(1.0, r.abs().sum(1).max().item())
+    assert (s[1] - (r * r).sum(1)).abs().max() <= 1e-5 * (r * r).sum(1).max().item()
+    # general fp32 operands: rounding happens inside the kernel (activations) / in pack_weight_bf16 (weights)
+    z2, _, _ = ops.conv3d_bf16_raw(_ndhwc(x).to(DEV), ops.pack_weight_bf16(w.to(DEV)), cin, cout, False)
+    assert torch.equal(z2, z)                      # in-kernel RNE == torch's .bfloat16()
+    assert _relerr(_ncdhw(z2.cpu()), F.conv3d(x.double(), w.double(), padding=1)) < 1e-2
+    # data gradient through the same kernel
+    if cout % 8 == 0:
+        dz = _rand(B, cout, D, H, W, seed=63).bfloat16().float()
+        xr = xb.double().requires_grad_(True)
+        F.conv3d(xr, wb.double(), padding=1).backward(dz.double())
+        dx, _, _ = ops.conv3d_bf16_raw(_ndhwc(dz).to(DEV), ops.pack_weight_dgrad_bf16(wb.to(DEV)), cout, cin, False)
+        assert _relerr(_ncdhw(dx.cpu()), xr.grad) < 2e-6
+
+
+def test_block_in_bf16_mode():
+    """A full sNet block with the bf16 conv precision: forward and gradients within bf16-operand accuracy of fp64."""
+    ops = _ops()
+    B, D, H, W, cin, cout, k, pool = 2, 16, 16, 16, 32, 64, 3, "max"
+    x = _rand(B, cin, D, H, W, seed=11)
+    w = _rand(cout, cin, k, k, k, seed=12, scale=(cin * k ** 3) ** -0.5)
+    b, g, be = _rand(cout, seed=13, scale=0.1), 1 + _rand(cout, seed=14, scale=0.1), _rand(cout, seed=15, scale=0.1)
+    rm, rv = _rand(cout, seed=16, scale=0.1), 1 + _rand(cout, seed=17, scale=0.1).abs()
+    xr, P, _rm, _rv, yr = _block_ref(x, w, b, g, be, rm, rv, True, pool, torch.float64)
+    go = _rand(*yr.shape, seed=18)
+    yr.backward(go.double())
+    ops.set_conv_precision("bf16")
+    try:
+        xg = _ndhwc(x).to(DEV).requires_grad_(True)
+        Pg = [t.clone().to(DEV).requires_grad_(True) for t in (w, b, g, be)]
+        yg = ops.conv_bn_act_pool(xg, Pg[0], Pg[1], Pg[2], Pg[3], rm.clone().to(DEV), rv.clone().to(DEV), True, pool=pool)
+        yg.backward(_ndhwc(go).to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_precision("fp32")
+    assert _relerr(_ncdhw(yg.detach().cpu()), yr.detach()) < 2e-2
+    assert _relerr(Pg[0].grad, P[0].grad) < 2e-2 and _relerr(_ncdhw(xg.grad.cpu()), xr.grad) < 2e-2

@@ -1,0 +1,244 @@
+// conv3d_bf16.hip — 3x3x3 convolution on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16, 2.5 PF dense) with
+// fp32 tensors in HBM and fp32 accumulation: the "bf16 with MFMA 3D conv" mode of BASELINE.json configs[2].
+//
+// Same brick / halo / weight-ring structure as conv3d_mfma.hip; what changes is the operand path:
+//   * activations are read as fp32, rounded to bf16 (RNE) ONCE while the halo is staged in LDS (80-B rows of
+//     32 channels), weights arrive pre-packed as bf16 [tap][cout][cin] (cin contiguous);
+//   * one ds_read_b128 per operand fragment: the 32x32x16 MFMA takes 8 consecutive k (= input channels) per
+//     lane, which is exactly the channels-last row;
+//   * a wave owns 64 voxels x 64 channels (2x2 tiles): 8 fragment reads feed 8 MFMAs per tap;
+//   * accumulators, BatchNorm statistic partials and the stored output stay fp32.
+// At 1/16 of the fp32 MFMA time the kernel is bound by halo staging and the fp32 output stream, not by the
+// matrix pipe.
+//
+// Forward and data-gradient (flipped / transposed weights) of networks.py:28,31,37,40,46.
+#include <type_traits>
+#include "tmf_common.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {     // round-to-nearest-even, a -> low half
+    unsigned int ua = __builtin_bit_cast(unsigned int, a), ub = __builtin_bit_cast(unsigned int, b);
+    ua += 0x7FFFu + ((ua >> 16) & 1u);
+    ub += 0x7FFFu + ((ub >> 16) & 1u);
+    return (ua >> 16) | (ub & 0xFFFF0000u);
+}
+
+constexpr int TD = 4, TH = 8, TW = 8;                 // brick: 256 voxels = 4 waves x 2 M-tiles
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+constexpr int NHALO = HD * HH * HW;
+constexpr int CINC = 32;                              // input channels per chunk
+constexpr int RP = 40;                                // LDS row pitch in bf16 (80 B: 16-B aligned, odd multiple of 16 B)
+constexpr int NB = 64;                                // output channels per workgroup
+constexpr int TPS = 3;                                // taps per weight stage
+constexpr int NSTAGES = 9;
+constexpr int WSTAGE = TPS * NB * RP;                 // bf16 elements per weight stage
+constexpr size_t LDS_BYTES = (size_t)(NHALO * RP + 2 * WSTAGE) * 2 + 4 * 64 * 2 * 4;
+
+__global__ __launch_bounds__(256) void conv3d_fwd_bf16_kernel(
+    const float* __restrict__ x, const u16* __restrict__ w, float* __restrict__ z,
+    float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
+    int tilesD, int tilesH, int tilesW, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* halo = reinterpret_cast<u16*>(smem_raw);
+    u16* Ws = halo + NHALO * RP;
+    float* red = reinterpret_cast<float*>(Ws + 2 * WSTAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+
+    const int tile = xcd_contiguous(blockIdx.x, ntiles);
+    int t = tile;
+    const int tw = t % tilesW; t /= tilesW;
+    const int th = t % tilesH; t /= tilesH;
+    const int td = t % tilesD;
+    const int b = t / tilesD;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+    const int n0 = blockIdx.y * NB;
+
+    // LDS element offsets (bf16 units) of this lane's fragments
+    int a_lane[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = (wave * 2 + i) * 32 + l31;
+        const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+        a_lane[i] = ((pd * HH + ph) * HW + pw) * RP + hsel * 8;
+    }
+    const int b_lane = l31 * RP + hsel * 8;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const float* xb = x + (size_t)b * D * H * W * Cin;
+
+    for (int c0 = 0; c0 < Cin; c0 += CINC) {
+        if (c0 > 0) __syncthreads();
+        // ---- halo: fp32 from HBM, rounded to bf16 on the way into LDS (all loads issued first) ----
+        constexpr int HV = (NHALO * 8 + 255) / 256;
+        f32x4 hreg[HV];
+#pragma unroll
+        for (int q = 0; q < HV; ++q) {
+            const int e = tid + q * 256;
+            const int hp = e >> 3, c4 = e & 7;
+            const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
+            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+            const int c = c0 + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < NHALO * 8 && c < Cin && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c);
+            hreg[q] = v;
+        }
+        // ---- weight stage loader: [tap][co][ci] bf16, one 16-B piece = 8 input channels of one output channel ----
+        constexpr int WV = (TPS * NB * 4 + 255) / 256;         // 4 pieces per (tap, co) row of 32 channels
+        u32x4 wreg[WV];
+        auto load_w = [&](int st) {
+#pragma unroll
+            for (int q = 0; q < WV; ++q) {
+                const int e = tid + q * 256;
+                const int row = e >> 2, piece = e & 3;             // row = tap_in_stage * NB + co
+                const int tap = st * TPS + row / NB, co = n0 + row % NB, ci = c0 + piece * 8;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (e < TPS * NB * 4 && co < Cout && ci < Cin)
+                    v = *reinterpret_cast<const u32x4*>(w + ((size_t)tap * Cout + co) * Cin + ci);
+                wreg[q] = v;
+            }
+        };
+        auto store_w = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < WV; ++q) {
+                const int e = tid + q * 256;
+                if (e < TPS * NB * 4)
+                    *reinterpret_cast<u32x4*>(Ws + buf * WSTAGE + (e >> 2) * RP + (e & 3) * 8) = wreg[q];
+            }
+        };
+        load_w(0);
+#pragma unroll
+        for (int q = 0; q < HV; ++q) {
+            const int e = tid + q * 256;
+            if (e < NHALO * 8) {
+                u32x2 pk = {pack_bf16(hreg[q][0], hreg[q][1]), pack_bf16(hreg[q][2], hreg[q][3])};
+                *reinterpret_cast<u32x2*>(halo + (e >> 3) * RP + (e & 7) * 4) = pk;
+            }
+        }
+        for (int st = 0; st < NSTAGES; ++st) {
+            const int buf = st & 1;
+            store_w(buf);
+            __syncthreads();
+            if (st + 1 < NSTAGES) load_w(st + 1);
+            const int stage_off = ((st / 3) * HH + (st % 3)) * HW * RP;
+            const u16* ws = Ws + buf * WSTAGE + b_lane;
+#pragma unroll
+            for (int tp = 0; tp < TPS; ++tp) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {                      // two k-blocks of 16 channels
+                    bf16x8 a[2], bb[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        a[i] = *reinterpret_cast<const bf16x8*>(halo + a_lane[i] + stage_off + tp * RP + s * 16);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        bb[j] = *reinterpret_cast<const bf16x8*>(ws + (tp * NB + j * 32) * RP + s * 16);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: fp32 NDHWC store + BatchNorm statistic partials (same as the fp32 kernel) ----
+    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float* zb = z + (size_t)b * D * H * W * Cout;
+    auto epilogue = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p = (wave * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+                const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+                const bool pv = FULL || (gd < D && gh < H && gw < W);
+                const int off = ((gd * H + gh) * W + gw) * Cout;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int co = n0 + j * 32 + l31;
+                    if (FULL || (pv && co < Cout)) {
+                        const float v = acc[i][j][r];
+                        zb[off + co] = v;
+                        s1[j] += v;
+                        s2[j] += v * v;
+                    }
+                }
+            }
+        }
+    };
+    if (d0 + TD <= D && h0 + TH <= H && w0 + TW <= W && n0 + NB <= Cout) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+
+    if (stat_partial != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+        }
+        if (hsel == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                red[(wave * 64 + j * 32 + l31) * 2 + 0] = s1[j];
+                red[(wave * 64 + j * 32 + l31) * 2 + 1] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) { a1 += red[(m * 64 + tid) * 2]; a2 += red[(m * 64 + tid) * 2 + 1]; }
+            const int co = n0 + tid;
+            if (co < Cout) {
+                stat_partial[((size_t)tile * 2 + 0) * Cout + co] = a1;
+                stat_partial[((size_t)tile * 2 + 1) * Cout + co] = a2;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
+}
+
+extern "C" int tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z, float* stat_partial,
+                                   int B, int D, int H, int W, int cin, int cout, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w_bf16); TMF_REQUIRE_PTR(z);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
+                "tmf_conv3d_fwd_bf16: non-positive dimension");
+    TMF_REQUIRE(cin % 8 == 0, TMF_E_SHAPE, "tmf_conv3d_fwd_bf16: cin=%d must be a multiple of 8", cin);
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
+                "tmf_conv3d_fwd_bf16: one sample exceeds 2^31 elements");
+    TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w_bf16); TMF_REQUIRE_ALIGNED(z);
+    const int tD = tmf_cdiv(D, TD), tH = tmf_cdiv(H, TH), tW = tmf_cdiv(W, TW);
+    const int ntiles = B * tD * tH * tW;
+    int rc;
+    if ((rc = tmf_allow_lds(conv3d_fwd_bf16_kernel, LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;
+    hipLaunchKernelGGL(conv3d_fwd_bf16_kernel, dim3(ntiles, tmf_cdiv(cout, NB)), dim3(256), LDS_BYTES,
+                       (hipStream_t)stream, x, (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout,
+                       tD, tH, tW, ntiles);
+    return tmf_launch_result("tmf_conv3d_fwd_bf16");
+}

@@ -49,6 +49,45 @@ def unpack_wgrad(dw: torch.Tensor, cout: int, cin: int, k: int) -> torch.Tensor:
     return dw.view(k, k, k, cin, cout).permute(4, 3, 0, 1, 2).contiguous()
 
 
+_PRECISION = "fp32"
+
+
+def set_conv_precision(precision: str) -> None:
+    """"fp32" (default: exact-fp32 MFMA everywhere) or "bf16": the forward and data-gradient 3x3x3 convolutions
+    round their operands to bf16 and run on the bf16 matrix cores with fp32 accumulation (tensors stay fp32)."""
+    global _PRECISION
+    if precision not in ("fp32", "bf16"):
+        raise ValueError(precision)
+    _PRECISION = precision
+
+
+def get_conv_precision() -> str:
+    return _PRECISION
+
+
+def pack_weight_bf16(weight: torch.Tensor) -> torch.Tensor:
+    """(Cout, Cin, 3,3,3) -> bf16 [27][Cout][Cin] (B operand rows: output channel, K = input channel contiguous)."""
+    return weight.permute(2, 3, 4, 0, 1).contiguous().to(torch.bfloat16)
+
+
+def pack_weight_dgrad_bf16(weight: torch.Tensor) -> torch.Tensor:
+    """Data-gradient weights, bf16 [27][Cin][Cout]: w'[26-t][ci][co] = w[co][ci][t]."""
+    return weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous().to(torch.bfloat16)
+
+
+def conv3d_bf16_raw(x, w_bf16, cin, cout, want_stats):
+    """z = conv3x3x3(bf16(x), w_bf16) with fp32 accumulation; returns (z, stat_partial or None, nblk)."""
+    B, D, H, W = x.shape[:4]
+    z = torch.empty((B, D, H, W, cout), device=x.device, dtype=_f32)
+    part, nblk = None, 0
+    if want_stats:
+        nblk = _lib.query("tmf_conv3d_bf16_stat_blocks", B, D, H, W)
+        part = torch.empty((nblk, 2, cout), device=x.device, dtype=_f32)
+    _lib.call("tmf_conv3d_fwd_bf16", x.data_ptr(), w_bf16.data_ptr(), z.data_ptr(), _ptr(part),
+              B, D, H, W, cin, cout, _stream())
+    return z, part, nblk
+
+
 def conv3d_raw(x, w_packed, cin, cout, ksize, want_stats):
     """z = conv(x, w) on NDHWC x; returns (z, stat_partial or None, nblk)."""
     B, D, H, W = x.shape[:4]
@@ -103,7 +142,14 @@ class ConvBnActPool(torch.autograd.Function):
         B, D, H, W, C = x.shape
         if C != cin:
             raise _lib.TmfError(f"conv expects {cin} input channels, got {C}")
-        wp = pack_weight(_chk(weight, "weight"))
+        weight = _chk(weight, "weight")
+        bf16 = _PRECISION == "bf16" and k == 3 and cin % 8 == 0 and cin > 1
+
+        def conv(stats):
+            if bf16:
+                return conv3d_bf16_raw(x, pack_weight_bf16(weight), cin, cout, stats)
+            return conv3d_raw(x, pack_weight(weight), cin, cout, k, stats)
+
         dev = x.device
         mean = torch.empty(cout, device=dev, dtype=_f32)
         invstd = torch.empty(cout, device=dev, dtype=_f32)
@@ -112,13 +158,13 @@ class ConvBnActPool(torch.autograd.Function):
         s = _stream()
         pc = _lib.pool_code(pool)
         if training:
-            z, part, nblk = conv3d_raw(x, wp, cin, cout, k, True)
+            z, part, nblk = conv(True)
             _lib.call("tmf_bn_finalize", part.data_ptr(), nblk, cout, float(B * D * H * W),
                       gamma.data_ptr(), beta.data_ptr(), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                       float(momentum), float(eps), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                       shift.data_ptr(), s)
         else:
-            z, _, _ = conv3d_raw(x, wp, cin, cout, k, False)
+            z, _, _ = conv(False)
             _lib.call("tmf_bn_eval_coeffs", gamma.data_ptr(), beta.data_ptr(), _ptr(bias), running_mean.data_ptr(),
                       running_var.data_ptr(), float(eps), cout, scale.data_ptr(), shift.data_ptr(), s)
             # xhat = (z + bias - running_mean) * invstd, written as (z - mean) * invstd
@@ -133,6 +179,7 @@ class ConvBnActPool(torch.autograd.Function):
                       B, D, H, W, cout, pc, float(slope), s)
         ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd)
         ctx.cfg = (training, float(slope), pc, cin, cout, k, bias is not None)
+        ctx.bf16 = bf16
         return out
 
     @staticmethod
@@ -165,7 +212,10 @@ class ConvBnActPool(torch.autograd.Function):
             dweight = unpack_wgrad(conv3d_wgrad(x, dz, cin, cout, k), cout, cin, k)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx, _, _ = conv3d_raw(dz, pack_weight_dgrad(weight), cout, cin, k, False)
+            if ctx.bf16 and cout % 8 == 0:
+                dx, _, _ = conv3d_bf16_raw(dz, pack_weight_dgrad_bf16(weight), cout, cin, False)
+            else:
+                dx, _, _ = conv3d_raw(dz, pack_weight_dgrad(weight), cout, cin, k, False)
         return (dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
 
 
