@@ -6,7 +6,7 @@
 //     32 channels), weights arrive pre-packed as bf16 [tap][cout][cin] (cin contiguous);
 //   * one ds_read_b128 per operand fragment: the 32x32x16 MFMA takes 8 consecutive k (= input channels) per
 //     lane, which is exactly the channels-last row;
-//   * a wave owns 64 voxels x 64 channels (2x2 tiles): 8 fragment reads feed 8 MFMAs per tap;
+//   * 8 waves of 32 voxels x (32|64) channels, <= 128 registers: two workgroups (16 waves) per CU hide the staging;
 //   * accumulators, BatchNorm statistic partials and the stored output stay fp32.
 // At 1/16 of the fp32 MFMA time the kernel is bound by halo staging and the fp32 output stream, not by the
 // matrix pipe.
@@ -29,21 +29,28 @@ __device__ __forceinline__ unsigned int pack_bf16(float a, float b) {     // rou
     return (ua >> 16) | (ub & 0xFFFF0000u);
 }
 
-constexpr int TD = 4, TH = 8, TW = 8;                 // brick: 256 voxels = 4 waves x 2 M-tiles
+constexpr int TD = 4, TH = 8, TW = 8;                 // brick: 256 voxels = 8 waves x one 32-voxel M-tile
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int NHALO = HD * HH * HW;
 constexpr int CINC = 32;                              // input channels per chunk
 constexpr int RP = 40;                                // LDS row pitch in bf16 (80 B: 16-B aligned, odd multiple of 16 B)
-constexpr int NB = 64;                                // output channels per workgroup
 constexpr int TPS = 3;                                // taps per weight stage
 constexpr int NSTAGES = 9;
-constexpr int WSTAGE = TPS * NB * RP;                 // bf16 elements per weight stage
-constexpr size_t LDS_BYTES = (size_t)(NHALO * RP + 2 * WSTAGE) * 2 + 4 * 64 * 2 * 4;
+constexpr int NTHR = 512;                             // 8 waves, one 32-voxel M-tile each
 
-__global__ __launch_bounds__(256) void conv3d_fwd_bf16_kernel(
+template <int NT>                                     // NT output-channel tiles of 32 per wave / workgroup
+struct BfCfg {
+    static constexpr int NB = 32 * NT;
+    static constexpr int WSTAGE = TPS * NB * RP;      // bf16 elements per weight stage
+    static constexpr size_t LDS_BYTES = (size_t)(NHALO * RP + 2 * WSTAGE) * 2 + 8 * NB * 2 * 4;
+};
+
+template <int NT>
+__global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
     const float* __restrict__ x, const u16* __restrict__ w, float* __restrict__ z,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
     int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int NB = BfCfg<NT>::NB, WSTAGE = BfCfg<NT>::WSTAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* halo = reinterpret_cast<u16*>(smem_raw);
     u16* Ws = halo + NHALO * RP;
@@ -64,49 +71,59 @@ __global__ __launch_bounds__(256) void conv3d_fwd_bf16_kernel(
     const int n0 = blockIdx.y * NB;
 
     // LDS element offsets (bf16 units) of this lane's fragments
-    int a_lane[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int p = (wave * 2 + i) * 32 + l31;
+    int a_lane;
+    {
+        const int p = wave * 32 + l31;
         const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
-        a_lane[i] = ((pd * HH + ph) * HW + pw) * RP + hsel * 8;
+        a_lane = ((pd * HH + ph) * HW + pw) * RP + hsel * 8;
     }
     const int b_lane = l31 * RP + hsel * 8;
 
-    f32x16 acc[2][2];
+    f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
     const float* xb = x + (size_t)b * D * H * W * Cin;
 
     for (int c0 = 0; c0 < Cin; c0 += CINC) {
         if (c0 > 0) __syncthreads();
-        // ---- halo: fp32 from HBM, rounded to bf16 on the way into LDS (all loads issued first) ----
-        constexpr int HV = (NHALO * 8 + 255) / 256;
-        f32x4 hreg[HV];
+        // ---- halo: fp32 from HBM, rounded to bf16 on the way into LDS.  The loads of a batch are all issued
+        //      before its LDS writes; two batches keep the kernel under 128 registers (two workgroups per CU) ----
+        constexpr int HV = (NHALO * 8 + NTHR - 1) / NTHR;
+        constexpr int HB = (HV + 1) / 2;
+        auto stage_halo = [&](const int q0, const int q1) {
+            f32x4 hreg[HB];
 #pragma unroll
-        for (int q = 0; q < HV; ++q) {
-            const int e = tid + q * 256;
-            const int hp = e >> 3, c4 = e & 7;
-            const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
-            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
-            const int c = c0 + c4 * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < NHALO * 8 && c < Cin && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
-                v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c);
-            hreg[q] = v;
-        }
+            for (int q = q0; q < q1; ++q) {
+                const int e = tid + q * NTHR;
+                const int hp = e >> 3, c4 = e & 7;
+                const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
+                const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+                const int c = c0 + c4 * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (e < NHALO * 8 && c < Cin && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                    v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c);
+                hreg[q - q0] = v;
+            }
+#pragma unroll
+            for (int q = q0; q < q1; ++q) {
+                const int e = tid + q * NTHR;
+                if (e < NHALO * 8) {
+                    const f32x4 v = hreg[q - q0];
+                    u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    *reinterpret_cast<u32x2*>(halo + (e >> 3) * RP + (e & 7) * 4) = pk;
+                }
+            }
+        };
         // ---- weight stage loader: [tap][co][ci] bf16, one 16-B piece = 8 input channels of one output channel ----
-        constexpr int WV = (TPS * NB * 4 + 255) / 256;         // 4 pieces per (tap, co) row of 32 channels
+        constexpr int WV = (TPS * NB * 4 + NTHR - 1) / NTHR;         // 4 pieces per (tap, co) row of 32 channels
         u32x4 wreg[WV];
         auto load_w = [&](int st) {
 #pragma unroll
             for (int q = 0; q < WV; ++q) {
-                const int e = tid + q * 256;
+                const int e = tid + q * NTHR;
                 const int row = e >> 2, piece = e & 3;             // row = tap_in_stage * NB + co
                 const int tap = st * TPS + row / NB, co = n0 + row % NB, ci = c0 + piece * 8;
                 u32x4 v = {0u, 0u, 0u, 0u};
@@ -118,20 +135,14 @@ __global__ __launch_bounds__(256) void conv3d_fwd_bf16_kernel(
         auto store_w = [&](int buf) {
 #pragma unroll
             for (int q = 0; q < WV; ++q) {
-                const int e = tid + q * 256;
+                const int e = tid + q * NTHR;
                 if (e < TPS * NB * 4)
                     *reinterpret_cast<u32x4*>(Ws + buf * WSTAGE + (e >> 2) * RP + (e & 3) * 8) = wreg[q];
             }
         };
         load_w(0);
-#pragma unroll
-        for (int q = 0; q < HV; ++q) {
-            const int e = tid + q * 256;
-            if (e < NHALO * 8) {
-                u32x2 pk = {pack_bf16(hreg[q][0], hreg[q][1]), pack_bf16(hreg[q][2], hreg[q][3])};
-                *reinterpret_cast<u32x2*>(halo + (e >> 3) * RP + (e & 7) * 4) = pk;
-            }
-        }
+        stage_halo(0, HB);
+        stage_halo(HB, HV);
         for (int st = 0; st < NSTAGES; ++st) {
             const int buf = st & 1;
             store_w(buf);
@@ -143,46 +154,39 @@ __global__ __launch_bounds__(256) void conv3d_fwd_bf16_kernel(
             for (int tp = 0; tp < TPS; ++tp) {
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {                      // two k-blocks of 16 channels
-                    bf16x8 a[2], bb[2];
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(halo + a_lane + stage_off + tp * RP + s * 16);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        a[i] = *reinterpret_cast<const bf16x8*>(halo + a_lane[i] + stage_off + tp * RP + s * 16);
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        bb[j] = *reinterpret_cast<const bf16x8*>(ws + (tp * NB + j * 32) * RP + s * 16);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) {
+                        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(ws + (tp * NB + j * 32) * RP + s * 16);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[j], 0, 0, 0);
+                    }
                 }
             }
         }
     }
 
     // ---- epilogue: fp32 NDHWC store + BatchNorm statistic partials (same as the fp32 kernel) ----
-    float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
     float* zb = z + (size_t)b * D * H * W * Cout;
     auto epilogue = [&](auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int r = 0; r < 16; ++r) {
+            const int p = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+            const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+            const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+            const bool pv = FULL || (gd < D && gh < H && gw < W);
+            const int off = ((gd * H + gh) * W + gw) * Cout;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int p = (wave * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-                const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
-                const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
-                const bool pv = FULL || (gd < D && gh < H && gw < W);
-                const int off = ((gd * H + gh) * W + gw) * Cout;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int co = n0 + j * 32 + l31;
-                    if (FULL || (pv && co < Cout)) {
-                        const float v = acc[i][j][r];
-                        zb[off + co] = v;
-                        s1[j] += v;
-                        s2[j] += v * v;
-                    }
+            for (int j = 0; j < NT; ++j) {
+                const int co = n0 + j * 32 + l31;
+                if (FULL || (pv && co < Cout)) {
+                    const float v = acc[j][r];
+                    zb[off + co] = v;
+                    s1[j] += v;
+                    s2[j] += v * v;
                 }
             }
         }
@@ -192,22 +196,22 @@ __global__ __launch_bounds__(256) void conv3d_fwd_bf16_kernel(
 
     if (stat_partial != nullptr) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NT; ++j) {
             s1[j] += __shfl_xor(s1[j], 32);
             s2[j] += __shfl_xor(s2[j], 32);
         }
         if (hsel == 0) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                red[(wave * 64 + j * 32 + l31) * 2 + 0] = s1[j];
-                red[(wave * 64 + j * 32 + l31) * 2 + 1] = s2[j];
+            for (int j = 0; j < NT; ++j) {
+                red[(wave * NB + j * 32 + l31) * 2 + 0] = s1[j];
+                red[(wave * NB + j * 32 + l31) * 2 + 1] = s2[j];
             }
         }
         __syncthreads();
         if (tid < NB) {
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) { a1 += red[(m * 64 + tid) * 2]; a2 += red[(m * 64 + tid) * 2 + 1]; }
+            for (int m = 0; m < 8; ++m) { a1 += red[(m * NB + tid) * 2]; a2 += red[(m * NB + tid) * 2 + 1]; }
             const int co = n0 + tid;
             if (co < Cout) {
                 stat_partial[((size_t)tile * 2 + 0) * Cout + co] = a1;
@@ -236,9 +240,15 @@ extern "C" int tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z,
     const int tD = tmf_cdiv(D, TD), tH = tmf_cdiv(H, TH), tW = tmf_cdiv(W, TW);
     const int ntiles = B * tD * tH * tW;
     int rc;
-    if ((rc = tmf_allow_lds(conv3d_fwd_bf16_kernel, LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;
-    hipLaunchKernelGGL(conv3d_fwd_bf16_kernel, dim3(ntiles, tmf_cdiv(cout, NB)), dim3(256), LDS_BYTES,
-                       (hipStream_t)stream, x, (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout,
-                       tD, tH, tW, ntiles);
+    hipStream_t s = (hipStream_t)stream;
+    if (cout <= 32) {
+        if ((rc = tmf_allow_lds(conv3d_fwd_bf16_kernel<1>, BfCfg<1>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;
+        hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<1>, dim3(ntiles, 1), dim3(NTHR), BfCfg<1>::LDS_BYTES, s,
+                           x, (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);
+    } else {
+        if ((rc = tmf_allow_lds(conv3d_fwd_bf16_kernel<2>, BfCfg<2>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;
+        hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<2>, dim3(ntiles, tmf_cdiv(cout, 64)), dim3(NTHR), BfCfg<2>::LDS_BYTES, s,
+                           x, (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);
+    }
     return tmf_launch_result("tmf_conv3d_fwd_bf16");
 }
