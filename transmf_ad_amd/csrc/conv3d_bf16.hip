@@ -241,14 +241,10 @@ extern "C" int tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z,
     const int ntiles = B * tD * tH * tW;
     int rc;
     hipStream_t s = (hipStream_t)stream;
-    if (cout <= 32) {
-        if ((rc = tmf_allow_lds(conv3d_fwd_bf16_kernel<1>, BfCfg<1>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;
-        hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<1>, dim3(ntiles, 1), dim3(NTHR), BfCfg<1>::LDS_BYTES, s,
-                           x, (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);
-    } else {
-        if ((rc = tmf_allow_lds(conv3d_fwd_bf16_kernel<2>, BfCfg<2>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;
-        hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<2>, dim3(ntiles, tmf_cdiv(cout, 64)), dim3(NTHR), BfCfg<2>::LDS_BYTES, s,
-                           x, (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);
-    }
+    // one 32-channel output tile per workgroup (104 registers: two workgroups per CU); wider layers use more
+    // workgroup columns — the two-tile variant needs > 128 registers and measured slower (0.237 vs 2 x 0.088 ms)
+    if ((rc = tmf_allow_lds(conv3d_fwd_bf16_kernel<1>, BfCfg<1>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;
+    hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<1>, dim3(ntiles, tmf_cdiv(cout, 32)), dim3(NTHR), BfCfg<1>::LDS_BYTES, s,
+                       x, (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);
     return tmf_launch_result("tmf_conv3d_fwd_bf16");
 }
