@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2, help="pairs in the bounded CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16: forward/dgrad 3x3x3 convs on the bf16 matrix cores (BASELINE configs[2] mode; not the headline)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (measured slower than eager on ROCm 7.2: 19.7 vs 18.2 ms)")
     args = ap.parse_args()
@@ -67,6 +69,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    ops.set_conv_precision(args.precision)
     torch.manual_seed(0)
     net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to(dev)
     if world > 1:
@@ -181,7 +184,9 @@ def main():
             "metric": "volume-pairs/sec fwd+bwd(+Adam), 96^3 MRI+PET batch=8 per GPU",
             "value": round(pairs_per_s, 3), "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "bf16 operands / f32 accumulate+storage (fwd, dgrad convs)",
+            "data": "synthetic",
             "config": {"workload": f"model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512) train step, "
                                    f"batch {B} pairs of 1x{S}^3 per GPU, fp32 (BASELINE configs[1])",
                        "global_batch": B * world, "parallelism": f"dp{world}",

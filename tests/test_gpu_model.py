@@ -375,3 +375,28 @@ def test_hipgraph_step_equals_eager_step():
         if k.endswith("num_batches_tracked"):
             continue
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("name", ["ad_mid", "ad_full_b8"])
+def test_bf16_conv_precision_mode(name):
+    """BASELINE configs[2] mode: forward / data-gradient 3x3x3 convolutions on the bf16 matrix cores (operands
+    rounded to bf16, fp32 accumulation and storage).  Tolerance vs the fp32 reference golden: the `cls` vector
+    within 3e-2 of its scale (bf16 has 8 mantissa bits; 6 rounded layers) and the loss within 0.1 — stated, loose,
+    and separate from the fp32 gate."""
+    if not available(name):
+        pytest.skip("fixture not generated")
+    import transmf_ad_amd as T
+    g = Golden(name)
+    T.set_conv_precision("bf16")
+    try:
+        net = build(g)
+        seen = {}
+        net.fuse_transformer.register_forward_hook(lambda _m, _i, o: seen.__setitem__("cls", o))
+        outs, loss = step(net, g, train=True)
+    finally:
+        T.set_conv_precision("fp32")
+    ref = g["f32/probe/cls"]
+    err = np.abs(probe(seen["cls"]) - ref).max()
+    assert err <= 3e-2 * max(1.0, np.abs(ref).max()), err
+    assert abs(loss.item() - float(g["f32/train/loss"])) <= 0.1
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
