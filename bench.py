@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: forward/dgrad 3x3x3 convs on the bf16 matrix cores (BASELINE configs[2] mode; not the headline)")
+    ap.add_argument("--no-fused-adam", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (measured slower than eager on ROCm 7.2: 19.7 vs 18.2 ms)")
     args = ap.parse_args()
@@ -74,7 +75,9 @@ def main():
     net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to(dev)
     if world > 1:
         net = GradAllReduce(net)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=args.graph and world == 1)
+    # same update rule as the reference's getOptimizer (utils/utils.py:38-39: Adam, lr 1e-4, wd 0), multi-tensor form
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=args.graph and world == 1,
+                           fused=not args.graph and not args.no_fused_adam)
     crit = nn.CrossEntropyLoss()
     B, S = args.batch, args.size
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -111,7 +114,7 @@ def main():
             mode = "hipgraph"
         except Exception as e:               # capture unsupported: fall back to the eager step, and say so
             print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
 
     def fence():
         if world > 1:
