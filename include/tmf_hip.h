@@ -77,6 +77,11 @@ int    tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void* worksp
 int  tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z, float* stat_partial,
                          int B, int D, int H, int W, int cin, int cout, void* stream);
 int  tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W);
+/* fp32-ACCURATE variant on the bf16 matrix cores: operands split exactly into three bf16 numbers (hi+mid+lo), the
+ * six partial products of order >= 2^-16 accumulated in fp32 (the dropped terms are below one fp32 ulp of the
+ * product).  w3_bf16: bf16 [3 parts][27][cout][cin]; same shapes / statistics layout as tmf_conv3d_fwd_bf16. */
+int  tmf_conv3d_fwd_split(const float* x, const void* w3_bf16, float* z, float* stat_partial,
+                          int B, int D, int H, int W, int cin, int cout, void* stream);
 
 /* First layer, cin == 1 (networks.py:22): x[b][d][h][w], w[27][cout]. */
 int    tmf_conv3d_c1_fwd(const float* x, const float* w, float* z, float* stat_partial,

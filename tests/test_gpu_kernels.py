@@ -394,3 +394,49 @@ def test_block_in_bf16_mode():
         return ((got.double().cpu() - ref).norm() / ref.norm()).item()
     assert l2(Pg[0].grad, P[0].grad) < 1e-1 and l2(_ncdhw(xg.grad.cpu()), xr.grad) < 1e-1, (l2(Pg[0].grad, P[0].grad), l2(_ncdhw(xg.grad.cpu()), xr.grad))
     assert l2(Pg[2].grad, P[2].grad) < 1e-1 and l2(Pg[3].grad, P[3].grad) < 1e-1
+
+
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+def test_conv3d_fp32_accurate_split(shape):
+    """3-way bf16 split on the bf16 matrix cores: held to the SAME tolerance as the exact-fp32 MFMA kernel (1e-5
+    of max vs fp64, general fp32 operands), and its error is compared with that kernel's on the same data."""
+    ops = _ops()
+    B, D, H, W, cin, cout = shape
+    x = _rand(B, cin, D, H, W, seed=71)
+    w = _rand(cout, cin, 3, 3, 3, seed=72, scale=(cin * 27) ** -0.5)
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    xg, wg = _ndhwc(x).to(DEV), w.to(DEV)
+    w3 = ops.split3_bf16(wg.permute(2, 3, 4, 0, 1).contiguous())
+    assert torch.equal(w3.float().sum(0), wg.permute(2, 3, 4, 0, 1))          # the decomposition is exact
+    z, part, _ = ops.conv3d_split_raw(xg, w3, cin, cout, True)
+    z32, _, _ = ops.conv3d_raw(xg, ops.pack_weight(wg), cin, cout, 3, False)
+    torch.cuda.synchronize()
+    e_split, e_f32 = _relerr(_ncdhw(z.cpu()), ref), _relerr(_ncdhw(z32.cpu()), ref)
+    assert e_split < 1e-5, (e_split, e_f32)
+    assert e_split < 4 * e_f32 + 1e-6, (e_split, e_f32)
+    s = part.double().sum(0).cpu()
+    r = ref.permute(1, 0, 2, 3, 4).reshape(cout, -1)
+    assert (s[1] - (r * r).sum(1)).abs().max() <= 1e-5 * (r * r).sum(1).max().item()
+    if cout % 8 == 0:
+        dz = _rand(B, cout, D, H, W, seed=73)
+        xr = x.double().requires_grad_(True)
+        F.conv3d(xr, w.double(), padding=1).backward(dz.double())
+        wd3 = ops.split3_bf16(wg.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())
+        dx, _, _ = ops.conv3d_split_raw(_ndhwc(dz).to(DEV), wd3, cout, cin, False)
+        assert _relerr(_ncdhw(dx.cpu()), xr.grad) < 1e-5
+
+
+def test_split_exact_on_integers():
+    ops = _ops()
+    cin, cout = 32, 64
+    x = torch.zeros(1, cin, 8, 8, 8)
+    x[0, :, 3, 4, 5] = torch.arange(cin, dtype=torch.float32) * 257 + 1        # needs > 8 significand bits
+    w = torch.zeros(cout, cin, 3, 3, 3)
+    for co in range(cout):
+        for ci in range(cin):
+            w[co, ci, 1, 1, 1] = (co * 37 + ci * 11) % 23 - 7.0
+    w[:, :, 0, 1, 2] = 0.5
+    ref = F.conv3d(x, w, padding=1)
+    w3 = ops.split3_bf16(w.to(DEV).permute(2, 3, 4, 0, 1).contiguous())
+    z, _, _ = ops.conv3d_split_raw(_ndhwc(x).to(DEV), w3, cin, cout, False)
+    assert torch.equal(_ncdhw(z.cpu()), ref)

@@ -16,5 +16,7 @@ for name, cin, cout, k, div, pool in LAYERS:
     fl = 2.0 * 27 * cin * cout * 8 * s ** 3
     t32 = timeit(lambda: ops.conv3d_raw(x, wp, cin, cout, 3, True), 10)
     t16 = timeit(lambda: ops.conv3d_bf16_raw(x, wb, cin, cout, True), 10)
+    w3 = ops.split3_bf16(w.permute(2, 3, 4, 0, 1).contiguous())
+    t3 = timeit(lambda: ops.conv3d_split_raw(x, w3, cin, cout, True), 10)
     gb = (x.numel() + 8 * s ** 3 * cout) * 4 / 1e9
-    print(f"{name}: fp32 {t32:.3f} ms ({fl/t32/1e9:6.1f} TF)   bf16 {t16:.3f} ms ({fl/t16/1e9:6.1f} TF, {gb/t16*1e3:5.0f} GB/s algorithmic)", flush=True)
+    print(f"{name}: fp32 {t32:.3f} ms ({fl/t32/1e9:6.1f} TF)   bf16 {t16:.3f} ms ({fl/t16/1e9:6.1f} TF, {gb/t16*1e3:5.0f} GB/s algorithmic)   fp32x(split) {t3:.3f} ms ({fl/t3/1e9:6.1f} TF-equivalent)", flush=True)

@@ -221,6 +221,185 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// fp32-ACCURATE convolution on the bf16 matrix cores ("3-way split"): every fp32 operand is written as
+// hi + mid + lo with three bf16 numbers (8 + 8 + 8 significand bits: the decomposition is EXACT), and the
+// product a*b is evaluated as the six partial products of order >= 2^-16 — (h,h) (h,m) (m,h) (h,l) (l,h) (m,m) —
+// each exact in fp32, accumulated in fp32 by the MFMA.  The three dropped terms are <= 2^-24 |a b|, i.e. below
+// the rounding of the fp32 product itself, so the result carries fp32 accuracy (tests hold it to the same 1e-5 as
+// the exact-fp32 MFMA kernel) at 6/16 of the fp32-MFMA matrix time.  Opt-in (set_conv_precision("fp32x")).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SC = 16;                                // input channels per chunk (one MFMA k-block)
+constexpr int SRP = 24;                               // LDS row pitch in bf16 (48 B = 3 x 16 B)
+constexpr int SHALO = NHALO * SRP;                    // bf16 elements per halo part
+constexpr int SWSTAGE = TPS * 32 * SRP;               // bf16 elements per weight stage and part
+constexpr size_t SPLIT_LDS_BYTES = (size_t)(3 * SHALO + 2 * 3 * SWSTAGE) * 2 + 8 * 32 * 2 * 4;
+
+__device__ __forceinline__ unsigned int rne_bf16_bits(float a) {          // bf16 bit pattern in the low half
+    unsigned int u = __builtin_bit_cast(unsigned int, a);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void split3(float a, unsigned int& h, unsigned int& m, unsigned int& l) {
+    h = rne_bf16_bits(a);
+    const float r1 = a - __builtin_bit_cast(float, h << 16);             // exact
+    m = rne_bf16_bits(r1);
+    const float r2 = r1 - __builtin_bit_cast(float, m << 16);            // exact, fits bf16
+    l = rne_bf16_bits(r2);
+}
+
+__global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
+    const float* __restrict__ x, const u16* __restrict__ w3, float* __restrict__ z,
+    float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
+    int tilesD, int tilesH, int tilesW, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* halo = reinterpret_cast<u16*>(smem_raw);             // [3 parts][NHALO][SRP]
+    u16* Ws = halo + 3 * SHALO;                                // [2 buffers][3 parts][TPS][32 co][SRP]
+    float* red = reinterpret_cast<float*>(Ws + 2 * 3 * SWSTAGE);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int tile = xcd_contiguous(blockIdx.x, ntiles);
+    int t = tile;
+    const int tw = t % tilesW; t /= tilesW;
+    const int th = t % tilesH; t /= tilesH;
+    const int td = t % tilesD;
+    const int b = t / tilesD;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+    const int n0 = blockIdx.y * 32;
+    const size_t wpart = (size_t)27 * Cout * Cin;              // elements per weight part in global memory
+
+    int a_lane;
+    {
+        const int p = wave * 32 + l31;
+        const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+        a_lane = ((pd * HH + ph) * HW + pw) * SRP + hsel * 8;
+    }
+    const int b_lane = l31 * SRP + hsel * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* xb = x + (size_t)b * D * H * W * Cin;
+
+    for (int c0 = 0; c0 < Cin; c0 += SC) {
+        if (c0 > 0) __syncthreads();
+        // ---- halo: fp32 -> (hi, mid, lo) bf16, three LDS images ----
+        constexpr int HV = (NHALO * 4 + NTHR - 1) / NTHR;       // float4 pieces: 4 per position
+        f32x4 hreg[HV];
+#pragma unroll
+        for (int q = 0; q < HV; ++q) {
+            const int e = tid + q * NTHR;
+            const int hp = e >> 2, c4 = e & 3;
+            const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
+            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+            const int c = c0 + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (e < NHALO * 4 && c < Cin && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
+                v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c);
+            hreg[q] = v;
+        }
+        // ---- weights: pre-split on the host, [part][tap][co][ci]; one 16-B piece = 8 input channels ----
+        constexpr int WV = (3 * TPS * 32 * 2 + NTHR - 1) / NTHR;   // 2 pieces per (part, tap, co) row of 16 channels
+        u32x4 wreg[WV];
+        auto load_w = [&](int st) {
+#pragma unroll
+            for (int q = 0; q < WV; ++q) {
+                const int e = tid + q * NTHR;
+                const int piece = e & 1, row = e >> 1;            // row = (part * TPS + tap_in_stage) * 32 + co
+                const int co = n0 + (row & 31), tp = (row >> 5) % TPS, part = row / (32 * TPS);
+                const int tap = st * TPS + tp, ci = c0 + piece * 8;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (e < 3 * TPS * 32 * 2 && co < Cout && ci < Cin)
+                    v = *reinterpret_cast<const u32x4*>(w3 + part * wpart + ((size_t)tap * Cout + co) * Cin + ci);
+                wreg[q] = v;
+            }
+        };
+        auto store_w = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < WV; ++q) {
+                const int e = tid + q * NTHR;
+                if (e < 3 * TPS * 32 * 2)
+                    *reinterpret_cast<u32x4*>(Ws + buf * 3 * SWSTAGE + (e >> 1) * SRP + (e & 1) * 8) = wreg[q];
+            }
+        };
+        load_w(0);
+#pragma unroll
+        for (int q = 0; q < HV; ++q) {
+            const int e = tid + q * NTHR;
+            if (e < NHALO * 4) {
+                unsigned int hh_[4], mm_[4], ll_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) split3(hreg[q][u], hh_[u], mm_[u], ll_[u]);
+                u16* dst = halo + (e >> 2) * SRP + (e & 3) * 4;
+                u32x2 ph = {hh_[0] | (hh_[1] << 16), hh_[2] | (hh_[3] << 16)};
+                u32x2 pm = {mm_[0] | (mm_[1] << 16), mm_[2] | (mm_[3] << 16)};
+                u32x2 pl = {ll_[0] | (ll_[1] << 16), ll_[2] | (ll_[3] << 16)};
+                *reinterpret_cast<u32x2*>(dst) = ph;
+                *reinterpret_cast<u32x2*>(dst + SHALO) = pm;
+                *reinterpret_cast<u32x2*>(dst + 2 * SHALO) = pl;
+            }
+        }
+        for (int st = 0; st < NSTAGES; ++st) {
+            const int buf = st & 1;
+            store_w(buf);
+            __syncthreads();
+            if (st + 1 < NSTAGES) load_w(st + 1);
+            const int stage_off = ((st / 3) * HH + (st % 3)) * HW * SRP;
+            const u16* ws = Ws + buf * 3 * SWSTAGE + b_lane;
+#pragma unroll
+            for (int tp = 0; tp < TPS; ++tp) {
+                const u16* ap = halo + a_lane + stage_off + tp * SRP;
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
+                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + SHALO);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * SHALO);
+                const u16* bp = ws + tp * 32 * SRP;
+                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
+                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + SWSTAGE);
+                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * SWSTAGE);
+                // smallest terms first
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+        }
+    }
+
+    float s1 = 0.f, s2 = 0.f;
+    float* zb = z + (size_t)b * D * H * W * Cout;
+    const int co = n0 + l31;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int p = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+        const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+        const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+        if (gd < D && gh < H && gw < W && co < Cout) {
+            const float v = acc[r];
+            zb[((gd * H + gh) * W + gw) * Cout + co] = v;
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    if (stat_partial != nullptr) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (hsel == 0) { red[(wave * 32 + l31) * 2] = s1; red[(wave * 32 + l31) * 2 + 1] = s2; }
+        __syncthreads();
+        if (tid < 32 && n0 + tid < Cout) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { a1 += red[(m * 32 + tid) * 2]; a2 += red[(m * 32 + tid) * 2 + 1]; }
+            stat_partial[((size_t)tile * 2 + 0) * Cout + n0 + tid] = a1;
+            stat_partial[((size_t)tile * 2 + 1) * Cout + n0 + tid] = a2;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W) {
@@ -247,4 +426,23 @@ extern "C" int tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z,
     hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<1>, dim3(ntiles, tmf_cdiv(cout, 32)), dim3(NTHR), BfCfg<1>::LDS_BYTES, s,
                        x, (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);
     return tmf_launch_result("tmf_conv3d_fwd_bf16");
+}
+
+extern "C" int tmf_conv3d_fwd_split(const float* x, const void* w3_bf16, float* z, float* stat_partial,
+                                    int B, int D, int H, int W, int cin, int cout, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w3_bf16); TMF_REQUIRE_PTR(z);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
+                "tmf_conv3d_fwd_split: non-positive dimension");
+    TMF_REQUIRE(cin % 8 == 0, TMF_E_SHAPE, "tmf_conv3d_fwd_split: cin=%d must be a multiple of 8", cin);
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
+                "tmf_conv3d_fwd_split: one sample exceeds 2^31 elements");
+    TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w3_bf16); TMF_REQUIRE_ALIGNED(z);
+    const int tD = tmf_cdiv(D, TD), tH = tmf_cdiv(H, TH), tW = tmf_cdiv(W, TW);
+    const int ntiles = B * tD * tH * tW;
+    int rc;
+    if ((rc = tmf_allow_lds(conv3d_fwd_split_kernel, SPLIT_LDS_BYTES, "tmf_conv3d_fwd_split"))) return rc;
+    hipLaunchKernelGGL(conv3d_fwd_split_kernel, dim3(ntiles, tmf_cdiv(cout, 32)), dim3(NTHR), SPLIT_LDS_BYTES,
+                       (hipStream_t)stream, x, (const u16*)w3_bf16, z, stat_partial, D, H, W, cin, cout,
+                       tD, tH, tW, ntiles);
+    return tmf_launch_result("tmf_conv3d_fwd_split");
 }

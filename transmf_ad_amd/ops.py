@@ -53,10 +53,11 @@ _PRECISION = "fp32"
 
 
 def set_conv_precision(precision: str) -> None:
-    """"fp32" (default: exact-fp32 MFMA everywhere) or "bf16": the forward and data-gradient 3x3x3 convolutions
-    round their operands to bf16 and run on the bf16 matrix cores with fp32 accumulation (tensors stay fp32)."""
+    """"fp32" (default: exact-fp32 MFMA everywhere); "bf16": the forward and data-gradient 3x3x3 convolutions
+    round their operands to bf16 and run on the bf16 matrix cores with fp32 accumulation (tensors stay fp32);
+    "fp32x": fp32-accurate 3-way bf16 split (six partial products) on the bf16 matrix cores."""
     global _PRECISION
-    if precision not in ("fp32", "bf16"):
+    if precision not in ("fp32", "fp32x", "bf16"):
         raise ValueError(precision)
     _PRECISION = precision
 
@@ -73,6 +74,28 @@ def pack_weight_bf16(weight: torch.Tensor) -> torch.Tensor:
 def pack_weight_dgrad_bf16(weight: torch.Tensor) -> torch.Tensor:
     """Data-gradient weights, bf16 [27][Cin][Cout]: w'[26-t][ci][co] = w[co][ci][t]."""
     return weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous().to(torch.bfloat16)
+
+
+def split3_bf16(t: torch.Tensor) -> torch.Tensor:
+    """Exact decomposition t = hi + mid + lo into three bf16 tensors, stacked on a new leading axis."""
+    hi = t.to(torch.bfloat16)
+    r1 = t - hi.float()
+    mid = r1.to(torch.bfloat16)
+    lo = (r1 - mid.float()).to(torch.bfloat16)
+    return torch.stack([hi, mid, lo]).contiguous()
+
+
+def conv3d_split_raw(x, w3, cin, cout, want_stats):
+    """fp32-accurate conv on the bf16 matrix cores; w3 = split3_bf16(packed [27][cout][cin] fp32 weights)."""
+    B, D, H, W = x.shape[:4]
+    z = torch.empty((B, D, H, W, cout), device=x.device, dtype=_f32)
+    part, nblk = None, 0
+    if want_stats:
+        nblk = _lib.query("tmf_conv3d_bf16_stat_blocks", B, D, H, W)
+        part = torch.empty((nblk, 2, cout), device=x.device, dtype=_f32)
+    _lib.call("tmf_conv3d_fwd_split", x.data_ptr(), w3.data_ptr(), z.data_ptr(), _ptr(part),
+              B, D, H, W, cin, cout, _stream())
+    return z, part, nblk
 
 
 def conv3d_bf16_raw(x, w_bf16, cin, cout, want_stats):
@@ -143,11 +166,13 @@ class ConvBnActPool(torch.autograd.Function):
         if C != cin:
             raise _lib.TmfError(f"conv expects {cin} input channels, got {C}")
         weight = _chk(weight, "weight")
-        bf16 = _PRECISION == "bf16" and k == 3 and cin % 8 == 0 and cin > 1
+        bf16 = _PRECISION if (_PRECISION != "fp32" and k == 3 and cin % 8 == 0 and cin > 1) else False
 
         def conv(stats):
-            if bf16:
+            if bf16 == "bf16":
                 return conv3d_bf16_raw(x, pack_weight_bf16(weight), cin, cout, stats)
+            if bf16 == "fp32x":
+                return conv3d_split_raw(x, split3_bf16(weight.permute(2, 3, 4, 0, 1).contiguous()), cin, cout, stats)
             return conv3d_raw(x, pack_weight(weight), cin, cout, k, stats)
 
         dev = x.device
@@ -212,8 +237,11 @@ class ConvBnActPool(torch.autograd.Function):
             dweight = unpack_wgrad(conv3d_wgrad(x, dz, cin, cout, k), cout, cin, k)
         dx = None
         if ctx.needs_input_grad[0]:
-            if ctx.bf16 and cout % 8 == 0:
+            if ctx.bf16 == "bf16" and cout % 8 == 0:
                 dx, _, _ = conv3d_bf16_raw(dz, pack_weight_dgrad_bf16(weight), cout, cin, False)
+            elif ctx.bf16 == "fp32x" and cout % 8 == 0:
+                w3 = split3_bf16(weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())
+                dx, _, _ = conv3d_split_raw(dz, w3, cout, cin, False)
             else:
                 dx, _, _ = conv3d_raw(dz, pack_weight_dgrad(weight), cout, cin, k, False)
         return (dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
