@@ -231,10 +231,13 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
 // the exact-fp32 MFMA kernel) at 6/16 of the fp32-MFMA matrix time.  Opt-in (set_conv_precision("fp32x")).
 // ------------------------------------------------------------------------------------------------------------
 constexpr int SC = 16;                                // input channels per chunk (one MFMA k-block)
-constexpr int SRP = 24;                               // LDS row pitch in bf16 (48 B = 3 x 16 B)
+constexpr int SRP = 16;                               // LDS row = 16 bf16 = 32 B, two 16-B halves XOR-swizzled by row bit 3
+constexpr int STPS = 9;                               // taps per weight stage: one kd plane, 3 stages per chunk
+constexpr int SNST = 3;
 constexpr int SHALO = NHALO * SRP;                    // bf16 elements per halo part
-constexpr int SWSTAGE = TPS * 32 * SRP;               // bf16 elements per weight stage and part
+constexpr int SWSTAGE = STPS * 32 * SRP;              // bf16 elements per weight stage and part
 constexpr size_t SPLIT_LDS_BYTES = (size_t)(3 * SHALO + 2 * 3 * SWSTAGE) * 2 + 8 * 32 * 2 * 4;
+__device__ __forceinline__ int swz(int row, int half) { return row * SRP + ((half ^ ((row >> 3) & 1)) << 3); }
 
 __device__ __forceinline__ unsigned int rne_bf16_bits(float a) {          // bf16 bit pattern in the low half
     unsigned int u = __builtin_bit_cast(unsigned int, a);
@@ -276,9 +279,8 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
     {
         const int p = wave * 32 + l31;
         const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
-        a_lane = ((pd * HH + ph) * HW + pw) * SRP + hsel * 8;
+        a_lane = (pd * HH + ph) * HW + pw;                      // halo ROW of this lane's voxel (tap (0,0,0))
     }
-    const int b_lane = l31 * SRP + hsel * 8;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -302,17 +304,17 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
             hreg[q] = v;
         }
         // ---- weights: pre-split on the host, [part][tap][co][ci]; one 16-B piece = 8 input channels ----
-        constexpr int WV = (3 * TPS * 32 * 2 + NTHR - 1) / NTHR;   // 2 pieces per (part, tap, co) row of 16 channels
+        constexpr int WV = (3 * STPS * 32 * 2 + NTHR - 1) / NTHR;   // 2 pieces per (part, tap, co) row of 16 channels
         u32x4 wreg[WV];
         auto load_w = [&](int st) {
 #pragma unroll
             for (int q = 0; q < WV; ++q) {
                 const int e = tid + q * NTHR;
                 const int piece = e & 1, row = e >> 1;            // row = (part * TPS + tap_in_stage) * 32 + co
-                const int co = n0 + (row & 31), tp = (row >> 5) % TPS, part = row / (32 * TPS);
-                const int tap = st * TPS + tp, ci = c0 + piece * 8;
+                const int co = n0 + (row & 31), tp = (row >> 5) % STPS, part = row / (32 * STPS);
+                const int tap = st * STPS + tp, ci = c0 + piece * 8;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (e < 3 * TPS * 32 * 2 && co < Cout && ci < Cin)
+                if (e < 3 * STPS * 32 * 2 && co < Cout && ci < Cin)
                     v = *reinterpret_cast<const u32x4*>(w3 + part * wpart + ((size_t)tap * Cout + co) * Cin + ci);
                 wreg[q] = v;
             }
@@ -321,8 +323,8 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
 #pragma unroll
             for (int q = 0; q < WV; ++q) {
                 const int e = tid + q * NTHR;
-                if (e < 3 * TPS * 32 * 2)
-                    *reinterpret_cast<u32x4*>(Ws + buf * 3 * SWSTAGE + (e >> 1) * SRP + (e & 1) * 8) = wreg[q];
+                if (e < 3 * STPS * 32 * 2)
+                    *reinterpret_cast<u32x4*>(Ws + buf * 3 * SWSTAGE + swz(e >> 1, e & 1)) = wreg[q];
             }
         };
         load_w(0);
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
                 unsigned int hh_[4], mm_[4], ll_[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) split3(hreg[q][u], hh_[u], mm_[u], ll_[u]);
-                u16* dst = halo + (e >> 2) * SRP + (e & 3) * 4;
+                u16* dst = halo + swz(e >> 2, (e & 3) >> 1) + (e & 1) * 4;
                 u32x2 ph = {hh_[0] | (hh_[1] << 16), hh_[2] | (hh_[3] << 16)};
                 u32x2 pm = {mm_[0] | (mm_[1] << 16), mm_[2] | (mm_[3] << 16)};
                 u32x2 pl = {ll_[0] | (ll_[1] << 16), ll_[2] | (ll_[3] << 16)};
@@ -342,20 +344,20 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
                 *reinterpret_cast<u32x2*>(dst + 2 * SHALO) = pl;
             }
         }
-        for (int st = 0; st < NSTAGES; ++st) {
+        for (int st = 0; st < SNST; ++st) {                     // stage = kd plane (9 taps)
             const int buf = st & 1;
             store_w(buf);
             __syncthreads();
-            if (st + 1 < NSTAGES) load_w(st + 1);
-            const int stage_off = ((st / 3) * HH + (st % 3)) * HW * SRP;
-            const u16* ws = Ws + buf * 3 * SWSTAGE + b_lane;
+            if (st + 1 < SNST) load_w(st + 1);
+            const u16* ws = Ws + buf * 3 * SWSTAGE;
 #pragma unroll
-            for (int tp = 0; tp < TPS; ++tp) {
-                const u16* ap = halo + a_lane + stage_off + tp * SRP;
+            for (int tp = 0; tp < STPS; ++tp) {
+                const int arow = a_lane + (st * HH + tp / 3) * HW + tp % 3;
+                const u16* ap = halo + swz(arow, hsel);
                 const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
                 const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + SHALO);
                 const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * SHALO);
-                const u16* bp = ws + tp * 32 * SRP;
+                const u16* bp = ws + swz(tp * 32 + l31, hsel);
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
                 const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + SWSTAGE);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * SWSTAGE);
