@@ -281,9 +281,9 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
         const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
         a_lane = (pd * HH + ph) * HW + pw;                      // halo ROW of this lane's voxel (tap (0,0,0))
     }
-    f32x16 acc;
+    f32x16 acc, acc2;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     const float* xb = x + (size_t)b * D * H * W * Cin;
 
     for (int c0 = 0; c0 < Cin; c0 += SC) {
@@ -361,16 +361,17 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
                 const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
                 const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + SWSTAGE);
                 const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * SWSTAGE);
-                // smallest terms first
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                // two independent chains: the 2^-16..2^-8 cross terms, and the leading terms
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
             }
         }
     }
+    acc += acc2;
 
     float s1 = 0.f, s2 = 0.f;
     float* zb = z + (size_t)b * D * H * W * Cout;
