@@ -41,6 +41,15 @@ def conv_flops_per_pair(size, dim=128):
     return 2 * tot
 
 
+def _profiled_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (counters cannot be read live)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv2.3_fwd.json")) as f:
+            return float(json.load(f)["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -167,7 +176,8 @@ def main():
         ach = flops / (k_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "conv3d_fwd_kernel<L64,k3,cin32> @conv2.3", "achieved": round(ach, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": None, "launch_ms": round(k_ms, 4), "flops_per_launch": flops}
+                "traffic": _profiled_traffic(), "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                "profiles/r01_pmc_traffic_conv2.3_fwd.json)", "launch_ms": round(k_ms, 4), "flops_per_launch": flops}
         del x, w, z, part
 
     cpu = None
