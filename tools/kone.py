@@ -28,7 +28,11 @@ w = torch.randn((cout, cin, k, k, k), device=dev) * (cin * k ** 3) ** -0.5
 dz = torch.randn((a.B, s, s, s, cout), device=dev)
 wp, wd = ops.pack_weight(w), ops.pack_weight_dgrad(w)
 for _ in range(a.reps):
-    if a.what == "fwd":
+    if a.what == "split":
+        ops.conv3d_split_raw(x, ops.split3_bf16(w.permute(2, 3, 4, 0, 1).contiguous()), cin, cout, True)
+    elif a.what == "bf16":
+        ops.conv3d_bf16_raw(x, ops.pack_weight_bf16(w), cin, cout, True)
+    elif a.what == "fwd":
         ops.conv3d_raw(x, wp, cin, cout, k, True)
     elif a.what == "dgrad":
         ops.conv3d_raw(dz, wd, cout, cin, k, False)
