@@ -350,17 +350,25 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
             __syncthreads();
             if (st + 1 < SNST) load_w(st + 1);
             const u16* ws = Ws + buf * 3 * SWSTAGE;
-#pragma unroll
-            for (int tp = 0; tp < STPS; ++tp) {
+            // explicit software pipeline: the six fragments of tap t+1 are in flight while tap t multiplies
+            bf16x8 fa[2][3], fb[2][3];
+            auto fetch = [&](const int tp, const int slot) {
                 const int arow = a_lane + (st * HH + tp / 3) * HW + tp % 3;
                 const u16* ap = halo + swz(arow, hsel);
-                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(ap);
-                const bf16x8 am = *reinterpret_cast<const bf16x8*>(ap + SHALO);
-                const bf16x8 al = *reinterpret_cast<const bf16x8*>(ap + 2 * SHALO);
                 const u16* bp = ws + swz(tp * 32 + l31, hsel);
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(bp);
-                const bf16x8 bm = *reinterpret_cast<const bf16x8*>(bp + SWSTAGE);
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(bp + 2 * SWSTAGE);
+#pragma unroll
+                for (int part = 0; part < 3; ++part) {
+                    fa[slot][part] = *reinterpret_cast<const bf16x8*>(ap + part * SHALO);
+                    fb[slot][part] = *reinterpret_cast<const bf16x8*>(bp + part * SWSTAGE);
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int tp = 0; tp < STPS; ++tp) {
+                const int cur = tp & 1;
+                if (tp + 1 < STPS) fetch(tp + 1, cur ^ 1);
+                const bf16x8 ah = fa[cur][0], am = fa[cur][1], al = fa[cur][2];
+                const bf16x8 bh = fb[cur][0], bm = fb[cur][1], bl = fb[cur][2];
                 // two independent chains: the 2^-16..2^-8 cross terms, and the leading terms
                 acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc2, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
