@@ -273,7 +273,6 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
     const int b = t / tilesD;
     const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
     const int n0 = blockIdx.y * 32;
-    const size_t wpart = (size_t)27 * Cout * Cin;              // elements per weight part in global memory
 
     int a_lane;
     {
@@ -286,59 +285,78 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
     const float* xb = x + (size_t)b * D * H * W * Cin;
 
+    // ---- brick-invariant addressing, computed ONCE (the staging VALU work was the bottleneck: 970 VALU
+    //      instructions per wave and chunk in the first version, PMC) ----
+    constexpr int HV = (NHALO * 4 + NTHR - 1) / NTHR;       // halo float4 pieces per thread (4 per position)
+    int hoff[HV], hdst[HV];                                   // global element offset (-1 = zero fill), LDS element offset
+#pragma unroll
+    for (int q = 0; q < HV; ++q) {
+        const int e = tid + q * NTHR;
+        const int hp = e >> 2, c4 = e & 3;
+        const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
+        const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+        const bool ok = e < NHALO * 4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+        hoff[q] = ok ? ((gd * H + gh) * W + gw) * Cin + c4 * 4 : -1;
+        hdst[q] = e < NHALO * 4 ? swz(hp, c4 >> 1) + (c4 & 1) * 4 : -1;
+    }
+    constexpr int WV = (3 * STPS * 32 * 2 + NTHR - 1) / NTHR;   // weight 16-B pieces per thread and stage
+    int woff[WV], wdst[WV];
+#pragma unroll
+    for (int q = 0; q < WV; ++q) {
+        const int e = tid + q * NTHR;
+        const int piece = e & 1, row = e >> 1;                // row = (part * STPS + tap_in_stage) * 32 + co
+        const int co = n0 + (row & 31), tp = (row >> 5) % STPS, part = row / (32 * STPS);
+        const bool ok = e < 3 * STPS * 32 * 2 && co < Cout;
+        woff[q] = ok ? part * (27 * Cout * Cin) + (tp * Cout + co) * Cin + piece * 8 : -1;
+        wdst[q] = e < 3 * STPS * 32 * 2 ? swz(row, piece) : -1;
+    }
+    const int wstage_stride = STPS * Cout * Cin;
+
     for (int c0 = 0; c0 < Cin; c0 += SC) {
         if (c0 > 0) __syncthreads();
         // ---- halo: fp32 -> (hi, mid, lo) bf16, three LDS images ----
-        constexpr int HV = (NHALO * 4 + NTHR - 1) / NTHR;       // float4 pieces: 4 per position
         f32x4 hreg[HV];
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
-            const int e = tid + q * NTHR;
-            const int hp = e >> 2, c4 = e & 3;
-            const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
-            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
-            const int c = c0 + c4 * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < NHALO * 4 && c < Cin && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
-                v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c);
+            if (hoff[q] >= 0 && c0 + (tid & 3) * 4 < Cin) v = *reinterpret_cast<const f32x4*>(xb + hoff[q] + c0);
             hreg[q] = v;
         }
         // ---- weights: pre-split on the host, [part][tap][co][ci]; one 16-B piece = 8 input channels ----
-        constexpr int WV = (3 * STPS * 32 * 2 + NTHR - 1) / NTHR;   // 2 pieces per (part, tap, co) row of 16 channels
         u32x4 wreg[WV];
         auto load_w = [&](int st) {
 #pragma unroll
             for (int q = 0; q < WV; ++q) {
-                const int e = tid + q * NTHR;
-                const int piece = e & 1, row = e >> 1;            // row = (part * TPS + tap_in_stage) * 32 + co
-                const int co = n0 + (row & 31), tp = (row >> 5) % STPS, part = row / (32 * STPS);
-                const int tap = st * STPS + tp, ci = c0 + piece * 8;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (e < 3 * STPS * 32 * 2 && co < Cout && ci < Cin)
-                    v = *reinterpret_cast<const u32x4*>(w3 + part * wpart + ((size_t)tap * Cout + co) * Cin + ci);
+                if (woff[q] >= 0 && c0 + (tid & 1) * 8 < Cin)
+                    v = *reinterpret_cast<const u32x4*>(w3 + woff[q] + st * wstage_stride + c0);
                 wreg[q] = v;
             }
         };
         auto store_w = [&](int buf) {
 #pragma unroll
-            for (int q = 0; q < WV; ++q) {
-                const int e = tid + q * NTHR;
-                if (e < 3 * STPS * 32 * 2)
-                    *reinterpret_cast<u32x4*>(Ws + buf * 3 * SWSTAGE + swz(e >> 1, e & 1)) = wreg[q];
-            }
+            for (int q = 0; q < WV; ++q)
+                if (wdst[q] >= 0) *reinterpret_cast<u32x4*>(Ws + buf * 3 * SWSTAGE + wdst[q]) = wreg[q];
         };
         load_w(0);
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
-            const int e = tid + q * NTHR;
-            if (e < NHALO * 4) {
+            if (hdst[q] >= 0) {
+                // exact 3-way split by truncation: a = hi + mid + lo, each with <= 8 significand bits
                 unsigned int hh_[4], mm_[4], ll_[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) split3(hreg[q][u], hh_[u], mm_[u], ll_[u]);
-                u16* dst = halo + swz(e >> 2, (e & 3) >> 1) + (e & 1) * 4;
-                u32x2 ph = {hh_[0] | (hh_[1] << 16), hh_[2] | (hh_[3] << 16)};
-                u32x2 pm = {mm_[0] | (mm_[1] << 16), mm_[2] | (mm_[3] << 16)};
-                u32x2 pl = {ll_[0] | (ll_[1] << 16), ll_[2] | (ll_[3] << 16)};
+                for (int u = 0; u < 4; ++u) {
+                    const float a = hreg[q][u];
+                    const unsigned int hb = __builtin_bit_cast(unsigned int, a) & 0xFFFF0000u;
+                    const float r1 = a - __builtin_bit_cast(float, hb);
+                    const unsigned int mb = __builtin_bit_cast(unsigned int, r1) & 0xFFFF0000u;
+                    const float r2 = r1 - __builtin_bit_cast(float, mb);
+                    hh_[u] = hb; mm_[u] = mb; ll_[u] = __builtin_bit_cast(unsigned int, r2);
+                }
+                u16* dst = halo + hdst[q];
+                u32x2 ph = {(hh_[0] >> 16) | hh_[1], (hh_[2] >> 16) | hh_[3]};
+                u32x2 pm = {(mm_[0] >> 16) | mm_[1], (mm_[2] >> 16) | mm_[3]};
+                u32x2 pl = {(ll_[0] >> 16) | (ll_[1] & 0xFFFF0000u), (ll_[2] >> 16) | (ll_[3] & 0xFFFF0000u)};
                 *reinterpret_cast<u32x2*>(dst) = ph;
                 *reinterpret_cast<u32x2*>(dst + SHALO) = pm;
                 *reinterpret_cast<u32x2*>(dst + 2 * SHALO) = pl;
