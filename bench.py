@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU")
     ap.add_argument("--size", type=int, default=96)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2, help="pairs in the bounded CPU sample")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="pairs in the bounded CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: forward/dgrad 3x3x3 convs on the bf16 matrix cores (BASELINE configs[2] mode; not the headline)")
@@ -174,7 +174,7 @@ def main():
         k_ms = e0.elapsed_time(e1) / reps
         flops = 2.0 * 27 * 32 * 64 * B * s2 ** 3
         ach = flops / (k_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": "conv3d_fwd_kernel<L64,k3,cin32> @conv2.3", "achieved": round(ach, 2),
+        roof = {"bound": "mfma", "kernel": "conv3d_fwd_kernel<FwdCfg<3,16,1,2,8,1,4,8,8,3>> @conv2.3 (B=8, 48^3, 32->64 ch)", "achieved": round(ach, 2),
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                 "traffic": _profiled_traffic(), "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
                 "profiles/r01_pmc_traffic_conv2.3_fwd.json)", "launch_ms": round(k_ms, 4), "flops_per_launch": flops}
@@ -184,11 +184,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tmf_oracle as O         # test infrastructure, used ONLY as the timed CPU baseline
         # MKL-DNN conv3d scales poorly past a few dozen threads (256 SMT threads: 85 s/step vs ~8 s on 8): cap at 32
-        sec, threads = O.cpu_train_step_seconds(args.cpu_batch, S, steps=1, warmup=1,
+        sec, threads = O.cpu_train_step_seconds(args.cpu_batch, S, steps=2, warmup=1,
                                                 threads=min(args.cpu_threads, os.cpu_count()))
         cpu = {"value": round(args.cpu_batch / sec, 4), "unit": "volume-pairs/s", "cores": threads, "kind": "port",
                "sample": f"oracle model_ad train-mode fwd+bwd, batch {args.cpu_batch} of 1x{S}^3 pairs "
-                         f"(1/{max(1, B // args.cpu_batch)} of one batch-{B} step), 1 warm-up + 1 timed step, "
+                         f"(1/{max(1, B // args.cpu_batch)} of one batch-{B} step), 1 warm-up + 2 timed steps, "
                          f"{sec:.2f} s/step, host cpu_count={os.cpu_count()}"}
 
     if rank == 0:
