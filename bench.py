@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: forward/dgrad 3x3x3 convs on the bf16 matrix cores (BASELINE configs[2] mode; not the headline)")
     ap.add_argument("--no-fused-adam", action="store_true")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="skip the train-step timing: only the dominant-kernel loop (so that a rocprofv3 --stats run "
+                         "of this command averages exactly the launches the roofline entry quotes)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the step from a hipGraph (measured slower than eager on ROCm 7.2: 19.7 vs 18.2 ms)")
     args = ap.parse_args()
@@ -130,6 +133,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.roofline_only:
+        args.warmup, args.steps = 1, 1
     for _ in range(args.warmup):
         step()
     fence()
