@@ -133,8 +133,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    loss = torch.zeros((), device=dev)
     if args.roofline_only:
-        args.warmup, args.steps = 1, 1
+        args.warmup, args.steps = 0, 0
     for _ in range(args.warmup):
         step()
     fence()
@@ -142,7 +143,7 @@ def main():
     for _ in range(args.steps):
         loss = step()
     fence()
-    dt = time.perf_counter() - t0
+    dt = max(time.perf_counter() - t0, 1e-9)
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -150,7 +151,7 @@ def main():
     final_loss = loss.item()
     assert final_loss == final_loss, "loss is NaN"
 
-    ms_per_step = dt / args.steps * 1e3
+    ms_per_step = dt / max(args.steps, 1) * 1e3
     pairs_per_s = world * B * args.steps / dt
 
     # ---- roofline of the dominant kernel: conv3d_fwd_kernel (forward + data-gradient = 2/3 of
