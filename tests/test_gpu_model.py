@@ -400,3 +400,21 @@ def test_bf16_conv_precision_mode(name):
     assert err <= 3e-2 * max(1.0, np.abs(ref).max()), err
     assert abs(loss.item() - float(g["f32/train/loss"])) <= 0.1
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_reference_checkpoint_eval_parity():
+    """Load the reference-format checkpoint fixture and reproduce the reference's eval-mode outputs (val_step)."""
+    import os
+    import transmf_ad_amd as T
+    from oracle import params as P
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ck = torch.load(os.path.join(here, "ref_ckpt_ad_tiny.pt"))
+    net = T.model_ad(dim=32, depth=2, heads=4, dim_head=8, mlp_dim=128, dropout=0.)
+    net.load_state_dict({k: v.float() if v.dtype == torch.float16 else v for k, v in ck["net_model"].items()}, strict=True)
+    net = net.to(DEV).eval()
+    mri, pet, _ = (torch.from_numpy(a).to(DEV) for a in P.make_inputs(2, (32, 32, 32), seed=1234))
+    with torch.no_grad():
+        lo, dm, dp = net(mri, pet)
+    ref = np.load(os.path.join(here, "ref_ckpt_ad_tiny_eval.npz"))
+    for got, k in ((lo, "logits"), (dm, "d_mri"), (dp, "d_pet")):
+        assert np.abs(got.cpu().numpy() - ref[k]).max() <= TOL, k

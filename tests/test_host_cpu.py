@@ -109,3 +109,17 @@ def test_revgrad():
     assert torch.equal(y, x)
     y.sum().backward()
     assert torch.equal(x.grad, torch.full_like(x, -2.0))
+
+
+def test_reference_checkpoint_loads_strict():
+    """A checkpoint written from the imported reference (tests/golden/make_ref_checkpoint.py, the mapping ignite's
+    Checkpoint stores: {'net_model': state_dict}) loads into the drop-in class with strict=True."""
+    import transmf_ad_amd as T
+    ck = torch.load(os.path.join(ROOT, "tests", "golden", "ref_ckpt_ad_tiny.pt"))
+    sd = {k: v.float() if v.dtype == torch.float16 else v for k, v in ck["net_model"].items()}
+    net = T.model_ad(dim=32, depth=2, heads=4, dim_head=8, mlp_dim=128, dropout=0.)
+    missing, unexpected = net.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    assert int(net.D[1].num_batches_tracked) == 2 and int(net.fc_cls[1].num_batches_tracked) == 1
+    # and back: our state_dict is loadable by anything expecting the reference's keys
+    assert list(net.state_dict().keys()) == list(sd.keys())
