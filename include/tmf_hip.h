@@ -77,6 +77,11 @@ int    tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void* worksp
 int  tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z, float* stat_partial,
                          int B, int D, int H, int W, int cin, int cout, void* stream);
 int  tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W);
+/* Weight gradient on the bf16 matrix cores (x and dz rounded to bf16 while staged, fp32 accumulation, fp32 dw
+ * [27][cin][cout]); workspace as tmf_conv3d_wgrad. */
+size_t tmf_conv3d_wgrad_bf16_workspace_bytes(int B, int D, int H, int W, int cin, int cout);
+int    tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
+                             int B, int D, int H, int W, int cin, int cout, void* stream);
 /* fp32-ACCURATE variant on the bf16 matrix cores: operands split exactly into three bf16 numbers (hi+mid+lo), the
  * six partial products of order >= 2^-16 accumulated in fp32 (the dropped terms are below one fp32 ulp of the
  * product).  w3_bf16: bf16 [3 parts][27][cout][cin]; same shapes / statistics layout as tmf_conv3d_fwd_bf16. */

@@ -368,6 +368,29 @@ def test_conv3d_bf16_mfma(shape):
         assert _relerr(_ncdhw(dx.cpu()), xr.grad) < 2e-6
 
 
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+def test_conv3d_wgrad_bf16_mfma(shape):
+    """bf16 matrix-core weight gradient: operands that ARE bf16 numbers give exact products, so the result is held
+    to fp32-accumulation accuracy against fp64; general fp32 operands are rounded in the kernel exactly as torch's
+    .bfloat16() does (bit-identical result), and stay within bf16-operand accuracy of the fp32 gradient."""
+    ops = _ops()
+    B, D, H, W, cin, cout = shape
+    x = _rand(B, cin, D, H, W, seed=81)
+    dz = _rand(B, cout, D, H, W, seed=82)
+    xb, dzb = x.bfloat16().float(), dz.bfloat16().float()
+    wr = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(xb.double(), wr, padding=1).backward(dzb.double())
+    dw = ops.conv3d_wgrad_bf16(_ndhwc(xb).to(DEV), _ndhwc(dzb).to(DEV), cin, cout)
+    torch.cuda.synchronize()
+    got = ops.unpack_wgrad(dw, cout, cin, 3).cpu()
+    assert _relerr(got, wr.grad) < 5e-6
+    dw2 = ops.conv3d_wgrad_bf16(_ndhwc(x).to(DEV), _ndhwc(dz).to(DEV), cin, cout)
+    assert torch.equal(dw2, dw)
+    wr2 = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x.double(), wr2, padding=1).backward(dz.double())
+    assert _relerr(got, wr2.grad) < 1e-2
+
+
 def test_block_in_bf16_mode():
     """A full sNet block with the bf16 conv precision: forward and gradients within bf16-operand accuracy of fp64."""
     ops = _ops()

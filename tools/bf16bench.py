@@ -20,3 +20,7 @@ for name, cin, cout, k, div, pool in LAYERS:
     t3 = timeit(lambda: ops.conv3d_split_raw(x, w3, cin, cout, True), 10)
     gb = (x.numel() + 8 * s ** 3 * cout) * 4 / 1e9
     print(f"{name}: fp32 {t32:.3f} ms ({fl/t32/1e9:6.1f} TF)   bf16 {t16:.3f} ms ({fl/t16/1e9:6.1f} TF, {gb/t16*1e3:5.0f} GB/s algorithmic)   fp32x(split) {t3:.3f} ms ({fl/t3/1e9:6.1f} TF-equivalent)", flush=True)
+    dz = torch.randn((8, s, s, s, cout), device=dev)
+    tw32 = timeit(lambda: ops.conv3d_wgrad(x, dz, cin, cout, 3), 10)
+    tw16 = timeit(lambda: ops.conv3d_wgrad_bf16(x, dz, cin, cout), 10)
+    print(f"{name}: wgrad fp32 {tw32:.3f} ms ({fl/tw32/1e9:6.1f} TF)   bf16 {tw16:.3f} ms ({fl/tw16/1e9:6.1f} TF)", flush=True)

@@ -429,6 +429,153 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient on the bf16 matrix cores:  dw[tap][ci][co] = sum_v x[v + tap][ci] * dz[v][co],  M = ci, N = co,
+// K = voxels.  The 32x32x16 MFMA wants 8 consecutive k per lane, i.e. 8 VOXELS of one channel, so both operands are
+// staged TRANSPOSED (channel-major, one brick row of 8 voxels = one 16-B fragment) while they are rounded to bf16.
+// A tap shift along w would misalign those 16-B runs, so x is kept as THREE images pre-shifted by kw = 0, 1, 2
+// (the thread that transposes a halo row holds its 10 values and writes the three 8-value windows); shifts along
+// d / h are plain row offsets.  Per-channel pitches of 61 / 33 sixteen-byte slots (odd) make both fragment reads
+// conflict-free.  Taps are spread over the waves exactly as in the fp32 kernel (7 per SIMD, 4 + 3 per wave pair).
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WG_XP = 61 * 8;                         // bf16 per input channel in one shifted image (60 halo rows + pad)
+constexpr int WG_XIMG = 32 * WG_XP;
+constexpr int WG_DP = 33 * 8;                         // bf16 per output channel (32 brick rows + pad)
+constexpr size_t WG_LDS_BYTES = (size_t)(3 * WG_XIMG + 32 * WG_DP) * 2;
+
+__global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_kernel(
+    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
+    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles, int tiles_per_split) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* xT = reinterpret_cast<u16*>(smem_raw);               // [3 shifts][32 ci][61 rows][8]
+    u16* dzT = xT + 3 * WG_XIMG;                              // [32 co][33 rows][8]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int split = blockIdx.x;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32;
+
+    const int tap_base = 7 * (wave & 3) + 4 * (wave >> 2);    // waves w and w+4 share a SIMD: 7 taps per SIMD
+    const int tap_cnt = wave < 4 ? 4 : 3;
+    int a_off[4];                                             // element offset of tap t's fragment at k-step 0
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        int tap = tap_base + t;
+        tap = tap > 26 ? 26 : tap;
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        a_off[t] = kw * WG_XIMG + l31 * WG_XP + (kd * HH + kh + hsel) * 8;
+    }
+    const int b_off = l31 * WG_DP + hsel * 8;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int tile_begin = split * tiles_per_split;
+    int tile_end = tile_begin + tiles_per_split;
+    if (tile_end > ntiles) tile_end = ntiles;
+    const bool ci_ok = ci0 + l31 < Cin, co_ok = co0 + l31 < Cout;
+
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        int tt = tile;
+        const int tw = tt % tilesW; tt /= tilesW;
+        const int th = tt % tilesH; tt /= tilesH;
+        const int td = tt % tilesD;
+        const int b = tt / tilesD;
+        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+        const float* xb = x + (size_t)b * D * H * W * Cin + ci0 + l31;
+        const float* dzb = dz + (size_t)b * D * H * W * Cout + co0 + l31;
+        __syncthreads();                                       // previous brick fully consumed
+        // ---- x halo rows -> three shifted, transposed bf16 images.  task = (halo row, ci): lanes = channels ----
+        for (int task = tid; task < HD * HH * 32; task += NTHR) {
+            const int hrow = task >> 5;
+            const int hd = hrow / HH, hh = hrow % HH;
+            const int gd = d0 + hd - 1, gh = h0 + hh - 1;
+            const bool rv = ci_ok && gd >= 0 && gd < D && gh >= 0 && gh < H;
+            float v[HW];
+#pragma unroll
+            for (int q = 0; q < HW; ++q) {
+                const int gw = w0 + q - 1;
+                v[q] = (rv && gw >= 0 && gw < W) ? xb[((size_t)(gd * H + gh) * W + gw) * Cin] : 0.f;
+            }
+            unsigned int pk[HW - 1];                           // pk[q] = bf16(v[q]) | bf16(v[q+1]) << 16
+#pragma unroll
+            for (int q = 0; q < HW - 1; ++q) pk[q] = pack_bf16(v[q], v[q + 1]);
+            u16* dst = xT + l31 * WG_XP + hrow * 8;
+#pragma unroll
+            for (int sft = 0; sft < 3; ++sft) {
+                u32x4 o = {pk[sft], pk[sft + 2], pk[sft + 4], pk[sft + 6]};
+                *reinterpret_cast<u32x4*>(dst + sft * WG_XIMG) = o;
+            }
+        }
+        // ---- dz brick rows -> transposed bf16 image.  task = (brick row, co) ----
+        for (int task = tid; task < TD * TH * 32; task += NTHR) {
+            const int row = task >> 5;
+            const int gd = d0 + row / TH, gh = h0 + row % TH;
+            const bool rv = co_ok && gd < D && gh < H;
+            float v[TW];
+#pragma unroll
+            for (int q = 0; q < TW; ++q)
+                v[q] = (rv && w0 + q < W) ? dzb[((size_t)(gd * H + gh) * W + w0 + q) * Cout] : 0.f;
+            u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+            *reinterpret_cast<u32x4*>(dzT + l31 * WG_DP + row * 8) = o;
+        }
+        __syncthreads();
+
+        auto mma = [&](auto ntaps_c) {
+            constexpr int NTAPS = decltype(ntaps_c)::value;
+#pragma unroll 4
+            for (int ks = 0; ks < TD * TH / 2; ++ks) {        // 16 voxels per step: brick rows 2*ks and 2*ks + 1
+                const int d = ks / (TH / 2), hp = (ks % (TH / 2)) * 2;
+                const bf16x8 bv = *reinterpret_cast<const bf16x8*>(dzT + b_off + (d * TH + hp) * 8);
+                const int xrow = (d * HH + hp) * 8;
+                bf16x8 av[NTAPS];
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t) av[t] = *reinterpret_cast<const bf16x8*>(xT + a_off[t] + xrow);
+#pragma unroll
+                for (int t = 0; t < NTAPS; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[t], bv, acc[t], 0, 0, 0);
+            }
+        };
+        if (wave < 4) mma(std::integral_constant<int, 4>{});
+        else mma(std::integral_constant<int, 3>{});
+    }
+
+    // partial[split][tap][ci][co]; D fragment: row = ci, column = co
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tap = tap_base + t;
+        if (t < tap_cnt && tap < 27) {
+            const int co = co0 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                if (ci < Cin && co < Cout)
+                    partial[(((size_t)split * 27 + tap) * Cin + ci) * Cout + co] = acc[t][r];
+            }
+        }
+    }
+}
+
+struct WgBfPlan { int tilesD, tilesH, tilesW, ntiles, gy, gz, tps, nsplit; };
+WgBfPlan plan_wgrad_bf16(int B, int D, int H, int W, int cin, int cout) {
+    WgBfPlan p;
+    p.tilesD = tmf_cdiv(D, TD); p.tilesH = tmf_cdiv(H, TH); p.tilesW = tmf_cdiv(W, TW);
+    p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
+    p.gy = tmf_cdiv(cin, 32); p.gz = tmf_cdiv(cout, 32);
+    int want = 512 / (p.gy * p.gz);
+    if (want < 1) want = 1;
+    if (want > p.ntiles) want = p.ntiles;
+    p.tps = tmf_cdiv(p.ntiles, want);
+    p.nsplit = tmf_cdiv(p.ntiles, p.tps);
+    return p;
+}
+
 }  // namespace
 
 extern "C" int tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W) {
@@ -474,4 +621,32 @@ extern "C" int tmf_conv3d_fwd_split(const float* x, const void* w3_bf16, float* 
                        (hipStream_t)stream, x, (const u16*)w3_bf16, z, stat_partial, D, H, W, cin, cout,
                        tD, tH, tW, ntiles);
     return tmf_launch_result("tmf_conv3d_fwd_split");
+}
+
+extern "C" size_t tmf_conv3d_wgrad_bf16_workspace_bytes(int B, int D, int H, int W, int cin, int cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
+    const WgBfPlan p = plan_wgrad_bf16(B, D, H, W, cin, cout);
+    return (size_t)(p.nsplit + tmf_reduce_groups(p.nsplit)) * 27 * cin * cout * 4;
+}
+
+extern "C" int tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
+                                     int B, int D, int H, int W, int cin, int cout, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(dz); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
+                "tmf_conv3d_wgrad_bf16: non-positive dimension");
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
+                "tmf_conv3d_wgrad_bf16: one sample exceeds 2^31 elements");
+    const size_t need = tmf_conv3d_wgrad_bf16_workspace_bytes(B, D, H, W, cin, cout);
+    TMF_REQUIRE(workspace_bytes >= need, TMF_E_WORKSPACE, "tmf_conv3d_wgrad_bf16: workspace %zu B < required %zu B",
+                workspace_bytes, need);
+    const WgBfPlan p = plan_wgrad_bf16(B, D, H, W, cin, cout);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = tmf_allow_lds(conv3d_wgrad_bf16_kernel, WG_LDS_BYTES, "tmf_conv3d_wgrad_bf16"))) return rc;
+    float* partial = (float*)workspace;
+    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel, dim3(p.nsplit, p.gy, p.gz), dim3(NTHR), WG_LDS_BYTES, s, x, dz, partial,
+                       D, H, W, cin, cout, p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);
+    if ((rc = tmf_launch_result("tmf_conv3d_wgrad_bf16"))) return rc;
+    const long n = 27L * cin * cout;
+    return tmf_reduce_slabs(partial, p.nsplit, n, partial + (size_t)p.nsplit * n, dw, s, "tmf_conv3d_wgrad_bf16(reduce)");
 }

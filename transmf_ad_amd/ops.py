@@ -131,6 +131,17 @@ def conv3d_raw(x, w_packed, cin, cout, ksize, want_stats):
     return z, part, nblk
 
 
+def conv3d_wgrad_bf16(x, dz, cin, cout):
+    """tap-major weight gradient [27][cin][cout] on the bf16 matrix cores (operands rounded to bf16)."""
+    B, D, H, W = x.shape[:4]
+    dw = torch.empty((27, cin, cout), device=x.device, dtype=_f32)
+    nbytes = _lib.query("tmf_conv3d_wgrad_bf16_workspace_bytes", B, D, H, W, cin, cout)
+    ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=_f32)
+    _lib.call("tmf_conv3d_wgrad_bf16", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
+              B, D, H, W, cin, cout, _stream())
+    return dw
+
+
 def conv3d_wgrad(x, dz, cin, cout, ksize):
     """tap-major weight gradient [k^3][cin][cout]."""
     B, D, H, W = x.shape[:4]
@@ -234,7 +245,10 @@ class ConvBnActPool(torch.autograd.Function):
                   mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dz.data_ptr(), B, D, H, W, cout, pc, slope, s)
         dweight = None
         if ctx.needs_input_grad[1]:
-            dweight = unpack_wgrad(conv3d_wgrad(x, dz, cin, cout, k), cout, cin, k)
+            if ctx.bf16 == "bf16":
+                dweight = unpack_wgrad(conv3d_wgrad_bf16(x, dz, cin, cout), cout, cin, k)
+            else:
+                dweight = unpack_wgrad(conv3d_wgrad(x, dz, cin, cout, k), cout, cin, k)
         dx = None
         if ctx.needs_input_grad[0]:
             if ctx.bf16 == "bf16" and cout % 8 == 0:
