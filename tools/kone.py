@@ -32,6 +32,8 @@ for _ in range(a.reps):
         ops.conv3d_split_raw(x, ops.split3_bf16(w.permute(2, 3, 4, 0, 1).contiguous()), cin, cout, True)
     elif a.what == "bf16":
         ops.conv3d_bf16_raw(x, ops.pack_weight_bf16(w), cin, cout, True)
+    elif a.what == "wgrad16":
+        ops.conv3d_wgrad_bf16(x, dz, cin, cout)
     elif a.what == "fwd":
         ops.conv3d_raw(x, wp, cin, cout, k, True)
     elif a.what == "dgrad":

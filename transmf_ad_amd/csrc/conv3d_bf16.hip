@@ -73,8 +73,10 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
     // LDS element offsets (bf16 units) of this lane's fragments
     int a_lane;
     {
-        const int p = wave * 32 + l31;
-        const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+        // wave = brick row h, lane = (d, w) with d in the two LOW bits: with the 80-B row pitch this is the mapping
+        // for which every 16-lane service group of ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}) lands on
+        // 16 distinct 16-B slots, for every tap offset (the 4 x 8 (h, w) mapping is 2-3-way conflicted)
+        const int pd = l31 & 3, pw = l31 >> 2, ph = wave;
         a_lane = ((pd * HH + ph) * HW + pw) * RP + hsel * 8;
     }
     const int b_lane = l31 * RP + hsel * 8;
@@ -174,8 +176,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
         constexpr bool FULL = decltype(full_c)::value;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int p = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-            const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+            const int pd = r & 3, pw = 2 * (r >> 2) + hsel, ph = wave;      // fragment row i -> (d = i & 3, w = i >> 2)
             const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
             const bool pv = FULL || (gd < D && gh < H && gw < W);
             const int off = ((gd * H + gh) * W + gw) * Cout;
@@ -276,8 +277,9 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
 
     int a_lane;
     {
-        const int p = wave * 32 + l31;
-        const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+        // wave = brick row h, lane = (d low bits, w): the mapping whose ds_read_b128 service groups are
+        // conflict-free with the bit-3 swizzle for every tap (searched exhaustively; see conv3d_fwd_bf16_kernel)
+        const int pd = l31 & 3, pw = l31 >> 2, ph = wave;
         a_lane = (pd * HH + ph) * HW + pw;                      // halo ROW of this lane's voxel (tap (0,0,0))
     }
     f32x16 acc, acc2;
@@ -404,8 +406,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_fwd_split_kernel(
     const int co = n0 + l31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int p = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-        const int pw = p % TW, ph = (p / TW) % TH, pd = p / (TW * TH);
+        const int pd = r & 3, pw = 2 * (r >> 2) + hsel, ph = wave;
         const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
         if (gd < D && gh < H && gw < W && co < Cout) {
             const float v = acc[r];
@@ -481,7 +482,12 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_kernel(
     if (tile_end > ntiles) tile_end = ntiles;
     const bool ci_ok = ci0 + l31 < Cin, co_ok = co0 + l31 < Cout;
 
-    for (int tile = tile_begin; tile < tile_end; ++tile) {
+    // Global loads of brick n+1 are issued into registers before the MFMA loop of brick n (the kernel was latency-
+    // bound on its staging: 19k cycles per brick against 3.5k of MFMA); conversion + LDS writes follow the loop.
+    constexpr int XQ = (HD * HH * 32 + NTHR - 1) / NTHR;      // 4 (halo row, ci) tasks per thread
+    constexpr int DQ = TD * TH * 32 / NTHR;                   // 2 (brick row, co) tasks per thread
+    float xv[XQ][HW], dv[DQ][TW];
+    auto fetch = [&](int tile) {
         int tt = tile;
         const int tw = tt % tilesW; tt /= tilesW;
         const int th = tt % tilesH; tt /= tilesH;
@@ -490,42 +496,60 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_kernel(
         const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
         const float* xb = x + (size_t)b * D * H * W * Cin + ci0 + l31;
         const float* dzb = dz + (size_t)b * D * H * W * Cout + co0 + l31;
-        __syncthreads();                                       // previous brick fully consumed
-        // ---- x halo rows -> three shifted, transposed bf16 images.  task = (halo row, ci): lanes = channels ----
-        for (int task = tid; task < HD * HH * 32; task += NTHR) {
-            const int hrow = task >> 5;
+#pragma unroll
+        for (int i = 0; i < XQ; ++i) {
+            const int hrow = (tid + i * NTHR) >> 5;
             const int hd = hrow / HH, hh = hrow % HH;
             const int gd = d0 + hd - 1, gh = h0 + hh - 1;
-            const bool rv = ci_ok && gd >= 0 && gd < D && gh >= 0 && gh < H;
-            float v[HW];
+            const bool rv = ci_ok && hrow < HD * HH && gd >= 0 && gd < D && gh >= 0 && gh < H;
+            const float* src = xb + (size_t)(gd * H + gh) * W * Cin;
 #pragma unroll
             for (int q = 0; q < HW; ++q) {
                 const int gw = w0 + q - 1;
-                v[q] = (rv && gw >= 0 && gw < W) ? xb[((size_t)(gd * H + gh) * W + gw) * Cin] : 0.f;
-            }
-            unsigned int pk[HW - 1];                           // pk[q] = bf16(v[q]) | bf16(v[q+1]) << 16
-#pragma unroll
-            for (int q = 0; q < HW - 1; ++q) pk[q] = pack_bf16(v[q], v[q + 1]);
-            u16* dst = xT + l31 * WG_XP + hrow * 8;
-#pragma unroll
-            for (int sft = 0; sft < 3; ++sft) {
-                u32x4 o = {pk[sft], pk[sft + 2], pk[sft + 4], pk[sft + 6]};
-                *reinterpret_cast<u32x4*>(dst + sft * WG_XIMG) = o;
+                xv[i][q] = (rv && gw >= 0 && gw < W) ? src[(size_t)gw * Cin] : 0.f;
             }
         }
-        // ---- dz brick rows -> transposed bf16 image.  task = (brick row, co) ----
-        for (int task = tid; task < TD * TH * 32; task += NTHR) {
-            const int row = task >> 5;
+#pragma unroll
+        for (int i = 0; i < DQ; ++i) {
+            const int row = (tid + i * NTHR) >> 5;
             const int gd = d0 + row / TH, gh = h0 + row % TH;
             const bool rv = co_ok && gd < D && gh < H;
-            float v[TW];
+            const float* src = dzb + (size_t)(gd * H + gh) * W * Cout;
 #pragma unroll
-            for (int q = 0; q < TW; ++q)
-                v[q] = (rv && w0 + q < W) ? dzb[((size_t)(gd * H + gh) * W + w0 + q) * Cout] : 0.f;
-            u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+            for (int q = 0; q < TW; ++q) dv[i][q] = (rv && w0 + q < W) ? src[(size_t)(w0 + q) * Cout] : 0.f;
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < XQ; ++i) {
+            const int hrow = (tid + i * NTHR) >> 5;
+            if (hrow < HD * HH) {
+                unsigned int pk[HW - 1];                       // pk[q] = bf16(v[q]) | bf16(v[q+1]) << 16
+#pragma unroll
+                for (int q = 0; q < HW - 1; ++q) pk[q] = pack_bf16(xv[i][q], xv[i][q + 1]);
+                u16* dst = xT + l31 * WG_XP + hrow * 8;
+#pragma unroll
+                for (int sft = 0; sft < 3; ++sft) {
+                    u32x4 o = {pk[sft], pk[sft + 2], pk[sft + 4], pk[sft + 6]};
+                    *reinterpret_cast<u32x4*>(dst + sft * WG_XIMG) = o;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < DQ; ++i) {
+            const int row = (tid + i * NTHR) >> 5;
+            u32x4 o = {pack_bf16(dv[i][0], dv[i][1]), pack_bf16(dv[i][2], dv[i][3]), pack_bf16(dv[i][4], dv[i][5]),
+                       pack_bf16(dv[i][6], dv[i][7])};
             *reinterpret_cast<u32x4*>(dzT + l31 * WG_DP + row * 8) = o;
         }
+    };
+
+    if (tile_begin < tile_end) fetch(tile_begin);
+    for (int tile = tile_begin; tile < tile_end; ++tile) {
+        __syncthreads();                                       // previous brick fully consumed
+        commit();
         __syncthreads();
+        if (tile + 1 < tile_end) fetch(tile + 1);
 
         auto mma = [&](auto ntaps_c) {
             constexpr int NTAPS = decltype(ntaps_c)::value;

@@ -49,6 +49,7 @@ struct FwdCfg {
     static constexpr int RED = NW * 32 * NT * 2;         // cross-wave stat scratch (floats)
     static constexpr size_t LDS_BYTES = (size_t)(NHALO * CP + 2 * BSTAGE + RED) * 4;
     static_assert(NPOS == 32 * MT * WM, "brick must be MT*WM tiles of 32 voxels");
+    static_assert(TD == 4 && (TW == 8 || TW == 4) && TH * TW == 8 * MT * WM, "lane mapping: 4 planes x 8 (h, w) per tile");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves per workgroup");
     static_assert(CINC % 8 == 0, "cin chunk is a multiple of 8");
     static_assert(NTAPS % TPS == 0, "taps per stage must divide the tap count");
@@ -86,8 +87,12 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
     int a_lane[C::MT];
 #pragma unroll
     for (int i = 0; i < C::MT; ++i) {
-        const int p = (wm * C::MT + i) * 32 + l31;
-        const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
+        // M-tile T covers all TD = 4 planes of 8 / TW brick rows; lane = (d in the two LOW bits, then w, then h).
+        // With the odd 16-B-slot row pitch this is the mapping whose ds_read_b128 service groups ({0-3,12-15,20-27},
+        // {4-11,16-19,28-31} per half-wave) hit 16 distinct slots for every tap offset; the natural (h, w) raster
+        // is 3-way conflicted (exhaustive search over bit permutations).
+        const int T = wm * C::MT + i, rest = l31 >> 2;
+        const int pd = l31 & 3, pw = rest % C::TW, ph = T * (8 / C::TW) + rest / C::TW;
         a_lane[i] = ((pd * C::HH + ph) * C::HW + pw) * C::CP + hsel * 4;
     }
     const int b_lane = hsel * 4 * C::NB + wn * C::NT * 32 + l31;
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
         for (int i = 0; i < C::MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int p = (wm * C::MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-                const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
+                const int T = wm * C::MT + i, rest = 2 * (r >> 2) + hsel;            // fragment row -> (d, w, h) as a_lane
+                const int pd = r & 3, pw = rest % C::TW, ph = T * (8 / C::TW) + rest / C::TW;
                 const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
                 const bool pv = FULL || (gd < D && gh < H && gw < W);
                 const int off = ((gd * H + gh) * W + gw) * Cout;
