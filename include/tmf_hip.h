@@ -181,12 +181,41 @@ int tmf_xattn_bwd(const float* q, const float* k, const float* v, const float* o
  * LayerNorm over the last dim (networks.py:117,219) and the token pooling of
  * CrossTransformer_MOD_AVG.forward (networks.py:276-281).
  * ---------------------------------------------------------------------------- */
-int tmf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+/* y = LayerNorm(x) * gamma + beta (+ residual, [rows][dim], may be NULL: the "+ tokens" of networks.py:262-263). */
+int tmf_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                       float* mean, float* rstd, int rows, int dim, float eps, void* stream);
 int tmf_layernorm_bwd_blocks(int rows, int dim);
 /* partial: [nblk][2][dim] (dgamma, dbeta partials; reduce with tmf_colsum_finalize, ncol = 2*dim). */
 int tmf_layernorm_bwd(const float* x, const float* gamma, const float* mean, const float* rstd,
                       const float* dy, float* dx, float* partial, int rows, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * Linear layers of the fusion transformer fused with their neighbours (token_gemm.hip): one launch per
+ * nn.Linear, 16-row token tiles, exact-fp32 MFMA.  Replaces, per Transformer block, F.layer_norm + F.linear
+ * (networks.py:117-121 with 158-159, 219), to_out + bias + residual (:160-163, 226), Linear + GELU + Linear +
+ * residual (:131-141, 227), and the matching backward passes.
+ *
+ * forward:  y = [GELU]( LayerNorm?(x) . w^T + bias ) + residual
+ *   x [R][K], w [Nout][K] (nn.Linear layout), y [R][Nout]; K % 16 == 0, Nout % 128 == 0.
+ *   ln_gamma != NULL: LayerNorm over K first (K must be 128); writes ln_mean / ln_rstd [R] and, when
+ *   ln_out != NULL, the normalised rows [R][K].  bias [Nout] and residual [R][Nout] may be NULL.
+ *   gelu_pre != NULL: gelu_pre = (..) . w^T + bias and y = GELU(gelu_pre) (erf form); no residual then.
+ * backward (input gradient):  dx = E( dy . w ),  dy [R][Nout], w [Nout][K], dx [R][K]; Nout % 16 == 0, K % 128 == 0.
+ *   gelu_pre != NULL: E(v) = v * GELU'(gelu_pre), gelu_pre [R][K].
+ *   ln_x != NULL (K == 128): E(v) = LayerNormBackward(v; ln_x, ln_mean, ln_rstd, ln_gamma) + add1 + add2, and the
+ *   row-block partials of dgamma / dbeta go to ln_partial[blk * partial_stride + {0..127 | 128..255}].
+ *   otherwise E(v) = v + add1.   add1 / add2 [R][K] may be NULL.
+ *   bias_partial != NULL: column sums of the block's dy rows -> bias_partial[blk * partial_stride + c], c < Nout.
+ *   blk < tmf_tok_row_blocks(R); reduce the partials with tmf_colsum_finalize(partial, nblk, partial_stride, ..).
+ * ---------------------------------------------------------------------------- */
+int tmf_tok_row_blocks(int R);
+int tmf_tok_linear_fwd(const float* x, const float* w, const float* bias, const float* residual, float* y,
+                       int R, int K, int Nout, const float* ln_gamma, const float* ln_beta, float eps,
+                       float* ln_mean, float* ln_rstd, float* ln_out, float* gelu_pre, void* stream);
+int tmf_tok_linear_bwd_input(const float* dy, const float* w, float* dx, int R, int Nout, int K,
+                             const float* gelu_pre, const float* ln_x, const float* ln_mean, const float* ln_rstd,
+                             const float* ln_gamma, const float* add1, const float* add2, float* ln_partial,
+                             float* bias_partial, int partial_stride, void* stream);
 
 /* cls[b] = [mean_n mri | mean_n pet | max_n mri | max_n pet]  (4*dim); argmax: int32 [B][2][dim]. */
 int tmf_token_pool_fwd(const float* mri, const float* pet, float* cls, int32_t* argmax,

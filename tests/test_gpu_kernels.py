@@ -463,3 +463,104 @@ def test_split_exact_on_integers():
     w3 = ops.split3_bf16(w.to(DEV).permute(2, 3, 4, 0, 1).contiguous())
     z, _, _ = ops.conv3d_split_raw(_ndhwc(x).to(DEV), w3, cin, cout, False)
     assert torch.equal(_ncdhw(z.cpu()), ref)
+
+
+# ---------------------------------------------------------------------------------------------------
+# fused transformer-block linears (csrc/token_gemm.hip)
+# ---------------------------------------------------------------------------------------------------
+
+def _gelu64(h):
+    return 0.5 * h * (1 + torch.erf(h / 2 ** 0.5))
+
+
+@pytest.mark.parametrize("R", [1728, 50])
+def test_tok_linear_fwd_variants(R):
+    ops = _ops()
+    x = _rand(R, 128, seed=91)
+    w = _rand(256, 128, seed=92, scale=128 ** -0.5)
+    b = _rand(256, seed=93, scale=0.1)
+    res = _rand(R, 256, seed=94)
+    g, be = 1 + _rand(128, seed=95, scale=0.1), _rand(128, seed=96, scale=0.1)
+    xd, wd = x.double(), w.double()
+    y, _, _ = ops.tok_linear_fwd(x.to(DEV), w.to(DEV))
+    assert _relerr(y.cpu(), xd @ wd.t()) < 2e-6
+    y, _, _ = ops.tok_linear_fwd(x.to(DEV), w.to(DEV), bias=b.to(DEV), residual=res.to(DEV))
+    assert _relerr(y.cpu(), xd @ wd.t() + b.double() + res.double()) < 2e-6
+    ln = F.layer_norm(xd, (128,), g.double(), be.double(), 1e-5)
+    y, (mean, rstd, a), _ = ops.tok_linear_fwd(x.to(DEV), w.to(DEV), ln=(g.to(DEV), be.to(DEV), 1e-5), keep_ln_out=True)
+    assert _relerr(a.cpu(), ln) < 2e-6 and _relerr(y.cpu(), ln @ wd.t()) < 2e-6
+    assert _relerr(mean.cpu(), xd.mean(1)) < 2e-6
+    assert _relerr(rstd.cpu(), (xd.var(1, unbiased=False) + 1e-5).rsqrt()) < 2e-6
+    y, _, pre = ops.tok_linear_fwd(x.to(DEV), w.to(DEV), bias=b.to(DEV), ln=(g.to(DEV), be.to(DEV), 1e-5), gelu=True)
+    h = ln @ wd.t() + b.double()
+    assert _relerr(pre.cpu(), h) < 2e-6 and _relerr(y.cpu(), _gelu64(h)) < 2e-6
+    # K = 512 -> 128 (second FeedForward linear)
+    x5, w5 = _rand(R, 512, seed=97), _rand(128, 512, seed=98, scale=512 ** -0.5)
+    y, _, _ = ops.tok_linear_fwd(x5.to(DEV), w5.to(DEV), bias=b[:128].to(DEV), residual=res[:, :128].contiguous().to(DEV))
+    assert _relerr(y.cpu(), x5.double() @ w5.double().t() + b[:128].double() + res[:, :128].double()) < 2e-6
+
+
+@pytest.mark.parametrize("R", [1728, 50])
+def test_tok_linear_bwd_input_variants(R):
+    ops = _ops()
+    from transmf_ad_amd import _lib as lib
+    nblk = lib.query("tmf_tok_row_blocks", R)
+    # plain + bias column sums:  dy [R][256] . w [256][128]
+    dy = _rand(R, 256, seed=101)
+    w = _rand(256, 128, seed=102, scale=0.1)
+    add1, add2 = _rand(R, 128, seed=103), _rand(R, 128, seed=104)
+    stride = 256 + 256
+    part = torch.zeros((nblk, stride), device=DEV)
+    dx = ops.tok_linear_bwd_input(dy.to(DEV), w.to(DEV), add1=add1.to(DEV), bias_partial=(part, 256), partial_stride=stride)
+    assert _relerr(dx.cpu(), dy.double() @ w.double() + add1.double()) < 2e-6
+    assert _relerr(part.sum(0)[256:].cpu(), dy.double().sum(0)) < 1e-5
+    # GELU' epilogue:  dy [R][128] . w [128][512] * gelu'(h)
+    dy2, w2, h = _rand(R, 128, seed=105), _rand(128, 512, seed=106, scale=0.1), _rand(R, 512, seed=107)
+    hd = h.double().requires_grad_(True)
+    _gelu64(hd).backward(dy2.double() @ w2.double())
+    dx = ops.tok_linear_bwd_input(dy2.to(DEV), w2.to(DEV), gelu_pre=h.to(DEV))
+    assert _relerr(dx.cpu(), hd.grad) < 2e-6
+    # LayerNorm-backward epilogue + two residual gradients + parameter partials
+    x = _rand(R, 128, seed=108)
+    g = 1 + _rand(128, seed=109, scale=0.1)
+    xd = x.double().requires_grad_(True)
+    gd = g.double().requires_grad_(True)
+    bd = torch.zeros(128, dtype=torch.float64, requires_grad=True)
+    F.layer_norm(xd, (128,), gd, bd, 1e-5).backward(dy.double() @ w.double())
+    mean = x.double().mean(1)
+    rstd = (x.double().var(1, unbiased=False) + 1e-5).rsqrt()
+    part = torch.zeros((nblk, stride), device=DEV)
+    dx = ops.tok_linear_bwd_input(dy.to(DEV), w.to(DEV), ln=(x.to(DEV), mean.float().to(DEV), rstd.float().to(DEV), g.to(DEV)),
+                                  add1=add1.to(DEV), add2=add2.to(DEV), ln_partial=(part, 0), partial_stride=stride)
+    assert _relerr(dx.cpu(), xd.grad + add1.double() + add2.double()) < 5e-6
+    sums = part.sum(0).cpu()
+    assert _relerr(sums[:128], gd.grad) < 1e-5 and _relerr(sums[128:256], bd.grad) < 1e-5
+
+
+def test_transformer_block_fused_matches_unfused():
+    """The fused block (6 + 13 launches) against the op-per-launch path on the same parameters: outputs and every
+    gradient agree to fp32 round-off, and both match an fp64 evaluation of the reference formula."""
+    ops = _ops()
+    from transmf_ad_amd import networks
+    torch.manual_seed(5)
+    tr = networks.Transformer(128, 1, 4, 32, 512, 0.).to(DEV)
+    with torch.no_grad():
+        for p in tr.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    x0 = _rand(3, 50, 128, seed=111).to(DEV)
+    c0 = _rand(3, 70, 128, seed=112).to(DEV)
+    go = _rand(3, 50, 128, seed=113).to(DEV)
+    res = {}
+    for fused in (True, False):
+        ops.FUSE_TOKEN_LINEARS = fused
+        try:
+            tr.zero_grad()
+            x, c = x0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+            y = tr(x, context=c, residual=x)
+            y.backward(go)
+            torch.cuda.synchronize()
+            res[fused] = [y.detach().cpu(), x.grad.cpu(), c.grad.cpu()] + [p.grad.cpu().clone() for p in tr.parameters()]
+        finally:
+            ops.FUSE_TOKEN_LINEARS = True
+    for a, b in zip(res[True], res[False]):
+        assert _relerr(a, b.double()) < 1e-5

@@ -54,7 +54,10 @@ PROTOTYPES = {
     "tmf_colsum_finalize": (_i, [_p, _i, _i, _p, _p]),
     "tmf_xattn_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_xattn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
-    "tmf_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "tmf_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "tmf_tok_row_blocks": (_i, [_i]),
+    "tmf_tok_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p]),
+    "tmf_tok_linear_bwd_input": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "tmf_layernorm_bwd_blocks": (_i, [_i, _i]),
     "tmf_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "tmf_token_pool_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),

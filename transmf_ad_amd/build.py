@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtmf_hip.so")
-SOURCES = ["conv3d_mfma.hip", "conv3d_bf16.hip", "conv1_fused.hip", "bn_act_pool.hip", "attention.hip", "token_ops.hip"]
+SOURCES = ["conv3d_mfma.hip", "conv3d_bf16.hip", "conv1_fused.hip", "bn_act_pool.hip", "attention.hip", "token_ops.hip", "token_gemm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 

@@ -22,11 +22,12 @@ typedef unsigned short u16;
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {     // round-to-nearest-even, a -> low half
-    unsigned int ua = __builtin_bit_cast(unsigned int, a), ub = __builtin_bit_cast(unsigned int, b);
-    ua += 0x7FFFu + ((ua >> 16) & 1u);
-    ub += 0x7FFFu + ((ub >> 16) & 1u);
-    return (ua >> 16) | (ub & 0xFFFF0000u);
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// round-to-nearest-even, a -> low half: one v_cvt_pk_bf16_f32 on gfx950 (the integer emulation cost 8 VALU
+// instructions per pair and made the staging of the bf16 kernels VALU-bound, PMC)
+__device__ __forceinline__ unsigned int pack_bf16(float a, float b) {
+    const bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned int, v);
 }
 
 constexpr int TD = 4, TH = 8, TW = 8;                 // brick: 256 voxels = 8 waves x one 32-voxel M-tile
@@ -89,24 +90,30 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
 
     const float* xb = x + (size_t)b * D * H * W * Cin;
 
+    // brick-invariant halo addressing, computed once (the div/mod chain per piece was a third of the VALU work)
+    constexpr int HV = (NHALO * 8 + NTHR - 1) / NTHR;
+    constexpr int HB = (HV + 1) / 2;
+    int hoff[HV];                                             // element offset of the position in the sample, -1 = zero fill
+#pragma unroll
+    for (int q = 0; q < HV; ++q) {
+        const int hp = (tid + q * NTHR) >> 3;
+        const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
+        const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+        const bool ok = hp < NHALO && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+        hoff[q] = ok ? ((gd * H + gh) * W + gw) * Cin : -1;
+    }
+
     for (int c0 = 0; c0 < Cin; c0 += CINC) {
         if (c0 > 0) __syncthreads();
         // ---- halo: fp32 from HBM, rounded to bf16 on the way into LDS.  The loads of a batch are all issued
         //      before its LDS writes; two batches keep the kernel under 128 registers (two workgroups per CU) ----
-        constexpr int HV = (NHALO * 8 + NTHR - 1) / NTHR;
-        constexpr int HB = (HV + 1) / 2;
         auto stage_halo = [&](const int q0, const int q1) {
             f32x4 hreg[HB];
 #pragma unroll
             for (int q = q0; q < q1; ++q) {
-                const int e = tid + q * NTHR;
-                const int hp = e >> 3, c4 = e & 7;
-                const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
-                const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
-                const int c = c0 + c4 * 4;
+                const int c = c0 + ((tid + q * NTHR) & 7) * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (e < NHALO * 8 && c < Cin && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W)
-                    v = *reinterpret_cast<const f32x4*>(xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c);
+                if (hoff[q] >= 0 && c < Cin) v = *reinterpret_cast<const f32x4*>(xb + hoff[q] + c);
                 hreg[q - q0] = v;
             }
 #pragma unroll
@@ -241,9 +248,7 @@ constexpr size_t SPLIT_LDS_BYTES = (size_t)(3 * SHALO + 2 * 3 * SWSTAGE) * 2 + 8
 __device__ __forceinline__ int swz(int row, int half) { return row * SRP + ((half ^ ((row >> 3) & 1)) << 3); }
 
 __device__ __forceinline__ unsigned int rne_bf16_bits(float a) {          // bf16 bit pattern in the low half
-    unsigned int u = __builtin_bit_cast(unsigned int, a);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return u >> 16;
+    return (unsigned int)__builtin_bit_cast(unsigned short, (__bf16)a);
 }
 __device__ __forceinline__ void split3(float a, unsigned int& h, unsigned int& m, unsigned int& l) {
     h = rne_bf16_bits(a);

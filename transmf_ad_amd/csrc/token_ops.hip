@@ -27,7 +27,8 @@ constexpr int LN_MAXV = 8;   // float4 groups per lane: dim <= 64*4*8 = 2048
 template <int VEC>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-    float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, int rows, int dim, float eps) {
+    const float* __restrict__ residual, float* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+    int rows, int dim, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -47,7 +48,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(
     float* yr = y + (size_t)row * dim;
     for (int i = lane * VEC; i < dim; i += 64 * VEC) {
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) yr[i + q] = (xr[i + q] - mu) * rs * gamma[i + q] + beta[i + q];
+        for (int q = 0; q < VEC; ++q) {
+            float v = (xr[i + q] - mu) * rs * gamma[i + q] + beta[i + q];
+            if (residual != nullptr) v += residual[(size_t)row * dim + i + q];
+            yr[i + q] = v;
+        }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 }
@@ -157,14 +162,14 @@ __global__ void token_pool_bwd_kernel(const float* __restrict__ dcls, const int3
 
 }  // namespace
 
-extern "C" int tmf_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+extern "C" int tmf_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                                  float* mean, float* rstd, int rows, int dim, float eps, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(gamma); TMF_REQUIRE_PTR(beta); TMF_REQUIRE_PTR(y);
     TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(rstd);
     TMF_REQUIRE(rows > 0 && dim > 0, TMF_E_SHAPE, "tmf_layernorm_fwd: rows=%d dim=%d", rows, dim);
     dim3 grid(tmf_cdiv(rows, 4)), block(256);
-    if (dim % 4 == 0) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, dim, eps);
-    else              hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, block, 0, (hipStream_t)stream, x, gamma, beta, y, mean, rstd, rows, dim, eps);
+    if (dim % 4 == 0) hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, (hipStream_t)stream, x, gamma, beta, residual, y, mean, rstd, rows, dim, eps);
+    else              hipLaunchKernelGGL(layernorm_fwd_kernel<1>, grid, block, 0, (hipStream_t)stream, x, gamma, beta, residual, y, mean, rstd, rows, dim, eps);
     return tmf_launch_result("tmf_layernorm_fwd");
 }
 

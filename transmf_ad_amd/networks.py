@@ -124,11 +124,25 @@ class Transformer(nn.Module):
                 PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
                 PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))]))
 
-    def forward(self, x, context=None):
-        for attn, ff in self.layers:
-            x = attn(x, context=context) + x
-            x = ff(x) + x
-        return ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+    def _fused(self, x):
+        attn, ff = self.layers[0]
+        a, f = attn.fn, ff.fn
+        drop = self.training and any(m.p > 0 for m in self.modules() if isinstance(m, nn.Dropout))
+        return (not drop) and x.is_cuda and ops.fused_block_supported(x.shape[-1], a.to_q.out_features,
+                                                                      f.net[0].out_features)
+
+    def forward(self, x, context=None, residual=None):
+        """``residual`` (optional) is added to the result inside the final LayerNorm pass — the caller's
+        ``enc(tokens, context) + tokens`` (reference networks.py:262-263) without a separate kernel."""
+        ctx = x if context is None else context
+        if self._fused(x):
+            for attn, ff in self.layers:
+                x = ops.transformer_layer(x, ctx, attn.norm, attn.fn, ff.norm, ff.fn)
+        else:
+            for attn, ff in self.layers:
+                x = attn(x, context=context) + x
+                x = ff(x) + x
+        return ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, residual)
 
 
 class CrossTransformer_MOD_AVG(nn.Module):
@@ -144,6 +158,8 @@ class CrossTransformer_MOD_AVG(nn.Module):
 
     def forward(self, mri_tokens, pet_tokens):
         for mri_enc, pet_enc in self.layers:
+            # (Transformer.forward can fold this "+ tokens" into its last LayerNorm pass via residual=; it is left
+            #  as its own add so that forward hooks on the Transformer modules see the reference's values)
             mri_tokens = mri_enc(mri_tokens, context=pet_tokens) + mri_tokens
             pet_tokens = pet_enc(pet_tokens, context=mri_tokens) + pet_tokens
         return ops.token_pool(mri_tokens, pet_tokens)

@@ -393,16 +393,18 @@ def cross_attention(q, kv, heads, scale):
 
 class LayerNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, residual):
         x = _chk(x, "x")
         dim = x.shape[-1]
         rows = x.numel() // dim
         y = torch.empty_like(x)
         mean = torch.empty(rows, device=x.device, dtype=_f32)
         rstd = torch.empty(rows, device=x.device, dtype=_f32)
-        _lib.call("tmf_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(),
+        res = _chk(residual, "residual") if residual is not None else None
+        _lib.call("tmf_layernorm_fwd", x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(res), y.data_ptr(),
                   mean.data_ptr(), rstd.data_ptr(), rows, dim, float(eps), _stream())
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.has_res = residual is not None
         return y
 
     @staticmethod
@@ -419,11 +421,139 @@ class LayerNorm(torch.autograd.Function):
                   dy.data_ptr(), dx.data_ptr(), part.data_ptr(), rows, dim, s)
         gb = torch.empty((2, dim), device=x.device, dtype=_f32)
         _lib.call("tmf_colsum_finalize", part.data_ptr(), nblk, 2 * dim, gb.data_ptr(), s)
-        return dx, gb[0], gb[1], None
+        return dx, gb[0], gb[1], None, (dy if ctx.has_res else None)
 
 
-def layer_norm(x, gamma, beta, eps=1e-5):
-    return LayerNorm.apply(x, gamma, beta, eps)
+def layer_norm(x, gamma, beta, eps=1e-5, residual=None):
+    """LayerNorm(x) * gamma + beta (+ residual, fused into the same pass)."""
+    return LayerNorm.apply(x, gamma, beta, eps, residual)
+
+
+# --------------------------------------------------------------------------------------
+# fused transformer block: every nn.Linear is one launch that also does the LayerNorm / bias / GELU /
+# residual around it (csrc/token_gemm.hip).                         (networks.py:114-175, 215-230)
+# --------------------------------------------------------------------------------------
+
+def tok_linear_fwd(x, w, bias=None, residual=None, ln=None, gelu=False, keep_ln_out=False):
+    """y = [GELU](LayerNorm?(x) @ w.T + bias) + residual on 2-D row-major fp32 tensors.
+    ln = (gamma, beta, eps).  Returns (y, ln_saved, pre): ln_saved = (mean, rstd, normalised rows | None)."""
+    R, K = x.shape
+    nout = w.shape[0]
+    y = torch.empty((R, nout), device=x.device, dtype=_f32)
+    mean = rstd = ln_out = pre = None
+    g = b = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = ln
+        mean = torch.empty(R, device=x.device, dtype=_f32)
+        rstd = torch.empty(R, device=x.device, dtype=_f32)
+        if keep_ln_out:
+            ln_out = torch.empty((R, K), device=x.device, dtype=_f32)
+    if gelu:
+        pre = torch.empty((R, nout), device=x.device, dtype=_f32)
+    _lib.call("tmf_tok_linear_fwd", x.data_ptr(), w.data_ptr(), _ptr(bias), _ptr(residual), y.data_ptr(), R, K, nout,
+              _ptr(g), _ptr(b), float(eps), _ptr(mean), _ptr(rstd), _ptr(ln_out), _ptr(pre), _stream())
+    return y, (mean, rstd, ln_out), pre
+
+
+def tok_linear_bwd_input(dy, w, gelu_pre=None, ln=None, add1=None, add2=None, ln_partial=None, bias_partial=None,
+                         partial_stride=0):
+    """dx = E(dy @ w); ln = (x, mean, rstd, gamma) selects the LayerNorm-backward epilogue.  ln_partial /
+    bias_partial are (tensor, column offset) pairs into one [row blocks][partial_stride] workspace."""
+    R, nout = dy.shape
+    K = w.shape[1]
+    dx = torch.empty((R, K), device=dy.device, dtype=_f32)
+    lx = lm = lr = lg = None
+    if ln is not None:
+        lx, lm, lr, lg = ln
+
+    def off(pair):
+        return None if pair is None else pair[0].data_ptr() + 4 * pair[1]
+    _lib.call("tmf_tok_linear_bwd_input", dy.data_ptr(), w.data_ptr(), dx.data_ptr(), R, nout, K, _ptr(gelu_pre),
+              _ptr(lx), _ptr(lm), _ptr(lr), _ptr(lg), _ptr(add1), _ptr(add2), off(ln_partial), off(bias_partial),
+              partial_stride, _stream())
+    return dx
+
+
+FUSE_TOKEN_LINEARS = True       # False: every op of the block is its own launch (kept for A/B tests)
+
+
+def fused_block_supported(dim, inner, mlp):
+    return FUSE_TOKEN_LINEARS and dim == 128 and inner % 128 == 0 and mlp % 128 == 0
+
+
+class TransformerLayer(torch.autograd.Function):
+    """x <- Attention(LayerNorm(x), context) + x ; x <- FeedForward(LayerNorm(x)) + x   as 6 launches forward
+    (to_q with LayerNorm prologue, to_kv, attention, to_out + bias + x, Linear + bias + GELU with LayerNorm
+    prologue, Linear + bias + x) and 7 + 5 weight-gradient GEMMs + 1 reduction backward."""
+
+    @staticmethod
+    def forward(ctx, x, context, g1, b1n, wq, wkv, wo, bo, g2, b2n, w1, b1, w2, b2, heads, scale, eps1, eps2):
+        x, context = _chk(x, "x"), _chk(context, "context")
+        B, N, dim = x.shape
+        M = context.shape[1]
+        inner = wq.shape[0]
+        x2d, c2d = x.view(B * N, dim), context.view(B * M, dim)
+        q, (mean1, rstd1, a), _ = tok_linear_fwd(x2d, wq, ln=(g1, b1n, eps1), keep_ln_out=True)
+        kv, _, _ = tok_linear_fwd(c2d, wkv)
+        dh = inner // heads
+        out = torch.empty((B * N, inner), device=x.device, dtype=_f32)
+        lse = torch.empty((B, heads, N), device=x.device, dtype=_f32)
+        _lib.call("tmf_xattn_fwd", q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 4, out.data_ptr(),
+                  lse.data_ptr(), B, heads, N, M, dh, inner, 2 * inner, float(scale), _stream())
+        x1, _, _ = tok_linear_fwd(out, wo, bias=bo, residual=x2d)
+        g, (mean2, rstd2, f), h = tok_linear_fwd(x1, w1, bias=b1, ln=(g2, b2n, eps2), gelu=True, keep_ln_out=True)
+        x2, _, _ = tok_linear_fwd(g, w2, bias=b2, residual=x1)
+        ctx.save_for_backward(x2d, c2d, g1, wq, wkv, wo, g2, w1, w2, mean1, rstd1, a, q, kv, out, lse, x1, mean2,
+                              rstd2, f, h, g)
+        ctx.cfg = (B, N, M, dim, inner, heads, float(scale))
+        return x2.view(B, N, dim)
+
+    @staticmethod
+    def backward(ctx, dx2):
+        (x2d, c2d, g1, wq, wkv, wo, g2, w1, w2, mean1, rstd1, a, q, kv, out, lse, x1, mean2, rstd2, f, h,
+         g) = ctx.saved_tensors
+        B, N, M, dim, inner, heads, scale = ctx.cfg
+        mlp = w1.shape[0]
+        R = B * N
+        dx2 = _chk(dx2, "grad_output").view(R, dim)
+        nblk = _lib.query("tmf_tok_row_blocks", R)
+        # one [row blocks][stride] workspace for every bias / LayerNorm parameter gradient of the block
+        o_b2, o_b1, o_bo, o_ln2, o_ln1 = 0, dim, dim + mlp, 2 * dim + mlp, 4 * dim + mlp
+        stride = 6 * dim + mlp
+        part = torch.empty((nblk, stride), device=dx2.device, dtype=_f32)
+        dh_ = tok_linear_bwd_input(dx2, w2, gelu_pre=h, bias_partial=(part, o_b2), partial_stride=stride)
+        dx1 = tok_linear_bwd_input(dh_, w1, ln=(x1, mean2, rstd2, g2), add1=dx2, ln_partial=(part, o_ln2),
+                                   bias_partial=(part, o_b1), partial_stride=stride)
+        dout = tok_linear_bwd_input(dx1, wo, bias_partial=(part, o_bo), partial_stride=stride)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        dhd = inner // heads
+        _lib.call("tmf_xattn_bwd", q.data_ptr(), kv.data_ptr(), kv.data_ptr() + inner * 4, out.data_ptr(),
+                  lse.data_ptr(), dout.data_ptr(), dq.data_ptr(), dkv.data_ptr(), dkv.data_ptr() + inner * 4,
+                  B, heads, N, M, dhd, inner, 2 * inner, 2 * inner, scale, _stream())
+        dctx = tok_linear_bwd_input(dkv, wkv) if ctx.needs_input_grad[1] else None
+        dx = tok_linear_bwd_input(dq, wq, ln=(x2d, mean1, rstd1, g1), add1=dx1, ln_partial=(part, o_ln1),
+                                  partial_stride=stride)
+        sums = torch.empty(stride, device=dx2.device, dtype=_f32)
+        _lib.call("tmf_colsum_finalize", part.data_ptr(), nblk, stride, sums.data_ptr(), _stream())
+        dw2 = dx2.t().mm(g)
+        dw1 = dh_.t().mm(f)
+        dwo = dx1.t().mm(out)
+        dwkv = dkv.t().mm(c2d)
+        dwq = dq.t().mm(a)
+        return (dx.view(B, N, dim), None if dctx is None else dctx.view(B, M, dim),
+                sums[o_ln1:o_ln1 + dim], sums[o_ln1 + dim:o_ln1 + 2 * dim], dwq, dwkv, dwo, sums[o_bo:o_bo + dim],
+                sums[o_ln2:o_ln2 + dim], sums[o_ln2 + dim:o_ln2 + 2 * dim], dw1, sums[o_b1:o_b1 + mlp], dw2,
+                sums[o_b2:o_b2 + dim], None, None, None, None)
+
+
+def transformer_layer(x, context, ln1, attn, ln2, ff):
+    """ln1 / ln2: nn.LayerNorm; attn: networks.Attention; ff: networks.FeedForward (parameter containers)."""
+    return TransformerLayer.apply(x, context, ln1.weight, ln1.bias, attn.to_q.weight, attn.to_kv.weight,
+                                  attn.to_out[0].weight, attn.to_out[0].bias, ln2.weight, ln2.bias,
+                                  ff.net[0].weight, ff.net[0].bias, ff.net[3].weight, ff.net[3].bias,
+                                  attn.heads, attn.scale, ln1.eps, ln2.eps)
 
 
 # --------------------------------------------------------------------------------------
