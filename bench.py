@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="bf16: forward/dgrad 3x3x3 convs on the bf16 matrix cores (BASELINE configs[2] mode; not the headline)")
+    ap.add_argument("--model", choices=["ad", "cnn", "single"], default="ad",
+                    help="ad: model_ad (headline); cnn: model_CNN_ad; single: model_single (MRI only) — BASELINE configs[4]")
     ap.add_argument("--no-fused-adam", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the train-step timing: only the dominant-kernel loop (so that a rocprofv3 --stats run "
@@ -93,7 +95,14 @@ def main():
 
     ops.set_conv_precision(args.precision)
     torch.manual_seed(0)
-    net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to(dev)
+    if args.model == "ad":
+        net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to(dev)
+    elif args.model == "cnn":
+        from transmf_ad_amd import model_CNN_ad
+        net = model_CNN_ad(dim=128).to(dev)
+    else:
+        from transmf_ad_amd import model_single
+        net = model_single(128).to(dev)
     if world > 1:
         net = GradAllReduce(net)
     # same update rule as the reference's getOptimizer (utils/utils.py:38-39: Adam, lr 1e-4, wd 0), multi-tensor form
@@ -111,8 +120,11 @@ def main():
     def step():
         net.train()
         opt.zero_grad()
-        lo, dm, dp = net(mri, pet)
-        loss = (crit(dm, ones) + crit(dp, zeros)) / 2 + crit(lo, label)
+        if args.model == "single":          # kfold_train_single.py:91-113: plain CE on model_single(MRI)
+            loss = crit(net(mri), label)
+        else:
+            lo, dm, dp = net(mri, pet)
+            loss = (crit(dm, ones) + crit(dp, zeros)) / 2 + crit(lo, label)
         loss.backward()
         opt.step()
         return loss
@@ -234,16 +246,21 @@ def main():
                          f"{sec:.2f} s/step, host cpu_count={os.cpu_count()}"}
 
     if rank == 0:
-        gf = conv_flops_per_pair(S)
+        gf = conv_flops_per_pair(S) * (0.5 if args.model == "single" else 1.0)
+        model_desc = {"ad": "model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512)",
+                      "cnn": "model_CNN_ad(dim=128) [BASELINE configs[4], dual-modality reading of --model CNN]",
+                      "single": "model_single(128), MRI only [BASELINE configs[4], single-modality reading]"}[args.model]
         out = {
-            "metric": f"volume-pairs/sec fwd+bwd(+Adam), {S}^3 MRI+PET batch={B} per GPU",
-            "value": round(pairs_per_s, 3), "unit": "volume-pairs/s", "n_gpus": world, "steps": args.steps,
+            "metric": (f"volume-pairs/sec fwd+bwd(+Adam), {S}^3 MRI+PET batch={B} per GPU" if args.model != "single"
+                       else f"volumes/sec fwd+bwd(+Adam), {S}^3 MRI only batch={B} per GPU"),
+            "value": round(pairs_per_s, 3), "unit": "volume-pairs/s" if args.model != "single" else "volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate+storage",
             "data": "synthetic",
-            "config": {"workload": f"model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512) train step, "
-                                   f"batch {B} pairs of 1x{S}^3 per GPU, {args.precision}" + _config_tag(B, S, args.precision),
+            "config": {"workload": f"{model_desc} train step, "
+                                   f"batch {B} {'volumes' if args.model == 'single' else 'pairs'} of 1x{S}^3 per GPU, {args.precision}"
+                                   + (_config_tag(B, S, args.precision) if args.model == "ad" else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "step": "zero_grad+fwd+loss+bwd+allreduce+Adam", "dispatch": mode},
             "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),

@@ -217,6 +217,12 @@ int tmf_tok_linear_bwd_input(const float* dy, const float* w, float* dx, int R, 
                              const float* ln_gamma, const float* add1, const float* add2, float* ln_partial,
                              float* bias_partial, int partial_stride, void* stream);
 
+/* Layout conversion between the reference's NCDHW tensors and the channels-last tensors every kernel here uses
+ * (voxels = D*H*W).  The model itself never needs it — its input has C == 1 (same bytes either way) and its output
+ * is handed back as a strided view — it is here for callers that feed or read intermediate activations. */
+int tmf_layout_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, long voxels, void* stream);
+int tmf_layout_ndhwc_to_ncdhw(const float* src, float* dst, int B, int C, long voxels, void* stream);
+
 /* cls[b] = [mean_n mri | mean_n pet | max_n mri | max_n pet]  (4*dim); argmax: int32 [B][2][dim]. */
 int tmf_token_pool_fwd(const float* mri, const float* pet, float* cls, int32_t* argmax,
                        int B, int N, int dim, void* stream);

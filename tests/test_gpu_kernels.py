@@ -564,3 +564,14 @@ def test_transformer_block_fused_matches_unfused():
             ops.FUSE_TOKEN_LINEARS = True
     for a, b in zip(res[True], res[False]):
         assert _relerr(a, b.double()) < 1e-5
+
+
+def test_layout_conversion_round_trip():
+    from transmf_ad_amd import _lib as lib
+    x = _rand(2, 5, 7, 9, 11, seed=121).to(DEV)                  # NCDHW, ragged against the 32 x 32 tiles
+    y = torch.empty((2, 7, 9, 11, 5), device=DEV)
+    lib.call("tmf_layout_ncdhw_to_ndhwc", x.data_ptr(), y.data_ptr(), 2, 5, 7 * 9 * 11, 0)
+    assert torch.equal(y, x.permute(0, 2, 3, 4, 1).contiguous())
+    z = torch.empty_like(x)
+    lib.call("tmf_layout_ndhwc_to_ncdhw", y.data_ptr(), z.data_ptr(), 2, 5, 7 * 9 * 11, 0)
+    assert torch.equal(z, x)

@@ -17,6 +17,7 @@ _POOL = {None: POOL_NONE, "none": POOL_NONE, "max": POOL_MAX2, "avg": POOL_AVG2}
 _p = C.c_void_p
 _i = C.c_int
 _f = C.c_float
+_l = C.c_long
 _d = C.c_double
 _z = C.c_size_t
 
@@ -55,6 +56,8 @@ PROTOTYPES = {
     "tmf_xattn_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_xattn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "tmf_layout_ncdhw_to_ndhwc": (_i, [_p, _p, _i, _i, _l, _p]),
+    "tmf_layout_ndhwc_to_ncdhw": (_i, [_p, _p, _i, _i, _l, _p]),
     "tmf_tok_row_blocks": (_i, [_i]),
     "tmf_tok_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p]),
     "tmf_tok_linear_bwd_input": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),

@@ -160,7 +160,40 @@ __global__ void token_pool_bwd_kernel(const float* __restrict__ dcls, const int3
     dst[((size_t)b * N + n) * dim + c] = gavg / N + (n == am ? gmax : 0.f);
 }
 
+// [B][R][C] <-> [B][C][R] through a 32 x 33 LDS tile (both sides coalesced); R = D*H*W voxels, C channels
+__global__ __launch_bounds__(256) void transpose_tile_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             int rows, int cols, int tiles_c) {
+    __shared__ float tile[32][33];
+    const size_t base = (size_t)blockIdx.y * rows * cols;
+    const int r0 = (blockIdx.x / tiles_c) * 32, c0 = (blockIdx.x % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = src[base + (size_t)(r0 + i) * cols + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) dst[base + (size_t)(c0 + i) * rows + r0 + tx] = tile[tx][i];
+}
+
 }  // namespace
+
+static int launch_transpose(const float* src, float* dst, int B, long rows, long cols, void* stream, const char* what) {
+    TMF_REQUIRE_PTR(src); TMF_REQUIRE_PTR(dst);
+    TMF_REQUIRE(B > 0 && B <= 65535 && rows > 0 && cols > 0 && rows < (1L << 31) && cols < (1L << 31), TMF_E_SHAPE,
+                "%s: B=%d rows=%ld cols=%ld", what, B, rows, cols);
+    const long tr = tmf_cdiv(rows, 32L), tc = tmf_cdiv(cols, 32L);
+    TMF_REQUIRE(tr * tc < (1L << 31), TMF_E_SHAPE, "%s: %ld tiles exceed the grid limit", what, tr * tc);
+    hipLaunchKernelGGL(transpose_tile_kernel, dim3((unsigned)(tr * tc), B), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       (int)rows, (int)cols, (int)tc);
+    return tmf_launch_result(what);
+}
+
+extern "C" int tmf_layout_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, long voxels, void* stream) {
+    return launch_transpose(src, dst, B, C, voxels, stream, "tmf_layout_ncdhw_to_ndhwc");
+}
+
+extern "C" int tmf_layout_ndhwc_to_ncdhw(const float* src, float* dst, int B, int C, long voxels, void* stream) {
+    return launch_transpose(src, dst, B, voxels, C, stream, "tmf_layout_ndhwc_to_ncdhw");
+}
 
 extern "C" int tmf_layernorm_fwd(const float* x, const float* gamma, const float* beta, const float* residual, float* y,
                                  float* mean, float* rstd, int rows, int dim, float eps, void* stream) {

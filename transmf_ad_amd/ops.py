@@ -6,6 +6,8 @@ fp32, contiguous, on a HIP device; activations are channels-last (B, D, H, W, C)
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -475,7 +477,8 @@ def tok_linear_bwd_input(dy, w, gelu_pre=None, ln=None, add1=None, add2=None, ln
     return dx
 
 
-FUSE_TOKEN_LINEARS = True       # False: every op of the block is its own launch (kept for A/B tests)
+# False / TMF_FUSE_TOKENS=0: every op of the block is its own launch (kept for A/B measurements and tests)
+FUSE_TOKEN_LINEARS = os.environ.get("TMF_FUSE_TOKENS", "1") != "0"
 
 
 def fused_block_supported(dim, inner, mlp):
