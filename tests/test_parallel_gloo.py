@@ -73,8 +73,13 @@ def _worker(rank, world, port, out_dir):
     # second step exercises bucket reset + zero_grad(set_to_none=True)
     opt.zero_grad()
     O.adversarial_loss(*net(mri, pet), y).backward()
-    torch.save(dict(grads=grads, p0=m.ps[0].detach().clone(), g2=[p.grad.clone() for p in m.ps]),
-               os.path.join(out_dir, f"rank{rank}.pt"))
+    g2 = [p.grad.clone() for p in m.ps]
+    # .grad now aliases the reduced buckets; zero_grad(set_to_none=False) keeps those views and the next backward
+    # accumulates into them in place — the result must still be the plain averaged gradient
+    opt.zero_grad(set_to_none=False)
+    O.adversarial_loss(*net(mri, pet), y).backward()
+    g3 = [p.grad.clone() for p in m.ps]
+    torch.save(dict(grads=grads, p0=m.ps[0].detach().clone(), g2=g2, g3=g3), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,3 +105,6 @@ def test_two_rank_gradient_average(tmp_path):
     assert torch.equal(res[0]["p0"], res[1]["p0"])             # replicas stay in lock-step after Adam
     for a, b in zip(res[0]["g2"], res[1]["g2"]):
         assert torch.equal(a, b)
+    for a, b, c in zip(res[0]["g3"], res[1]["g3"], res[0]["g2"]):
+        assert torch.equal(a, b)
+        assert (a - c).abs().max() <= 1e-3 * c.abs().max().clamp_min(1e-6)     # same parameters, same data as step 2

@@ -14,11 +14,13 @@ there is no call pattern to mirror; this is sized for the path itself:
     backward kernels.  xGMI is point-to-point (≈153 GB/s per link): a ring over 8 GPUs moves
     2*(7/8)*16.7 MB ≈ 29 MB per GPU per step (≈0.2 ms on one link) — few, large buckets keep
     that bandwidth-bound rather than latency-bound;
-  * a queued autograd callback waits for the buckets, averages, and scatters the result back
-    into ``param.grad`` before ``optimizer.step()`` — the reference's train_step is unchanged.
+  * a queued autograd callback waits for the buckets, averages, and re-points ``param.grad`` at views of
+    the reduced buckets before ``optimizer.step()`` — the reference's train_step is unchanged.  Per step this
+    costs one multi-tensor pack, one all-reduce and one scale per bucket (no per-parameter kernels).
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -48,11 +50,13 @@ class _Bucket:
         self.pending = len(params)
         self.filled = [False] * len(params)
         self.work = None
+        self.streams = {}
 
     def reset(self):
         self.pending = len(self.params)
         self.filled = [False] * len(self.params)
         self.work = None
+        self.streams = {}
 
 
 class GradAllReduce(nn.Module):
@@ -75,6 +79,8 @@ class GradAllReduce(nn.Module):
         self._callback_queued = False
         self._streams = {}
         self.require_sync = True
+        # TMF_DDP_FORCE=1 keeps the bucket machinery live in a 1-rank group (to measure its overhead on one GPU)
+        self._force = os.environ.get("TMF_DDP_FORCE", "0") == "1"
         params = [p for p in module.parameters() if p.requires_grad]
         if broadcast_from_rank0 and self.world > 1:
             with torch.no_grad():
@@ -116,15 +122,27 @@ class GradAllReduce(nn.Module):
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
 
-    def _pack(self, b, i, p):
-        n = p.numel()
-        b.flat[b.offsets[i]:b.offsets[i] + n].copy_(p.grad.reshape(-1))
+    def _views(self, b):
+        return [b.flat[o:o + p.numel()].view_as(p) for o, p in zip(b.offsets, b.params)]
 
     def _launch(self, b):
+        """Pack the bucket with ONE multi-tensor copy (all of its gradients exist by now) and start its all-reduce.
+        Gradients come from more than one stream (MRI / PET encoders): the staging stream waits on every stream a
+        hook of this bucket fired on."""
+        views = self._views(b)
+        grads, dst = [], []
+        for i, p in enumerate(b.params):
+            if b.filled[i] and p.grad is not None:
+                grads.append(p.grad.reshape(p.shape))
+                dst.append(views[i])
+            else:                               # no gradient this pass: contribute zeros
+                views[i].zero_()
+        if grads:
+            torch._foreach_copy_(dst, grads)
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p: torch.Tensor):
-        if not self.require_sync or self.world == 1:
+        if not self.require_sync or (self.world == 1 and not self._force):
             return
         if not self._callback_queued:
             self._callback_queued = True
@@ -135,17 +153,19 @@ class GradAllReduce(nn.Module):
         b.filled[i] = True
         b.pending -= 1
         if p.grad.is_cuda:
-            st = self._staging(p.device)
-            st.wait_stream(torch.cuda.current_stream(p.device))
-            with torch.cuda.stream(st):
-                self._pack(b, i, p)
-                p.grad.record_stream(st)
-                if b.pending == 0:
-                    self._launch(b)
-        else:
-            self._pack(b, i, p)
+            cur = torch.cuda.current_stream(p.device)
+            b.streams[cur.cuda_stream] = cur
             if b.pending == 0:
-                self._launch(b)
+                st = self._staging(p.device)
+                for s_ in b.streams.values():
+                    st.wait_stream(s_)
+                with torch.cuda.stream(st):
+                    self._launch(b)
+                    for q in b.params:
+                        if q.grad is not None:
+                            q.grad.record_stream(st)
+        elif b.pending == 0:
+            self._launch(b)
 
     def _finalize(self):
         self._callback_queued = False
@@ -157,24 +177,18 @@ class GradAllReduce(nn.Module):
             st.wait_stream(torch.cuda.current_stream(dev))
         with ctx:
             for b in self._buckets:
-                if b.work is None:        # some parameter got no gradient this pass: send zeros for it
-                    for i, p in enumerate(b.params):
-                        if not b.filled[i]:
-                            b.flat[b.offsets[i]:b.offsets[i] + p.numel()].zero_()
+                if b.work is None:        # some parameter got no gradient this pass
                     self._launch(b)
             for b in self._buckets:
                 b.work.wait()
                 b.flat.div_(self.world)
         if cuda:
             torch.cuda.current_stream(dev).wait_stream(st)
+        # .grad becomes a VIEW of the reduced bucket (no copy back); the next zero_grad() drops it and the next
+        # backward's pack — stream-ordered after the optimizer step that reads these views — refills the bucket.
         for b in self._buckets:
-            for i, p in enumerate(b.params):
-                n = p.numel()
-                g = b.flat[b.offsets[i]:b.offsets[i] + n].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
+            for p, v in zip(b.params, self._views(b)):
+                p.grad = v
             b.reset()
 
     def reduce_gradients(self):
@@ -183,22 +197,20 @@ class GradAllReduce(nn.Module):
         if self.world == 1:
             return
         for b in self._buckets:
-            for i, p in enumerate(b.params):
-                n = p.numel()
-                if p.grad is None:
-                    b.flat[b.offsets[i]:b.offsets[i] + n].zero_()
-                else:
-                    b.flat[b.offsets[i]:b.offsets[i] + n].copy_(p.grad.reshape(-1))
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            b.filled = [p.grad is not None for p in b.params]
+            self._launch(b)
         for b in self._buckets:
             b.work.wait()
             b.flat.div_(self.world)
-            for i, p in enumerate(b.params):
-                g = b.flat[b.offsets[i]:b.offsets[i] + p.numel()].view_as(p)
+            # copy back INTO the existing .grad tensors (a captured graph owns them and rewrites them on replay)
+            views = self._views(b)
+            dst = [p.grad for p in b.params if p.grad is not None]
+            src = [v for p, v in zip(b.params, views) if p.grad is not None]
+            if dst:
+                torch._foreach_copy_(dst, src)
+            for p, v in zip(b.params, views):
                 if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
+                    p.grad = v.clone()
             b.reset()
 
     # -- nn.Module surface -------------------------------------------------------------------
