@@ -117,6 +117,18 @@ int    tmf_c1_bwd_wgrad(const float* x, const float* w, const float* scale, cons
                         const float* mean, const float* invstd, const float* coef, const float* dpool,
                         float* dw, void* workspace, size_t workspace_bytes,
                         int B, int D, int H, int W, int C, float slope, void* stream);
+/* The same four passes with both products on the bf16 matrix cores (operands rounded to bf16, fp32 accumulation,
+ * fp32 I/O): 2 MFMAs per tile instead of 14 / 16.  Same arguments, same workspace / block counts. */
+int    tmf_c1_stats_bf16(const float* x, const float* w, float* stat_partial, int B, int D, int H, int W, int C, void* stream);
+int    tmf_c1_bn_pool_fwd_bf16(const float* x, const float* w, const float* scale, const float* shift, float* pooled,
+                               int B, int D, int H, int W, int C, float slope, void* stream);
+int    tmf_c1_bwd_reduce_bf16(const float* x, const float* w, const float* scale, const float* shift,
+                              const float* mean, const float* invstd, const float* dpool, float* partial,
+                              int B, int D, int H, int W, int C, float slope, void* stream);
+int    tmf_c1_bwd_wgrad_bf16(const float* x, const float* w, const float* scale, const float* shift,
+                             const float* mean, const float* invstd, const float* coef, const float* dpool,
+                             float* dw, void* workspace, size_t workspace_bytes,
+                             int B, int D, int H, int W, int C, float slope, void* stream);
 
 /* ------------------------------------------------------------------------------
  * BatchNorm3d (training statistics) + LeakyReLU + 2x2x2 pool, two passes.

@@ -173,6 +173,36 @@ def test_conv_bn_act_pool_block(case, train):
         assert _relerr(_ncdhw(xg.grad.cpu()), xr.grad) < 5e-4, "dx"
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16, 32), (1, 10, 13, 9, 24), (2, 32, 32, 32, 32)])
+def test_first_block_in_bf16_mode(shape):
+    """Fused Conv3d(1->C) block with both products on the bf16 matrix cores.  Inputs and weights that ARE bf16
+    numbers make the convolution exact, so the forward (statistics, activation, pooling) is held to fp32 accuracy
+    against fp64; the weight gradient additionally rounds dz to bf16 (<= 2^-9 relative per element)."""
+    ops = _ops()
+    B, D, H, W, C = shape
+    x = _rand(B, 1, D, H, W, seed=131).abs().bfloat16().float()
+    w = _rand(C, 1, 3, 3, 3, seed=132, scale=27 ** -0.5).bfloat16().float()
+    b, g, be = _rand(C, seed=133, scale=0.1), 1 + _rand(C, seed=134, scale=0.1), _rand(C, seed=135, scale=0.1)
+    rm, rv = _rand(C, seed=136, scale=0.1), 1 + _rand(C, seed=137, scale=0.1).abs()
+    xr, P, rm_ref, rv_ref, yr = _block_ref(x, w, b, g, be, rm, rv, True, "max", torch.float64)
+    go = _rand(*yr.shape, seed=138)
+    yr.backward(go.double())
+    ops.set_conv_precision("bf16")
+    try:
+        Pg = [t.clone().to(DEV).requires_grad_(True) for t in (w, b, g, be)]
+        rmg, rvg = rm.clone().to(DEV), rv.clone().to(DEV)
+        yg = ops.conv_bn_act_pool(_ndhwc(x).to(DEV), Pg[0], Pg[1], Pg[2], Pg[3], rmg, rvg, True, pool="max")
+        yg.backward(_ndhwc(go).to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_conv_precision("fp32")
+    assert _relerr(_ncdhw(yg.detach().cpu()), yr.detach()) < 2e-5
+    assert _relerr(rmg, rm_ref) < 1e-5 and _relerr(rvg, rv_ref) < 1e-5
+    assert _relerr(Pg[2].grad, P[2].grad) < 5e-4 and _relerr(Pg[3].grad, P[3].grad) < 5e-4      # fp32 reductions
+    assert _relerr(Pg[0].grad, P[0].grad) < 1e-2                                                # dz rounded to bf16
+    assert Pg[1].grad.abs().max().item() == 0.0
+
+
 def test_maxpool_first_argmax_on_ties():
     """Ties inside a pooling window route the gradient to the FIRST maximum in (d,h,w) order (torch)."""
     ops = _ops()

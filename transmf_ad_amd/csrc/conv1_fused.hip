@@ -55,7 +55,16 @@ struct Args {
     float slope;
 };
 
-template <int MODE>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ tmf_bf16x8 pack8(const float (&v)[8]) {
+    const u32x4 p = {tmf_pack_bf16(v[0], v[1]), tmf_pack_bf16(v[2], v[3]), tmf_pack_bf16(v[4], v[5]), tmf_pack_bf16(v[6], v[7])};
+    return __builtin_bit_cast(tmf_bf16x8, p);
+}
+
+// BF16 = true: both products run on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32 accumulation) — the
+// 27-tap convolution is 2 MFMAs instead of 14 and the tap-gradient product 2 instead of 16, which turns the four
+// passes from matrix-bound into LDS / HBM-bound (the opt-in bf16 mode of BASELINE configs[2]).
+template <int MODE, bool BF16>
 __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
     __shared__ float halo[NHALO];
     __shared__ float red[4 * 32 * 32];      // cross-wave reduction scratch (16 KB)
@@ -68,11 +77,25 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
     const bool cv = co < a.C;
     const int OD = a.D / 2, OH = a.H / 2, OW = a.W / 2;
 
-    float bw[14];
+    float bw[BF16 ? 1 : 14];
+    tmf_bf16x8 bwb[2];                      // BF16: B[k = 16 m + 8 hsel + j][co], taps >= 27 are zero
+    if (BF16) {
 #pragma unroll
-    for (int s = 0; s < 14; ++s) {
-        const int tap = 2 * s + hsel;
-        bw[s] = (tap < 27 && cv) ? a.w[tap * a.C + co] : 0.f;
+        for (int m = 0; m < 2; ++m) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int tap = 16 * m + 8 * hsel + j;
+                v[j] = (tap < 27 && cv) ? a.w[tap * a.C + co] : 0.f;
+            }
+            bwb[m] = pack8(v);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < 14; ++s) {
+            const int tap = 2 * s + hsel;
+            bw[s] = (tap < 27 && cv) ? a.w[tap * a.C + co] : 0.f;
+        }
     }
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f, c0 = 0.f, c1 = 0.f;
     if (MODE != MODE_STATS && cv) { sc = a.scale[co]; sh = a.shift[co]; }
@@ -143,12 +166,28 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zt[ti][r] = 0.f;
             }
+            if (BF16) {
+                // A[i = voxel][k = 16 m + 8 hsel + j]: eight taps of the lane's voxel per MFMA (taps >= 27 read a
+                // finite halo value against a zero weight)
 #pragma unroll
-            for (int s = 0; s < 14; ++s) {
-                const int off = hsel ? tapoff(2 * s + 1) : tapoff(2 * s);
+                for (int m = 0; m < 2; ++m) {
 #pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-                    zt[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_vox[ti] + off], bw[s], zt[ti], 0, 0, 0);
+                    for (int ti = 0; ti < 2; ++ti) {
+                        float v[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j)
+                            v[j] = halo[a_vox[ti] + (hsel ? tapoff(16 * m + 8 + j) : tapoff(16 * m + j))];
+                        zt[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(v), bwb[m], zt[ti], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 14; ++s) {
+                    const int off = hsel ? tapoff(2 * s + 1) : tapoff(2 * s);
+#pragma unroll
+                    for (int ti = 0; ti < 2; ++ti)
+                        zt[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_vox[ti] + off], bw[s], zt[ti], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
@@ -207,9 +246,21 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
             if (MODE == MODE_WGRAD) {
                 // dw[tap][co] += sum_voxel x[voxel + tap] * dz[voxel][co]:  A[i = tap][k = lane half], B = dz regs
                 const int a_row = org + hsel * 2 * HW + a_tap;
+                if (BF16) {
+                    // K = the 16 voxels of fragment rows 8 m .. 8 m + 7 of both lane halves: B is the lane's own dz
+                    // registers, A the same voxels' inputs shifted by the lane's tap
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    accw = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_row + row_off(r)], z[r], accw, 0, 0, 0);
+                    for (int m = 0; m < 2; ++m) {
+                        float av[8], bv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { av[j] = halo[a_row + row_off(8 * m + j)]; bv[j] = z[8 * m + j]; }
+                        accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(av), pack8(bv), accw, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        accw = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_row + row_off(r)], z[r], accw, 0, 0, 0);
+                }
             }
         }
         };
@@ -289,33 +340,51 @@ extern "C" int tmf_c1_blocks(int B, int D, int H, int W, int C) {
     return make_plan(B, D, H, W, C, SLAB_BLOCKS).nblk;
 }
 
-extern "C" int tmf_c1_stats(const float* x, const float* w, float* stat_partial,
-                            int B, int D, int H, int W, int C, void* stream) {
+static int c1_stats(bool bf16, const float* x, const float* w, float* stat_partial,
+                    int B, int D, int H, int W, int C, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(stat_partial);
     int rc = check("tmf_c1_stats", B, D, H, W, C);
     if (rc) return rc;
     const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
     Args a = base_args(x, w, D, H, W, C, p, 0.f);
     a.partial = stat_partial;
-    hipLaunchKernelGGL(conv1_fused_kernel<MODE_STATS>, dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    if (bf16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_STATS, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else      hipLaunchKernelGGL((conv1_fused_kernel<MODE_STATS, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_c1_stats");
 }
+extern "C" int tmf_c1_stats(const float* x, const float* w, float* stat_partial,
+                            int B, int D, int H, int W, int C, void* stream) {
+    return c1_stats(false, x, w, stat_partial, B, D, H, W, C, stream);
+}
+extern "C" int tmf_c1_stats_bf16(const float* x, const float* w, float* stat_partial,
+                                 int B, int D, int H, int W, int C, void* stream) {
+    return c1_stats(true, x, w, stat_partial, B, D, H, W, C, stream);
+}
 
-extern "C" int tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* scale, const float* shift,
-                                  float* pooled, int B, int D, int H, int W, int C, float slope, void* stream) {
+static int c1_bn_pool_fwd(bool bf16, const float* x, const float* w, const float* scale, const float* shift,
+                          float* pooled, int B, int D, int H, int W, int C, float slope, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(pooled);
     int rc = check("tmf_c1_bn_pool_fwd", B, D, H, W, C);
     if (rc) return rc;
     const Plan p = make_plan(B, D, H, W, C, 4 * SLAB_BLOCKS);     // a few bricks per workgroup (halo prefetch)
     Args a = base_args(x, w, D, H, W, C, p, slope);
     a.scale = scale; a.shift = shift; a.pooled = pooled;
-    hipLaunchKernelGGL(conv1_fused_kernel<MODE_FWD>, dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    if (bf16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else      hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_c1_bn_pool_fwd");
 }
+extern "C" int tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* scale, const float* shift,
+                                  float* pooled, int B, int D, int H, int W, int C, float slope, void* stream) {
+    return c1_bn_pool_fwd(false, x, w, scale, shift, pooled, B, D, H, W, C, slope, stream);
+}
+extern "C" int tmf_c1_bn_pool_fwd_bf16(const float* x, const float* w, const float* scale, const float* shift,
+                                       float* pooled, int B, int D, int H, int W, int C, float slope, void* stream) {
+    return c1_bn_pool_fwd(true, x, w, scale, shift, pooled, B, D, H, W, C, slope, stream);
+}
 
-extern "C" int tmf_c1_bwd_reduce(const float* x, const float* w, const float* scale, const float* shift,
-                                 const float* mean, const float* invstd, const float* dpool, float* partial,
-                                 int B, int D, int H, int W, int C, float slope, void* stream) {
+static int c1_bwd_reduce(bool bf16, const float* x, const float* w, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, const float* dpool, float* partial,
+                         int B, int D, int H, int W, int C, float slope, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift);
     TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(invstd); TMF_REQUIRE_PTR(dpool); TMF_REQUIRE_PTR(partial);
     int rc = check("tmf_c1_bwd_reduce", B, D, H, W, C);
@@ -323,8 +392,19 @@ extern "C" int tmf_c1_bwd_reduce(const float* x, const float* w, const float* sc
     const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
     Args a = base_args(x, w, D, H, W, C, p, slope);
     a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.dpool = dpool; a.partial = partial;
-    hipLaunchKernelGGL(conv1_fused_kernel<MODE_REDUCE>, dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    if (bf16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else      hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_c1_bwd_reduce");
+}
+extern "C" int tmf_c1_bwd_reduce(const float* x, const float* w, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, const float* dpool, float* partial,
+                                 int B, int D, int H, int W, int C, float slope, void* stream) {
+    return c1_bwd_reduce(false, x, w, scale, shift, mean, invstd, dpool, partial, B, D, H, W, C, slope, stream);
+}
+extern "C" int tmf_c1_bwd_reduce_bf16(const float* x, const float* w, const float* scale, const float* shift,
+                                      const float* mean, const float* invstd, const float* dpool, float* partial,
+                                      int B, int D, int H, int W, int C, float slope, void* stream) {
+    return c1_bwd_reduce(true, x, w, scale, shift, mean, invstd, dpool, partial, B, D, H, W, C, slope, stream);
 }
 
 extern "C" size_t tmf_c1_bwd_wgrad_workspace_bytes(int B, int D, int H, int W, int C) {
@@ -333,10 +413,10 @@ extern "C" size_t tmf_c1_bwd_wgrad_workspace_bytes(int B, int D, int H, int W, i
     return (size_t)(p.nblk + tmf_reduce_groups(p.nblk)) * 27 * C * 4;
 }
 
-extern "C" int tmf_c1_bwd_wgrad(const float* x, const float* w, const float* scale, const float* shift,
-                                const float* mean, const float* invstd, const float* coef, const float* dpool,
-                                float* dw, void* workspace, size_t workspace_bytes,
-                                int B, int D, int H, int W, int C, float slope, void* stream) {
+static int c1_bwd_wgrad(bool bf16, const float* x, const float* w, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* coef, const float* dpool,
+                        float* dw, void* workspace, size_t workspace_bytes,
+                        int B, int D, int H, int W, int C, float slope, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(mean);
     TMF_REQUIRE_PTR(invstd); TMF_REQUIRE_PTR(coef); TMF_REQUIRE_PTR(dpool); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
     int rc = check("tmf_c1_bwd_wgrad", B, D, H, W, C);
@@ -349,9 +429,25 @@ extern "C" int tmf_c1_bwd_wgrad(const float* x, const float* w, const float* sca
     a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.coef = coef; a.dpool = dpool;
     a.partial = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(conv1_fused_kernel<MODE_WGRAD>, dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    if (bf16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    else      hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, false>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
     if ((rc = tmf_launch_result("tmf_c1_bwd_wgrad"))) return rc;
     const long n = 27L * C;
     return tmf_reduce_slabs((const float*)workspace, p.nblk, n, (float*)workspace + (size_t)p.nblk * n, dw, s,
                             "tmf_c1_bwd_wgrad(reduce)");
+}
+
+extern "C" int tmf_c1_bwd_wgrad(const float* x, const float* w, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, const float* coef, const float* dpool,
+                                float* dw, void* workspace, size_t workspace_bytes,
+                                int B, int D, int H, int W, int C, float slope, void* stream) {
+    return c1_bwd_wgrad(false, x, w, scale, shift, mean, invstd, coef, dpool, dw, workspace, workspace_bytes, B, D, H, W, C,
+                        slope, stream);
+}
+extern "C" int tmf_c1_bwd_wgrad_bf16(const float* x, const float* w, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, const float* coef, const float* dpool,
+                                     float* dw, void* workspace, size_t workspace_bytes,
+                                     int B, int D, int H, int W, int C, float slope, void* stream) {
+    return c1_bwd_wgrad(true, x, w, scale, shift, mean, invstd, coef, dpool, dw, workspace, workspace_bytes, B, D, H, W, C,
+                        slope, stream);
 }

@@ -597,7 +597,7 @@ WgBfPlan plan_wgrad_bf16(int B, int D, int H, int W, int cin, int cout) {
     p.tilesD = tmf_cdiv(D, TD); p.tilesH = tmf_cdiv(H, TH); p.tilesW = tmf_cdiv(W, TW);
     p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
     p.gy = tmf_cdiv(cin, 32); p.gz = tmf_cdiv(cout, 32);
-    int want = 512 / (p.gy * p.gz);
+    int want = 256 / (p.gy * p.gz);                     // one workgroup per CU and group; each walks ntiles / want bricks
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
     p.tps = tmf_cdiv(p.ntiles, want);

@@ -9,6 +9,15 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef __HIPCC__
+typedef __bf16 tmf_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 tmf_bf16x8 __attribute__((ext_vector_type(8)));
+// two floats -> two bf16 (round-to-nearest-even, a in the low half): one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ unsigned int tmf_pack_bf16(float a, float b) {
+    const tmf_bf16x2 v = {(__bf16)a, (__bf16)b};
+    return __builtin_bit_cast(unsigned int, v);
+}
+#endif
 
 void tmf_set_error(const char* fmt, ...);
 

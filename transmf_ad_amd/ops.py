@@ -279,10 +279,11 @@ class Conv1BnPool(torch.autograd.Function):
         scale = torch.empty(C, device=dev, dtype=_f32)
         shift = torch.empty(C, device=dev, dtype=_f32)
         s = _stream()
+        sfx = "_bf16" if _PRECISION == "bf16" else ""      # both products on the bf16 matrix cores (opt-in mode)
         if training:
             nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
             part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
-            _lib.call("tmf_c1_stats", x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
+            _lib.call("tmf_c1_stats" + sfx, x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
             _lib.call("tmf_bn_finalize", part.data_ptr(), nblk, C, float(B * D * H * W),
                       gamma.data_ptr(), beta.data_ptr(), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                       float(momentum), float(eps), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
@@ -294,23 +295,23 @@ class Conv1BnPool(torch.autograd.Function):
             mean = running_mean - bias if bias is not None else running_mean.clone()
         out = torch.empty((B, D // 2, H // 2, W // 2, C), device=dev, dtype=_f32)
         if out.numel() > 0:
-            _lib.call("tmf_c1_bn_pool_fwd", x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+            _lib.call("tmf_c1_bn_pool_fwd" + sfx, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                       out.data_ptr(), B, D, H, W, C, float(slope), s)
         ctx.save_for_backward(x, wp, scale, shift, mean, invstd)
-        ctx.cfg = (training, float(slope), C, bias is not None)
+        ctx.cfg = (training, float(slope), C, bias is not None, sfx)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, wp, scale, shift, mean, invstd = ctx.saved_tensors
-        training, slope, C, has_bias = ctx.cfg
+        training, slope, C, has_bias, sfx = ctx.cfg
         B, D, H, W, _ = x.shape
         dev = x.device
         s = _stream()
         dout = _chk(dout, "grad_output")
         nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
         part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
-        _lib.call("tmf_c1_bwd_reduce", x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+        _lib.call("tmf_c1_bwd_reduce" + sfx, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                   mean.data_ptr(), invstd.data_ptr(), dout.data_ptr(), part.data_ptr(), B, D, H, W, C, slope, s)
         dgamma = torch.empty(C, device=dev, dtype=_f32)
         dbeta = torch.empty(C, device=dev, dtype=_f32)
@@ -327,7 +328,7 @@ class Conv1BnPool(torch.autograd.Function):
             nbytes = _lib.query("tmf_c1_bwd_wgrad_workspace_bytes", B, D, H, W, C)
             ws = torch.empty((max(nbytes, 16) // 4,), device=dev, dtype=_f32)
             dw = torch.empty((27, C), device=dev, dtype=_f32)
-            _lib.call("tmf_c1_bwd_wgrad", x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+            _lib.call("tmf_c1_bwd_wgrad" + sfx, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                       mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dout.data_ptr(), dw.data_ptr(),
                       ws.data_ptr(), nbytes, B, D, H, W, C, slope, s)
             dweight = unpack_wgrad(dw, C, 1, 3)
