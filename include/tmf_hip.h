@@ -62,6 +62,12 @@ int         tmf_set_option(const char* name, int value);
 int  tmf_conv3d_fwd(const float* x, const float* w, float* z, float* stat_partial,
                     int B, int D, int H, int W, int cin, int cout, int ksize, void* stream);
 int  tmf_conv3d_stat_blocks(int B, int D, int H, int W, int cin, int cout, int ksize);
+/* Eval-mode block in ONE pass (BatchNorm is affine in eval mode; val_step, kfold_train_adversarial.py:144-161):
+ *   y = pool( LeakyReLU( scale[c] * conv(x)[c] + shift[c] ) ),   pool = TMF_POOL_NONE | MAX2 | AVG2 (floor mode),
+ * scale / shift from tmf_bn_eval_coeffs (they absorb the conv bias).  The raw conv output is never written.
+ * y: [B][D][H][W][cout] or [B][D/2][H/2][W/2][cout].  cin and cout must be multiples of 4.  Forward only. */
+int  tmf_conv3d_fwd_affine(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                           int B, int D, int H, int W, int cin, int cout, int ksize, int pool, float slope, void* stream);
 
 /* Weight gradient: dw[t][ci][co] = sum_{b,pos} x[b,pos+t-1][ci] * dz[b,pos][co].
  * Two stages: split-K partial slabs into `workspace`, then a deterministic reduce.

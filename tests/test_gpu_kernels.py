@@ -203,6 +203,46 @@ def test_first_block_in_bf16_mode(shape):
     assert Pg[1].grad.abs().max().item() == 0.0
 
 
+EVAL_EXTRA = [
+    (1, 24, 24, 24, 64, 128, 3, "max"),    # two output-channel groups, cross-wave h pairs
+    (1, 18, 20, 22, 32, 32, 3, "max"),     # ragged 4x8x8 bricks, odd pooled edge in no dimension, partial bricks
+    (1, 17, 19, 21, 32, 64, 3, "max"),     # odd sizes: floor-mode pooling drops the last plane / row / column
+    (1, 12, 12, 12, 128, 256, 3, None),    # 4x4x4 bricks x 128 channels (conv4.0)
+    (2, 12, 12, 12, 256, 128, 1, "avg"),   # 1x1x1 + average pool (conv4.3)
+    (1, 12, 10, 14, 128, 128, 3, "max"),   # 4x4x4 bricks with pooling (h pairs inside one lane)
+    (1, 16, 16, 16, 32, 32, 3, None),
+]
+
+
+@pytest.mark.parametrize("case", BLOCK_CASES + EVAL_EXTRA)
+def test_eval_block_single_pass(case):
+    """Inference form (no_grad, eval): conv + folded BN + LeakyReLU + pool in one kernel, against fp64 on the host
+    and against the two-pass path on the same data."""
+    ops = _ops()
+    B, D, H, W, cin, cout, k, pool = case
+    if cin == 1 or cin % 4 or cout % 4:
+        pytest.skip("single-pass eval kernel needs cin > 1 and channel counts that are multiples of 4")
+    x = _rand(B, cin, D, H, W, seed=141)
+    w = _rand(cout, cin, k, k, k, seed=142, scale=(cin * k ** 3) ** -0.5)
+    b, g, be = _rand(cout, seed=143, scale=0.1), 1 + _rand(cout, seed=144, scale=0.1), _rand(cout, seed=145, scale=0.1)
+    rm, rv = _rand(cout, seed=146, scale=0.1), 1 + _rand(cout, seed=147, scale=0.1).abs()
+    _, _, _, _, yr = _block_ref(x, w, b, g, be, rm, rv, False, pool, torch.float64)
+    args = [t.to(DEV) for t in (w, b, g, be, rm, rv)]
+    with torch.no_grad():
+        y1 = ops.conv_bn_act_pool(_ndhwc(x).to(DEV), *args, False, pool=pool)
+        ops.FUSE_EVAL_BLOCKS = False
+        try:
+            y2 = ops.conv_bn_act_pool(_ndhwc(x).to(DEV), *args, False, pool=pool)
+        finally:
+            ops.FUSE_EVAL_BLOCKS = True
+    torch.cuda.synchronize()
+    assert tuple(y1.shape) == tuple(_ndhwc(yr).shape)
+    if yr.numel() == 0:
+        return
+    assert _relerr(_ncdhw(y1.cpu()), yr.detach()) < 2e-5
+    assert _relerr(y1, y2.cpu()) < 2e-6
+
+
 def test_maxpool_first_argmax_on_ties():
     """Ties inside a pooling window route the gradient to the FIRST maximum in (d,h,w) order (torch)."""
     ops = _ops()

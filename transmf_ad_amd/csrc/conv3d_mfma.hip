@@ -56,11 +56,17 @@ struct FwdCfg {
     static_assert(KS == 1 || TPS == 1 || TPS == 3, "stage = 1 tap or one kw row");
 };
 
-template <class C, bool VEC>
+// FUSED = true is the eval-mode block in ONE pass (BatchNorm is affine there): the epilogue applies
+// y = LeakyReLU(scale * z + shift) to the accumulators and, for a pooled block, reduces the 2x2x2 windows before
+// anything is stored — d pairs sit in one lane's registers (r & 3), w pairs in lane / lane + 32, h pairs in the same
+// lane (4x4x4 bricks, MT = 2) or in the neighbouring wave (through LDS).  z is then the (pooled) output tensor.
+template <class C, bool VEC, bool FUSED = false>
 __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
-    int tilesD, int tilesH, int tilesW, int ntiles, int dbg) {
+    int tilesD, int tilesH, int tilesW, int ntiles, int dbg,
+    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr,
+    float slope = 0.f, int pool = 0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;
     float* Bs = smem + C::NHALO * C::CP;
@@ -226,6 +232,87 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
         }
     }
 
+    if constexpr (FUSED) {
+#pragma unroll
+        for (int j = 0; j < C::NT; ++j) {
+            const int co = n0 + (wn * C::NT + j) * 32 + l31;
+            const float sc = co < Cout ? aff_scale[co] : 0.f, sh = co < Cout ? aff_shift[co] : 0.f;
+#pragma unroll
+            for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[i][j][r] * sc + sh;
+                    acc[i][j][r] = v > 0.f ? v : v * slope;
+                }
+        }
+        if (pool != 0) {
+            const bool is_max = pool == 1;
+            auto op = [&](float a_, float b_) { return is_max ? fmaxf(a_, b_) : a_ + b_; };
+            const int OD = D / 2, OH = H / 2, OW = W / 2;
+            float* yb = z + (size_t)b * OD * OH * OW * Cout;
+            // d pairs (in-lane) and w pairs (lane <-> lane + 32); q = r >> 2
+            float m[C::MT][C::NT][2][4];
+#pragma unroll
+            for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+                for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+                    for (int dp = 0; dp < 2; ++dp)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float t = op(acc[i][j][2 * dp + 4 * q], acc[i][j][2 * dp + 1 + 4 * q]);
+                            m[i][j][dp][q] = op(t, __shfl_xor(t, 32));
+                        }
+            auto put = [&](int j, int php, int pwp, float v) {        // this half-wave stores pooled plane dp = hsel
+                const int od = d0 / 2 + hsel, oh = h0 / 2 + php, ow = w0 / 2 + pwp;
+                const int co = n0 + (wn * C::NT + j) * 32 + l31;
+                if (od < OD && oh < OH && ow < OW && co < Cout)
+                    yb[((size_t)(od * OH + oh) * OW + ow) * Cout + co] = is_max ? v : v * 0.125f;
+            };
+            if constexpr (C::TW == 4) {                               // ph = 2 T + (q >> 1), pw = 2 (q & 1) + hsel
+#pragma unroll
+                for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float v0 = op(m[i][j][0][q], m[i][j][0][q + 2]), v1 = op(m[i][j][1][q], m[i][j][1][q + 2]);
+                            put(j, wm * C::MT + i, q, hsel ? v1 : v0);
+                        }
+            } else if constexpr (C::MT == 2) {                        // ph = 2 wm + i, pw = 2 q + hsel
+#pragma unroll
+                for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v0 = op(m[0][j][0][q], m[1][j][0][q]), v1 = op(m[0][j][1][q], m[1][j][1][q]);
+                        put(j, wm, q, hsel ? v1 : v0);
+                    }
+            } else {                                                  // ph = wm: the partner row is wave wm ^ 1
+                __syncthreads();                                      // every wave is done with the halo
+                float* ex = halo;
+                const int slot = (((wm >> 1) * C::WN + wn) * C::NT) * 4;
+#pragma unroll
+                for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float mine = hsel ? m[0][j][1][q] : m[0][j][0][q];
+                        if (wm & 1) ex[(slot + j * 4 + q) * 64 + lane] = mine;
+                    }
+                __syncthreads();
+                if (!(wm & 1)) {
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float mine = hsel ? m[0][j][1][q] : m[0][j][0][q];
+                            put(j, wm >> 1, q, op(mine, ex[(slot + j * 4 + q) * 64 + lane]));
+                        }
+                }
+            }
+            return;
+        }
+    }
+
     // ---- epilogue: NDHWC store (+ BatchNorm statistic partials) ----
     // C/D fragment: column = lane & 31 (output channel), row r -> voxel (r&3) + 8*(r>>2) + 4*(lane>>5)
     float s1[C::NT], s2[C::NT];
@@ -353,31 +440,41 @@ FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks) {
     return p;
 }
 
+struct Affine { const float* scale; const float* shift; float slope; int pool; };
+
 template <class C>
 int launch_fwd_cfg(const FwdPlan& p, const float* x, const float* w, float* z, float* sp,
-                   int D, int H, int W, int cin, int cout, hipStream_t s) {
+                   int D, int H, int W, int cin, int cout, hipStream_t s, const Affine* aff) {
     const bool vec = (cin % 4 == 0) && (cout % 4 == 0);
     dim3 grid(p.ntiles, p.nby), block(C::NTHR);
     int rc;
+    if (aff != nullptr) {
+        TMF_REQUIRE(vec, TMF_E_SHAPE, "tmf_conv3d_fwd_affine: cin=%d and cout=%d must be multiples of 4", cin, cout);
+        auto k = conv3d_fwd_kernel<C, true, true>;
+        if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd_affine"))) return rc;
+        hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, (float*)nullptr, D, H, W, cin, cout,
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, 0, aff->scale, aff->shift, aff->slope, aff->pool);
+        return tmf_launch_result("tmf_conv3d_fwd_affine");
+    }
     if (vec) {
-        auto k = conv3d_fwd_kernel<C, true>;
+        auto k = conv3d_fwd_kernel<C, true, false>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0);
     } else {
-        auto k = conv3d_fwd_kernel<C, false>;
+        auto k = conv3d_fwd_kernel<C, false, false>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0);
     }
     return tmf_launch_result("tmf_conv3d_fwd");
 }
 
 template <int KS>
 int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float* sp,
-               int D, int H, int W, int cin, int cout, hipStream_t s) {
+               int D, int H, int W, int cin, int cout, hipStream_t s, const Affine* aff = nullptr) {
 #define TMF_FWD_CASE(CFG, CINC)                                                                   \
-    if (p.cinc == CINC) return launch_fwd_cfg<CFG<KS, CINC>>(p, x, w, z, sp, D, H, W, cin, cout, s);
+    if (p.cinc == CINC) return launch_fwd_cfg<CFG<KS, CINC>>(p, x, w, z, sp, D, H, W, cin, cout, s, aff);
     if (p.cfg == 0) { TMF_FWD_CASE(CfgL32, 8) TMF_FWD_CASE(CfgL32, 16) TMF_FWD_CASE(CfgL32, 32) }
     if (p.cfg == 1) { TMF_FWD_CASE(CfgL64, 8) TMF_FWD_CASE(CfgL64, 16) TMF_FWD_CASE(CfgL64, 32) }
     if (p.cfg == 2) { TMF_FWD_CASE(CfgS128, 8) TMF_FWD_CASE(CfgS128, 16) TMF_FWD_CASE(CfgS128, 32) }
@@ -912,6 +1009,26 @@ extern "C" int tmf_conv3d_fwd(const float* x, const float* w, float* z, float* s
     hipStream_t s = (hipStream_t)stream;
     return ksize == 3 ? launch_fwd<3>(p, x, w, z, stat_partial, D, H, W, cin, cout, s)
                       : launch_fwd<1>(p, x, w, z, stat_partial, D, H, W, cin, cout, s);
+}
+
+extern "C" int tmf_conv3d_fwd_affine(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                     int B, int D, int H, int W, int cin, int cout, int ksize, int pool, float slope,
+                                     void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(y);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
+                "tmf_conv3d_fwd_affine: non-positive dimension (B=%d D=%d H=%d W=%d cin=%d cout=%d)", B, D, H, W, cin, cout);
+    TMF_REQUIRE(ksize == 1 || ksize == 3, TMF_E_ARG, "tmf_conv3d_fwd_affine: ksize must be 1 or 3, got %d", ksize);
+    TMF_REQUIRE(pool == TMF_POOL_NONE || pool == TMF_POOL_MAX2 || pool == TMF_POOL_AVG2, TMF_E_ARG,
+                "tmf_conv3d_fwd_affine: unknown pool mode %d", pool);
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
+                "tmf_conv3d_fwd_affine: one sample exceeds 2^31 elements");
+    TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w); TMF_REQUIRE_ALIGNED(y);
+    if (pool != TMF_POOL_NONE && (D / 2 == 0 || H / 2 == 0 || W / 2 == 0)) return TMF_OK;      // empty output
+    const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize);
+    const Affine aff = {scale, shift, slope, pool};
+    hipStream_t s = (hipStream_t)stream;
+    return ksize == 3 ? launch_fwd<3>(p, x, w, y, nullptr, D, H, W, cin, cout, s, &aff)
+                      : launch_fwd<1>(p, x, w, y, nullptr, D, H, W, cin, cout, s, &aff);
 }
 
 extern "C" size_t tmf_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int cin, int cout, int ksize) {

@@ -337,8 +337,37 @@ class Conv1BnPool(torch.autograd.Function):
         return (None, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None)
 
 
+def conv_bn_act_pool_eval_fused(x, weight, bias, gamma, beta, running_mean, running_var, eps, slope, pool):
+    """Inference form of a block (no autograd graph): conv + folded BatchNorm + LeakyReLU + pool in ONE kernel."""
+    x, weight = _chk(x, "x"), _chk(weight, "weight")
+    cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    B, D, H, W, C = x.shape
+    if C != cin:
+        raise _lib.TmfError(f"conv expects {cin} input channels, got {C}")
+    dev = x.device
+    scale = torch.empty(cout, device=dev, dtype=_f32)
+    shift = torch.empty(cout, device=dev, dtype=_f32)
+    s = _stream()
+    _lib.call("tmf_bn_eval_coeffs", gamma.data_ptr(), beta.data_ptr(), _ptr(bias), running_mean.data_ptr(),
+              running_var.data_ptr(), float(eps), cout, scale.data_ptr(), shift.data_ptr(), s)
+    pc = _lib.pool_code(pool)
+    shape = (B, D, H, W, cout) if pc == _lib.POOL_NONE else (B, D // 2, H // 2, W // 2, cout)
+    out = torch.empty(shape, device=dev, dtype=_f32)
+    if out.numel() > 0:
+        _lib.call("tmf_conv3d_fwd_affine", x.data_ptr(), pack_weight(weight).data_ptr(), scale.data_ptr(),
+                  shift.data_ptr(), out.data_ptr(), B, D, H, W, cin, cout, k, pc, float(slope), s)
+    return out
+
+
+FUSE_EVAL_BLOCKS = os.environ.get("TMF_FUSE_EVAL", "1") != "0"
+
+
 def conv_bn_act_pool(x, weight, bias, gamma, beta, running_mean, running_var, training,
                      momentum=0.1, eps=1e-5, slope=0.01, pool=None):
+    needs_graph = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or gamma.requires_grad)
+    if (FUSE_EVAL_BLOCKS and not training and not needs_graph and _PRECISION == "fp32" and weight.shape[1] > 1
+            and weight.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0):
+        return conv_bn_act_pool_eval_fused(x, weight, bias, gamma, beta, running_mean, running_var, eps, slope, pool)
     if (weight.shape[1] == 1 and weight.shape[2] == 3 and pool == "max" and not x.requires_grad):
         return Conv1BnPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
                                  training, momentum, eps, slope)
