@@ -235,11 +235,24 @@ int tmf_tok_linear_bwd_input(const float* dy, const float* w, float* dx, int R, 
                              const float* ln_gamma, const float* add1, const float* add2, float* ln_partial,
                              float* bias_partial, int partial_stride, void* stream);
 
+/* Conv weights from the reference layout (Cout, Cin, k, k, k) (taps = k^3 = 1 | 27) into the forward / weight-gradient
+ * layout w_fwd[t][ci][co] and, when w_dgrad != NULL, the data-gradient layout w_dgrad[taps-1-t][co][ci], in one launch
+ * (what the host side otherwise does with permute / flip copies on every step). */
+int tmf_pack_conv_weights(const float* w, float* w_fwd, float* w_dgrad, int cout, int cin, int taps, void* stream);
+
 /* Layout conversion between the reference's NCDHW tensors and the channels-last tensors every kernel here uses
  * (voxels = D*H*W).  The model itself never needs it — its input has C == 1 (same bytes either way) and its output
  * is handed back as a strided view — it is here for callers that feed or read intermediate activations. */
 int tmf_layout_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, long voxels, void* stream);
 int tmf_layout_ndhwc_to_ncdhw(const float* src, float* dst, int B, int C, long voxels, void* stream);
+
+/* Weight gradients of up to 8 Linears in one launch: dw[p][n][k] = sum_r dy[p][r][n] * x[p][r][k]
+ * (dy[p]: [R[p]][N[p]], x[p]: [R[p]][K[p]], dw[p]: [N[p]][K[p]] = nn.Linear.weight layout; N, K multiples of 32).
+ * dy / x / dw are HOST arrays of device pointers, R / N / K host arrays.  Split over 8 row ranges into `workspace`,
+ * then summed in fixed order (deterministic). */
+size_t tmf_tok_wgrad_multi_workspace_bytes(int nprob, const int* N, const int* K);
+int    tmf_tok_wgrad_multi(int nprob, const float* const* dy, const float* const* x, float* const* dw,
+                           const int* R, const int* N, const int* K, void* workspace, size_t workspace_bytes, void* stream);
 
 /* cls[b] = [mean_n mri | mean_n pet | max_n mri | max_n pet]  (4*dim); argmax: int32 [B][2][dim]. */
 int tmf_token_pool_fwd(const float* mri, const float* pet, float* cls, int32_t* argmax,

@@ -607,6 +607,17 @@ def test_tok_linear_bwd_input_variants(R):
     assert _relerr(sums[:128], gd.grad) < 1e-5 and _relerr(sums[128:256], bd.grad) < 1e-5
 
 
+@pytest.mark.parametrize("R", [1728, 50, 7])
+def test_tok_wgrad_multi(R):
+    ops = _ops()
+    shapes = [(128, 512), (512, 128), (128, 128), (256, 128), (32, 64)]
+    pairs = [(_rand(R + 3 * i, n, seed=150 + i), _rand(R + 3 * i, k, seed=160 + i)) for i, (n, k) in enumerate(shapes)]
+    outs = ops.tok_wgrad_multi([(a.to(DEV), b.to(DEV)) for a, b in pairs])
+    torch.cuda.synchronize()
+    for (dy, x), got in zip(pairs, outs):
+        assert _relerr(got.cpu(), dy.double().t() @ x.double()) < 5e-6
+
+
 def test_transformer_block_fused_matches_unfused():
     """The fused block (6 + 13 launches) against the op-per-launch path on the same parameters: outputs and every
     gradient agree to fp32 round-off, and both match an fp64 evaluation of the reference formula."""

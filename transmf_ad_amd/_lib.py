@@ -61,9 +61,12 @@ PROTOTYPES = {
     "tmf_xattn_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_xattn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
+    "tmf_pack_conv_weights": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "tmf_layout_ncdhw_to_ndhwc": (_i, [_p, _p, _i, _i, _l, _p]),
     "tmf_layout_ndhwc_to_ncdhw": (_i, [_p, _p, _i, _i, _l, _p]),
     "tmf_tok_row_blocks": (_i, [_i]),
+    "tmf_tok_wgrad_multi_workspace_bytes": (_z, [_i, _p, _p]),
+    "tmf_tok_wgrad_multi": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _z, _p]),
     "tmf_tok_linear_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _p, _p, _f, _p, _p, _p, _p, _p]),
     "tmf_tok_linear_bwd_input": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _p]),
     "tmf_layernorm_bwd_blocks": (_i, [_i, _i]),

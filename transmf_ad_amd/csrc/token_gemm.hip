@@ -292,3 +292,123 @@ extern "C" int tmf_tok_linear_bwd_input(const float* dy, const float* w, float* 
     TMF_REQUIRE(add2 == nullptr, TMF_E_SHAPE, "tmf_tok_linear_bwd_input: add2 needs the LayerNorm epilogue");
     return launch_tok<true, false, EPI_PLAIN>(a, s, "tmf_tok_linear_bwd_input");
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradients of the block's Linears, all in one launch:  dW_p[n][k] = sum_r dy_p[r][n] * x_p[r][k]  for up to
+// 8 problems p (the five of a Transformer block: to_q, to_kv, to_out, the two FeedForward layers).  One workgroup =
+// one 32 x 32 tile of one dW and one of NSPLIT row ranges; its 4 waves take a quarter of the range each (both
+// operands straight from L2: a lane reads dy[row][n0 + lane&31] / x[row][k0 + lane&31], rows 2 s + lane>>5 — coalesced
+// 128-B segments, no LDS staging), v_mfma_f32_32x32x2_f32, cross-wave sum in LDS, partial tile to the workspace; a
+// second small kernel adds the NSPLIT partials in fixed order (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int WG_MAXP = 8, WG_NSPLIT = 8;
+struct WgMulti {
+    const float* dy[WG_MAXP]; const float* x[WG_MAXP]; float* dw[WG_MAXP];
+    int R[WG_MAXP], N[WG_MAXP], K[WG_MAXP], tile0[WG_MAXP + 1], elem0[WG_MAXP + 1];
+    int nprob;
+};
+
+__global__ __launch_bounds__(256) void tok_wgrad_multi_kernel(const WgMulti p, float* __restrict__ partial, long total_elems) {
+    __shared__ float red[3][32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    int q = 0;
+    while (q + 1 < p.nprob && (int)blockIdx.x >= p.tile0[q + 1]) ++q;
+    const int t = blockIdx.x - p.tile0[q];
+    const int tiles_k = p.K[q] >> 5;
+    const int n0 = (t / tiles_k) * 32, k0 = (t % tiles_k) * 32;
+    const int R = p.R[q], N = p.N[q], K = p.K[q];
+    int rows = (R + WG_NSPLIT - 1) / WG_NSPLIT;
+    rows = (rows + 7) & ~7;                                  // 4 waves x pairs of rows
+    const int rb = blockIdx.y * rows + wave * (rows >> 2);
+    const float* dy = p.dy[q] + n0 + l31;
+    const float* xx = p.x[q] + k0 + l31;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int steps = rows >> 3;                             // row pairs per wave
+#pragma unroll 4
+    for (int s = 0; s < steps; ++s) {
+        const int row = rb + 2 * s + hsel;
+        const bool ok = row < R;
+        const float a = ok ? dy[(size_t)row * N] : 0.f;
+        const float b = ok ? xx[(size_t)row * K] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    // D[i = n][j = k]: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 hsel
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][((r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + l31] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* dst = partial + (size_t)blockIdx.y * total_elems + p.elem0[q];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * hsel;
+            const float v = acc[r] + red[0][i * 32 + l31] + red[1][i * 32 + l31] + red[2][i * 32 + l31];
+            dst[(size_t)(n0 + i) * K + k0 + l31] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void tok_wgrad_multi_reduce_kernel(const WgMulti p, const float* __restrict__ partial,
+                                                                     long total_elems) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total_elems) return;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < WG_NSPLIT; ++k) s += partial[(size_t)k * total_elems + e];
+    int q = 0;
+    while (q + 1 < p.nprob && e >= p.elem0[q + 1]) ++q;
+    p.dw[q][e - p.elem0[q]] = s;
+}
+
+int fill_multi(WgMulti& m, int nprob, const float* const* dy, const float* const* x, float* const* dw,
+               const int* R, const int* N, const int* K, const char* fn) {
+    TMF_REQUIRE(nprob > 0 && nprob <= WG_MAXP, TMF_E_SHAPE, "%s: 1..%d problems, got %d", fn, WG_MAXP, nprob);
+    m.nprob = nprob;
+    m.tile0[0] = 0; m.elem0[0] = 0;
+    for (int q = 0; q < nprob; ++q) {
+        TMF_REQUIRE(R[q] > 0 && N[q] > 0 && K[q] > 0 && N[q] % 32 == 0 && K[q] % 32 == 0, TMF_E_SHAPE,
+                    "%s: problem %d: R=%d N=%d K=%d (N and K must be multiples of 32)", fn, q, R[q], N[q], K[q]);
+        m.R[q] = R[q]; m.N[q] = N[q]; m.K[q] = K[q];
+        if (dy) { m.dy[q] = dy[q]; m.x[q] = x[q]; m.dw[q] = dw[q]; }
+        m.tile0[q + 1] = m.tile0[q] + (N[q] / 32) * (K[q] / 32);
+        m.elem0[q + 1] = m.elem0[q] + N[q] * K[q];
+    }
+    return TMF_OK;
+}
+
+}  // namespace
+
+extern "C" size_t tmf_tok_wgrad_multi_workspace_bytes(int nprob, const int* N, const int* K) {
+    if (nprob <= 0 || nprob > WG_MAXP || N == nullptr || K == nullptr) return 0;
+    size_t e = 0;
+    for (int q = 0; q < nprob; ++q) e += (size_t)N[q] * K[q];
+    return e * WG_NSPLIT * 4;
+}
+
+extern "C" int tmf_tok_wgrad_multi(int nprob, const float* const* dy, const float* const* x, float* const* dw,
+                                   const int* R, const int* N, const int* K, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+    TMF_REQUIRE_PTR(dy); TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(R); TMF_REQUIRE_PTR(N); TMF_REQUIRE_PTR(K);
+    TMF_REQUIRE_PTR(workspace);
+    WgMulti m = {};
+    int rc = fill_multi(m, nprob, dy, x, dw, R, N, K, "tmf_tok_wgrad_multi");
+    if (rc) return rc;
+    for (int q = 0; q < nprob; ++q) { TMF_REQUIRE_PTR(dy[q]); TMF_REQUIRE_PTR(x[q]); TMF_REQUIRE_PTR(dw[q]); }
+    const size_t need = tmf_tok_wgrad_multi_workspace_bytes(nprob, N, K);
+    TMF_REQUIRE(workspace_bytes >= need, TMF_E_WORKSPACE, "tmf_tok_wgrad_multi: workspace %zu B < required %zu B",
+                workspace_bytes, need);
+    const long total = m.elem0[nprob];
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(tok_wgrad_multi_kernel, dim3(m.tile0[nprob], WG_NSPLIT), dim3(256), 0, s, m, (float*)workspace, total);
+    if ((rc = tmf_launch_result("tmf_tok_wgrad_multi"))) return rc;
+    hipLaunchKernelGGL(tok_wgrad_multi_reduce_kernel, dim3((unsigned)tmf_cdiv(total, 256L)), dim3(256), 0, s, m,
+                       (const float*)workspace, total);
+    return tmf_launch_result("tmf_tok_wgrad_multi(reduce)");
+}

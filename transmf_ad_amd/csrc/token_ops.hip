@@ -160,6 +160,26 @@ __global__ void token_pool_bwd_kernel(const float* __restrict__ dcls, const int3
     dst[((size_t)b * N + n) * dim + c] = gavg / N + (n == am ? gmax : 0.f);
 }
 
+// Conv weights, reference layout (Cout, Cin, k, k, k) -> the two layouts the kernels consume, in ONE launch:
+//   fwd  [t][ci][co]       = w[co][ci][t]          (tmf_conv3d_fwd / tmf_conv3d_wgrad order)
+//   dgrad[T-1-t][co][ci]   = w[co][ci][t]          (the same kernel computing the data gradient)
+// Writes are coalesced (one thread per output element); the strided reads hit L2 (<= 3.5 MB of weights).
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __restrict__ w, float* __restrict__ fwd,
+                                                                float* __restrict__ dgrad, int cout, int cin, int T) {
+    const long n = (long)cout * cin * T;
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) {
+        const int co = e % cout, ci = (e / cout) % cin, t = e / ((long)cout * cin);
+        fwd[e] = w[((long)co * cin + ci) * T + t];
+        return;
+    }
+    e -= n;
+    if (dgrad != nullptr && e < n) {
+        const int ci = e % cin, co = (e / cin) % cout, tr = e / ((long)cout * cin);
+        dgrad[e] = w[((long)co * cin + ci) * T + (T - 1 - tr)];
+    }
+}
+
 // [B][R][C] <-> [B][C][R] through a 32 x 33 LDS tile (both sides coalesced); R = D*H*W voxels, C channels
 __global__ __launch_bounds__(256) void transpose_tile_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                              int rows, int cols, int tiles_c) {
@@ -185,6 +205,17 @@ static int launch_transpose(const float* src, float* dst, int B, long rows, long
     hipLaunchKernelGGL(transpose_tile_kernel, dim3((unsigned)(tr * tc), B), dim3(256), 0, (hipStream_t)stream, src, dst,
                        (int)rows, (int)cols, (int)tc);
     return tmf_launch_result(what);
+}
+
+extern "C" int tmf_pack_conv_weights(const float* w, float* w_fwd, float* w_dgrad, int cout, int cin, int taps, void* stream) {
+    TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(w_fwd);
+    TMF_REQUIRE(cout > 0 && cin > 0 && (taps == 1 || taps == 27), TMF_E_SHAPE,
+                "tmf_pack_conv_weights: cout=%d cin=%d taps=%d", cout, cin, taps);
+    const long n = (long)cout * cin * taps;
+    const long total = w_dgrad != nullptr ? 2 * n : n;
+    hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((unsigned)tmf_cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream,
+                       w, w_fwd, w_dgrad, cout, cin, taps);
+    return tmf_launch_result("tmf_pack_conv_weights");
 }
 
 extern "C" int tmf_layout_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, long voxels, void* stream) {

@@ -52,11 +52,14 @@ class sNet(nn.Module):
             raise ValueError(f"sNet expects (B, 1, D, H, W), got {tuple(vol.shape)}")
         B, _, D, H, W = vol.shape
         x = vol.reshape(B, D, H, W, 1)          # C == 1: NCDHW and NDHWC are the same bytes
+        if self.training:                       # all seven counters in one multi-tensor launch
+            nbt = [getattr(self, n)[i + 1].num_batches_tracked for n, i, _ in self._PLAN
+                   if getattr(self, n)[i + 1].track_running_stats]
+            if nbt:
+                torch._foreach_add_(nbt, 1)
         for seq_name, i, pool in self._PLAN:
             seq = getattr(self, seq_name)
             conv, bn, act = seq[i], seq[i + 1], seq[i + 2]
-            if self.training and bn.track_running_stats:
-                bn.num_batches_tracked += 1
             x = ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                      bn.running_var, self.training or not bn.track_running_stats,
                                      momentum=bn.momentum, eps=bn.eps, slope=act.negative_slope, pool=pool)

@@ -46,6 +46,15 @@ def pack_weight_dgrad(weight: torch.Tensor) -> torch.Tensor:
     return weight.flip(2, 3, 4).permute(2, 3, 4, 0, 1).contiguous()
 
 
+def pack_weights_both(weight: torch.Tensor, want_dgrad: bool):
+    """Forward layout [k^3][Cin][Cout] and (optionally) data-gradient layout [k^3][Cout][Cin] in one launch."""
+    cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    wf = torch.empty((k ** 3, cin, cout), device=weight.device, dtype=_f32)
+    wd = torch.empty((k ** 3, cout, cin), device=weight.device, dtype=_f32) if want_dgrad else None
+    _lib.call("tmf_pack_conv_weights", weight.data_ptr(), wf.data_ptr(), _ptr(wd), cout, cin, k ** 3, _stream())
+    return wf, wd
+
+
 def unpack_wgrad(dw: torch.Tensor, cout: int, cin: int, k: int) -> torch.Tensor:
     """tap-major [k^3][Cin][Cout] gradient -> reference (Cout, Cin, k, k, k)."""
     return dw.view(k, k, k, cin, cout).permute(4, 3, 0, 1, 2).contiguous()
@@ -180,13 +189,16 @@ class ConvBnActPool(torch.autograd.Function):
             raise _lib.TmfError(f"conv expects {cin} input channels, got {C}")
         weight = _chk(weight, "weight")
         bf16 = _PRECISION if (_PRECISION != "fp32" and k == 3 and cin % 8 == 0 and cin > 1) else False
+        wf = wd = None
+        if not bf16:                      # both weight layouts in one launch; the dgrad one is kept for backward
+            wf, wd = pack_weights_both(weight, ctx.needs_input_grad[0])
 
         def conv(stats):
             if bf16 == "bf16":
                 return conv3d_bf16_raw(x, pack_weight_bf16(weight), cin, cout, stats)
             if bf16 == "fp32x":
                 return conv3d_split_raw(x, split3_bf16(weight.permute(2, 3, 4, 0, 1).contiguous()), cin, cout, stats)
-            return conv3d_raw(x, pack_weight(weight), cin, cout, k, stats)
+            return conv3d_raw(x, wf, cin, cout, k, stats)
 
         dev = x.device
         mean = torch.empty(cout, device=dev, dtype=_f32)
@@ -215,9 +227,10 @@ class ConvBnActPool(torch.autograd.Function):
         if out.numel() > 0:
             _lib.call("tmf_bn_act_pool_fwd", z.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
                       B, D, H, W, cout, pc, float(slope), s)
-        ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd)
+        ctx.save_for_backward(x, weight if wd is None else wd, z, scale, shift, mean, invstd)
         ctx.cfg = (training, float(slope), pc, cin, cout, k, bias is not None)
         ctx.bf16 = bf16
+        ctx.packed_dgrad = wd is not None
         return out
 
     @staticmethod
@@ -259,7 +272,7 @@ class ConvBnActPool(torch.autograd.Function):
                 w3 = split3_bf16(weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())
                 dx, _, _ = conv3d_split_raw(dz, w3, cout, cin, False)
             else:
-                dx, _, _ = conv3d_raw(dz, pack_weight_dgrad(weight), cout, cin, k, False)
+                dx, _, _ = conv3d_raw(dz, weight if ctx.packed_dgrad else pack_weight_dgrad(weight), cout, cin, k, False)
         return (dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
 
 
@@ -511,6 +524,29 @@ def tok_linear_bwd_input(dy, w, gelu_pre=None, ln=None, add1=None, add2=None, ln
 FUSE_TOKEN_LINEARS = os.environ.get("TMF_FUSE_TOKENS", "1") != "0"
 
 
+def tok_wgrad_multi(pairs):
+    """[dy_p^T @ x_p for (dy_p, x_p) in pairs] — all weight gradients of a block in one launch (+ one reduction)."""
+    import ctypes as C
+    n = len(pairs)
+    Rs = (C.c_int * n)(*[dy.shape[0] for dy, _ in pairs])
+    Ns = (C.c_int * n)(*[dy.shape[1] for dy, _ in pairs])
+    Ks = (C.c_int * n)(*[x.shape[1] for _, x in pairs])
+    dev = pairs[0][0].device
+    flat = torch.empty(sum(dy.shape[1] * x.shape[1] for dy, x in pairs), device=dev, dtype=_f32)
+    outs, o = [], 0
+    for dy, x in pairs:
+        m = dy.shape[1] * x.shape[1]
+        outs.append(flat[o:o + m].view(dy.shape[1], x.shape[1]))
+        o += m
+    dys = (C.c_void_p * n)(*[dy.data_ptr() for dy, _ in pairs])
+    xs = (C.c_void_p * n)(*[x.data_ptr() for _, x in pairs])
+    dws = (C.c_void_p * n)(*[t.data_ptr() for t in outs])
+    nbytes = _lib.query("tmf_tok_wgrad_multi_workspace_bytes", n, Ns, Ks)
+    ws = torch.empty(nbytes // 4, device=dev, dtype=_f32)
+    _lib.call("tmf_tok_wgrad_multi", n, dys, xs, dws, Rs, Ns, Ks, ws.data_ptr(), nbytes, _stream())
+    return outs
+
+
 def fused_block_supported(dim, inner, mlp):
     return FUSE_TOKEN_LINEARS and dim == 128 and inner % 128 == 0 and mlp % 128 == 0
 
@@ -518,7 +554,7 @@ def fused_block_supported(dim, inner, mlp):
 class TransformerLayer(torch.autograd.Function):
     """x <- Attention(LayerNorm(x), context) + x ; x <- FeedForward(LayerNorm(x)) + x   as 6 launches forward
     (to_q with LayerNorm prologue, to_kv, attention, to_out + bias + x, Linear + bias + GELU with LayerNorm
-    prologue, Linear + bias + x) and 7 + 5 weight-gradient GEMMs + 1 reduction backward."""
+    prologue, Linear + bias + x) and 7 + 1 (all five weight gradients) + 2 reductions backward."""
 
     @staticmethod
     def forward(ctx, x, context, g1, b1n, wq, wkv, wo, bo, g2, b2n, w1, b1, w2, b2, heads, scale, eps1, eps2):
@@ -570,11 +606,7 @@ class TransformerLayer(torch.autograd.Function):
                                   partial_stride=stride)
         sums = torch.empty(stride, device=dx2.device, dtype=_f32)
         _lib.call("tmf_colsum_finalize", part.data_ptr(), nblk, stride, sums.data_ptr(), _stream())
-        dw2 = dx2.t().mm(g)
-        dw1 = dh_.t().mm(f)
-        dwo = dx1.t().mm(out)
-        dwkv = dkv.t().mm(c2d)
-        dwq = dq.t().mm(a)
+        dw2, dw1, dwo, dwkv, dwq = tok_wgrad_multi([(dx2, g), (dh_, f), (dx1, out), (dkv, c2d), (dq, a)])
         return (dx.view(B, N, dim), None if dctx is None else dctx.view(B, M, dim),
                 sums[o_ln1:o_ln1 + dim], sums[o_ln1 + dim:o_ln1 + 2 * dim], dwq, dwkv, dwo, sums[o_bo:o_bo + dim],
                 sums[o_ln2:o_ln2 + dim], sums[o_ln2 + dim:o_ln2 + 2 * dim], dw1, sums[o_b1:o_b1 + mlp], dw2,
