@@ -24,7 +24,11 @@
 
 namespace {
 
-constexpr int TD = 4, TH = 8, TW = 8;
+#ifndef TMF_C1_TD
+#define TMF_C1_TD 4
+#endif
+constexpr int TD = TMF_C1_TD, TH = 8, TW = 8;
+constexpr int NTI = TD / 2;                           // M-tiles per wave and brick (4 waves, TD * 2 tiles of 32 voxels)
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int NHALO = HD * HH * HW;
 
@@ -154,14 +158,14 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
         constexpr bool FULL = decltype(full_c)::value;   // brick entirely inside the volume: no per-voxel checks
         // ---- z = conv(x) for BOTH M-tiles of this wave, interleaved (two independent MFMA chains) ----
         //      A[i = voxel][k = tap], voxel i = lane & 31 in fragment-row order
-        f32x16 zt[2];
+        f32x16 zt[NTI];
         {
             const int i = l31;
             const int vox = (((i >> 3) & 1) * HH + 2 * ((i >> 2) & 1) + ((i >> 1) & 1)) * HW + 2 * ((i >> 4) & 1) + (i & 1);
-            int a_vox[2];
+            int a_vox[NTI];
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti) {
-                const int mt = wave * 2 + ti;
+            for (int ti = 0; ti < NTI; ++ti) {
+                const int mt = wave * NTI + ti;
                 a_vox[ti] = ((2 * (mt >> 2)) * HH + 4 * ((mt >> 1) & 1)) * HW + 4 * (mt & 1) + vox;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zt[ti][r] = 0.f;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
 #pragma unroll
-                    for (int ti = 0; ti < 2; ++ti) {
+                    for (int ti = 0; ti < NTI; ++ti) {
                         float v[8];
 #pragma unroll
                         for (int j = 0; j < 8; ++j)
@@ -185,14 +189,14 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
                 for (int s = 0; s < 14; ++s) {
                     const int off = hsel ? tapoff(2 * s + 1) : tapoff(2 * s);
 #pragma unroll
-                    for (int ti = 0; ti < 2; ++ti)
+                    for (int ti = 0; ti < NTI; ++ti)
                         zt[ti] = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_vox[ti] + off], bw[s], zt[ti], 0, 0, 0);
                 }
             }
         }
 #pragma unroll
-        for (int ti = 0; ti < 2; ++ti) {
-            const int mt = wave * 2 + ti;                       // M-tile 0..7 of the brick (wave-uniform)
+        for (int ti = 0; ti < NTI; ++ti) {
+            const int mt = wave * NTI + ti;                     // M-tile of the brick (wave-uniform)
             const int org = ((2 * (mt >> 2)) * HH + 4 * ((mt >> 1) & 1)) * HW + 4 * (mt & 1);
             f32x16& z = zt[ti];
             // voxel coordinates of this lane's 16 rows (row r, lane half hsel), relative to the brick:
