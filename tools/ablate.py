@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from transmf_ad_amd import _lib, ops
 from tools.kbench import timeit
 dev = "cuda:0"
-for (cin, cout, s) in [(32, 64, 48), (32, 32, 48), (64, 64, 24), (128, 256, 12)]:
+for (cin, cout, s) in ([] if os.environ.get("FWD_ONLY") else [(32, 64, 48), (32, 32, 48), (64, 64, 24), (128, 256, 12)]):
     x = torch.randn((8, s, s, s, cin), device=dev)
     dz = torch.randn((8, s, s, s, cout), device=dev)
     fl = 2.0 * 27 * cin * cout * 8 * s ** 3
@@ -24,9 +24,9 @@ for (cin, cout, s_) in [(32, 64, 48), (32, 32, 48), (64, 32, 48), (64, 64, 24), 
     w = torch.randn((27, cin, cout), device=dev) * 0.03
     fl = 2.0 * 27 * cin * cout * 8 * s_ ** 3
     row = []
-    for dbg in (0, 2, 4, 6):
+    for dbg in (0, 0, 2, 4, 8, 16, 28, 0):            # 8 = no weight ring / stage barriers, 16 = no halo loads
         _lib.call("tmf_set_option", b"debug", dbg)
-        ms = timeit(lambda: ops.conv3d_raw(x, w, cin, cout, 3, True), 10)
+        ms = timeit(lambda: ops.conv3d_raw(x, w, cin, cout, 3, True), 30)
         row.append(f"dbg{dbg}: {ms:.3f} ms ({fl / ms / 1e9:6.1f} TF)")
     _lib.call("tmf_set_option", b"debug", 0)
     print(f"fwd {cin}->{cout} @{s_}^3  " + " | ".join(row), flush=True)

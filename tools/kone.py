@@ -17,7 +17,8 @@ ap.add_argument("layer")
 ap.add_argument("--B", type=int, default=8)
 ap.add_argument("--S", type=int, default=96)
 ap.add_argument("--reps", type=int, default=5)
-ap.add_argument("--waves", type=int, default=8)
+ap.add_argument("--waves", type=int, default=16)
+ap.add_argument("--spin", type=int, default=0, help="launches of another conv shape first (loaded clock state)")
 a = ap.parse_args()
 _lib.call("tmf_set_option", b"conv_waves", a.waves)
 name, cin, cout, k, div, pool = [l for l in LAYERS if l[0] == a.layer][0]
@@ -27,6 +28,12 @@ x = torch.randn((a.B, s, s, s, cin), device=dev)
 w = torch.randn((cout, cin, k, k, k), device=dev) * (cin * k ** 3) ** -0.5
 dz = torch.randn((a.B, s, s, s, cout), device=dev)
 wp, wd = ops.pack_weight(w), ops.pack_weight_dgrad(w)
+if a.spin:
+    ws = torch.randn((27, 32, 32), device=dev) * 0.03
+    xs = torch.randn((a.B, 48, 48, 48, 32), device=dev)
+    for _ in range(a.spin):
+        ops.conv3d_raw(xs, ws, 32, 32, 3, True)
+    torch.cuda.synchronize()
 for _ in range(a.reps):
     if a.what == "split":
         ops.conv3d_split_raw(x, ops.split3_bf16(w.permute(2, 3, 4, 0, 1).contiguous()), cin, cout, True)
