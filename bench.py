@@ -162,15 +162,14 @@ def main():
     loss = torch.zeros((), device=dev)
     if args.roofline_only:
         args.warmup, args.steps = 0, 0
-    # N > 1: the first ~20 steps of a process pay one-off costs that are not part of a step (RCCL communicator and
-    # channel set-up on the first collectives, the caching allocator growing until the cross-stream gradient
-    # buffers recycle: 23 ms/step over steps 6-25 against 17.8 ms from step 40 on, measured with a 1-rank group).
-    # They are run here as set-up, before the W warm-up steps the contract asks for.
-    setup_steps = 0
-    if (world > 1 or os.environ.get("TMF_DDP_FORCE", "0") == "1") and args.steps > 0:
-        setup_steps = 30
-        for _ in range(setup_steps):
-            step()
+    # The first ~30 steps of a process pay one-off host costs that are not part of a step: lazy code-object loading,
+    # the caching allocator growing until buffers recycle (hipMalloc synchronises), hipBLASLt heuristics, and for N > 1
+    # the RCCL communicator / channel set-up on the first collectives (measured: 11.4 ms/step over steps 6-25 against
+    # 7.3 ms from step 30 on in the host-bound bf16 mode; 23 vs 17.8 ms with a 1-rank RCCL group).  They run here as
+    # set-up, before the W warm-up steps the contract asks for; the GPU-bound fp32 step does not change with them.
+    setup_steps = 30 if args.steps > 0 else 0
+    for _ in range(setup_steps):
+        step()
     for _ in range(args.warmup):
         step()
     fence()

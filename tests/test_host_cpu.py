@@ -123,3 +123,21 @@ def test_reference_checkpoint_loads_strict():
     assert int(net.D[1].num_batches_tracked) == 2 and int(net.fc_cls[1].num_batches_tracked) == 1
     # and back: our state_dict is loadable by anything expecting the reference's keys
     assert list(net.state_dict().keys()) == list(sd.keys())
+
+
+def test_fast_mode_switch_matches_module_train():
+    """model.train()/.eval() through the cached flat loop sets exactly what nn.Module.train() sets, also after a
+    sub-module is replaced."""
+    import transmf_ad_amd as T
+    net = T.model_ad(32, 2, 4, 8, 128, 0.)
+    net.eval()
+    assert not any(m.training for m in net.modules())
+    net.train()
+    assert all(m.training for m in net.modules())
+    net.fc_cls[3] = torch.nn.Dropout(0.25)               # replace a sub-module: the cache must be rebuilt
+    net.fc_cls[3].eval()
+    net.train()
+    assert net.fc_cls[3].training
+    net.add_module("extra", torch.nn.Linear(2, 2))
+    net.eval()
+    assert not net.extra.training and not any(m.training for m in net.modules())

@@ -16,7 +16,9 @@ _f32 = torch.float32
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream (the private fast path: the public current_stream() builds a
+    Stream object and costs ~10 us, ~0.7 ms per train step over ~75 calls)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
