@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="pairs in the bounded CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
-    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--precision", choices=["fp32", "bf16", "fp32x"], default="fp32",
                     help="bf16: forward/dgrad 3x3x3 convs on the bf16 matrix cores (BASELINE configs[2] mode; not the headline)")
     ap.add_argument("--model", choices=["ad", "cnn", "single"], default="ad",
                     help="ad: model_ad (headline); cnn: model_CNN_ad; single: model_single (MRI only) — BASELINE configs[4]")
@@ -279,7 +279,8 @@ def main():
             "value": round(pairs_per_s, 3), "unit": "volume-pairs/s" if args.model != "single" else "volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.precision == "fp32" else "bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate+storage",
+            "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate+storage",
+                      "fp32x": "f32 via exact 3-way bf16 split on the bf16 MFMA (conv fwd/dgrad; wgrad exact f32 MFMA)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{model_desc} train step, "
                                    f"batch {B} {'volumes' if args.model == 'single' else 'pairs'} of 1x{S}^3 per GPU, {args.precision}"

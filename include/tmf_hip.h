@@ -235,7 +235,8 @@ int tmf_tok_linear_bwd_input(const float* dy, const float* w, float* dx, int R, 
                              const float* ln_gamma, const float* add1, const float* add2, float* ln_partial,
                              float* bias_partial, int partial_stride, void* stream);
 
-/* Conv weights from the reference layout (Cout, Cin, k, k, k) (taps = k^3 = 1 | 27) into the forward / weight-gradient
+/* Conv weights from the reference layout (Cout, Cin, k, k, k) of nn.Conv3d (networks.py:22,28,31,37,40,46,49;
+ * taps = k^3 = 1 | 27) into the forward / weight-gradient
  * layout w_fwd[t][ci][co] and, when w_dgrad != NULL, the data-gradient layout w_dgrad[taps-1-t][co][ci], in one launch
  * (what the host side otherwise does with permute / flip copies on every step). */
 int tmf_pack_conv_weights(const float* w, float* w_fwd, float* w_dgrad, int cout, int cin, int taps, void* stream);
@@ -246,7 +247,8 @@ int tmf_pack_conv_weights(const float* w, float* w_fwd, float* w_dgrad, int cout
 int tmf_layout_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, long voxels, void* stream);
 int tmf_layout_ndhwc_to_ncdhw(const float* src, float* dst, int B, int C, long voxels, void* stream);
 
-/* Weight gradients of up to 8 Linears in one launch: dw[p][n][k] = sum_r dy[p][r][n] * x[p][r][k]
+/* Weight gradients of up to 8 Linears in one launch (the backward of to_q / to_kv / to_out, networks.py:149-155, and of
+ * the two FeedForward Linears, :129-132): dw[p][n][k] = sum_r dy[p][r][n] * x[p][r][k]
  * (dy[p]: [R[p]][N[p]], x[p]: [R[p]][K[p]], dw[p]: [N[p]][K[p]] = nn.Linear.weight layout; N, K multiples of 32).
  * dy / x / dw are HOST arrays of device pointers, R / N / K host arrays.  Split over 8 row ranges into `workspace`,
  * then summed in fixed order (deterministic). */
