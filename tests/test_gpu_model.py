@@ -76,6 +76,22 @@ CASES = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid", 
 
 @pytest.mark.parametrize("name", CASES)
 def test_train_step_matches_reference_golden(name):
+    _golden_train_step(name)
+
+
+@pytest.mark.parametrize("name", ["ad_mid", "ad_full_b2", "cnn_mid", "single_mid"])
+def test_train_step_matches_reference_golden_fp32x(name):
+    """The opt-in fp32x mode (exact 3-way bf16 split of every conv operand, six partial products on the bf16
+    matrix cores) must pass the SAME golden comparison at the SAME tolerances as the exact-fp32 path."""
+    import transmf_ad_amd as T
+    T.set_conv_precision("fp32x")
+    try:
+        _golden_train_step(name)
+    finally:
+        T.set_conv_precision("fp32")
+
+
+def _golden_train_step(name):
     if not available(name):
         pytest.skip("fixture not generated")
     g = Golden(name)
