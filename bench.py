@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp32x"], default="fp32",
                     help="bf16: forward/dgrad 3x3x3 convs on the bf16 matrix cores (BASELINE configs[2] mode; not the headline)")
+    ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16 (with --precision bf16): sNet activations between the conv blocks stored as bf16 tensors")
     ap.add_argument("--model", choices=["ad", "cnn", "single"], default="ad",
                     help="ad: model_ad (headline); cnn: model_CNN_ad; single: model_single (MRI only) — BASELINE configs[4]")
     ap.add_argument("--no-fused-adam", action="store_true")
@@ -94,6 +96,9 @@ def main():
     dev = torch.device("cuda", local)
 
     ops.set_conv_precision(args.precision)
+    if args.storage == "bf16" and args.precision != "bf16":
+        raise SystemExit("--storage bf16 needs --precision bf16")
+    ops.set_activation_storage(args.storage)
     torch.manual_seed(0)
     if args.model == "ad":
         net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to(dev)
@@ -279,7 +284,8 @@ def main():
             "value": round(pairs_per_s, 3), "unit": "volume-pairs/s" if args.model != "single" else "volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate+storage",
+            "dtype": {"fp32": "f32", "bf16": ("bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate, bf16 activation storage between conv blocks"
+                               if args.storage == "bf16" else "bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate+storage"),
                       "fp32x": "f32 via exact 3-way bf16 split on the bf16 MFMA (conv fwd/dgrad; wgrad exact f32 MFMA)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{model_desc} train step, "

@@ -88,6 +88,13 @@ int  tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W);
 size_t tmf_conv3d_wgrad_bf16_workspace_bytes(int B, int D, int H, int W, int cin, int cout);
 int    tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
                              int B, int D, int H, int W, int cin, int cout, void* stream);
+/* bf16 ACTIVATION STORAGE (configs[2]: "bf16 storage + bf16 MFMA with fp32 accumulate"): the same kernels reading /
+ * writing bf16 tensors directly (no conversion in the staging path, half the bytes).  io bits for the forward: 1 = x is
+ * bf16, 2 = z is bf16 (statistics still from the fp32 accumulators); for the weight gradient io = 1: x and dz are bf16. */
+int    tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z, float* stat_partial,
+                             int B, int D, int H, int W, int cin, int cout, int io, void* stream);
+int    tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
+                               int B, int D, int H, int W, int cin, int cout, int io, void* stream);
 /* fp32-ACCURATE variant on the bf16 matrix cores: operands split exactly into three bf16 numbers (hi+mid+lo), the
  * six partial products of order >= 2^-16 accumulated in fp32 (the dropped terms are below one fp32 ulp of the
  * product).  w3_bf16: bf16 [3 parts][27][cout][cin]; same shapes / statistics layout as tmf_conv3d_fwd_bf16. */
@@ -123,18 +130,19 @@ int    tmf_c1_bwd_wgrad(const float* x, const float* w, const float* scale, cons
                         const float* mean, const float* invstd, const float* coef, const float* dpool,
                         float* dw, void* workspace, size_t workspace_bytes,
                         int B, int D, int H, int W, int C, float slope, void* stream);
-/* The same four passes with both products on the bf16 matrix cores (operands rounded to bf16, fp32 accumulation,
- * fp32 I/O): 2 MFMAs per tile instead of 14 / 16.  Same arguments, same workspace / block counts. */
+/* The same four passes with both products on the bf16 matrix cores (operands rounded to bf16, fp32 accumulation):
+ * 2 MFMAs per tile instead of 14 / 16.  Same arguments, same workspace / block counts; pooled_bf16 != 0: the pooled
+ * output / its gradient dpool are bf16 tensors (bf16 activation storage, BASELINE configs[2]). */
 int    tmf_c1_stats_bf16(const float* x, const float* w, float* stat_partial, int B, int D, int H, int W, int C, void* stream);
-int    tmf_c1_bn_pool_fwd_bf16(const float* x, const float* w, const float* scale, const float* shift, float* pooled,
-                               int B, int D, int H, int W, int C, float slope, void* stream);
+int    tmf_c1_bn_pool_fwd_bf16(const float* x, const float* w, const float* scale, const float* shift, void* pooled,
+                               int B, int D, int H, int W, int C, float slope, int pooled_bf16, void* stream);
 int    tmf_c1_bwd_reduce_bf16(const float* x, const float* w, const float* scale, const float* shift,
-                              const float* mean, const float* invstd, const float* dpool, float* partial,
-                              int B, int D, int H, int W, int C, float slope, void* stream);
+                              const float* mean, const float* invstd, const void* dpool, float* partial,
+                              int B, int D, int H, int W, int C, float slope, int pooled_bf16, void* stream);
 int    tmf_c1_bwd_wgrad_bf16(const float* x, const float* w, const float* scale, const float* shift,
-                             const float* mean, const float* invstd, const float* coef, const float* dpool,
+                             const float* mean, const float* invstd, const float* coef, const void* dpool,
                              float* dw, void* workspace, size_t workspace_bytes,
-                             int B, int D, int H, int W, int C, float slope, void* stream);
+                             int B, int D, int H, int W, int C, float slope, int pooled_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------
  * BatchNorm3d (training statistics) + LeakyReLU + 2x2x2 pool, two passes.
@@ -174,6 +182,18 @@ int tmf_bn_bwd_finalize(const float* partial, int nblk, int C, double count,
 int tmf_bn_act_pool_bwd_apply(const float* z, const float* dout, const float* scale, const float* shift,
                               const float* mean, const float* invstd, const float* coef, float* dz,
                               int B, int D, int H, int W, int C, int pool, float slope, void* stream);
+
+/* The three passes on typed tensors.  io bit 0: z and dz are bf16 tensors; bit 1: out and dout are bf16 tensors
+ * (io = 0 all float, 1 = bf16 z with a float output (the block feeding the fp32 1x1x1 layer), 3 = all bf16).  Arithmetic,
+ * per-channel vectors and partials are fp32 in every mode. */
+int tmf_bn_act_pool_fwd_t(const void* z, const float* scale, const float* shift, void* out,
+                          int B, int D, int H, int W, int C, int pool, float slope, int io, void* stream);
+int tmf_bn_act_pool_bwd_reduce_t(const void* z, const void* dout, const float* scale, const float* shift,
+                                 const float* mean, const float* invstd, float* partial,
+                                 int B, int D, int H, int W, int C, int pool, float slope, int io, void* stream);
+int tmf_bn_act_pool_bwd_apply_t(const void* z, const void* dout, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, const float* coef, void* dz,
+                                int B, int D, int H, int W, int C, int pool, float slope, int io, void* stream);
 
 /* Sum `nblk` partial rows of `ncol` floats (fp64 accumulation) into out[ncol]. */
 int tmf_colsum_finalize(const float* partial, int nblk, int ncol, float* out, void* stream);

@@ -243,6 +243,49 @@ def test_eval_block_single_pass(case):
     assert _relerr(y1, y2.cpu()) < 2e-6
 
 
+def test_two_blocks_with_bf16_activation_storage():
+    """Two chained blocks (32->32 no pool, 32->64 max pool) with bf16 tensors between and inside them, forward and
+    backward, against fp64 on the host: bf16-operand accuracy (one extra 2^-9 rounding per stored tensor)."""
+    ops = _ops()
+    B, S = 2, 16
+    x = _rand(B, 32, S, S, S, seed=171)
+    w1 = _rand(32, 32, 3, 3, 3, seed=172, scale=(32 * 27) ** -0.5)
+    w2 = _rand(64, 32, 3, 3, 3, seed=173, scale=(32 * 27) ** -0.5)
+    P1 = [_rand(32, seed=174, scale=0.1), 1 + _rand(32, seed=175, scale=0.1), _rand(32, seed=176, scale=0.1)]
+    P2 = [_rand(64, seed=177, scale=0.1), 1 + _rand(64, seed=178, scale=0.1), _rand(64, seed=179, scale=0.1)]
+    rm1, rv1, rm2, rv2 = torch.zeros(32), torch.ones(32), torch.zeros(64), torch.ones(64)
+    xr, Q1, _, _, y1 = _block_ref(x, w1, *P1, rm1, rv1, True, None, torch.float64)
+    w2d = w2.double().requires_grad_(True)
+    g2, b2 = P2[1].double().requires_grad_(True), P2[2].double().requires_grad_(True)
+    y2 = F.max_pool3d(F.leaky_relu(F.batch_norm(F.conv3d(y1, w2d, P2[0].double(), padding=1), rm2.double(), rv2.double(),
+                                                 g2, b2, True, 0.1, 1e-5), 0.01), 2, 2)
+    go = _rand(*y2.shape, seed=180)
+    y2.backward(go.double())
+    ops.set_conv_precision("bf16")
+    ops.set_activation_storage("bf16")
+    try:
+        xg = _ndhwc(x).to(DEV).bfloat16().requires_grad_(True)
+        A1 = [t.clone().to(DEV).requires_grad_(True) for t in (w1, *P1)]
+        A2 = [t.clone().to(DEV).requires_grad_(True) for t in (w2, *P2)]
+        h = ops.conv_bn_act_pool(xg, A1[0], A1[1], A1[2], A1[3], rm1.to(DEV), rv1.to(DEV), True, pool=None, out_bf16=True)
+        assert h.dtype == torch.bfloat16
+        yg = ops.conv_bn_act_pool(h, A2[0], A2[1], A2[2], A2[3], rm2.to(DEV), rv2.to(DEV), True, pool="max", out_bf16=False)
+        assert yg.dtype == torch.float32
+        yg.backward(_ndhwc(go).to(DEV))
+        torch.cuda.synchronize()
+    finally:
+        ops.set_activation_storage("fp32")
+        ops.set_conv_precision("fp32")
+    assert _relerr(_ncdhw(yg.detach().cpu()), y2.detach()) < 3e-2
+
+    def l2(got, ref):
+        return ((got.double().cpu() - ref).norm() / ref.norm()).item()
+    assert xg.grad.dtype == torch.bfloat16
+    # bf16 noise (4e-3 of z) flips max-pool / LeakyReLU decisions on random data: gradients are compared in L2
+    assert l2(A2[0].grad, w2d.grad) < 2e-1 and l2(A1[0].grad, Q1[0].grad) < 2e-1
+    assert l2(A2[2].grad, g2.grad) < 2e-1 and l2(_ncdhw(xg.grad.float().cpu()), xr.grad) < 2e-1
+
+
 def test_maxpool_first_argmax_on_ties():
     """Ties inside a pooling window route the gradient to the FIRST maximum in (d,h,w) order (torch)."""
     ops = _ops()

@@ -422,6 +422,47 @@ def test_bf16_conv_precision_mode(name):
     assert all(torch.isfinite(p.grad).all() for p in net.parameters())
 
 
+@pytest.mark.parametrize("name", ["ad_mid", "ad_full_b8"])
+def test_bf16_activation_storage_mode(name):
+    """configs[2] as SURVEY §8d states it — bf16 storage + bf16 MFMA, fp32 accumulation: the activations between the
+    conv blocks are bf16 tensors.  Every stored value carries one more 2^-9 rounding than the fp32-storage bf16 mode, so
+    the stated tolerance is 5e-2 of the `cls` scale (fp32-storage mode: 3e-2) and 0.15 on the B=8 loss; the two
+    bf16 modes must also agree with each other to 3e-2."""
+    if not available(name):
+        pytest.skip("fixture not generated")
+    import transmf_ad_amd as T
+    g = Golden(name)
+    got = {}
+    for storage in ("fp32", "bf16"):
+        T.set_conv_precision("bf16")
+        T.set_activation_storage(storage)
+        try:
+            net = build(g)
+            seen = {}
+            net.fuse_transformer.register_forward_hook(lambda _m, _i, o: seen.__setitem__("cls", o))
+            outs, loss = step(net, g, train=True)
+            got[storage] = (probe(seen["cls"]), loss.item(), net)
+        finally:
+            T.set_activation_storage("fp32")
+            T.set_conv_precision("fp32")
+    ref = g["f32/probe/cls"]
+    scale = max(1.0, np.abs(ref).max())
+    err = np.abs(got["bf16"][0] - ref).max()
+    assert err <= 5e-2 * scale, err
+    assert np.abs(got["bf16"][0] - got["fp32"][0]).max() <= 3e-2 * scale
+    if g.batch >= 8:
+        assert abs(got["bf16"][1] - float(g["f32/train/loss"])) <= 0.15
+    net = got["bf16"][2]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    # gradients of the two bf16 modes: a sanity bound in L2 only — on uniform-noise volumes the discrete max-pool /
+    # LeakyReLU decisions flip under either rounding and the first layer collects every flip downstream of it (0.52
+    # measured on conv1; the well-conditioned gradient comparisons are the kernel tests)
+    for (k, a), (_, b) in zip(got["bf16"][2].named_parameters(), got["fp32"][2].named_parameters()):
+        if "conv" in k and k.endswith("weight") and g.batch >= 8:
+            rel = ((a.grad - b.grad).norm() / b.grad.norm().clamp_min(1e-20)).item()
+            assert rel < 1.0, (k, rel)
+
+
 def test_reference_checkpoint_eval_parity():
     """Load the reference-format checkpoint fixture and reproduce the reference's eval-mode outputs (val_step)."""
     import os

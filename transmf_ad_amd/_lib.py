@@ -45,9 +45,14 @@ PROTOTYPES = {
     "tmf_c1_bn_pool_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_c1_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_c1_stats_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "tmf_c1_bn_pool_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
-    "tmf_c1_bwd_reduce_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
-    "tmf_c1_bwd_wgrad_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _p]),
+    "tmf_c1_bn_pool_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "tmf_c1_bwd_reduce_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "tmf_c1_bwd_wgrad_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "tmf_conv3d_fwd_bf16_t": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tmf_conv3d_wgrad_bf16_t": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tmf_bn_act_pool_fwd_t": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "tmf_bn_act_pool_bwd_reduce_t": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "tmf_bn_act_pool_bwd_apply_t": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "tmf_c1_bwd_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "tmf_c1_bwd_wgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_bn_finalize": (_i, [_p, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),

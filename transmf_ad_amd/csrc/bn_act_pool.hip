@@ -19,19 +19,16 @@
 
 namespace {
 
-typedef float f32x1 __attribute__((ext_vector_type(1)));
+typedef tmf_f32x1 f32x1;
 template <int VEC> struct Vec;
 template <> struct Vec<4> { typedef f32x4 T; };
 template <> struct Vec<1> { typedef f32x1 T; };
 
-template <int VEC>
-__device__ __forceinline__ typename Vec<VEC>::T ldv(const float* p) {
-    return *reinterpret_cast<const typename Vec<VEC>::T*>(p);
-}
-template <int VEC>
-__device__ __forceinline__ void stv(float* p, typename Vec<VEC>::T v) {
-    *reinterpret_cast<typename Vec<VEC>::T*>(p) = v;
-}
+// activations are float or bf16 tensors (TmfIO widens / rounds); per-channel vectors are always float
+template <int VEC, typename T>
+__device__ __forceinline__ typename Vec<VEC>::T ldv(const T* p) { return TmfIO<T, VEC>::ld(p); }
+template <int VEC, typename T>
+__device__ __forceinline__ void stv(T* p, typename Vec<VEC>::T v) { TmfIO<T, VEC>::st(p, v); }
 
 struct Geo {
     int B, D, H, W, C;
@@ -51,10 +48,10 @@ __host__ __device__ inline Geo make_geo(int B, int D, int H, int W, int C, int p
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
-template <int VEC, int POOL>
+template <int VEC, int POOL, typename ZT = float, typename YT = float>
 __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(
-    const float* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
-    float* __restrict__ out, Geo g, int CQ, int ROWS, float slope) {
+    const ZT* __restrict__ z, const float* __restrict__ scale, const float* __restrict__ shift,
+    YT* __restrict__ out, Geo g, int CQ, int ROWS, float slope) {
     typedef typename Vec<VEC>::T V;
     const int cq = threadIdx.x % CQ, prow = threadIdx.x / CQ;
     if (prow >= ROWS) return;
@@ -105,7 +102,7 @@ __global__ __launch_bounds__(256) void bn_act_pool_fwd_kernel(
 // ---------------------------------------------------------------------------------
 // For one pooling window (or one voxel when POOL == NONE) and one channel group, produce for
 // each of the (up to 8) voxels: validity, xhat and dy = dLoss/d(BN output).
-template <int VEC, int POOL>
+template <int VEC, int POOL, typename ZT = float, typename YT = float>
 struct Window {
     typedef typename Vec<VEC>::T V;
     static constexpr int NV = POOL == TMF_POOL_NONE ? 1 : 8;
@@ -113,7 +110,7 @@ struct Window {
     long off[NV];        // element offset of voxel k (channel group included)
     V xhat[NV], dy[NV];
 
-    __device__ __forceinline__ void eval(const float* __restrict__ z, const float* __restrict__ dout,
+    __device__ __forceinline__ void eval(const ZT* __restrict__ z, const YT* __restrict__ dout,
                                          const Geo& g, long win, int c, const V& sc, const V& sh,
                                          const V& mu, const V& is, float slope) {
         long t = win;
@@ -180,9 +177,9 @@ struct Window {
     }
 };
 
-template <int VEC, int POOL>
+template <int VEC, int POOL, typename ZT = float, typename YT = float>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const float* __restrict__ z, const float* __restrict__ dout, const float* __restrict__ scale,
+    const ZT* __restrict__ z, const YT* __restrict__ dout, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
     float* __restrict__ partial, Geo g, int CQ, int ROWS, float slope) {
     typedef typename Vec<VEC>::T V;
@@ -195,11 +192,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     for (int q = 0; q < VEC; ++q) { s_dy[q] = 0.f; s_dyx[q] = 0.f; }
     if (live) {
         const V sc = ldv<VEC>(scale + c), sh = ldv<VEC>(shift + c), mu = ldv<VEC>(mean + c), is = ldv<VEC>(invstd + c);
-        Window<VEC, POOL> wn;
+        Window<VEC, POOL, ZT, YT> wn;
         for (long win = (long)blockIdx.x * ROWS + prow; win < g.nwin; win += (long)gridDim.x * ROWS) {
             wn.eval(z, dout, g, win, c, sc, sh, mu, is, slope);
 #pragma unroll
-            for (int k = 0; k < Window<VEC, POOL>::NV; ++k) {
+            for (int k = 0; k < Window<VEC, POOL, ZT, YT>::NV; ++k) {
                 if (wn.valid[k]) {
 #pragma unroll
                     for (int q = 0; q < VEC; ++q) {
@@ -223,22 +220,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
-template <int VEC, int POOL>
+template <int VEC, int POOL, typename ZT = float, typename YT = float>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const float* __restrict__ z, const float* __restrict__ dout, const float* __restrict__ scale,
+    const ZT* __restrict__ z, const YT* __restrict__ dout, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ coef, float* __restrict__ dz, Geo g, int CQ, int ROWS, float slope) {
+    const float* __restrict__ coef, ZT* __restrict__ dz, Geo g, int CQ, int ROWS, float slope) {
     typedef typename Vec<VEC>::T V;
     const int cq = threadIdx.x % CQ, prow = threadIdx.x / CQ;
     if (prow >= ROWS) return;
     const int c = cq * VEC;
     const V sc = ldv<VEC>(scale + c), sh = ldv<VEC>(shift + c), mu = ldv<VEC>(mean + c), is = ldv<VEC>(invstd + c);
     const V k0 = ldv<VEC>(coef + c), k1 = ldv<VEC>(coef + g.C + c);
-    Window<VEC, POOL> wn;
+    Window<VEC, POOL, ZT, YT> wn;
     for (long win = (long)blockIdx.x * ROWS + prow; win < g.nwin; win += (long)gridDim.x * ROWS) {
         wn.eval(z, dout, g, win, c, sc, sh, mu, is, slope);
 #pragma unroll
-        for (int k = 0; k < Window<VEC, POOL>::NV; ++k) {
+        for (int k = 0; k < Window<VEC, POOL, ZT, YT>::NV; ++k) {
             if (wn.valid[k]) {
                 V r;
 #pragma unroll
@@ -386,8 +383,17 @@ extern "C" int tmf_bn_eval_coeffs(const float* gamma, const float* beta, const f
     return tmf_launch_result("tmf_bn_eval_coeffs");
 }
 
-extern "C" int tmf_bn_act_pool_fwd(const float* z, const float* scale, const float* shift, float* out,
-                                   int B, int D, int H, int W, int C, int pool, float slope, void* stream) {
+// io: bit 0 = z / dz are bf16 tensors, bit 1 = out / dout are bf16 tensors (0 = everything float)
+#define TMF_DISPATCH_IO(LAUNCH, io, fn)                                                                   \
+    do {                                                                                                  \
+        if ((io) == 0) { LAUNCH(float, float); }                                                          \
+        else if ((io) == 3) { LAUNCH(tmf_bf16_t, tmf_bf16_t); }                                           \
+        else if ((io) == 1) { LAUNCH(tmf_bf16_t, float); }                                                \
+        else { tmf_set_error("%s: unsupported io mode %d (0, 1 or 3)", fn, (int)(io)); return TMF_E_ARG; } \
+    } while (0)
+
+extern "C" int tmf_bn_act_pool_fwd_t(const void* z, const float* scale, const float* shift, void* out,
+                                     int B, int D, int H, int W, int C, int pool, float slope, int io, void* stream) {
     TMF_REQUIRE_PTR(z); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(out);
     int rc = check_geo("tmf_bn_act_pool_fwd", B, D, H, W, C, pool);
     if (rc) return rc;
@@ -396,10 +402,18 @@ extern "C" int tmf_bn_act_pool_fwd(const float* z, const float* scale, const flo
     const long nout = pool ? (long)B * (D / 2) * (H / 2) * (W / 2) : (long)B * D * H * W;
     if (nout == 0) return TMF_OK;
     const EwPlan p = plan_ew(nout, C);
-#define K_FWD(V, P, ...) hipLaunchKernelGGL((bn_act_pool_fwd_kernel<V, P>), dim3(p.nblk), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
-    TMF_DISPATCH_VP(K_FWD, p.vec, pool, z, scale, shift, out, g, p.cq, p.rows, slope);
+#define K_FWD(V, P, ...) hipLaunchKernelGGL((bn_act_pool_fwd_kernel<V, P, ZT_, YT_>), dim3(p.nblk), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+#define L_FWD(ZT, YT) { typedef ZT ZT_; typedef YT YT_; \
+        TMF_DISPATCH_VP(K_FWD, p.vec, pool, (const ZT_*)z, scale, shift, (YT_*)out, g, p.cq, p.rows, slope); }
+    TMF_DISPATCH_IO(L_FWD, io, "tmf_bn_act_pool_fwd_t");
+#undef L_FWD
 #undef K_FWD
     return tmf_launch_result("tmf_bn_act_pool_fwd");
+}
+
+extern "C" int tmf_bn_act_pool_fwd(const float* z, const float* scale, const float* shift, float* out,
+                                   int B, int D, int H, int W, int C, int pool, float slope, void* stream) {
+    return tmf_bn_act_pool_fwd_t(z, scale, shift, out, B, D, H, W, C, pool, slope, 0, stream);
 }
 
 extern "C" int tmf_bn_act_pool_bwd_blocks(int B, int D, int H, int W, int C, int pool) {
@@ -408,9 +422,9 @@ extern "C" int tmf_bn_act_pool_bwd_blocks(int B, int D, int H, int W, int C, int
     return plan_ew(g.nwin, C).nblk;
 }
 
-extern "C" int tmf_bn_act_pool_bwd_reduce(const float* z, const float* dout, const float* scale, const float* shift,
-                                          const float* mean, const float* invstd, float* partial,
-                                          int B, int D, int H, int W, int C, int pool, float slope, void* stream) {
+extern "C" int tmf_bn_act_pool_bwd_reduce_t(const void* z, const void* dout, const float* scale, const float* shift,
+                                            const float* mean, const float* invstd, float* partial,
+                                            int B, int D, int H, int W, int C, int pool, float slope, int io, void* stream) {
     TMF_REQUIRE_PTR(z); TMF_REQUIRE_PTR(dout); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift);
     TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(invstd); TMF_REQUIRE_PTR(partial);
     int rc = check_geo("tmf_bn_act_pool_bwd_reduce", B, D, H, W, C, pool);
@@ -419,10 +433,19 @@ extern "C" int tmf_bn_act_pool_bwd_reduce(const float* z, const float* dout, con
     const Geo g = make_geo(B, D, H, W, C, pool);
     const EwPlan p = plan_ew(g.nwin, C);
     const size_t lds = (size_t)p.rows * 2 * C * 4;
-#define K_RED(V, P, ...) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, P>), dim3(p.nblk), dim3(256), lds, (hipStream_t)stream, __VA_ARGS__)
-    TMF_DISPATCH_VP(K_RED, p.vec, pool, z, dout, scale, shift, mean, invstd, partial, g, p.cq, p.rows, slope);
+#define K_RED(V, P, ...) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, P, ZT_, YT_>), dim3(p.nblk), dim3(256), lds, (hipStream_t)stream, __VA_ARGS__)
+#define L_RED(ZT, YT) { typedef ZT ZT_; typedef YT YT_; \
+        TMF_DISPATCH_VP(K_RED, p.vec, pool, (const ZT_*)z, (const YT_*)dout, scale, shift, mean, invstd, partial, g, p.cq, p.rows, slope); }
+    TMF_DISPATCH_IO(L_RED, io, "tmf_bn_act_pool_bwd_reduce_t");
+#undef L_RED
 #undef K_RED
     return tmf_launch_result("tmf_bn_act_pool_bwd_reduce");
+}
+
+extern "C" int tmf_bn_act_pool_bwd_reduce(const float* z, const float* dout, const float* scale, const float* shift,
+                                          const float* mean, const float* invstd, float* partial,
+                                          int B, int D, int H, int W, int C, int pool, float slope, void* stream) {
+    return tmf_bn_act_pool_bwd_reduce_t(z, dout, scale, shift, mean, invstd, partial, B, D, H, W, C, pool, slope, 0, stream);
 }
 
 extern "C" int tmf_bn_bwd_finalize(const float* partial, int nblk, int C, double count,
@@ -434,9 +457,9 @@ extern "C" int tmf_bn_bwd_finalize(const float* partial, int nblk, int C, double
     return tmf_launch_result("tmf_bn_bwd_finalize");
 }
 
-extern "C" int tmf_bn_act_pool_bwd_apply(const float* z, const float* dout, const float* scale, const float* shift,
-                                         const float* mean, const float* invstd, const float* coef, float* dz,
-                                         int B, int D, int H, int W, int C, int pool, float slope, void* stream) {
+extern "C" int tmf_bn_act_pool_bwd_apply_t(const void* z, const void* dout, const float* scale, const float* shift,
+                                           const float* mean, const float* invstd, const float* coef, void* dz,
+                                           int B, int D, int H, int W, int C, int pool, float slope, int io, void* stream) {
     TMF_REQUIRE_PTR(z); TMF_REQUIRE_PTR(dout); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift);
     TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(invstd); TMF_REQUIRE_PTR(coef); TMF_REQUIRE_PTR(dz);
     int rc = check_geo("tmf_bn_act_pool_bwd_apply", B, D, H, W, C, pool);
@@ -444,10 +467,19 @@ extern "C" int tmf_bn_act_pool_bwd_apply(const float* z, const float* dout, cons
     TMF_REQUIRE_ALIGNED(z); TMF_REQUIRE_ALIGNED(dout); TMF_REQUIRE_ALIGNED(dz);
     const Geo g = make_geo(B, D, H, W, C, pool);
     const EwPlan p = plan_ew(g.nwin, C);
-#define K_APP(V, P, ...) hipLaunchKernelGGL((bn_bwd_apply_kernel<V, P>), dim3(p.nblk), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
-    TMF_DISPATCH_VP(K_APP, p.vec, pool, z, dout, scale, shift, mean, invstd, coef, dz, g, p.cq, p.rows, slope);
+#define K_APP(V, P, ...) hipLaunchKernelGGL((bn_bwd_apply_kernel<V, P, ZT_, YT_>), dim3(p.nblk), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
+#define L_APP(ZT, YT) { typedef ZT ZT_; typedef YT YT_; \
+        TMF_DISPATCH_VP(K_APP, p.vec, pool, (const ZT_*)z, (const YT_*)dout, scale, shift, mean, invstd, coef, (ZT_*)dz, g, p.cq, p.rows, slope); }
+    TMF_DISPATCH_IO(L_APP, io, "tmf_bn_act_pool_bwd_apply_t");
+#undef L_APP
 #undef K_APP
     return tmf_launch_result("tmf_bn_act_pool_bwd_apply");
+}
+
+extern "C" int tmf_bn_act_pool_bwd_apply(const float* z, const float* dout, const float* scale, const float* shift,
+                                         const float* mean, const float* invstd, const float* coef, float* dz,
+                                         int B, int D, int H, int W, int C, int pool, float slope, void* stream) {
+    return tmf_bn_act_pool_bwd_apply_t(z, dout, scale, shift, mean, invstd, coef, dz, B, D, H, W, C, pool, slope, 0, stream);
 }
 
 extern "C" int tmf_colsum_finalize(const float* partial, int nblk, int ncol, float* out, void* stream) {

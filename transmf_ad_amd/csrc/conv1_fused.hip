@@ -51,8 +51,8 @@ struct Args {
     const float* mean;     // (REDUCE, WGRAD)
     const float* invstd;
     const float* coef;     // [2][C] (WGRAD)
-    const float* dpool;    // [B][D/2][H/2][W/2][C] (REDUCE, WGRAD)
-    float* pooled;         // (FWD)
+    const void* dpool;     // [B][D/2][H/2][W/2][C] (REDUCE, WGRAD); float, or bf16 when P16
+    void* pooled;          // (FWD)
     float* partial;        // STATS/REDUCE: [nblk][2][C];  WGRAD: [nblk][27][C]
     int D, H, W, C;
     int tilesD, tilesH, tilesW, ntiles, tiles_per_block;
@@ -68,7 +68,7 @@ __device__ __forceinline__ tmf_bf16x8 pack8(const float (&v)[8]) {
 // BF16 = true: both products run on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32 accumulation) — the
 // 27-tap convolution is 2 MFMAs instead of 14 and the tap-gradient product 2 instead of 16, which turns the four
 // passes from matrix-bound into LDS / HBM-bound (the opt-in bf16 mode of BASELINE configs[2]).
-template <int MODE, bool BF16>
+template <int MODE, bool BF16, bool P16 = false>     // P16: pooled / dpool are bf16 tensors (bf16 activation storage)
 __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
     __shared__ float halo[NHALO];
     __shared__ float red[4 * 32 * 32];      // cross-wave reduction scratch (16 KB)
@@ -229,10 +229,16 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
                 }
                 const size_t pidx = ((((size_t)b * OD + od) * OH + oh) * OW + ow) * a.C + co;
                 if (MODE == MODE_FWD) {
-                    if (pooled) a.pooled[pidx] = best;
+                    if (pooled) {
+                        if (P16) reinterpret_cast<tmf_bf16_t*>(a.pooled)[pidx] = (tmf_bf16_t)(tmf_pack_bf16(best, 0.f) & 0xFFFFu);
+                        else reinterpret_cast<float*>(a.pooled)[pidx] = best;
+                    }
                     continue;
                 }
-                const float g = pooled ? a.dpool[pidx] : 0.f;
+                float g = 0.f;
+                if (pooled)
+                    g = P16 ? __builtin_bit_cast(float, (unsigned int)reinterpret_cast<const tmf_bf16_t*>(a.dpool)[pidx] << 16)
+                            : reinterpret_cast<const float*>(a.dpool)[pidx];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int r = 8 * q + k;
@@ -365,29 +371,32 @@ extern "C" int tmf_c1_stats_bf16(const float* x, const float* w, float* stat_par
     return c1_stats(true, x, w, stat_partial, B, D, H, W, C, stream);
 }
 
-static int c1_bn_pool_fwd(bool bf16, const float* x, const float* w, const float* scale, const float* shift,
-                          float* pooled, int B, int D, int H, int W, int C, float slope, void* stream) {
+static int c1_bn_pool_fwd(bool bf16, bool p16, const float* x, const float* w, const float* scale, const float* shift,
+                          void* pooled, int B, int D, int H, int W, int C, float slope, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(pooled);
     int rc = check("tmf_c1_bn_pool_fwd", B, D, H, W, C);
     if (rc) return rc;
     const Plan p = make_plan(B, D, H, W, C, 4 * SLAB_BLOCKS);     // a few bricks per workgroup (halo prefetch)
     Args a = base_args(x, w, D, H, W, C, p, slope);
     a.scale = scale; a.shift = shift; a.pooled = pooled;
-    if (bf16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
-    else      hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    TMF_REQUIRE(bf16 || !p16, TMF_E_ARG, "tmf_c1_bn_pool_fwd: bf16 tensors only with the bf16 kernels");
+    if (bf16 && p16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, true, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else if (bf16)   hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else             hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_c1_bn_pool_fwd");
 }
 extern "C" int tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* scale, const float* shift,
                                   float* pooled, int B, int D, int H, int W, int C, float slope, void* stream) {
-    return c1_bn_pool_fwd(false, x, w, scale, shift, pooled, B, D, H, W, C, slope, stream);
+    return c1_bn_pool_fwd(false, false, x, w, scale, shift, pooled, B, D, H, W, C, slope, stream);
 }
 extern "C" int tmf_c1_bn_pool_fwd_bf16(const float* x, const float* w, const float* scale, const float* shift,
-                                       float* pooled, int B, int D, int H, int W, int C, float slope, void* stream) {
-    return c1_bn_pool_fwd(true, x, w, scale, shift, pooled, B, D, H, W, C, slope, stream);
+                                       void* pooled, int B, int D, int H, int W, int C, float slope, int pooled_bf16,
+                                       void* stream) {
+    return c1_bn_pool_fwd(true, pooled_bf16 != 0, x, w, scale, shift, pooled, B, D, H, W, C, slope, stream);
 }
 
-static int c1_bwd_reduce(bool bf16, const float* x, const float* w, const float* scale, const float* shift,
-                         const float* mean, const float* invstd, const float* dpool, float* partial,
+static int c1_bwd_reduce(bool bf16, bool p16, const float* x, const float* w, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, const void* dpool, float* partial,
                          int B, int D, int H, int W, int C, float slope, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift);
     TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(invstd); TMF_REQUIRE_PTR(dpool); TMF_REQUIRE_PTR(partial);
@@ -396,19 +405,21 @@ static int c1_bwd_reduce(bool bf16, const float* x, const float* w, const float*
     const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
     Args a = base_args(x, w, D, H, W, C, p, slope);
     a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.dpool = dpool; a.partial = partial;
-    if (bf16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
-    else      hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    TMF_REQUIRE(bf16 || !p16, TMF_E_ARG, "tmf_c1_bwd_reduce: bf16 tensors only with the bf16 kernels");
+    if (bf16 && p16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, true, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else if (bf16)   hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else             hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_c1_bwd_reduce");
 }
 extern "C" int tmf_c1_bwd_reduce(const float* x, const float* w, const float* scale, const float* shift,
                                  const float* mean, const float* invstd, const float* dpool, float* partial,
                                  int B, int D, int H, int W, int C, float slope, void* stream) {
-    return c1_bwd_reduce(false, x, w, scale, shift, mean, invstd, dpool, partial, B, D, H, W, C, slope, stream);
+    return c1_bwd_reduce(false, false, x, w, scale, shift, mean, invstd, dpool, partial, B, D, H, W, C, slope, stream);
 }
 extern "C" int tmf_c1_bwd_reduce_bf16(const float* x, const float* w, const float* scale, const float* shift,
-                                      const float* mean, const float* invstd, const float* dpool, float* partial,
-                                      int B, int D, int H, int W, int C, float slope, void* stream) {
-    return c1_bwd_reduce(true, x, w, scale, shift, mean, invstd, dpool, partial, B, D, H, W, C, slope, stream);
+                                      const float* mean, const float* invstd, const void* dpool, float* partial,
+                                      int B, int D, int H, int W, int C, float slope, int pooled_bf16, void* stream) {
+    return c1_bwd_reduce(true, pooled_bf16 != 0, x, w, scale, shift, mean, invstd, dpool, partial, B, D, H, W, C, slope, stream);
 }
 
 extern "C" size_t tmf_c1_bwd_wgrad_workspace_bytes(int B, int D, int H, int W, int C) {
@@ -417,8 +428,8 @@ extern "C" size_t tmf_c1_bwd_wgrad_workspace_bytes(int B, int D, int H, int W, i
     return (size_t)(p.nblk + tmf_reduce_groups(p.nblk)) * 27 * C * 4;
 }
 
-static int c1_bwd_wgrad(bool bf16, const float* x, const float* w, const float* scale, const float* shift,
-                        const float* mean, const float* invstd, const float* coef, const float* dpool,
+static int c1_bwd_wgrad(bool bf16, bool p16, const float* x, const float* w, const float* scale, const float* shift,
+                        const float* mean, const float* invstd, const float* coef, const void* dpool,
                         float* dw, void* workspace, size_t workspace_bytes,
                         int B, int D, int H, int W, int C, float slope, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(mean);
@@ -433,8 +444,10 @@ static int c1_bwd_wgrad(bool bf16, const float* x, const float* w, const float* 
     a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.coef = coef; a.dpool = dpool;
     a.partial = (float*)workspace;
     hipStream_t s = (hipStream_t)stream;
-    if (bf16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
-    else      hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, false>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    TMF_REQUIRE(bf16 || !p16, TMF_E_ARG, "tmf_c1_bwd_wgrad: bf16 tensors only with the bf16 kernels");
+    if (bf16 && p16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, true, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    else if (bf16)   hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    else             hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, false>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
     if ((rc = tmf_launch_result("tmf_c1_bwd_wgrad"))) return rc;
     const long n = 27L * C;
     return tmf_reduce_slabs((const float*)workspace, p.nblk, n, (float*)workspace + (size_t)p.nblk * n, dw, s,
@@ -445,13 +458,13 @@ extern "C" int tmf_c1_bwd_wgrad(const float* x, const float* w, const float* sca
                                 const float* mean, const float* invstd, const float* coef, const float* dpool,
                                 float* dw, void* workspace, size_t workspace_bytes,
                                 int B, int D, int H, int W, int C, float slope, void* stream) {
-    return c1_bwd_wgrad(false, x, w, scale, shift, mean, invstd, coef, dpool, dw, workspace, workspace_bytes, B, D, H, W, C,
-                        slope, stream);
+    return c1_bwd_wgrad(false, false, x, w, scale, shift, mean, invstd, coef, dpool, dw, workspace, workspace_bytes, B, D, H, W,
+                        C, slope, stream);
 }
 extern "C" int tmf_c1_bwd_wgrad_bf16(const float* x, const float* w, const float* scale, const float* shift,
-                                     const float* mean, const float* invstd, const float* coef, const float* dpool,
+                                     const float* mean, const float* invstd, const float* coef, const void* dpool,
                                      float* dw, void* workspace, size_t workspace_bytes,
-                                     int B, int D, int H, int W, int C, float slope, void* stream) {
-    return c1_bwd_wgrad(true, x, w, scale, shift, mean, invstd, coef, dpool, dw, workspace, workspace_bytes, B, D, H, W, C,
-                        slope, stream);
+                                     int B, int D, int H, int W, int C, float slope, int pooled_bf16, void* stream) {
+    return c1_bwd_wgrad(true, pooled_bf16 != 0, x, w, scale, shift, mean, invstd, coef, dpool, dw, workspace, workspace_bytes,
+                        B, D, H, W, C, slope, stream);
 }

@@ -46,9 +46,12 @@ struct BfCfg {
     static constexpr size_t LDS_BYTES = (size_t)(NHALO * RP + 2 * WSTAGE) * 2 + 8 * NB * 2 * 4;
 };
 
-template <int NT>
+// IN16 / OUT16: the activation tensors themselves are bf16 (configs[2] "bf16 storage"): the halo is then a plain
+// 8-byte copy per 4 channels (no conversion through the VALU) and z is rounded once on the way out — the BatchNorm
+// statistics still come from the fp32 accumulators.
+template <int NT, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
-    const float* __restrict__ x, const u16* __restrict__ w, float* __restrict__ z,
+    const void* __restrict__ x_, const u16* __restrict__ w, void* __restrict__ z_,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
     int tilesD, int tilesH, int tilesW, int ntiles) {
     constexpr int NB = BfCfg<NT>::NB, WSTAGE = BfCfg<NT>::WSTAGE;
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    const float* xb = x + (size_t)b * D * H * W * Cin;
+    const float* xb = reinterpret_cast<const float*>(x_) + (IN16 ? 0 : (size_t)b * D * H * W * Cin);
+    const u16* xb16 = reinterpret_cast<const u16*>(x_) + (IN16 ? (size_t)b * D * H * W * Cin : 0);
 
     // brick-invariant halo addressing, computed once (the div/mod chain per piece was a third of the VALU work)
     constexpr int HV = (NHALO * 8 + NTHR - 1) / NTHR;
@@ -108,20 +112,32 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
         // ---- halo: fp32 from HBM, rounded to bf16 on the way into LDS.  The loads of a batch are all issued
         //      before its LDS writes; two batches keep the kernel under 128 registers (two workgroups per CU) ----
         auto stage_halo = [&](const int q0, const int q1) {
-            f32x4 hreg[HB];
+            f32x4 hreg[IN16 ? 1 : HB];
+            u32x2 hreg16[IN16 ? HB : 1];
 #pragma unroll
             for (int q = q0; q < q1; ++q) {
                 const int c = c0 + ((tid + q * NTHR) & 7) * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (hoff[q] >= 0 && c < Cin) v = *reinterpret_cast<const f32x4*>(xb + hoff[q] + c);
-                hreg[q - q0] = v;
+                const bool ok = hoff[q] >= 0 && c < Cin;
+                if (IN16) {
+                    u32x2 v = {0u, 0u};
+                    if (ok) v = *reinterpret_cast<const u32x2*>(xb16 + hoff[q] + c);
+                    hreg16[q - q0] = v;
+                } else {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) v = *reinterpret_cast<const f32x4*>(xb + hoff[q] + c);
+                    hreg[q - q0] = v;
+                }
             }
 #pragma unroll
             for (int q = q0; q < q1; ++q) {
                 const int e = tid + q * NTHR;
                 if (e < NHALO * 8) {
-                    const f32x4 v = hreg[q - q0];
-                    u32x2 pk = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    u32x2 pk;
+                    if (IN16) pk = hreg16[q - q0];
+                    else {
+                        const f32x4 v = hreg[q - q0];
+                        pk = u32x2{pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3])};
+                    }
                     *reinterpret_cast<u32x2*>(halo + (e >> 3) * RP + (e & 7) * 4) = pk;
                 }
             }
@@ -178,9 +194,38 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
-    float* zb = z + (size_t)b * D * H * W * Cout;
+    float* zb = reinterpret_cast<float*>(z_) + (OUT16 ? 0 : (size_t)b * D * H * W * Cout);
+    u16* zb16 = reinterpret_cast<u16*>(z_) + (OUT16 ? (size_t)b * D * H * W * Cout : 0);
     auto epilogue = [&](auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
+        if constexpr (OUT16) {
+            // bf16 tensor: rows are taken in pairs (r, r + 1 = planes d, d + 1) and neighbouring channel lanes swap one
+            // value, so that the even lane stores the channel PAIR of row r and the odd lane that of row r + 1 as one
+            // dword each (sub-dword stores run at a fraction of the rate).  Cout is even (checked on the host).
+            const int odd = lane & 1;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int pw = 2 * (r >> 2) + hsel, ph = wave;
+                const int gh = h0 + ph, gw = w0 + pw;
+                const int gd = d0 + (r & 3) + odd;                        // the row this lane stores
+                const bool pv = FULL || (gd < D && gh < H && gw < W);
+                const int off = ((gd * H + gh) * W + gw) * Cout;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int co = n0 + j * 32 + l31;
+                    const float a = acc[j][r], b = acc[j][r + 1];
+                    const float other = __shfl_xor(odd ? a : b, 1);       // even lane gets the odd lane's a, odd gets b
+                    const unsigned int pk = odd ? pack_bf16(other, b) : pack_bf16(a, other);
+                    if (FULL || (pv && co < Cout))
+                        *reinterpret_cast<unsigned int*>(zb16 + off + (co & ~1)) = pk;
+                    // statistics: each lane's own channel, both rows (validity of each row separately)
+                    const bool va = FULL || (d0 + (r & 3) < D && gh < H && gw < W && co < Cout);
+                    const bool vb = FULL || (d0 + (r & 3) + 1 < D && gh < H && gw < W && co < Cout);
+                    if (va) { s1[j] += a; s2[j] += a * a; }
+                    if (vb) { s1[j] += b; s2[j] += b * b; }
+                }
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int pd = r & 3, pw = 2 * (r >> 2) + hsel, ph = wave;      // fragment row i -> (d = i & 3, w = i >> 2)
@@ -197,6 +242,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
                     s2[j] += v * v;
                 }
             }
+        }
         }
     };
     if (d0 + TD <= D && h0 + TH <= H && w0 + TW <= W && n0 + NB <= Cout) epilogue(std::true_type{});
@@ -450,8 +496,9 @@ constexpr int WG_XIMG = 32 * WG_XP;
 constexpr int WG_DP = 33 * 8;                         // bf16 per output channel (32 brick rows + pad)
 constexpr size_t WG_LDS_BYTES = (size_t)(3 * WG_XIMG + 32 * WG_DP) * 2;
 
+template <bool IN16>
 __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_kernel(
-    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
+    const void* __restrict__ x_, const void* __restrict__ dz_, float* __restrict__ partial,
     int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles, int tiles_per_split) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* xT = reinterpret_cast<u16*>(smem_raw);               // [3 shifts][32 ci][61 rows][8]
@@ -491,7 +538,12 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_kernel(
     // bound on its staging: 19k cycles per brick against 3.5k of MFMA); conversion + LDS writes follow the loop.
     constexpr int XQ = (HD * HH * 32 + NTHR - 1) / NTHR;      // 4 (halo row, ci) tasks per thread
     constexpr int DQ = TD * TH * 32 / NTHR;                   // 2 (brick row, co) tasks per thread
-    float xv[XQ][HW], dv[DQ][TW];
+    // bf16 tensors: a lane loads a DWORD = one channel PAIR (sub-dword loads run at a fraction of the rate: the first
+    // version with 2-byte loads was 3x slower than the fp32-tensor path), so tasks are (row, channel pair)
+    constexpr int XQ2 = (HD * HH * 16 + NTHR - 1) / NTHR;     // 2
+    float xv[IN16 ? 1 : XQ][HW], dv[IN16 ? 1 : DQ][TW];
+    unsigned int xw[IN16 ? XQ2 : 1][HW], dw2[TW];
+    const int pr = tid & 15;
     auto fetch = [&](int tile) {
         int tt = tile;
         const int tw = tt % tilesW; tt /= tilesW;
@@ -499,53 +551,113 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_kernel(
         const int td = tt % tilesD;
         const int b = tt / tilesD;
         const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
-        const float* xb = x + (size_t)b * D * H * W * Cin + ci0 + l31;
-        const float* dzb = dz + (size_t)b * D * H * W * Cout + co0 + l31;
+        if constexpr (IN16) {
+            const u16* xb16 = reinterpret_cast<const u16*>(x_) + (size_t)b * D * H * W * Cin + ci0 + 2 * pr;
+            const u16* dzb16 = reinterpret_cast<const u16*>(dz_) + (size_t)b * D * H * W * Cout + co0 + 2 * pr;
+            const bool cp_ok = ci0 + 2 * pr < Cin, op_ok = co0 + 2 * pr < Cout;
 #pragma unroll
-        for (int i = 0; i < XQ; ++i) {
-            const int hrow = (tid + i * NTHR) >> 5;
-            const int hd = hrow / HH, hh = hrow % HH;
-            const int gd = d0 + hd - 1, gh = h0 + hh - 1;
-            const bool rv = ci_ok && hrow < HD * HH && gd >= 0 && gd < D && gh >= 0 && gh < H;
-            const float* src = xb + (size_t)(gd * H + gh) * W * Cin;
+            for (int i = 0; i < XQ2; ++i) {
+                const int hrow = (tid + i * NTHR) >> 4;
+                const int hd = hrow / HH, hh = hrow % HH;
+                const int gd = d0 + hd - 1, gh = h0 + hh - 1;
+                const bool rv = cp_ok && hrow < HD * HH && gd >= 0 && gd < D && gh >= 0 && gh < H;
+                const size_t src = (size_t)(gd * H + gh) * W * Cin;
 #pragma unroll
-            for (int q = 0; q < HW; ++q) {
-                const int gw = w0 + q - 1;
-                xv[i][q] = (rv && gw >= 0 && gw < W) ? src[(size_t)gw * Cin] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < DQ; ++i) {
-            const int row = (tid + i * NTHR) >> 5;
-            const int gd = d0 + row / TH, gh = h0 + row % TH;
-            const bool rv = co_ok && gd < D && gh < H;
-            const float* src = dzb + (size_t)(gd * H + gh) * W * Cout;
-#pragma unroll
-            for (int q = 0; q < TW; ++q) dv[i][q] = (rv && w0 + q < W) ? src[(size_t)(w0 + q) * Cout] : 0.f;
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int i = 0; i < XQ; ++i) {
-            const int hrow = (tid + i * NTHR) >> 5;
-            if (hrow < HD * HH) {
-                unsigned int pk[HW - 1];                       // pk[q] = bf16(v[q]) | bf16(v[q+1]) << 16
-#pragma unroll
-                for (int q = 0; q < HW - 1; ++q) pk[q] = pack_bf16(xv[i][q], xv[i][q + 1]);
-                u16* dst = xT + l31 * WG_XP + hrow * 8;
-#pragma unroll
-                for (int sft = 0; sft < 3; ++sft) {
-                    u32x4 o = {pk[sft], pk[sft + 2], pk[sft + 4], pk[sft + 6]};
-                    *reinterpret_cast<u32x4*>(dst + sft * WG_XIMG) = o;
+                for (int q = 0; q < HW; ++q) {
+                    const int gw = w0 + q - 1;
+                    xw[i][q] = (rv && gw >= 0 && gw < W) ? *reinterpret_cast<const unsigned int*>(xb16 + src + (size_t)gw * Cin) : 0u;
                 }
             }
-        }
+            {
+                const int row = tid >> 4;
+                const int gd = d0 + row / TH, gh = h0 + row % TH;
+                const bool rv = op_ok && gd < D && gh < H;
+                const size_t src = (size_t)(gd * H + gh) * W * Cout;
 #pragma unroll
-        for (int i = 0; i < DQ; ++i) {
-            const int row = (tid + i * NTHR) >> 5;
-            u32x4 o = {pack_bf16(dv[i][0], dv[i][1]), pack_bf16(dv[i][2], dv[i][3]), pack_bf16(dv[i][4], dv[i][5]),
-                       pack_bf16(dv[i][6], dv[i][7])};
-            *reinterpret_cast<u32x4*>(dzT + l31 * WG_DP + row * 8) = o;
+                for (int q = 0; q < TW; ++q)
+                    dw2[q] = (rv && w0 + q < W) ? *reinterpret_cast<const unsigned int*>(dzb16 + src + (size_t)(w0 + q) * Cout) : 0u;
+            }
+        } else {
+            const float* xb = reinterpret_cast<const float*>(x_) + (size_t)b * D * H * W * Cin + ci0 + l31;
+            const float* dzb = reinterpret_cast<const float*>(dz_) + (size_t)b * D * H * W * Cout + co0 + l31;
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) {
+                const int hrow = (tid + i * NTHR) >> 5;
+                const int hd = hrow / HH, hh = hrow % HH;
+                const int gd = d0 + hd - 1, gh = h0 + hh - 1;
+                const bool rv = ci_ok && hrow < HD * HH && gd >= 0 && gd < D && gh >= 0 && gh < H;
+                const float* src = xb + (size_t)(gd * H + gh) * W * Cin;
+#pragma unroll
+                for (int q = 0; q < HW; ++q) {
+                    const int gw = w0 + q - 1;
+                    xv[i][q] = (rv && gw >= 0 && gw < W) ? src[(size_t)gw * Cin] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < DQ; ++i) {
+                const int row = (tid + i * NTHR) >> 5;
+                const int gd = d0 + row / TH, gh = h0 + row % TH;
+                const bool rv = co_ok && gd < D && gh < H;
+                const float* src = dzb + (size_t)(gd * H + gh) * W * Cout;
+#pragma unroll
+                for (int q = 0; q < TW; ++q) dv[i][q] = (rv && w0 + q < W) ? src[(size_t)(w0 + q) * Cout] : 0.f;
+            }
+        }
+    };
+    // channel h (0 = low half, 1 = high half) of two pair-dwords, as one dword of two consecutive voxels
+    auto pair16 = [](unsigned int a, unsigned int b_, int h) {
+        return h ? ((a >> 16) | (b_ & 0xFFFF0000u)) : ((a & 0xFFFFu) | (b_ << 16));
+    };
+    auto commit = [&]() {
+        if constexpr (IN16) {
+#pragma unroll
+            for (int i = 0; i < XQ2; ++i) {
+                const int hrow = (tid + i * NTHR) >> 4;
+                if (hrow < HD * HH) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        unsigned int pk[HW - 1];
+#pragma unroll
+                        for (int q = 0; q < HW - 1; ++q) pk[q] = pair16(xw[i][q], xw[i][q + 1], h);
+                        u16* dst = xT + (2 * pr + h) * WG_XP + hrow * 8;
+#pragma unroll
+                        for (int sft = 0; sft < 3; ++sft) {
+                            u32x4 o = {pk[sft], pk[sft + 2], pk[sft + 4], pk[sft + 6]};
+                            *reinterpret_cast<u32x4*>(dst + sft * WG_XIMG) = o;
+                        }
+                    }
+                }
+            }
+            const int row = tid >> 4;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 o = {pair16(dw2[0], dw2[1], h), pair16(dw2[2], dw2[3], h), pair16(dw2[4], dw2[5], h),
+                           pair16(dw2[6], dw2[7], h)};
+                *reinterpret_cast<u32x4*>(dzT + (2 * pr + h) * WG_DP + row * 8) = o;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) {
+                const int hrow = (tid + i * NTHR) >> 5;
+                if (hrow < HD * HH) {
+                    unsigned int pk[HW - 1];                       // pk[q] = bf16(v[q]) | bf16(v[q+1]) << 16
+#pragma unroll
+                    for (int q = 0; q < HW - 1; ++q) pk[q] = pack_bf16(xv[i][q], xv[i][q + 1]);
+                    u16* dst = xT + l31 * WG_XP + hrow * 8;
+#pragma unroll
+                    for (int sft = 0; sft < 3; ++sft) {
+                        u32x4 o = {pk[sft], pk[sft + 2], pk[sft + 4], pk[sft + 6]};
+                        *reinterpret_cast<u32x4*>(dst + sft * WG_XIMG) = o;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < DQ; ++i) {
+                const int row = (tid + i * NTHR) >> 5;
+                u32x4 o = {pack_bf16(dv[i][0], dv[i][1]), pack_bf16(dv[i][2], dv[i][3]), pack_bf16(dv[i][4], dv[i][5]),
+                           pack_bf16(dv[i][6], dv[i][7])};
+                *reinterpret_cast<u32x4*>(dzT + l31 * WG_DP + row * 8) = o;
+            }
         }
     };
 
@@ -612,12 +724,15 @@ extern "C" int tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W) {
     return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
 }
 
-extern "C" int tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z, float* stat_partial,
-                                   int B, int D, int H, int W, int cin, int cout, void* stream) {
+// io: bit 0 = x is a bf16 tensor, bit 1 = z is a bf16 tensor
+extern "C" int tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z, float* stat_partial,
+                                     int B, int D, int H, int W, int cin, int cout, int io, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w_bf16); TMF_REQUIRE_PTR(z);
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
                 "tmf_conv3d_fwd_bf16: non-positive dimension");
     TMF_REQUIRE(cin % 8 == 0, TMF_E_SHAPE, "tmf_conv3d_fwd_bf16: cin=%d must be a multiple of 8", cin);
+    TMF_REQUIRE(io >= 0 && io <= 3, TMF_E_ARG, "tmf_conv3d_fwd_bf16: io mode %d", io);
+    TMF_REQUIRE(!(io & 2) || cout % 2 == 0, TMF_E_SHAPE, "tmf_conv3d_fwd_bf16: a bf16 output needs an even cout (%d)", cout);
     TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
                 "tmf_conv3d_fwd_bf16: one sample exceeds 2^31 elements");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w_bf16); TMF_REQUIRE_ALIGNED(z);
@@ -627,10 +742,24 @@ extern "C" int tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z,
     hipStream_t s = (hipStream_t)stream;
     // one 32-channel output tile per workgroup (104 registers: two workgroups per CU); wider layers use more
     // workgroup columns — the two-tile variant needs > 128 registers and measured slower (0.237 vs 2 x 0.088 ms)
-    if ((rc = tmf_allow_lds(conv3d_fwd_bf16_kernel<1>, BfCfg<1>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;
-    hipLaunchKernelGGL(conv3d_fwd_bf16_kernel<1>, dim3(ntiles, tmf_cdiv(cout, 32)), dim3(NTHR), BfCfg<1>::LDS_BYTES, s,
-                       x, (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);
+#define TMF_BF_LAUNCH(I16, O16)                                                                                      \
+    {                                                                                                                \
+        auto k = conv3d_fwd_bf16_kernel<1, I16, O16>;                                                                \
+        if ((rc = tmf_allow_lds(k, BfCfg<1>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;                          \
+        hipLaunchKernelGGL(k, dim3(ntiles, tmf_cdiv(cout, 32)), dim3(NTHR), BfCfg<1>::LDS_BYTES, s, x,               \
+                           (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);             \
+    }
+    if (io == 0) TMF_BF_LAUNCH(false, false)
+    else if (io == 1) TMF_BF_LAUNCH(true, false)
+    else if (io == 2) TMF_BF_LAUNCH(false, true)
+    else TMF_BF_LAUNCH(true, true)
+#undef TMF_BF_LAUNCH
     return tmf_launch_result("tmf_conv3d_fwd_bf16");
+}
+
+extern "C" int tmf_conv3d_fwd_bf16(const float* x, const void* w_bf16, float* z, float* stat_partial,
+                                   int B, int D, int H, int W, int cin, int cout, void* stream) {
+    return tmf_conv3d_fwd_bf16_t(x, w_bf16, z, stat_partial, B, D, H, W, cin, cout, 0, stream);
 }
 
 extern "C" int tmf_conv3d_fwd_split(const float* x, const void* w3_bf16, float* z, float* stat_partial,
@@ -658,11 +787,14 @@ extern "C" size_t tmf_conv3d_wgrad_bf16_workspace_bytes(int B, int D, int H, int
     return (size_t)(p.nsplit + tmf_reduce_groups(p.nsplit)) * 27 * cin * cout * 4;
 }
 
-extern "C" int tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
-                                     int B, int D, int H, int W, int cin, int cout, void* stream) {
+extern "C" int tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
+                                       int B, int D, int H, int W, int cin, int cout, int io, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(dz); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
                 "tmf_conv3d_wgrad_bf16: non-positive dimension");
+    TMF_REQUIRE(io == 0 || io == 1, TMF_E_ARG, "tmf_conv3d_wgrad_bf16: io mode %d (0 = float tensors, 1 = bf16 tensors)", io);
+    TMF_REQUIRE(io == 0 || (cin % 2 == 0 && cout % 2 == 0), TMF_E_SHAPE,
+                "tmf_conv3d_wgrad_bf16: bf16 tensors need even channel counts (cin=%d cout=%d)", cin, cout);
     TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
                 "tmf_conv3d_wgrad_bf16: one sample exceeds 2^31 elements");
     const size_t need = tmf_conv3d_wgrad_bf16_workspace_bytes(B, D, H, W, cin, cout);
@@ -671,11 +803,22 @@ extern "C" int tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw,
     const WgBfPlan p = plan_wgrad_bf16(B, D, H, W, cin, cout);
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if ((rc = tmf_allow_lds(conv3d_wgrad_bf16_kernel, WG_LDS_BYTES, "tmf_conv3d_wgrad_bf16"))) return rc;
     float* partial = (float*)workspace;
-    hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel, dim3(p.nsplit, p.gy, p.gz), dim3(NTHR), WG_LDS_BYTES, s, x, dz, partial,
-                       D, H, W, cin, cout, p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);
+    if (io == 0) {
+        if ((rc = tmf_allow_lds(conv3d_wgrad_bf16_kernel<false>, WG_LDS_BYTES, "tmf_conv3d_wgrad_bf16"))) return rc;
+        hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<false>, dim3(p.nsplit, p.gy, p.gz), dim3(NTHR), WG_LDS_BYTES, s, x, dz,
+                           partial, D, H, W, cin, cout, p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);
+    } else {
+        if ((rc = tmf_allow_lds(conv3d_wgrad_bf16_kernel<true>, WG_LDS_BYTES, "tmf_conv3d_wgrad_bf16"))) return rc;
+        hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<true>, dim3(p.nsplit, p.gy, p.gz), dim3(NTHR), WG_LDS_BYTES, s, x, dz,
+                           partial, D, H, W, cin, cout, p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);
+    }
     if ((rc = tmf_launch_result("tmf_conv3d_wgrad_bf16"))) return rc;
     const long n = 27L * cin * cout;
     return tmf_reduce_slabs(partial, p.nsplit, n, partial + (size_t)p.nsplit * n, dw, s, "tmf_conv3d_wgrad_bf16(reduce)");
+}
+
+extern "C" int tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
+                                     int B, int D, int H, int W, int cin, int cout, void* stream) {
+    return tmf_conv3d_wgrad_bf16_t(x, dz, dw, workspace, workspace_bytes, B, D, H, W, cin, cout, 0, stream);
 }

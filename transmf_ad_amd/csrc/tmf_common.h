@@ -17,6 +17,37 @@ __device__ __forceinline__ unsigned int tmf_pack_bf16(float a, float b) {
     const tmf_bf16x2 v = {(__bf16)a, (__bf16)b};
     return __builtin_bit_cast(unsigned int, v);
 }
+// Typed activation I/O: float tensors, or bf16 tensors (unsigned short storage) widened to / rounded from fp32 registers.
+typedef unsigned short tmf_bf16_t;
+typedef unsigned int tmf_u32x2 __attribute__((ext_vector_type(2)));
+typedef float tmf_f32x1 __attribute__((ext_vector_type(1)));
+template <typename T, int VEC> struct TmfIO;
+template <> struct TmfIO<float, 4> {
+    static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct TmfIO<float, 1> {
+    static __device__ __forceinline__ tmf_f32x1 ld(const float* p) { return *reinterpret_cast<const tmf_f32x1*>(p); }
+    static __device__ __forceinline__ void st(float* p, tmf_f32x1 v) { *p = v[0]; }
+};
+template <> struct TmfIO<tmf_bf16_t, 4> {
+    static __device__ __forceinline__ f32x4 ld(const tmf_bf16_t* p) {
+        const tmf_u32x2 r = *reinterpret_cast<const tmf_u32x2*>(p);
+        return f32x4{__builtin_bit_cast(float, r[0] << 16), __builtin_bit_cast(float, r[0] & 0xFFFF0000u),
+                     __builtin_bit_cast(float, r[1] << 16), __builtin_bit_cast(float, r[1] & 0xFFFF0000u)};
+    }
+    static __device__ __forceinline__ void st(tmf_bf16_t* p, f32x4 v) {
+        *reinterpret_cast<tmf_u32x2*>(p) = tmf_u32x2{tmf_pack_bf16(v[0], v[1]), tmf_pack_bf16(v[2], v[3])};
+    }
+};
+template <> struct TmfIO<tmf_bf16_t, 1> {
+    static __device__ __forceinline__ tmf_f32x1 ld(const tmf_bf16_t* p) {
+        return tmf_f32x1{__builtin_bit_cast(float, (unsigned int)(*p) << 16)};
+    }
+    static __device__ __forceinline__ void st(tmf_bf16_t* p, tmf_f32x1 v) {
+        *p = (tmf_bf16_t)(tmf_pack_bf16(v[0], 0.f) & 0xFFFFu);
+    }
+};
 #endif
 
 void tmf_set_error(const char* fmt, ...);

@@ -57,12 +57,20 @@ class sNet(nn.Module):
                    if getattr(self, n)[i + 1].track_running_stats]
             if nbt:
                 torch._foreach_add_(nbt, 1)
-        for seq_name, i, pool in self._PLAN:
+        store16 = ops.activation_storage_bf16()
+        for n_blk, (seq_name, i, pool) in enumerate(self._PLAN):
             seq = getattr(self, seq_name)
             conv, bn, act = seq[i], seq[i + 1], seq[i + 2]
+            # bf16 activation storage: a block hands a bf16 tensor to the next block iff BOTH run on the bf16 kernels
+            out16 = False
+            if store16 and n_blk + 1 < len(self._PLAN):
+                nxt = getattr(self, self._PLAN[n_blk + 1][0])[self._PLAN[n_blk + 1][1]]
+                mine_ok = conv.in_channels == 1 or ops.bf16_conv_capable(conv.in_channels, conv.kernel_size[0])
+                out16 = mine_ok and ops.bf16_conv_capable(nxt.in_channels, nxt.kernel_size[0])
             x = ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                      bn.running_var, self.training or not bn.track_running_stats,
-                                     momentum=bn.momentum, eps=bn.eps, slope=act.negative_slope, pool=pool)
+                                     momentum=bn.momentum, eps=bn.eps, slope=act.negative_slope, pool=pool,
+                                     out_bf16=out16)
         return x                                 # (B, d, h, w, dim)
 
     def forward(self, mri):

@@ -21,11 +21,11 @@ def _stream():
     return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
-def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+def _chk(t: torch.Tensor, name: str, allow_bf16: bool = False) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.TmfError(
             f"{name} is on {t.device}: transmf_ad_amd runs only on a HIP device (MI355X); there is no CPU fallback")
-    if t.dtype != _f32:
+    if t.dtype != _f32 and not (allow_bf16 and t.dtype == torch.bfloat16):
         raise _lib.TmfError(f"{name} must be float32, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()
 
@@ -79,6 +79,29 @@ def get_conv_precision() -> str:
     return _PRECISION
 
 
+_ACT16 = False
+_b16 = torch.bfloat16
+
+
+def set_activation_storage(dtype: str) -> None:
+    """"fp32" (default) or "bf16": with conv precision "bf16", keep the sNet activations BETWEEN the conv blocks (raw
+    conv outputs z, block outputs, and their gradients) as bf16 tensors — BASELINE configs[2] "bf16 storage".  The
+    network input, the BatchNorm statistics / parameters, the 1x1x1 layer and everything after the encoders stay fp32."""
+    global _ACT16
+    if dtype not in ("fp32", "bf16"):
+        raise ValueError(dtype)
+    _ACT16 = dtype == "bf16"
+
+
+def activation_storage_bf16() -> bool:
+    return _ACT16 and _PRECISION == "bf16"
+
+
+def bf16_conv_capable(cin: int, k: int) -> bool:
+    """the 3x3x3 bf16 matrix-core kernels need 8-channel input groups"""
+    return k == 3 and cin > 1 and cin % 8 == 0
+
+
 def pack_weight_bf16(weight: torch.Tensor) -> torch.Tensor:
     """(Cout, Cin, 3,3,3) -> bf16 [27][Cout][Cin] (B operand rows: output channel, K = input channel contiguous)."""
     return weight.permute(2, 3, 4, 0, 1).contiguous().to(torch.bfloat16)
@@ -111,16 +134,18 @@ def conv3d_split_raw(x, w3, cin, cout, want_stats):
     return z, part, nblk
 
 
-def conv3d_bf16_raw(x, w_bf16, cin, cout, want_stats):
-    """z = conv3x3x3(bf16(x), w_bf16) with fp32 accumulation; returns (z, stat_partial or None, nblk)."""
+def conv3d_bf16_raw(x, w_bf16, cin, cout, want_stats, out_bf16=False):
+    """z = conv3x3x3(bf16(x), w_bf16) with fp32 accumulation; x may be an fp32 or a bf16 tensor, z is fp32 or
+    (out_bf16) bf16; returns (z, stat_partial or None, nblk)."""
     B, D, H, W = x.shape[:4]
-    z = torch.empty((B, D, H, W, cout), device=x.device, dtype=_f32)
+    z = torch.empty((B, D, H, W, cout), device=x.device, dtype=_b16 if out_bf16 else _f32)
     part, nblk = None, 0
     if want_stats:
         nblk = _lib.query("tmf_conv3d_bf16_stat_blocks", B, D, H, W)
         part = torch.empty((nblk, 2, cout), device=x.device, dtype=_f32)
-    _lib.call("tmf_conv3d_fwd_bf16", x.data_ptr(), w_bf16.data_ptr(), z.data_ptr(), _ptr(part),
-              B, D, H, W, cin, cout, _stream())
+    io = (1 if x.dtype == _b16 else 0) | (2 if out_bf16 else 0)
+    _lib.call("tmf_conv3d_fwd_bf16_t", x.data_ptr(), w_bf16.data_ptr(), z.data_ptr(), _ptr(part),
+              B, D, H, W, cin, cout, io, _stream())
     return z, part, nblk
 
 
@@ -150,8 +175,10 @@ def conv3d_wgrad_bf16(x, dz, cin, cout):
     dw = torch.empty((27, cin, cout), device=x.device, dtype=_f32)
     nbytes = _lib.query("tmf_conv3d_wgrad_bf16_workspace_bytes", B, D, H, W, cin, cout)
     ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=_f32)
-    _lib.call("tmf_conv3d_wgrad_bf16", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
-              B, D, H, W, cin, cout, _stream())
+    if x.dtype != dz.dtype:                      # mixed storage (not produced by sNet): widen the bf16 side
+        x, dz = x.float(), dz.float()
+    _lib.call("tmf_conv3d_wgrad_bf16_t", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
+              B, D, H, W, cin, cout, 1 if x.dtype == _b16 else 0, _stream())
     return dw
 
 
@@ -183,21 +210,26 @@ class ConvBnActPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var,
-                training, momentum, eps, slope, pool):
-        x = _chk(x, "x")
+                training, momentum, eps, slope, pool, out_bf16=False):
+        x = _chk(x, "x", allow_bf16=True)
         cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
         B, D, H, W, C = x.shape
         if C != cin:
             raise _lib.TmfError(f"conv expects {cin} input channels, got {C}")
         weight = _chk(weight, "weight")
         bf16 = _PRECISION if (_PRECISION != "fp32" and k == 3 and cin % 8 == 0 and cin > 1) else False
+        z16 = bf16 == "bf16" and _ACT16          # raw conv output (and dz) stored as bf16
+        if x.dtype == _b16 and bf16 != "bf16":
+            x = x.float()                         # only the bf16 kernels read bf16 tensors
+        if out_bf16 and not z16:
+            raise _lib.TmfError("a bf16 block output needs conv precision 'bf16' with bf16 activation storage")
         wf = wd = None
         if not bf16:                      # both weight layouts in one launch; the dgrad one is kept for backward
             wf, wd = pack_weights_both(weight, ctx.needs_input_grad[0])
 
         def conv(stats):
             if bf16 == "bf16":
-                return conv3d_bf16_raw(x, pack_weight_bf16(weight), cin, cout, stats)
+                return conv3d_bf16_raw(x, pack_weight_bf16(weight), cin, cout, stats, out_bf16=z16)
             if bf16 == "fp32x":
                 return conv3d_split_raw(x, split3_bf16(weight.permute(2, 3, 4, 0, 1).contiguous()), cin, cout, stats)
             return conv3d_raw(x, wf, cin, cout, k, stats)
@@ -222,17 +254,20 @@ class ConvBnActPool(torch.autograd.Function):
             # xhat = (z + bias - running_mean) * invstd, written as (z - mean) * invstd
             invstd = torch.rsqrt(running_var + eps)
             mean = running_mean - bias if bias is not None else running_mean.clone()
+        odt = _b16 if out_bf16 else _f32
         if pc == _lib.POOL_NONE:
-            out = torch.empty((B, D, H, W, cout), device=dev, dtype=_f32)
+            out = torch.empty((B, D, H, W, cout), device=dev, dtype=odt)
         else:
-            out = torch.empty((B, D // 2, H // 2, W // 2, cout), device=dev, dtype=_f32)
+            out = torch.empty((B, D // 2, H // 2, W // 2, cout), device=dev, dtype=odt)
+        io = (1 if z16 else 0) | (2 if out_bf16 else 0)
         if out.numel() > 0:
-            _lib.call("tmf_bn_act_pool_fwd", z.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
-                      B, D, H, W, cout, pc, float(slope), s)
+            _lib.call("tmf_bn_act_pool_fwd_t", z.data_ptr(), scale.data_ptr(), shift.data_ptr(), out.data_ptr(),
+                      B, D, H, W, cout, pc, float(slope), io, s)
         ctx.save_for_backward(x, weight if wd is None else wd, z, scale, shift, mean, invstd)
         ctx.cfg = (training, float(slope), pc, cin, cout, k, bias is not None)
         ctx.bf16 = bf16
         ctx.packed_dgrad = wd is not None
+        ctx.io = io
         return out
 
     @staticmethod
@@ -242,11 +277,14 @@ class ConvBnActPool(torch.autograd.Function):
         B, D, H, W, _ = x.shape
         dev = x.device
         s = _stream()
-        dout = _chk(dout, "grad_output")
+        io = ctx.io
+        dout = _chk(dout, "grad_output", allow_bf16=True)
+        if (dout.dtype == _b16) != bool(io & 2):
+            dout = dout.to(_b16 if io & 2 else _f32)
         nblk = _lib.query("tmf_bn_act_pool_bwd_blocks", B, D, H, W, cout, pc)
         part = torch.empty((nblk, 2, cout), device=dev, dtype=_f32)
-        _lib.call("tmf_bn_act_pool_bwd_reduce", z.data_ptr(), dout.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                  mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), B, D, H, W, cout, pc, slope, s)
+        _lib.call("tmf_bn_act_pool_bwd_reduce_t", z.data_ptr(), dout.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr(), part.data_ptr(), B, D, H, W, cout, pc, slope, io, s)
         dgamma = torch.empty(cout, device=dev, dtype=_f32)
         dbeta = torch.empty(cout, device=dev, dtype=_f32)
         coef = torch.empty((2, cout), device=dev, dtype=_f32)
@@ -258,8 +296,8 @@ class ConvBnActPool(torch.autograd.Function):
             coef.zero_()                      # eval-mode BN is affine: dz = scale * dy
             dbias = scale * dbeta if has_bias else None
         dz = torch.empty_like(z)
-        _lib.call("tmf_bn_act_pool_bwd_apply", z.data_ptr(), dout.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                  mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dz.data_ptr(), B, D, H, W, cout, pc, slope, s)
+        _lib.call("tmf_bn_act_pool_bwd_apply_t", z.data_ptr(), dout.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                  mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dz.data_ptr(), B, D, H, W, cout, pc, slope, io, s)
         dweight = None
         if ctx.needs_input_grad[1]:
             if ctx.bf16 == "bf16":
@@ -269,13 +307,16 @@ class ConvBnActPool(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if ctx.bf16 == "bf16" and cout % 8 == 0:
-                dx, _, _ = conv3d_bf16_raw(dz, pack_weight_dgrad_bf16(weight), cout, cin, False)
+                dx, _, _ = conv3d_bf16_raw(dz, pack_weight_dgrad_bf16(weight), cout, cin, False, out_bf16=x.dtype == _b16)
             elif ctx.bf16 == "fp32x" and cout % 8 == 0:
                 w3 = split3_bf16(weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())
                 dx, _, _ = conv3d_split_raw(dz, w3, cout, cin, False)
             else:
-                dx, _, _ = conv3d_raw(dz, weight if ctx.packed_dgrad else pack_weight_dgrad(weight), cout, cin, k, False)
-        return (dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
+                dzf = dz if dz.dtype == _f32 else dz.float()
+                dx, _, _ = conv3d_raw(dzf, weight if ctx.packed_dgrad else pack_weight_dgrad(weight), cout, cin, k, False)
+            if dx.dtype != x.dtype:
+                dx = dx.to(x.dtype)
+        return (dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None)
 
 
 class Conv1BnPool(torch.autograd.Function):
@@ -283,7 +324,8 @@ class Conv1BnPool(torch.autograd.Function):
     forward, backward-reduce and weight-gradient passes each recompute it from the input volume."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
+                out_bf16=False):
         x = _chk(x, "x")
         B, D, H, W, _ = x.shape
         C = weight.shape[0]
@@ -308,26 +350,32 @@ class Conv1BnPool(torch.autograd.Function):
                       running_var.data_ptr(), float(eps), C, scale.data_ptr(), shift.data_ptr(), s)
             invstd = torch.rsqrt(running_var + eps)
             mean = running_mean - bias if bias is not None else running_mean.clone()
-        out = torch.empty((B, D // 2, H // 2, W // 2, C), device=dev, dtype=_f32)
+        if out_bf16 and not sfx:
+            raise _lib.TmfError("a bf16 block output needs conv precision 'bf16'")
+        out = torch.empty((B, D // 2, H // 2, W // 2, C), device=dev, dtype=_b16 if out_bf16 else _f32)
+        p16 = (int(out_bf16),) if sfx else ()
         if out.numel() > 0:
             _lib.call("tmf_c1_bn_pool_fwd" + sfx, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                      out.data_ptr(), B, D, H, W, C, float(slope), s)
+                      out.data_ptr(), B, D, H, W, C, float(slope), *p16, s)
         ctx.save_for_backward(x, wp, scale, shift, mean, invstd)
-        ctx.cfg = (training, float(slope), C, bias is not None, sfx)
+        ctx.cfg = (training, float(slope), C, bias is not None, sfx, p16)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, wp, scale, shift, mean, invstd = ctx.saved_tensors
-        training, slope, C, has_bias, sfx = ctx.cfg
+        training, slope, C, has_bias, sfx, p16 = ctx.cfg
         B, D, H, W, _ = x.shape
         dev = x.device
         s = _stream()
-        dout = _chk(dout, "grad_output")
+        dout = _chk(dout, "grad_output", allow_bf16=True)
+        want16 = bool(p16 and p16[0])
+        if (dout.dtype == _b16) != want16:
+            dout = dout.to(_b16 if want16 else _f32)
         nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
         part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
         _lib.call("tmf_c1_bwd_reduce" + sfx, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                  mean.data_ptr(), invstd.data_ptr(), dout.data_ptr(), part.data_ptr(), B, D, H, W, C, slope, s)
+                  mean.data_ptr(), invstd.data_ptr(), dout.data_ptr(), part.data_ptr(), B, D, H, W, C, slope, *p16, s)
         dgamma = torch.empty(C, device=dev, dtype=_f32)
         dbeta = torch.empty(C, device=dev, dtype=_f32)
         coef = torch.empty((2, C), device=dev, dtype=_f32)
@@ -345,11 +393,11 @@ class Conv1BnPool(torch.autograd.Function):
             dw = torch.empty((27, C), device=dev, dtype=_f32)
             _lib.call("tmf_c1_bwd_wgrad" + sfx, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
                       mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dout.data_ptr(), dw.data_ptr(),
-                      ws.data_ptr(), nbytes, B, D, H, W, C, slope, s)
+                      ws.data_ptr(), nbytes, B, D, H, W, C, slope, *p16, s)
             dweight = unpack_wgrad(dw, C, 1, 3)
         if ctx.needs_input_grad[0]:
             raise _lib.TmfError("the fused first block has no data gradient (the network input needs none)")
-        return (None, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None)
+        return (None, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
 
 
 def conv_bn_act_pool_eval_fused(x, weight, bias, gamma, beta, running_mean, running_var, eps, slope, pool):
@@ -378,16 +426,20 @@ FUSE_EVAL_BLOCKS = os.environ.get("TMF_FUSE_EVAL", "1") != "0"
 
 
 def conv_bn_act_pool(x, weight, bias, gamma, beta, running_mean, running_var, training,
-                     momentum=0.1, eps=1e-5, slope=0.01, pool=None):
+                     momentum=0.1, eps=1e-5, slope=0.01, pool=None, out_bf16=False):
     needs_graph = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or gamma.requires_grad)
     if (FUSE_EVAL_BLOCKS and not training and not needs_graph and _PRECISION == "fp32" and weight.shape[1] > 1
             and weight.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0):
         return conv_bn_act_pool_eval_fused(x, weight, bias, gamma, beta, running_mean, running_var, eps, slope, pool)
     if (weight.shape[1] == 1 and weight.shape[2] == 3 and pool == "max" and not x.requires_grad):
+        if out_bf16 and _PRECISION != "bf16":
+            raise _lib.TmfError("a bf16 block output needs conv precision 'bf16'")
         return Conv1BnPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
-                                 training, momentum, eps, slope)
-    return ConvBnActPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
-                               training, momentum, eps, slope, pool)
+                                 training, momentum, eps, slope, out_bf16 and _PRECISION == "bf16")
+    can16 = out_bf16 and activation_storage_bf16() and bf16_conv_capable(weight.shape[1], weight.shape[2])
+    y = ConvBnActPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
+                            training, momentum, eps, slope, pool, can16)
+    return y.to(_b16) if (out_bf16 and not can16) else y
 
 
 # --------------------------------------------------------------------------------------
