@@ -34,11 +34,16 @@ if a.spin:
     for _ in range(a.spin):
         ops.conv3d_raw(xs, ws, 32, 32, 3, True)
     torch.cuda.synchronize()
+x16, dz16, wb16 = x.bfloat16(), dz.bfloat16(), ops.pack_weight_bf16(w)
 for _ in range(a.reps):
     if a.what == "split":
         ops.conv3d_split_raw(x, ops.split3_bf16(w.permute(2, 3, 4, 0, 1).contiguous()), cin, cout, True)
     elif a.what == "bf16":
         ops.conv3d_bf16_raw(x, ops.pack_weight_bf16(w), cin, cout, True)
+    elif a.what == "bf16s":
+        ops.conv3d_bf16_raw(x16, wb16, cin, cout, True, out_bf16=True)
+    elif a.what == "wgrad16s":
+        ops.conv3d_wgrad_bf16(x16, dz16, cin, cout)
     elif a.what == "wgrad16":
         ops.conv3d_wgrad_bf16(x, dz, cin, cout)
     elif a.what == "fwd":
