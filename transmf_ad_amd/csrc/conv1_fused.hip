@@ -212,23 +212,27 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
                 continue;
             }
 
-            // ---- per pooling window q (= r >> 3): activation, first maximum ----
+            // ---- per pooling window q (= r >> 3): LeakyReLU (slope > 0) is increasing, so the window maximum of the
+            //      activation is the activation of the maximum of y = scale*z + shift: one fma per element and a max
+            //      tree instead of activation + mask + running arg-max per element (the passes were VALU-bound).  The
+            //      routed element is the FIRST k (torch scan order k = 4 d + 2 h + w) with y[k] == max. ----
+            float K0 = 0.f, K1 = 0.f;
+            if (MODE == MODE_WGRAD) {        // dz = sc*(dy - c0 - xhat*c1) = sc*dy + z*K1 + K0
+                K1 = -sc * c1 * is;
+                K0 = sc * (c1 * mu * is - c0);
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int od = bd >> 1, oh = bh >> 1, ow = (bwid >> 1) + q;
                 const bool pooled = FULL ? cv : (od < OD && oh < OH && ow < OW && cv);
-                float best = -INFINITY;
-                int arg = 0;
-                float lr[8];
+                float y[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {                   // k = 4*d0bit + 2*h0bit + w0bit: torch scan order
-                    const float y = z[8 * q + k] * sc + sh;
-                    const float act = y > 0.f ? y : y * a.slope;
-                    lr[k] = y > 0.f ? 1.f : a.slope;
-                    if (act > best) { best = act; arg = k; }
-                }
+                for (int k = 0; k < 8; ++k) y[k] = z[8 * q + k] * sc + sh;
+                const float ymax = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
+                const float lrm = ymax > 0.f ? 1.f : a.slope;
                 const size_t pidx = ((((size_t)b * OD + od) * OH + oh) * OW + ow) * a.C + co;
                 if (MODE == MODE_FWD) {
+                    const float best = ymax * lrm;
                     if (pooled) {
                         if (P16) reinterpret_cast<tmf_bf16_t*>(a.pooled)[pidx] = (tmf_bf16_t)(tmf_pack_bf16(best, 0.f) & 0xFFFFu);
                         else reinterpret_cast<float*>(a.pooled)[pidx] = best;
@@ -239,17 +243,25 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
                 if (pooled)
                     g = P16 ? __builtin_bit_cast(float, (unsigned int)reinterpret_cast<const tmf_bf16_t*>(a.dpool)[pidx] << 16)
                             : reinterpret_cast<const float*>(a.dpool)[pidx];
+                const float gl = g * lrm;                       // dLoss/dy at the routed element
+                if (MODE == MODE_REDUCE) {
+                    float zs = z[8 * q + 7];                    // z of the first maximum (a pooled window is all-valid)
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int r = 8 * q + k;
-                    const int gd = bd + ((r >> 2) & 1), gh = bh + ((r >> 1) & 1), gw = bwid + 2 * q + (r & 1);
-                    const bool vv = FULL || (gd < a.D && gh < a.H && gw < a.W);
-                    const float dy = (k == arg) ? g * lr[k] : 0.f;
-                    const float xh = (z[r] - mu) * is;
-                    if (MODE == MODE_REDUCE) {
-                        if (vv) { s1 += dy; s2 += dy * xh; }
-                    } else {
-                        z[r] = (vv && cv) ? sc * (dy - c0 - xh * c1) : 0.f;        // dz, in place
+                    for (int k = 6; k >= 0; --k) zs = (y[k] == ymax) ? z[8 * q + k] : zs;
+                    s1 += gl;
+                    s2 += gl * ((zs - mu) * is);
+                } else {
+                    int arg = 7;
+#pragma unroll
+                    for (int k = 6; k >= 0; --k) arg = (y[k] == ymax) ? k : arg;
+                    const float add = sc * gl;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int r = 8 * q + k;
+                        const int gd = bd + ((r >> 2) & 1), gh = bh + ((r >> 1) & 1), gw = bwid + 2 * q + (r & 1);
+                        const bool vv = FULL || (gd < a.D && gh < a.H && gw < a.W);
+                        const float dzv = z[r] * K1 + K0 + (k == arg ? add : 0.f);
+                        z[r] = (vv && cv) ? dzv : 0.f;          // dz, in place
                     }
                 }
             }
