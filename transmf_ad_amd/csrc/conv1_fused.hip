@@ -338,8 +338,14 @@ Plan make_plan(int B, int D, int H, int W, int C, int target_blocks) {
     p.nblk = tmf_cdiv(p.ntiles, p.tpb);
     return p;
 }
-// STATS / REDUCE / WGRAD write one slab per workgroup: keep them few (8 per CU); FWD has no slab.
-constexpr int SLAB_BLOCKS = 2048;
+// STATS / REDUCE / WGRAD write one slab per workgroup: keep them few (4 per CU: measured 0.772 ms for the four passes
+// against 0.796 at 8 per CU and 0.81 at 14-20; TMF_C1_BLOCKS overrides); FWD has no slab.
+static int slab_blocks() {
+    static int v = 0;
+    if (v == 0) { const char* e = getenv("TMF_C1_BLOCKS"); v = e ? atoi(e) : 1024; if (v < 64) v = 1024; }
+    return v;
+}
+#define SLAB_BLOCKS slab_blocks()
 
 int check(const char* fn, int B, int D, int H, int W, int C) {
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, TMF_E_SHAPE, "%s: non-positive dimension", fn);
@@ -388,7 +394,8 @@ static int c1_bn_pool_fwd(bool bf16, bool p16, const float* x, const float* w, c
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(pooled);
     int rc = check("tmf_c1_bn_pool_fwd", B, D, H, W, C);
     if (rc) return rc;
-    const Plan p = make_plan(B, D, H, W, C, 4 * SLAB_BLOCKS);     // a few bricks per workgroup (halo prefetch)
+    static const int fwd_mult = getenv("TMF_C1_FWD_MULT") ? atoi(getenv("TMF_C1_FWD_MULT")) : 4;
+    const Plan p = make_plan(B, D, H, W, C, fwd_mult * SLAB_BLOCKS);     // a few bricks per workgroup (halo prefetch)
     Args a = base_args(x, w, D, H, W, C, p, slope);
     a.scale = scale; a.shift = shift; a.pooled = pooled;
     TMF_REQUIRE(bf16 || !p16, TMF_E_ARG, "tmf_c1_bn_pool_fwd: bf16 tensors only with the bf16 kernels");
