@@ -60,13 +60,12 @@ struct FwdCfg {
 // y = LeakyReLU(scale * z + shift) to the accumulators and, for a pooled block, reduces the 2x2x2 windows before
 // anything is stored — d pairs sit in one lane's registers (r & 3), w pairs in lane / lane + 32, h pairs in the same
 // lane (4x4x4 bricks, MT = 2) or in the neighbouring wave (through LDS).  z is then the (pooled) output tensor.
-template <class C, bool VEC, bool FUSED = false>
-__global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
+template <class C, bool VEC, bool FUSED>
+__device__ __forceinline__ void conv3d_fwd_tile(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
     int tilesD, int tilesH, int tilesW, int ntiles, int dbg,
-    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr,
-    float slope = 0.f, int pool = 0) {
+    const float* __restrict__ aff_scale, const float* __restrict__ aff_shift, float slope, int pool, const int tile) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;
     float* Bs = smem + C::NHALO * C::CP;
@@ -79,7 +78,6 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
     const int hsel = lane >> 5;
     const int wm = wave / C::WN, wn = wave % C::WN;
 
-    const int tile = xcd_contiguous(blockIdx.x, ntiles);
     int t = tile;
     const int tw = t % tilesW; t /= tilesW;
     const int th = t % tilesH; t /= tilesH;
@@ -396,6 +394,29 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
     }
 }
 
+// The kernel proper.  gridDim.x == ntiles: one brick per workgroup.  gridDim.x < ntiles ("persistent", conv_persist
+// option): every workgroup walks bricks blockIdx.x, + gridDim.x, ...  Two workgroups share a CU and, launched together with
+// identical work, run in LOCKSTEP — both stage, both multiply, both store at the same time, so neither covers the
+// other's non-MFMA phases (the timing ablations add up almost linearly for exactly this reason).  With persistent
+// workgroups a ONE-TIME stagger of every second co-resident workgroup (blockIdx bit 8: workgroups i and i + 256 land on
+// the same CU) shifts its staging / store phases under the partner's MFMA phases for the whole launch.
+template <class C, bool VEC, bool FUSED = false>
+__global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
+    float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
+    int tilesD, int tilesH, int tilesW, int ntiles, int dbg,
+    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr,
+    float slope = 0.f, int pool = 0, int stagger = 0) {
+    if (stagger > 0 && (blockIdx.x & 256)) {
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 clocks ~ 3.4 us each
+    }
+    for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
+        if (vt != (int)blockIdx.x) __syncthreads();                         // LDS of the previous brick is free
+        conv3d_fwd_tile<C, VEC, FUSED>(x, w, z, stat_partial, D, H, W, Cin, Cout, tilesD, tilesH, tilesW, ntiles, dbg,
+                                       aff_scale, aff_shift, slope, pool, xcd_contiguous(vt, ntiles));
+    }
+}
+
 // Config table.  Names: <brick><NB>.
 //  L32 / L64 : 4x8x8 brick (256 voxels), 32 / 64 output channels per workgroup, 3 taps per weight stage
 //  S128      : 4x4x4 brick (64 voxels), 128 output channels, 1 tap per stage (deep, small layers)
@@ -417,6 +438,11 @@ template <int KS, int CINC> using CfgM64 = FwdCfg<KS, CINC, 1, 2, 4, 1, 4, 4, 8,
 // stages / stores while the other multiplies (measured +3..7 % over 8 on the 48^3 layers)
 int g_debug = 0;          // timing ablations only (tmf_set_option("debug", bits)); results are garbage when set
 int g_conv_waves = 0;
+int g_conv_persist = -1;       // -1: read TMF_CONV_PERSIST once; 0 = one brick per workgroup; n > 0 = persistent, stagger n x 3.4 us
+int conv_persist() {
+    if (g_conv_persist < 0) { const char* e = getenv("TMF_CONV_PERSIST"); g_conv_persist = e ? atoi(e) : 0; if (g_conv_persist < 0) g_conv_persist = 0; }
+    return g_conv_persist;
+}
 int conv_waves() {
     if (g_conv_waves == 0) {
         const char* e = getenv("TMF_CONV_WAVES");
@@ -462,26 +488,29 @@ template <class C>
 int launch_fwd_cfg(const FwdPlan& p, const float* x, const float* w, float* z, float* sp,
                    int D, int H, int W, int cin, int cout, hipStream_t s, const Affine* aff) {
     const bool vec = (cin % 4 == 0) && (cout % 4 == 0);
-    dim3 grid(p.ntiles, p.nby), block(C::NTHR);
+    const int persist = conv_persist();
+    const int gx = (persist > 0 && p.ntiles > 512) ? 512 : p.ntiles;       // 2 workgroups per CU walking the bricks
+    const int stg = gx < p.ntiles ? persist : 0;
+    dim3 grid(gx, p.nby), block(C::NTHR);
     int rc;
     if (aff != nullptr) {
         TMF_REQUIRE(vec, TMF_E_SHAPE, "tmf_conv3d_fwd_affine: cin=%d and cout=%d must be multiples of 4", cin, cout);
         auto k = conv3d_fwd_kernel<C, true, true>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd_affine"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, (float*)nullptr, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, 0, aff->scale, aff->shift, aff->slope, aff->pool);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, 0, aff->scale, aff->shift, aff->slope, aff->pool, stg);
         return tmf_launch_result("tmf_conv3d_fwd_affine");
     }
     if (vec) {
         auto k = conv3d_fwd_kernel<C, true, false>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0, stg);
     } else {
         auto k = conv3d_fwd_kernel<C, false, false>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0, stg);
     }
     return tmf_launch_result("tmf_conv3d_fwd");
 }
@@ -1003,6 +1032,11 @@ extern "C" int tmf_set_option(const char* name, int value) {
         return TMF_OK;
     }
     if (strcmp(name, "debug") == 0) { g_debug = value; return TMF_OK; }
+    if (strcmp(name, "conv_persist") == 0) {
+        TMF_REQUIRE(value >= 0 && value <= 64, TMF_E_ARG, "tmf_set_option: conv_persist must be 0..64, got %d", value);
+        g_conv_persist = value;
+        return TMF_OK;
+    }
     tmf_set_error("tmf_set_option: unknown option '%s'", name);
     return TMF_E_ARG;
 }
