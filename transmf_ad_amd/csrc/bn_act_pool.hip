@@ -23,6 +23,7 @@ typedef tmf_f32x1 f32x1;
 template <int VEC> struct Vec;
 template <> struct Vec<4> { typedef f32x4 T; };
 template <> struct Vec<1> { typedef f32x1 T; };
+template <> struct Vec<8> { typedef tmf_f32x8 T; };
 
 // activations are float or bf16 tensors (TmfIO widens / rounds); per-channel vectors are always float
 template <int VEC, typename T>
@@ -327,9 +328,9 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
 }
 
 struct EwPlan { int vec, cq, rows, nblk; };
-EwPlan plan_ew(long nwork, int C) {
+EwPlan plan_ew(long nwork, int C, bool wide = false) {
     EwPlan p;
-    p.vec = (C % 4 == 0) ? 4 : 1;
+    p.vec = (wide && C % 8 == 0) ? 8 : (C % 4 == 0) ? 4 : 1;      // wide: 8 bf16 channels = one 16-byte access per lane
     p.cq = C / p.vec;
     p.rows = 256 / p.cq;
     if (p.rows < 1) p.rows = 0;      // C/vec > 256 unsupported
@@ -352,7 +353,10 @@ int check_geo(const char* fn, int B, int D, int H, int W, int C, int pool) {
 
 #define TMF_DISPATCH_VP(KERNEL, vec, pool, ...)                                              \
     do {                                                                                     \
-        if (vec == 4 && pool == TMF_POOL_NONE) { KERNEL(4, TMF_POOL_NONE, __VA_ARGS__); }    \
+        if (vec == 8 && pool == TMF_POOL_NONE) { KERNEL(8, TMF_POOL_NONE, __VA_ARGS__); }    \
+        else if (vec == 8 && pool == TMF_POOL_MAX2) { KERNEL(8, TMF_POOL_MAX2, __VA_ARGS__); } \
+        else if (vec == 8) { KERNEL(8, TMF_POOL_AVG2, __VA_ARGS__); }                        \
+        else if (vec == 4 && pool == TMF_POOL_NONE) { KERNEL(4, TMF_POOL_NONE, __VA_ARGS__); }    \
         else if (vec == 4 && pool == TMF_POOL_MAX2) { KERNEL(4, TMF_POOL_MAX2, __VA_ARGS__); } \
         else if (vec == 4) { KERNEL(4, TMF_POOL_AVG2, __VA_ARGS__); }                        \
         else if (pool == TMF_POOL_NONE) { KERNEL(1, TMF_POOL_NONE, __VA_ARGS__); }           \
@@ -401,7 +405,7 @@ extern "C" int tmf_bn_act_pool_fwd_t(const void* z, const float* scale, const fl
     const Geo g = make_geo(B, D, H, W, C, pool);
     const long nout = pool ? (long)B * (D / 2) * (H / 2) * (W / 2) : (long)B * D * H * W;
     if (nout == 0) return TMF_OK;
-    const EwPlan p = plan_ew(nout, C);
+    const EwPlan p = plan_ew(nout, C, io == 3);
 #define K_FWD(V, P, ...) hipLaunchKernelGGL((bn_act_pool_fwd_kernel<V, P, ZT_, YT_>), dim3(p.nblk), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 #define L_FWD(ZT, YT) { typedef ZT ZT_; typedef YT YT_; \
         TMF_DISPATCH_VP(K_FWD, p.vec, pool, (const ZT_*)z, scale, shift, (YT_*)out, g, p.cq, p.rows, slope); }
@@ -431,7 +435,9 @@ extern "C" int tmf_bn_act_pool_bwd_reduce_t(const void* z, const void* dout, con
     if (rc) return rc;
     TMF_REQUIRE_ALIGNED(z); TMF_REQUIRE_ALIGNED(dout);
     const Geo g = make_geo(B, D, H, W, C, pool);
-    const EwPlan p = plan_ew(g.nwin, C);
+    // 16-byte lanes only without pooling: the pooled window evaluation at 8 channels needs 200 registers (measured slower)
+    EwPlan p = plan_ew(g.nwin, C, io == 3 && pool == TMF_POOL_NONE);
+    p.nblk = plan_ew(g.nwin, C).nblk;            // the slab count callers size `partial` with (tmf_bn_act_pool_bwd_blocks)
     const size_t lds = (size_t)p.rows * 2 * C * 4;
 #define K_RED(V, P, ...) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, P, ZT_, YT_>), dim3(p.nblk), dim3(256), lds, (hipStream_t)stream, __VA_ARGS__)
 #define L_RED(ZT, YT) { typedef ZT ZT_; typedef YT YT_; \
@@ -466,7 +472,7 @@ extern "C" int tmf_bn_act_pool_bwd_apply_t(const void* z, const void* dout, cons
     if (rc) return rc;
     TMF_REQUIRE_ALIGNED(z); TMF_REQUIRE_ALIGNED(dout); TMF_REQUIRE_ALIGNED(dz);
     const Geo g = make_geo(B, D, H, W, C, pool);
-    const EwPlan p = plan_ew(g.nwin, C);
+    const EwPlan p = plan_ew(g.nwin, C, io == 3 && pool == TMF_POOL_NONE);
 #define K_APP(V, P, ...) hipLaunchKernelGGL((bn_bwd_apply_kernel<V, P, ZT_, YT_>), dim3(p.nblk), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 #define L_APP(ZT, YT) { typedef ZT ZT_; typedef YT YT_; \
         TMF_DISPATCH_VP(K_APP, p.vec, pool, (const ZT_*)z, (const YT_*)dout, scale, shift, mean, invstd, coef, (ZT_*)dz, g, p.cq, p.rows, slope); }

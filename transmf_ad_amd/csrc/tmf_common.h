@@ -40,6 +40,34 @@ template <> struct TmfIO<tmf_bf16_t, 4> {
         *reinterpret_cast<tmf_u32x2*>(p) = tmf_u32x2{tmf_pack_bf16(v[0], v[1]), tmf_pack_bf16(v[2], v[3])};
     }
 };
+typedef float tmf_f32x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int tmf_u32x4 __attribute__((ext_vector_type(4)));
+template <> struct TmfIO<float, 8> {
+    static __device__ __forceinline__ tmf_f32x8 ld(const float* p) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+        return tmf_f32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    }
+    static __device__ __forceinline__ void st(float* p, tmf_f32x8 v) {
+        *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    }
+};
+template <> struct TmfIO<tmf_bf16_t, 8> {          // one 16-byte access per lane
+    static __device__ __forceinline__ tmf_f32x8 ld(const tmf_bf16_t* p) {
+        const tmf_u32x4 r = *reinterpret_cast<const tmf_u32x4*>(p);
+        tmf_f32x8 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __builtin_bit_cast(float, r[i] << 16);
+            v[2 * i + 1] = __builtin_bit_cast(float, r[i] & 0xFFFF0000u);
+        }
+        return v;
+    }
+    static __device__ __forceinline__ void st(tmf_bf16_t* p, tmf_f32x8 v) {
+        *reinterpret_cast<tmf_u32x4*>(p) = tmf_u32x4{tmf_pack_bf16(v[0], v[1]), tmf_pack_bf16(v[2], v[3]),
+                                                      tmf_pack_bf16(v[4], v[5]), tmf_pack_bf16(v[6], v[7])};
+    }
+};
 template <> struct TmfIO<tmf_bf16_t, 1> {
     static __device__ __forceinline__ tmf_f32x1 ld(const tmf_bf16_t* p) {
         return tmf_f32x1{__builtin_bit_cast(float, (unsigned int)(*p) << 16)};
