@@ -479,3 +479,31 @@ def test_reference_checkpoint_eval_parity():
     ref = np.load(os.path.join(here, "ref_ckpt_ad_tiny_eval.npz"))
     for got, k in ((lo, "logits"), (dm, "d_mri"), (dp, "d_pet")):
         assert np.abs(got.cpu().numpy() - ref[k]).max() <= TOL, k
+
+
+def test_input_gradients_match_oracle():
+    """Gradients with respect to the INPUT volumes (saliency maps; the reference supports them through autograd): the
+    first block then takes the stored-output path with a data gradient.  Eval mode, tiny configuration, vs the fp64
+    oracle."""
+    import transmf_ad_amd as T
+    from oracle import params as P
+    from oracle import tmf_oracle as O
+    kw = dict(dim=32, depth=2, heads=4, dim_head=8, mlp_dim=128)
+    spec = O.state_spec("model_ad", **kw)
+    arrs = P.init_arrays(spec, seed=3)
+    net = T.model_ad(dropout=0., **kw).to(DEV)
+    net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in arrs.items()}, strict=True)
+    mri, pet, _y = P.make_inputs(2, (32, 32, 32), seed=5)
+    m = torch.from_numpy(mri).to(DEV).requires_grad_(True)
+    p = torch.from_numpy(pet).to(DEV).requires_grad_(True)
+    net.eval()
+    lo, dm, dp = net(m, p)
+    (lo.sum() + dm.sum() + dp.sum()).backward()
+    S = O.to_state(arrs, spec, dtype=torch.float64, requires_grad=False)
+    m2 = torch.from_numpy(mri).double().requires_grad_(True)
+    p2 = torch.from_numpy(pet).double().requires_grad_(True)
+    lo2, dm2, dp2 = O.model_ad_forward(S, m2, p2, dim=32, depth=2, heads=4, train=False)
+    (lo2.sum() + dm2.sum() + dp2.sum()).backward()
+    assert (lo.double().cpu() - lo2).abs().max().item() < 1e-5
+    for got, ref in ((m.grad, m2.grad), (p.grad, p2.grad)):
+        assert ((got.double().cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-4
