@@ -191,7 +191,47 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     V s_dy, s_dyx;
 #pragma unroll
     for (int q = 0; q < VEC; ++q) { s_dy[q] = 0.f; s_dyx[q] = 0.f; }
-    if (live) {
+    if (live && POOL == TMF_POOL_MAX2) {
+        // Max pool: the gradient reaches ONE voxel per window and channel — the first maximum of y = scale*z + shift
+        // (LeakyReLU is increasing) — so the pass only needs that voxel's z: a streaming maximum, no per-voxel
+        // arrays (the array form needs 200 registers at 8 channels per lane).  Border windows that are not pooled
+        // (floor mode) carry no gradient and are skipped.
+        const V sc = ldv<VEC>(scale + c), sh = ldv<VEC>(shift + c), mu = ldv<VEC>(mean + c), is = ldv<VEC>(invstd + c);
+        const int OD = g.D / 2, OH = g.H / 2, OW = g.W / 2;
+        for (long win = (long)blockIdx.x * ROWS + prow; win < g.nwin; win += (long)gridDim.x * ROWS) {
+            long t = win;
+            const int ww0 = t % g.WW; t /= g.WW;
+            const int wh0 = t % g.WH; t /= g.WH;
+            const int wd0 = t % g.WD;
+            const int b = t / g.WD;
+            if (!(wd0 < OD && wh0 < OH && ww0 < OW)) continue;
+            const V go = ldv<VEC>(dout + ((((long)b * OD + wd0) * OH + wh0) * OW + ww0) * g.C + c);
+            V ymax, zs;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int dd = 2 * wd0 + (k >> 2), hh = 2 * wh0 + ((k >> 1) & 1), ww = 2 * ww0 + (k & 1);
+                const V v = ldv<VEC>(z + (((long)(b * g.D + dd) * g.H + hh) * g.W + ww) * g.C + c);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) {
+                    const float y = v[q] * sc[q] + sh[q];
+                    const bool up = k == 0 || y > ymax[q];          // strict '>' keeps the FIRST maximum (torch)
+                    ymax[q] = up ? y : ymax[q];
+                    zs[q] = up ? v[q] : zs[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) {
+                const float d = go[q] * (ymax[q] > 0.f ? 1.f : slope);
+                s_dy[q] += d;
+                s_dyx[q] += d * ((zs[q] - mu[q]) * is[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            red[(prow * 2 + 0) * g.C + c + q] = s_dy[q];
+            red[(prow * 2 + 1) * g.C + c + q] = s_dyx[q];
+        }
+    } else if (live) {
         const V sc = ldv<VEC>(scale + c), sh = ldv<VEC>(shift + c), mu = ldv<VEC>(mean + c), is = ldv<VEC>(invstd + c);
         Window<VEC, POOL, ZT, YT> wn;
         for (long win = (long)blockIdx.x * ROWS + prow; win < g.nwin; win += (long)gridDim.x * ROWS) {
@@ -232,6 +272,61 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const int c = cq * VEC;
     const V sc = ldv<VEC>(scale + c), sh = ldv<VEC>(shift + c), mu = ldv<VEC>(mean + c), is = ldv<VEC>(invstd + c);
     const V k0 = ldv<VEC>(coef + c), k1 = ldv<VEC>(coef + g.C + c);
+    if (POOL == TMF_POOL_MAX2 && VEC == 8) {      // (at 4 channels per lane the array form below measured faster: 88 vs 101 us)
+        // dz = scale*(dy - k0 - xhat*k1) = z*K1 + K0 (+ scale*dy at the routed voxel of a pooled window)
+        V K1, K0;
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+            K1[q] = -sc[q] * k1[q] * is[q];
+            K0[q] = sc[q] * (k1[q] * mu[q] * is[q] - k0[q]);
+        }
+        const int OD = g.D / 2, OH = g.H / 2, OW = g.W / 2;
+        for (long win = (long)blockIdx.x * ROWS + prow; win < g.nwin; win += (long)gridDim.x * ROWS) {
+            long t = win;
+            const int ww0 = t % g.WW; t /= g.WW;
+            const int wh0 = t % g.WH; t /= g.WH;
+            const int wd0 = t % g.WD;
+            const int b = t / g.WD;
+            const bool pooled = wd0 < OD && wh0 < OH && ww0 < OW;
+            V zv[8], ymax, add;
+            int arg[VEC];
+#pragma unroll
+            for (int q = 0; q < VEC; ++q) { add[q] = 0.f; arg[q] = -1; ymax[q] = 0.f; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int dd = 2 * wd0 + (k >> 2), hh = 2 * wh0 + ((k >> 1) & 1), ww = 2 * ww0 + (k & 1);
+                const bool valid = dd < g.D && hh < g.H && ww < g.W;
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) zv[k][q] = 0.f;
+                if (valid) zv[k] = ldv<VEC>(z + (((long)(b * g.D + dd) * g.H + hh) * g.W + ww) * g.C + c);
+                if (pooled) {
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) {
+                        const float y = zv[k][q] * sc[q] + sh[q];
+                        const bool up = k == 0 || y > ymax[q];
+                        ymax[q] = up ? y : ymax[q];
+                        arg[q] = up ? k : arg[q];
+                    }
+                }
+            }
+            if (pooled) {
+                const V go = ldv<VEC>(dout + ((((long)b * OD + wd0) * OH + wh0) * OW + ww0) * g.C + c);
+#pragma unroll
+                for (int q = 0; q < VEC; ++q) add[q] = sc[q] * go[q] * (ymax[q] > 0.f ? 1.f : slope);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int dd = 2 * wd0 + (k >> 2), hh = 2 * wh0 + ((k >> 1) & 1), ww = 2 * ww0 + (k & 1);
+                if (dd < g.D && hh < g.H && ww < g.W) {
+                    V r;
+#pragma unroll
+                    for (int q = 0; q < VEC; ++q) r[q] = zv[k][q] * K1[q] + K0[q] + (arg[q] == k ? add[q] : 0.f);
+                    stv<VEC>(dz + (((long)(b * g.D + dd) * g.H + hh) * g.W + ww) * g.C + c, r);
+                }
+            }
+        }
+        return;
+    }
     Window<VEC, POOL, ZT, YT> wn;
     for (long win = (long)blockIdx.x * ROWS + prow; win < g.nwin; win += (long)gridDim.x * ROWS) {
         wn.eval(z, dout, g, win, c, sc, sh, mu, is, slope);
@@ -435,8 +530,7 @@ extern "C" int tmf_bn_act_pool_bwd_reduce_t(const void* z, const void* dout, con
     if (rc) return rc;
     TMF_REQUIRE_ALIGNED(z); TMF_REQUIRE_ALIGNED(dout);
     const Geo g = make_geo(B, D, H, W, C, pool);
-    // 16-byte lanes only without pooling: the pooled window evaluation at 8 channels needs 200 registers (measured slower)
-    EwPlan p = plan_ew(g.nwin, C, io == 3 && pool == TMF_POOL_NONE);
+    EwPlan p = plan_ew(g.nwin, C, io == 3 && pool != TMF_POOL_AVG2);
     p.nblk = plan_ew(g.nwin, C).nblk;            // the slab count callers size `partial` with (tmf_bn_act_pool_bwd_blocks)
     const size_t lds = (size_t)p.rows * 2 * C * 4;
 #define K_RED(V, P, ...) hipLaunchKernelGGL((bn_bwd_reduce_kernel<V, P, ZT_, YT_>), dim3(p.nblk), dim3(256), lds, (hipStream_t)stream, __VA_ARGS__)
@@ -472,7 +566,7 @@ extern "C" int tmf_bn_act_pool_bwd_apply_t(const void* z, const void* dout, cons
     if (rc) return rc;
     TMF_REQUIRE_ALIGNED(z); TMF_REQUIRE_ALIGNED(dout); TMF_REQUIRE_ALIGNED(dz);
     const Geo g = make_geo(B, D, H, W, C, pool);
-    const EwPlan p = plan_ew(g.nwin, C, io == 3 && pool == TMF_POOL_NONE);
+    const EwPlan p = plan_ew(g.nwin, C, io == 3 && pool != TMF_POOL_AVG2);
 #define K_APP(V, P, ...) hipLaunchKernelGGL((bn_bwd_apply_kernel<V, P, ZT_, YT_>), dim3(p.nblk), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__)
 #define L_APP(ZT, YT) { typedef ZT ZT_; typedef YT YT_; \
         TMF_DISPATCH_VP(K_APP, p.vec, pool, (const ZT_*)z, (const YT_*)dout, scale, shift, mean, invstd, coef, (ZT_*)dz, g, p.cq, p.rows, slope); }
