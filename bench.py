@@ -261,6 +261,38 @@ def main():
                     "fp32_kernel_same_shape": {"launch_ms": round(k_ms, 4), "achieved": round(ach, 2),
                                                "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}}
         del x, w, z, part
+        # every 3x3x3 layer of one encoder, forward / data-gradient / weight-gradient launches (fp32 kernels, same
+        # loaded clock state, 10 launches each): TFLOP/s and fraction of the fp32-MFMA peak
+        if not args.roofline_only and args.precision == "fp32":
+            def _t(fn, n=10):
+                fn()
+                torch.cuda.synchronize()
+                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a0.record()
+                for _ in range(n):
+                    fn()
+                a1.record()
+                torch.cuda.synchronize()
+                return a0.elapsed_time(a1) / n
+            layers = {}
+            for name, ci, co, div in (("conv2.0", 32, 32, 2), ("conv2.3", 32, 64, 2), ("conv3.0", 64, 64, 4),
+                                      ("conv3.3", 64, 128, 4), ("conv4.0", 128, 256, 8)):
+                sl = S // div
+                xl = torch.randn((B, sl, sl, sl, ci), device=dev)
+                dzl = torch.randn((B, sl, sl, sl, co), device=dev)
+                wl = torch.randn((27, ci, co), device=dev) * 0.03
+                wdl = torch.randn((27, co, ci), device=dev) * 0.03
+                fl = 2.0 * 27 * ci * co * B * sl ** 3
+                row = {}
+                for key, fn in (("fwd", lambda: ops.conv3d_raw(xl, wl, ci, co, 3, True)),
+                                ("dgrad", lambda: ops.conv3d_raw(dzl, wdl, co, ci, 3, False)),
+                                ("wgrad", lambda: ops.conv3d_wgrad(xl, dzl, ci, co, 3))):
+                    ms = _t(fn)
+                    row[key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1),
+                                "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 3)}
+                layers[name] = row
+                del xl, dzl, wl, wdl
+            roof["layers"] = layers
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
