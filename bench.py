@@ -39,13 +39,18 @@ def _config_tag(B, S, precision):
 
 def conv_flops_per_pair(size, dim=128):
     """Algorithmic conv FLOPs fwd+bwd per MRI+PET pair: 6*sum(F_l) - 2*F_conv1 per
-    stream... summed over both streams; no dgrad for conv1."""
+    stream... summed over both streams; no dgrad for conv1.  size: edge length or (D, H, W); floor-mode pooling."""
     q, h, d, d2 = dim // 4, dim // 2, dim, dim * 2
     layers = [(1, q, 3, 1), (q, q, 3, 2), (q, h, 3, 2), (h, h, 3, 4), (h, d, 3, 4), (d, d2, 3, 8), (d2, d, 1, 8)]
+    dims = (size, size, size) if isinstance(size, int) else tuple(size)
     tot = 0.0
     for i, (ci, co, k, div) in enumerate(layers):
-        s = size // div
-        f = 2.0 * ci * co * k ** 3 * s ** 3
+        vox = 1
+        for e in dims:
+            for _ in range(div.bit_length() - 1):
+                e //= 2
+            vox *= e
+        f = 2.0 * ci * co * k ** 3 * vox
         tot += f * (2 if i == 0 else 3)
     return 2 * tot
 
@@ -66,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="pairs per GPU")
     ap.add_argument("--size", type=int, default=96)
+    ap.add_argument("--shape", type=int, nargs=3, default=None, metavar=("D", "H", "W"),
+                    help="non-cubic volumes, e.g. 91 109 91 (the ADNI volumes of the reference, datasets/ADNI.py:96)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="pairs in the bounded CPU sample")
     ap.add_argument("--cpu-threads", type=int, default=32)
@@ -121,8 +128,9 @@ def main():
     crit = nn.CrossEntropyLoss()
     B, S = args.batch, args.size
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    mri = torch.rand((B, 1, S, S, S), device=dev, generator=g)
-    pet = torch.rand((B, 1, S, S, S), device=dev, generator=g)
+    vol = tuple(args.shape) if args.shape else (S, S, S)
+    mri = torch.rand((B, 1) + vol, device=dev, generator=g)
+    pet = torch.rand((B, 1) + vol, device=dev, generator=g)
     label = (torch.arange(B, device=dev) % 2).long()
     ones = torch.ones(B, dtype=torch.int64, device=dev)
     zeros = torch.zeros(B, dtype=torch.int64, device=dev)
@@ -306,13 +314,14 @@ def main():
                          f"{sec:.2f} s/step, host cpu_count={os.cpu_count()}"}
 
     if rank == 0:
-        gf = conv_flops_per_pair(S) * (0.5 if args.model == "single" else 1.0)
+        gf = conv_flops_per_pair(vol) * (0.5 if args.model == "single" else 1.0)
+        vtxt = f"{S}^3" if not args.shape else "x".join(map(str, vol))
         model_desc = {"ad": "model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512)",
                       "cnn": "model_CNN_ad(dim=128) [BASELINE configs[4], dual-modality reading of --model CNN]",
                       "single": "model_single(128), MRI only [BASELINE configs[4], single-modality reading]"}[args.model]
         out = {
-            "metric": (f"volume-pairs/sec fwd+bwd(+Adam), {S}^3 MRI+PET batch={B} per GPU" if args.model != "single"
-                       else f"volumes/sec fwd+bwd(+Adam), {S}^3 MRI only batch={B} per GPU"),
+            "metric": (f"volume-pairs/sec fwd+bwd(+Adam), {vtxt} MRI+PET batch={B} per GPU" if args.model != "single"
+                       else f"volumes/sec fwd+bwd(+Adam), {vtxt} MRI only batch={B} per GPU"),
             "value": round(pairs_per_s, 3), "unit": "volume-pairs/s" if args.model != "single" else "volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
@@ -321,7 +330,8 @@ def main():
                       "fp32x": "f32 via exact 3-way bf16 split on the bf16 MFMA (conv fwd/dgrad; wgrad exact f32 MFMA)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": f"{model_desc} train step, "
-                                   f"batch {B} {'volumes' if args.model == 'single' else 'pairs'} of 1x{S}^3 per GPU, {args.precision}"
+                                   f"batch {B} {'volumes' if args.model == 'single' else 'pairs'} of 1x"
+                                   + (f"{S}^3" if not args.shape else "x".join(map(str, vol))) + f" per GPU, {args.precision}"
                                    + (_config_tag(B, S, args.precision) if args.model == "ad" else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}",
                        "step": "zero_grad+fwd+loss+bwd+allreduce+Adam", "dispatch": mode,
