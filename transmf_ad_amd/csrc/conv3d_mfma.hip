@@ -85,7 +85,10 @@ __device__ __forceinline__ void conv3d_fwd_tile(
     const int b = t / tilesD;
     const int d0 = td * C::TD, h0 = th * C::TH, w0 = tw * C::TW;
     const int n0 = blockIdx.y * C::NB;
-    const bool wave_active = (n0 + wn * C::NT * 32) < Cout;
+    // a wave is idle when its output channels lie beyond Cout, or when ALL brick rows h of its M-tiles lie beyond H
+    // (wave = brick row: an odd pooled size like 27 leaves 5 of the last brick's 8 rows outside the volume) — it still
+    // takes part in staging and barriers, but leaves the matrix pipe to the other waves
+    const bool wave_active = (n0 + wn * C::NT * 32) < Cout && h0 + (wm * C::MT) * (8 / C::TW) < H;
 
     // per-lane halo float index of the voxel this lane feeds to M-tile i (tap (0,0,0))
     int a_lane[C::MT];
