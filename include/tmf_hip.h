@@ -44,9 +44,8 @@ extern "C" {
 int         tmf_version(void);                 /* ABI version, currently 1 */
 const char* tmf_last_error_string(void);
 /* Process-wide tuning knobs (never change results).  "conv_waves" = 2 | 4 | 8 | 16: workgroup shape of the
- * convolution kernels (16, the default: two 8-wave workgroups per CU).  "conv_persist" = 0 (default) | n: persistent
- * forward workgroups (512 walking all bricks) with a one-time stagger of n x 3.4 us on every second co-resident one.
- * "debug": timing ablations only (results are garbage when set). */
+ * convolution kernels (16, the default: two 8-wave workgroups per CU).  "debug": timing ablations only (results are
+ * garbage when set). */
 int         tmf_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------

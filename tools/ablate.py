@@ -24,7 +24,7 @@ for (cin, cout, s_) in [(32, 64, 48), (32, 32, 48), (64, 32, 48), (64, 64, 24), 
     w = torch.randn((27, cin, cout), device=dev) * 0.03
     fl = 2.0 * 27 * cin * cout * 8 * s_ ** 3
     row = []
-    for dbg in (0, 0, 2, 4, 8, 16, 28, 0):            # 8 = no weight ring / stage barriers, 16 = no halo loads
+    for dbg in (0, 2, 4, 6):            # 8 = no weight ring / stage barriers, 16 = no halo loads
         _lib.call("tmf_set_option", b"debug", dbg)
         ms = timeit(lambda: ops.conv3d_raw(x, w, cin, cout, 3, True), 30)
         row.append(f"dbg{dbg}: {ms:.3f} ms ({fl / ms / 1e9:6.1f} TF)")

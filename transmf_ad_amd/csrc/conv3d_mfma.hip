@@ -54,18 +54,23 @@ struct FwdCfg {
     static_assert(CINC % 8 == 0, "cin chunk is a multiple of 8");
     static_assert(NTAPS % TPS == 0, "taps per stage must divide the tap count");
     static_assert(KS == 1 || TPS == 1 || TPS == 3, "stage = 1 tap or one kw row");
+    // two 8-wave workgroups per CU need <= 128 registers per wave: ask for 4 waves per SIMD where the LDS allows two
+    // (the kernel sits at 117-123 without the bound; an innocent-looking change once pushed it to 130-156 and silently
+    // halved the occupancy — the bound turns that into a visible spill instead)
+    static constexpr int MIN_WAVES = (NW == 8 && LDS_BYTES * 2 <= 160 * 1024) ? 4 : 1;
 };
 
 // FUSED = true is the eval-mode block in ONE pass (BatchNorm is affine there): the epilogue applies
 // y = LeakyReLU(scale * z + shift) to the accumulators and, for a pooled block, reduces the 2x2x2 windows before
 // anything is stored — d pairs sit in one lane's registers (r & 3), w pairs in lane / lane + 32, h pairs in the same
 // lane (4x4x4 bricks, MT = 2) or in the neighbouring wave (through LDS).  z is then the (pooled) output tensor.
-template <class C, bool VEC, bool FUSED>
-__device__ __forceinline__ void conv3d_fwd_tile(
+template <class C, bool VEC, bool FUSED = false>
+__global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
     int tilesD, int tilesH, int tilesW, int ntiles, int dbg,
-    const float* __restrict__ aff_scale, const float* __restrict__ aff_shift, float slope, int pool, const int tile) {
+    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr,
+    float slope = 0.f, int pool = 0) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* halo = smem;
     float* Bs = smem + C::NHALO * C::CP;
@@ -78,6 +83,7 @@ __device__ __forceinline__ void conv3d_fwd_tile(
     const int hsel = lane >> 5;
     const int wm = wave / C::WN, wn = wave % C::WN;
 
+    const int tile = xcd_contiguous(blockIdx.x, ntiles);
     int t = tile;
     const int tw = t % tilesW; t /= tilesW;
     const int th = t % tilesH; t /= tilesH;
@@ -114,42 +120,23 @@ __device__ __forceinline__ void conv3d_fwd_tile(
 
     const float* xb = x + (size_t)b * D * H * W * Cin;
 
-    // ---- brick-invariant addressing, computed once: the per-chunk / per-stage index arithmetic (div / mod chains,
-    //      64-bit multiplies) was ~40 % of the kernel's non-MFMA vector instructions ----
-    constexpr int C4 = C::CINC / 4;
-    constexpr int HV = (C::NHALO * C4 + C::NTHR - 1) / C::NTHR;
-    int hoff[HV];                       // element offset of the halo position in the sample (+ c4 * 4), -1 = zero fill
-#pragma unroll
-    for (int q = 0; q < HV; ++q) {
-        const int e = tid + q * C::NTHR;
-        const int hp = e / C4, c4 = e % C4;
-        const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
-        const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
-        const bool ok = e < C::NHALO * C4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
-        hoff[q] = ok ? ((gd * H + gh) * W + gw) * Cin + c4 * 4 : -1;
-    }
-    int boff[C::BV];                    // weight element offset inside a (stage, chunk) slab, -1 = outside
-    int bci[C::BV];                     // input channel inside the chunk (to test against Cin)
-#pragma unroll
-    for (int q = 0; q < C::BV; ++q) {
-        const int e = tid + q * C::NTHR;
-        const int row = e / (C::NB / 4), col = (e % (C::NB / 4)) * 4;
-        const int co = n0 + col;
-        bci[q] = row % C::CINC;
-        boff[q] = (e < C::BSTAGE / 4 && (VEC ? co < Cout : true)) ? ((row / C::CINC) * Cin + bci[q]) * Cout + co : -1;
-    }
-
     for (int c0 = 0; c0 < Cin; c0 += C::CINC) {
         if (c0 > 0) __syncthreads();   // everyone is done with the previous halo and weight ring
         // ---- stage the input halo for channels [c0, c0+CINC): issue every load first, then the LDS writes, so
         //      the workgroup pays one memory latency instead of one per loop trip ----
+        constexpr int C4 = C::CINC / 4;
+        constexpr int HV = (C::NHALO * C4 + C::NTHR - 1) / C::NTHR;
         f32x4 hreg[HV];
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
-            const int c = c0 + ((tid + q * C::NTHR) % C4) * 4;
+            const int e = tid + q * C::NTHR;
+            const int hp = e / C4, c4 = e % C4;
+            const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
+            const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
+            const int c = c0 + c4 * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (hoff[q] >= 0 && !(dbg & 16)) {         // dbg 16 (timing ablation): no halo loads
-                const float* src = xb + hoff[q] + c0;
+            if (e < C::NHALO * C4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
+                const float* src = xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c;
                 if (VEC) {
                     if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
                 } else {
@@ -164,19 +151,24 @@ __device__ __forceinline__ void conv3d_fwd_tile(
         // ---- weight stage loader: element e -> (row = tap_in_stage*CINC + ci, 4 couts) ----
         f32x4 breg[C::BV];
         auto load_b = [&](int st) {
-            const float* wst = w + (size_t)(st * C::TPS * Cin + c0) * Cout;       // wave-uniform
 #pragma unroll
             for (int q = 0; q < C::BV; ++q) {
+                const int e = tid + q * C::NTHR;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (boff[q] >= 0 && c0 + bci[q] < Cin) {
-                    const float* src = wst + boff[q];
-                    if (VEC) {
-                        v = *reinterpret_cast<const f32x4*>(src);
-                    } else {
-                        const int co = n0 + ((tid + q * C::NTHR) % (C::NB / 4)) * 4;
+                if (e < C::BSTAGE / 4) {
+                    const int row = e / (C::NB / 4), col = (e % (C::NB / 4)) * 4;
+                    const int tap = st * C::TPS + row / C::CINC;
+                    const int ci = c0 + row % C::CINC;
+                    const int co = n0 + col;
+                    if (ci < Cin) {
+                        const float* src = w + ((size_t)tap * Cin + ci) * Cout + co;
+                        if (VEC) {
+                            if (co < Cout) v = *reinterpret_cast<const f32x4*>(src);
+                        } else {
 #pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (co + u < Cout) v[u] = src[u];
+                            for (int u = 0; u < 4; ++u)
+                                if (co + u < Cout) v[u] = src[u];
+                        }
                     }
                 }
                 breg[q] = v;
@@ -199,11 +191,9 @@ __device__ __forceinline__ void conv3d_fwd_tile(
         }
         for (int st = 0; st < C::NSTAGES; ++st) {
             const int buf = st & 1;
-            if (!(dbg & 8) || st == 0) {               // dbg 8 (timing ablation): no weight ring, no per-stage barrier
-                store_b(buf);
-                __syncthreads();
-                if (st + 1 < C::NSTAGES && !(dbg & 8)) load_b(st + 1);   // in flight while this stage computes
-            }
+            store_b(buf);
+            __syncthreads();
+            if (st + 1 < C::NSTAGES) load_b(st + 1);   // in flight while this stage computes
             if (wave_active && !(dbg & 2)) {
                 // halo offset of this stage's first tap
                 int stage_off;
@@ -397,29 +387,6 @@ __device__ __forceinline__ void conv3d_fwd_tile(
     }
 }
 
-// The kernel proper.  gridDim.x == ntiles: one brick per workgroup.  gridDim.x < ntiles ("persistent", conv_persist
-// option): every workgroup walks bricks blockIdx.x, + gridDim.x, ...  Two workgroups share a CU and, launched together with
-// identical work, run in LOCKSTEP — both stage, both multiply, both store at the same time, so neither covers the
-// other's non-MFMA phases (the timing ablations add up almost linearly for exactly this reason).  With persistent
-// workgroups a ONE-TIME stagger of every second co-resident workgroup (blockIdx bit 8: workgroups i and i + 256 land on
-// the same CU) shifts its staging / store phases under the partner's MFMA phases for the whole launch.
-template <class C, bool VEC, bool FUSED = false>
-__global__ __launch_bounds__(C::NTHR) void conv3d_fwd_kernel(
-    const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
-    float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
-    int tilesD, int tilesH, int tilesW, int ntiles, int dbg,
-    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr,
-    float slope = 0.f, int pool = 0, int stagger = 0) {
-    if (stagger > 0 && (blockIdx.x & 256)) {
-        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);      // 127 x 64 clocks ~ 3.4 us each
-    }
-    for (int vt = blockIdx.x; vt < ntiles; vt += gridDim.x) {
-        if (vt != (int)blockIdx.x) __syncthreads();                         // LDS of the previous brick is free
-        conv3d_fwd_tile<C, VEC, FUSED>(x, w, z, stat_partial, D, H, W, Cin, Cout, tilesD, tilesH, tilesW, ntiles, dbg,
-                                       aff_scale, aff_shift, slope, pool, xcd_contiguous(vt, ntiles));
-    }
-}
-
 // Config table.  Names: <brick><NB>.
 //  L32 / L64 : 4x8x8 brick (256 voxels), 32 / 64 output channels per workgroup, 3 taps per weight stage
 //  S128      : 4x4x4 brick (64 voxels), 128 output channels, 1 tap per stage (deep, small layers)
@@ -441,11 +408,6 @@ template <int KS, int CINC> using CfgM64 = FwdCfg<KS, CINC, 1, 2, 4, 1, 4, 4, 8,
 // stages / stores while the other multiplies (measured +3..7 % over 8 on the 48^3 layers)
 int g_debug = 0;          // timing ablations only (tmf_set_option("debug", bits)); results are garbage when set
 int g_conv_waves = 0;
-int g_conv_persist = -1;       // -1: read TMF_CONV_PERSIST once; 0 = one brick per workgroup; n > 0 = persistent, stagger n x 3.4 us
-int conv_persist() {
-    if (g_conv_persist < 0) { const char* e = getenv("TMF_CONV_PERSIST"); g_conv_persist = e ? atoi(e) : 0; if (g_conv_persist < 0) g_conv_persist = 0; }
-    return g_conv_persist;
-}
 int conv_waves() {
     if (g_conv_waves == 0) {
         const char* e = getenv("TMF_CONV_WAVES");
@@ -491,29 +453,26 @@ template <class C>
 int launch_fwd_cfg(const FwdPlan& p, const float* x, const float* w, float* z, float* sp,
                    int D, int H, int W, int cin, int cout, hipStream_t s, const Affine* aff) {
     const bool vec = (cin % 4 == 0) && (cout % 4 == 0);
-    const int persist = conv_persist();
-    const int gx = (persist > 0 && p.ntiles > 512) ? 512 : p.ntiles;       // 2 workgroups per CU walking the bricks
-    const int stg = gx < p.ntiles ? persist : 0;
-    dim3 grid(gx, p.nby), block(C::NTHR);
+    dim3 grid(p.ntiles, p.nby), block(C::NTHR);
     int rc;
     if (aff != nullptr) {
         TMF_REQUIRE(vec, TMF_E_SHAPE, "tmf_conv3d_fwd_affine: cin=%d and cout=%d must be multiples of 4", cin, cout);
         auto k = conv3d_fwd_kernel<C, true, true>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd_affine"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, (float*)nullptr, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, 0, aff->scale, aff->shift, aff->slope, aff->pool, stg);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, 0, aff->scale, aff->shift, aff->slope, aff->pool);
         return tmf_launch_result("tmf_conv3d_fwd_affine");
     }
     if (vec) {
         auto k = conv3d_fwd_kernel<C, true, false>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0, stg);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0);
     } else {
         auto k = conv3d_fwd_kernel<C, false, false>;
         if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
         hipLaunchKernelGGL(k, grid, block, C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0, stg);
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_debug, (const float*)nullptr, (const float*)nullptr, 0.f, 0);
     }
     return tmf_launch_result("tmf_conv3d_fwd");
 }
@@ -1035,11 +994,6 @@ extern "C" int tmf_set_option(const char* name, int value) {
         return TMF_OK;
     }
     if (strcmp(name, "debug") == 0) { g_debug = value; return TMF_OK; }
-    if (strcmp(name, "conv_persist") == 0) {
-        TMF_REQUIRE(value >= 0 && value <= 64, TMF_E_ARG, "tmf_set_option: conv_persist must be 0..64, got %d", value);
-        g_conv_persist = value;
-        return TMF_OK;
-    }
     tmf_set_error("tmf_set_option: unknown option '%s'", name);
     return TMF_E_ARG;
 }
