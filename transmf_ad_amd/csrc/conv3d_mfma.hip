@@ -257,19 +257,12 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
             auto op = [&](float a_, float b_) { return is_max ? fmaxf(a_, b_) : a_ + b_; };
             const int OD = D / 2, OH = H / 2, OW = W / 2;
             float* yb = z + (size_t)b * OD * OH * OW * Cout;
-            // d pairs (in-lane) and w pairs (lane <-> lane + 32); q = r >> 2
-            float m[C::MT][C::NT][2][4];
-#pragma unroll
-            for (int i = 0; i < C::MT; ++i)
-#pragma unroll
-                for (int j = 0; j < C::NT; ++j)
-#pragma unroll
-                    for (int dp = 0; dp < 2; ++dp)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float t = op(acc[i][j][2 * dp + 4 * q], acc[i][j][2 * dp + 1 + 4 * q]);
-                            m[i][j][dp][q] = op(t, __shfl_xor(t, 32));
-                        }
+            // d pairs (in-lane) and w pairs (lane <-> lane + 32); q = r >> 2.  (A helper, not an array: an array of
+            // these partials indexed through hsel-dependent selects ended up in scratch memory.)
+            auto dw = [&](int i, int j, int dp, int q) {
+                const float t = op(acc[i][j][2 * dp + 4 * q], acc[i][j][2 * dp + 1 + 4 * q]);
+                return op(t, __shfl_xor(t, 32));
+            };
             auto put = [&](int j, int php, int pwp, float v) {        // this half-wave stores pooled plane dp = hsel
                 const int od = d0 / 2 + hsel, oh = h0 / 2 + php, ow = w0 / 2 + pwp;
                 const int co = n0 + (wn * C::NT + j) * 32 + l31;
@@ -283,7 +276,7 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                     for (int j = 0; j < C::NT; ++j)
 #pragma unroll
                         for (int q = 0; q < 2; ++q) {
-                            const float v0 = op(m[i][j][0][q], m[i][j][0][q + 2]), v1 = op(m[i][j][1][q], m[i][j][1][q + 2]);
+                            const float v0 = op(dw(i, j, 0, q), dw(i, j, 0, q + 2)), v1 = op(dw(i, j, 1, q), dw(i, j, 1, q + 2));
                             put(j, wm * C::MT + i, q, hsel ? v1 : v0);
                         }
             } else if constexpr (C::MT == 2) {                        // ph = 2 wm + i, pw = 2 q + hsel
@@ -291,7 +284,7 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                 for (int j = 0; j < C::NT; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float v0 = op(m[0][j][0][q], m[1][j][0][q]), v1 = op(m[0][j][1][q], m[1][j][1][q]);
+                        const float v0 = op(dw(0, j, 0, q), dw(1, j, 0, q)), v1 = op(dw(0, j, 1, q), dw(1, j, 1, q));
                         put(j, wm, q, hsel ? v1 : v0);
                     }
             } else {                                                  // ph = wm: the partner row is wave wm ^ 1
@@ -302,7 +295,8 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                 for (int j = 0; j < C::NT; ++j)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const float mine = hsel ? m[0][j][1][q] : m[0][j][0][q];
+                        const float m0 = dw(0, j, 0, q), m1 = dw(0, j, 1, q);
+                        const float mine = hsel ? m1 : m0;
                         if (wm & 1) ex[(slot + j * 4 + q) * 64 + lane] = mine;
                     }
                 __syncthreads();
@@ -311,7 +305,8 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                     for (int j = 0; j < C::NT; ++j)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const float mine = hsel ? m[0][j][1][q] : m[0][j][0][q];
+                            const float m0 = dw(0, j, 0, q), m1 = dw(0, j, 1, q);
+                            const float mine = hsel ? m1 : m0;
                             put(j, wm >> 1, q, op(mine, ex[(slot + j * 4 + q) * 64 + lane]));
                         }
                 }
