@@ -120,23 +120,39 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
 
     const float* xb = x + (size_t)b * D * H * W * Cin;
 
+    // ---- brick-invariant addressing, computed once ----
+    constexpr int C4 = C::CINC / 4;
+    constexpr int HV = (C::NHALO * C4 + C::NTHR - 1) / C::NTHR;
+    int hoff[HV];                       // element offset of the halo position in the sample (+ c4 * 4), -1 = zero fill
+#pragma unroll
+    for (int q = 0; q < HV; ++q) {
+        const int e = tid + q * C::NTHR;
+        const int hp = e / C4, c4 = e % C4;
+        const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
+        const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
+        const bool ok = e < C::NHALO * C4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+        hoff[q] = ok ? ((gd * H + gh) * W + gw) * Cin + c4 * 4 : -1;
+    }
+    int boff[C::BV];                    // weight element offset inside a (stage, chunk) slab, -1 = outside
+    int bci[C::BV];                     // input channel inside the chunk (to test against Cin)
+#pragma unroll
+    for (int q = 0; q < C::BV; ++q) {
+        const int e = tid + q * C::NTHR;
+        const int row = e / (C::NB / 4), col = (e % (C::NB / 4)) * 4;
+        const int co = n0 + col;
+        bci[q] = row % C::CINC;
+        boff[q] = (e < C::BSTAGE / 4 && (VEC ? co < Cout : true)) ? ((row / C::CINC) * Cin + bci[q]) * Cout + co : -1;
+    }
+
     for (int c0 = 0; c0 < Cin; c0 += C::CINC) {
         if (c0 > 0) __syncthreads();   // everyone is done with the previous halo and weight ring
-        // ---- stage the input halo for channels [c0, c0+CINC): issue every load first, then the LDS writes, so
-        //      the workgroup pays one memory latency instead of one per loop trip ----
-        constexpr int C4 = C::CINC / 4;
-        constexpr int HV = (C::NHALO * C4 + C::NTHR - 1) / C::NTHR;
         f32x4 hreg[HV];
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
-            const int e = tid + q * C::NTHR;
-            const int hp = e / C4, c4 = e % C4;
-            const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
-            const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
-            const int c = c0 + c4 * 4;
+            const int c = c0 + ((tid + q * C::NTHR) % C4) * 4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < C::NHALO * C4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
-                const float* src = xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c;
+            if (hoff[q] >= 0) {
+                const float* src = xb + hoff[q] + c0;
                 if (VEC) {
                     if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
                 } else {
@@ -148,27 +164,21 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
             hreg[q] = v;
         }
 
-        // ---- weight stage loader: element e -> (row = tap_in_stage*CINC + ci, 4 couts) ----
         f32x4 breg[C::BV];
         auto load_b = [&](int st) {
+            const float* wst = w + (size_t)(st * C::TPS * Cin + c0) * Cout;       // wave-uniform
 #pragma unroll
             for (int q = 0; q < C::BV; ++q) {
-                const int e = tid + q * C::NTHR;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (e < C::BSTAGE / 4) {
-                    const int row = e / (C::NB / 4), col = (e % (C::NB / 4)) * 4;
-                    const int tap = st * C::TPS + row / C::CINC;
-                    const int ci = c0 + row % C::CINC;
-                    const int co = n0 + col;
-                    if (ci < Cin) {
-                        const float* src = w + ((size_t)tap * Cin + ci) * Cout + co;
-                        if (VEC) {
-                            if (co < Cout) v = *reinterpret_cast<const f32x4*>(src);
-                        } else {
+                if (boff[q] >= 0 && c0 + bci[q] < Cin) {
+                    const float* src = wst + boff[q];
+                    if (VEC) {
+                        v = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+                        const int co = n0 + ((tid + q * C::NTHR) % (C::NB / 4)) * 4;
 #pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (co + u < Cout) v[u] = src[u];
-                        }
+                        for (int u = 0; u < 4; ++u)
+                            if (co + u < Cout) v[u] = src[u];
                     }
                 }
                 breg[q] = v;
