@@ -349,7 +349,7 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                     const int co = n0 + (wn * C::NT + j) * 32 + l31;
                     if (FULL || (pv && co < Cout)) {
                         const float v = acc[i][j][r];
-                        if (!(dbg & 4)) zb[off + co] = v;
+                        if (!(dbg & 4)) __builtin_nontemporal_store(v, &zb[off + co]);
                         s1[j] += v;
                         s2[j] += v * v;
                     }
