@@ -15,6 +15,7 @@
 //
 // Replaces F.batch_norm, F.leaky_relu, max_pool3d, avg_pool3d (+ their backward) at
 // /root/reference/models/networks.py:23-25, 29-30, 32-34, 38-39, 41-43, 47-48, 50-52.
+#include <type_traits>
 #include "tmf_common.h"
 
 namespace {
@@ -30,6 +31,17 @@ template <int VEC, typename T>
 __device__ __forceinline__ typename Vec<VEC>::T ldv(const T* p) { return TmfIO<T, VEC>::ld(p); }
 template <int VEC, typename T>
 __device__ __forceinline__ void stv(T* p, typename Vec<VEC>::T v) { TmfIO<T, VEC>::st(p, v); }
+// streaming accesses of the big activation tensors (only the fp32 x 4 form has a nontemporal variant)
+template <int VEC, typename T>
+__device__ __forceinline__ typename Vec<VEC>::T ldv_s(const T* p) {
+    if constexpr (VEC == 4 && std::is_same<T, float>::value) return TmfIO<float, 4>::ld_nt(p);
+    else return TmfIO<T, VEC>::ld(p);
+}
+template <int VEC, typename T>
+__device__ __forceinline__ void stv_s(T* p, typename Vec<VEC>::T v) {
+    if constexpr (VEC == 4 && std::is_same<T, float>::value) TmfIO<float, 4>::st_nt(p, v);
+    else TmfIO<T, VEC>::st(p, v);
+}
 
 struct Geo {
     int B, D, H, W, C;
@@ -338,7 +350,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
                 for (int q = 0; q < VEC; ++q)
                     r[q] = sc[q] *
                                     (wn.dy[k][q] - k0[q] - wn.xhat[k][q] * k1[q]);
-                stv<VEC>(dz + wn.off[k], r);
+                stv_s<VEC>(dz + wn.off[k], r);
             }
         }
     }

@@ -25,6 +25,9 @@ template <typename T, int VEC> struct TmfIO;
 template <> struct TmfIO<float, 4> {
     static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
     static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+    // streaming (read-once / write-once) forms: keep the lines out of L2 so that re-used data (halos, weights) stay
+    static __device__ __forceinline__ f32x4 ld_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+    static __device__ __forceinline__ void st_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 };
 template <> struct TmfIO<float, 1> {
     static __device__ __forceinline__ tmf_f32x1 ld(const float* p) { return *reinterpret_cast<const tmf_f32x1*>(p); }
