@@ -306,12 +306,21 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tmf_oracle as O         # test infrastructure, used ONLY as the timed CPU baseline
         # MKL-DNN conv3d scales poorly past a few dozen threads (256 SMT threads: 85 s/step vs ~8 s on 8): cap at 32
-        sec, threads = O.cpu_train_step_seconds(args.cpu_batch, S, steps=2, warmup=1,
+        sec, threads = O.cpu_train_step_seconds(args.cpu_batch, S, steps=3, warmup=1,
                                                 threads=min(args.cpu_threads, os.cpu_count()))
+        cpu_model = "unknown CPU"
+        try:
+            with open("/proc/cpuinfo") as f:
+                for line in f:
+                    if line.startswith("model name"):
+                        cpu_model = line.split(":", 1)[1].strip()
+                        break
+        except OSError:
+            pass
         cpu = {"value": round(args.cpu_batch / sec, 4), "unit": "volume-pairs/s", "cores": threads, "kind": "port",
                "sample": f"oracle model_ad train-mode fwd+bwd, batch {args.cpu_batch} of 1x{S}^3 pairs "
-                         f"(1/{max(1, B // args.cpu_batch)} of one batch-{B} step), 1 warm-up + 2 timed steps, "
-                         f"{sec:.2f} s/step, host cpu_count={os.cpu_count()}"}
+                         f"(1/{max(1, B // args.cpu_batch)} of one batch-{B} step), 1 warm-up + 3 timed steps, "
+                         f"{sec:.2f} s/step, {cpu_model}, host cpu_count={os.cpu_count()}, torch threads={threads}"}
 
     if rank == 0:
         gf = conv_flops_per_pair(vol) * (0.5 if args.model == "single" else 1.0)
