@@ -82,6 +82,8 @@ def main():
                     help="bf16 (with --precision bf16): sNet activations between the conv blocks stored as bf16 tensors")
     ap.add_argument("--model", choices=["ad", "cnn", "single"], default="ad",
                     help="ad: model_ad (headline); cnn: model_CNN_ad; single: model_single (MRI only) — BASELINE configs[4]")
+    ap.add_argument("--eval", action="store_true",
+                    help="time the reference's val_step instead (eval mode, no_grad forward + CE; kfold_train_adversarial.py:144-161)")
     ap.add_argument("--no-fused-adam", action="store_true")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the train-step timing: only the dominant-kernel loop (so that a rocprofv3 --stats run "
@@ -135,7 +137,17 @@ def main():
     ones = torch.ones(B, dtype=torch.int64, device=dev)
     zeros = torch.zeros(B, dtype=torch.int64, device=dev)
 
+    def val_step():
+        net.eval()
+        with torch.no_grad():
+            if args.model == "single":
+                return crit(net(mri), label)
+            lo, _dm, _dp = net(mri, pet)
+            return crit(lo, label)
+
     def step():
+        if args.eval:
+            return val_step()
         net.train()
         opt.zero_grad()
         if args.model == "single":          # kfold_train_single.py:91-113: plain CE on model_single(MRI)
@@ -324,13 +336,16 @@ def main():
 
     if rank == 0:
         gf = conv_flops_per_pair(vol) * (0.5 if args.model == "single" else 1.0)
+        if args.eval:       # forward only: sum of F_l per stream
+            gf = gf * (32.219 / 95.125) if vol == (96, 96, 96) else gf / 3.0
         vtxt = f"{S}^3" if not args.shape else "x".join(map(str, vol))
         model_desc = {"ad": "model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512)",
                       "cnn": "model_CNN_ad(dim=128) [BASELINE configs[4], dual-modality reading of --model CNN]",
                       "single": "model_single(128), MRI only [BASELINE configs[4], single-modality reading]"}[args.model]
         out = {
-            "metric": (f"volume-pairs/sec fwd+bwd(+Adam), {vtxt} MRI+PET batch={B} per GPU" if args.model != "single"
-                       else f"volumes/sec fwd+bwd(+Adam), {vtxt} MRI only batch={B} per GPU"),
+            "metric": ((f"volume-pairs/sec fwd+bwd(+Adam), {vtxt} MRI+PET batch={B} per GPU" if args.model != "single"
+                        else f"volumes/sec fwd+bwd(+Adam), {vtxt} MRI only batch={B} per GPU") if not args.eval else
+                       f"volume-pairs/sec eval forward (val_step), {vtxt} batch={B} per GPU"),
             "value": round(pairs_per_s, 3), "unit": "volume-pairs/s" if args.model != "single" else "volumes/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
@@ -338,12 +353,13 @@ def main():
                                if args.storage == "bf16" else "bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate+storage"),
                       "fp32x": "f32 via exact 3-way bf16 split on the bf16 MFMA (conv fwd/dgrad; wgrad exact f32 MFMA)"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": f"{model_desc} train step, "
+            "config": {"workload": f"{model_desc} {'val_step' if args.eval else 'train step'}, "
                                    f"batch {B} {'volumes' if args.model == 'single' else 'pairs'} of 1x"
                                    + (f"{S}^3" if not args.shape else "x".join(map(str, vol))) + f" per GPU, {args.precision}"
                                    + (_config_tag(B, S, args.precision) if args.model == "ad" else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "step": "zero_grad+fwd+loss+bwd+allreduce+Adam", "dispatch": mode,
+                       "step": "val_step: eval-mode no_grad forward + CE" if args.eval else "zero_grad+fwd+loss+bwd+allreduce+Adam",
+                       "dispatch": mode,
                        "setup_steps_untimed": setup_steps},
             "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
             "loss": round(final_loss, 6),
