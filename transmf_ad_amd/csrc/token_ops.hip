@@ -125,23 +125,42 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     }
 }
 
-// cls[b] = [mean_n mri | mean_n pet | max_n mri | max_n pet]; one thread per (b, modality, channel)
-__global__ void token_pool_fwd_kernel(const float* __restrict__ mri, const float* __restrict__ pet,
-                                      float* __restrict__ cls, int32_t* __restrict__ argmax, int B, int N, int dim) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * 2 * dim) return;
-    const int c = i % dim, mod = (i / dim) % 2, b = i / (2 * dim);
-    const float* src = (mod == 0 ? mri : pet) + (size_t)b * N * dim + c;
+// cls[b] = [mean_n mri | mean_n pet | max_n mri | max_n pet].  One workgroup per (b, modality, 64-channel group): 4
+// token lanes per channel walk the N tokens with stride 4 (coalesced 256-B rows), then combine in token order so that
+// the FIRST maximum wins, as AdaptiveMaxPool1d (the one-thread-per-channel form took 55 us on the critical path).
+__global__ __launch_bounds__(256) void token_pool_fwd_kernel(const float* __restrict__ mri, const float* __restrict__ pet,
+                                                             float* __restrict__ cls, int32_t* __restrict__ argmax,
+                                                             int B, int N, int dim) {
+    __shared__ float ssum[4][64], smax[4][64];
+    __shared__ int sarg[4][64];
+    const int cgroups = (dim + 63) / 64;
+    const int cg = blockIdx.x % cgroups, mod = (blockIdx.x / cgroups) % 2, b = blockIdx.x / (2 * cgroups);
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const int c = cg * 64 + cl;
     float s = 0.f, mx = -INFINITY;
     int am = 0;
-    for (int n = 0; n < N; ++n) {
-        const float v = src[(size_t)n * dim];
-        s += v;
-        if (v > mx) { mx = v; am = n; }      // first maximum, as AdaptiveMaxPool1d
+    if (c < dim) {
+        const float* src = (mod == 0 ? mri : pet) + (size_t)b * N * dim + c;
+        for (int n = tl; n < N; n += 4) {
+            const float v = src[(size_t)n * dim];
+            s += v;
+            if (v > mx) { mx = v; am = n; }
+        }
     }
-    cls[(size_t)b * 4 * dim + mod * dim + c] = s / N;
-    cls[(size_t)b * 4 * dim + (2 + mod) * dim + c] = mx;
-    argmax[i] = am;
+    ssum[tl][cl] = s; smax[tl][cl] = mx; sarg[tl][cl] = am;
+    __syncthreads();
+    if (tl == 0 && c < dim) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            s += ssum[k][cl];
+            const float v = smax[k][cl];
+            const int a = sarg[k][cl];
+            if (v > mx || (v == mx && a < am)) { mx = v; am = a; }      // ties: the earliest token
+        }
+        cls[(size_t)b * 4 * dim + mod * dim + c] = s / N;
+        cls[(size_t)b * 4 * dim + (2 + mod) * dim + c] = mx;
+        argmax[((size_t)b * 2 + mod) * dim + c] = am;
+    }
 }
 
 __global__ void token_pool_bwd_kernel(const float* __restrict__ dcls, const int32_t* __restrict__ argmax,
@@ -268,7 +287,7 @@ extern "C" int tmf_token_pool_fwd(const float* mri, const float* pet, float* cls
                                   int B, int N, int dim, void* stream) {
     TMF_REQUIRE_PTR(mri); TMF_REQUIRE_PTR(pet); TMF_REQUIRE_PTR(cls); TMF_REQUIRE_PTR(argmax);
     TMF_REQUIRE(B > 0 && N > 0 && dim > 0, TMF_E_SHAPE, "tmf_token_pool_fwd: B=%d N=%d dim=%d", B, N, dim);
-    hipLaunchKernelGGL(token_pool_fwd_kernel, dim3(tmf_cdiv((long)B * 2 * dim, 64)), dim3(64), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(token_pool_fwd_kernel, dim3(B * 2 * tmf_cdiv(dim, 64)), dim3(256), 0, (hipStream_t)stream,
                        mri, pet, cls, argmax, B, N, dim);
     return tmf_launch_result("tmf_token_pool_fwd");
 }
