@@ -89,7 +89,7 @@ def main():
                     help="skip the train-step timing: only the dominant-kernel loop (so that a rocprofv3 --stats run "
                          "of this command averages exactly the launches the roofline entry quotes)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the step from a hipGraph (measured slower than eager on ROCm 7.2: 19.7 vs 18.2 ms)")
+                    help="replay the step from a hipGraph (measured slower than eager on ROCm 7.2: 28.0 vs 16.8 ms)")
     args = ap.parse_args()
 
     from transmf_ad_amd import model_ad, ops, _lib

@@ -7,7 +7,8 @@ the forward and the long convolution backward.  Capturing zero_grad -> forward -
 optimizer.step once and replaying it removes the host from the loop: the kernels, their order, their stream
 fork/join (MRI and PET encoders on two streams) and their numerics are exactly those of the eager step.
 
-Measured on MI355X / ROCm 7.2 (B=8, 96^3): the replayed step takes 19.7 ms against 18.2 ms eager — hipGraph node
+Measured on MI355X / ROCm 7.2 (B=8, 96^3): the replayed step took 19.7 ms against 18.2 ms eager when this was written (28.0 vs
+16.8 ms with the current kernels) — hipGraph node
 dispatch costs more than it saves here because the eager step is GPU-bound for 85 % of its length — so bench.py
 keeps the eager step as the default and offers --graph.
 
