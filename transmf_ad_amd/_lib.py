@@ -92,11 +92,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("TMF_LIB", LIB_PATH)      # TMF_LIB: another build of the same library (kernel A/B runs)
+    if not os.path.exists(path):
         raise TmfError(
-            f"{LIB_PATH} is missing: build it with `python -m transmf_ad_amd.build` "
+            f"{path} is missing: build it with `python -m transmf_ad_amd.build` "
             "(hipcc --offload-arch=gfx950). transmf_ad_amd has no CPU or PyTorch fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res

@@ -25,6 +25,14 @@
 #include <type_traits>
 #include "tmf_common.h"
 
+// kernel A/B switches (builds for TMF_LIB=...): plane-long partial sums, buffer-resource staging
+#ifndef TMF_CONV_ACC
+#define TMF_CONV_ACC 1
+#endif
+#ifndef TMF_CONV_BUF
+#define TMF_CONV_BUF 1
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------
@@ -121,9 +129,16 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
     const float* xb = x + (size_t)b * D * H * W * Cin;
 
     // ---- brick-invariant addressing, computed once ----
+    // VEC path: x (one sample) and w are read through buffer resources: per-lane BYTE offsets are computed once per
+    // brick, the chunk / stage base travels in the scalar offset, and an out-of-volume (or out-of-tile) piece carries
+    // the offset 2^31 >= num_records, which the hardware answers with zeros: no compare / select / 64-bit address per
+    // piece inside the chunk and stage loops (every v_* instruction here is paid in matrix time).
     constexpr int C4 = C::CINC / 4;
     constexpr int HV = (C::NHALO * C4 + C::NTHR - 1) / C::NTHR;
-    int hoff[HV];                       // element offset of the halo position in the sample (+ c4 * 4), -1 = zero fill
+    constexpr int OOB = (int)0x80000000u;
+    constexpr bool BUF = VEC && TMF_CONV_BUF;
+    const int esz = BUF ? 4 : 1;        // offsets in bytes (buffer path) or elements (scalar path)
+    int hoff[HV];                       // offset of the halo position in the sample (+ c4 * 4 channels); < 0 = zero fill
 #pragma unroll
     for (int q = 0; q < HV; ++q) {
         const int e = tid + q * C::NTHR;
@@ -131,9 +146,9 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
         const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
         const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
         const bool ok = e < C::NHALO * C4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
-        hoff[q] = ok ? ((gd * H + gh) * W + gw) * Cin + c4 * 4 : -1;
+        hoff[q] = ok ? (((gd * H + gh) * W + gw) * Cin + c4 * 4) * esz : OOB;
     }
-    int boff[C::BV];                    // weight element offset inside a (stage, chunk) slab, -1 = outside
+    int boff[C::BV];                    // weight offset inside a (stage, chunk) slab; < 0 = outside
     int bci[C::BV];                     // input channel inside the chunk (to test against Cin)
 #pragma unroll
     for (int q = 0; q < C::BV; ++q) {
@@ -141,8 +156,12 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
         const int row = e / (C::NB / 4), col = (e % (C::NB / 4)) * 4;
         const int co = n0 + col;
         bci[q] = row % C::CINC;
-        boff[q] = (e < C::BSTAGE / 4 && (VEC ? co < Cout : true)) ? ((row / C::CINC) * Cin + bci[q]) * Cout + co : -1;
+        boff[q] = (e < C::BSTAGE / 4 && (VEC ? co < Cout : true)) ? (((row / C::CINC) * Cin + bci[q]) * Cout + co) * esz : OOB;
     }
+    const bool ragged = Cin % C::CINC != 0;               // the last chunk is partly beyond Cin
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, D * H * W * Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, C::NTAPS * Cin * Cout * 4, 0x00020000);
 
     for (int c0 = 0; c0 < Cin; c0 += C::CINC) {
         if (c0 > 0) __syncthreads();   // everyone is done with the previous halo and weight ring
@@ -150,38 +169,52 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
             const int c = c0 + ((tid + q * C::NTHR) % C4) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (hoff[q] >= 0) {
-                const float* src = xb + hoff[q] + c0;
-                if (VEC) {
-                    if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
-                } else {
+            if constexpr (BUF) {
+                const int off = (ragged && c >= Cin) ? OOB : hoff[q];
+                hreg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, c0 * 4, 0));
+            } else {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (hoff[q] >= 0) {
+                    const float* src = xb + hoff[q] + c0;
+                    if (VEC) {
+                        if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
+                    } else {
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (c + u < Cin) v[u] = src[u];
+                        for (int u = 0; u < 4; ++u)
+                            if (c + u < Cin) v[u] = src[u];
+                    }
                 }
+                hreg[q] = v;
             }
-            hreg[q] = v;
         }
 
         f32x4 breg[C::BV];
         auto load_b = [&](int st) {
-            const float* wst = w + (size_t)(st * C::TPS * Cin + c0) * Cout;       // wave-uniform
+            if constexpr (BUF) {
+                const int sbase = ((st * C::TPS * Cin + c0) * Cout) * 4;              // wave-uniform
 #pragma unroll
-            for (int q = 0; q < C::BV; ++q) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (boff[q] >= 0 && c0 + bci[q] < Cin) {
-                    const float* src = wst + boff[q];
-                    if (VEC) {
-                        v = *reinterpret_cast<const f32x4*>(src);
-                    } else {
-                        const int co = n0 + ((tid + q * C::NTHR) % (C::NB / 4)) * 4;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (co + u < Cout) v[u] = src[u];
-                    }
+                for (int q = 0; q < C::BV; ++q) {
+                    const int off = (ragged && c0 + bci[q] >= Cin) ? OOB : boff[q];
+                    breg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, sbase, 0));
                 }
-                breg[q] = v;
+            } else {
+                const float* wst = w + (size_t)(st * C::TPS * Cin + c0) * Cout;       // wave-uniform
+#pragma unroll
+                for (int q = 0; q < C::BV; ++q) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (boff[q] >= 0 && c0 + bci[q] < Cin) {
+                        const float* src = wst + boff[q];
+                        if (VEC) {
+                            v = *reinterpret_cast<const f32x4*>(src);
+                        } else {
+                            const int co = n0 + ((tid + q * C::NTHR) % (C::NB / 4)) * 4;
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (co + u < Cout) v[u] = src[u];
+                        }
+                    }
+                    breg[q] = v;
+                }
             }
         };
         auto store_b = [&](int buf) {
@@ -199,21 +232,65 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
             const int e = tid + q * C::NTHR;
             if (e < C::NHALO * C4) *reinterpret_cast<f32x4*>(&halo[(e / C4) * C::CP + (e % C4) * 4]) = hreg[q];
         }
-        for (int st = 0; st < C::NSTAGES; ++st) {
-            const int buf = st & 1;
-            store_b(buf);
-            __syncthreads();
-            if (st + 1 < C::NSTAGES) load_b(st + 1);   // in flight while this stage computes
-            if (wave_active && !(dbg & 2)) {
-                // halo offset of this stage's first tap
-                int stage_off;
-                if (C::KS == 1) stage_off = 0;
-                else if (C::TPS == 3) stage_off = ((st / 3) * C::HH + (st % 3)) * C::HW * C::CP;
-                else stage_off = (((st / 9) * C::HH + (st / 3) % 3) * C::HW + st % 3) * C::CP;
-                const float* bs = Bs + buf * C::BSTAGE + b_lane;
-                // Each stage (<= 96 products per output) accumulates from zero and is then added to the running
-                // sum: the fp32 MFMA is a strict k-ordered fma chain, and one 864..3456-term chain would carry
-                // ~sqrt(K) ulp of drift; short chains + 9 adds per channel chunk keep it ~3-5x smaller.
+        // Partial sums: a stage (NT = 1) or a whole kd plane (NT = 2: 9 taps x CINC <= 288 products per output)
+        // accumulates from zero and is then added to the running sum.  The fp32 MFMA is a strict k-ordered fma chain,
+        // and one 864..3456-term chain would carry ~sqrt(K) ulp of drift; short chains + 3..9 adds per channel chunk keep
+        // it 2-5x smaller.  The adds are vector-ALU work = matrix time: plane-long chains cut them to a
+        // third.  The one-N-tile kernels on 4x8x8 bricks keep per-stage partials and a loop the compiler unrolls
+        // completely (grouped, they lose 3-7 %; everything else gains 2-7 %).
+        constexpr int ACC = (C::KS == 1 || (C::NT == 1 && C::TPS == 3) || !TMF_CONV_ACC) ? 1 : 9 / C::TPS;      // stages per partial sum
+        static_assert(C::NSTAGES % ACC == 0, "partial sums cover whole kd planes");
+        auto mma = [&](int st, int buf, f32x16 (&part)[C::MT][C::NT]) {       // this wave's MFMAs of stage st
+            int stage_off;                                                     // halo offset of the stage's first tap
+            if (C::KS == 1) stage_off = 0;
+            else if (C::TPS == 3) stage_off = ((st / 3) * C::HH + (st % 3)) * C::HW * C::CP;
+            else stage_off = (((st / 9) * C::HH + (st / 3) % 3) * C::HW + st % 3) * C::CP;
+            const float* bs = Bs + buf * C::BSTAGE + b_lane;
+#pragma unroll
+            for (int tp = 0; tp < C::TPS; ++tp) {
+#pragma unroll
+                for (int g = 0; g < C::CINC / 8; ++g) {
+                    f32x4 a[C::MT];
+#pragma unroll
+                    for (int i = 0; i < C::MT; ++i)
+                        a[i] = *reinterpret_cast<const f32x4*>(&halo[a_lane[i] + stage_off + tp * C::CP + g * 8]);
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j) {
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) {
+                            const float bv = bs[(tp * C::CINC + g * 8 + s) * C::NB + j * 32];
+#pragma unroll
+                            for (int i = 0; i < C::MT; ++i)
+                                part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], bv, part[i][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        };
+        if constexpr (ACC == 1) {
+            for (int st = 0; st < C::NSTAGES; ++st) {                  // unrolling left to the compiler
+                const int buf = st & 1;
+                store_b(buf);
+                __syncthreads();
+                if (st + 1 < C::NSTAGES) load_b(st + 1);   // in flight while this stage computes
+                if (wave_active && !(dbg & 2)) {
+                    f32x16 part[C::MT][C::NT];
+#pragma unroll
+                    for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+                    mma(st, buf, part);
+#pragma unroll
+                    for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::NT; ++j) acc[i][j] += part[i][j];
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int sg = 0; sg < C::NSTAGES / ACC; ++sg) {
                 f32x16 part[C::MT][C::NT];
 #pragma unroll
                 for (int i = 0; i < C::MT; ++i)
@@ -221,25 +298,13 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                     for (int j = 0; j < C::NT; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
-#pragma unroll
-                for (int tp = 0; tp < C::TPS; ++tp) {
-#pragma unroll
-                    for (int g = 0; g < C::CINC / 8; ++g) {
-                        f32x4 a[C::MT];
-#pragma unroll
-                        for (int i = 0; i < C::MT; ++i)
-                            a[i] = *reinterpret_cast<const f32x4*>(&halo[a_lane[i] + stage_off + tp * C::CP + g * 8]);
-#pragma unroll
-                        for (int j = 0; j < C::NT; ++j) {
-#pragma unroll
-                            for (int s = 0; s < 4; ++s) {
-                                const float bv = bs[(tp * C::CINC + g * 8 + s) * C::NB + j * 32];
-#pragma unroll
-                                for (int i = 0; i < C::MT; ++i)
-                                    part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], bv, part[i][j], 0, 0, 0);
-                            }
-                        }
-                    }
+#pragma unroll 1
+                for (int ss = 0; ss < ACC; ++ss) {
+                    const int st = sg * ACC + ss, buf = st & 1;
+                    store_b(buf);
+                    __syncthreads();
+                    if (st + 1 < C::NSTAGES) load_b(st + 1);
+                    if (wave_active && !(dbg & 2)) mma(st, buf, part);
                 }
 #pragma unroll
                 for (int i = 0; i < C::MT; ++i)
@@ -1259,8 +1324,9 @@ extern "C" int tmf_conv3d_fwd(const float* x, const float* w, float* z, float* s
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
                 "tmf_conv3d_fwd: non-positive dimension (B=%d D=%d H=%d W=%d cin=%d cout=%d)", B, D, H, W, cin, cout);
     TMF_REQUIRE(ksize == 1 || ksize == 3, TMF_E_ARG, "tmf_conv3d_fwd: ksize must be 1 or 3, got %d", ksize);
-    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
-                "tmf_conv3d_fwd: one sample exceeds 2^31 elements");
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 29), TMF_E_SHAPE,
+                "tmf_conv3d_fwd: one sample exceeds 2^29 elements (32-bit byte offsets inside a sample)");
+    TMF_REQUIRE((long)ksize * ksize * ksize * cin * cout < (1L << 29), TMF_E_SHAPE, "tmf_conv3d_fwd: weight tensor exceeds 2^29 elements");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w); TMF_REQUIRE_ALIGNED(z);
     const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize);
     hipStream_t s = (hipStream_t)stream;
@@ -1285,8 +1351,9 @@ extern "C" int tmf_conv3d_fwd_affine(const float* x, const float* w, const float
     TMF_REQUIRE(ksize == 1 || ksize == 3, TMF_E_ARG, "tmf_conv3d_fwd_affine: ksize must be 1 or 3, got %d", ksize);
     TMF_REQUIRE(pool == TMF_POOL_NONE || pool == TMF_POOL_MAX2 || pool == TMF_POOL_AVG2, TMF_E_ARG,
                 "tmf_conv3d_fwd_affine: unknown pool mode %d", pool);
-    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
-                "tmf_conv3d_fwd_affine: one sample exceeds 2^31 elements");
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 29), TMF_E_SHAPE,
+                "tmf_conv3d_fwd_affine: one sample exceeds 2^29 elements (32-bit byte offsets inside a sample)");
+    TMF_REQUIRE((long)ksize * ksize * ksize * cin * cout < (1L << 29), TMF_E_SHAPE, "tmf_conv3d_fwd_affine: weight tensor exceeds 2^29 elements");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w); TMF_REQUIRE_ALIGNED(y);
     if (pool != TMF_POOL_NONE && (D / 2 == 0 || H / 2 == 0 || W / 2 == 0)) return TMF_OK;      // empty output
     const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize);
