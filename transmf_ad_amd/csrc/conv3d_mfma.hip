@@ -35,6 +35,8 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 // ------------------------------------------------------------------------------------
 // forward / dgrad
 // ------------------------------------------------------------------------------------
@@ -298,14 +300,18 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                     for (int j = 0; j < C::NT; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
-#pragma unroll 1
-                for (int ss = 0; ss < ACC; ++ss) {
-                    const int st = sg * ACC + ss, buf = st & 1;
+                // the group's first stage is peeled: its MFMAs take the literal 0 as C, so the partial sums are never
+                // zeroed with 32 moves per group
+                auto one = [&](int st) {
+                    const int buf = st & 1;
                     store_b(buf);
                     __syncthreads();
                     if (st + 1 < C::NSTAGES) load_b(st + 1);
                     if (wave_active && !(dbg & 2)) mma(st, buf, part);
-                }
+                };
+                one(sg * ACC);
+#pragma unroll 1
+                for (int ss = 1; ss < ACC; ++ss) one(sg * ACC + ss);
 #pragma unroll
                 for (int i = 0; i < C::MT; ++i)
 #pragma unroll
@@ -396,34 +402,90 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
 #pragma unroll
     for (int j = 0; j < C::NT; ++j) s1[j] = s2[j] = 0.f;
     float* zb = z + (size_t)b * D * H * W * Cout;
-    // 32-bit offsets inside the sample (checked < 2^31 on the host); a brick that lies inside the volume with a
-    // full channel tile takes the branch-free path (no per-voxel predicates around the stores)
-    auto epilogue = [&](auto full_c) {
-        constexpr bool FULL = decltype(full_c)::value;
+    // 32-bit offsets inside the sample (checked on the host); a brick that lies inside the volume with a full channel
+    // tile takes the branch-free path (no per-voxel predicates around the stores)
+    if constexpr (VEC && TMF_CONV_BUF) {
+        // Buffer stores: the lane part of the address (channel, w parity, brick row) is one VGPR per (M-tile, w pair),
+        // the plane d travels in the scalar offset, the second N-tile in the instruction offset; a lane outside the
+        // volume or beyond Cout carries an out-of-range offset and its store is dropped by the hardware.
+        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, D * H * W * Cout * 4, 0x00020000);
+        const int co0 = n0 + wn * C::NT * 32 + l31;
+        const bool full = d0 + C::TD <= D && h0 + C::TH <= H && w0 + C::TW <= W && n0 + C::NB <= Cout;
+        const int plane = H * W * Cout * 4;
+        auto epilogue = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+            f32x2 p1[C::NT], p2[C::NT];
 #pragma unroll
-        for (int i = 0; i < C::MT; ++i) {
+            for (int j = 0; j < C::NT; ++j) p1[j] = p2[j] = f32x2{0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int T = wm * C::MT + i, rest = 2 * (r >> 2) + hsel;            // fragment row -> (d, w, h) as a_lane
-                const int pd = r & 3, pw = rest % C::TW, ph = T * (8 / C::TW) + rest / C::TW;
-                const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
-                const bool pv = FULL || (gd < D && gh < H && gw < W);
-                const int off = ((gd * H + gh) * W + gw) * Cout;
+            for (int i = 0; i < C::MT; ++i) {
 #pragma unroll
-                for (int j = 0; j < C::NT; ++j) {
-                    const int co = n0 + (wn * C::NT + j) * 32 + l31;
-                    if (FULL || (pv && co < Cout)) {
-                        const float v = acc[i][j][r];
-                        if (!(dbg & 4)) __builtin_nontemporal_store(v, &zb[off + co]);
-                        s1[j] += v;
-                        s2[j] += v * v;
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int T = wm * C::MT + i, rest = 2 * q4 + hsel;                 // fragment row -> (d, w, h) as a_lane
+                    const int pw = rest % C::TW, ph = T * (8 / C::TW) + rest / C::TW;
+                    const int gh = h0 + ph, gw = w0 + pw;
+                    const bool hw_ok = FULL || (gh < H && gw < W);
+                    const int vo = ((gh * W + gw) * Cout + co0) * 4;
+                    int voj[C::NT];
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j) voj[j] = (FULL || (hw_ok && co0 + j * 32 < Cout)) ? vo + j * 128 : OOB;
+#pragma unroll
+                    for (int pd = 0; pd < 4; pd += 2) {
+                        const int r = q4 * 4 + pd;
+                        const bool d_ok0 = FULL || d0 + pd < D, d_ok1 = FULL || d0 + pd + 1 < D;      // wave-uniform
+#pragma unroll
+                        for (int j = 0; j < C::NT; ++j) {
+                            // (scalars, not elements of the pair: __builtin_bit_cast of v[1] reads v[0] with this compiler)
+                            float v0 = acc[i][j][r], v1 = acc[i][j][r + 1];
+                            if (!(dbg & 4)) {
+                                if (d_ok0) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), zr, voj[j], (d0 + pd) * plane, 2);
+                                if (d_ok1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), zr, voj[j], (d0 + pd + 1) * plane, 2);
+                            }
+                            if (!FULL) {
+                                const bool lane_ok = voj[j] >= 0;
+                                v0 = (lane_ok && d_ok0) ? v0 : 0.f;
+                                v1 = (lane_ok && d_ok1) ? v1 : 0.f;
+                            }
+                            const f32x2 v = {v0, v1};
+                            p1[j] += v;
+                            p2[j] += v * v;
+                        }
                     }
                 }
             }
-        }
-    };
-    if (d0 + C::TD <= D && h0 + C::TH <= H && w0 + C::TW <= W && n0 + C::NB <= Cout) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j) { s1[j] = p1[j][0] + p1[j][1]; s2[j] = p2[j][0] + p2[j][1]; }
+        };
+        if (full) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+    } else {
+        auto epilogue = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+            for (int i = 0; i < C::MT; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int T = wm * C::MT + i, rest = 2 * (r >> 2) + hsel;            // fragment row -> (d, w, h) as a_lane
+                    const int pd = r & 3, pw = rest % C::TW, ph = T * (8 / C::TW) + rest / C::TW;
+                    const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+                    const bool pv = FULL || (gd < D && gh < H && gw < W);
+                    const int off = ((gd * H + gh) * W + gw) * Cout;
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j) {
+                        const int co = n0 + (wn * C::NT + j) * 32 + l31;
+                        if (FULL || (pv && co < Cout)) {
+                            const float v = acc[i][j][r];
+                            if (!(dbg & 4)) __builtin_nontemporal_store(v, &zb[off + co]);
+                            s1[j] += v;
+                            s2[j] += v * v;
+                        }
+                    }
+                }
+            }
+        };
+        if (d0 + C::TD <= D && h0 + C::TH <= H && w0 + C::TW <= W && n0 + C::NB <= Cout) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
+    }
     if (stat_partial != nullptr) {
 #pragma unroll
         for (int j = 0; j < C::NT; ++j) {
