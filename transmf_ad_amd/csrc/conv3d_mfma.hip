@@ -897,8 +897,10 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
     int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles,
     int tiles_per_split, int dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xh = smem;                       // [NHALO][32]
-    float* dzs = smem + C::NHALO * C::CI;   // [NPOS][NB]
+    // dz rows first: their ds_read_b32 offsets then fit the 16-bit instruction field (behind the 77 KB halo every
+    // read needed its own v_add, and vector-ALU instructions are paid in matrix time)
+    float* dzs = smem;                      // [NPOS][NB]
+    float* xh = smem + C::NPOS * C::NB;     // [NHALO][32]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -952,54 +954,126 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
     // slots [0, HVP) of the halo are prefetched a whole brick ahead, the rest rides with the dz batch
     // (register budget: 2 waves per SIMD -> 256 VGPRs, half of them accumulators when NT == 2)
     constexpr int HVP = (C::NW == 8 && C::NT == 2) ? (HV > 3 ? HV - 3 : 0) : HV;
+    // VEC path: buffer loads.  The per-lane byte offset of every piece RELATIVE to the brick's halo origin and its halo
+    // coordinates (one byte each) are computed once per kernel; per brick only the scalar base moves.  A brick whose
+    // halo lies inside the volume loads with no vector arithmetic at all; at the volume faces a piece is valid iff
+    // lo <= (hd, hh, hw) <= hi per byte (5 vector instructions), and an invalid piece carries the offset 2^31 >=
+    // num_records, which the hardware answers with zeros.
+    constexpr int OOB = (int)0x80000000u;
+    constexpr bool BUF = VEC && TMF_CONV_BUF;
+    int hrel[BUF ? HV : 1], hcrd[BUF ? HV : 1], drel[BUF ? DV : 1], dcrd[BUF ? DV : 1];
+    if constexpr (BUF) {
+#pragma unroll
+        for (int q = 0; q < HV; ++q) {
+            const int e = tid + q * C::NTHR;
+            const int hp = e >> 3, c = ci0 + (e & 7) * 4;
+            const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
+            hrel[q] = (e < C::NHALO * 8 && c < Cin) ? (((hd * H + hh) * W + hw) * Cin + c) * 4 : OOB;
+            hcrd[q] = hd | hh << 8 | hw << 16;
+        }
+#pragma unroll
+        for (int q = 0; q < DV; ++q) {
+            const int e = tid + q * C::NTHR;
+            const int p = e / (C::NB / 4), c = co0 + (e % (C::NB / 4)) * 4;
+            const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
+            drel[q] = (e < C::NPOS * (C::NB / 4) && c < Cout) ? (((pd * H + ph) * W + pw) * Cout + c) * 4 : OOB;
+            dcrd[q] = pd | ph << 8 | pw << 16;
+        }
+    }
+    // valid iff every byte of crd lies in [lo, hi] (all bytes < 128): bit 7 of each byte of (crd + 0x808080 - lo) and of
+    // ((hi | 0x808080) - crd) survives exactly when there is no borrow
+    auto in_box = [](int crd, int lo_bias, int hi_bias) {
+        const unsigned t = (unsigned)crd + (unsigned)lo_bias, u = (unsigned)hi_bias - (unsigned)crd;
+        return ((t & u) | ~0x808080u) == 0xFFFFFFFFu;
+    };
+    auto min_i = [](int a_, int b_) { return a_ < b_ ? a_ : b_; };
     auto fetch_halo = [&](int tile, const int q0, const int q1) {
         int b, d0, h0, w0;
         locate(tile, b, d0, h0, w0);
         const float* xb = x + (size_t)b * D * H * W * Cin;
+        if constexpr (BUF) {
+            // origin = halo position (0, 0, 0); at a low face it points before the sample (never dereferenced there)
+            const float* org = xb + ((long)((d0 - 1) * H + (h0 - 1)) * W + (w0 - 1)) * Cin;
+            const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(org), 0, 0x7FFFFFFF, 0x00020000);
+            const bool interior = d0 >= 1 && d0 + C::TD < D && h0 >= 1 && h0 + C::TH < H && w0 >= 1 && w0 + C::TW < W;
+            if (interior) {
 #pragma unroll
-        for (int q = q0; q < q1; ++q) {
-            const int e = tid + q * C::NTHR;
-            const int hp = e >> 3, c4 = e & 7;
-            const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
-            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
-            const int c = ci0 + c4 * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < C::NHALO * 8 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
-                const float* src = xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c;
-                if (VEC) {
-                    if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
-                } else {
+                for (int q = q0; q < q1; ++q)
+                    hreg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, hrel[q], 0, 0));
+            } else {
+                const int lo = (d0 == 0 ? 1 : 0) | (h0 == 0 ? 1 : 0) << 8 | (w0 == 0 ? 1 : 0) << 16;
+                const int hi = min_i(C::HD - 1, D - d0) | min_i(C::HH - 1, H - h0) << 8 | min_i(C::HW - 1, W - w0) << 16;
+                const int lo_bias = 0x808080 - lo, hi_bias = hi | 0x808080;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (c + u < Cin) v[u] = src[u];
+                for (int q = q0; q < q1; ++q) {
+                    const int off = in_box(hcrd[q], lo_bias, hi_bias) ? hrel[q] : OOB;
+                    hreg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, off, 0, 0));
                 }
             }
-            hreg[q] = v;
+        } else {
+#pragma unroll
+            for (int q = q0; q < q1; ++q) {
+                const int e = tid + q * C::NTHR;
+                const int hp = e >> 3, c4 = e & 7;
+                const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
+                const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+                const int c = ci0 + c4 * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (e < C::NHALO * 8 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
+                    const float* src = xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c;
+                    if (VEC) {
+                        if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (c + u < Cin) v[u] = src[u];
+                    }
+                }
+                hreg[q] = v;
+            }
         }
     };
     auto fetch_dz = [&](int tile) {
         int b, d0, h0, w0;
         locate(tile, b, d0, h0, w0);
         const float* dzb = dz + (size_t)b * D * H * W * Cout;
+        if constexpr (BUF) {
+            const float* org = dzb + ((long)(d0 * H + h0) * W + w0) * Cout;
+            const __amdgpu_buffer_rsrc_t dr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(org), 0, 0x7FFFFFFF, 0x00020000);
+            if (d0 + C::TD <= D && h0 + C::TH <= H && w0 + C::TW <= W) {
 #pragma unroll
-        for (int q = 0; q < DV; ++q) {
-            const int e = tid + q * C::NTHR;
-            const int p = e / (C::NB / 4), c4 = e % (C::NB / 4);
-            const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
-            const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
-            const int c = co0 + c4 * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (e < C::NPOS * (C::NB / 4) && gd < D && gh < H && gw < W) {
-                const float* src = dzb + ((size_t)(gd * H + gh) * W + gw) * Cout + c;
-                if (VEC) {
-                    if (c < Cout) v = *reinterpret_cast<const f32x4*>(src);
-                } else {
+                for (int q = 0; q < DV; ++q)
+                    dreg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, drel[q], 0, 0));
+            } else {
+                const int hi = min_i(C::TD, D - d0) - 1 | (min_i(C::TH, H - h0) - 1) << 8 | (min_i(C::TW, W - w0) - 1) << 16;
+                const int hi_bias = hi | 0x808080;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (c + u < Cout) v[u] = src[u];
+                for (int q = 0; q < DV; ++q) {
+                    const int off = in_box(dcrd[q], 0x808080, hi_bias) ? drel[q] : OOB;
+                    dreg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dr, off, 0, 0));
                 }
             }
-            dreg[q] = v;
+        } else {
+#pragma unroll
+            for (int q = 0; q < DV; ++q) {
+                const int e = tid + q * C::NTHR;
+                const int p = e / (C::NB / 4), c4 = e % (C::NB / 4);
+                const int pw = p % C::TW, ph = (p / C::TW) % C::TH, pd = p / (C::TW * C::TH);
+                const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+                const int c = co0 + c4 * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (e < C::NPOS * (C::NB / 4) && gd < D && gh < H && gw < W) {
+                    const float* src = dzb + ((size_t)(gd * H + gh) * W + gw) * Cout + c;
+                    if (VEC) {
+                        if (c < Cout) v = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (c + u < Cout) v[u] = src[u];
+                    }
+                }
+                dreg[q] = v;
+            }
         }
     };
 
@@ -1442,6 +1516,8 @@ extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
                 "tmf_conv3d_wgrad: non-positive dimension");
     TMF_REQUIRE(ksize == 1 || ksize == 3, TMF_E_ARG, "tmf_conv3d_wgrad: ksize must be 1 or 3, got %d", ksize);
+    TMF_REQUIRE((long)(D > 6 ? D : 6) * H * W * (cin > cout ? cin : cout) < (1L << 29), TMF_E_SHAPE,
+                "tmf_conv3d_wgrad: one sample exceeds 2^29 elements (32-bit byte offsets inside a sample)");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(dz); TMF_REQUIRE_ALIGNED(dw); TMF_REQUIRE_ALIGNED(workspace);
     const size_t need = tmf_conv3d_wgrad_workspace_bytes(B, D, H, W, cin, cout, ksize);
     TMF_REQUIRE(workspace_bytes >= need, TMF_E_WORKSPACE, "tmf_conv3d_wgrad: workspace %zu B < required %zu B",
