@@ -28,7 +28,7 @@ def main():
     blocks, cur, name = [], {}, lines[start]
     for l in lines[start + 1:]:
         t = l.strip()
-        if t.startswith("s_endpgm"):
+        if t.startswith(".Lfunc_end"):
             break
         if re.match(r"^\.LBB\d+_\d+:", l):
             blocks.append((name, cur)); cur, name = {}, l.split(":")[0]

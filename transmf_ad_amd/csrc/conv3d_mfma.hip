@@ -1110,21 +1110,29 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
         // before its MFMAs and the compiler pipelines them across pairs.
         auto mma_bricks = [&](auto ntaps_c) {
             constexpr int NTAPS = decltype(ntaps_c)::value;
-            for (int row = 0; row < C::TD * C::TH; ++row) {
-                const int rowoff = ((row / C::TH) * C::HH + (row % C::TH)) * C::HW * C::CI;
-                const float* bsrc = dzs + b_lane + row * C::TW * C::NB;
+            // one plane of the brick per iteration, its TH rows unrolled: the row and pair offsets of the x reads are
+            // instruction offsets (ds_read2st64: 256-B units), so the only vector adds are one per tap and plane
+#pragma unroll 1
+            for (int pd = 0; pd < C::TD; ++pd) {
+                const float* xp[NTAPS];
 #pragma unroll
-                for (int q = 0; q < C::TW / 2; ++q) {
-                    float bv[C::NT], av[NTAPS];
+                for (int t = 0; t < NTAPS; ++t) xp[t] = xh + tapoff[t] + pd * C::HH * C::HW * C::CI;
+                const float* bsrc = dzs + b_lane + pd * C::TH * C::TW * C::NB;
 #pragma unroll
-                    for (int j = 0; j < C::NT; ++j) bv[j] = bsrc[2 * q * C::NB + j * 32];
+                for (int ph = 0; ph < C::TH; ++ph) {
 #pragma unroll
-                    for (int t = 0; t < NTAPS; ++t) av[t] = xh[tapoff[t] + rowoff + 2 * q * C::CI];
+                    for (int q = 0; q < C::TW / 2; ++q) {
+                        float bv[C::NT], av[NTAPS];
 #pragma unroll
-                    for (int t = 0; t < NTAPS; ++t)
+                        for (int j = 0; j < C::NT; ++j) bv[j] = bsrc[(ph * C::TW + 2 * q) * C::NB + j * 32];
 #pragma unroll
-                        for (int j = 0; j < C::NT; ++j)
-                            acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[j], acc[t][j], 0, 0, 0);
+                        for (int t = 0; t < NTAPS; ++t) av[t] = xp[t][ph * C::HW * C::CI + 2 * q * C::CI];
+#pragma unroll
+                        for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                            for (int j = 0; j < C::NT; ++j)
+                                acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[j], acc[t][j], 0, 0, 0);
+                    }
                 }
             }
         };
