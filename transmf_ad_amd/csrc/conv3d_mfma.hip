@@ -247,7 +247,14 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
             if (C::KS == 1) stage_off = 0;
             else if (C::TPS == 3) stage_off = ((st / 3) * C::HH + (st % 3)) * C::HW * C::CP;
             else stage_off = (((st / 9) * C::HH + (st / 3) % 3) * C::HW + st % 3) * C::CP;
-            const float* bs = Bs + buf * C::BSTAGE + b_lane;
+            // B reads of the 64-channel tiles: two base registers 128 B apart (the two N-tiles), which
+            // the compiler must not recognise as one base: every read is then a multiple of 256 B away from its base and
+            // pairs up as ds_read2st64 with instruction offsets that reach the whole weight ring.  Pairing the two
+            // N-tiles of a row instead (plain ds_read2, 1-KB reach) cost a vector add per 4 rows.
+            const float* bs0 = Bs + buf * C::BSTAGE + b_lane;
+            int delta = 32;                                // (an opaque OFFSET: laundering the pointer would lose the LDS
+            asm volatile("" : "+v"(delta));                //  address space and turn the reads into flat loads)
+            const float* bs1 = bs0 + delta;
 #pragma unroll
             for (int tp = 0; tp < C::TPS; ++tp) {
 #pragma unroll
@@ -260,7 +267,8 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                     for (int j = 0; j < C::NT; ++j) {
 #pragma unroll
                         for (int s = 0; s < 4; ++s) {
-                            const float bv = bs[(tp * C::CINC + g * 8 + s) * C::NB + j * 32];
+                            const int row = tp * C::CINC + g * 8 + s;
+                            const float bv = C::NB == 64 ? (j ? bs1 : bs0)[row * C::NB] : bs0[row * C::NB + j * 32];
 #pragma unroll
                             for (int i = 0; i < C::MT; ++i)
                                 part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], bv, part[i][j], 0, 0, 0);
