@@ -884,17 +884,23 @@ int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float
 // ------------------------------------------------------------------------------------
 // weight gradient, 3x3x3
 // ------------------------------------------------------------------------------------
-template <int NT_, int TD_, int TH_, int TW_, int NW_ = 4>
+template <int NT_, int TD_, int TH_, int TW_, int NW_ = 4, int CI_ = 32>
 struct WgCfg {
     static constexpr int NT = NT_, TD = TD_, TH = TH_, TW = TW_, NW = NW_;
     static constexpr int NTHR = 64 * NW;
     static constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
     static constexpr int NHALO = HD * HH * HW;
-    static constexpr int CI = 32;                 // input channels per workgroup (one MFMA M-tile)
+    // input channels per workgroup.  32 = one MFMA M-tile per tap.  16 (layers with Cin <= 16) PACKS TWO TAPS into
+    // one M-tile: rows 0-15 are tap 2p, rows 16-31 tap 2p + 1, each lane reading its own tap's shifted halo address —
+    // 14 tile-taps instead of 27 half-empty ones.
+    static constexpr int CI = CI_;
+    static constexpr bool PACK = CI_ == 16;
     static constexpr int NB = 32 * NT;            // output channels per workgroup
     static constexpr int NPOS = TD * TH * TW;
-    // taps per wave: 4 waves x 7, or 8 waves as 4 SIMD pairs of (4 + 3) -> 7 taps per SIMD either way
-    static constexpr int TPW = NW == 4 ? 7 : 4;
+    // accumulator tiles per wave: 4 waves x 7 taps, or 8 waves as 4 SIMD pairs of (4 + 3) -> 7 taps per SIMD either
+    // way; packed: tap pairs p = wave, wave + 8 (p < 14) -> 4, 4, 3, 3 tiles per SIMD
+    static constexpr int TPW = PACK ? 2 : (NW == 4 ? 7 : 4);
+    static_assert(CI_ == 32 || (CI_ == 16 && NW_ == 8), "packed taps are an 8-wave configuration");
     static constexpr size_t LDS_BYTES = (size_t)(NHALO * CI + NPOS * NB) * 4;
     static_assert(TW % 2 == 0, "voxel pairs must not straddle a row");
 };
@@ -921,15 +927,15 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
 
     // This wave's taps.  Waves w and w+4 share a SIMD (dispatch order), each SIMD owns 7 consecutive taps.
     const int tap_base = C::NW == 4 ? 7 * wave : 7 * (wave & 3) + 4 * (wave >> 2);
-    const int tap_cnt = C::NW == 4 ? 7 : (wave < 4 ? 4 : 3);
+    const int tap_cnt = C::PACK ? (wave < 6 ? 2 : 1) : C::NW == 4 ? 7 : (wave < 4 ? 4 : 3);
     // halo float offset of each tap (clamped; surplus taps are neither computed nor written)
     int tapoff[C::TPW];
 #pragma unroll
     for (int t = 0; t < C::TPW; ++t) {
-        int tap = tap_base + t;
+        int tap = C::PACK ? 2 * (wave + 8 * t) + (l31 >> 4) : tap_base + t;
         tap = tap > 26 ? 26 : tap;
         const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-        tapoff[t] = ((kd * C::HH + kh) * C::HW + kw + hsel) * C::CI + l31;
+        tapoff[t] = ((kd * C::HH + kh) * C::HW + kw + hsel) * C::CI + (C::PACK ? (l31 & 15) : l31);
     }
     const int b_lane = hsel * C::NB + l31;
 
@@ -948,7 +954,8 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
     // Software pipeline over bricks: the NEXT brick's halo travels HBM -> registers while the current brick is
     // being multiplied and is written to LDS after the compute phase (one barrier pair per brick); the dz rows
     // (shorter, and the register file is full of accumulators) are fetched in one batch at the brick boundary.
-    constexpr int HV = (C::NHALO * 8 + C::NTHR - 1) / C::NTHR;
+    constexpr int C4 = C::CI / 4;                  // float4 pieces per halo position
+    constexpr int HV = (C::NHALO * C4 + C::NTHR - 1) / C::NTHR;
     constexpr int DV = (C::NPOS * (C::NB / 4) + C::NTHR - 1) / C::NTHR;
     f32x4 hreg[HV], dreg[DV];
     auto locate = [&](int tile, int& b, int& d0, int& h0, int& w0) {
@@ -974,9 +981,9 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
             const int e = tid + q * C::NTHR;
-            const int hp = e >> 3, c = ci0 + (e & 7) * 4;
+            const int hp = e / C4, c = ci0 + (e % C4) * 4;
             const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
-            hrel[q] = (e < C::NHALO * 8 && c < Cin) ? (((hd * H + hh) * W + hw) * Cin + c) * 4 : OOB;
+            hrel[q] = (e < C::NHALO * C4 && c < Cin) ? (((hd * H + hh) * W + hw) * Cin + c) * 4 : OOB;
             hcrd[q] = hd | hh << 8 | hw << 16;
         }
 #pragma unroll
@@ -1022,12 +1029,12 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
 #pragma unroll
             for (int q = q0; q < q1; ++q) {
                 const int e = tid + q * C::NTHR;
-                const int hp = e >> 3, c4 = e & 7;
+                const int hp = e / C4, c4 = e % C4;
                 const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
                 const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
                 const int c = ci0 + c4 * 4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (e < C::NHALO * 8 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
+                if (e < C::NHALO * C4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) {
                     const float* src = xb + ((size_t)(gd * H + gh) * W + gw) * Cin + c;
                     if (VEC) {
                         if (c < Cin) v = *reinterpret_cast<const f32x4*>(src);
@@ -1098,7 +1105,7 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
             const int e = tid + q * C::NTHR;
-            if (e < C::NHALO * 8) *reinterpret_cast<f32x4*>(&xh[e * 4]) = hreg[q];
+            if (e < C::NHALO * C4) *reinterpret_cast<f32x4*>(&xh[e * 4]) = hreg[q];
         }
 #pragma unroll
         for (int q = 0; q < DV; ++q) {
@@ -1144,7 +1151,11 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
                 }
             }
         };
-        if (C::NW == 4) mma_bricks(std::integral_constant<int, C::TPW>{});
+        if (C::PACK) {
+            if (wave < 6) mma_bricks(std::integral_constant<int, 2>{});
+            else mma_bricks(std::integral_constant<int, 1>{});
+        }
+        else if (C::NW == 4) mma_bricks(std::integral_constant<int, C::TPW>{});
         else if (wave < 4) mma_bricks(std::integral_constant<int, 4>{});
         else mma_bricks(std::integral_constant<int, 3>{});     // tap 27 (wave 7) is clamped: computed, not stored
     }
@@ -1152,15 +1163,17 @@ __global__ __launch_bounds__(C::NTHR) void conv3d_wgrad_kernel(
     // partial[split][tap][ci][co];  D fragment: row = ci, column = co
 #pragma unroll
     for (int t = 0; t < C::TPW; ++t) {
-        const int tap = tap_base + t;
-        if (t < tap_cnt && tap < 27) {
+        const int tap0 = C::PACK ? 2 * (wave + 8 * t) : tap_base + t;
+        if (t < tap_cnt && tap0 < 27) {
 #pragma unroll
             for (int j = 0; j < C::NT; ++j) {
                 const int co = co0 + j * 32 + l31;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
-                    if (ci < Cin && co < Cout)
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * hsel;            // M-tile row (>= 16 iff r >= 8)
+                    const int tap = C::PACK ? tap0 + (r >> 3) : tap0;
+                    const int ci = ci0 + (C::PACK ? (m & 15) : m);
+                    if (tap < 27 && ci < Cin && co < Cout)
                         partial[(((size_t)split * 27 + tap) * Cin + ci) * Cout + co] = acc[t][j][r];
                 }
             }
@@ -1216,6 +1229,7 @@ __global__ __launch_bounds__(256) void conv1x1_wgrad_kernel(
 struct WgPlan {
     int nt, tilesD, tilesH, tilesW, ntiles, tps, nsplit, gy, gz;
     int small;   // 1 = 4x4x4 bricks
+    int pack;    // 1 = Cin <= 16: two taps per MFMA M-tile
 };
 
 WgPlan plan_wgrad(int B, int D, int H, int W, int cin, int cout) {
@@ -1229,7 +1243,8 @@ WgPlan plan_wgrad(int B, int D, int H, int W, int cin, int cout) {
     p.nt = (cout <= 32 || w8) ? 1 : 2;
     p.tilesD = tmf_cdiv(D, td); p.tilesH = tmf_cdiv(H, th); p.tilesW = tmf_cdiv(W, tw);
     p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
-    p.gy = tmf_cdiv(cin, 32);
+    p.pack = w8 && cin <= 16;            // two taps per MFMA M-tile (WgCfg::PACK)
+    p.gy = p.pack ? 1 : tmf_cdiv(cin, 32);
     p.gz = tmf_cdiv(cout, 32 * p.nt);
     const int groups = p.gy * p.gz;
     int want = 256 / groups;             // one workgroup per CU in total: one round, half the partial slabs of two
@@ -1562,8 +1577,13 @@ extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void
         using L2w8 = WgCfg<2, 4, 8, 8, 8>;
         using S1w8 = WgCfg<1, 4, 4, 4, 8>;
         using S2w8 = WgCfg<2, 4, 4, 4, 8>;
+        using L1w8p = WgCfg<1, 4, 8, 8, 8, 16>;
+        using S1w8p = WgCfg<1, 4, 4, 4, 8, 16>;
         const bool w8 = vec && conv_waves() >= 8;
-        if (w8) {
+        if (w8 && p.pack) {
+            if (!p.small) TMF_WG_LAUNCH(L1w8p, true);
+            else          TMF_WG_LAUNCH(S1w8p, true);
+        } else if (w8) {
             if (!p.small && p.nt == 1) TMF_WG_LAUNCH(L1w8, true);
             else if (!p.small)         TMF_WG_LAUNCH(L2w8, true);
             else if (p.nt == 1)        TMF_WG_LAUNCH(S1w8, true);
