@@ -44,8 +44,11 @@ extern "C" {
 int         tmf_version(void);                 /* ABI version, currently 1 */
 const char* tmf_last_error_string(void);
 /* Process-wide tuning knobs (never change results).  "conv_waves" = 2 | 4 | 8 | 16: workgroup shape of the
- * convolution kernels (16, the default: two 8-wave workgroups per CU).  "debug": timing ablations only (results are
- * garbage when set). */
+ * convolution kernels (16, the default: two 8-wave workgroups per CU).  "conv_ws" = 1: the experimental wave-specialised
+ * forward kernel for eligible 3x3x3 layers (default 0; higher values are its timing ablations).  "debug": timing ablations
+ * only (results are garbage when set).
+ * Size limits of the convolution entries: one sample of a layer (D*H*W*max(cin, cout)) and one weight tensor stay below
+ * 2^29 elements — offsets inside a sample are 32-bit byte offsets of buffer resources; violating shapes return TMF_E_SHAPE. */
 int         tmf_set_option(const char* name, int value);
 
 /* ------------------------------------------------------------------------------
