@@ -36,8 +36,10 @@ def test_two_workgroup_conv_kernels_fit_128_registers_without_scratch(kernels):
 
 
 def test_hot_kernels_do_not_spill(kernels):
-    checks = [("conv3d_mfma.o", "conv3d_wgrad_kernelINS_5WgCfgILi1ELi4ELi8ELi8ELi8EEELb1E"),
-              ("conv3d_mfma.o", "conv3d_wgrad_kernelINS_5WgCfgILi1ELi4ELi4ELi4ELi8EEELb1E"),
+    checks = [("conv3d_mfma.o", "conv3d_wgrad_kernelINS_5WgCfgILi1ELi4ELi8ELi8ELi8ELi32EEELb1E"),
+              ("conv3d_mfma.o", "conv3d_wgrad_kernelINS_5WgCfgILi1ELi4ELi4ELi4ELi8ELi32EEELb1E"),
+              ("conv3d_mfma.o", "conv3d_wgrad_kernelINS_5WgCfgILi1ELi4ELi8ELi8ELi8ELi16EEELb1E"),
+              ("conv3d_mfma.o", "conv3d_wgrad_kernelINS_5WgCfgILi1ELi4ELi4ELi4ELi8ELi16EEELb1E"),
               ("conv3d_bf16.o", "conv3d_wgrad_bf16_kernel"), ("conv3d_bf16.o", "conv3d_fwd_split_kernel"),
               ("conv1_fused.o", "conv1_fused_kernel"), ("bn_act_pool.o", "bn_"), ("attention.o", "xattn_"),
               ("token_gemm.o", "tok_"), ("token_ops.o", "layernorm_")]
