@@ -141,14 +141,26 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
     constexpr bool BUF = VEC && TMF_CONV_BUF;
     const int esz = BUF ? 4 : 1;        // offsets in bytes (buffer path) or elements (scalar path)
     int hoff[HV];                       // offset of the halo position in the sample (+ c4 * 4 channels); < 0 = zero fill
+    {
+        // piece q of this thread is halo position tid / C4 + q * (NTHR / C4), same channel quad: the position is taken
+        // apart into (hd, hh, hw) once and then WALKED by the constant step with two carries — the three divisions per
+        // piece were most of this per-brick prologue, and every vector instruction here is paid in matrix time
+        static_assert(C::NTHR % C4 == 0, "all pieces of a thread share their channel quad");
+        constexpr int STEP = C::NTHR / C4;
+        constexpr int SW = STEP % C::HW, SH = (STEP / C::HW) % C::HH, SD = STEP / (C::HW * C::HH);
+        const int hp0 = tid / C4, c4 = tid % C4;
+        int hw = hp0 % C::HW, hh = (hp0 / C::HW) % C::HH, hd = hp0 / (C::HW * C::HH);
 #pragma unroll
-    for (int q = 0; q < HV; ++q) {
-        const int e = tid + q * C::NTHR;
-        const int hp = e / C4, c4 = e % C4;
-        const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
-        const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
-        const bool ok = e < C::NHALO * C4 && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
-        hoff[q] = ok ? (((gd * H + gh) * W + gw) * Cin + c4 * 4) * esz : OOB;
+        for (int q = 0; q < HV; ++q) {
+            const int gd = d0 + hd - C::PAD, gh = h0 + hh - C::PAD, gw = w0 + hw - C::PAD;
+            const bool ok = hd < C::HD && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            hoff[q] = ok ? (((gd * H + gh) * W + gw) * Cin + c4 * 4) * esz : OOB;
+            hw += SW;
+            if (hw >= C::HW) { hw -= C::HW; ++hh; }
+            hh += SH;
+            if (hh >= C::HH) { hh -= C::HH; ++hd; }
+            hd += SD;
+        }
     }
     int boff[C::BV];                    // weight offset inside a (stage, chunk) slab; < 0 = outside
     int bci[C::BV];                     // input channel inside the chunk (to test against Cin)
