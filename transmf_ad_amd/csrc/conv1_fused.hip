@@ -60,6 +60,7 @@ struct Args {
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ tmf_bf16x8 pack8(const float (&v)[8]) {
     const u32x4 p = {tmf_pack_bf16(v[0], v[1]), tmf_pack_bf16(v[2], v[3]), tmf_pack_bf16(v[4], v[5]), tmf_pack_bf16(v[6], v[7])};
     return __builtin_bit_cast(tmf_bf16x8, p);
@@ -69,7 +70,7 @@ __device__ __forceinline__ tmf_bf16x8 pack8(const float (&v)[8]) {
 // 27-tap convolution is 2 MFMAs instead of 14 and the tap-gradient product 2 instead of 16, which turns the four
 // passes from matrix-bound into LDS / HBM-bound (the opt-in bf16 mode of BASELINE configs[2]).
 template <int MODE, bool BF16, bool P16 = false>     // P16: pooled / dpool are bf16 tensors (bf16 activation storage)
-__global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
+__global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Args a) {   // <= 256 registers: MFMA results in VGPRs (no v_accvgpr_read copies)
     __shared__ float halo[NHALO];
     __shared__ float red[4 * 32 * 32];      // cross-wave reduction scratch (16 KB)
     const int tid = threadIdx.x;
@@ -116,27 +117,54 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
     int tile_end = tile_begin + a.tiles_per_block;
     if (tile_end > a.ntiles) tile_end = a.ntiles;
 
-    // halo brick: 600 scalars / 256 threads -> 3 registers per thread, fetched one brick ahead
+    // halo brick: 600 scalars / 256 threads -> 3 registers per thread, fetched one brick ahead through a buffer
+    // resource whose base is the brick's halo origin: the per-lane byte offsets and halo coordinates are computed once
+    // per kernel, an interior brick loads with no vector arithmetic, a brick at a volume face checks (hd, hh, hw) of a
+    // piece with one packed-byte range test, and an invalid piece carries the offset 2^31 >= num_records (hardware
+    // zero fill).  fp32 MFMA and the vector ALU share one issue port: the index arithmetic this
+    // replaces (~30 instructions per piece) and the 64-bit pooled addresses below were a third of these passes.
+    constexpr int OOB = (int)0x80000000u;
     constexpr int HVN = (NHALO + 255) / 256;
     float hv[HVN];
+    int hrel[HVN], hcrd[HVN];
+#pragma unroll
+    for (int q = 0; q < HVN; ++q) {
+        const int e = tid + q * 256;
+        const int hw = e % HW, hh = (e / HW) % HH, hd = e / (HW * HH);
+        hrel[q] = e < NHALO ? ((hd * a.H + hh) * a.W + hw) * 4 : OOB;
+        hcrd[q] = hd | hh << 8 | hw << 16;
+    }
+    auto min_i = [](int x_, int y_) { return x_ < y_ ? x_ : y_; };
     auto fetch = [&](int tile) {
         int t = tile;
         const int tw = t % a.tilesW; t /= a.tilesW;
         const int th = t % a.tilesH; t /= a.tilesH;
         const int td = t % a.tilesD;
         const int b = t / a.tilesD;
-        const float* xb = a.x + (size_t)b * a.D * a.H * a.W;
+        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+        const float* org = a.x + (size_t)b * a.D * a.H * a.W + ((long)((d0 - 1) * a.H + (h0 - 1)) * a.W + (w0 - 1));
+        const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(org), 0, 0x7FFFFFFF, 0x00020000);
+        if (d0 >= 1 && d0 + TD < a.D && h0 >= 1 && h0 + TH < a.H && w0 >= 1 && w0 + TW < a.W) {
 #pragma unroll
-        for (int q = 0; q < HVN; ++q) {
-            const int e = tid + q * 256;
-            const int hw = e % HW, hh = (e / HW) % HH, hd = e / (HW * HH);
-            const int gd = td * TD + hd - 1, gh = th * TH + hh - 1, gw = tw * TW + hw - 1;
-            float v = 0.f;
-            if (e < NHALO && gd >= 0 && gd < a.D && gh >= 0 && gh < a.H && gw >= 0 && gw < a.W)
-                v = xb[(size_t)(gd * a.H + gh) * a.W + gw];
-            hv[q] = v;
+            for (int q = 0; q < HVN; ++q)
+                hv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, hrel[q], 0, 0));
+        } else {
+            // valid iff lo <= (hd, hh, hw) <= hi per byte: bit 7 of every byte of (crd + 0x808080 - lo) and of
+            // ((hi | 0x808080) - crd) survives exactly when there is no borrow
+            const int lo = (d0 == 0 ? 1 : 0) | (h0 == 0 ? 1 : 0) << 8 | (w0 == 0 ? 1 : 0) << 16;
+            const int hi = min_i(HD - 1, a.D - d0) | min_i(HH - 1, a.H - h0) << 8 | min_i(HW - 1, a.W - w0) << 16;
+            const unsigned lo_bias = 0x808080u - (unsigned)lo, hi_bias = (unsigned)hi | 0x808080u;
+#pragma unroll
+            for (int q = 0; q < HVN; ++q) {
+                const unsigned tt = (unsigned)hcrd[q] + lo_bias, uu = hi_bias - (unsigned)hcrd[q];
+                const int off = (((tt & uu) | ~0x808080u) == 0xFFFFFFFFu) ? hrel[q] : OOB;
+                hv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, off, 0, 0));
+            }
         }
     };
+    // pooled / dpool addresses: lane part = (second brick row of the lane half, channel); everything else is scalar
+    constexpr int PSZ = P16 ? 2 : 4;
+    const int pl_lane = cv ? (hsel * OW * a.C + co) * PSZ : OOB;
     if (tile_begin < tile_end) fetch(tile_begin);
     for (int tile = tile_begin; tile < tile_end; ++tile) {
         int t = tile;
@@ -204,10 +232,22 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
             const int bd = d0 + 2 * (mt >> 2), bh = h0 + 4 * ((mt >> 1) & 1) + 2 * hsel, bwid = w0 + 4 * (mt & 1);
 
             if (MODE == MODE_STATS) {
+                if (FULL) {                                     // register pairs: packed add / fma
+                    f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2 v = {z[r], z[r + 1]};
+                        p1 += v;
+                        p2 += v * v;
+                    }
+                    s1 += p1[0] + p1[1];
+                    s2 += p2[0] + p2[1];
+                    continue;
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int gd = bd + ((r >> 2) & 1), gh = bh + ((r >> 1) & 1), gw = bwid + 2 * ((r >> 3) & 1) + (r & 1);
-                    if (FULL || (gd < a.D && gh < a.H && gw < a.W)) { s1 += z[r]; s2 += z[r] * z[r]; }
+                    if (gd < a.D && gh < a.H && gw < a.W) { s1 += z[r]; s2 += z[r] * z[r]; }
                 }
                 continue;
             }
@@ -221,28 +261,39 @@ __global__ __launch_bounds__(256) void conv1_fused_kernel(Args a) {
                 K1 = -sc * c1 * is;
                 K0 = sc * (c1 * mu * is - c0);
             }
+            // pooled window of this lane: (od, ohb + hsel, owb + q); the sample's pooled tensor is one buffer resource
+            const int od = (d0 >> 1) + (mt >> 2), ohb = (h0 >> 1) + 2 * ((mt >> 1) & 1), owb = (w0 >> 1) + 2 * (mt & 1);
+            void* pbase = MODE == MODE_FWD ? a.pooled : const_cast<void*>(a.dpool);
+            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<char*>(pbase) + (size_t)b * OD * OH * OW * a.C * PSZ, 0, OD * OH * OW * a.C * PSZ, 0x00020000);
+            const int pv = (FULL || ohb + hsel < OH) ? pl_lane : OOB;      // this lane's voffset (out of range = no window)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int od = bd >> 1, oh = bh >> 1, ow = (bwid >> 1) + q;
-                const bool pooled = FULL ? cv : (od < OD && oh < OH && ow < OW && cv);
+                const int ow = owb + q;
+                const bool win_u = FULL || (od < OD && ow < OW);           // wave-uniform part of "the window exists"
+                const int psoff = ((od * OH + ohb) * OW + ow) * a.C * PSZ;
                 float y[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) y[k] = z[8 * q + k] * sc + sh;
+                for (int k = 0; k < 8; k += 2) {                // v_pk_fma_f32 on register pairs
+                    const f32x2 zz = {z[8 * q + k], z[8 * q + k + 1]};
+                    const f32x2 yy = zz * f32x2{sc, sc} + f32x2{sh, sh};
+                    y[k] = yy[0];
+                    y[k + 1] = yy[1];
+                }
                 const float ymax = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
                 const float lrm = ymax > 0.f ? 1.f : a.slope;
-                const size_t pidx = ((((size_t)b * OD + od) * OH + oh) * OW + ow) * a.C + co;
                 if (MODE == MODE_FWD) {
                     const float best = ymax * lrm;
-                    if (pooled) {
-                        if (P16) reinterpret_cast<tmf_bf16_t*>(a.pooled)[pidx] = (tmf_bf16_t)(tmf_pack_bf16(best, 0.f) & 0xFFFFu);
-                        else reinterpret_cast<float*>(a.pooled)[pidx] = best;
+                    if (win_u) {
+                        if (P16) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tmf_pack_bf16(best, 0.f) & 0xFFFFu), pr, pv, psoff, 0);
+                        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, best), pr, pv, psoff, 0);
                     }
                     continue;
                 }
-                float g = 0.f;
-                if (pooled)
-                    g = P16 ? __builtin_bit_cast(float, (unsigned int)reinterpret_cast<const tmf_bf16_t*>(a.dpool)[pidx] << 16)
-                            : reinterpret_cast<const float*>(a.dpool)[pidx];
+                float g = 0.f;                                             // lanes without a window read zeros
+                if (win_u)
+                    g = P16 ? __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_raw_buffer_load_b16(pr, pv, psoff, 0) << 16)
+                            : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, pv, psoff, 0));
                 const float gl = g * lrm;                       // dLoss/dy at the routed element
                 if (MODE == MODE_REDUCE) {
                     float zs = z[8 * q + 7];                    // z of the first maximum (a pooled window is all-valid)
@@ -350,6 +401,7 @@ static int slab_blocks() {
 int check(const char* fn, int B, int D, int H, int W, int C) {
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && C > 0, TMF_E_SHAPE, "%s: non-positive dimension", fn);
     TMF_REQUIRE((long)D * H * W * C < (1L << 31), TMF_E_SHAPE, "%s: one sample exceeds 2^31 elements", fn);
+    TMF_REQUIRE((long)(D > 6 ? D : 6) * H * W < (1L << 29), TMF_E_SHAPE, "%s: the input volume exceeds 2^29 voxels", fn);
     return TMF_OK;
 }
 
