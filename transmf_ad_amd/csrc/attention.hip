@@ -74,7 +74,7 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* src, int str
 }
 
 template <int DH>
-__global__ __launch_bounds__(256) void xattn_fwd_kernel(
+__global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_fwd_kernel(   // <= 256 registers: MFMA results stay in VGPRs
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     float* __restrict__ out, float* __restrict__ lse, int heads, int N, int M, int q_stride, int kv_stride,
     float scale, int sb) {
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void xattn_fwd_kernel(
 
 // dQ: same geometry as the forward (K, V resident in LDS; a wave owns 32 queries).
 template <int DH>
-__global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(
+__global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_bwd_dq_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ dout,
     float* __restrict__ dq, int heads, int N, int M, int q_stride, int kv_stride, float scale, int sb) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void xattn_bwd_dq_kernel(
 
 // dK, dV: a wave owns 32 keys; Q and dO (all queries) are resident in LDS with lse / delta.
 template <int DH>
-__global__ __launch_bounds__(256) void xattn_bwd_dkv_kernel(
+__global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_bwd_dkv_kernel(
     const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
     const float* __restrict__ out, const float* __restrict__ lse, const float* __restrict__ dout,
     float* __restrict__ dk, float* __restrict__ dv, int heads, int N, int M, int q_stride, int kv_stride,

@@ -47,7 +47,7 @@ __device__ __forceinline__ float half_sum(float v) {         // sum over the 32 
 enum { EPI_PLAIN = 0, EPI_GELU = 1, EPI_GELU_GRAD = 2, EPI_LN_BWD = 3 };
 
 template <bool NN, bool LN, int EPI>
-__global__ __launch_bounds__(TTHR) void tok_gemm_kernel(const TokArgs p) {
+__global__ __launch_bounds__(TTHR, 2) void tok_gemm_kernel(const TokArgs p) {   // <= 256 registers: MFMA results stay in VGPRs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int KP = p.K + 4;
     float* As = smem;                              // [16][K + 4]
@@ -310,7 +310,7 @@ struct WgMulti {
     int nprob;
 };
 
-__global__ __launch_bounds__(256) void tok_wgrad_multi_kernel(const WgMulti p, float* __restrict__ partial, long total_elems) {
+__global__ __launch_bounds__(256, 2) void tok_wgrad_multi_kernel(const WgMulti p, float* __restrict__ partial, long total_elems) {
     __shared__ float red[3][32 * 32];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
