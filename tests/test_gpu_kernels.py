@@ -112,6 +112,7 @@ BLOCK_CASES = [
     (2, 10, 9, 8, 1, 8, 3, "max"),        # first layer (fused recompute path: conv output never stored)
     (1, 13, 17, 11, 1, 32, 3, "max"),     # first layer, every brick ragged, odd pooling edges
     (2, 8, 16, 24, 1, 40, 3, "max"),      # first layer, two channel tiles
+    (1, 12, 24, 24, 1, 32, 3, "max"),     # first layer with an interior brick (mask-free buffer loads) next to face bricks
     (1, 6, 6, 6, 1, 8, 3, None),          # first layer without pool -> generic (stored-z) path
     (1, 5, 4, 3, 6, 10, 3, "max"),        # scalar channel path
     (2, 16, 16, 16, 32, 64, 3, "max"),
