@@ -113,7 +113,7 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
         //      before its LDS writes; two batches keep the kernel under 128 registers (two workgroups per CU) ----
         auto stage_halo = [&](const int q0, const int q1) {
             f32x4 hreg[IN16 ? 1 : HB];
-            u32x2 hreg16[IN16 ? HB : 1];
+            u32x2 hreg16[IN16 ? HV : 1];
 #pragma unroll
             for (int q = q0; q < q1; ++q) {
                 const int c = c0 + ((tid + q * NTHR) & 7) * 4;
@@ -144,8 +144,13 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
         };
         // ---- weight stage loader: [tap][co][ci] bf16, one 16-B piece = 8 input channels of one output channel ----
         constexpr int WV = (TPS * NB * 4 + NTHR - 1) / NTHR;         // 4 pieces per (tap, co) row of 32 channels
-        u32x4 wreg[WV];
-        auto load_w = [&](int st) {
+        // A stage is only 6 NT MFMAs (~200 NT cycles): with the next stage's weights requested one stage ahead, every
+        // stage waited a full L2 round trip (9 per chunk: the kernel ran at 5 % matrix utilisation per wave).  The
+        // loads now run PW stages ahead in registers (in-flight global loads survive the barriers: __syncthreads only
+        // waits for LDS traffic), and the stage loop is unrolled so the register slots are static.
+        constexpr int PW = NT == 1 ? 6 : 3;
+        u32x4 wreg[PW][WV];
+        auto load_w = [&](int st, int slot) {
 #pragma unroll
             for (int q = 0; q < WV; ++q) {
                 const int e = tid + q * NTHR;
@@ -154,25 +159,34 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
                 u32x4 v = {0u, 0u, 0u, 0u};
                 if (e < TPS * NB * 4 && co < Cout && ci < Cin)
                     v = *reinterpret_cast<const u32x4*>(w + ((size_t)tap * Cout + co) * Cin + ci);
-                wreg[q] = v;
+                wreg[slot][q] = v;
             }
         };
-        auto store_w = [&](int buf) {
+        auto store_w = [&](int buf, int slot) {
 #pragma unroll
             for (int q = 0; q < WV; ++q) {
                 const int e = tid + q * NTHR;
                 if (e < TPS * NB * 4)
-                    *reinterpret_cast<u32x4*>(Ws + buf * WSTAGE + (e >> 2) * RP + (e & 3) * 8) = wreg[q];
+                    *reinterpret_cast<u32x4*>(Ws + buf * WSTAGE + (e >> 2) * RP + (e & 3) * 8) = wreg[slot][q];
             }
         };
-        load_w(0);
-        stage_halo(0, HB);
-        stage_halo(HB, HV);
+        load_w(0, 0);
+        if constexpr (IN16) {                     // bf16 tensors: the whole halo is 20 registers, one latency instead of two
+#pragma unroll
+            for (int st = 1; st < PW; ++st) load_w(st, st);
+            stage_halo(0, HV);
+        } else {
+            stage_halo(0, HB);
+#pragma unroll
+            for (int st = 1; st < PW; ++st) load_w(st, st);
+            stage_halo(HB, HV);
+        }
+#pragma unroll
         for (int st = 0; st < NSTAGES; ++st) {
             const int buf = st & 1;
-            store_w(buf);
+            store_w(buf, st % PW);
             __syncthreads();
-            if (st + 1 < NSTAGES) load_w(st + 1);
+            if (st + PW < NSTAGES) load_w(st + PW, st % PW);
             const int stage_off = ((st / 3) * HH + (st % 3)) * HW * RP;
             const u16* ws = Ws + buf * WSTAGE + b_lane;
 #pragma unroll
