@@ -250,9 +250,15 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
         // accumulates from zero and is then added to the running sum.  The fp32 MFMA is a strict k-ordered fma chain,
         // and one 864..3456-term chain would carry ~sqrt(K) ulp of drift; short chains + 3..9 adds per channel chunk keep
         // it 2-5x smaller.  The adds are vector-ALU work = matrix time: plane-long chains cut them to a
-        // third.  The one-N-tile kernels on 4x8x8 bricks keep per-stage partials and a loop the compiler unrolls
-        // completely (grouped, they lose 3-7 %; everything else gains 2-7 %).
-        constexpr int ACC = (C::KS == 1 || (C::NT == 1 && C::TPS == 3) || !TMF_CONV_ACC) ? 1 : 9 / C::TPS;      // stages per partial sum
+        // third.  The one-N-tile kernels on 4x8x8 bricks keep per-stage partials: with plane-long sums (both loops
+        // unrolled, TMF_CONV_ACC1=1) they gain 2 %, but the error of the 512-d feature vector against the fp64 reference
+        // doubles (4e-6 -> 8e-6), and the ill-conditioned batch-2 head of the ad_full_b2 fixture amplifies that to
+        // 1.02e-3 on one logit — over the 1e-3 gate.  Parity wins.
+#ifndef TMF_CONV_ACC1
+#define TMF_CONV_ACC1 0
+#endif
+        constexpr bool UNROLL_ALL = C::NT == 1 && C::TPS == 3 && C::KS == 3;     // small stage body: 9 stages unrolled
+        constexpr int ACC = (C::KS == 1 || (UNROLL_ALL && !(TMF_CONV_ACC1 && VEC)) || !TMF_CONV_ACC) ? 1 : 9 / C::TPS;      // stages per partial sum
         static_assert(C::NSTAGES % ACC == 0, "partial sums cover whole kd planes");
         auto mma = [&](int st, int buf, f32x16 (&part)[C::MT][C::NT]) {       // this wave's MFMAs of stage st
             int stage_off;                                                     // halo offset of the stage's first tap
@@ -309,6 +315,29 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
 #pragma unroll
                         for (int j = 0; j < C::NT; ++j) acc[i][j] += part[i][j];
                 }
+            }
+        } else if constexpr (UNROLL_ALL) {
+#pragma unroll
+            for (int sg = 0; sg < C::NSTAGES / ACC; ++sg) {
+                f32x16 part[C::MT][C::NT];
+#pragma unroll
+                for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+#pragma unroll
+                for (int ss = 0; ss < ACC; ++ss) {
+                    const int st = sg * ACC + ss, buf = st & 1;
+                    store_b(buf);
+                    __syncthreads();
+                    if (st + 1 < C::NSTAGES) load_b(st + 1);
+                    if (wave_active && !(dbg & 2)) mma(st, buf, part);
+                }
+#pragma unroll
+                for (int i = 0; i < C::MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::NT; ++j) acc[i][j] += part[i][j];
             }
         } else {
 #pragma unroll 1
