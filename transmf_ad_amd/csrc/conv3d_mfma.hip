@@ -177,9 +177,18 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
     const __amdgpu_buffer_rsrc_t wr =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, C::NTAPS * Cin * Cout * 4, 0x00020000);
 
-    for (int c0 = 0; c0 < Cin; c0 += C::CINC) {
-        if (c0 > 0) __syncthreads();   // everyone is done with the previous halo and weight ring
-        f32x4 hreg[HV];
+#ifndef TMF_CONV_PIPE
+#define TMF_CONV_PIPE 1
+#endif
+    // PIPE: the NEXT chunk's halo and first weight stage are requested during the last stage of the current chunk (the
+    // registers of both prefetches are free there).  Measured: -1.1 % on the one-tile kernels with 4 chunks (conv2.3
+    // data gradient), nothing with 2 chunks, +3-4 % (slower) on the 4x4x4-brick kernels, and the two-tile kernels
+    // spill under their 128-register bound — so the exposed global-load latency per chunk is not what the remaining
+    // ~7 % of waits are made of.  Enabled where it measured faster.
+    constexpr bool PIPE = BUF && TMF_CONV_PIPE && C::NT == 1 && C::TPS == 3;
+    f32x4 hreg[HV];
+    f32x4 breg[C::BV];
+    auto load_halo = [&](int c0) {
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
             const int c = c0 + ((tid + q * C::NTHR) % C4) * 4;
@@ -201,35 +210,46 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                 hreg[q] = v;
             }
         }
-
-        f32x4 breg[C::BV];
-        auto load_b = [&](int st) {
-            if constexpr (BUF) {
-                const int sbase = ((st * C::TPS * Cin + c0) * Cout) * 4;              // wave-uniform
+    };
+    auto load_b = [&](int st, int c0) {
+        if constexpr (BUF) {
+            const int sbase = ((st * C::TPS * Cin + c0) * Cout) * 4;              // wave-uniform
 #pragma unroll
-                for (int q = 0; q < C::BV; ++q) {
-                    const int off = (ragged && c0 + bci[q] >= Cin) ? OOB : boff[q];
-                    breg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, sbase, 0));
-                }
-            } else {
-                const float* wst = w + (size_t)(st * C::TPS * Cin + c0) * Cout;       // wave-uniform
-#pragma unroll
-                for (int q = 0; q < C::BV; ++q) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (boff[q] >= 0 && c0 + bci[q] < Cin) {
-                        const float* src = wst + boff[q];
-                        if (VEC) {
-                            v = *reinterpret_cast<const f32x4*>(src);
-                        } else {
-                            const int co = n0 + ((tid + q * C::NTHR) % (C::NB / 4)) * 4;
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if (co + u < Cout) v[u] = src[u];
-                        }
-                    }
-                    breg[q] = v;
-                }
+            for (int q = 0; q < C::BV; ++q) {
+                const int off = (ragged && c0 + bci[q] >= Cin) ? OOB : boff[q];
+                breg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wr, off, sbase, 0));
             }
+        } else {
+            const float* wst = w + (size_t)(st * C::TPS * Cin + c0) * Cout;       // wave-uniform
+#pragma unroll
+            for (int q = 0; q < C::BV; ++q) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (boff[q] >= 0 && c0 + bci[q] < Cin) {
+                    const float* src = wst + boff[q];
+                    if (VEC) {
+                        v = *reinterpret_cast<const f32x4*>(src);
+                    } else {
+                        const int co = n0 + ((tid + q * C::NTHR) % (C::NB / 4)) * 4;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (co + u < Cout) v[u] = src[u];
+                    }
+                }
+                breg[q] = v;
+            }
+        }
+    };
+
+    for (int c0 = 0; c0 < Cin; c0 += C::CINC) {
+        if (c0 > 0) __syncthreads();   // everyone is done with the previous halo and weight ring
+        if (!PIPE || c0 == 0) {
+            load_halo(c0);
+            load_b(0, c0);
+        }
+        // loads issued after stage st has started: the next stage's weights, or (last stage) the next chunk's first loads
+        auto next_loads = [&](int st) {
+            if (st + 1 < C::NSTAGES) load_b(st + 1, c0);
+            else if (PIPE && c0 + C::CINC < Cin) { load_halo(c0 + C::CINC); load_b(0, c0 + C::CINC); }
         };
         auto store_b = [&](int buf) {
 #pragma unroll
@@ -240,7 +260,6 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
             }
         };
 
-        load_b(0);
 #pragma unroll
         for (int q = 0; q < HV; ++q) {
             const int e = tid + q * C::NTHR;
@@ -300,7 +319,7 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                 const int buf = st & 1;
                 store_b(buf);
                 __syncthreads();
-                if (st + 1 < C::NSTAGES) load_b(st + 1);   // in flight while this stage computes
+                next_loads(st);                            // in flight while this stage computes
                 if (wave_active && !(dbg & 2)) {
                     f32x16 part[C::MT][C::NT];
 #pragma unroll
@@ -331,7 +350,7 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                     const int st = sg * ACC + ss, buf = st & 1;
                     store_b(buf);
                     __syncthreads();
-                    if (st + 1 < C::NSTAGES) load_b(st + 1);
+                    next_loads(st);
                     if (wave_active && !(dbg & 2)) mma(st, buf, part);
                 }
 #pragma unroll
@@ -355,7 +374,7 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
                     const int buf = st & 1;
                     store_b(buf);
                     __syncthreads();
-                    if (st + 1 < C::NSTAGES) load_b(st + 1);
+                    next_loads(st);
                     if (wave_active && !(dbg & 2)) mma(st, buf, part);
                 };
                 one(sg * ACC);
