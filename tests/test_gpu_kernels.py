@@ -700,3 +700,115 @@ def test_layout_conversion_round_trip():
     z = torch.empty_like(x)
     lib.call("tmf_layout_ndhwc_to_ncdhw", y.data_ptr(), z.data_ptr(), 2, 5, 7 * 9 * 11, 0)
     assert torch.equal(z, x)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# memory-safety properties of the buffer-addressed kernels: results must not depend on what lies around the
+# inputs (reads stay in bounds / masked lanes read nothing), and nothing outside the outputs may be written
+# ---------------------------------------------------------------------------------------------------------
+def _guarded(t, fill, pad=4096):
+    big = torch.full((t.numel() + 2 * pad,), fill, device=t.device, dtype=t.dtype)
+    v = big[pad:pad + t.numel()].view(t.shape)
+    v.copy_(t)
+    return v, big
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 24, 24, 32, 64), (1, 11, 13, 9, 64, 64), (2, 12, 12, 12, 128, 256)])
+def test_conv_kernels_ignore_memory_around_their_inputs(shape):
+    ops = _ops()
+    B, D, H, W, cin, cout = shape
+    torch.manual_seed(0)
+    x0 = torch.randn((B, D, H, W, cin), device=DEV)
+    dz0 = torch.randn((B, D, H, W, cout), device=DEV) * 0.1
+    w = torch.randn((cout, cin, 3, 3, 3), device=DEV) * 0.05
+    wp, wb = ops.pack_weight(w), ops.pack_weight_bf16(w)
+    res = []
+    for fill in (0.0, float("nan"), 3e30):
+        xg, k1 = _guarded(x0, fill)
+        dg, k2 = _guarded(dz0, fill)
+        wg, k3 = _guarded(wp, fill)
+        x16, k4 = _guarded(x0.bfloat16(), fill)
+        d16, k5 = _guarded(dz0.bfloat16(), fill)
+        z, part, _ = ops.conv3d_raw(xg, wg, cin, cout, 3, True)
+        dw = ops.conv3d_wgrad(xg, dg, cin, cout, 3)
+        zb, pb, _ = ops.conv3d_bf16_raw(x16, wb, cin, cout, True, out_bf16=True)
+        dwb = ops.conv3d_wgrad_bf16(x16, d16, cin, cout)
+        torch.cuda.synchronize()
+        res.append([t.float().clone() for t in (z, part, dw, zb, pb, dwb)])
+    for other in res[1:]:
+        for a, b in zip(res[0], other):
+            assert torch.isfinite(b).all()
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 24, 24, 64, 64, 3), (1, 11, 13, 9, 64, 32, 3), (1, 6, 6, 6, 256, 128, 0)])
+def test_bf16_conv_writes_only_its_output(shape):
+    ops = _ops()
+    from transmf_ad_amd import _lib
+    B, D, H, W, cin, cout, io = shape
+    x = torch.randn((B, D, H, W, cin), device=DEV)
+    if io & 1:
+        x = x.bfloat16()
+    w = ops.pack_weight_bf16(torch.randn((cout, cin, 3, 3, 3), device=DEV) * 0.05)
+    n, pad, sent = B * D * H * W * cout, 1 << 14, 12345.0
+    big = torch.full((n + 2 * pad,), sent, device=DEV, dtype=torch.bfloat16 if io & 2 else torch.float32)
+    nblk = _lib.query("tmf_conv3d_bf16_stat_blocks", B, D, H, W)
+    pbig = torch.full((nblk * 2 * cout + 2 * pad,), sent, device=DEV)
+    _lib.call("tmf_conv3d_fwd_bf16_t", x.data_ptr(), w.data_ptr(), big[pad:].data_ptr(), pbig[pad:].data_ptr(),
+              B, D, H, W, cin, cout, io, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert (big[:pad] == sent).all() and (big[pad + n:] == sent).all()
+    assert (pbig[:pad] == sent).all() and (pbig[pad + nblk * 2 * cout:] == sent).all()
+    assert int((big[pad:pad + n] == sent).sum()) == 0          # every output element was written
+
+
+def test_first_block_ignores_memory_around_its_inputs():
+    ops = _ops()
+    import transmf_ad_amd as T
+    for prec, out16 in (("fp32", False), ("bf16", True)):
+        T.set_conv_precision(prec)
+        T.set_activation_storage("bf16" if out16 else "fp32")
+        try:
+            torch.manual_seed(0)
+            B, S, C = 2, 24, 32
+            x = torch.rand((B, S, S, S, 1), device=DEV)
+            P = [(torch.randn((C, 1, 3, 3, 3), device=DEV) * 0.2).requires_grad_(True), torch.zeros(C, device=DEV, requires_grad=True),
+                 torch.ones(C, device=DEV, requires_grad=True), torch.zeros(C, device=DEV, requires_grad=True)]
+            dout = torch.randn((B, S // 2, S // 2, S // 2, C), device=DEV) * 0.1
+            if out16:
+                dout = dout.bfloat16()
+            res = []
+            for fill in (0.0, float("nan"), 1e30):
+                xg, k1 = _guarded(x, fill)
+                dg, k2 = _guarded(dout, fill)
+                for p in P:
+                    p.grad = None
+                y = ops.conv_bn_act_pool(xg, *P, torch.zeros(C, device=DEV), torch.ones(C, device=DEV), True, pool="max", out_bf16=out16)
+                y.backward(dg)
+                torch.cuda.synchronize()
+                res.append([y.detach().float().clone()] + [p.grad.clone() for p in (P[0], P[2], P[3])])
+            for other in res[1:]:
+                for a, b in zip(res[0], other):
+                    assert torch.isfinite(b).all() and torch.equal(a, b)
+        finally:
+            T.set_conv_precision("fp32")
+            T.set_activation_storage("fp32")
+
+
+def test_conv_kernels_are_deterministic_on_two_concurrent_streams():
+    ops = _ops()
+    torch.manual_seed(0)
+    cin, cout, s = 32, 64, 24
+    xa, xb = (torch.randn((4, s, s, s, cin), device=DEV) for _ in range(2))
+    wa, wb = (ops.pack_weight(torch.randn((cout, cin, 3, 3, 3), device=DEV) * 0.05) for _ in range(2))
+    za0, pa0, _ = ops.conv3d_raw(xa, wa, cin, cout, 3, True)
+    zb0, pb0, _ = ops.conv3d_raw(xb, wb, cin, cout, 3, True)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(5):
+        with torch.cuda.stream(s1):
+            za, pa, _n = ops.conv3d_raw(xa, wa, cin, cout, 3, True)
+        with torch.cuda.stream(s2):
+            zb, pb, _n = ops.conv3d_raw(xb, wb, cin, cout, 3, True)
+        torch.cuda.synchronize()
+        assert torch.equal(za, za0) and torch.equal(zb, zb0) and torch.equal(pa, pa0) and torch.equal(pb, pb0)
