@@ -507,3 +507,43 @@ def test_input_gradients_match_oracle():
     assert (lo.double().cpu() - lo2).abs().max().item() < 1e-5
     for got, ref in ((m.grad, m2.grad), (p.grad, p2.grad)):
         assert ((got.double().cpu() - ref).abs().max() / ref.abs().max()).item() < 1e-4
+
+
+@pytest.mark.parametrize("mode", [("fp32", "fp32"), ("bf16", "bf16")])
+def test_train_step_is_bit_reproducible_with_two_streams(mode):
+    """Same weights, same batch, same dropout seed: every gradient of the full-size model is bit-identical from one
+    fwd+bwd to the next, with the two encoders on their two streams (no atomics, fixed reduction orders, and no
+    cross-stream reuse of a buffer that is still being read)."""
+    import transmf_ad_amd as T
+    from torch import nn
+    prec, store = mode
+    T.set_conv_precision(prec)
+    T.set_activation_storage(store)
+    try:
+        torch.manual_seed(0)
+        net = T.model_ad(128, 3, 4, 32, 512, 0.).to("cuda:0")
+        B, S = 8, 96
+        g = torch.Generator(device="cuda:0").manual_seed(1)
+        mri = torch.rand((B, 1, S, S, S), device="cuda:0", generator=g)
+        pet = torch.rand((B, 1, S, S, S), device="cuda:0", generator=g)
+        y = (torch.arange(B, device="cuda:0") % 2).long()
+        ce = nn.CrossEntropyLoss()
+        ref = None
+        for it in range(6):
+            torch.manual_seed(123)
+            net.train()
+            net.zero_grad(set_to_none=True)
+            lo, dm, dp = net(mri, pet)
+            loss = (ce(dm, torch.ones_like(y)) + ce(dp, torch.zeros_like(y))) / 2 + ce(lo, y)
+            loss.backward()
+            torch.cuda.synchronize()
+            cur = {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+            cur["loss"] = loss.detach().clone()
+            if ref is None:
+                ref = cur
+                continue
+            bad = [n for n in ref if not torch.equal(cur[n], ref[n])]
+            assert not bad, (it, bad[:8])
+    finally:
+        T.set_conv_precision("fp32")
+        T.set_activation_storage("fp32")
