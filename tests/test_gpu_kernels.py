@@ -812,3 +812,26 @@ def test_conv_kernels_are_deterministic_on_two_concurrent_streams():
             zb, pb, _n = ops.conv3d_raw(xb, wb, cin, cout, 3, True)
         torch.cuda.synchronize()
         assert torch.equal(za, za0) and torch.equal(zb, zb0) and torch.equal(pa, pa0) and torch.equal(pb, pb0)
+
+
+@pytest.mark.parametrize("shape", [(4, 24, 32, 64), (2, 13, 64, 64), (4, 12, 128, 256)])
+def test_weight_gradients_write_only_output_and_workspace(shape):
+    from transmf_ad_amd import _lib
+    B, s, cin, cout = shape
+    sent, pad = 777.0, 1 << 14
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.randn((B, s, s, s, cin), device=DEV)
+    dz = torch.randn((B, s, s, s, cout), device=DEV) * 0.1
+    for entry, query, xs, dzs, extra in (
+            ("tmf_conv3d_wgrad", "tmf_conv3d_wgrad_workspace_bytes", x, dz, (3,)),
+            ("tmf_conv3d_wgrad_bf16_t", "tmf_conv3d_wgrad_bf16_workspace_bytes", x.bfloat16(), dz.bfloat16(), (1,))):
+        nbytes = _lib.query(query, B, s, s, s, cin, cout, *(extra if entry == "tmf_conv3d_wgrad" else ()))
+        nws, ndw = max(nbytes, 16) // 4, 27 * cin * cout
+        wbig = torch.full((nws + 2 * pad,), sent, device=DEV)
+        dbig = torch.full((ndw + 2 * pad,), sent, device=DEV)
+        _lib.call(entry, xs.data_ptr(), dzs.data_ptr(), dbig[pad:].data_ptr(), wbig[pad:].data_ptr(), nbytes,
+                  B, s, s, s, cin, cout, *extra, st)
+        torch.cuda.synchronize()
+        assert (wbig[:pad] == sent).all() and (wbig[pad + nws:] == sent).all(), entry
+        assert (dbig[:pad] == sent).all() and (dbig[pad + ndw:] == sent).all(), entry
+        assert int((dbig[pad:pad + ndw] == sent).sum()) == 0, entry
