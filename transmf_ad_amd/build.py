@@ -9,7 +9,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtmf_hip.so")
 SOURCES = ["conv3d_mfma.hip", "conv3d_bf16.hip", "conv1_fused.hip", "bn_act_pool.hip", "attention.hip", "token_ops.hip", "token_gemm.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast",
+# -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 work into v_pk_*_f32 and then patches one half of the pair
+# with a single-pass instruction (v_pk_mul_f32 v[6:7] ...; v_mov_b32 v6, v5; v_pk_add_f32 ..., v[6:7]).  On gfx950 that
+# sequence intermittently delivered the stale half in lanes 16-31 when the instructions issued back to back (the
+# first-block reduce pass at the tail of its grid: DESIGN.md 3.6) — found as a loss of run-to-run bit reproducibility.
+# Without the pass none of these sequences are left in the conv / BatchNorm / attention kernels (tools/pk_waw_scan.py).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 
 

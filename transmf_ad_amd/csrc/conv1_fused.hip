@@ -232,22 +232,10 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
             const int bd = d0 + 2 * (mt >> 2), bh = h0 + 4 * ((mt >> 1) & 1) + 2 * hsel, bwid = w0 + 4 * (mt & 1);
 
             if (MODE == MODE_STATS) {
-                if (FULL) {                                     // register pairs: packed add / fma
-                    f32x2 p1 = {0.f, 0.f}, p2 = {0.f, 0.f};
-#pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const f32x2 v = {z[r], z[r + 1]};
-                        p1 += v;
-                        p2 += v * v;
-                    }
-                    s1 += p1[0] + p1[1];
-                    s2 += p2[0] + p2[1];
-                    continue;
-                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int gd = bd + ((r >> 2) & 1), gh = bh + ((r >> 1) & 1), gw = bwid + 2 * ((r >> 3) & 1) + (r & 1);
-                    if (gd < a.D && gh < a.H && gw < a.W) { s1 += z[r]; s2 += z[r] * z[r]; }
+                    if (FULL || (gd < a.D && gh < a.H && gw < a.W)) { s1 += z[r]; s2 += z[r] * z[r]; }
                 }
                 continue;
             }
@@ -274,12 +262,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
                 const int psoff = ((od * OH + ohb) * OW + ow) * a.C * PSZ;
                 float y[8];
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) {                // v_pk_fma_f32 on register pairs
-                    const f32x2 zz = {z[8 * q + k], z[8 * q + k + 1]};
-                    const f32x2 yy = zz * f32x2{sc, sc} + f32x2{sh, sh};
-                    y[k] = yy[0];
-                    y[k + 1] = yy[1];
-                }
+                for (int k = 0; k < 8; ++k) y[k] = z[8 * q + k] * sc + sh;
                 const float ymax = fmaxf(fmaxf(fmaxf(y[0], y[1]), fmaxf(y[2], y[3])), fmaxf(fmaxf(y[4], y[5]), fmaxf(y[6], y[7])));
                 const float lrm = ymax > 0.f ? 1.f : a.slope;
                 if (MODE == MODE_FWD) {

@@ -757,14 +757,11 @@ extern "C" int tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z,
     const int ntiles = B * tD * tH * tW;
     int rc;
     hipStream_t s = (hipStream_t)stream;
-    // TMF_BF_NT2=1: 64 output channels per workgroup where Cout allows it — half the workgroups (the per-workgroup
-    // overhead — offsets, LDS writes, 9 barriers per chunk, epilogue — is 40 % of this kernel), half the halo loads, one
-    // A fragment per two MFMAs; both variants stay under 128 registers / 80 KB, two workgroups per CU.  Measured -20 %
-    // per launch (conv2.3 at 64^3, bf16 tensors: 0.395 -> 0.317 ms) and 744 instead of 725 pairs/s at 128^3.  NOT the
-    // default: with it the two-stream training step is no longer bit-reproducible run to run (first-block gradients
-    // of one encoder move by ~1e-3) although the kernel itself is deterministic under two concurrent streams and
-    // passes the read- and write-guard tests; the interaction is not understood yet.
-    static const bool nt2 = [] { const char* e = getenv("TMF_BF_NT2"); return e != nullptr && atoi(e) != 0; }();
+    // 64 output channels per workgroup where Cout allows it (TMF_BF_NT2=0 selects the 32-channel kernel everywhere): half
+    // the workgroups (the per-workgroup overhead — offsets, LDS writes, 9 barriers per chunk, epilogue — is 40 % of this
+    // kernel), half the halo loads, one A fragment per two MFMAs; both variants stay under 128 registers / 80 KB, two
+    // workgroups per CU.  -20 % per launch (conv2.3 at 64^3, bf16 tensors: 0.395 -> 0.317 ms).
+    static const bool nt2 = [] { const char* e = getenv("TMF_BF_NT2"); return e == nullptr || atoi(e) != 0; }();
     const bool two = nt2 && cout % 64 == 0;
 #define TMF_BF_LAUNCH(I16, O16)                                                                                      \
     if (two) {                                                                                                       \
