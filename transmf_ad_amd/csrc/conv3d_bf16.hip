@@ -183,7 +183,8 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
             for (int st = 1; st < PW; ++st) load_w(st, st);
             stage_halo(HB, HV);
         }
-#pragma unroll(NT == 1 ? NSTAGES : 1)
+        constexpr int UNR = NT == 1 ? NSTAGES : 1;        // static register slots need the unrolled form
+#pragma unroll UNR
         for (int st = 0; st < NSTAGES; ++st) {
             const int buf = st & 1;
             store_w(buf, st % PW);
