@@ -58,15 +58,50 @@ def _is_bn_key(name: str, spec) -> bool:
     return (prefix + ".running_mean") in spec
 
 
-def make_inputs(batch: int, size, seed: int = 1234):
+def make_inputs(batch: int, size, seed: int = 1234, kind: str = "uniform"):
     """MRI first, then PET, from one stream, uniform [0,1) (the range ScaleIntensityd
-    produces, datasets/ADNI.py:64); labels arange(B) % 2."""
+    produces, datasets/ADNI.py:64); labels arange(B) % 2.  kind="blobs": structured volumes
+    (make_inputs_blobs) whose pooled features differ from sample to sample."""
+    if kind == "blobs":
+        return make_inputs_blobs(batch, size, seed)
+    if kind != "uniform":
+        raise ValueError(kind)
     rs = np.random.RandomState(seed)
     shape = (batch, 1) + tuple(size)
     mri = rs.rand(*shape).astype(np.float32)
     pet = rs.rand(*shape).astype(np.float32)
     y = (np.arange(batch) % 2).astype(np.int64)
     return mri, pet, y
+
+
+def make_inputs_blobs(batch: int, size, seed: int = 1234):
+    """Structured volumes: per sample a noise floor + a linear ramp + four Gaussian blobs with sample-specific
+    centres / widths / amplitudes, min-max scaled to [0, 1] per volume (what ScaleIntensityd does,
+    datasets/ADNI.py:64).  Unlike uniform noise the pooled features of two samples differ by O(0.1), so the
+    train-mode BatchNorm1d layers of the heads (batch of 2!) are well conditioned.  MRI volumes first, then PET."""
+    rs = np.random.RandomState(seed)
+    D, H, W = size
+    zz = np.linspace(-1.0, 1.0, D, dtype=np.float32)[:, None, None]
+    yy = np.linspace(-1.0, 1.0, H, dtype=np.float32)[None, :, None]
+    xx = np.linspace(-1.0, 1.0, W, dtype=np.float32)[None, None, :]
+    vols = []
+    for _modality in range(2):
+        out = np.empty((batch, 1, D, H, W), np.float32)
+        for b in range(batch):
+            v = (0.15 * rs.rand(D, H, W)).astype(np.float32)
+            g = rs.uniform(-1.0, 1.0, 3).astype(np.float32)
+            v += 0.2 * (g[0] * zz + g[1] * yy + g[2] * xx)
+            for _ in range(4):
+                c = rs.uniform(-0.6, 0.6, 3).astype(np.float32)
+                sig = np.float32(rs.uniform(0.15, 0.45))
+                amp = np.float32(rs.uniform(0.3, 1.0))
+                r2 = (zz - c[0]) ** 2 + (yy - c[1]) ** 2 + (xx - c[2]) ** 2
+                v += amp * np.exp(-r2 / (2.0 * sig * sig)).astype(np.float32)
+            lo, hi = v.min(), v.max()
+            out[b, 0] = (v - lo) / (hi - lo)
+        vols.append(out)
+    y = (np.arange(batch) % 2).astype(np.int64)
+    return vols[0], vols[1], y
 
 
 def make_masks(batch: int, seed: int = 99):

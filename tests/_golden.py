@@ -48,7 +48,8 @@ class Golden:
         return P.init_arrays(self.spec, seed=self.meta["param_seed"])
 
     def inputs(self):
-        return P.make_inputs(self.batch, self.size, seed=self.meta["input_seed"])
+        return P.make_inputs(self.batch, self.size, seed=self.meta["input_seed"],
+                             kind=self.meta.get("input_kind", "uniform"))
 
     def masks(self):
         return P.make_masks(self.batch, seed=self.meta["mask_seed"])

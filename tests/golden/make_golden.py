@@ -39,12 +39,18 @@ CASES = {
     "ad_ragged":  ("model_ad", dict(dim=32, depth=2, heads=4, dim_head=8, mlp_dim=128), (35, 38, 33), 3, True),
     "ad_mid":     ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (48, 48, 48), 2, True),
     "ad_full_b2": ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (96, 96, 96), 2, True),
-    "ad_full_b8": ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (96, 96, 96), 8, False),
+    "ad_full_b8": ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (96, 96, 96), 8, True),
+    # well-conditioned full-size case: structured volumes (oracle/params.make_inputs_blobs)
+    "ad_full_b2_blobs": ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (96, 96, 96), 2, True, "blobs"),
+    # the reference's real ADNI volume shape (datasets/ADNI.py:93): odd pooled sizes 45x54x45 / 22x27x22 / 11x13x11
+    "ad_adni_b2": ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (91, 109, 91), 2, True, "blobs"),
+    # BASELINE configs[2]: 128^3, batch 8 — fp32 reference run that the bf16 modes are gated against
+    "ad_128_b8":  ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (128, 128, 128), 8, False, "blobs"),
     "cnn_tiny":   ("model_CNN_ad", dict(dim=32), (32, 32, 32), 2, True),
     "cnn_mid":    ("model_CNN_ad", dict(dim=128), (48, 40, 48), 2, True),
     "single_mid": ("model_single", dict(dim=128), (48, 48, 48), 3, True),
 }
-DEFAULT = [c for c in CASES if c != "ad_full_b8"]
+DEFAULT = [c for c in CASES if c not in ("ad_full_b8", "ad_128_b8")]
 
 
 def build_reference(model, kw):
@@ -99,14 +105,15 @@ def attach_probes(net, model, store):
 
 
 def run_case(name):
-    model, kw, size, B, do64 = CASES[name]
+    model, kw, size, B, do64 = CASES[name][:5]
+    kind = CASES[name][5] if len(CASES[name]) > 5 else "uniform"
     spec = spec_for(model, kw)
     arrays = P.init_arrays(spec, seed=7)
-    mri, pet, y = P.make_inputs(B, size, seed=1234)
+    mri, pet, y = P.make_inputs(B, size, seed=1234, kind=kind)
     k1, k2 = P.make_masks(B)
     out = {}
     meta = dict(case=name, model=model, kwargs=kw, size=list(size), batch=B, param_seed=7, input_seed=1234,
-                mask_seed=99, torch=torch.__version__,
+                mask_seed=99, input_kind=kind, torch=torch.__version__,
                 keys=[[k, list(s)] for k, (_kind, s) in spec.items()])
 
     for prec, dt in (("f32", torch.float32), ("f64", torch.float64)):

@@ -71,7 +71,17 @@ def step(net, g: Golden, train=True):
     return outs, loss
 
 
-CASES = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid", "ad_full_b2"]
+CASES = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid", "ad_full_b2", "ad_full_b2_blobs",
+         "ad_adni_b2"]
+# Logit tolerance per fixture.  Default: the north-star gate.  The structured-volume fixtures (oracle/params.
+# make_inputs_blobs: per-sample blobs, so the pooled features of the two samples differ by O(0.1) and the train-mode
+# BatchNorm1d heads are well conditioned) are held 5x tighter: they are the full-size B=2 cases the gate really
+# stands on (measured: logits 6.7e-6, loss 2e-6, gradients <= 4.4e-3 of max); `ad_full_b2` (uniform noise, BN1d over
+# two near-identical samples) stays as the stress case.  `ad_adni_b2` (the reference's 91x109x91 volume shape) keeps
+# the default gate: the reference's own fp32 run is 1.5e-4 from its fp64 run there (ours: 1.6e-4 / 3.1e-4).
+LOGIT_TOL = {"ad_full_b2_blobs": 2e-4}
+# gradient-probe tolerance (16 sampled elements, relative to the reference tensor's max-abs) of the golden train step
+GRAD_PROBE_TOL = {"ad_full_b2_blobs": 2e-2}
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -119,10 +129,10 @@ def _golden_train_step(name):
         assert (outs["logits"].detach().double().cpu() - ref_head).abs().max().item() <= GATE
     for k, v in outs.items():
         got = v.detach().double().cpu().numpy()
-        tol = GATE if k == "logits" else TOL
+        tol = LOGIT_TOL.get(name, GATE) if k == "logits" else TOL
         assert np.abs(got - g[f"f32/train/{k}"]).max() <= tol, (k, "vs reference fp32")
         assert np.abs(got - g[f"f64/train/{k}"]).max() <= tol, (k, "vs reference fp64")
-    assert abs(loss.item() - float(g["f64/train/loss"])) <= GATE
+    assert abs(loss.item() - float(g["f64/train/loss"])) <= LOGIT_TOL.get(name, GATE)
     # gradients against the reference's fp64 probes (its own fp32 grads are only good to ~2e-2 of max)
     zk = zero_grad_keys(g.spec, g.model)
     worst = 0.0
@@ -137,7 +147,7 @@ def _golden_train_step(name):
         worst = max(worst, err)
         # loose: these gradients flow back through the same ill-conditioned BatchNorm1d heads (see GATE note);
         # the tight gradient check is test_activations_and_grads_match_oracle
-        assert err <= 5e-2, (k, err)
+        assert err <= GRAD_PROBE_TOL.get(name, 5e-2), (k, err)
     # BatchNorm buffers after one step (running stats, num_batches_tracked incl. D's double update)
     for k, b in net.named_buffers():
         ref = g[f"f32/buf/{k}"]
@@ -273,8 +283,28 @@ def test_state_dict_round_trip_and_nchw_view():
     assert torch.equal(a, b)                                # deterministic kernels: bitwise
 
 
+def _grad_probe_errors(net, g, prec):
+    """Per parameter: max error of the 16 sampled gradient elements relative to the reference tensor's max-abs, and
+    the relative error of the |.|-sum — against the fixture's `prec` ("f64" / "f32") gradient probes."""
+    zk = zero_grad_keys(g.spec, g.model)
+    rows = {}
+    for k, p in net.named_parameters():
+        ref = g[f"{prec}/grad/{k}"]
+        got = gprobe(p.grad if p.grad is not None else torch.zeros_like(p))
+        if k in zk:
+            ref_w = g[f"{prec}/grad/{k[:-4]}weight"][2]
+            rows[k] = ("zero", got[2], ref_w)
+            continue
+        rows[k] = ("val", np.abs(got[3:] - ref[3:]).max() / max(ref[2], 1e-30), abs(got[1] - ref[1]) / max(ref[1], 1e-30))
+    return rows
+
+
 def test_full_size_properties_b8_96():
-    """BASELINE config 2 (B=8, 96^3, fp32): size-independent properties + the B=8 golden if present."""
+    """BASELINE configs[1] (B=8, 96^3, fp32) — the benchmark configuration: outputs, loss AND every parameter gradient
+    (kfold_train_adversarial.py:131-135 is half the metric) against the reference's golden run, plus run-to-run bitwise
+    determinism.  Gradient bounds (16 sampled elements per tensor relative to its max-abs, and the |.|-sum):
+    conv weights / BN 2e-2 — the reference's OWN fp32 run is up to 1.8e-2 from its fp64 run there —
+    transformer and heads 1e-3 ... measured margins in DESIGN.md 4; mathematically-zero gradients are bounded."""
     import transmf_ad_amd as T
     name = "ad_full_b8"
     kw = dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512)
@@ -282,9 +312,21 @@ def test_full_size_properties_b8_96():
         g = Golden(name)
         net = build(g)
         outs, loss = step(net, g, train=True)
-        for k, v in outs.items():
-            assert np.abs(v.detach().double().cpu().numpy() - g[f"f32/train/{k}"]).max() <= 1e-3, k
-        assert abs(loss.item() - float(g["f32/train/loss"])) <= 1e-3
+        for prec in ("f32", "f64"):
+            if not g.has(f"{prec}/train/logits"):
+                continue
+            for k, v in outs.items():
+                assert np.abs(v.detach().double().cpu().numpy() - g[f"{prec}/train/{k}"]).max() <= (GATE if k == "logits" else TOL), (k, prec)
+            assert abs(loss.item() - float(g[f"{prec}/train/loss"])) <= GATE
+        prec = "f64" if g.has("f64/grad/fc_cls.8.weight") else "f32"
+        for k, row in _grad_probe_errors(net, g, prec).items():
+            if row[0] == "zero":
+                assert row[1] <= 1e-3 * max(row[2], 1e-12) + 1e-6, (k, "mathematically-zero gradient", row[1])
+                continue
+            conv_side = "_cnn." in k
+            tol_s, tol_a = (2e-2, 2e-2) if conv_side else (1e-3, 1e-3)
+            assert row[1] <= tol_s, (k, "sampled elements", row[1])
+            assert row[2] <= tol_a, (k, "|.|-sum", row[2])
         first = {k: p.grad.clone() for k, p in net.named_parameters()}
         net2 = build(g)
         outs2, loss2 = step(net2, g, train=True)
@@ -300,6 +342,59 @@ def test_full_size_properties_b8_96():
     # BN statistics property: the normalised pre-activation of conv1 has zero mean / unit variance
     s = net.mri_cnn
     assert int(s.conv1[1].num_batches_tracked.item()) == 1
+
+
+# BASELINE configs[2]: batch 8, 128^3, bf16 MFMA convolutions — with fp32 and with bf16 activation storage — against the
+# reference's fp32 run on the same structured volumes (tests/golden/ad_128_b8.npz, make_golden.py); the exact-fp32
+# path runs the same fixture at the fp32 tolerances.
+# Stated bf16 tolerances = ~3x the measured values (tools/parity_report.py --cases ad_128_b8 --modes bf16,bf16s --grads;
+# DESIGN.md 4).  bf16 has 8 significand bits and every conv operand of the seven layers per encoder is rounded (fp32
+# accumulation), so activations move by ~1e-2 of their scale; the train-mode BatchNorm1d head (batch 8) amplifies that
+# to ~0.1 on the logits while the loss moves 2e-2.  Gradients: the weight gradient of a conv that feeds a BatchNorm is
+# a small residual of large cancelling sums (its components along W and along the all-ones direction vanish), so
+# rounding the operands x and dz to bf16 leaves errors of tens of percent of the RESULT although every product is
+# within 2^-8 — the |.|-sum per tensor is bounded, element-wise agreement is not expected (measured: 0.28 / 0.18).
+# (logits, D logits, loss, cls / sNet-output probes relative to scale, conv-side |grad| sum, fusion+head |grad| sum)
+CFG3_TOL = {"fp32": dict(logits=2e-4, d=2e-4, loss=2e-4, act=5e-5, gconv=2e-2, gtok=1e-3),
+            "bf16": dict(logits=0.3, d=3e-2, loss=6e-2, act=3e-2, gconv=0.6, gtok=0.35),
+            "bf16s": dict(logits=0.35, d=3e-2, loss=6e-2, act=4e-2, gconv=0.6, gtok=0.5)}
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16s"])
+def test_config3_128_b8_matches_reference_fp32_golden(mode):
+    if not available("ad_128_b8"):
+        pytest.skip("fixture not generated")
+    import transmf_ad_amd as T
+    g = Golden("ad_128_b8")
+    assert g.batch == 8 and g.size == (128, 128, 128)
+    tol = CFG3_TOL[mode]
+    T.set_conv_precision("fp32" if mode == "fp32" else "bf16")
+    T.set_activation_storage("bf16" if mode == "bf16s" else "fp32")
+    try:
+        net = build(g)
+        seen = {}
+        net.fuse_transformer.register_forward_hook(lambda _m, _i, o: seen.__setitem__("cls", o))
+        for c in ("mri_cnn", "pet_cnn"):
+            getattr(net, c).register_forward_hook(lambda _m, _i, o, c=c: seen.__setitem__(f"{c}.conv4.3", o.contiguous()))
+        outs, loss = step(net, g, train=True)
+    finally:
+        T.set_activation_storage("fp32")
+        T.set_conv_precision("fp32")
+    for k, v in outs.items():
+        err = np.abs(v.detach().double().cpu().numpy() - g[f"f32/train/{k}"]).max()
+        assert err <= (tol["logits"] if k == "logits" else tol["d"]), (k, err)
+    assert abs(loss.item() - float(g["f32/train/loss"])) <= tol["loss"]
+    for k, t in seen.items():
+        ref = g[f"f32/probe/{k}"]
+        err = np.abs(probe(t) - ref).max() / max(1.0, np.abs(ref).max())
+        assert err <= tol["act"], (k, err)
+    for k, row in _grad_probe_errors(net, g, "f32").items():
+        if row[0] == "zero":
+            continue
+        assert np.isfinite(row[1]) and row[2] <= (tol["gconv"] if "_cnn." in k else tol["gtok"]), (k, row)
+        if mode == "fp32":
+            assert row[1] <= (tol["gconv"] if "_cnn." in k else tol["gtok"]), (k, row)
+    assert int(net.mri_cnn.conv1[1].num_batches_tracked.item()) == 1
 
 
 @pytest.mark.parametrize("which", ["model_CNN_ad", "model_single"])

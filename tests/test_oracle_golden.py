@@ -7,7 +7,7 @@ import torch
 from _golden import Golden, available, gprobe, probe, run_oracle, zero_grad_keys
 
 FAST = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid"]
-SLOW = ["ad_full_b2"]
+SLOW = ["ad_full_b2", "ad_full_b2_blobs", "ad_adni_b2"]
 
 
 def _check_case(name, dtype, prec):
@@ -84,4 +84,6 @@ def test_oracle_full_size(name):
     r = run_oracle(g, dtype=torch.float32, train=True, backward=False)
     for k, v in r["outs"].items():
         assert np.abs(v.detach().double().numpy() - g[f"f32/train/{k}"]).max() <= 2e-5, k
-        assert np.abs(v.detach().double().numpy() - g[f"f64/train/{k}"]).max() <= 1e-4, k
+        # fp32 run vs the fp64 golden: the reference's own fp32 run is 8e-5 (ad_full_b2) / 1.5e-4 (ad_adni_b2) away
+        # (train-mode BatchNorm1d over a batch of 2)
+        assert np.abs(v.detach().double().numpy() - g[f"f64/train/{k}"]).max() <= 3e-4, k

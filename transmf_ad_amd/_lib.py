@@ -97,6 +97,18 @@ def load():
         raise TmfError(
             f"{path} is missing: build it with `python -m transmf_ad_amd.build` "
             "(hipcc --offload-arch=gfx950). transmf_ad_amd has no CPU or PyTorch fallback.")
+    if "TMF_LIB" not in os.environ and os.environ.get("TMF_SKIP_STAMP_CHECK", "0") != "1":
+        # a library built from other sources / other compile flags than the ones next to it must not run silently
+        from . import build as _build
+        try:
+            with open(path + ".stamp") as f:
+                stamp = f.read().strip()
+        except OSError:
+            stamp = None
+        if stamp != _build.source_digest():
+            raise TmfError(
+                f"{path} is stale: it was not built from the current csrc/*.hip + headers + compile flags "
+                "(stamp mismatch). Rebuild with `python -m transmf_ad_amd.build`.")
     lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -25,36 +25,68 @@ def _hipcc():
     raise RuntimeError("hipcc not found: libtmf_hip.so cannot be built")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _digest(paths, extra=""):
+    """Content hash of the sources + headers + compile flags an artefact was built from."""
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _headers():
+    return [os.path.join(CSRC, "tmf_common.h"), os.path.join(HERE, "..", "include", "tmf_hip.h")]
+
+
+def source_digest():
+    """Digest of everything libtmf_hip.so is made from (all sources, headers, FLAGS).  build() writes it to
+    libtmf_hip.so.stamp; _lib.load() refuses a library whose stamp does not match the sources next to it."""
+    return _digest([os.path.join(CSRC, s) for s in SOURCES] + _headers(), " ".join(FLAGS))
 
 
 def build(force=False, verbose=True):
-    """Compile every HIP source for gfx950 and link libtmf_hip.so next to this file."""
+    """Compile every HIP source for gfx950 and link libtmf_hip.so next to this file.  An object is rebuilt when the
+    digest of (its source, the headers, FLAGS) differs from the stamp written next to it — so a change of compile flags
+    (e.g. -fno-slp-vectorize, a correctness matter: DESIGN.md 3.6) rebuilds everything, unlike an mtime comparison."""
     hipcc = _hipcc()
-    hdrs = [os.path.join(CSRC, "tmf_common.h"), os.path.join(HERE, "..", "include", "tmf_hip.h")]
+    hdrs = _headers()
     objs = []
     procs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
+        dig = _digest([s] + hdrs, " ".join(FLAGS))
+        if force or not os.path.exists(o) or _read(o + ".stamp") != dig:
             cmd = [hipcc, "-x", "hip", "-c", s, "-o", o] + FLAGS
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
-        if p.wait() != 0:
-            raise RuntimeError(f"hipcc failed on {src}")
-    if force or procs or _stale(LIB, objs):
+            if os.path.exists(o + ".stamp"):
+                os.remove(o + ".stamp")
+            procs.append((src, o, dig, subprocess.Popen(cmd)))
+    failed = [src for src, _o, _d, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed on {failed}")
+    for _src, o, dig, _p in procs:
+        with open(o + ".stamp", "w") as f:
+            f.write(dig)
+    want = source_digest()
+    if force or procs or not os.path.exists(LIB) or _read(LIB + ".stamp") != want:
         cmd = [hipcc, "-shared", "-o", LIB] + objs + ["--offload-arch=gfx950"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(LIB + ".stamp", "w") as f:
+            f.write(want)
     return LIB
 
 

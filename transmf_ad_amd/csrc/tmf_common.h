@@ -121,11 +121,16 @@ static inline int tmf_launch_result(const char* what) {
 template <typename K>
 static inline int tmf_allow_lds(K kernel, size_t bytes, const char* what) {
     // once per kernel instantiation and size (K is a distinct function-pointer VALUE per call site, so key on it)
+    // ... and on the device: the attribute belongs to the function ON ONE DEVICE, so a second GPU driven from the
+    // same thread needs its own call
     static thread_local const void* last_fn[8] = {};
     static thread_local size_t last_sz[8] = {};
+    static thread_local int last_dev[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
     const void* fn = reinterpret_cast<const void*>(kernel);
     const unsigned slot = (unsigned)((reinterpret_cast<uintptr_t>(fn) >> 4) & 7u);
-    if (last_fn[slot] == fn && last_sz[slot] >= bytes) return TMF_OK;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (last_fn[slot] == fn && last_dev[slot] == dev && last_sz[slot] >= bytes) return TMF_OK;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) {
         tmf_set_error("%s: cannot reserve %zu B of LDS: %s", what, bytes, hipGetErrorString(e));
@@ -133,6 +138,7 @@ static inline int tmf_allow_lds(K kernel, size_t bytes, const char* what) {
     }
     last_fn[slot] = fn;
     last_sz[slot] = bytes;
+    last_dev[slot] = dev;
     return TMF_OK;
 }
 

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void token_pool_fwd_kernel(const float* __rest
         for (int n = tl; n < N; n += 4) {
             const float v = src[(size_t)n * dim];
             s += v;
-            if (v > mx) { mx = v; am = n; }
+            if (v > mx || v != v) { mx = v; am = n; }     // NaN propagates, as in ATen's adaptive max pool
         }
     }
     ssum[tl][cl] = s; smax[tl][cl] = mx; sarg[tl][cl] = am;
@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256) void token_pool_fwd_kernel(const float* __rest
             s += ssum[k][cl];
             const float v = smax[k][cl];
             const int a = sarg[k][cl];
-            if (v > mx || (v == mx && a < am)) { mx = v; am = a; }      // ties: the earliest token
+            if (v != v) {                                               // NaN wins (ATen: the LAST NaN token)
+                if (mx == mx || a > am) { mx = v; am = a; }
+            } else if (mx == mx && (v > mx || (v == mx && a < am))) { mx = v; am = a; }      // ties: the earliest token
         }
         cls[(size_t)b * 4 * dim + mod * dim + c] = s / N;
         cls[(size_t)b * 4 * dim + (2 + mod) * dim + c] = mx;

@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from .gradient_reversal import revgrad
-from .networks import CrossTransformer_MOD_AVG, sNet
+from .networks import CrossTransformer_MOD_AVG, device_guard, sNet
 
 
 def _init_like_reference(module: nn.Module) -> None:
@@ -113,6 +113,7 @@ class model_single(_FastModeSwitch, nn.Module):
         self.fc = nn.Sequential(nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 2))
         _init_like_reference(self)
 
+    @device_guard
     def forward(self, img):
         return self.fc(_tokens(self.cnn(img)).mean(dim=1))
 
@@ -127,6 +128,7 @@ class model_CNN_ad(_FastModeSwitch, nn.Module):
         self.D = _discriminator(dim)
         _init_like_reference(self)
 
+    @device_guard
     def forward(self, mri, pet):
         mri_emb, pet_emb = _two_streams(self.mri_cnn, mri, self.pet_cnn, pet)
         mri_feat = _tokens(mri_emb).mean(dim=1)                 # == AdaptiveAvgPool3d(1) + flatten
@@ -150,6 +152,7 @@ class model_ad(_FastModeSwitch, nn.Module):
         self.D = _discriminator(dim)
         _init_like_reference(self)
 
+    @device_guard
     def forward_features(self, mri, pet):
         """-> (cls (B, 4*dim), D_MRI_logits, D_PET_logits); everything ahead of fc_cls."""
         mri_emb, pet_emb = _two_streams(self.mri_cnn, mri, self.pet_cnn, pet)

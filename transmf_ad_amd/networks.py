@@ -20,6 +20,21 @@ from torch import nn
 from . import ops
 
 
+def device_guard(forward):
+    """Run a module's forward with its first tensor's GPU as the current HIP device: the kernels are launched on the
+    CURRENT device's current stream, so a model moved with ``.to('cuda:1')`` works while device 0 is current (as the
+    reference's stock modules do).  Backward needs no guard: autograd's device threads set the device themselves."""
+    import functools
+
+    @functools.wraps(forward)
+    def wrapped(self, x, *args, **kwargs):
+        if x.is_cuda and x.device.index != torch._C._cuda_getDevice():
+            with torch.cuda.device(x.device):
+                return forward(self, x, *args, **kwargs)
+        return forward(self, x, *args, **kwargs)
+    return wrapped
+
+
 # ---------------------------------------------------------------------------------------
 # sNet                                                         reference: networks.py:18-61
 # ---------------------------------------------------------------------------------------
@@ -47,6 +62,7 @@ class sNet(nn.Module):
         self.conv4 = nn.Sequential(*_conv_block(dim, dim * 2, 3), *_conv_block(dim * 2, dim, 1),
                                    nn.AvgPool3d(2, stride=2))
 
+    @device_guard
     def forward_channels_last(self, vol):
         if vol.dim() != 5 or vol.shape[1] != 1:
             raise ValueError(f"sNet expects (B, 1, D, H, W), got {tuple(vol.shape)}")
@@ -67,9 +83,13 @@ class sNet(nn.Module):
                 nxt = getattr(self, self._PLAN[n_blk + 1][0])[self._PLAN[n_blk + 1][1]]
                 mine_ok = conv.in_channels == 1 or ops.bf16_conv_capable(conv.in_channels, conv.kernel_size[0])
                 out16 = mine_ok and ops.bf16_conv_capable(nxt.in_channels, nxt.kernel_size[0])
+            momentum = bn.momentum
+            if momentum is None:                # BatchNorm(momentum=None): cumulative moving average 1 / n
+                momentum = (1.0 / float(bn.num_batches_tracked.item())
+                            if self.training and bn.track_running_stats else 0.0)
             x = ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                      bn.running_var, self.training or not bn.track_running_stats,
-                                     momentum=bn.momentum, eps=bn.eps, slope=act.negative_slope, pool=pool,
+                                     momentum=momentum, eps=bn.eps, slope=act.negative_slope, pool=pool,
                                      out_bf16=out16)
         return x                                 # (B, d, h, w, dim)
 
@@ -89,6 +109,7 @@ class PreNorm(nn.Module):
         self.norm = nn.LayerNorm(dim)
         self.fn = fn
 
+    @device_guard
     def forward(self, x, **kwargs):
         return self.fn(ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps), **kwargs)
 
@@ -117,6 +138,7 @@ class Attention(nn.Module):
         self.to_kv = nn.Linear(dim, inner_dim * 2, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
 
+    @device_guard
     def forward(self, x, context=None, kv_include_self=False):
         context = x if context is None else context
         if kv_include_self:
@@ -145,18 +167,34 @@ class Transformer(nn.Module):
         return (not drop) and x.is_cuda and ops.fused_block_supported(x.shape[-1], a.to_q.out_features,
                                                                       f.net[0].out_features)
 
+    @device_guard
     def forward(self, x, context=None, residual=None):
         """``residual`` (optional) is added to the result inside the final LayerNorm pass — the caller's
         ``enc(tokens, context) + tokens`` (reference networks.py:262-263) without a separate kernel."""
-        ctx = x if context is None else context
-        if self._fused(x):
+        # The fused layer reads keys / values from an UN-normalised context — what PreNorm hands the attention when
+        # a context is passed (networks.py:120-121).  Without one the reference attends over LayerNorm(x) of the
+        # CURRENT layer (networks.py:162 `default(context, x)` sees the normalised x), which the op-per-launch
+        # branch below reproduces.
+        if context is not None and self._fused(x):
             for attn, ff in self.layers:
-                x = ops.transformer_layer(x, ctx, attn.norm, attn.fn, ff.norm, ff.fn)
+                x = ops.transformer_layer(x, context, attn.norm, attn.fn, ff.norm, ff.fn)
         else:
             for attn, ff in self.layers:
                 x = attn(x, context=context) + x
                 x = ff(x) + x
         return ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps, residual)
+
+
+class _TokenReduce(nn.Module):
+    """'b n d -> b d' by mean / max over the tokens: the reference's Rearrange + AdaptiveAvg/MaxPool1d(1) + Rearrange
+    (networks.py:264-269) for callers that use ``fuse_transformer.gap`` / ``.gmp`` directly."""
+
+    def __init__(self, how):
+        super().__init__()
+        self.how = how
+
+    def forward(self, tokens):
+        return tokens.mean(dim=1) if self.how == "mean" else tokens.amax(dim=1)
 
 
 class CrossTransformer_MOD_AVG(nn.Module):
@@ -169,7 +207,11 @@ class CrossTransformer_MOD_AVG(nn.Module):
         for _ in range(depth):
             self.layers.append(nn.ModuleList([Transformer(dim, 1, heads, dim_head, mlp_dim, dropout=dropout),
                                               Transformer(dim, 1, heads, dim_head, mlp_dim, dropout=dropout)]))
+        # attribute parity with networks.py:264-269 (parameter-free; forward() pools all four in ONE launch instead)
+        self.gap = _TokenReduce("mean")
+        self.gmp = _TokenReduce("max")
 
+    @device_guard
     def forward(self, mri_tokens, pet_tokens):
         for mri_enc, pet_enc in self.layers:
             # (Transformer.forward can fold this "+ tokens" into its last LayerNorm pass via residual=; it is left

@@ -25,6 +25,12 @@ def _chk(t: torch.Tensor, name: str, allow_bf16: bool = False) -> torch.Tensor:
     if not t.is_cuda:
         raise _lib.TmfError(
             f"{name} is on {t.device}: transmf_ad_amd runs only on a HIP device (MI355X); there is no CPU fallback")
+    if t.device.index != torch._C._cuda_getDevice():
+        # the kernels are launched on the CURRENT device's current stream (_stream): pointers of another GPU there
+        # would fault or race.  The module forwards install the guard themselves (networks.on_device_of).
+        raise _lib.TmfError(
+            f"{name} is on {t.device} but the current HIP device is cuda:{torch._C._cuda_getDevice()}: "
+            f"call under `with torch.cuda.device({t.device.index}):`")
     if t.dtype != _f32 and not (allow_bf16 and t.dtype == torch.bfloat16):
         raise _lib.TmfError(f"{name} must be float32, got {t.dtype}")
     return t if t.is_contiguous() else t.contiguous()

@@ -186,9 +186,13 @@ class GradAllReduce(nn.Module):
             torch.cuda.current_stream(dev).wait_stream(st)
         # .grad becomes a VIEW of the reduced bucket (no copy back); the next zero_grad() drops it and the next
         # backward's pack — stream-ordered after the optimizer step that reads these views — refills the bucket.
+        # A parameter that received no gradient in this backward keeps ``.grad = None`` — exactly what a single-process
+        # run leaves, so Adam skips it there and here alike (its zero-filled slice still rode in the all-reduce).  As
+        # with torch DDP(find_unused_parameters=False) the set of used parameters must be the same on every rank.
         for b in self._buckets:
-            for p, v in zip(b.params, self._views(b)):
-                p.grad = v
+            for i, (p, v) in enumerate(zip(b.params, self._views(b))):
+                if b.filled[i]:
+                    p.grad = v
             b.reset()
 
     def reduce_gradients(self):
