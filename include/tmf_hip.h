@@ -66,6 +66,11 @@ int         tmf_set_option(const char* name, int value);
 int  tmf_conv3d_fwd(const float* x, const float* w, float* z, float* stat_partial,
                     int B, int D, int H, int W, int cin, int cout, int ksize, void* stream);
 int  tmf_conv3d_stat_blocks(int B, int D, int H, int W, int cin, int cout, int ksize);
+/* Template-argument text ("FwdCfg<3, 16, 1, 1, 8, 1, 4, 8, 8, 3>" / "WgCfg<1, 4, 8, 8, 8, 32>") of the kernel instance
+ * tmf_conv3d_fwd / tmf_conv3d_wgrad launch for a shape, as a kernel trace prints it (measurement aid: bench.py groups
+ * its live launch timings by it).  Thread-local static storage; "?" for shapes without a kernel. */
+const char* tmf_conv3d_fwd_kernel_name(int B, int D, int H, int W, int cin, int cout, int ksize);
+const char* tmf_conv3d_wgrad_kernel_name(int B, int D, int H, int W, int cin, int cout, int ksize);
 /* Eval-mode block in ONE pass (BatchNorm is affine in eval mode; val_step, kfold_train_adversarial.py:144-161):
  *   y = pool( LeakyReLU( scale[c] * conv(x)[c] + shift[c] ) ),   pool = TMF_POOL_NONE | MAX2 | AVG2 (floor mode),
  * scale / shift from tmf_bn_eval_coeffs (they absorb the conv bias).  The raw conv output is never written.

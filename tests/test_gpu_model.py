@@ -151,7 +151,10 @@ def _golden_train_step(name):
     # BatchNorm buffers after one step (running stats, num_batches_tracked incl. D's double update)
     for k, b in net.named_buffers():
         ref = g[f"f32/buf/{k}"]
-        assert np.abs(b.detach().double().cpu().numpy() - ref).max() <= 1e-4 * max(1.0, np.abs(ref).max()), k
+        # fc_cls.5 sits BEHIND the first train-mode BatchNorm1d of the head (batch of 2 in most fixtures: that layer
+        # amplifies fp32 noise, see GATE) — its statistics get the gate, everything else 1e-4
+        btol = GATE if k.startswith("fc_cls.5.") else 1e-4
+        assert np.abs(b.detach().double().cpu().numpy() - ref).max() <= btol * max(1.0, np.abs(ref).max()), k
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -29,6 +29,8 @@ PROTOTYPES = {
     "tmf_conv3d_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tmf_conv3d_fwd_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_conv3d_stat_blocks": (_i, [_i, _i, _i, _i, _i, _i, _i]),
+    "tmf_conv3d_fwd_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
+    "tmf_conv3d_wgrad_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tmf_conv3d_fwd_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -941,6 +941,31 @@ int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float
     return TMF_E_SHAPE;
 }
 
+// Template-argument text of the kernel a plan selects, as rocprofv3 prints it ("FwdCfg<3, 16, 1, 1, 8, 1, 4, 8, 8, 3>"):
+// bench.py groups its live per-launch timings by this name so that they can be checked against a kernel-trace.
+template <int KS, int CINC, int MT, int NT, int WM, int WN, int TD, int TH, int TW, int TPS>
+const char* cfg_name(const FwdCfg<KS, CINC, MT, NT, WM, WN, TD, TH, TW, TPS>*) {
+    static thread_local char buf[96];
+    snprintf(buf, sizeof buf, "FwdCfg<%d, %d, %d, %d, %d, %d, %d, %d, %d, %d>", KS, CINC, MT, NT, WM, WN, TD, TH, TW, TPS);
+    return buf;
+}
+template <int KS>
+const char* fwd_kernel_name(const FwdPlan& p) {
+#define TMF_FWD_CASE(CFG, CINC) if (p.cinc == CINC) return cfg_name((const CFG<KS, CINC>*)nullptr);
+    if (p.cfg == 0) { TMF_FWD_CASE(CfgL32, 8) TMF_FWD_CASE(CfgL32, 16) TMF_FWD_CASE(CfgL32, 32) }
+    if (p.cfg == 1) { TMF_FWD_CASE(CfgL64, 8) TMF_FWD_CASE(CfgL64, 16) TMF_FWD_CASE(CfgL64, 32) }
+    if (p.cfg == 2) { TMF_FWD_CASE(CfgS128, 8) TMF_FWD_CASE(CfgS128, 16) TMF_FWD_CASE(CfgS128, 32) }
+    if (p.cfg == 3) { TMF_FWD_CASE(CfgL32w8, 32) }
+    if (p.cfg == 4) { TMF_FWD_CASE(CfgL64w8, 32) }
+    if (p.cfg == 5) { TMF_FWD_CASE(CfgS128w8, 32) }
+    if (p.cfg == 8) { TMF_FWD_CASE(CfgL32w8, 16) }
+    if (p.cfg == 9) { TMF_FWD_CASE(CfgL64w8, 16) }
+    if (p.cfg == 6) { TMF_FWD_CASE(CfgM32, 32) }
+    if (p.cfg == 7) { TMF_FWD_CASE(CfgM64, 32) }
+#undef TMF_FWD_CASE
+    return p.cfg == 10 ? "conv3d_fwd_ws_kernel" : "?";
+}
+
 // ------------------------------------------------------------------------------------
 // weight gradient, 3x3x3
 // ------------------------------------------------------------------------------------
@@ -1538,6 +1563,25 @@ extern "C" int tmf_set_option(const char* name, int value) {
     if (strcmp(name, "conv_ws") == 0) { g_conv_ws = value; return TMF_OK; }
     tmf_set_error("tmf_set_option: unknown option '%s'", name);
     return TMF_E_ARG;
+}
+
+extern "C" const char* tmf_conv3d_fwd_kernel_name(int B, int D, int H, int W, int cin, int cout, int ksize) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0 || (ksize != 1 && ksize != 3)) return "?";
+    const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize);
+    return ksize == 3 ? fwd_kernel_name<3>(p) : fwd_kernel_name<1>(p);
+}
+
+extern "C" const char* tmf_conv3d_wgrad_kernel_name(int B, int D, int H, int W, int cin, int cout, int ksize) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return "?";
+    if (ksize != 3) return "conv1x1_wgrad_kernel";
+    const WgPlan p = plan_wgrad(B, D, H, W, cin, cout);
+    const bool vec = (cin % 4 == 0) && (cout % 4 == 0);
+    const bool w8 = vec && conv_waves() >= 8;
+    static thread_local char buf[64];
+    const int edge = p.small ? 4 : 8;
+    const int nt = (w8 && p.pack) ? 1 : p.nt;
+    snprintf(buf, sizeof buf, "WgCfg<%d, 4, %d, %d, %d, %d>", nt, edge, edge, w8 ? 8 : 4, (w8 && p.pack) ? 16 : 32);
+    return buf;
 }
 
 extern "C" int tmf_conv3d_stat_blocks(int B, int D, int H, int W, int cin, int cout, int ksize) {
