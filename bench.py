@@ -55,13 +55,194 @@ def conv_flops_per_pair(size, dim=128):
     return 2 * tot
 
 
-def _profiled_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (counters cannot be read live)."""
+def conv_bytes_per_pair(size, elem, dim=128):
+    """Algorithmic HBM bytes fwd+bwd per MRI+PET pair, two-pass-BatchNorm minimum: per conv layer with
+    input bytes I, raw output bytes O, post-pool bytes P:  fwd = I + 2O + P;  bwd = 2I + 5O + 2P  (minus I + O on conv1:
+    no data gradient); both streams.  elem = 4 (fp32 tensors) or 2 (bf16 storage; SURVEY's 3.094 GB at 128^3 prices the network
+    input at 2 B as well although it stays fp32 here — the smaller, conservative figure is used)."""
+    q, h, d, d2 = dim // 4, dim // 2, dim, dim * 2
+    layers = [(1, q, 0, True), (q, q, 1, False), (q, h, 1, True), (h, h, 2, False), (h, d, 2, True), (d, d2, 3, False),
+              (d2, d, 3, True)]
+    dims = (size, size, size) if isinstance(size, int) else tuple(size)
+    tot = 0.0
+    for i, (ci, co, lvl, pooled) in enumerate(layers):
+        vox = 1
+        pvox = 1
+        for e in dims:
+            e >>= lvl
+            vox *= e
+            pvox *= e // 2
+        I = vox * ci * elem
+        O = vox * co * elem
+        P = (pvox if pooled else vox) * co * elem
+        tot += (I + 2 * O + P) + (2 * I + 5 * O + 2 * P) - ((I + O) if i == 0 else 0)
+    return 2 * tot
+
+
+def _pmc_traffic(kernel):
+    """HBM bytes per launch of a kernel instance from the committed rocprofv3 --pmc passes (counters cannot be read
+    live): profiles/r02_pmc_traffic.json = {kernel name substring: {"hbm_bytes_per_launch": ..., "shape": ...}}."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_conv2.3_fwd.json")) as f:
-            return float(json.load(f)["hbm_bytes_per_launch"])
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            tab = json.load(f)
+        for key, row in tab.items():
+            if key in kernel:
+                return row
     except Exception:
-        return None
+        pass
+    return None
+
+
+def _spin_up(dev, seconds):
+    """The chip raises its clocks only after a few hundred ms of load (a launch measured straight after start-up is
+    ~12 % slower).  Load it with an UNRELATED kernel (a torch matmul) so that neither the live numbers nor a kernel trace
+    of this command mix warm-up launches into the conv kernels' statistics."""
+    a = torch.randn((4096, 4096), device=dev)
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(10):
+            torch.mm(a, a)
+        torch.cuda.synchronize()
+
+
+def _time_launches(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
+    """Every convolution launch of ONE encoder's train step, timed live with HIP events on the launching stream (torch's
+    current stream), `reps` back-to-back launches each: forward, data-gradient and weight-gradient (+ its slab
+    reduction) of the five Cin > 1 3x3x3 layers, and the four passes of the fused first block as one group.  Returns a
+    list of rows {layer, pass, kernel, ms, flops, bytes}: flops / bytes are ALGORITHMIC per launch (2*27*Cin*Cout per
+    output voxel; tensors read + written once, at the storage width the step really uses)."""
+    dim = 128
+    rows = []
+    b16 = precision == "bf16"
+    s16 = b16 and storage == "bf16"
+    adt = torch.bfloat16 if s16 else torch.float32
+    el = 2 if s16 else 4
+    for name, ci, co, lvl in (("conv2.0", 32, 32, 1), ("conv2.3", 32, 64, 1), ("conv3.0", 64, 64, 2),
+                              ("conv3.3", 64, 128, 2), ("conv4.0", 128, 256, 3)):
+        D, H, W = (e >> lvl for e in vol)
+        vox = B * D * H * W
+        x = torch.randn((B, D, H, W, ci), device=dev).to(adt)
+        dz = torch.randn((B, D, H, W, co), device=dev).to(adt)
+        w = torch.randn((co, ci, 3, 3, 3), device=dev) * (27 * ci) ** -0.5
+        fl = 2.0 * 27 * ci * co * vox
+        by = float(vox * (ci + co) * el)
+        if b16:
+            wf, wd = ops.pack_weight_bf16(w), ops.pack_weight_dgrad_bf16(w)
+            fns = (("fwd", "conv3d_fwd_bf16_kernel", lambda: ops.conv3d_bf16_raw(x, wf, ci, co, True, out_bf16=s16)),
+                   ("dgrad", "conv3d_fwd_bf16_kernel", lambda: ops.conv3d_bf16_raw(dz, wd, co, ci, False, out_bf16=s16)),
+                   ("wgrad", "conv3d_wgrad_bf16_kernel", lambda: ops.conv3d_wgrad_bf16(x, dz, ci, co)))
+        else:
+            wf, wd = ops.pack_weights_both(w, True)
+            kf = _lib.query("tmf_conv3d_fwd_kernel_name", B, D, H, W, ci, co, 3).decode()
+            kd = _lib.query("tmf_conv3d_fwd_kernel_name", B, D, H, W, co, ci, 3).decode()
+            kw = _lib.query("tmf_conv3d_wgrad_kernel_name", B, D, H, W, ci, co, 3).decode()
+            fns = (("fwd", f"conv3d_fwd_kernel<{kf}>", lambda: ops.conv3d_raw(x, wf, ci, co, 3, True)),
+                   ("dgrad", f"conv3d_fwd_kernel<{kd}>", lambda: ops.conv3d_raw(dz, wd, co, ci, 3, False)),
+                   ("wgrad", f"conv3d_wgrad_kernel<{kw}>", lambda: ops.conv3d_wgrad(x, dz, ci, co, 3)))
+        for pas, kern, fn in fns:
+            ms = _time_launches(fn, reps)
+            rows.append(dict(layer=name, **{"pass": pas}, kernel=kern, ms=ms, flops=fl, bytes=by))
+        del x, dz, w, wf, wd
+    # fused first block: statistics + normalise/pool forward, backward reduce + weight gradient (z never stored)
+    D, H, W = vol
+    q = dim // 4
+    x = torch.rand((B, D, H, W, 1), device=dev)
+    conv = torch.nn.Conv3d(1, q, 3, padding=1).to(dev)
+    bn = torch.nn.BatchNorm3d(q).to(dev)
+    go = torch.randn((B, D // 2, H // 2, W // 2, q), device=dev).to(adt)
+
+    def first_block():
+        conv.weight.grad = None
+        y = ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var, True,
+                                 pool="max", out_bf16=s16)
+        y.backward(go)
+    ms = _time_launches(first_block, reps)
+    vox = B * D * H * W
+    rows.append(dict(layer="conv1.0", **{"pass": "fwd+bwd (4 recompute passes)"},
+                     kernel="conv1_fused_kernel<0..3>" + (" bf16" if b16 else ""), ms=ms, flops=2 * 2.0 * 27 * q * vox,
+                     bytes=float(2 * vox * 4 + 2 * (vox // 8) * q * el)))
+    return rows
+
+
+def roofline_report(rows, precision, pairs_per_s, world, gf_pair, bytes_pair, B, vol):
+    """Fold the per-launch rows into the bench line's `roofline` object:
+      * main entry  = the time-dominant kernel instance of a step (all of its launches, FLOP-weighted);
+      * step_conv   = FLOP-weighted over EVERY conv launch of one step (both encoders);
+      * whole_step  = the train step itself (pairs/s x algorithmic figure per pair) against both ceilings;
+      * best_launch = the single best launch (what round 1 quoted);  layers = the full table."""
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    groups = {}
+    for r in rows:
+        g = groups.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, members=[]))
+        g["ms"] += r["ms"]; g["flops"] += r["flops"]; g["bytes"] += r["bytes"]; g["launches"] += 1
+        g["members"].append(f"{r['layer']} {r['pass']}")
+    dom_name, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+
+    def entry(fl, by, ms):
+        tf, gbs = fl / ms / 1e9, by / ms / 1e6
+        t_mfma, t_hbm = fl / peak_tf / 1e9, by / PEAK_HBM_GBS / 1e6            # ms at either ceiling
+        return tf, gbs, ("mfma" if t_mfma >= t_hbm else "hbm")
+    tf, gbs, bound = entry(dom["flops"], dom["bytes"], dom["ms"])
+    tot_ms = sum(r["ms"] for r in rows)
+    tot_fl = sum(r["flops"] for r in rows)
+    tot_by = sum(r["bytes"] for r in rows)
+    best = max((r for r in rows if r["layer"] != "conv1.0"), key=lambda r: r["flops"] / r["ms"])
+    traffic = _pmc_traffic(dom_name)
+    roof = {
+        "bound": bound,
+        "kernel": dom_name,
+        "scope": f"all {dom['launches']} launches of the time-dominant kernel instance in one encoder's train step "
+                 f"({', '.join(dom['members'])}); B={B}, volume {'x'.join(map(str, vol))}",
+        "achieved": round(tf if bound == "mfma" else gbs, 2),
+        "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
+        "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+        "frac": round((tf / peak_tf) if bound == "mfma" else (gbs / PEAK_HBM_GBS), 4),
+        "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
+        "traffic_note": None if traffic is None else traffic.get("note"),
+        "launch_ms": round(dom["ms"] / dom["launches"], 4),
+        "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
+        "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
+        "mfma_frac": round(tf / peak_tf, 4), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+        "share_of_conv_time": round(dom["ms"] / tot_ms, 3),
+        "kernels": {k: {"launches_per_encoder_step": g["launches"], "ms": round(g["ms"], 4),
+                        "avg_launch_ms": round(g["ms"] / g["launches"], 4),
+                        "tflops": round(g["flops"] / g["ms"] / 1e9, 1),
+                        "mfma_frac": round(g["flops"] / g["ms"] / 1e9 / peak_tf, 4),
+                        "hbm_frac": round(g["bytes"] / g["ms"] / 1e6 / PEAK_HBM_GBS, 4)} for k, g in groups.items()},
+        "step_conv": {"what": "FLOP-weighted over every conv launch of one train step (fwd + dgrad + wgrad of the five "
+                              "Cin>1 layers + the fused first block; x2 encoders), launches timed back to back",
+                      "ms_per_step": round(2 * tot_ms, 3), "tflops": round(tot_fl / tot_ms / 1e9, 2),
+                      "mfma_frac": round(tot_fl / tot_ms / 1e9 / peak_tf, 4),
+                      "hbm_frac": round(tot_by / tot_ms / 1e6 / PEAK_HBM_GBS, 4)},
+        "best_launch": {"layer": best["layer"], "pass": best["pass"], "kernel": best["kernel"],
+                        "ms": round(best["ms"], 4), "tflops": round(best["flops"] / best["ms"] / 1e9, 2),
+                        "mfma_frac": round(best["flops"] / best["ms"] / 1e9 / peak_tf, 4)},
+        "layers": {f"{r['layer']} {r['pass']}": {"ms": round(r["ms"], 4), "tflops": round(r["flops"] / r["ms"] / 1e9, 1),
+                                                 "mfma_frac": round(r["flops"] / r["ms"] / 1e9 / peak_tf, 3),
+                                                 "hbm_frac": round(r["bytes"] / r["ms"] / 1e6 / PEAK_HBM_GBS, 3)}
+                   for r in rows},
+    }
+    if pairs_per_s is not None:
+        per_gpu = pairs_per_s / world
+        roof["whole_step"] = {
+            "what": "the train step itself: pairs/s per GPU x algorithmic figure per pair (SURVEY.md 8d)",
+            "conv_tflops": round(per_gpu * gf_pair / 1e12, 2), "mfma_frac": round(per_gpu * gf_pair / 1e12 / peak_tf, 4),
+            "hbm_GBps": round(per_gpu * bytes_pair / 1e9, 1), "hbm_frac": round(per_gpu * bytes_pair / 1e9 / PEAK_HBM_GBS, 4),
+            "algorithmic_GFLOP_per_pair": round(gf_pair / 1e9, 2), "algorithmic_GB_per_pair": round(bytes_pair / 1e9, 3),
+            "bound": "mfma" if gf_pair / peak_tf / 1e12 >= bytes_pair / PEAK_HBM_GBS / 1e9 else "hbm"}
+    return roof
 
 
 def main():
@@ -85,6 +266,9 @@ def main():
     ap.add_argument("--eval", action="store_true",
                     help="time the reference's val_step instead (eval mode, no_grad forward + CE; kfold_train_adversarial.py:144-161)")
     ap.add_argument("--no-fused-adam", action="store_true")
+    ap.add_argument("--no-item-sync", action="store_true",
+                    help="leave out the reference step's two loss.item() host syncs between forward and backward "
+                         "(kfold_train_adversarial.py:127-128); the default step has them")
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the train-step timing: only the dominant-kernel loop (so that a rocprofv3 --stats run "
                          "of this command averages exactly the launches the roofline entry quotes)")
@@ -154,7 +338,12 @@ def main():
             loss = crit(net(mri), label)
         else:
             lo, dm, dp = net(mri, pet)
-            loss = (crit(dm, ones) + crit(dp, zeros)) / 2 + crit(lo, label)
+            ce_loss = crit(lo, label)
+            ad_loss = (crit(dm, ones) + crit(dp, zeros)) / 2
+            if not args.no_item_sync:       # the reference reads both losses on the host BEFORE backward
+                ce_loss.item()              # (kfold_train_adversarial.py:127-128: two host syncs per step)
+                ad_loss.item()
+            loss = ad_loss + ce_loss
         loss.backward()
         opt.step()
         return loss
@@ -213,106 +402,16 @@ def main():
     ms_per_step = dt / max(args.steps, 1) * 1e3
     pairs_per_s = world * B * args.steps / dt
 
-    # ---- roofline of the dominant kernel: conv3d_fwd_kernel (forward + data-gradient = 2/3 of
-    # the MFMA work) at its largest launch, conv2.3 (32 -> 64 channels at (S/2)^3), timed live
-    # with HIP events on the stream the kernel is launched on ----
+    # ---- roofline: every conv launch of a step timed live (HIP events on the launching stream), folded into the
+    # time-dominant kernel instance (main entry), the FLOP-weighted step figure, and the whole-step fractions ----
     roof = None
-    if rank == 0:
-        s2 = S // 2
-        x = torch.randn((B, s2, s2, s2, 32), device=dev)
-        w = torch.randn((27, 32, 64), device=dev) * 0.03
-        # The chip raises its clocks only after a few hundred ms of load: straight after start-up (--roofline-only)
-        # this launch takes 0.87 ms, after the train steps above 0.78 ms.  Bring it to the loaded state with unrelated
-        # work first, so the live number and a rocprofv3 --stats average of THIS kernel describe the same state.
-        w_spin = torch.randn((27, 32, 32), device=dev) * 0.03          # conv2.0 shape: a different kernel instance
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < float(os.environ.get("TMF_ROOF_SPIN_S", "0.5")):
-            for _ in range(20):
-                ops.conv3d_raw(x, w_spin, 32, 32, 3, True)
-            torch.cuda.synchronize()
-        del w_spin
-        for _ in range(3):
-            ops.conv3d_raw(x, w, 32, 64, 3, True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        z = torch.empty((B, s2, s2, s2, 64), device=dev)
-        nblk = _lib.query("tmf_conv3d_stat_blocks", B, s2, s2, s2, 32, 64, 3)
-        part = torch.empty((nblk, 2, 64), device=dev)
-        st = torch.cuda.current_stream().cuda_stream
-        torch.cuda.synchronize()
-        e0.record()
-        for _ in range(reps):
-            _lib.call("tmf_conv3d_fwd", x.data_ptr(), w.data_ptr(), z.data_ptr(), part.data_ptr(),
-                      B, s2, s2, s2, 32, 64, 3, st)
-        e1.record()
-        torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / reps
-        flops = 2.0 * 27 * 32 * 64 * B * s2 ** 3
-        ach = flops / (k_ms * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": f"conv3d_fwd_kernel<FwdCfg<3,16,1,2,8,1,4,8,8,3>> @conv2.3 (B={B}, {s2}^3, 32->64 ch)", "achieved": round(ach, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-                "traffic": _profiled_traffic() if (B, S) == (8, 96) else None,
-                "traffic_unit": "HBM bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
-                "profiles/r01_pmc_traffic_conv2.3_fwd.json)", "launch_ms": round(k_ms, 4), "flops_per_launch": flops}
-        if args.precision == "bf16":
-            # the opt-in bf16 mode's dominant kernel, priced against BOTH ceilings: it is far from the bf16 MFMA
-            # peak by construction (fp32 activations in HBM: 384 B per voxel for 2*27*32*64 flops)
-            wb = ops.pack_weight_bf16(torch.randn((64, 32, 3, 3, 3), device=dev) * 0.03)
-            nb16 = _lib.query("tmf_conv3d_bf16_stat_blocks", B, s2, s2, s2, 64)
-            part16 = torch.empty((nb16, 2, 64), device=dev)
-            for _ in range(3):
-                ops.conv3d_bf16_raw(x, wb, 32, 64, True)
-            torch.cuda.synchronize()
-            e0.record()
-            for _ in range(reps):
-                _lib.call("tmf_conv3d_fwd_bf16", x.data_ptr(), wb.data_ptr(), z.data_ptr(), part16.data_ptr(),
-                          B, s2, s2, s2, 32, 64, st)
-            e1.record()
-            torch.cuda.synchronize()
-            k16 = e0.elapsed_time(e1) / reps
-            ach16 = flops / (k16 * 1e-3) / 1e12
-            alg_bytes = (x.numel() + z.numel()) * 4.0
-            roof = {"bound": "mfma", "kernel": f"conv3d_fwd_bf16_kernel<1> @conv2.3 (B={B}, {s2}^3, 32->64 ch)",
-                    "achieved": round(ach16, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach16 / PEAK_BF16_MFMA_TFLOPS, 4), "traffic": None,
-                    "launch_ms": round(k16, 4), "flops_per_launch": flops,
-                    "hbm": {"algorithmic_bytes_per_launch": alg_bytes, "achieved_GBps": round(alg_bytes / k16 / 1e6, 1),
-                            "peak_GBps": 8000.0, "frac": round(alg_bytes / k16 / 1e6 / 8000.0, 4)},
-                    "fp32_kernel_same_shape": {"launch_ms": round(k_ms, 4), "achieved": round(ach, 2),
-                                               "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}}
-        del x, w, z, part
-        # every 3x3x3 layer of one encoder, forward / data-gradient / weight-gradient launches (fp32 kernels, same
-        # loaded clock state, 10 launches each): TFLOP/s and fraction of the fp32-MFMA peak
-        if not args.roofline_only and args.precision == "fp32":
-            def _t(fn, n=10):
-                fn()
-                torch.cuda.synchronize()
-                a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                a0.record()
-                for _ in range(n):
-                    fn()
-                a1.record()
-                torch.cuda.synchronize()
-                return a0.elapsed_time(a1) / n
-            layers = {}
-            for name, ci, co, div in (("conv2.0", 32, 32, 2), ("conv2.3", 32, 64, 2), ("conv3.0", 64, 64, 4),
-                                      ("conv3.3", 64, 128, 4), ("conv4.0", 128, 256, 8)):
-                sl = S // div
-                xl = torch.randn((B, sl, sl, sl, ci), device=dev)
-                dzl = torch.randn((B, sl, sl, sl, co), device=dev)
-                wl = torch.randn((27, ci, co), device=dev) * 0.03
-                wdl = torch.randn((27, co, ci), device=dev) * 0.03
-                fl = 2.0 * 27 * ci * co * B * sl ** 3
-                row = {}
-                for key, fn in (("fwd", lambda: ops.conv3d_raw(xl, wl, ci, co, 3, True)),
-                                ("dgrad", lambda: ops.conv3d_raw(dzl, wdl, co, ci, 3, False)),
-                                ("wgrad", lambda: ops.conv3d_wgrad(xl, dzl, ci, co, 3))):
-                    ms = _t(fn)
-                    row[key] = {"ms": round(ms, 4), "tflops": round(fl / ms / 1e9, 1),
-                                "frac": round(fl / ms / 1e9 / PEAK_FP32_MFMA_TFLOPS, 3)}
-                layers[name] = row
-                del xl, dzl, wl, wdl
-            roof["layers"] = layers
+    gf_pair = conv_flops_per_pair(vol) * (0.5 if args.model == "single" else 1.0)
+    by_pair = conv_bytes_per_pair(vol, 2 if args.storage == "bf16" else 4) * (0.5 if args.model == "single" else 1.0)
+    if rank == 0 and not args.eval:
+        _spin_up(dev, float(os.environ.get("TMF_ROOF_SPIN_S", "0.5")))
+        rows = measure_conv_launches(ops, _lib, dev, B, vol, args.precision, args.storage,
+                                     reps=int(os.environ.get("TMF_ROOF_REPS", "10")))
+        roof = roofline_report(rows, args.precision, pairs_per_s if args.steps > 0 else None, world, gf_pair, by_pair, B, vol)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -335,7 +434,7 @@ def main():
                          f"{sec:.2f} s/step, {cpu_model}, host cpu_count={os.cpu_count()}, torch threads={threads}"}
 
     if rank == 0:
-        gf = conv_flops_per_pair(vol) * (0.5 if args.model == "single" else 1.0)
+        gf = gf_pair
         if args.eval:       # forward only: sum of F_l per stream
             gf = gf * (32.219 / 95.125) if vol == (96, 96, 96) else gf / 3.0
         vtxt = f"{S}^3" if not args.shape else "x".join(map(str, vol))
@@ -358,7 +457,9 @@ def main():
                                    + (f"{S}^3" if not args.shape else "x".join(map(str, vol))) + f" per GPU, {args.precision}"
                                    + (_config_tag(B, S, args.precision) if args.model == "ad" else ""),
                        "global_batch": B * world, "parallelism": f"dp{world}",
-                       "step": "val_step: eval-mode no_grad forward + CE" if args.eval else "zero_grad+fwd+loss+bwd+allreduce+Adam",
+                       "step": "val_step: eval-mode no_grad forward + CE" if args.eval else
+                               ("zero_grad+fwd+loss+bwd+allreduce+Adam" if args.no_item_sync or args.model == "single" else
+                                "zero_grad+fwd+loss+2x loss.item()+bwd+allreduce+Adam (kfold_train_adversarial.py:101-136)"),
                        "dispatch": mode,
                        "setup_steps_untimed": setup_steps},
             "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),

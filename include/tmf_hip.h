@@ -37,6 +37,11 @@ extern "C" {
 #define TMF_E_WORKSPACE    -4   /* workspace smaller than *_workspace_bytes() */
 #define TMF_E_ARG          -5   /* bad enum / scalar argument */
 
+/* layout of a convolution weight gradient: tap-major dw[t][cin][cout] (the kernels' own weight layout) or the
+ * reference's nn.Conv3d layout (Cout, Cin, k, k, k) = dw[cout][cin][t], written directly by the final reduction */
+#define TMF_DW_TAPMAJOR  0
+#define TMF_DW_REFERENCE 1
+
 #define TMF_POOL_NONE 0
 #define TMF_POOL_MAX2 1        /* MaxPool3d(2, stride=2), floor mode */
 #define TMF_POOL_AVG2 2        /* AvgPool3d(2, stride=2), floor mode */
@@ -83,7 +88,7 @@ int  tmf_conv3d_fwd_affine(const float* x, const float* w, const float* scale, c
  * Replaces the weight half of aten::convolution_backward for the call sites above. */
 size_t tmf_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, int cin, int cout, int ksize);
 int    tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
-                        int B, int D, int H, int W, int cin, int cout, int ksize, void* stream);
+                        int B, int D, int H, int W, int cin, int cout, int ksize, int dw_layout, void* stream);
 
 /* bf16 matrix-core variant (BASELINE configs[2]: "bf16 with MFMA 3D conv"), 3x3x3 only: fp32 tensors in HBM,
  * operands rounded to bf16 (RNE) on the way into LDS, v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32
@@ -103,7 +108,7 @@ int    tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw, void* w
 int    tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z, float* stat_partial,
                              int B, int D, int H, int W, int cin, int cout, int io, void* stream);
 int    tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
-                               int B, int D, int H, int W, int cin, int cout, int io, void* stream);
+                               int B, int D, int H, int W, int cin, int cout, int io, int dw_layout, void* stream);
 /* fp32-ACCURATE variant on the bf16 matrix cores: operands split exactly into three bf16 numbers (hi+mid+lo), the
  * six partial products of order >= 2^-16 accumulated in fp32 (the dropped terms are below one fp32 ulp of the
  * product).  w3_bf16: bf16 [3 parts][27][cout][cin]; same shapes / statistics layout as tmf_conv3d_fwd_bf16. */
@@ -116,7 +121,7 @@ int    tmf_conv3d_c1_fwd(const float* x, const float* w, float* z, float* stat_p
 int    tmf_conv3d_c1_stat_blocks(int B, int D, int H, int W, int cout);
 size_t tmf_conv3d_c1_wgrad_workspace_bytes(int B, int D, int H, int W, int cout);
 int    tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
-                           int B, int D, int H, int W, int cout, void* stream);
+                           int B, int D, int H, int W, int cout, int dw_layout, void* stream);
 
 /* ------------------------------------------------------------------------------
  * Fused first block: Conv3d(1->C,3x3x3) -> BatchNorm3d -> LeakyReLU -> MaxPool3d(2) (networks.py:21-26)
@@ -138,7 +143,7 @@ size_t tmf_c1_bwd_wgrad_workspace_bytes(int B, int D, int H, int W, int C);
 int    tmf_c1_bwd_wgrad(const float* x, const float* w, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* coef, const float* dpool,
                         float* dw, void* workspace, size_t workspace_bytes,
-                        int B, int D, int H, int W, int C, float slope, void* stream);
+                        int B, int D, int H, int W, int C, float slope, int dw_layout, void* stream);
 /* The same four passes with both products on the bf16 matrix cores (operands rounded to bf16, fp32 accumulation):
  * 2 MFMAs per tile instead of 14 / 16.  Same arguments, same workspace / block counts; pooled_bf16 != 0: the pooled
  * output / its gradient dpool are bf16 tensors (bf16 activation storage, BASELINE configs[2]). */
@@ -151,7 +156,7 @@ int    tmf_c1_bwd_reduce_bf16(const float* x, const float* w, const float* scale
 int    tmf_c1_bwd_wgrad_bf16(const float* x, const float* w, const float* scale, const float* shift,
                              const float* mean, const float* invstd, const float* coef, const void* dpool,
                              float* dw, void* workspace, size_t workspace_bytes,
-                             int B, int D, int H, int W, int C, float slope, int pooled_bf16, void* stream);
+                             int B, int D, int H, int W, int C, float slope, int pooled_bf16, int dw_layout, void* stream);
 
 /* ------------------------------------------------------------------------------
  * BatchNorm3d (training statistics) + LeakyReLU + 2x2x2 pool, two passes.
@@ -269,6 +274,10 @@ int tmf_tok_linear_bwd_input(const float* dy, const float* w, float* dx, int R, 
  * layout w_fwd[t][ci][co] and, when w_dgrad != NULL, the data-gradient layout w_dgrad[taps-1-t][co][ci], in one launch
  * (what the host side otherwise does with permute / flip copies on every step). */
 int tmf_pack_conv_weights(const float* w, float* w_fwd, float* w_dgrad, int cout, int cin, int taps, void* stream);
+/* The same for the bf16 matrix-core kernels: w_fwd_bf16[t][co][ci] = bf16(w[co][ci][t]) (the layout tmf_conv3d_fwd_bf16
+ * reads) and, when w_dgrad_bf16 != NULL, w_dgrad_bf16[taps-1-t][ci][co] (its data-gradient call).  RNE rounding,
+ * bit-identical to torch's .to(bfloat16).  cin (and cout, with a dgrad copy) even. */
+int tmf_pack_conv_weights_bf16(const float* w, void* w_fwd_bf16, void* w_dgrad_bf16, int cout, int cin, int taps, void* stream);
 
 /* Layout conversion between the reference's NCDHW tensors and the channels-last tensors every kernel here uses
  * (voxels = D*H*W).  The model itself never needs it — its input has C == 1 (same bytes either way) and its output
@@ -290,6 +299,60 @@ int tmf_token_pool_fwd(const float* mri, const float* pet, float* cls, int32_t* 
                        int B, int N, int dim, void* stream);
 int tmf_token_pool_bwd(const float* dcls, const int32_t* argmax, float* dmri, float* dpet,
                        int B, int N, int dim, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * Whole-encoder entries (csrc/snet_path.hip): ONE call enqueues every launch of an sNet train-mode forward, or of its
+ * backward.  Replaces, per modality, `self.mri_cnn(mri)` / `self.pet_cnn(pet)` (models/mymodel.py:206-207 ->
+ * networks.py:55-61) and the matching slice of `all_loss.backward()` (kfold_train_adversarial.py:131-132).  Same kernels,
+ * same order and arguments as calling the per-block entries above one by one — bit-identical results — but the host
+ * side of a pass is one call instead of ~100, and every intermediate tensor lives in ONE caller-allocated workspace.
+ *
+ * Network: channels 1 -> dim/4 -> dim/4 -> dim/2 -> dim/2 -> dim -> 2*dim -> dim, 3x3x3 except the last (1x1x1), max
+ * pools after blocks 0, 2, 4 and an average pool after block 6 (TMF_SNET_BLOCKS = 7 blocks).  dim % 32 == 0, every
+ * volume edge >= 16.  precision: TMF_PREC_FP32 (exact fp32 MFMA) or TMF_PREC_BF16 (operands rounded to bf16, fp32
+ * accumulation; storage_bf16 != 0 keeps the activations between the 3x3x3 blocks as bf16 tensors).
+ *
+ * Parameters are the reference's state_dict tensors as they are: weight[l] (Cout, Cin, k, k, k), bias[l] (may be NULL),
+ * gamma / beta = BatchNorm3d weight / bias, running_mean / running_var (updated in place, torch semantics; may be NULL).
+ *   tmf_snet_train_fwd : vol [B][D][H][W] fp32 -> out [B][D/16][H/16][W/16][dim] fp32 (channels-last); `saved`
+ *                        (>= tmf_snet_saved_bytes) receives everything backward needs and must stay untouched until then.
+ *   tmf_snet_train_bwd : dout (same shape as out) -> gradients written into g: dweight[l] in the nn.Conv3d layout,
+ *                        dbias[l] (exact zeros: a bias ahead of batch-statistics BatchNorm), dgamma[l], dbeta[l].  NULL
+ *                        dweight / dbias entries are skipped.  `scratch` >= tmf_snet_bwd_scratch_bytes, free afterwards.
+ * There is no gradient for vol (the network input needs none: kfold_train_adversarial.py:106-107).
+ * ---------------------------------------------------------------------------- */
+#define TMF_SNET_BLOCKS 7
+#define TMF_PREC_FP32 0
+#define TMF_PREC_BF16 1
+typedef struct tmf_snet_desc {
+    int   B, D, H, W;                /* input volumes (B, 1, D, H, W) */
+    int   dim;                       /* sNet(dim) */
+    int   precision;                 /* TMF_PREC_* */
+    int   storage_bf16;              /* bf16 activation storage between the 3x3x3 blocks (TMF_PREC_BF16 only) */
+    float momentum[TMF_SNET_BLOCKS]; /* BatchNorm3d.momentum, .eps and LeakyReLU.negative_slope per block */
+    float eps[TMF_SNET_BLOCKS];
+    float slope[TMF_SNET_BLOCKS];
+} tmf_snet_desc;
+typedef struct tmf_snet_params {
+    const float* weight[TMF_SNET_BLOCKS];
+    const float* bias[TMF_SNET_BLOCKS];
+    const float* gamma[TMF_SNET_BLOCKS];
+    const float* beta[TMF_SNET_BLOCKS];
+    float*       running_mean[TMF_SNET_BLOCKS];
+    float*       running_var[TMF_SNET_BLOCKS];
+} tmf_snet_params;
+typedef struct tmf_snet_grads {
+    float* dweight[TMF_SNET_BLOCKS];
+    float* dbias[TMF_SNET_BLOCKS];
+    float* dgamma[TMF_SNET_BLOCKS];
+    float* dbeta[TMF_SNET_BLOCKS];
+} tmf_snet_grads;
+size_t tmf_snet_saved_bytes(const tmf_snet_desc* d);
+size_t tmf_snet_bwd_scratch_bytes(const tmf_snet_desc* d);
+int    tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, const tmf_snet_params* params,
+                          void* saved, size_t saved_bytes, float* out, void* stream);
+int    tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, const void* saved, size_t saved_bytes,
+                          const float* dout, const tmf_snet_grads* grads, void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -82,6 +82,8 @@ def test_conv3d_wgrad_and_dgrad(shape):
     xg, dzg = _ndhwc(x.detach().float()).to(DEV), _ndhwc(dz).to(DEV)
     dw = ops.unpack_wgrad(ops.conv3d_wgrad(xg, dzg, cin, cout, k), cout, cin, k)
     assert _relerr(dw, w.grad) < 5e-6
+    # TMF_DW_REFERENCE: the final reduction stores the nn.Conv3d layout itself — bit-identical values
+    assert torch.equal(ops.conv3d_wgrad(xg, dzg, cin, cout, k, reference_layout=True), dw)
     if cin > 1:
         dx, _, _ = ops.conv3d_raw(dzg, ops.pack_weight_dgrad(w.detach().float().to(DEV)), cout, cin, k, False)
         assert _relerr(_ncdhw(dx.cpu()), x.grad) < 1e-5
@@ -409,7 +411,10 @@ def test_argument_errors_are_reported_not_launched():
         _lib.call("tmf_conv3d_fwd", x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 1, 1, 1, 1, 8, 8, 2, None)
     with pytest.raises(_lib.TmfError, match="workspace"):
         _lib.call("tmf_conv3d_wgrad", x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 0,
-                  1, 4, 4, 4, 8, 8, 3, None)
+                  1, 4, 4, 4, 8, 8, 3, 0, None)
+    with pytest.raises(_lib.TmfError, match="dw_layout"):
+        _lib.call("tmf_conv3d_wgrad", x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 1 << 20,
+                  1, 4, 4, 4, 8, 8, 3, 7, None)
     with pytest.raises(_lib.TmfError, match="dim_head"):
         _lib.call("tmf_xattn_fwd", x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
                   1, 1, 4, 4, 12, 12, 24, 1.0, None)
@@ -860,9 +865,10 @@ def test_weight_gradients_write_only_output_and_workspace(shape):
     x = torch.randn((B, s, s, s, cin), device=DEV)
     dz = torch.randn((B, s, s, s, cout), device=DEV) * 0.1
     for entry, query, xs, dzs, extra in (
-            ("tmf_conv3d_wgrad", "tmf_conv3d_wgrad_workspace_bytes", x, dz, (3,)),
-            ("tmf_conv3d_wgrad_bf16_t", "tmf_conv3d_wgrad_bf16_workspace_bytes", x.bfloat16(), dz.bfloat16(), (1,))):
-        nbytes = _lib.query(query, B, s, s, s, cin, cout, *(extra if entry == "tmf_conv3d_wgrad" else ()))
+            ("tmf_conv3d_wgrad", "tmf_conv3d_wgrad_workspace_bytes", x, dz, (3, 0)),
+            ("tmf_conv3d_wgrad", "tmf_conv3d_wgrad_workspace_bytes", x, dz, (3, 1)),          # reference-layout stores
+            ("tmf_conv3d_wgrad_bf16_t", "tmf_conv3d_wgrad_bf16_workspace_bytes", x.bfloat16(), dz.bfloat16(), (1, 1))):
+        nbytes = _lib.query(query, B, s, s, s, cin, cout, *((3,) if entry == "tmf_conv3d_wgrad" else ()))
         nws, ndw = max(nbytes, 16) // 4, 27 * cin * cout
         wbig = torch.full((nws + 2 * pad,), sent, device=DEV)
         dbig = torch.full((ndw + 2 * pad,), sent, device=DEV)

@@ -645,3 +645,47 @@ def test_train_step_is_bit_reproducible_with_two_streams(mode):
     finally:
         T.set_conv_precision("fp32")
         T.set_activation_storage("fp32")
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16s"])
+@pytest.mark.parametrize("name", ["ad_ragged", "ad_mid"])
+def test_one_call_encoder_is_bit_identical_to_block_by_block(name, mode):
+    """tmf_snet_train_fwd / _bwd (one library call per encoder pass, csrc/snet_path.hip) enqueue exactly the launches of
+    the block-by-block path: logits, loss, every gradient and every BatchNorm buffer are bit-identical."""
+    import transmf_ad_amd as T
+    from transmf_ad_amd import ops
+    g = Golden(name)
+    T.set_conv_precision("fp32" if mode == "fp32" else "bf16")
+    T.set_activation_storage("bf16" if mode == "bf16s" else "fp32")
+    res = []
+    try:
+        for one_call in (True, False):
+            ops.SNET_ONE_CALL = one_call
+            net = build(g)
+            used = []
+            orig = ops.SNetTrain.apply
+            outs, loss = step(net, g, train=True)
+            res.append((outs, loss, {k: p.grad.clone() for k, p in net.named_parameters()},
+                        {k: b.clone() for k, b in net.named_buffers()}))
+    finally:
+        ops.SNET_ONE_CALL = True
+        T.set_activation_storage("fp32")
+        T.set_conv_precision("fp32")
+    (o1, l1, g1, b1), (o2, l2, g2, b2) = res
+    assert torch.equal(l1, l2)
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    for k in b1:
+        assert torch.equal(b1[k], b2[k]), k
+
+
+def test_one_call_encoder_is_taken_by_default():
+    """The drop-in sNet in train mode goes through ONE autograd node (ops.SNetTrain), not seven."""
+    import transmf_ad_amd as T
+    g = Golden("ad_tiny")
+    net = build(g).train()
+    mri, _pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+    out = net.mri_cnn(mri)
+    assert type(out.grad_fn.next_functions[0][0]).__name__.startswith("SNetTrain"), out.grad_fn.next_functions

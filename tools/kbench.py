@@ -93,7 +93,7 @@ def main():
                 f["wgrad"] = timeit(lambda: _lib.call("tmf_c1_bwd_wgrad", xi.data_ptr(), wp1.data_ptr(), sc.data_ptr(),
                                                       sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), coef.data_ptr(),
                                                       out.data_ptr(), dwo.data_ptr(), ws1.data_ptr(), nby,
-                                                      a.B, s, s, s, cout, 0.01, st), a.reps)
+                                                      a.B, s, s, s, cout, 0.01, 0, st), a.reps)
                 r["fused_c1_ms"] = f
                 print(f"   fused conv1 block: stats {f['stats']:.3f} fwd {f['fwd']:.3f} reduce {f['reduce']:.3f} "
                       f"wgrad {f['wgrad']:.3f}  sum {sum(f.values()):.3f} ms  (unfused sum "

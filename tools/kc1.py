@@ -24,5 +24,5 @@ for _ in range(3):
     _lib.call("tmf_c1_bwd_reduce", x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(),
               out.data_ptr(), part.data_ptr(), B, S, S, S, C, 0.01, st)
     _lib.call("tmf_c1_bwd_wgrad", x.data_ptr(), w.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(),
-              coef.data_ptr(), out.data_ptr(), dw.data_ptr(), ws.data_ptr(), nby, B, S, S, S, C, 0.01, st)
+              coef.data_ptr(), out.data_ptr(), dw.data_ptr(), ws.data_ptr(), nby, B, S, S, S, C, 0.01, 0, st)
 torch.cuda.synchronize()

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtmf_hip.so")
 
 POOL_NONE, POOL_MAX2, POOL_AVG2 = 0, 1, 2
+DW_TAPMAJOR, DW_REFERENCE = 0, 1
 _POOL = {None: POOL_NONE, "none": POOL_NONE, "max": POOL_MAX2, "avg": POOL_AVG2}
 
 _p = C.c_void_p
@@ -32,7 +33,7 @@ PROTOTYPES = {
     "tmf_conv3d_fwd_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
-    "tmf_conv3d_wgrad": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tmf_conv3d_wgrad": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tmf_conv3d_fwd_bf16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "tmf_conv3d_wgrad_bf16_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad_bf16": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),
@@ -41,7 +42,7 @@ PROTOTYPES = {
     "tmf_conv3d_c1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tmf_conv3d_c1_stat_blocks": (_i, [_i, _i, _i, _i, _i]),
     "tmf_conv3d_c1_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
-    "tmf_conv3d_c1_wgrad": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
+    "tmf_conv3d_c1_wgrad": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),
     "tmf_c1_blocks": (_i, [_i, _i, _i, _i, _i]),
     "tmf_c1_stats": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tmf_c1_bn_pool_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
@@ -49,14 +50,14 @@ PROTOTYPES = {
     "tmf_c1_stats_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tmf_c1_bn_pool_fwd_bf16": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
     "tmf_c1_bwd_reduce_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _i, _p]),
-    "tmf_c1_bwd_wgrad_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "tmf_c1_bwd_wgrad_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "tmf_conv3d_fwd_bf16_t": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "tmf_conv3d_wgrad_bf16_t": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "tmf_conv3d_wgrad_bf16_t": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tmf_bn_act_pool_fwd_t": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "tmf_bn_act_pool_bwd_reduce_t": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "tmf_bn_act_pool_bwd_apply_t": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _i, _p]),
     "tmf_c1_bwd_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
-    "tmf_c1_bwd_wgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _p]),
+    "tmf_c1_bwd_wgrad": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _i, _p]),
     "tmf_bn_finalize": (_i, [_p, _i, _i, _d, _p, _p, _p, _p, _p, _f, _f, _p, _p, _p, _p, _p]),
     "tmf_bn_eval_coeffs": (_i, [_p, _p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "tmf_bn_act_pool_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _f, _p]),
@@ -69,6 +70,7 @@ PROTOTYPES = {
     "tmf_xattn_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_layernorm_fwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _f, _p]),
     "tmf_pack_conv_weights": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "tmf_pack_conv_weights_bf16": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "tmf_layout_ncdhw_to_ndhwc": (_i, [_p, _p, _i, _i, _l, _p]),
     "tmf_layout_ndhwc_to_ncdhw": (_i, [_p, _p, _i, _i, _l, _p]),
     "tmf_tok_row_blocks": (_i, [_i]),
@@ -81,6 +83,30 @@ PROTOTYPES = {
     "tmf_token_pool_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
     "tmf_token_pool_bwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _p]),
 }
+
+
+
+class SnetDesc(C.Structure):
+    """tmf_snet_desc (include/tmf_hip.h)"""
+    _fields_ = [("B", _i), ("D", _i), ("H", _i), ("W", _i), ("dim", _i), ("precision", _i), ("storage_bf16", _i),
+                ("momentum", _f * 7), ("eps", _f * 7), ("slope", _f * 7)]
+
+
+class SnetParams(C.Structure):
+    _fields_ = [("weight", _p * 7), ("bias", _p * 7), ("gamma", _p * 7), ("beta", _p * 7),
+                ("running_mean", _p * 7), ("running_var", _p * 7)]
+
+
+class SnetGrads(C.Structure):
+    _fields_ = [("dweight", _p * 7), ("dbias", _p * 7), ("dgamma", _p * 7), ("dbeta", _p * 7)]
+
+
+PROTOTYPES.update({
+    "tmf_snet_saved_bytes": (_z, [C.POINTER(SnetDesc)]),
+    "tmf_snet_bwd_scratch_bytes": (_z, [C.POINTER(SnetDesc)]),
+    "tmf_snet_train_fwd": (_i, [C.POINTER(SnetDesc), _p, C.POINTER(SnetParams), _p, _z, _p, _p]),
+    "tmf_snet_train_bwd": (_i, [C.POINTER(SnetDesc), _p, _p, _z, _p, C.POINTER(SnetGrads), _p, _z, _p]),
+})
 
 _lib = None
 

@@ -599,6 +599,6 @@ extern "C" int tmf_colsum_finalize(const float* partial, int nblk, int ncol, flo
     TMF_REQUIRE(nblk > 0 && ncol > 0, TMF_E_SHAPE, "tmf_colsum_finalize: nblk=%d ncol=%d", nblk, ncol);
     const dim3 block(64 * TMF_RED_LANES);
     hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(tmf_cdiv(ncol, 64), 1), block, 0, (hipStream_t)stream,
-                       partial, out, nblk, (long)ncol, nblk);
+                       partial, out, nblk, (long)ncol, nblk, 0, 0);
     return tmf_launch_result("tmf_colsum_finalize");
 }

@@ -485,7 +485,9 @@ extern "C" size_t tmf_c1_bwd_wgrad_workspace_bytes(int B, int D, int H, int W, i
 static int c1_bwd_wgrad(bool bf16, bool p16, const float* x, const float* w, const float* scale, const float* shift,
                         const float* mean, const float* invstd, const float* coef, const void* dpool,
                         float* dw, void* workspace, size_t workspace_bytes,
-                        int B, int D, int H, int W, int C, float slope, void* stream) {
+                        int B, int D, int H, int W, int C, float slope, int dw_layout, void* stream) {
+    TMF_REQUIRE(dw_layout == TMF_DW_TAPMAJOR || dw_layout == TMF_DW_REFERENCE, TMF_E_ARG,
+                "tmf_c1_bwd_wgrad: unknown dw_layout %d", dw_layout);
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(mean);
     TMF_REQUIRE_PTR(invstd); TMF_REQUIRE_PTR(coef); TMF_REQUIRE_PTR(dpool); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
     int rc = check("tmf_c1_bwd_wgrad", B, D, H, W, C);
@@ -505,20 +507,21 @@ static int c1_bwd_wgrad(bool bf16, bool p16, const float* x, const float* w, con
     if ((rc = tmf_launch_result("tmf_c1_bwd_wgrad"))) return rc;
     const long n = 27L * C;
     return tmf_reduce_slabs((const float*)workspace, p.nblk, n, (float*)workspace + (size_t)p.nblk * n, dw, s,
-                            "tmf_c1_bwd_wgrad(reduce)");
+                            "tmf_c1_bwd_wgrad(reduce)", dw_layout == TMF_DW_REFERENCE ? 1 : 0, C);
 }
 
 extern "C" int tmf_c1_bwd_wgrad(const float* x, const float* w, const float* scale, const float* shift,
                                 const float* mean, const float* invstd, const float* coef, const float* dpool,
                                 float* dw, void* workspace, size_t workspace_bytes,
-                                int B, int D, int H, int W, int C, float slope, void* stream) {
+                                int B, int D, int H, int W, int C, float slope, int dw_layout, void* stream) {
     return c1_bwd_wgrad(false, false, x, w, scale, shift, mean, invstd, coef, dpool, dw, workspace, workspace_bytes, B, D, H, W,
-                        C, slope, stream);
+                        C, slope, dw_layout, stream);
 }
 extern "C" int tmf_c1_bwd_wgrad_bf16(const float* x, const float* w, const float* scale, const float* shift,
                                      const float* mean, const float* invstd, const float* coef, const void* dpool,
                                      float* dw, void* workspace, size_t workspace_bytes,
-                                     int B, int D, int H, int W, int C, float slope, int pooled_bf16, void* stream) {
+                                     int B, int D, int H, int W, int C, float slope, int pooled_bf16, int dw_layout,
+                                     void* stream) {
     return c1_bwd_wgrad(true, pooled_bf16 != 0, x, w, scale, shift, mean, invstd, coef, dpool, dw, workspace, workspace_bytes,
-                        B, D, H, W, C, slope, stream);
+                        B, D, H, W, C, slope, dw_layout, stream);
 }

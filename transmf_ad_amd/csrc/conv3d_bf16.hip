@@ -815,7 +815,9 @@ extern "C" size_t tmf_conv3d_wgrad_bf16_workspace_bytes(int B, int D, int H, int
 }
 
 extern "C" int tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
-                                       int B, int D, int H, int W, int cin, int cout, int io, void* stream) {
+                                       int B, int D, int H, int W, int cin, int cout, int io, int dw_layout, void* stream) {
+    TMF_REQUIRE(dw_layout == TMF_DW_TAPMAJOR || dw_layout == TMF_DW_REFERENCE, TMF_E_ARG,
+                "tmf_conv3d_wgrad_bf16: unknown dw_layout %d", dw_layout);
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(dz); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
                 "tmf_conv3d_wgrad_bf16: non-positive dimension");
@@ -842,10 +844,11 @@ extern "C" int tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw,
     }
     if ((rc = tmf_launch_result("tmf_conv3d_wgrad_bf16"))) return rc;
     const long n = 27L * cin * cout;
-    return tmf_reduce_slabs(partial, p.nsplit, n, partial + (size_t)p.nsplit * n, dw, s, "tmf_conv3d_wgrad_bf16(reduce)");
+    return tmf_reduce_slabs(partial, p.nsplit, n, partial + (size_t)p.nsplit * n, dw, s, "tmf_conv3d_wgrad_bf16(reduce)",
+                            dw_layout == TMF_DW_REFERENCE ? cin : 0, cout);
 }
 
 extern "C" int tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
                                      int B, int D, int H, int W, int cin, int cout, void* stream) {
-    return tmf_conv3d_wgrad_bf16_t(x, dz, dw, workspace, workspace_bytes, B, D, H, W, cin, cout, 0, stream);
+    return tmf_conv3d_wgrad_bf16_t(x, dz, dw, workspace, workspace_bytes, B, D, H, W, cin, cout, 0, TMF_DW_TAPMAJOR, stream);
 }

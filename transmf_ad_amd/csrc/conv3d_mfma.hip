@@ -1646,7 +1646,9 @@ extern "C" size_t tmf_conv3d_wgrad_workspace_bytes(int B, int D, int H, int W, i
 
 extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void* workspace,
                                 size_t workspace_bytes, int B, int D, int H, int W, int cin, int cout,
-                                int ksize, void* stream) {
+                                int ksize, int dw_layout, void* stream) {
+    TMF_REQUIRE(dw_layout == TMF_DW_TAPMAJOR || dw_layout == TMF_DW_REFERENCE, TMF_E_ARG,
+                "tmf_conv3d_wgrad: unknown dw_layout %d", dw_layout);
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(dz); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
                 "tmf_conv3d_wgrad: non-positive dimension");
@@ -1711,7 +1713,8 @@ extern "C" int tmf_conv3d_wgrad(const float* x, const float* dz, float* dw, void
         nelem = (long)cin * cout;
         nsplit = p.nsplit;
     }
-    return tmf_reduce_slabs(partial, nsplit, nelem, partial + (size_t)nsplit * nelem, dw, s, "tmf_conv3d_wgrad(reduce)");
+    return tmf_reduce_slabs(partial, nsplit, nelem, partial + (size_t)nsplit * nelem, dw, s, "tmf_conv3d_wgrad(reduce)",
+                            dw_layout == TMF_DW_REFERENCE ? cin : 0, cout);
 }
 
 extern "C" int tmf_conv3d_c1_stat_blocks(int B, int D, int H, int W, int cout) {
@@ -1737,7 +1740,10 @@ extern "C" size_t tmf_conv3d_c1_wgrad_workspace_bytes(int B, int D, int H, int W
 }
 
 extern "C" int tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* workspace,
-                                   size_t workspace_bytes, int B, int D, int H, int W, int cout, void* stream) {
+                                   size_t workspace_bytes, int B, int D, int H, int W, int cout, int dw_layout,
+                                   void* stream) {
+    TMF_REQUIRE(dw_layout == TMF_DW_TAPMAJOR || dw_layout == TMF_DW_REFERENCE, TMF_E_ARG,
+                "tmf_conv3d_c1_wgrad: unknown dw_layout %d", dw_layout);
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(dz); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cout > 0, TMF_E_SHAPE, "tmf_conv3d_c1_wgrad: non-positive dimension");
     const size_t need = tmf_conv3d_c1_wgrad_workspace_bytes(B, D, H, W, cout);
@@ -1753,5 +1759,5 @@ extern "C" int tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, v
     if ((rc = tmf_launch_result("tmf_conv3d_c1_wgrad"))) return rc;
     const long nelem = 27L * cout;
     return tmf_reduce_slabs(partial, p.nblk * 4, nelem, partial + (size_t)p.nblk * 4 * nelem, dw, s,
-                            "tmf_conv3d_c1_wgrad(reduce)");
+                            "tmf_conv3d_c1_wgrad(reduce)", dw_layout == TMF_DW_REFERENCE ? 1 : 0, cout);
 }

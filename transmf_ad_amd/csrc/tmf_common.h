@@ -165,8 +165,12 @@ __device__ __forceinline__ int xcd_contiguous(int bid, int n) {
 // out[g][e] = sum over the slabs s of group g of partial[s][e]   (fixed order -> deterministic; fp64
 // accumulation: the sums cancel heavily).  Block = 64 consecutive elements x TMF_RED_LANES slab lanes.
 #define TMF_RED_LANES 16
+// tcin > 0: the n = T * cin * cout sums are a tap-major weight gradient [t][ci][co] and are stored in the reference's
+// nn.Conv3d layout (Cout, Cin, k, k, k) = [co][ci][t] instead (T = n / (tcin * tcout)); <= 3.5 MB, the scattered
+// 4-byte stores are noise next to the slab reads.
 static __global__ __launch_bounds__(64 * TMF_RED_LANES) void tmf_slab_reduce_kernel(
-    const float* __restrict__ partial, float* __restrict__ out, int nsplit, long n, int slabs_per_group) {
+    const float* __restrict__ partial, float* __restrict__ out, int nsplit, long n, int slabs_per_group,
+    int tcin = 0, int tcout = 0) {
     __shared__ double red[TMF_RED_LANES][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const long e = (long)blockIdx.x * 64 + tx;
@@ -191,7 +195,13 @@ static __global__ __launch_bounds__(64 * TMF_RED_LANES) void tmf_slab_reduce_ker
     if (ty == 0 && e < n) {
 #pragma unroll
         for (int k = 1; k < TMF_RED_LANES; ++k) a += red[k][tx];
-        out[(size_t)g * n + e] = (float)a;
+        size_t o = (size_t)g * n + e;
+        if (tcin > 0) {
+            const int co = (int)(e % tcout), ci = (int)((e / tcout) % tcin), t = (int)(e / ((long)tcout * tcin));
+            const int T = (int)(n / ((long)tcin * tcout));
+            o = ((size_t)co * tcin + ci) * T + t;
+        }
+        out[o] = (float)a;
     }
 }
 
@@ -208,20 +218,21 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // Reduce `nsplit` slabs of `n` floats into out[n].  `scratch` (>= tmf_reduce_groups(nsplit)*n floats) is only
 // touched when the plan has two stages.
+// tcin / tcout > 0 (weight gradients, dw_layout == TMF_DW_REFERENCE): the final stage stores in the nn.Conv3d layout.
 static inline int tmf_reduce_slabs(const float* partial, int nsplit, long n, float* scratch, float* out,
-                                   hipStream_t s, const char* what) {
+                                   hipStream_t s, const char* what, int tcin = 0, int tcout = 0) {
     const int G = tmf_reduce_groups(nsplit);
     const dim3 block(64 * TMF_RED_LANES);
     const int gx = (int)((n + 63) / 64);
     if (G == 1) {
-        hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, 1), block, 0, s, partial, out, nsplit, n, nsplit);
+        hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, 1), block, 0, s, partial, out, nsplit, n, nsplit, tcin, tcout);
         return tmf_launch_result(what);
     }
     const int spg = (nsplit + G - 1) / G;
-    hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, G), block, 0, s, partial, scratch, nsplit, n, spg);
+    hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, G), block, 0, s, partial, scratch, nsplit, n, spg, 0, 0);
     int rc = tmf_launch_result(what);
     if (rc) return rc;
-    hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, 1), block, 0, s, (const float*)scratch, out, G, n, G);
+    hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, 1), block, 0, s, (const float*)scratch, out, G, n, G, tcin, tcout);
     return tmf_launch_result(what);
 }
 #endif

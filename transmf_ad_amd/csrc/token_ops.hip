@@ -201,6 +201,31 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
     }
 }
 
+// The bf16 matrix-core kernels' weight layouts from the reference tensor, in ONE launch (what the host side did with
+// permute / flip / contiguous / to(bfloat16) copies — several launches per layer and step):
+//   fwd16  [t][co][ci]       = bf16(w[co][ci][t])     (B operand rows = output channel, K = input channel contiguous)
+//   dgrad16[T-1-t][ci][co]   = bf16(w[co][ci][t])     (the same kernel computing the data gradient)
+// One thread per PAIR of consecutive output elements (one 4-byte store); cin and cout are even.
+__global__ __launch_bounds__(256) void pack_conv_weights_bf16_kernel(const float* __restrict__ w, unsigned int* __restrict__ fwd,
+                                                                     unsigned int* __restrict__ dgrad, int cout, int cin, int T) {
+    const long n2 = (long)cout * cin * T / 2;
+    long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p < n2) {
+        const long e = 2 * p;
+        const int ci = e % cin, co = (e / cin) % cout, t = e / ((long)cin * cout);
+        const float* src = w + ((long)co * cin + ci) * T + t;
+        fwd[p] = tmf_pack_bf16(src[0], src[T]);
+        return;
+    }
+    p -= n2;
+    if (dgrad != nullptr && p < n2) {
+        const long e = 2 * p;
+        const int co = e % cout, ci = (e / cout) % cin, tr = e / ((long)cin * cout);
+        const float* src = w + ((long)co * cin + ci) * T + (T - 1 - tr);
+        dgrad[p] = tmf_pack_bf16(src[0], src[(long)cin * T]);
+    }
+}
+
 // [B][R][C] <-> [B][C][R] through a 32 x 33 LDS tile (both sides coalesced); R = D*H*W voxels, C channels
 __global__ __launch_bounds__(256) void transpose_tile_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                              int rows, int cols, int tiles_c) {
@@ -237,6 +262,20 @@ extern "C" int tmf_pack_conv_weights(const float* w, float* w_fwd, float* w_dgra
     hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((unsigned)tmf_cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream,
                        w, w_fwd, w_dgrad, cout, cin, taps);
     return tmf_launch_result("tmf_pack_conv_weights");
+}
+
+extern "C" int tmf_pack_conv_weights_bf16(const float* w, void* w_fwd_bf16, void* w_dgrad_bf16, int cout, int cin, int taps,
+                                          void* stream) {
+    TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(w_fwd_bf16);
+    TMF_REQUIRE(cout > 0 && cin > 0 && (taps == 1 || taps == 27), TMF_E_SHAPE,
+                "tmf_pack_conv_weights_bf16: cout=%d cin=%d taps=%d", cout, cin, taps);
+    TMF_REQUIRE(cin % 2 == 0 && (w_dgrad_bf16 == nullptr || cout % 2 == 0), TMF_E_SHAPE,
+                "tmf_pack_conv_weights_bf16: channel counts must be even (cin=%d cout=%d)", cin, cout);
+    const long n2 = (long)cout * cin * taps / 2;
+    const long total = w_dgrad_bf16 != nullptr ? 2 * n2 : n2;
+    hipLaunchKernelGGL(pack_conv_weights_bf16_kernel, dim3((unsigned)tmf_cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream,
+                       w, (unsigned int*)w_fwd_bf16, (unsigned int*)w_dgrad_bf16, cout, cin, taps);
+    return tmf_launch_result("tmf_pack_conv_weights_bf16");
 }
 
 extern "C" int tmf_layout_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, long voxels, void* stream) {

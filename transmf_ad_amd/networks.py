@@ -73,6 +73,15 @@ class sNet(nn.Module):
                    if getattr(self, n)[i + 1].track_running_stats]
             if nbt:
                 torch._foreach_add_(nbt, 1)
+        blocks = [(getattr(self, n)[i], getattr(self, n)[i + 1], getattr(self, n)[i + 2]) for n, i, _ in self._PLAN]
+        if self._one_call_ok(vol, blocks):
+            params, buffers = [], []
+            for conv, bn, _act in blocks:
+                params += [conv.weight, conv.bias, bn.weight, bn.bias]
+                buffers.append((bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None))
+            cfg = (blocks[-1][0].out_channels, tuple(float(bn.momentum) for _c, bn, _a in blocks),
+                   tuple(float(bn.eps) for _c, bn, _a in blocks), tuple(float(a.negative_slope) for _c, _b, a in blocks))
+            return ops.SNetTrain.apply(vol, cfg, buffers, *params)
         store16 = ops.activation_storage_bf16()
         for n_blk, (seq_name, i, pool) in enumerate(self._PLAN):
             seq = getattr(self, seq_name)
@@ -92,6 +101,24 @@ class sNet(nn.Module):
                                      momentum=momentum, eps=bn.eps, slope=act.negative_slope, pool=pool,
                                      out_bf16=out16)
         return x                                 # (B, d, h, w, dim)
+
+    def _one_call_ok(self, vol, blocks):
+        """Train-mode batch statistics in every block, the standard sNet(dim) geometry, no gradient wanted for the
+        input: the whole pass is one library call (ops.SNetTrain); anything else goes block by block."""
+        if vol.requires_grad or not vol.is_cuda or vol.dtype != torch.float32:
+            return False
+        B, _, D, H, W = vol.shape
+        dim = blocks[-1][0].out_channels
+        if not ops.snet_one_call_supported(B, D, H, W, dim):
+            return False
+        q, h = dim // 4, dim // 2
+        want = ((1, q, 3), (q, q, 3), (q, h, 3), (h, h, 3), (h, dim, 3), (dim, 2 * dim, 3), (2 * dim, dim, 1))
+        for (conv, bn, _act), (ci, co, k) in zip(blocks, want):
+            if (conv.in_channels, conv.out_channels, conv.kernel_size) != (ci, co, (k, k, k)):
+                return False
+            if not (self.training or not bn.track_running_stats) or bn.momentum is None or not bn.affine:
+                return False
+        return True
 
     def forward(self, mri):
         return self.forward_channels_last(mri).permute(0, 4, 1, 2, 3)

@@ -113,6 +113,15 @@ def pack_weight_bf16(weight: torch.Tensor) -> torch.Tensor:
     return weight.permute(2, 3, 4, 0, 1).contiguous().to(torch.bfloat16)
 
 
+def pack_weights_both_bf16(weight: torch.Tensor, want_dgrad: bool):
+    """pack_weight_bf16 and (optionally) pack_weight_dgrad_bf16 of one weight tensor in ONE launch."""
+    cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    wf = torch.empty((k ** 3, cout, cin), device=weight.device, dtype=torch.bfloat16)
+    wd = torch.empty((k ** 3, cin, cout), device=weight.device, dtype=torch.bfloat16) if want_dgrad else None
+    _lib.call("tmf_pack_conv_weights_bf16", weight.data_ptr(), wf.data_ptr(), _ptr(wd), cout, cin, k ** 3, _stream())
+    return wf, wd
+
+
 def pack_weight_dgrad_bf16(weight: torch.Tensor) -> torch.Tensor:
     """Data-gradient weights, bf16 [27][Cin][Cout]: w'[26-t][ci][co] = w[co][ci][t]."""
     return weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous().to(torch.bfloat16)
@@ -175,33 +184,35 @@ def conv3d_raw(x, w_packed, cin, cout, ksize, want_stats):
     return z, part, nblk
 
 
-def conv3d_wgrad_bf16(x, dz, cin, cout):
-    """tap-major weight gradient [27][cin][cout] on the bf16 matrix cores (operands rounded to bf16)."""
+def conv3d_wgrad_bf16(x, dz, cin, cout, reference_layout=False):
+    """weight gradient on the bf16 matrix cores (operands rounded to bf16): tap-major [27][cin][cout], or
+    (reference_layout) the nn.Conv3d layout (cout, cin, 3, 3, 3) written directly by the final reduction."""
     B, D, H, W = x.shape[:4]
-    dw = torch.empty((27, cin, cout), device=x.device, dtype=_f32)
+    dw = torch.empty((cout, cin, 3, 3, 3) if reference_layout else (27, cin, cout), device=x.device, dtype=_f32)
     nbytes = _lib.query("tmf_conv3d_wgrad_bf16_workspace_bytes", B, D, H, W, cin, cout)
     ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=_f32)
     if x.dtype != dz.dtype:                      # mixed storage (not produced by sNet): widen the bf16 side
         x, dz = x.float(), dz.float()
     _lib.call("tmf_conv3d_wgrad_bf16_t", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
-              B, D, H, W, cin, cout, 1 if x.dtype == _b16 else 0, _stream())
+              B, D, H, W, cin, cout, 1 if x.dtype == _b16 else 0, int(reference_layout), _stream())
     return dw
 
 
-def conv3d_wgrad(x, dz, cin, cout, ksize):
-    """tap-major weight gradient [k^3][cin][cout]."""
+def conv3d_wgrad(x, dz, cin, cout, ksize, reference_layout=False):
+    """weight gradient: tap-major [k^3][cin][cout], or (reference_layout) nn.Conv3d's (cout, cin, k, k, k)."""
     B, D, H, W = x.shape[:4]
-    dw = torch.empty((ksize ** 3, cin, cout), device=x.device, dtype=_f32)
+    dw = torch.empty((cout, cin, ksize, ksize, ksize) if reference_layout else (ksize ** 3, cin, cout),
+                     device=x.device, dtype=_f32)
     if cin == 1 and ksize == 3:
         nbytes = _lib.query("tmf_conv3d_c1_wgrad_workspace_bytes", B, D, H, W, cout)
         ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=_f32)
         _lib.call("tmf_conv3d_c1_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
-                  B, D, H, W, cout, _stream())
+                  B, D, H, W, cout, int(reference_layout), _stream())
     else:
         nbytes = _lib.query("tmf_conv3d_wgrad_workspace_bytes", B, D, H, W, cin, cout, ksize)
         ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=_f32)
         _lib.call("tmf_conv3d_wgrad", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
-                  B, D, H, W, cin, cout, ksize, _stream())
+                  B, D, H, W, cin, cout, ksize, int(reference_layout), _stream())
     return dw
 
 
@@ -232,10 +243,12 @@ class ConvBnActPool(torch.autograd.Function):
         wf = wd = None
         if not bf16:                      # both weight layouts in one launch; the dgrad one is kept for backward
             wf, wd = pack_weights_both(weight, ctx.needs_input_grad[0])
+        elif bf16 == "bf16":
+            wf, wd = pack_weights_both_bf16(weight, ctx.needs_input_grad[0] and cout % 8 == 0)
 
         def conv(stats):
             if bf16 == "bf16":
-                return conv3d_bf16_raw(x, pack_weight_bf16(weight), cin, cout, stats, out_bf16=z16)
+                return conv3d_bf16_raw(x, wf, cin, cout, stats, out_bf16=z16)
             if bf16 == "fp32x":
                 return conv3d_split_raw(x, split3_bf16(weight.permute(2, 3, 4, 0, 1).contiguous()), cin, cout, stats)
             return conv3d_raw(x, wf, cin, cout, k, stats)
@@ -307,13 +320,13 @@ class ConvBnActPool(torch.autograd.Function):
         dweight = None
         if ctx.needs_input_grad[1]:
             if ctx.bf16 == "bf16":
-                dweight = unpack_wgrad(conv3d_wgrad_bf16(x, dz, cin, cout), cout, cin, k)
+                dweight = conv3d_wgrad_bf16(x, dz, cin, cout, reference_layout=True)
             else:
-                dweight = unpack_wgrad(conv3d_wgrad(x, dz, cin, cout, k), cout, cin, k)
+                dweight = conv3d_wgrad(x, dz, cin, cout, k, reference_layout=True)
         dx = None
         if ctx.needs_input_grad[0]:
             if ctx.bf16 == "bf16" and cout % 8 == 0:
-                dx, _, _ = conv3d_bf16_raw(dz, pack_weight_dgrad_bf16(weight), cout, cin, False, out_bf16=x.dtype == _b16)
+                dx, _, _ = conv3d_bf16_raw(dz, weight, cout, cin, False, out_bf16=x.dtype == _b16)    # weight = packed wd
             elif ctx.bf16 == "fp32x" and cout % 8 == 0:
                 w3 = split3_bf16(weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())
                 dx, _, _ = conv3d_split_raw(dz, w3, cout, cin, False)
@@ -396,11 +409,10 @@ class Conv1BnPool(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             nbytes = _lib.query("tmf_c1_bwd_wgrad_workspace_bytes", B, D, H, W, C)
             ws = torch.empty((max(nbytes, 16) // 4,), device=dev, dtype=_f32)
-            dw = torch.empty((27, C), device=dev, dtype=_f32)
+            dweight = torch.empty((C, 1, 3, 3, 3), device=dev, dtype=_f32)       # written in the reference layout
             _lib.call("tmf_c1_bwd_wgrad" + sfx, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                      mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dout.data_ptr(), dw.data_ptr(),
-                      ws.data_ptr(), nbytes, B, D, H, W, C, slope, *p16, s)
-            dweight = unpack_wgrad(dw, C, 1, 3)
+                      mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), dout.data_ptr(), dweight.data_ptr(),
+                      ws.data_ptr(), nbytes, B, D, H, W, C, slope, *p16, _lib.DW_REFERENCE, s)
         if ctx.needs_input_grad[0]:
             raise _lib.TmfError("the fused first block has no data gradient (the network input needs none)")
         return (None, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
@@ -446,6 +458,82 @@ def conv_bn_act_pool(x, weight, bias, gamma, beta, running_mean, running_var, tr
     y = ConvBnActPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
                             training, momentum, eps, slope, pool, can16)
     return y.to(_b16) if (out_bf16 and not can16) else y
+
+
+# --------------------------------------------------------------------------------------
+# whole encoder in one call per pass                                   (networks.py:55-61)
+# --------------------------------------------------------------------------------------
+
+# False / TMF_SNET_C=0: every block is its own autograd.Function issued from Python (kept for A/B runs and tests)
+SNET_ONE_CALL = os.environ.get("TMF_SNET_C", "1") != "0"
+
+
+def snet_one_call_supported(B, D, H, W, dim):
+    return (SNET_ONE_CALL and _PRECISION in ("fp32", "bf16") and dim >= 32 and dim % 32 == 0
+            and min(D, H, W) >= 16 and B > 0)
+
+
+class SNetTrain(torch.autograd.Function):
+    """Train-mode sNet forward / backward as ONE library call each (tmf_snet_train_fwd / _bwd: csrc/snet_path.hip): the
+    same kernels in the same order as the block-by-block path, every intermediate tensor inside one workspace tensor,
+    weight gradients written in the reference layout.  forward(vol (B,1,D,H,W), cfg, buffers, *params) with params =
+    7 x (conv weight, conv bias | None, bn weight, bn bias) -> (B, d, h, w, dim) channels-last."""
+
+    @staticmethod
+    def forward(ctx, vol, cfg, buffers, *params):
+        import ctypes as C
+        vol = _chk(vol, "vol")
+        dim, momentum, eps, slope = cfg
+        B, _, D, H, W = vol.shape
+        desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision=1 if _PRECISION == "bf16" else 0,
+                             storage_bf16=int(activation_storage_bf16()))
+        prm = _lib.SnetParams()
+        for l in range(7):
+            desc.momentum[l], desc.eps[l], desc.slope[l] = momentum[l], eps[l], slope[l]
+            w, b, g, be = params[4 * l:4 * l + 4]
+            rm, rv = buffers[l]
+            for t, name in ((w, "conv weight"), (g, "BatchNorm weight"), (be, "BatchNorm bias")):
+                if not (t.is_cuda and t.dtype == _f32 and t.is_contiguous()):
+                    raise _lib.TmfError(f"sNet block {l}: {name} must be a contiguous float32 tensor on the HIP device")
+            prm.weight[l], prm.bias[l], prm.gamma[l], prm.beta[l] = w.data_ptr(), _ptr(b), g.data_ptr(), be.data_ptr()
+            prm.running_mean[l], prm.running_var[l] = _ptr(rm), _ptr(rv)
+        nsaved = _lib.query("tmf_snet_saved_bytes", C.byref(desc))
+        if nsaved == 0:
+            raise _lib.TmfError("tmf_snet_saved_bytes: " + (_lib.load().tmf_last_error_string() or b"").decode())
+        saved = torch.empty(nsaved, device=vol.device, dtype=torch.uint8)
+        out = torch.empty((B, D // 16, H // 16, W // 16, dim), device=vol.device, dtype=_f32)
+        _lib.call("tmf_snet_train_fwd", C.byref(desc), vol.data_ptr(), C.byref(prm), saved.data_ptr(), nsaved,
+                  out.data_ptr(), _stream())
+        ctx.save_for_backward(vol, saved)
+        ctx.desc = desc
+        ctx.shapes = [None if p is None else p.shape for p in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes as C
+        vol, saved = ctx.saved_tensors
+        desc = ctx.desc
+        if ctx.needs_input_grad[0]:
+            raise _lib.TmfError("the one-call sNet has no data gradient (the network input needs none)")
+        dout = _chk(dout, "grad_output")
+        sizes = [0 if s is None else s.numel() for s in ctx.shapes]
+        flat = torch.empty(sum(sizes), device=vol.device, dtype=_f32)        # all 28 gradients in one allocation
+        grads = [None if s is None else t.view(s) for t, s in zip(flat.split(sizes), ctx.shapes)]
+        g = _lib.SnetGrads()
+        for l in range(7):
+            dw, db, dg, dbe = grads[4 * l:4 * l + 4]
+            g.dweight[l] = dw.data_ptr() if ctx.needs_input_grad[3 + 4 * l] else None
+            g.dbias[l] = None if db is None else db.data_ptr()
+            g.dgamma[l], g.dbeta[l] = dg.data_ptr(), dbe.data_ptr()
+        nscr = _lib.query("tmf_snet_bwd_scratch_bytes", C.byref(desc))
+        scratch = torch.empty(nscr, device=vol.device, dtype=torch.uint8)
+        _lib.call("tmf_snet_train_bwd", C.byref(desc), vol.data_ptr(), saved.data_ptr(), saved.numel(), dout.data_ptr(),
+                  C.byref(g), scratch.data_ptr(), nscr, _stream())
+        out = [None, None, None]
+        for i, gr in enumerate(grads):
+            out.append(gr if (gr is not None and ctx.needs_input_grad[3 + i]) else None)
+        return tuple(out)
 
 
 # --------------------------------------------------------------------------------------
