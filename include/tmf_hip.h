@@ -354,6 +354,40 @@ int    tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, const tmf_sn
 int    tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, const void* saved, size_t saved_bytes,
                           const float* dout, const tmf_snet_grads* grads, void* scratch, size_t scratch_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------
+ * Whole-fusion entries (csrc/fusion_path.hip): ONE call enqueues every launch of CrossTransformer_MOD_AVG's train-mode
+ * forward, or of its backward.  Replaces `self.fuse_transformer(mri_embeddings, pet_embeddings)` (models/mymodel.py:220
+ * -> networks.py:272-281: depth x [mri <- Transformer(mri | pet) + mri; pet <- Transformer(pet | NEW mri) + pet], then
+ * cat[mean, mean, max, max] over tokens) and its slice of `all_loss.backward()`.  Dropout must be inactive (p = 0, the
+ * reference default options/option.py:39).  dim == 128; heads*dim_head and mlp multiples of 128.
+ *
+ * inst[2*l] / inst[2*l + 1] = the mri / pet Transformer(depth=1) of layer l, parameters = the reference's state_dict
+ * tensors (nn.Linear weights (out, in)).  Gradients: small = [b2 (dim) | b1 (mlp) | bo (dim) | ln2 gamma | ln2 beta |
+ * ln1 gamma | ln1 beta] contiguous (6*dim + mlp floats), lnf = [gamma | beta] of the block-final LayerNorm, dw* in the
+ * nn.Linear layout.  mri_tok / pet_tok: [B][N][dim]; cls: [B][4*dim]; dmri_tok / dpet_tok: [B][N][dim].
+ * ---------------------------------------------------------------------------- */
+#define TMF_FUSION_MAX_DEPTH 16
+typedef struct tmf_fusion_desc { int B, N, dim, heads, dim_head, mlp, depth; } tmf_fusion_desc;
+typedef struct tmf_xformer_params {
+    const float *ln1_g, *ln1_b;         /* layers.0.0.norm                          (networks.py:117) */
+    const float *wq, *wkv, *wo, *bo;    /* layers.0.0.fn.to_q / to_kv / to_out.0    (:149-155) */
+    const float *ln2_g, *ln2_b;         /* layers.0.1.norm */
+    const float *w1, *b1, *w2, *b2;     /* layers.0.1.fn.net.0 / net.3              (:129-132) */
+    const float *lnf_g, *lnf_b;         /* norm                                     (:219) */
+    float eps1, eps2, epsf;
+} tmf_xformer_params;
+typedef struct tmf_xformer_grads {
+    float *small, *lnf, *dwq, *dwkv, *dwo, *dw1, *dw2;
+} tmf_xformer_grads;
+size_t tmf_fusion_saved_bytes(const tmf_fusion_desc* d);
+size_t tmf_fusion_bwd_scratch_bytes(const tmf_fusion_desc* d);
+int    tmf_fusion_train_fwd(const tmf_fusion_desc* d, const float* mri_tok, const float* pet_tok,
+                            const tmf_xformer_params* inst, void* saved, size_t saved_bytes, float* cls, void* stream);
+int    tmf_fusion_train_bwd(const tmf_fusion_desc* d, const float* mri_tok, const float* pet_tok,
+                            const tmf_xformer_params* inst, const void* saved, size_t saved_bytes, const float* dcls,
+                            const tmf_xformer_grads* grads, float* dmri_tok, float* dpet_tok,
+                            void* scratch, size_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -689,3 +689,40 @@ def test_one_call_encoder_is_taken_by_default():
     mri, _pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
     out = net.mri_cnn(mri)
     assert type(out.grad_fn.next_functions[0][0]).__name__.startswith("SNetTrain"), out.grad_fn.next_functions
+
+
+@pytest.mark.parametrize("name", ["ad_mid", "ad_full_b2_blobs"])
+def test_one_call_fusion_matches_instance_by_instance(name):
+    """tmf_fusion_train_fwd / _bwd (one library call per pass for the whole CrossTransformer_MOD_AVG,
+    csrc/fusion_path.hip) against the per-Transformer autograd path: the forward is the same launch sequence (bitwise
+    equal logits and loss); in backward the residual gradients are summed inside the kernels' epilogues instead of by
+    separate adds, so gradients agree to fp32 round-off (1e-5 of each tensor's max)."""
+    import transmf_ad_amd as T
+    from transmf_ad_amd import ops
+    g = Golden(name)
+    res = []
+    try:
+        for one_call in (True, False):
+            ops.FUSION_ONE_CALL = one_call
+            net = build(g)
+            outs, loss = step(net, g, train=True)
+            fn = outs["logits"].grad_fn
+            res.append((outs, loss, {k: p.grad.clone() for k, p in net.named_parameters()}))
+    finally:
+        ops.FUSION_ONE_CALL = True
+    (o1, l1, g1), (o2, l2, g2) = res
+    assert torch.equal(l1, l2)
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+    for k in g1:
+        err = (g1[k] - g2[k]).abs().max().item() / max(g2[k].abs().max().item(), 1e-30)
+        assert err <= 1e-5, (k, err)
+
+
+def test_one_call_fusion_is_taken_by_default():
+    import transmf_ad_amd as T
+    g = Golden("ad_mid")
+    net = build(g).train()
+    mri, pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+    cls, _dm, _dp = net.forward_features(mri, pet)
+    assert type(cls.grad_fn).__name__.startswith("FusionTrain"), cls.grad_fn

@@ -108,6 +108,31 @@ PROTOTYPES.update({
     "tmf_snet_train_bwd": (_i, [C.POINTER(SnetDesc), _p, _p, _z, _p, C.POINTER(SnetGrads), _p, _z, _p]),
 })
 
+
+
+class FusionDesc(C.Structure):
+    _fields_ = [(n, _i) for n in ("B", "N", "dim", "heads", "dim_head", "mlp", "depth")]
+
+
+XFORMER_PTRS = ("ln1_g", "ln1_b", "wq", "wkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2", "lnf_g", "lnf_b")
+
+
+class XformerParams(C.Structure):
+    _fields_ = [(n, _p) for n in XFORMER_PTRS] + [("eps1", _f), ("eps2", _f), ("epsf", _f)]
+
+
+class XformerGrads(C.Structure):
+    _fields_ = [(n, _p) for n in ("small", "lnf", "dwq", "dwkv", "dwo", "dw1", "dw2")]
+
+
+PROTOTYPES.update({
+    "tmf_fusion_saved_bytes": (_z, [C.POINTER(FusionDesc)]),
+    "tmf_fusion_bwd_scratch_bytes": (_z, [C.POINTER(FusionDesc)]),
+    "tmf_fusion_train_fwd": (_i, [C.POINTER(FusionDesc), _p, _p, C.POINTER(XformerParams), _p, _z, _p, _p]),
+    "tmf_fusion_train_bwd": (_i, [C.POINTER(FusionDesc), _p, _p, C.POINTER(XformerParams), _p, _z, _p,
+                                  C.POINTER(XformerGrads), _p, _p, _p, _z, _p]),
+})
+
 _lib = None
 
 

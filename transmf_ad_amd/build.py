@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtmf_hip.so")
-SOURCES = ["conv3d_mfma.hip", "conv3d_bf16.hip", "conv1_fused.hip", "bn_act_pool.hip", "attention.hip", "token_ops.hip", "token_gemm.hip", "snet_path.hip"]
+SOURCES = ["conv3d_mfma.hip", "conv3d_bf16.hip", "conv1_fused.hip", "bn_act_pool.hip", "attention.hip", "token_ops.hip", "token_gemm.hip", "snet_path.hip", "fusion_path.hip"]
 # -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 work into v_pk_*_f32 and then patches one half of the pair
 # with a single-pass instruction (v_pk_mul_f32 v[6:7] ...; v_mov_b32 v6, v5; v_pk_add_f32 ..., v[6:7]).  On gfx950 that
 # sequence intermittently delivered the stale half in lanes 16-31 when the instructions issued back to back (the

@@ -238,8 +238,42 @@ class CrossTransformer_MOD_AVG(nn.Module):
         self.gap = _TokenReduce("mean")
         self.gmp = _TokenReduce("max")
 
+    def _one_call_ok(self, mri_tokens):
+        """dim-128 geometry, depth-1 Transformer instances, dropout inactive, nobody listening on the inner modules:
+        the whole fusion is one library call per pass (ops.FusionTrain)."""
+        if not (mri_tokens.is_cuda and torch.is_grad_enabled()) or len(self.layers) == 0:
+            return False
+        t0 = self.layers[0][0]
+        a, f = t0.layers[0][0].fn, t0.layers[0][1].fn
+        inner = a.to_q.out_features
+        if not ops.fusion_one_call_supported(mri_tokens.shape[-1], inner, f.net[0].out_features, inner // a.heads,
+                                             len(self.layers)):
+            return False
+        for pair in self.layers:
+            for tr in pair:
+                if len(tr.layers) != 1 or not tr._fused(mri_tokens) or tr._forward_hooks or tr._forward_pre_hooks:
+                    return False
+                at = tr.layers[0][0].fn
+                if at.heads != a.heads or at.to_q.out_features != inner or at.scale != (inner // a.heads) ** -0.5:
+                    return False
+        return True
+
     @device_guard
     def forward(self, mri_tokens, pet_tokens):
+        if self._one_call_ok(mri_tokens):
+            params, eps = [], []
+            for pair in self.layers:
+                for tr in pair:
+                    pa, pf = tr.layers[0]
+                    a, f = pa.fn, pf.fn
+                    params += [pa.norm.weight, pa.norm.bias, a.to_q.weight, a.to_kv.weight, a.to_out[0].weight,
+                               a.to_out[0].bias, pf.norm.weight, pf.norm.bias, f.net[0].weight, f.net[0].bias,
+                               f.net[3].weight, f.net[3].bias, tr.norm.weight, tr.norm.bias]
+                    eps.append((float(pa.norm.eps), float(pf.norm.eps), float(tr.norm.eps)))
+            a0 = self.layers[0][0].layers[0][0].fn
+            f0 = self.layers[0][0].layers[0][1].fn
+            cfg = (a0.heads, a0.to_q.out_features // a0.heads, f0.net[0].out_features, len(self.layers), tuple(eps))
+            return ops.FusionTrain.apply(mri_tokens, pet_tokens, cfg, *params)
         for mri_enc, pet_enc in self.layers:
             # (Transformer.forward can fold this "+ tokens" into its last LayerNorm pass via residual=; it is left
             #  as its own add so that forward hooks on the Transformer modules see the reference's values)

@@ -770,6 +770,95 @@ def transformer_layer(x, context, ln1, attn, ln2, ff):
 
 
 # --------------------------------------------------------------------------------------
+# whole fusion transformer in one call per pass                      (networks.py:255-281)
+# --------------------------------------------------------------------------------------
+
+FUSION_ONE_CALL = os.environ.get("TMF_FUSION_C", "1") != "0"
+
+
+def fusion_one_call_supported(dim, inner, mlp, dim_head, depth):
+    return (FUSION_ONE_CALL and FUSE_TOKEN_LINEARS and dim == 128 and inner % 128 == 0 and mlp % 128 == 0
+            and dim_head in (8, 16, 32, 64) and 0 < depth <= 16)
+
+
+class FusionTrain(torch.autograd.Function):
+    """CrossTransformer_MOD_AVG forward / backward as ONE library call each (tmf_fusion_train_fwd / _bwd,
+    csrc/fusion_path.hip).  forward(mri_tok, pet_tok, cfg, *params): params = per Transformer instance (mri enc of layer
+    0, pet enc of layer 0, mri enc of layer 1, ...) the 14 tensors of _lib.XFORMER_PTRS order -> cls (B, 4*dim)."""
+
+    @staticmethod
+    def forward(ctx, mri, pet, cfg, *params):
+        import ctypes as C
+        mri, pet = _chk(mri, "mri_tokens"), _chk(pet, "pet_tokens")
+        heads, dim_head, mlp, depth, eps = cfg
+        B, N, dim = mri.shape
+        if pet.shape != mri.shape:
+            raise _lib.TmfError(f"token shapes differ: {tuple(mri.shape)} vs {tuple(pet.shape)}")
+        desc = _lib.FusionDesc(B=B, N=N, dim=dim, heads=heads, dim_head=dim_head, mlp=mlp, depth=depth)
+        inst = (_lib.XformerParams * (2 * depth))()
+        for i in range(2 * depth):
+            for j, name in enumerate(_lib.XFORMER_PTRS):
+                t = params[14 * i + j]
+                if not (t.is_cuda and t.dtype == _f32 and t.is_contiguous()):
+                    raise _lib.TmfError(f"Transformer instance {i}: {name} must be a contiguous float32 HIP tensor")
+                setattr(inst[i], name, t.data_ptr())
+            inst[i].eps1, inst[i].eps2, inst[i].epsf = eps[i]
+        nsaved = _lib.query("tmf_fusion_saved_bytes", C.byref(desc))
+        if nsaved == 0:
+            raise _lib.TmfError("tmf_fusion_saved_bytes: " + (_lib.load().tmf_last_error_string() or b"").decode())
+        saved = torch.empty(nsaved, device=mri.device, dtype=torch.uint8)
+        cls = torch.empty((B, 4 * dim), device=mri.device, dtype=_f32)
+        _lib.call("tmf_fusion_train_fwd", C.byref(desc), mri.data_ptr(), pet.data_ptr(), inst, saved.data_ptr(), nsaved,
+                  cls.data_ptr(), _stream())
+        ctx.save_for_backward(mri, pet, saved, *params)
+        ctx.desc, ctx.eps = desc, eps
+        return cls
+
+    @staticmethod
+    def backward(ctx, dcls):
+        import ctypes as C
+        mri, pet, saved = ctx.saved_tensors[:3]
+        params = ctx.saved_tensors[3:]
+        desc = ctx.desc
+        depth, dim, mlp = desc.depth, desc.dim, desc.mlp
+        inner = desc.heads * desc.dim_head
+        dcls = _chk(dcls, "grad_output")
+        inst = (_lib.XformerParams * (2 * depth))()
+        grads = (_lib.XformerGrads * (2 * depth))()
+        # per instance ONE flat gradient buffer: [small (6*dim + mlp) | lnf (2*dim) | dwq | dwkv | dwo | dw1 | dw2]
+        sizes = [6 * dim + mlp, 2 * dim, inner * dim, 2 * inner * dim, dim * inner, mlp * dim, dim * mlp]
+        per = sum(sizes)
+        flat = torch.empty(2 * depth * per, device=mri.device, dtype=_f32)
+        out = [None, None, None]
+        base = flat.data_ptr()
+        for i in range(2 * depth):
+            for j, name in enumerate(_lib.XFORMER_PTRS):
+                setattr(inst[i], name, params[14 * i + j].data_ptr())
+            inst[i].eps1, inst[i].eps2, inst[i].epsf = ctx.eps[i]
+            o = i * per
+            ptrs = []
+            for n in sizes:
+                ptrs.append(base + 4 * o)
+                o += n
+            (grads[i].small, grads[i].lnf, grads[i].dwq, grads[i].dwkv, grads[i].dwo, grads[i].dw1, grads[i].dw2) = ptrs
+            f = flat[i * per:(i + 1) * per]
+            small, lnf, dwq, dwkv, dwo, dw1, dw2 = f.split(sizes)
+            b2, b1, bo, g2, be2, g1, be1 = small.split([dim, mlp, dim, dim, dim, dim, dim])
+            gf, bf = lnf.split([dim, dim])
+            # order of _lib.XFORMER_PTRS
+            out += [g1, be1, dwq.view(inner, dim), dwkv.view(2 * inner, dim), dwo.view(dim, inner), bo, g2, be2,
+                    dw1.view(mlp, dim), b1, dw2.view(dim, mlp), b2, gf, bf]
+        dm = torch.empty_like(mri)
+        dp = torch.empty_like(pet)
+        nscr = _lib.query("tmf_fusion_bwd_scratch_bytes", C.byref(desc))
+        scratch = torch.empty(nscr, device=mri.device, dtype=torch.uint8)
+        _lib.call("tmf_fusion_train_bwd", C.byref(desc), mri.data_ptr(), pet.data_ptr(), inst, saved.data_ptr(),
+                  saved.numel(), dcls.data_ptr(), grads, dm.data_ptr(), dp.data_ptr(), scratch.data_ptr(), nscr, _stream())
+        out[0], out[1] = dm, dp
+        return tuple(out)
+
+
+# --------------------------------------------------------------------------------------
 # token pooling head                                                (networks.py:276-281)
 # --------------------------------------------------------------------------------------
 
