@@ -50,7 +50,9 @@ int         tmf_version(void);                 /* ABI version, currently 1 */
 const char* tmf_last_error_string(void);
 /* Process-wide tuning knobs (never change results).  "conv_waves" = 2 | 4 | 8 | 16: workgroup shape of the
  * convolution kernels (16, the default: two 8-wave workgroups per CU).  "conv_ws" = 1: the experimental wave-specialised
- * forward kernel for eligible 3x3x3 layers (default 0; higher values are its timing ablations).  "debug": timing ablations
+ * forward kernel for eligible 3x3x3 layers (default 0; higher values are its timing ablations).  "bf16_v2" = 0 | 1 | 2:
+ * bf16 forward / data-gradient kernel with 8x8x8 bricks and 2 x 2 register tiles never / by brick count (default) /
+ * always (results equal up to fp32 summation order; tmf_conv3d_bf16_stat_blocks follows the choice).  "debug": timing ablations
  * only (results are garbage when set).
  * Size limits of the convolution entries: one sample of a layer (D*H*W*max(cin, cout)) and one weight tensor stay below
  * 2^29 elements — offsets inside a sample are 32-bit byte offsets of buffer resources; violating shapes return TMF_E_SHAPE. */
@@ -111,9 +113,11 @@ int    tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw, void* w
                                int B, int D, int H, int W, int cin, int cout, int io, int dw_layout, void* stream);
 /* fp32-ACCURATE variant on the bf16 matrix cores: operands split exactly into three bf16 numbers (hi+mid+lo), the
  * six partial products of order >= 2^-16 accumulated in fp32 (the dropped terms are below one fp32 ulp of the
- * product).  w3_bf16: bf16 [3 parts][27][cout][cin]; same shapes / statistics layout as tmf_conv3d_fwd_bf16. */
+ * product).  w3_bf16: bf16 [3 parts][27][cout][cin]; same shapes as tmf_conv3d_fwd_bf16; stat_partial:
+ * [tmf_conv3d_split_stat_blocks()][2][cout]. */
 int  tmf_conv3d_fwd_split(const float* x, const void* w3_bf16, float* z, float* stat_partial,
                           int B, int D, int H, int W, int cin, int cout, void* stream);
+int  tmf_conv3d_split_stat_blocks(int B, int D, int H, int W);        /* rows of its stat_partial */
 
 /* First layer, cin == 1 (networks.py:22): x[b][d][h][w], w[27][cout]. */
 int    tmf_conv3d_c1_fwd(const float* x, const float* w, float* z, float* stat_partial,

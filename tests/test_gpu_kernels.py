@@ -30,6 +30,16 @@ def _ncdhw(x):
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
+@pytest.fixture(params=[0, 2], ids=["small-brick", "8x8x8-brick"])
+def bf16_kernel_choice(request):
+    """Run a test with the bf16 forward kernel forced to the 4x8x8-brick variant (0) and to the 8x8x8-brick, 2 x NT
+    register-tile variant (2); the default (1) picks by brick count."""
+    from transmf_ad_amd import _lib
+    _lib.call("tmf_set_option", b"bf16_v2", request.param)
+    yield request.param
+    _lib.call("tmf_set_option", b"bf16_v2", 1)
+
+
 def _relerr(got, ref):
     ref = ref.double()
     return ((got.double().cpu() - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item()
@@ -246,7 +256,7 @@ def test_eval_block_single_pass(case):
     assert _relerr(y1, y2.cpu()) < 2e-6
 
 
-def test_two_blocks_with_bf16_activation_storage():
+def test_two_blocks_with_bf16_activation_storage(bf16_kernel_choice):
     """Two chained blocks (32->32 no pool, 32->64 max pool) with bf16 tensors between and inside them, forward and
     backward, against fp64 on the host: bf16-operand accuracy (one extra 2^-9 rounding per stored tensor)."""
     ops = _ops()
@@ -456,8 +466,8 @@ BF16_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("shape", BF16_SHAPES)
-def test_conv3d_bf16_mfma(shape):
+@pytest.mark.parametrize("shape", BF16_SHAPES + [(1, 17, 16, 24, 32, 32), (2, 16, 16, 16, 16, 24)])
+def test_conv3d_bf16_mfma(shape, bf16_kernel_choice):
     """bf16 matrix-core convolution: with inputs and weights that ARE bf16 numbers the products are exact in fp32, so
     the kernel must match an fp64 reference to fp32-accumulation accuracy (2e-6); with general fp32 inputs the
     error is the bf16 rounding of the operands (<= 2^-8 each) — bounded at 1e-2 of max, typically 2e-3."""
@@ -510,7 +520,7 @@ def test_conv3d_wgrad_bf16_mfma(shape):
     assert _relerr(got, wr2.grad) < 1e-2
 
 
-def test_block_in_bf16_mode():
+def test_block_in_bf16_mode(bf16_kernel_choice):
     """A full sNet block with the bf16 conv precision: forward and gradients within bf16-operand accuracy of fp64."""
     ops = _ops()
     B, D, H, W, cin, cout, k, pool = 2, 16, 16, 16, 32, 64, 3, "max"
@@ -784,7 +794,7 @@ def test_conv_kernels_ignore_memory_around_their_inputs(shape):
 
 
 @pytest.mark.parametrize("shape", [(2, 24, 24, 24, 64, 64, 3), (1, 11, 13, 9, 64, 32, 3), (1, 6, 6, 6, 256, 128, 0)])
-def test_bf16_conv_writes_only_its_output(shape):
+def test_bf16_conv_writes_only_its_output(shape, bf16_kernel_choice):
     ops = _ops()
     from transmf_ad_amd import _lib
     B, D, H, W, cin, cout, io = shape

@@ -19,8 +19,10 @@ ap.add_argument("--S", type=int, default=96)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--waves", type=int, default=16)
 ap.add_argument("--spin", type=int, default=0, help="launches of another conv shape first (loaded clock state)")
+ap.add_argument("--v2", type=int, default=1, help="tmf_set_option('bf16_v2', v): 0 small-brick, 2 8x8x8-brick bf16 forward kernel")
 a = ap.parse_args()
 _lib.call("tmf_set_option", b"conv_waves", a.waves)
+_lib.call("tmf_set_option", b"bf16_v2", a.v2)
 name, cin, cout, k, div, pool = [l for l in LAYERS if l[0] == a.layer][0]
 s = a.S // div
 dev = "cuda:0"

@@ -295,6 +295,261 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
 
 
 // ------------------------------------------------------------------------------------------------------------
+// Large-layer variant: 8x8x8 bricks, a 2 x NT REGISTER TILE per wave.
+//
+// The kernel above is bound by its LDS traffic, not by the matrix pipe (PMC: pipe 24-30 % busy, LDS > 40 %): a wave
+// owns ONE 32-voxel M-tile, so every MFMA needs 1.5-2 ds_read_b128 (one A and one B fragment per 32x32x16 product;
+// at the bf16 rate the CU's LDS port delivers exactly two per MFMA slot), and a 256-voxel brick re-stages the full
+// 27-tap weight set (135 KB per 32-channel chunk) for only 864 MFMAs.  Here
+//   * a wave owns TWO M-tiles (planes 0-3 and 4-7 of its brick row) x NT N-tiles: 2 + NT reads feed 2 NT MFMAs
+//     (1.0 read per MFMA at NT = 2), and a 512-voxel brick halves the weight staging per MFMA;
+//   * input channels go in chunks of 16 (one MFMA k-block): halo rows are 48 B (32 B + 16 B pad: the same lane ->
+//     voxel map stays conflict-free — 12 pd + 3 pw (mod 16) is a bijection on each 16-lane service group), the
+//     10x10x10 halo is 48 KB and the 3-tap weight ring 2 x 9 KB: 66 KB per workgroup, two workgroups per CU;
+//   * everything else (zero-filled halo, weight stages prefetched in registers across the barriers, fp32 accumulation,
+//     statistics from the accumulators, dword stores of bf16 outputs) is the scheme of the kernel above.
+// Used when the launch has enough 512-voxel bricks to fill the chip (host: use_v2()); results are identical to
+// the small-brick kernel up to fp32 summation order (k runs 16-channel chunk -> tap here, 32-channel chunk -> tap -> half
+// there).
+// ------------------------------------------------------------------------------------------------------------
+namespace v2 {
+constexpr int TD = 8, TH = 8, TW = 8;
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
+constexpr int NHALO = HD * HH * HW;                   // 1000
+constexpr int CINC = 16;
+constexpr int RP = 24;                                // bf16 per LDS row: 48 B
+constexpr int TPS = 3, NSTAGES = 9;
+constexpr int NTHR = 512;
+constexpr int MT2 = 4 * HH * HW * RP;                 // LDS offset of the wave's second M-tile (planes 4-7)
+template <int NT>
+struct Cfg {
+    static constexpr int NB = 32 * NT;
+    static constexpr int WSTAGE = TPS * NB * RP;      // bf16 elements per weight stage
+    static constexpr size_t LDS_BYTES = (size_t)(NHALO * RP + 2 * WSTAGE) * 2;     // statistics scratch aliases the halo
+};
+}  // namespace v2
+
+template <int NT, bool IN16, bool OUT16>
+__global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
+    const void* __restrict__ x_, const u16* __restrict__ w, void* __restrict__ z_,
+    float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
+    int tilesD, int tilesH, int tilesW, int ntiles) {
+    constexpr int TD = v2::TD, TH = v2::TH, TW = v2::TW, HH = v2::HH, HW = v2::HW, NHALO = v2::NHALO, CINC = v2::CINC,
+                  RP = v2::RP, TPS = v2::TPS, NSTAGES = v2::NSTAGES, NTHR = v2::NTHR, MT2 = v2::MT2;
+    constexpr int NB = v2::Cfg<NT>::NB, WSTAGE = v2::Cfg<NT>::WSTAGE;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    u16* halo = reinterpret_cast<u16*>(smem_raw);
+    u16* Ws = halo + NHALO * RP;
+    float* red = reinterpret_cast<float*>(smem_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+
+    const int tile = xcd_contiguous(blockIdx.x, ntiles);
+    int t = tile;
+    const int tw = t % tilesW; t /= tilesW;
+    const int th = t % tilesH; t /= tilesH;
+    const int td = t % tilesD;
+    const int b = t / tilesD;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+    const int n0 = blockIdx.y * NB;
+
+    // wave = brick row h; lane = (d & 3 in the two LOW bits, w); M-tile m = planes 4m .. 4m + 3
+    const int a_lane = (((l31 & 3) * HH + wave) * HW + (l31 >> 2)) * RP + hsel * 8;
+    const int b_lane = l31 * RP + hsel * 8;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+    const float* xb = reinterpret_cast<const float*>(x_) + (IN16 ? 0 : (size_t)b * D * H * W * Cin);
+    const u16* xb16 = reinterpret_cast<const u16*>(x_) + (IN16 ? (size_t)b * D * H * W * Cin : 0);
+
+    // halo pieces of 16 B: bf16 tensors 2 per position (8 channels each), fp32 tensors 4 per position (4 channels each)
+    constexpr int PPP = IN16 ? 2 : 4;                         // pieces per position
+    constexpr int PSH = IN16 ? 1 : 2;
+    constexpr int HV = (NHALO * PPP + NTHR - 1) / NTHR;       // 4 | 8
+    int hoff[HV];                                             // element offset of the position in the sample, -1 = zero fill
+#pragma unroll
+    for (int q = 0; q < HV; ++q) {
+        const int hp = (tid + q * NTHR) >> PSH;
+        const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
+        const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+        const bool ok = hp < NHALO && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+        hoff[q] = ok ? ((gd * H + gh) * W + gw) * Cin : -1;
+    }
+
+    for (int c0 = 0; c0 < Cin; c0 += CINC) {
+        if (c0 > 0) __syncthreads();
+        // ---- weight stages: [tap][co][ci] bf16; a stage = 3 taps x NB rows x 16 channels = 2 pieces of 16 B per row ----
+        constexpr int NPIECE = TPS * NB * 2;                  // 384 | 192 <= NTHR: one piece per thread
+        constexpr int PW = 2;                                 // stages requested ahead, in registers
+        u32x4 wreg[PW];
+        auto load_w = [&](int st, int slot) {
+            const int row = tid >> 1, piece = tid & 1;        // row = tap_in_stage * NB + co
+            const int tap = st * TPS + row / NB, co = n0 + row % NB, ci = c0 + piece * 8;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (tid < NPIECE && co < Cout && ci < Cin)
+                v = *reinterpret_cast<const u32x4*>(w + ((size_t)tap * Cout + co) * Cin + ci);
+            wreg[slot] = v;
+        };
+        auto store_w = [&](int buf, int slot) {
+            if (tid < NPIECE)
+                *reinterpret_cast<u32x4*>(Ws + buf * WSTAGE + (tid >> 1) * RP + (tid & 1) * 8) = wreg[slot];
+        };
+#pragma unroll
+        for (int st = 0; st < PW; ++st) load_w(st, st);
+        // ---- halo: all loads of the chunk are issued before the first LDS write ----
+        if constexpr (IN16) {
+            u32x4 hreg[HV];
+#pragma unroll
+            for (int q = 0; q < HV; ++q) {
+                const int c = c0 + ((tid + q * NTHR) & 1) * 8;
+                u32x4 v = {0u, 0u, 0u, 0u};
+                if (hoff[q] >= 0 && c < Cin) v = *reinterpret_cast<const u32x4*>(xb16 + hoff[q] + c);
+                hreg[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < HV; ++q) {
+                const int e = tid + q * NTHR;
+                if (e < NHALO * PPP) *reinterpret_cast<u32x4*>(halo + (e >> 1) * RP + (e & 1) * 8) = hreg[q];
+            }
+        } else {
+            // fp32 tensors: batches of HB pieces keep the kernel under 128 registers
+            constexpr int HB = NT == 2 ? 2 : 4;
+#pragma unroll
+            for (int q0 = 0; q0 < HV; q0 += HB) {
+                f32x4 hreg[HB];
+#pragma unroll
+                for (int q = q0; q < q0 + HB; ++q) {
+                    const int c = c0 + ((tid + q * NTHR) & 3) * 4;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (hoff[q] >= 0 && c < Cin) v = *reinterpret_cast<const f32x4*>(xb + hoff[q] + c);
+                    hreg[q - q0] = v;
+                }
+#pragma unroll
+                for (int q = q0; q < q0 + HB; ++q) {
+                    const int e = tid + q * NTHR;
+                    if (e < NHALO * PPP)
+                        *reinterpret_cast<u32x2*>(halo + (e >> 2) * RP + (e & 3) * 4) =
+                            u32x2{pack_bf16(hreg[q - q0][0], hreg[q - q0][1]), pack_bf16(hreg[q - q0][2], hreg[q - q0][3])};
+                }
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < NSTAGES; ++st) {
+            const int buf = st & 1;
+            store_w(buf, st % PW);
+            __syncthreads();
+            if (st + PW < NSTAGES) load_w(st + PW, st % PW);
+            const u16* ap = halo + a_lane + ((st / 3) * HH + (st % 3)) * HW * RP;          // kd = st / 3, kh = st % 3
+            const u16* ws = Ws + buf * WSTAGE + b_lane;
+#pragma unroll
+            for (int tp = 0; tp < TPS; ++tp) {                                            // kw
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + tp * RP);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + tp * RP + MT2);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const bf16x8 bb = *reinterpret_cast<const bf16x8*>(ws + (tp * NB + j * 32) * RP);
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1][j], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: NDHWC store (fp32, or bf16 as channel-pair dwords) + BatchNorm statistic partials ----
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+    float* zb = reinterpret_cast<float*>(z_) + (OUT16 ? 0 : (size_t)b * D * H * W * Cout);
+    u16* zb16 = reinterpret_cast<u16*>(z_) + (OUT16 ? (size_t)b * D * H * W * Cout : 0);
+    auto epilogue = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            if constexpr (OUT16) {
+                const int odd = lane & 1;
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const int gh = h0 + wave, gw = w0 + 2 * (r >> 2) + hsel;
+                    const int dA = d0 + 4 * m + (r & 3);                      // plane of accumulator row r (r + 1: dA + 1)
+                    const int gd = dA + odd;                                  // the row this lane stores
+                    const bool pv = FULL || (gd < D && gh < H && gw < W);
+                    const int off = ((gd * H + gh) * W + gw) * Cout;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int co = n0 + j * 32 + l31;
+                        const float a = acc[m][j][r], bq = acc[m][j][r + 1];
+                        const float other = __shfl_xor(odd ? a : bq, 1);
+                        const unsigned int pk = odd ? pack_bf16(other, bq) : pack_bf16(a, other);
+                        if (FULL || (pv && co < Cout))
+                            *reinterpret_cast<unsigned int*>(zb16 + off + (co & ~1)) = pk;
+                        const bool va = FULL || (dA < D && gh < H && gw < W && co < Cout);
+                        const bool vb = FULL || (dA + 1 < D && gh < H && gw < W && co < Cout);
+                        if (va) { s1[j] += a; s2[j] += a * a; }
+                        if (vb) { s1[j] += bq; s2[j] += bq * bq; }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gd = d0 + 4 * m + (r & 3), gh = h0 + wave, gw = w0 + 2 * (r >> 2) + hsel;
+                    const bool pv = FULL || (gd < D && gh < H && gw < W);
+                    const int off = ((gd * H + gh) * W + gw) * Cout;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const int co = n0 + j * 32 + l31;
+                        if (FULL || (pv && co < Cout)) {
+                            const float v = acc[m][j][r];
+                            zb[off + co] = v;
+                            s1[j] += v;
+                            s2[j] += v * v;
+                        }
+                    }
+                }
+            }
+        }
+    };
+    if (d0 + TD <= D && h0 + TH <= H && w0 + TW <= W && n0 + NB <= Cout) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
+
+    if (stat_partial != nullptr) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 32);
+        }
+        __syncthreads();                                      // every wave is done reading the halo (red aliases it)
+        if (hsel == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                red[(wave * NB + j * 32 + l31) * 2 + 0] = s1[j];
+                red[(wave * NB + j * 32 + l31) * 2 + 1] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) { a1 += red[(m * NB + tid) * 2]; a2 += red[(m * NB + tid) * 2 + 1]; }
+            const int co = n0 + tid;
+            if (co < Cout) {
+                stat_partial[((size_t)tile * 2 + 0) * Cout + co] = a1;
+                stat_partial[((size_t)tile * 2 + 1) * Cout + co] = a2;
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
 // fp32-ACCURATE convolution on the bf16 matrix cores ("3-way split"): every fp32 operand is written as
 // hi + mid + lo with three bf16 numbers (8 + 8 + 8 significand bits: the decomposition is EXACT), and the
 // product a*b is evaluated as the six partial products of order >= 2^-16 — (h,h) (h,m) (m,h) (h,l) (l,h) (m,m) —
@@ -737,8 +992,27 @@ WgBfPlan plan_wgrad_bf16(int B, int D, int H, int W, int cin, int cout) {
 
 }  // namespace
 
+// 8x8x8-brick kernel (2 x NT register tiles) when the launch has enough of those bricks to fill the chip's 512 workgroup
+// slots reasonably; the choice depends on the geometry only (tmf_conv3d_bf16_stat_blocks has no channel arguments).
+// tmf_set_option("bf16_v2", 0) / TMF_BF_V2=0 selects the small-brick kernel everywhere, 2 the large-brick kernel
+// everywhere (A/B runs, tests), 1 (default) by the brick count.
+int tmf_g_bf16_v2 = -1;          // tmf_set_option("bf16_v2", 0 | 1 | 2); -1 = not set yet: TMF_BF_V2 or 1
+static bool use_v2(int B, int D, int H, int W) {
+    if (tmf_g_bf16_v2 < 0) { const char* e = getenv("TMF_BF_V2"); tmf_g_bf16_v2 = e == nullptr ? 1 : atoi(e); }
+    const int mode = tmf_g_bf16_v2;
+    if (mode == 0) return false;
+    if (mode == 2) return true;
+    return (long)B * tmf_cdiv(D, v2::TD) * tmf_cdiv(H, v2::TH) * tmf_cdiv(W, v2::TW) >= 384;
+}
+
+extern "C" int tmf_conv3d_split_stat_blocks(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);          // the split kernel always uses 4x8x8 bricks
+}
+
 extern "C" int tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (use_v2(B, D, H, W)) return B * tmf_cdiv(D, v2::TD) * tmf_cdiv(H, v2::TH) * tmf_cdiv(W, v2::TW);
     return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
 }
 
@@ -754,10 +1028,33 @@ extern "C" int tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z,
     TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
                 "tmf_conv3d_fwd_bf16: one sample exceeds 2^31 elements");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w_bf16); TMF_REQUIRE_ALIGNED(z);
-    const int tD = tmf_cdiv(D, TD), tH = tmf_cdiv(H, TH), tW = tmf_cdiv(W, TW);
-    const int ntiles = B * tD * tH * tW;
     int rc;
     hipStream_t s = (hipStream_t)stream;
+    if (use_v2(B, D, H, W)) {
+        const int tD = tmf_cdiv(D, v2::TD), tH = tmf_cdiv(H, v2::TH), tW = tmf_cdiv(W, v2::TW);
+        const int ntiles = B * tD * tH * tW;
+#define TMF_BF2_LAUNCH(NT, I16, O16)                                                                                 \
+    do {                                                                                                             \
+        auto k = conv3d_fwd_bf16_v2_kernel<NT, I16, O16>;                                                            \
+        if ((rc = tmf_allow_lds(k, v2::Cfg<NT>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;                       \
+        hipLaunchKernelGGL(k, dim3(ntiles, tmf_cdiv(cout, 32 * NT)), dim3(v2::NTHR), v2::Cfg<NT>::LDS_BYTES, s, x,    \
+                           (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);             \
+    } while (0)
+#define TMF_BF2_IO(NT)                                                                                               \
+    do {                                                                                                             \
+        if (io == 0) TMF_BF2_LAUNCH(NT, false, false);                                                               \
+        else if (io == 1) TMF_BF2_LAUNCH(NT, true, false);                                                           \
+        else if (io == 2) TMF_BF2_LAUNCH(NT, false, true);                                                           \
+        else TMF_BF2_LAUNCH(NT, true, true);                                                                         \
+    } while (0)
+        if (cout > 32) TMF_BF2_IO(2);
+        else TMF_BF2_IO(1);
+#undef TMF_BF2_IO
+#undef TMF_BF2_LAUNCH
+        return tmf_launch_result("tmf_conv3d_fwd_bf16(v2)");
+    }
+    const int tD = tmf_cdiv(D, TD), tH = tmf_cdiv(H, TH), tW = tmf_cdiv(W, TW);
+    const int ntiles = B * tD * tH * tW;
     // 64 output channels per workgroup where Cout allows it (TMF_BF_NT2=0 selects the 32-channel kernel everywhere): half
     // the workgroups (the per-workgroup overhead — offsets, LDS writes, 9 barriers per chunk, epilogue — is 40 % of this
     // kernel), half the halo loads, one A fragment per two MFMAs; both variants stay under 128 registers / 80 KB, two

@@ -1561,6 +1561,11 @@ extern "C" int tmf_set_option(const char* name, int value) {
     }
     if (strcmp(name, "debug") == 0) { g_debug = value; return TMF_OK; }
     if (strcmp(name, "conv_ws") == 0) { g_conv_ws = value; return TMF_OK; }
+    if (strcmp(name, "bf16_v2") == 0) {
+        TMF_REQUIRE(value >= 0 && value <= 2, TMF_E_ARG, "tmf_set_option: bf16_v2 must be 0, 1 or 2, got %d", value);
+        tmf_g_bf16_v2 = value;
+        return TMF_OK;
+    }
     tmf_set_error("tmf_set_option: unknown option '%s'", name);
     return TMF_E_ARG;
 }

@@ -142,7 +142,7 @@ def conv3d_split_raw(x, w3, cin, cout, want_stats):
     z = torch.empty((B, D, H, W, cout), device=x.device, dtype=_f32)
     part, nblk = None, 0
     if want_stats:
-        nblk = _lib.query("tmf_conv3d_bf16_stat_blocks", B, D, H, W)
+        nblk = _lib.query("tmf_conv3d_split_stat_blocks", B, D, H, W)
         part = torch.empty((nblk, 2, cout), device=x.device, dtype=_f32)
     _lib.call("tmf_conv3d_fwd_split", x.data_ptr(), w3.data_ptr(), z.data_ptr(), _ptr(part),
               B, D, H, W, cin, cout, _stream())
