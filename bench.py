@@ -266,6 +266,11 @@ def main():
     ap.add_argument("--eval", action="store_true",
                     help="time the reference's val_step instead (eval mode, no_grad forward + CE; kfold_train_adversarial.py:144-161)")
     ap.add_argument("--no-fused-adam", action="store_true")
+    ap.add_argument("--from-host", action="store_true",
+                    help="feed every step from HOST memory: raw volumes staged in pinned buffers, copied on a side stream "
+                         "(double-buffered) and scaled / flipped on the device (transmf_ad_amd.pipeline, the device form of "
+                         "datasets/ADNI.py:59-66 + kfold_train_adversarial.py:106-108) — the PCIe-inclusive rate; the default "
+                         "(and the headline value) has the batch resident in HBM")
     ap.add_argument("--no-item-sync", action="store_true",
                     help="leave out the reference step's two loss.item() host syncs between forward and backward "
                          "(kfold_train_adversarial.py:127-128); the default step has them")
@@ -315,11 +320,21 @@ def main():
     B, S = args.batch, args.size
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     vol = tuple(args.shape) if args.shape else (S, S, S)
-    mri = torch.rand((B, 1) + vol, device=dev, generator=g)
-    pet = torch.rand((B, 1) + vol, device=dev, generator=g)
-    label = (torch.arange(B, device=dev) % 2).long()
+    mri = mri0 = torch.rand((B, 1) + vol, device=dev, generator=g)
+    pet = pet0 = torch.rand((B, 1) + vol, device=dev, generator=g)
+    label = label0 = (torch.arange(B, device=dev) % 2).long()
     ones = torch.ones(B, dtype=torch.int64, device=dev)
     zeros = torch.zeros(B, dtype=torch.int64, device=dev)
+
+    feeder = None
+    if args.from_host:
+        import itertools
+        import numpy as np
+        from transmf_ad_amd import DevicePrefetcher
+        rs = np.random.RandomState(1234 + rank)
+        pool = [dict(MRI=(rs.rand(B, 1, *vol) * 4000.0).astype(np.float32), PET=(rs.rand(B, 1, *vol) * 9.0).astype(np.float32),
+                     label=np.arange(B) % 2) for _ in range(3)]              # raw intensities; 3 host batches, cycled
+        feeder = iter(DevicePrefetcher(itertools.cycle(pool), device=dev, flip_prob=0.3, seed=rank))
 
     def val_step():
         net.eval()
@@ -333,6 +348,11 @@ def main():
         if args.eval:
             return val_step()
         net.train()
+        if feeder is not None:              # kfold_train_adversarial.py:106-108: this step's batch arrives from the host
+            batch = next(feeder)
+            mri, pet, label = batch["MRI"], batch["PET"], batch["label"]
+        else:
+            mri, pet, label = mri0, pet0, label0
         opt.zero_grad()
         if args.model == "single":          # kfold_train_single.py:91-113: plain CE on model_single(MRI)
             loss = crit(net(mri), label)
@@ -387,11 +407,31 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    if isinstance(net, GradAllReduce):
+        net.timing = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    torch.cuda.synchronize()
+    dt_local = max(time.perf_counter() - t0, 1e-9)          # this rank's own time, before the barrier
     fence()
     dt = max(time.perf_counter() - t0, 1e-9)
+    per_rank = None
+    if isinstance(net, GradAllReduce):
+        net.timing = False
+        ar = net.exposed_allreduce_ms()
+        mine = torch.tensor([dt_local / max(args.steps, 1) * 1e3, sum(ar) / max(len(ar), 1), max(ar) if ar else 0.0],
+                            device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)] if world > 1 else [mine]
+        if world > 1:
+            dist.all_gather(allr, mine)
+        per_rank = {"ms_per_step": [round(t[0].item(), 3) for t in allr],
+                    "allreduce_exposed_ms_mean": [round(t[1].item(), 3) for t in allr],
+                    "allreduce_exposed_ms_max": [round(t[2].item(), 3) for t in allr],
+                    "bucket_bytes": net.bucket_sizes_bytes,
+                    "note": "ms_per_step: each rank's own time for the K steps before the final barrier; "
+                            "allreduce_exposed: time between the end of backward's compute and the last gradient bucket "
+                            "being reduced + scaled (RCCL time that did not hide under backward)"}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -461,16 +501,28 @@ def main():
                                ("zero_grad+fwd+loss+bwd+allreduce+Adam" if args.no_item_sync or args.model == "single" else
                                 "zero_grad+fwd+loss+2x loss.item()+bwd+allreduce+Adam (kfold_train_adversarial.py:101-136)"),
                        "dispatch": mode,
+                       "input": ("host: raw volumes -> pinned staging -> H2D on a copy stream (double-buffered) -> device "
+                                 "ScaleIntensity + RandFlip(0.3), every step (PCIe-inclusive)" if args.from_host else
+                                 "resident in HBM"),
                        "setup_steps_untimed": setup_steps},
             "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
             "loss": round(final_loss, 6),
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        if per_rank is not None:
+            out["per_rank"] = per_rank
     if world > 1:
         dist.barrier()
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: RCCL's version banner sits in the C stdio buffer until then (piped stdout)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -305,6 +305,21 @@ int tmf_token_pool_bwd(const float* dcls, const int32_t* argmax, float* dmri, fl
                        int B, int N, int dim, void* stream);
 
 /* ------------------------------------------------------------------------------
+ * Input pipeline step ahead of the path, on the device (csrc/input_pipeline.hip).  Replaces MONAI's ScaleIntensityd and
+ * RandFlipd(spatial_axis=0) of datasets/ADNI.py:64-66 (host, num_workers=0) for volumes already copied to the device
+ * (kfold_train_adversarial.py:106-108).  Exact fp32 formulas (bit-identical to the numpy restatement in
+ * oracle/input_oracle.py):  minmax[b] = (min, max) of volume b;  dst = (src - min) / (max - min)  (a constant volume
+ * gives zeros, as monai.transforms.utils.rescale_array);  flip_d[b] != 0 reverses the first spatial axis of volume b
+ * (the random decision itself stays with the caller: MONAI draws it from its own RandomState).  vol / src / dst:
+ * [B][D][H][W] fp32;  workspace >= tmf_scale_intensity_workspace_bytes(B).  RandRotated / RandZoomd are not provided.
+ * ---------------------------------------------------------------------------- */
+size_t tmf_scale_intensity_workspace_bytes(int B);
+int    tmf_volume_minmax(const float* vol, float* minmax, void* workspace, size_t workspace_bytes, int B, long voxels,
+                         void* stream);
+int    tmf_scale_flip(const float* src, float* dst, const float* minmax, const unsigned char* flip_d,
+                      int B, int D, int H, int W, void* stream);
+
+/* ------------------------------------------------------------------------------
  * Whole-encoder entries (csrc/snet_path.hip): ONE call enqueues every launch of an sNet train-mode forward, or of its
  * backward.  Replaces, per modality, `self.mri_cnn(mri)` / `self.pet_cnn(pet)` (models/mymodel.py:206-207 ->
  * networks.py:55-61) and the matching slice of `all_loss.backward()` (kfold_train_adversarial.py:131-132).  Same kernels,

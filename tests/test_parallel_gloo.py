@@ -108,3 +108,66 @@ def test_two_rank_gradient_average(tmp_path):
     for a, b, c in zip(res[0]["g3"], res[1]["g3"], res[0]["g2"]):
         assert torch.equal(a, b)
         assert (a - c).abs().max() <= 1e-3 * c.abs().max().clamp_min(1e-6)     # same parameters, same data as step 2
+
+
+def _plan_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import transmf_ad_amd as T
+    from transmf_ad_amd.parallel import GradAllReduce
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # a 1-rank group: only the plan is inspected
+    torch.manual_seed(0)
+    net = T.model_ad(128, 3, 4, 32, 512, 0.)            # parameter holders only: no forward on the CPU
+    ddp = GradAllReduce(net, broadcast_from_rank0=False)
+    names = {id(p): n for n, p in net.named_parameters()}
+    plan = [[names[id(p)] for p in b.params] for b in ddp._buckets]
+    if rank == 0:
+        torch.save(dict(sizes=ddp.bucket_sizes_bytes, plan=plan, order=[n for n, _ in net.named_parameters()]),
+                   os.path.join(out_dir, "plan.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucket_plan_of_the_benchmark_model(tmp_path):
+    """model_ad(128, 3, 4, 32, 512) has 4 173 060 fp32 parameters = 16.69 MB of gradients; with the default 6 MB
+    cap that is 3 buckets, filled in REVERSE registration order (the order backward produces gradients: heads, fusion
+    transformer, conv4 ... conv1), every parameter in exactly one bucket."""
+    mp.spawn(_plan_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "plan.pt")
+    sizes, plan, order = r["sizes"], r["plan"], r["order"]
+    assert sum(sizes) == 4173060 * 4 and abs(sum(sizes) / 1e6 - 16.69) < 0.01
+    assert len(sizes) == 3 and all(s <= 6.0 * (1 << 20) + 3.6e6 for s in sizes)        # a bucket closes once it would exceed the cap
+    flat = [n for b in plan for n in b]
+    assert flat == list(reversed(order))                                               # reverse registration order, no gaps
+    assert plan[0][0].startswith("D.") and plan[-1][-1] == "mri_cnn.conv1.0.weight"
+    # the LAST bucket is the one that closes latest in backward: it must hold the first-block gradients
+    assert any(n.startswith("mri_cnn.conv1.") for n in plan[-1])
+
+
+def _unused_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from transmf_ad_amd.parallel import GradAllReduce, init_from_env
+    init_from_env("gloo")
+    torch.manual_seed(0)
+    m = nn.Sequential(nn.Linear(4, 4), nn.Linear(4, 4), nn.Linear(4, 2))
+    extra = nn.Linear(4, 4)                       # registered but never used in forward
+    m.add_module("unused", extra)
+    net = GradAllReduce(m, bucket_mb=0.0001)
+    x = torch.randn(3, 4) + rank
+    m[2](m[1](m[0](x))).sum().backward()
+    ok = extra.weight.grad is None and extra.bias.grad is None and all(p.grad is not None for p in m[0].parameters())
+    g0 = m[0].weight.grad.clone()
+    torch.save(dict(ok=ok, g0=g0), os.path.join(out_dir, f"u{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_unused_parameters_keep_grad_none(tmp_path):
+    """A parameter that receives no gradient keeps .grad = None on every rank (as in a single-process run, so Adam skips
+    it in both), while the used ones are averaged."""
+    world = 2
+    mp.spawn(_unused_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f"u{r}.pt") for r in range(world)]
+    assert all(r["ok"] for r in res)
+    assert torch.equal(res[0]["g0"], res[1]["g0"])

@@ -15,8 +15,10 @@ def kernels_of(obj):
     """[{name, vgpr, sgpr, scratch, lds}] for one host object with an embedded gfx950 code object."""
     with tempfile.TemporaryDirectory() as td:
         fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
-        subprocess.check_call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, os.path.join(td, "x.o")],
-                              stderr=subprocess.DEVNULL)
+        rc = subprocess.call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, os.path.join(td, "x.o")],
+                             stderr=subprocess.DEVNULL)
+        if rc != 0 or not os.path.exists(fat) or os.path.getsize(fat) == 0:
+            return []                   # host-only object (snet_path.o / fusion_path.o: pure launch orchestration)
         subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], stderr=subprocess.DEVNULL)
         notes = subprocess.check_output([f"{LLVM}/llvm-readelf", "--notes", co], text=True)

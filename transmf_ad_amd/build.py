@@ -8,12 +8,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libtmf_hip.so")
-SOURCES = ["conv3d_mfma.hip", "conv3d_bf16.hip", "conv1_fused.hip", "bn_act_pool.hip", "attention.hip", "token_ops.hip", "token_gemm.hip", "snet_path.hip", "fusion_path.hip"]
-# -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 work into v_pk_*_f32 and then patches one half of the pair
-# with a single-pass instruction (v_pk_mul_f32 v[6:7] ...; v_mov_b32 v6, v5; v_pk_add_f32 ..., v[6:7]).  On gfx950 that
-# sequence intermittently delivered the stale half in lanes 16-31 when the instructions issued back to back (the
-# first-block reduce pass at the tail of its grid: DESIGN.md 3.6) — found as a loss of run-to-run bit reproducibility.
-# Without the pass none of these sequences are left in the conv / BatchNorm / attention kernels (tools/pk_waw_scan.py).
+SOURCES = ["conv3d_mfma.hip", "conv3d_bf16.hip", "conv1_fused.hip", "bn_act_pool.hip", "attention.hip", "token_ops.hip", "token_gemm.hip", "snet_path.hip", "fusion_path.hip", "input_pipeline.hip"]
+# -fno-slp-vectorize: clang's SLP pass pairs adjacent scalar fp32 adds / muls into v_pk_*_f32.  Beside MFMAs that is
+# slower on gfx950 (MI355X_MICROARCH.md: packed fp32 fillers cost +22..26 cycles per MFMA gap against scalar v_fma_f32) and
+# it makes the hot loops depend on the vectoriser's cost model of the day.  (Round 1 also blamed a run-to-run
+# nondeterminism on a hardware hazard of the packed sequence; round 2 refuted that — profiles/r02_pk_waw_investigation.txt:
+# the sequence is correct in isolation, wait states do not cure the old failing object, and today's sources are
+# bit-reproducible with and without the flag.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
 

@@ -79,6 +79,10 @@ class GradAllReduce(nn.Module):
         self._callback_queued = False
         self._streams = {}
         self.require_sync = True
+        # timing = True: record a pair of events per step around "all buckets reduced" on the staging stream — the time
+        # backward's END has to wait for the collectives that did not hide under it (exposed_allreduce_ms())
+        self.timing = False
+        self._timing_events = []
         # TMF_DDP_FORCE=1 keeps the bucket machinery live in a 1-rank group (to measure its overhead on one GPU)
         self._force = os.environ.get("TMF_DDP_FORCE", "0") == "1"
         params = [p for p in module.parameters() if p.requires_grad]
@@ -179,9 +183,16 @@ class GradAllReduce(nn.Module):
             for b in self._buckets:
                 if b.work is None:        # some parameter got no gradient this pass
                     self._launch(b)
+            ev0 = ev1 = None
+            if cuda and self.timing:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record(st)
             for b in self._buckets:
                 b.work.wait()
                 b.flat.div_(self.world)
+            if ev0 is not None:
+                ev1.record(st)
+                self._timing_events.append((ev0, ev1))
         if cuda:
             torch.cuda.current_stream(dev).wait_stream(st)
         # .grad becomes a VIEW of the reduced bucket (no copy back); the next zero_grad() drops it and the next
@@ -194,6 +205,16 @@ class GradAllReduce(nn.Module):
                 if b.filled[i]:
                     p.grad = v
             b.reset()
+
+    def exposed_allreduce_ms(self):
+        """Per recorded step: milliseconds between the end of backward's compute and the last bucket being reduced and
+        scaled (what the collectives cost on top of backward).  Synchronises; clears the record."""
+        if not self._timing_events:
+            return []
+        self._timing_events[-1][1].synchronize()
+        out = [a.elapsed_time(b) for a, b in self._timing_events]
+        self._timing_events = []
+        return out
 
     def reduce_gradients(self):
         """Synchronous form (no overlap): all-reduce every bucket from the gradients currently in ``.grad``.

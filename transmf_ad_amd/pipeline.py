@@ -1,0 +1,156 @@
+"""Input pipeline ahead of the hot path, on the device.
+
+The reference feeds `train_step` from a MONAI `DataLoader(num_workers=0)` (datasets/__init__.py:56): NIfTI load,
+`ScaleIntensityd`, `RandFlipd(prob=0.3, spatial_axis=0)`, `RandRotated`, `RandZoomd` on the host (datasets/ADNI.py:59-70),
+then `batch['MRI'].to(device)` inside the step (kfold_train_adversarial.py:106-108).  Here the RAW volumes go to the
+device through pinned staging buffers on a copy stream (double-buffered: the copy of batch i + 1 overlaps the step of
+batch i) and the intensity scaling and the flip run there as HIP kernels (csrc/input_pipeline.hip, bit-identical to
+MONAI's published formulas as restated in oracle/input_oracle.py).  The random flip DECISIONS are drawn on the host with
+numpy (MONAI draws them from its own RandomState; only the probability is part of the reference's configuration).
+
+RandRotated / RandZoomd are not applied: their interpolation conventions cannot be pinned without MONAI (not installed,
+not vendored) — `DevicePrefetcher(..., strict_reference_aug=True)` raises instead of silently training without them.
+"""
+from __future__ import annotations
+
+from typing import Iterable, Iterator, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def scale_intensity_flip(vol: torch.Tensor, flips: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+                         stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+    """ScaleIntensity (per volume min-max to [0, 1]) and Flip(spatial_axis=0) of a device batch (B, 1, D, H, W) / (B, D, H, W).
+    flips: uint8 device tensor (B,), non-zero = reverse the first spatial axis of that volume."""
+    if not vol.is_cuda or vol.dtype != torch.float32:
+        raise _lib.TmfError("scale_intensity_flip needs a float32 tensor on the HIP device (there is no CPU fallback)")
+    v = vol.contiguous()
+    B = v.shape[0]
+    D, H, W = v.shape[-3:]
+    if v.numel() != B * D * H * W:
+        raise _lib.TmfError(f"expected (B, 1, D, H, W) or (B, D, H, W), got {tuple(vol.shape)}")
+    if flips is not None and not (flips.is_cuda and flips.dtype == torch.uint8 and flips.numel() == B):
+        raise _lib.TmfError("flips must be a uint8 device tensor of B elements")
+    with torch.cuda.device(v.device), (torch.cuda.stream(stream) if stream is not None else _Null()):
+        # allocations and launches under the SAME current stream (the caching allocator ties a block to its stream)
+        out = torch.empty_like(v) if out is None else out
+        s = torch.cuda.current_stream(v.device).cuda_stream
+        nws = _lib.query("tmf_scale_intensity_workspace_bytes", B)
+        ws = torch.empty(nws // 4 + 2 * B, device=v.device, dtype=torch.float32)
+        minmax = ws[nws // 4:]
+        _lib.call("tmf_volume_minmax", v.data_ptr(), minmax.data_ptr(), ws.data_ptr(), nws, B, D * H * W, s)
+        _lib.call("tmf_scale_flip", v.data_ptr(), out.data_ptr(), minmax.data_ptr(),
+                  None if flips is None else flips.data_ptr(), B, D, H, W, s)
+    return out
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class DevicePrefetcher:
+    """Iterate device batches {'MRI', 'PET', 'label'} from an iterable of HOST batches with the same keys (numpy arrays
+    or CPU tensors; MRI / PET raw float32 volumes (B, 1, D, H, W)).  Batch i + 1 is staged into pinned memory and copied
+    on a side stream while the caller trains on batch i; ScaleIntensity + flip run on that side stream too."""
+
+    def __init__(self, batches: Iterable, device="cuda", flip_prob: float = 0.3, seed: Optional[int] = None,
+                 train: bool = True, strict_reference_aug: bool = False):
+        if strict_reference_aug and train:
+            raise NotImplementedError(
+                "RandRotated / RandZoomd (datasets/ADNI.py:67-68) are not implemented on the device: their MONAI "
+                "interpolation conventions cannot be verified without the library")
+        self.batches = batches
+        self.device = torch.device(device)
+        self.flip_prob = flip_prob if train else 0.0
+        self.rs = np.random.RandomState(seed)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._pinned = [dict(), dict()]          # two staging sets, reused while shapes stay the same
+
+    def _stage(self, slot, key, arr):
+        t = torch.as_tensor(arr)
+        buf = self._pinned[slot].get(key)
+        if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
+            buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            self._pinned[slot][key] = buf
+        buf.copy_(t)
+        return buf
+
+    def _launch(self, slot, host_batch):
+        B = len(host_batch["label"])
+        flips = (self.rs.random_sample(B) < self.flip_prob).astype(np.uint8)      # one decision per subject
+        with torch.cuda.stream(self.copy_stream):
+            out = {}
+            fl = self._stage(slot, "_flips", flips).to(self.device, non_blocking=True)
+            for key in ("MRI", "PET"):
+                raw = self._stage(slot, key, host_batch[key]).to(self.device, non_blocking=True)
+                out[key] = scale_intensity_flip(raw, fl if self.flip_prob > 0 else None, stream=self.copy_stream)
+            out["label"] = self._stage(slot, "label", np.asarray(host_batch["label"], dtype=np.int64)).to(
+                self.device, non_blocking=True)
+            out["_flips"] = flips
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        return out, ev
+
+    def __iter__(self) -> Iterator[dict]:
+        """A worker thread stages batch i + 1 (pageable -> pinned memcpy, H2D and the two kernels on the copy stream) while
+        the caller trains on batch i: the main thread only waits on an event.  (Staging from the training thread itself
+        serialises a 57 MB host memcpy per step with the kernel launches: 36 ms per step instead of 17.)"""
+        import queue
+        import threading
+        q: "queue.Queue" = queue.Queue(maxsize=1)          # one batch ready + one being staged = the two pinned sets
+        stop = threading.Event()
+        dev = self.device
+
+        def worker():
+            try:
+                torch.cuda.set_device(dev)
+                events = [None, None]
+                slot = 0
+                for host_batch in self.batches:
+                    if stop.is_set():
+                        break
+                    if events[slot] is not None:
+                        events[slot].synchronize()          # the copies out of this pinned set have completed
+                    out, ev = self._launch(slot, host_batch)
+                    events[slot] = ev
+                    slot ^= 1
+                    while not stop.is_set():
+                        try:
+                            q.put((out, ev), timeout=0.1)
+                            break
+                        except queue.Full:
+                            continue
+                q.put(None)
+            except BaseException as e:                       # surface worker failures in the training thread
+                q.put(e)
+
+        th = threading.Thread(target=worker, name="tmf-prefetch", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                if isinstance(item, BaseException):
+                    raise item
+                out, ev = item
+                cur = torch.cuda.current_stream(self.device)
+                cur.wait_event(ev)
+                for k in ("MRI", "PET", "label"):
+                    out[k].record_stream(cur)
+                yield out
+        finally:
+            stop.set()
+            while th.is_alive():
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
