@@ -335,6 +335,18 @@ def main():
         pool = [dict(MRI=(rs.rand(B, 1, *vol) * 4000.0).astype(np.float32), PET=(rs.rand(B, 1, *vol) * 9.0).astype(np.float32),
                      label=np.arange(B) % 2) for _ in range(3)]              # raw intensities; 3 host batches, cycled
         feeder = iter(DevicePrefetcher(itertools.cycle(pool), device=dev, flip_prob=0.3, seed=rank))
+        # what the box's host link delivers (pinned -> device, 64 MB copies): the ceiling of this mode
+        pin = torch.empty(16 << 20, dtype=torch.float32, pin_memory=True)
+        pin.fill_(1.0)                       # touch the pages: an untouched pinned buffer copies at a fantasy rate
+        dbuf = torch.empty(16 << 20, dtype=torch.float32, device=dev)
+        dbuf.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        t_h = time.perf_counter()
+        for _ in range(5):
+            dbuf.copy_(pin, non_blocking=True)
+        torch.cuda.synchronize()
+        h2d_gbps = 5 * pin.numel() * 4 / (time.perf_counter() - t_h) / 1e9
+        del pin, dbuf
 
     def val_step():
         net.eval()
@@ -438,6 +450,9 @@ def main():
         dt = t.item()
     final_loss = loss.item()
     assert final_loss == final_loss, "loss is NaN"
+    if feeder is not None:
+        feeder.close()                     # stops and joins the prefetch thread
+        feeder = None
 
     ms_per_step = dt / max(args.steps, 1) * 1e3
     pairs_per_s = world * B * args.steps / dt
@@ -502,8 +517,9 @@ def main():
                                 "zero_grad+fwd+loss+2x loss.item()+bwd+allreduce+Adam (kfold_train_adversarial.py:101-136)"),
                        "dispatch": mode,
                        "input": ("host: raw volumes -> pinned staging -> H2D on a copy stream (double-buffered) -> device "
-                                 "ScaleIntensity + RandFlip(0.3), every step (PCIe-inclusive)" if args.from_host else
-                                 "resident in HBM"),
+                                 f"ScaleIntensity + RandFlip(0.3), every step (PCIe-inclusive); {2 * B * vol[0] * vol[1] * vol[2] * 4 / 1e6:.1f} "
+                                 f"MB per step over a host link measured at {h2d_gbps:.1f} GB/s pinned -> device on this box"
+                                 if args.from_host else "resident in HBM"),
                        "setup_steps_untimed": setup_steps},
             "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
             "loss": round(final_loss, 6),

@@ -61,7 +61,7 @@ class DevicePrefetcher:
     on a side stream while the caller trains on batch i; ScaleIntensity + flip run on that side stream too."""
 
     def __init__(self, batches: Iterable, device="cuda", flip_prob: float = 0.3, seed: Optional[int] = None,
-                 train: bool = True, strict_reference_aug: bool = False):
+                 train: bool = True, strict_reference_aug: bool = False, pinned_staging: bool = False):
         if strict_reference_aug and train:
             raise NotImplementedError(
                 "RandRotated / RandZoomd (datasets/ADNI.py:67-68) are not implemented on the device: their MONAI "
@@ -72,9 +72,16 @@ class DevicePrefetcher:
         self.rs = np.random.RandomState(seed)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._pinned = [dict(), dict()]          # two staging sets, reused while shapes stay the same
+        # pinned_staging=False (default): the worker thread copies straight from the loader's pageable arrays with a
+        # blocking .to(device) on the copy stream — the runtime stages through its own pinned pool at the full link rate
+        # (50 GB/s measured here), and only the WORKER blocks.  Re-filling our own pinned set every batch measured 15 ms
+        # per 28 MB on this box (tools/prefetch_probe.py), slower than the copy it was meant to speed up.
+        self.pinned_staging = pinned_staging
 
     def _stage(self, slot, key, arr):
         t = torch.as_tensor(arr)
+        if not self.pinned_staging:
+            return t
         buf = self._pinned[slot].get(key)
         if buf is None or buf.shape != t.shape or buf.dtype != t.dtype:
             buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
@@ -87,12 +94,13 @@ class DevicePrefetcher:
         flips = (self.rs.random_sample(B) < self.flip_prob).astype(np.uint8)      # one decision per subject
         with torch.cuda.stream(self.copy_stream):
             out = {}
-            fl = self._stage(slot, "_flips", flips).to(self.device, non_blocking=True)
+            nb = self.pinned_staging
+            fl = self._stage(slot, "_flips", flips).to(self.device, non_blocking=nb)
             for key in ("MRI", "PET"):
-                raw = self._stage(slot, key, host_batch[key]).to(self.device, non_blocking=True)
+                raw = self._stage(slot, key, host_batch[key]).to(self.device, non_blocking=nb)
                 out[key] = scale_intensity_flip(raw, fl if self.flip_prob > 0 else None, stream=self.copy_stream)
             out["label"] = self._stage(slot, "label", np.asarray(host_batch["label"], dtype=np.int64)).to(
-                self.device, non_blocking=True)
+                self.device, non_blocking=nb)
             out["_flips"] = flips
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
@@ -131,6 +139,14 @@ class DevicePrefetcher:
             except BaseException as e:                       # surface worker failures in the training thread
                 q.put(e)
 
+        # The training thread is busy issuing launches for most of a step and only hands the GIL over every
+        # sys.getswitchinterval() = 5 ms; the worker needs it ~30 times per batch (between its GIL-free copies and
+        # launches), so with the default interval a 1 ms staging job stretches to tens of ms and the step waits for it
+        # (measured: 36 ms per step instead of 17).  A 100 us interval while the prefetcher runs costs the trainer nothing
+        # measurable and lets the worker through.
+        import sys
+        old_interval = sys.getswitchinterval()
+        sys.setswitchinterval(1e-4)
         th = threading.Thread(target=worker, name="tmf-prefetch", daemon=True)
         th.start()
         try:
@@ -147,6 +163,7 @@ class DevicePrefetcher:
                     out[k].record_stream(cur)
                 yield out
         finally:
+            sys.setswitchinterval(old_interval)
             stop.set()
             while th.is_alive():
                 try:
