@@ -109,6 +109,7 @@ int    tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw, void* w
  * bf16, 2 = z is bf16 (statistics still from the fp32 accumulators); for the weight gradient io = 1: x and dz are bf16. */
 int    tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z, float* stat_partial,
                              int B, int D, int H, int W, int cin, int cout, int io, void* stream);
+const char* tmf_conv3d_fwd_bf16_kernel_name(int B, int D, int H, int W, int cin, int cout, int io);   /* as tmf_conv3d_fwd_kernel_name */
 int    tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
                                int B, int D, int H, int W, int cin, int cout, int io, int dw_layout, void* stream);
 /* fp32-ACCURATE variant on the bf16 matrix cores: operands split exactly into three bf16 numbers (hi+mid+lo), the

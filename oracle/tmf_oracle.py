@@ -171,9 +171,87 @@ def _batch_norm(S: Dict[str, Tensor], p: str, x: Tensor, train: bool) -> Tensor:
                         S[p + ".weight"], S[p + ".bias"], train, BN_MOMENTUM, BN_EPS)
 
 
+# --------------------------------------------------------------------------
+# The opt-in bf16 modes of the HIP path (BASELINE configs[2]), restated: the SAME algorithm with the product path's
+# rounding points made explicit, so that the bf16 kernels have an oracle of their own (tests/test_gpu_model.py).
+#   conv_mode "bf16" : every 3x3x3 convolution product — forward, data gradient, weight gradient, incl. the first
+#                      block — takes its two operands rounded to bf16 (RNE) and accumulates exactly (here: in the run's
+#                      dtype, fp64 in the tests); the 1x1x1 layer stays exact.
+#   conv_mode "bf16s": additionally the tensors BETWEEN the 3x3x3 blocks are bf16: the raw conv output z is rounded once
+#                      (BatchNorm statistics still come from the unrounded accumulators), a block's output is rounded
+#                      when the next block also runs on the bf16 kernels, and the gradients of those tensors (dz, and the
+#                      data gradient written into a bf16 tensor) are rounded the same way.
+# --------------------------------------------------------------------------
+
+def _rb(t: Tensor) -> Tensor:
+    """round to bf16 (RNE, from the fp32 value — what the kernels see) and back to the run's dtype"""
+    return t.float().bfloat16().to(t.dtype)
+
+
+class _ConvBf16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, pad):
+        xr, wr = _rb(x), _rb(w)
+        ctx.save_for_backward(xr, wr)
+        ctx.pad = pad
+        return F.conv3d(xr, wr, None, stride=1, padding=pad)
+
+    @staticmethod
+    def backward(ctx, dz):
+        xr, wr = ctx.saved_tensors
+        dzr = _rb(dz)
+        dx = torch.nn.grad.conv3d_input(xr.shape, wr, dzr, stride=1, padding=ctx.pad) if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv3d_weight(xr, wr.shape, dzr, stride=1, padding=ctx.pad)
+        return dx, dw, None
+
+
+class _RoundSTE(torch.autograd.Function):
+    """a tensor stored as bf16: the value is rounded on the way forward, its gradient on the way back"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _rb(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rb(g)
+
+
+class _BnStoredZ(torch.autograd.Function):
+    """Train-mode BatchNorm whose statistics come from the UNROUNDED conv output while the normalised tensor is the
+    stored (bf16) one; backward is the kernels' closed form on the stored tensor with the saved statistics:
+        xhat = (zs - mean) * invstd;  dgamma = sum(dy * xhat);  dbeta = sum(dy);
+        dz = gamma * invstd * (dy - mean(dy) - xhat * mean(dy * xhat))"""
+
+    @staticmethod
+    def forward(ctx, zs, mean, invstd, gamma, beta):
+        shp = (1, -1, 1, 1, 1)
+        xhat = (zs - mean.view(shp)) * invstd.view(shp)
+        ctx.save_for_backward(xhat, invstd, gamma)
+        return xhat * gamma.view(shp) + beta.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, invstd, gamma = ctx.saved_tensors
+        shp = (1, -1, 1, 1, 1)
+        dims = (0, 2, 3, 4)
+        n = dy.numel() / dy.shape[1]
+        dbeta = dy.sum(dims)
+        dgamma = (dy * xhat).sum(dims)
+        dz = (gamma * invstd).view(shp) * (dy - (dbeta / n).view(shp) - xhat * (dgamma / n).view(shp))
+        return dz, None, None, dgamma, dbeta
+
+
+def _bf16_capable(L: dict) -> bool:
+    return L["k"] == 3 and L["cin"] > 1 and L["cin"] % 8 == 0
+
+
 def snet_forward(S: Dict[str, Tensor], pre: str, dim: int, x: Tensor, train: bool,
-                 probes: Optional[dict] = None) -> Tensor:
-    """``sNet.forward`` (networks.py:55-61).  x: (B,1,D,H,W) -> (B,dim,D/16,H/16,W/16)."""
+                 probes: Optional[dict] = None, conv_mode: str = "exact") -> Tensor:
+    """``sNet.forward`` (networks.py:55-61).  x: (B,1,D,H,W) -> (B,dim,D/16,H/16,W/16).
+    conv_mode: "exact" (the reference), or the restated bf16 modes of the HIP path (see above; train mode only)."""
+    if conv_mode != "exact":
+        return _snet_forward_bf16(S, pre, dim, x, train, probes, conv_mode)
     for L in snet_layers(dim):
         w, b = S[f"{pre}{L['conv']}.weight"], S[f"{pre}{L['conv']}.bias"]
         x = F.conv3d(x, w, b, stride=1, padding=1 if L["k"] == 3 else 0)
@@ -185,6 +263,48 @@ def snet_forward(S: Dict[str, Tensor], pre: str, dim: int, x: Tensor, train: boo
             x = F.avg_pool3d(x, 2, 2)
         if probes is not None:
             probes[f"{pre}{L['conv']}"] = x
+    return x
+
+
+def _snet_forward_bf16(S, pre, dim, x, train, probes, conv_mode):
+    assert train and conv_mode in ("bf16", "bf16s")
+    store16 = conv_mode == "bf16s"
+    layers = snet_layers(dim)
+    for i, L in enumerate(layers):
+        w, b = S[f"{pre}{L['conv']}.weight"], S[f"{pre}{L['conv']}.bias"]
+        bn = f"{pre}{L['bn']}"
+        on_bf16 = L["cin"] == 1 or _bf16_capable(L)           # the fused first block has bf16 passes of its own
+        if on_bf16:
+            z = _ConvBf16.apply(x, w, 1)
+        else:
+            z = F.conv3d(x, w, None, stride=1, padding=1 if L["k"] == 3 else 0)
+        # batch statistics from the unrounded accumulators; the conv bias only shifts the mean (folded: it reaches
+        # running_mean, never the activations)
+        dims = (0, 2, 3, 4)
+        mean = z.mean(dims)
+        var = z.var(dims, unbiased=False)
+        n = z.numel() / z.shape[1]
+        with torch.no_grad():
+            S[bn + ".num_batches_tracked"] += 1
+            S[bn + ".running_mean"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * (mean + b).to(S[bn + ".running_mean"].dtype))
+            S[bn + ".running_var"].mul_(1 - BN_MOMENTUM).add_(BN_MOMENTUM * (var * n / (n - 1)).to(S[bn + ".running_var"].dtype))
+        invstd = (var + BN_EPS).rsqrt()
+        z16 = store16 and _bf16_capable(L)                    # the first block never stores z
+        if z16:
+            y = _BnStoredZ.apply(_RoundSTE.apply(z), mean.detach(), invstd.detach(), S[bn + ".weight"], S[bn + ".bias"])
+        else:
+            shp = (1, -1, 1, 1, 1)
+            y = (z - mean.view(shp)) * invstd.view(shp) * S[bn + ".weight"].view(shp) + S[bn + ".bias"].view(shp)
+        y = F.leaky_relu(y, LRELU_SLOPE)
+        if L["pool"] == "max":
+            y = F.max_pool3d(y, 2, 2)
+        elif L["pool"] == "avg":
+            y = F.avg_pool3d(y, 2, 2)
+        if store16 and i + 1 < len(layers) and on_bf16 and _bf16_capable(layers[i + 1]):
+            y = _RoundSTE.apply(y)
+        if probes is not None:
+            probes[f"{pre}{L['conv']}"] = y
+        x = y
     return x
 
 
@@ -274,10 +394,10 @@ def _drop(x: Tensor, mask: Optional[Tensor], train: bool, p: float = 0.5) -> Ten
 
 def model_ad_forward(S, mri: Tensor, pet: Tensor, *, dim=128, depth=3, heads=4, train=True,
                      dropout_masks: Optional[Tuple[Tensor, Tensor]] = None,
-                     probes: Optional[dict] = None):
+                     probes: Optional[dict] = None, conv_mode: str = "exact"):
     """``model_ad.forward`` (mymodel.py:204-222) -> (logits, D_MRI_logits, D_PET_logits)."""
-    m = snet_forward(S, "mri_cnn.", dim, mri, train, probes)
-    p = snet_forward(S, "pet_cnn.", dim, pet, train, probes)
+    m = snet_forward(S, "mri_cnn.", dim, mri, train, probes, conv_mode)
+    p = snet_forward(S, "pet_cnn.", dim, pet, train, probes, conv_mode)
     vm = _RevGrad.apply(m.mean(dim=(2, 3, 4)), REVGRAD_ALPHA)          # :210
     vp = _RevGrad.apply(p.mean(dim=(2, 3, 4)), REVGRAD_ALPHA)          # :211
     d_m = _disc_forward(S, vm, train)                                   # :214

@@ -726,3 +726,87 @@ def test_one_call_fusion_is_taken_by_default():
     mri, pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
     cls, _dm, _dp = net.forward_features(mri, pet)
     assert type(cls.grad_fn).__name__.startswith("FusionTrain"), cls.grad_fn
+
+
+def _bf16_mode_errors(mode, B=4, size=(48, 48, 48)):
+    """HIP path in a bf16 mode against the oracle's restatement of THAT mode (oracle/tmf_oracle.py conv_mode: the same
+    algorithm with the kernels' rounding points, evaluated in fp64) on structured volumes.  Returns error figures."""
+    import transmf_ad_amd as T
+    from oracle import params as P
+    from oracle import tmf_oracle as O
+    kw = dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512)
+    spec = O.state_spec("model_ad", **kw)
+    arrs = P.init_arrays(spec, seed=11)
+    mri, pet, y = P.make_inputs(B, size, seed=77, kind="blobs")
+    k1, k2 = P.make_masks(B, seed=5)
+    # oracle, fp64, with the mode's roundings
+    S = O.to_state(arrs, spec, dtype=torch.float64)
+    probes = {}
+    lo, dm, dp = O.model_ad_forward(S, torch.from_numpy(mri).double(), torch.from_numpy(pet).double(), dim=128, depth=3,
+                                    heads=4, train=True, dropout_masks=(torch.from_numpy(k1), torch.from_numpy(k2)),
+                                    probes=probes, conv_mode=mode)
+    loss_ref = O.adversarial_loss(lo, dm, dp, torch.from_numpy(y))
+    loss_ref.backward()
+    gref = O.grads_of(S, spec)
+    # HIP path
+    T.set_conv_precision("bf16")
+    T.set_activation_storage("bf16" if mode == "bf16s" else "fp32")
+    try:
+        net = T.model_ad(dropout=0., **kw)
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in arrs.items()}, strict=True)
+        net = net.to(DEV).train()
+        net.fc_cls[3] = FixedMaskDropout(torch.from_numpy(k1).float().to(DEV))
+        net.fc_cls[7] = FixedMaskDropout(torch.from_numpy(k2).float().to(DEV))
+        seen = {}
+        net.fuse_transformer.register_forward_hook(lambda _m, _i, o: seen.__setitem__("cls", o))
+        for c in ("mri_cnn", "pet_cnn"):
+            getattr(net, c).register_forward_hook(lambda _m, _i, o, c=c: seen.__setitem__(f"{c}.conv4.3", o))
+        xm, xp, yt = (torch.from_numpy(a).to(DEV) for a in (mri, pet, y))
+        crit = nn.CrossEntropyLoss()
+        l2, d2m, d2p = net(xm, xp)
+        loss = (crit(d2m, torch.ones_like(yt)) + crit(d2p, torch.zeros_like(yt))) / 2 + crit(l2, yt)
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        T.set_activation_storage("fp32")
+        T.set_conv_precision("fp32")
+    err = {"loss": abs(loss.item() - loss_ref.item()),
+           "logits": (l2.detach().double().cpu() - lo.detach()).abs().max().item(),
+           "d": max((d2m.detach().double().cpu() - dm.detach()).abs().max().item(),
+                    (d2p.detach().double().cpu() - dp.detach()).abs().max().item())}
+    for k in ("cls", "mri_cnn.conv4.3", "pet_cnn.conv4.3"):
+        ref = probes[k].detach()
+        err[k] = ((seen[k].detach().double().cpu() - ref).abs().max() / ref.abs().max()).item()
+    zk = zero_grad_keys(spec, "model_ad")
+    gl2 = {}
+    for k, p in net.named_parameters():
+        if k in zk:
+            continue
+        r = gref[k]
+        gl2[k] = ((p.grad.double().cpu() - r).norm() / r.norm().clamp_min(1e-30)).item()
+    err["grad_l2_conv"] = max(v for k, v in gl2.items() if "_cnn." in k)
+    err["grad_l2_rest"] = max(v for k, v in gl2.items() if "_cnn." not in k)
+    err["worst_grad"] = max(gl2.items(), key=lambda kv: kv[1])
+    return err
+
+
+# Tolerances ~3x the measured values (B=4, 48^3 structured volumes, dim 128: bf16 -> sNet outputs / cls 1.4-1.7e-3 of
+# their scale, logits 1.5e-2, D logits 3e-3, loss 3e-3, gradients 9.2e-2 (conv side) / 5.0e-2 (fusion + heads) in relative
+# L2;  bf16 storage -> 2.8e-3, 1.7e-2, 6.3e-3, 4.6e-4, 0.14 / 0.11).  Against the UN-rounded fp32 reference the same
+# quantities are 4-10x larger (test_config3_128_b8...: activations 7e-3 .. 1.1e-2, gradients not comparable element-wise).
+BF16_ORACLE_TOL = {"bf16": dict(act=5e-3, logits=5e-2, d=1e-2, loss=1e-2, gconv=0.25, grest=0.15),
+                   "bf16s": dict(act=8e-3, logits=5e-2, d=2e-2, loss=1e-2, gconv=0.35, grest=0.3)}
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16s"])
+def test_bf16_modes_match_their_own_oracle(mode):
+    """configs[2] parity proper: the bf16 modes are a DEFINED algorithm (the reference's, with bf16 rounding of the conv
+    operands — and, in the storage mode, of the tensors between the 3x3x3 blocks — at stated points), restated on the host
+    in fp64 (oracle/tmf_oracle.py, conv_mode).  Against that oracle the HIP path agrees an order of magnitude closer than
+    against the un-rounded fp32 reference; what is left are bf16 rounding-boundary flips (a value within fp32 round-off of
+    a bf16 rounding boundary goes the other way: one 2^-8 step in one element) and discrete pool / LeakyReLU decisions."""
+    e = _bf16_mode_errors(mode)
+    tol = BF16_ORACLE_TOL[mode]
+    assert max(e["cls"], e["mri_cnn.conv4.3"], e["pet_cnn.conv4.3"]) <= tol["act"], e
+    assert e["logits"] <= tol["logits"] and e["d"] <= tol["d"] and e["loss"] <= tol["loss"], e
+    assert e["grad_l2_conv"] <= tol["gconv"] and e["grad_l2_rest"] <= tol["grest"], e

@@ -1,26 +1,35 @@
-# One GPU-box pass that regenerates what profiles/ holds for the fp32 headline configuration.
-# Run through gpurun from the repo root: gpurun --timeout 1500 -- 'bash tools/scripts/refresh_profiles.sh'; then copy
-# gpurun_out/refresh/* into profiles/ under the round's names.
+# One GPU-box pass that regenerates what profiles/ holds for the round (fp32 headline + configs[2] bf16 report).
+# Run through gpurun from the repo root:  gpurun --timeout 2400 -- 'bash tools/scripts/refresh_profiles.sh r02'
+# then copy gpurun_out/refresh/* into profiles/.
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/refresh
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd $R
-timeout 400 python3 bench.py > $O/bench_n1.log 2>&1; grep "^{" $O/bench_n1.log | tail -1 > $O/bench_n1.json
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/roof -o roof -- python3 bench.py --roofline-only > $O/roof.log 2>&1
-grep "^{" $O/roof.log | tail -1 > $O/roofline_only.json
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b2s -o b2s -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/b2s.log 2>&1
-TMF_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b1s -o b1s -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/b1s.log 2>&1
-cp $O/roof/roof_kernel_stats.csv $O/roofline_only_kernel_stats.csv
-cp $O/b2s/b2s_kernel_stats.csv $O/bench_kernel_stats.csv
-cp $O/b1s/b1s_kernel_stats.csv $O/bench_kernel_stats_1stream.csv
-rm -rf $O/roof $O/b2s $O/b1s
-bash tools/scripts/pmc_fp32_hot.sh
-cp gpurun_out/pmc32_summary.txt $O/pmc_conv2.3_hot.txt
-python3 -c "
-import json
-d = json.load(open('$O/bench_n1.json')); r = json.load(open('$O/roofline_only.json'))
-print('bench', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'])
-print('roofline-only', r.get('roofline', r))
-"
-grep conv3d_fwd_kernel $O/roofline_only_kernel_stats.csv | head -3 | cut -c1-260
+# --- bench lines (un-profiled) ---
+timeout 600 python3 bench.py > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_n1.json
+timeout 300 python3 bench.py --no-item-sync --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_n1_no_item_sync.json
+timeout 300 python3 bench.py --from-host --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_n1_from_host.json
+timeout 300 python3 bench.py --precision bf16 --storage bf16 --size 128 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_128_bf16_storage.json
+timeout 300 python3 bench.py --precision bf16 --size 128 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_128_bf16.json
+timeout 300 python3 bench.py --precision bf16 --storage bf16 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_96_bf16_storage.json
+timeout 300 python3 bench.py --size 128 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_128_fp32.json
+timeout 300 python3 bench.py --shape 91 109 91 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_adni_shape.json
+timeout 300 python3 bench.py --model cnn --batch 16 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_cnn_b16.json
+timeout 300 python3 bench.py --model single --batch 16 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_single_b16.json
+timeout 300 python3 bench.py --eval --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_eval_n1.json
+# --- kernel-trace statistics of the SAME commands (roofline loop only: the averages the roofline object quotes) ---
+prof() { # name, bench flags...
+  n=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/_p -o p -- python3 bench.py "$@" > $O/_p.log 2>&1
+  cp $O/_p/p_kernel_stats.csv $O/${TAG}_${n}_kernel_stats.csv; grep "^{" $O/_p.log | tail -1 > $O/${TAG}_${n}.json; rm -rf $O/_p
+}
+prof roofline_only --roofline-only --no-cpu-baseline
+prof roofline_only_128_bf16_storage --roofline-only --no-cpu-baseline --precision bf16 --storage bf16 --size 128
+# --- kernel-trace statistics of whole train steps (two encoder streams, and one stream for additive numbers) ---
+TMF_ROOF_REPS=1 TMF_ROOF_SPIN_S=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/_p -o p -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/_p.log 2>&1; cp $O/_p/p_kernel_stats.csv $O/${TAG}_bench_kernel_stats.csv; rm -rf $O/_p
+TMF_STREAMS=1 TMF_ROOF_REPS=1 TMF_ROOF_SPIN_S=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/_p -o p -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $O/_p.log 2>&1; cp $O/_p/p_kernel_stats.csv $O/${TAG}_bench_kernel_stats_1stream.csv; rm -rf $O/_p
+TMF_STREAMS=1 TMF_ROOF_REPS=1 TMF_ROOF_SPIN_S=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/_p -o p -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --precision bf16 --storage bf16 --size 128 > $O/_p.log 2>&1; cp $O/_p/p_kernel_stats.csv $O/${TAG}_bench_128_bf16_storage_kernel_stats_1stream.csv; rm -rf $O/_p
+rm -f $O/b.log $O/_p.log
+ls -la $O

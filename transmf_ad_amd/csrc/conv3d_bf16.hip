@@ -1016,6 +1016,20 @@ extern "C" int tmf_conv3d_bf16_stat_blocks(int B, int D, int H, int W) {
     return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
 }
 
+// kernel-trace name of the instance tmf_conv3d_fwd_bf16_t launches for a shape (measurement aid, as tmf_conv3d_fwd_kernel_name)
+extern "C" const char* tmf_conv3d_fwd_bf16_kernel_name(int B, int D, int H, int W, int cin, int cout, int io) {
+    static thread_local char buf[64];
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return "?";
+    const char* i16 = (io & 1) ? "true" : "false";
+    const char* o16 = (io & 2) ? "true" : "false";
+    if (use_v2(B, D, H, W)) snprintf(buf, sizeof buf, "conv3d_fwd_bf16_v2_kernel<%d, %s, %s>", cout > 32 ? 2 : 1, i16, o16);
+    else {
+        static const bool nt2 = [] { const char* e = getenv("TMF_BF_NT2"); return e == nullptr || atoi(e) != 0; }();
+        snprintf(buf, sizeof buf, "conv3d_fwd_bf16_kernel<%d, %s, %s>", (nt2 && cout % 64 == 0) ? 2 : 1, i16, o16);
+    }
+    return buf;
+}
+
 // io: bit 0 = x is a bf16 tensor, bit 1 = z is a bf16 tensor
 extern "C" int tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z, float* stat_partial,
                                      int B, int D, int H, int W, int cin, int cout, int io, void* stream) {
