@@ -333,7 +333,9 @@ template <int NT, bool IN16, bool OUT16>
 __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     const void* __restrict__ x_, const u16* __restrict__ w, void* __restrict__ z_,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
-    int tilesD, int tilesH, int tilesW, int ntiles) {
+    int tilesD, int tilesH, int tilesW, int ntiles, int dbg) {
+    // dbg (tmf_set_option("debug", bits), timing ablations only — results are garbage when set): 1 = no weight loads,
+    // 2 = no halo loads, 4 = no stage barriers, 8 = no MFMAs, 16 = no output stores
     constexpr int TD = v2::TD, TH = v2::TH, TW = v2::TW, HH = v2::HH, HW = v2::HW, NHALO = v2::NHALO, CINC = v2::CINC,
                   RP = v2::RP, TPS = v2::TPS, NSTAGES = v2::NSTAGES, NTHR = v2::NTHR, MT2 = v2::MT2;
     constexpr int NB = v2::Cfg<NT>::NB, WSTAGE = v2::Cfg<NT>::WSTAGE;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
             const int row = tid >> 1, piece = tid & 1;        // row = tap_in_stage * NB + co
             const int tap = st * TPS + row / NB, co = n0 + row % NB, ci = c0 + piece * 8;
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (tid < NPIECE && co < Cout && ci < Cin)
+            if (tid < NPIECE && co < Cout && ci < Cin && !(dbg & 1))
                 v = *reinterpret_cast<const u32x4*>(w + ((size_t)tap * Cout + co) * Cin + ci);
             wreg[slot] = v;
         };
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
             for (int q = 0; q < HV; ++q) {
                 const int c = c0 + ((tid + q * NTHR) & 1) * 8;
                 u32x4 v = {0u, 0u, 0u, 0u};
-                if (hoff[q] >= 0 && c < Cin) v = *reinterpret_cast<const u32x4*>(xb16 + hoff[q] + c);
+                if (hoff[q] >= 0 && c < Cin && !(dbg & 2)) v = *reinterpret_cast<const u32x4*>(xb16 + hoff[q] + c);
                 hreg[q] = v;
             }
 #pragma unroll
@@ -446,9 +448,10 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
         for (int st = 0; st < NSTAGES; ++st) {
             const int buf = st & 1;
             store_w(buf, st % PW);
-            __syncthreads();
+            if (!(dbg & 4)) __syncthreads();
             if (st + PW < NSTAGES) load_w(st + PW, st % PW);
             const u16* ap = halo + a_lane + ((st / 3) * HH + (st % 3)) * HW * RP;          // kd = st / 3, kh = st % 3
+            if (dbg & 8) continue;
             const u16* ws = Ws + buf * WSTAGE + b_lane;
 #pragma unroll
             for (int tp = 0; tp < TPS; ++tp) {                                            // kw
@@ -489,7 +492,7 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
                         const float a = acc[m][j][r], bq = acc[m][j][r + 1];
                         const float other = __shfl_xor(odd ? a : bq, 1);
                         const unsigned int pk = odd ? pack_bf16(other, bq) : pack_bf16(a, other);
-                        if (FULL || (pv && co < Cout))
+                        if ((FULL || (pv && co < Cout)) && !(dbg & 16))
                             *reinterpret_cast<unsigned int*>(zb16 + off + (co & ~1)) = pk;
                         const bool va = FULL || (dA < D && gh < H && gw < W && co < Cout);
                         const bool vb = FULL || (dA + 1 < D && gh < H && gw < W && co < Cout);
@@ -996,6 +999,7 @@ WgBfPlan plan_wgrad_bf16(int B, int D, int H, int W, int cin, int cout) {
 // slots reasonably; the choice depends on the geometry only (tmf_conv3d_bf16_stat_blocks has no channel arguments).
 // tmf_set_option("bf16_v2", 0) / TMF_BF_V2=0 selects the small-brick kernel everywhere, 2 the large-brick kernel
 // everywhere (A/B runs, tests), 1 (default) by the brick count.
+int tmf_g_debug = 0;             // tmf_set_option("debug", bits): timing ablations (results are garbage when set)
 int tmf_g_bf16_v2 = -1;          // tmf_set_option("bf16_v2", 0 | 1 | 2); -1 = not set yet: TMF_BF_V2 or 1
 static bool use_v2(int B, int D, int H, int W) {
     if (tmf_g_bf16_v2 < 0) { const char* e = getenv("TMF_BF_V2"); tmf_g_bf16_v2 = e == nullptr ? 1 : atoi(e); }
@@ -1052,7 +1056,7 @@ extern "C" int tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z,
         auto k = conv3d_fwd_bf16_v2_kernel<NT, I16, O16>;                                                            \
         if ((rc = tmf_allow_lds(k, v2::Cfg<NT>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;                       \
         hipLaunchKernelGGL(k, dim3(ntiles, tmf_cdiv(cout, 32 * NT)), dim3(v2::NTHR), v2::Cfg<NT>::LDS_BYTES, s, x,    \
-                           (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles);             \
+                           (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles, tmf_g_debug); \
     } while (0)
 #define TMF_BF2_IO(NT)                                                                                               \
     do {                                                                                                             \

@@ -1559,7 +1559,7 @@ extern "C" int tmf_set_option(const char* name, int value) {
         g_conv_waves = value;
         return TMF_OK;
     }
-    if (strcmp(name, "debug") == 0) { g_debug = value; return TMF_OK; }
+    if (strcmp(name, "debug") == 0) { g_debug = value; tmf_g_debug = value; return TMF_OK; }
     if (strcmp(name, "conv_ws") == 0) { g_conv_ws = value; return TMF_OK; }
     if (strcmp(name, "bf16_v2") == 0) {
         TMF_REQUIRE(value >= 0 && value <= 2, TMF_E_ARG, "tmf_set_option: bf16_v2 must be 0, 1 or 2, got %d", value);

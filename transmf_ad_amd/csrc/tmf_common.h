@@ -82,6 +82,7 @@ template <> struct TmfIO<tmf_bf16_t, 1> {
 #endif
 
 void tmf_set_error(const char* fmt, ...);
+extern int tmf_g_debug;          // conv3d_bf16.hip: timing-ablation bits (tmf_set_option("debug", ..))
 extern int tmf_g_bf16_v2;        // conv3d_bf16.hip: kernel choice of the bf16 forward (tmf_set_option("bf16_v2", ..))
 
 #define TMF_REQUIRE_PTR(p)                                                     \
