@@ -79,12 +79,13 @@ def conv_bytes_per_pair(size, elem, dim=128):
     return 2 * tot
 
 
-def _pmc_traffic(kernel):
+def _pmc_traffic(kernel, precision, storage, B, vol):
     """HBM bytes per launch of a kernel instance from the committed rocprofv3 --pmc passes (counters cannot be read
-    live): profiles/r02_pmc_traffic.json = {kernel name substring: {"hbm_bytes_per_launch": ..., "shape": ...}}."""
+    live): profiles/r02_pmc_traffic.json = {"precision|storage|B|DxHxW": {kernel instance: {"hbm_bytes_per_launch": ...}}};
+    None for configurations that were not profiled."""
     try:
         with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            tab = json.load(f)
+            tab = json.load(f).get(f"{precision}|{storage}|{B}|{'x'.join(map(str, vol))}", {})
         for key, row in tab.items():
             if key in kernel:
                 return row
@@ -180,7 +181,7 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
     return rows
 
 
-def roofline_report(rows, precision, pairs_per_s, world, gf_pair, bytes_pair, B, vol):
+def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes_pair, B, vol):
     """Fold the per-launch rows into the bench line's `roofline` object:
       * main entry  = the time-dominant kernel instance of a step (all of its launches, FLOP-weighted);
       * step_conv   = FLOP-weighted over EVERY conv launch of one step (both encoders);
@@ -203,7 +204,7 @@ def roofline_report(rows, precision, pairs_per_s, world, gf_pair, bytes_pair, B,
     tot_fl = sum(r["flops"] for r in rows)
     tot_by = sum(r["bytes"] for r in rows)
     best = max((r for r in rows if r["layer"] != "conv1.0"), key=lambda r: r["flops"] / r["ms"])
-    traffic = _pmc_traffic(dom_name)
+    traffic = _pmc_traffic(dom_name, precision, storage, B, vol)
     roof = {
         "bound": bound,
         "kernel": dom_name,
@@ -470,7 +471,8 @@ def main():
         _spin_up(dev, float(os.environ.get("TMF_ROOF_SPIN_S", "0.5")))
         rows = measure_conv_launches(ops, _lib, dev, B, vol, args.precision, args.storage,
                                      reps=int(os.environ.get("TMF_ROOF_REPS", "10")))
-        roof = roofline_report(rows, args.precision, pairs_per_s if args.steps > 0 else None, world, gf_pair, by_pair, B, vol)
+        roof = roofline_report(rows, args.precision, args.storage, pairs_per_s if args.steps > 0 else None, world, gf_pair,
+                               by_pair, B, vol)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
