@@ -373,6 +373,12 @@ int    tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, const tmf_sn
                           void* saved, size_t saved_bytes, float* out, void* stream);
 int    tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, const void* saved, size_t saved_bytes,
                           const float* dout, const tmf_snet_grads* grads, void* scratch, size_t scratch_bytes, void* stream);
+/* Inference form (val_step, kfold_train_adversarial.py:144-161; eval-mode BatchNorm folded into each block's single
+ * conv + BN + LeakyReLU + pool kernel): one call per encoder, fp32 precision, running statistics required; `workspace`
+ * (>= tmf_snet_eval_workspace_bytes) is scratch. */
+size_t tmf_snet_eval_workspace_bytes(const tmf_snet_desc* d);
+int    tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const tmf_snet_params* params,
+                         void* workspace, size_t workspace_bytes, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------
  * Whole-fusion entries (csrc/fusion_path.hip): ONE call enqueues every launch of CrossTransformer_MOD_AVG's train-mode
@@ -407,6 +413,39 @@ int    tmf_fusion_train_bwd(const tmf_fusion_desc* d, const float* mri_tok, cons
                             const tmf_xformer_params* inst, const void* saved, size_t saved_bytes, const float* dcls,
                             const tmf_xformer_grads* grads, float* dmri_tok, float* dpet_tok,
                             void* scratch, size_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * The dense heads of model_ad in one launch per direction (csrc/heads.hip).  Replaces `self.D(D_MRI_inp)`,
+ * `self.D(D_PET_inp)` on the reversed-gradient token means and `self.fc_cls(fused_embeds)` (models/mymodel.py:209-215,
+ * 221; modules :190-194) and their backward.  fc_cls = Linear(4*dim, H1)-BatchNorm1d-ReLU-Dropout-Linear(H1, H2)-
+ * BatchNorm1d-ReLU-Dropout-Linear(H2, NC);  D = Linear(dim, HD)-BatchNorm1d-ReLU-Linear(HD, NC), applied to the MRI then
+ * the PET mean with separate batch statistics (running statistics updated twice, in that order).  B <= 16.
+ *   cls [B][4*dim]; mri_tok / pet_tok [B][N][dim] (their means over N are D's inputs); mask1 [B][H1], mask2 [B][H2]:
+ *   Dropout keep-masks ALREADY scaled by 1 / (1 - p), NULL = no dropout (eval, or p = 0); the random draw stays with the
+ *   caller.  training != 0: batch statistics + running update (momentum / eps index 0 = fc_cls.1, 1 = fc_cls.5, 2 = D.1);
+ *   else running statistics.  Outputs: logits, d_mri_logits, d_pet_logits [B][NC]; `saved` (tmf_heads_saved_bytes) for
+ *   backward.  Backward: parameter gradients into g (same shapes as the parameters; D's collect both calls), d_cls,
+ *   and d_mri_tok / d_pet_tok = -revgrad_alpha * dmean / N broadcast over the tokens (gradient reversal, mymodel.py:209).
+ * ---------------------------------------------------------------------------- */
+typedef struct tmf_heads_desc { int B, N, dim, H1, H2, HD, NC, training; float momentum[3], eps[3]; } tmf_heads_desc;
+typedef struct tmf_heads_params {
+    const float *fc0_w, *fc0_b, *bn1_g, *bn1_b, *fc4_w, *fc4_b, *bn5_g, *bn5_b, *fc8_w, *fc8_b;   /* fc_cls.0/.1/.4/.5/.8 */
+    const float *d0_w, *d0_b, *dbn_g, *dbn_b, *d3_w, *d3_b;                                         /* D.0/.1/.3 */
+    float *bn1_rm, *bn1_rv, *bn5_rm, *bn5_rv, *dbn_rm, *dbn_rv;                                     /* running statistics */
+} tmf_heads_params;
+typedef struct tmf_heads_grads {
+    float *fc0_w, *fc0_b, *bn1_g, *bn1_b, *fc4_w, *fc4_b, *bn5_g, *bn5_b, *fc8_w, *fc8_b, *d0_w, *d0_b, *dbn_g, *dbn_b, *d3_w, *d3_b;
+} tmf_heads_grads;
+size_t tmf_heads_saved_bytes(const tmf_heads_desc* d);
+size_t tmf_heads_bwd_scratch_bytes(const tmf_heads_desc* d);
+int    tmf_heads_fwd(const tmf_heads_desc* d, const float* cls, const float* mri_tok, const float* pet_tok,
+                     const float* mask1, const float* mask2, const tmf_heads_params* params, float* logits,
+                     float* d_mri_logits, float* d_pet_logits, void* saved, size_t saved_bytes, void* stream);
+int    tmf_heads_bwd(const tmf_heads_desc* d, const float* cls, const float* mask1, const float* mask2,
+                     const tmf_heads_params* params, const void* saved, size_t saved_bytes, const float* d_logits,
+                     const float* d_d_mri_logits, const float* d_d_pet_logits, const tmf_heads_grads* grads,
+                     float* d_cls, float* d_mri_tok, float* d_pet_tok, float revgrad_alpha,
+                     void* scratch, size_t scratch_bytes, void* stream);
 
 #ifdef __cplusplus
 }

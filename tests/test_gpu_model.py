@@ -30,6 +30,10 @@ class FixedMaskDropout(nn.Module):
     def forward(self, x):
         return x * self.mask * 2.0 if self.training else x
 
+    def tmf_keep_mask(self, training):
+        """the scaled keep-mask the one-launch heads (ops.HeadsAD) take instead of calling this module"""
+        return self.mask * 2.0 if training else None
+
 
 def build(g: Golden, inject_masks=True):
     import transmf_ad_amd as T
@@ -691,6 +695,28 @@ def test_one_call_encoder_is_taken_by_default():
     assert type(out.grad_fn.next_functions[0][0]).__name__.startswith("SNetTrain"), out.grad_fn.next_functions
 
 
+@pytest.mark.parametrize("name", ["ad_tiny", "ad_adni_b2"])
+def test_one_call_eval_encoder_is_bit_identical_to_block_by_block(name):
+    """tmf_snet_eval_fwd (val_step's encoder as one library call) enqueues the launches of the block-by-block eval path:
+    after one train step (so the running statistics are not the initial ones) the eval tokens of both are bit-identical."""
+    from transmf_ad_amd import ops
+    g = Golden(name)
+    net = build(g)
+    step(net, g, train=True)
+    net.eval()
+    mri, pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+    toks = []
+    try:
+        for one_call in (True, False):
+            ops.SNET_ONE_CALL = one_call
+            with torch.no_grad():
+                toks.append((net.mri_cnn.forward_channels_last(mri), net.pet_cnn.forward_channels_last(pet)))
+    finally:
+        ops.SNET_ONE_CALL = True
+    assert torch.equal(toks[0][0], toks[1][0]) and torch.equal(toks[0][1], toks[1][1])
+    assert toks[0][0].abs().max().item() > 0
+
+
 @pytest.mark.parametrize("name", ["ad_mid", "ad_full_b2_blobs"])
 def test_one_call_fusion_matches_instance_by_instance(name):
     """tmf_fusion_train_fwd / _bwd (one library call per pass for the whole CrossTransformer_MOD_AVG,
@@ -810,3 +836,79 @@ def test_bf16_modes_match_their_own_oracle(mode):
     assert max(e["cls"], e["mri_cnn.conv4.3"], e["pet_cnn.conv4.3"]) <= tol["act"], e
     assert e["logits"] <= tol["logits"] and e["d"] <= tol["d"] and e["loss"] <= tol["loss"], e
     assert e["grad_l2_conv"] <= tol["gconv"] and e["grad_l2_rest"] <= tol["grest"], e
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("name", ["ad_tiny", "ad_mid"])
+def test_one_launch_heads_match_stock_modules(name, train):
+    """ops.HeadsAD (fc_cls and both discriminator calls as one kernel per direction, csrc/heads.hip) against the stock
+    torch modules it stands in for, on the same inputs: outputs, the gradients of cls / both token tensors / all 16 head
+    parameters, and the BatchNorm1d buffers (D's updated twice)."""
+    import copy
+    import transmf_ad_amd as T
+    from transmf_ad_amd import revgrad
+    g = Golden(name)
+    net = build(g).train(train)
+    ref = copy.deepcopy(net).train(train)
+    dim = g.kw["dim"]
+    B, N = 6, 27
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    k1 = (torch.rand((B, 512), device=DEV, generator=gen) > 0.5).float()
+    k2 = (torch.rand((B, 64), device=DEV, generator=gen) > 0.5).float()
+    for n_ in (net, ref):
+        n_.fc_cls[3], n_.fc_cls[7] = FixedMaskDropout(k1), FixedMaskDropout(k2)
+        n_.train(train)
+    cls0 = torch.randn((B, 4 * dim), device=DEV, generator=gen)
+    m0 = torch.randn((B, N, dim), device=DEV, generator=gen)
+    p0 = torch.randn((B, N, dim), device=DEV, generator=gen)
+    go = [torch.randn((B, 2), device=DEV, generator=gen) for _ in range(3)]
+
+    def run(model, fused):
+        cls, m, p = (t.clone().requires_grad_(True) for t in (cls0, m0, p0))
+        if fused:
+            assert model._heads_one_call_ok(m)
+            lo, dm, dp = model._heads(cls, m, p)
+        else:
+            dm = model.D(revgrad(m.mean(dim=1), 2.0))
+            dp = model.D(revgrad(p.mean(dim=1), 2.0))
+            lo = model.fc_cls(cls)
+        torch.autograd.backward([lo, dm, dp], go)
+        torch.cuda.synchronize()
+        return [lo, dm, dp], [cls.grad, m.grad, p.grad]
+
+    o1, g1 = run(net, True)
+    o2, g2 = run(ref, False)
+    for a, b in zip(o1 + g1, o2 + g2):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    heads = [(k, p) for k, p in net.named_parameters() if k.startswith(("fc_cls.", "D."))]
+    rp = dict(ref.named_parameters())
+    assert len(heads) == 16
+    for k, p in heads:
+        r = rp[k].grad
+        # a bias ahead of a train-mode BatchNorm1d has a mathematically zero gradient (rounding noise on both sides):
+        # compare on the scale of the same layer's weight gradient
+        scale = max(r.abs().max().item(), rp[k[:-4] + "weight"].grad.abs().max().item() if k.endswith(".bias") else 0.0, 1e-3)
+        assert (p.grad - r).abs().max().item() <= 2e-5 * scale, k
+    rb = dict(ref.named_buffers())
+    for k, b in net.named_buffers():
+        if k.startswith(("fc_cls.", "D.")):
+            assert (b.double() - rb[k].double()).abs().max().item() <= 1e-6 * max(1.0, rb[k].double().abs().max().item()), k
+
+
+def test_one_launch_heads_are_taken_by_default_and_with_real_dropout():
+    """model_ad as the reference constructs it (nn.Dropout(0.5) in fc_cls) goes through ops.HeadsAD; with real dropout
+    the result is random but finite, and eval mode is deterministic."""
+    import transmf_ad_amd as T
+    g = Golden("ad_mid")
+    net = build(g, inject_masks=False).train()
+    mri, pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+    lo, dm, dp = net(mri, pet)
+    assert type(lo.grad_fn).__name__.startswith("HeadsAD"), lo.grad_fn
+    (lo.sum() + dm.sum() + dp.sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+    assert int(net.D[1].num_batches_tracked) == 2 and int(net.fc_cls[1].num_batches_tracked) == 1
+    net.eval()
+    with torch.no_grad():
+        a = net(mri, pet)
+        b = net(mri, pet)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))

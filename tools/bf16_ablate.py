@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Timing ablations of the 8x8x8-brick bf16 forward kernel (tmf_set_option("debug", bits); results are garbage):
-which part of a launch the waves spend waiting on.   python tools/bf16_ablate.py [--layer conv2.3] [--S 128]"""
+which part of a launch the waves spend waiting on.  The switches exist only in a -DTMF_ABLATE build:
+    export TMF_EXTRA_FLAGS=-DTMF_ABLATE; python -m transmf_ad_amd.build; python tools/bf16_ablate.py [--ci 32 --co 64 --s 64]
+(and rebuild without the variable afterwards)."""
 import argparse
 import os
 import sys
@@ -16,6 +18,8 @@ ap.add_argument("--co", type=int, default=64)
 ap.add_argument("--s", type=int, default=64)
 ap.add_argument("--B", type=int, default=8)
 a = ap.parse_args()
+if "-DTMF_ABLATE" not in os.environ.get("TMF_EXTRA_FLAGS", ""):
+    sys.exit("bf16_ablate: needs a library built with TMF_EXTRA_FLAGS=-DTMF_ABLATE (see the header of this file)")
 dev = "cuda:0"
 x = torch.randn((a.B, a.s, a.s, a.s, a.ci), device=dev).bfloat16()
 w = ops.pack_weight_bf16(torch.randn((a.co, a.ci, 3, 3, 3), device=dev) * 0.05)

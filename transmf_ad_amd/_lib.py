@@ -111,6 +111,8 @@ PROTOTYPES.update({
     "tmf_snet_bwd_scratch_bytes": (_z, [C.POINTER(SnetDesc)]),
     "tmf_snet_train_fwd": (_i, [C.POINTER(SnetDesc), _p, C.POINTER(SnetParams), _p, _z, _p, _p]),
     "tmf_snet_train_bwd": (_i, [C.POINTER(SnetDesc), _p, _p, _z, _p, C.POINTER(SnetGrads), _p, _z, _p]),
+    "tmf_snet_eval_workspace_bytes": (_z, [C.POINTER(SnetDesc)]),
+    "tmf_snet_eval_fwd": (_i, [C.POINTER(SnetDesc), _p, C.POINTER(SnetParams), _p, _z, _p, _p]),
 })
 
 
@@ -136,6 +138,33 @@ PROTOTYPES.update({
     "tmf_fusion_train_fwd": (_i, [C.POINTER(FusionDesc), _p, _p, C.POINTER(XformerParams), _p, _z, _p, _p]),
     "tmf_fusion_train_bwd": (_i, [C.POINTER(FusionDesc), _p, _p, C.POINTER(XformerParams), _p, _z, _p,
                                   C.POINTER(XformerGrads), _p, _p, _p, _z, _p]),
+})
+
+
+
+class HeadsDesc(C.Structure):
+    _fields_ = [(n, _i) for n in ("B", "N", "dim", "H1", "H2", "HD", "NC", "training")] + [("momentum", _f * 3), ("eps", _f * 3)]
+
+
+HEADS_PARAMS = ("fc0_w", "fc0_b", "bn1_g", "bn1_b", "fc4_w", "fc4_b", "bn5_g", "bn5_b", "fc8_w", "fc8_b",
+                "d0_w", "d0_b", "dbn_g", "dbn_b", "d3_w", "d3_b")
+HEADS_BUFFERS = ("bn1_rm", "bn1_rv", "bn5_rm", "bn5_rv", "dbn_rm", "dbn_rv")
+
+
+class HeadsParams(C.Structure):
+    _fields_ = [(n, _p) for n in HEADS_PARAMS + HEADS_BUFFERS]
+
+
+class HeadsGrads(C.Structure):
+    _fields_ = [(n, _p) for n in HEADS_PARAMS]
+
+
+PROTOTYPES.update({
+    "tmf_heads_saved_bytes": (_z, [C.POINTER(HeadsDesc)]),
+    "tmf_heads_bwd_scratch_bytes": (_z, [C.POINTER(HeadsDesc)]),
+    "tmf_heads_fwd": (_i, [C.POINTER(HeadsDesc), _p, _p, _p, _p, _p, C.POINTER(HeadsParams), _p, _p, _p, _p, _z, _p]),
+    "tmf_heads_bwd": (_i, [C.POINTER(HeadsDesc), _p, _p, _p, C.POINTER(HeadsParams), _p, _z, _p, _p, _p,
+                           C.POINTER(HeadsGrads), _p, _p, _p, _f, _p, _z, _p]),
 })
 
 _lib = None

@@ -333,9 +333,16 @@ template <int NT, bool IN16, bool OUT16>
 __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     const void* __restrict__ x_, const u16* __restrict__ w, void* __restrict__ z_,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
-    int tilesD, int tilesH, int tilesW, int ntiles, int dbg) {
+    int tilesD, int tilesH, int tilesW, int ntiles, int dbg_arg) {
     // dbg (tmf_set_option("debug", bits), timing ablations only — results are garbage when set): 1 = no weight loads,
-    // 2 = no halo loads, 4 = no stage barriers, 8 = no MFMAs, 16 = no output stores
+    // 2 = no halo loads, 4 = no stage barriers, 8 = no MFMAs, 16 = no output stores.  Live only in a -DTMF_ABLATE
+    // build (tools/bf16_ablate.py makes one); the shipped kernel folds every test away.
+#ifdef TMF_ABLATE
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     constexpr int TD = v2::TD, TH = v2::TH, TW = v2::TW, HH = v2::HH, HW = v2::HW, NHALO = v2::NHALO, CINC = v2::CINC,
                   RP = v2::RP, TPS = v2::TPS, NSTAGES = v2::NSTAGES, NTHR = v2::NTHR, MT2 = v2::MT2;
     constexpr int NB = v2::Cfg<NT>::NB, WSTAGE = v2::Cfg<NT>::WSTAGE;

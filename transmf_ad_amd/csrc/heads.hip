@@ -1,0 +1,700 @@
+// heads.hip — the dense heads of model_ad in ONE launch per direction.
+//
+// reference: models/mymodel.py:190-194 (`fc_cls` = Linear(4*dim, 512)-BatchNorm1d-ReLU-Dropout(.5)-Linear(512, 64)-
+// BatchNorm1d-ReLU-Dropout(.5)-Linear(64, 2);  `D` = Linear(dim, 128)-BatchNorm1d-ReLU-Linear(128, 2)), driven by
+// model_ad.forward :209-215, 221: D is applied TWICE — to revgrad(mean over tokens of the MRI embedding, 2.0) and to the
+// PET one — each call with its own batch statistics, the running statistics updated twice in that order.
+//
+// Why a kernel for (B, <= 512) matrices: as stock torch modules these heads are ~25 forward and ~40 backward launches of
+// a few microseconds, and backward STARTS with them, right after the reference step's two loss.item() host syncs
+// (kfold_train_adversarial.py:127-128) have drained the queue: the GPU idles for the 1.3 ms the host needs to issue
+// them (tools/host_probe.py) before the first real kernel of backward can start.  One workgroup does the whole thing
+// in tens of microseconds; a thread owns an output feature, so the BatchNorm1d batch statistics (over B <= 16 rows) are
+// register-local and nothing is reduced across threads except the K-split of the 512 -> 64 layer.
+//
+// Numerics: fp32 fma chains in k order per output; BatchNorm1d as torch (biased variance for normalisation, unbiased
+// into running_var, momentum, eps); Dropout by a caller-supplied keep-mask already scaled by 1 / (1 - p) (NULL = none).
+#include "tmf_common.h"
+
+namespace {
+
+constexpr int HT = 512;          // threads
+constexpr int MAXB = 16;
+
+struct HeadsArgs {
+    // inputs
+    const float* cls;            // [B][C4]
+    const float* tok[2];         // [B][N][dim] MRI, PET tokens (the D inputs are their means over N)
+    const float* mask1;          // [B][H1] or NULL
+    const float* mask2;          // [B][H2] or NULL
+    // fc_cls parameters
+    const float *w0, *b0, *g1, *be1; float *rm1, *rv1;     // Linear(C4, H1), BatchNorm1d(H1)
+    const float *w4, *b4, *g5, *be5; float *rm5, *rv5;     // Linear(H1, H2), BatchNorm1d(H2)
+    const float *w8, *b8;                                   // Linear(H2, NC)
+    // D parameters
+    const float *dw0, *db0, *dg1, *dbe1; float *drm1, *drv1;   // Linear(dim, HD), BatchNorm1d(HD)
+    const float *dw3, *db3;                                     // Linear(HD, NC)
+    // outputs
+    float* logits;               // [B][NC]
+    float* dlog[2];              // [B][NC] D(MRI), D(PET)
+    float* saved;                // tmf_heads_saved_floats()
+    int B, N, dim, C4, H1, H2, HD, NC, training;
+    float mom1, eps1, mom5, eps5, dmom, deps;
+};
+
+struct SavedPlan { int v, xhD, isD, xh1, is1, a1, xh2, is2, a2, total; };
+__host__ __device__ inline SavedPlan saved_plan(int B, int dim, int H1, int H2, int HD) {
+    SavedPlan p;
+    int o = 0;
+    p.v = o; o += 2 * B * dim;          // token means (the D inputs)
+    p.xhD = o; o += 2 * B * HD;         // normalised pre-activations of D's BatchNorm, per call
+    p.isD = o; o += 2 * HD;
+    p.xh1 = o; o += B * H1;
+    p.is1 = o; o += H1;
+    p.a1 = o; o += B * H1;              // input of Linear(H1, H2): after ReLU and dropout
+    p.xh2 = o; o += B * H2;
+    p.is2 = o; o += H2;
+    p.a2 = o; o += B * H2;
+    p.total = o;
+    return p;
+}
+
+// BatchNorm1d of one feature over the batch held in acc[0..B): returns xhat in place, writes y = gamma*xhat + beta to yv
+__device__ __forceinline__ void bn1d(float (&acc)[MAXB], float (&yv)[MAXB], int B, bool training, float g, float be,
+                                     float* rmean, float* rvar, float mom, float eps, float& invstd, bool update) {
+    float mean, var;
+    if (training) {
+        float s = 0.f;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) if (b < B) s += acc[b];
+        mean = s / B;
+        float q = 0.f;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) if (b < B) { const float d = acc[b] - mean; q += d * d; }
+        var = q / B;
+        if (update && rmean != nullptr) {
+            *rmean = (1.f - mom) * *rmean + mom * mean;
+            *rvar = (1.f - mom) * *rvar + mom * (B > 1 ? q / (B - 1) : var);
+        }
+    } else {
+        mean = *rmean;
+        var = *rvar;
+    }
+    invstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b)
+        if (b < B) {
+            acc[b] = (acc[b] - mean) * invstd;
+            yv[b] = acc[b] * g + be;
+        }
+}
+
+// v[m][b][c] = mean over the N tokens of tok_m[b][n][c]: one workgroup per (modality, sample), 4 token slices per channel
+// (one thread walking 216-512 dependent-latency loads is what made a single-workgroup version of the heads slow)
+__global__ __launch_bounds__(HT) void token_mean_kernel(const float* __restrict__ mri, const float* __restrict__ pet,
+                                                        float* __restrict__ v, int B, int N, int dim) {
+    __shared__ float part[HT];
+    const int m = blockIdx.x / B, b = blockIdx.x % B;
+    const float* src = (m == 0 ? mri : pet) + (size_t)b * N * dim;
+    const int t = threadIdx.x;
+    for (int c0 = 0; c0 < dim; c0 += 128) {
+        const int c = c0 + (t & 127), sl = t >> 7;            // 4 slices of tokens
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (c < dim) {
+            int n = sl;
+            for (; n + 12 < N; n += 16) {
+                s0 += src[(size_t)n * dim + c];
+                s1 += src[(size_t)(n + 4) * dim + c];
+                s2 += src[(size_t)(n + 8) * dim + c];
+                s3 += src[(size_t)(n + 12) * dim + c];
+            }
+            for (; n < N; n += 4) s0 += src[(size_t)n * dim + c];
+        }
+        part[t] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (sl == 0 && c < dim) v[((size_t)m * B + b) * dim + c] = (part[t] + part[t + 128] + part[t + 256] + part[t + 384]) / N;
+        __syncthreads();
+    }
+}
+
+// fc_cls.0 / .1 / .2 / .3 on H1 / 64 workgroups: 64 output features per workgroup, 8 threads per feature split K in
+// interleaved 16-byte pieces (the 8 threads of a feature read 128 contiguous bytes of its weight row per step; all of a
+// thread's loads are in flight at once).  A feature's batch column ends up in one thread: BatchNorm1d is register-local.
+__global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
+    extern __shared__ float lds[];
+    const int t = threadIdx.x, B = a.B;
+    const SavedPlan sp = saved_plan(B, a.dim, a.H1, a.H2, a.HD);
+    for (int e = t; e < B * a.C4; e += HT) lds[e] = a.cls[e];
+    __syncthreads();
+    const int j = blockIdx.x * 64 + (t >> 3), part = t & 7;
+    float acc[MAXB], y[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+    if (j < a.H1) {
+        const float* wr = a.w0 + (size_t)j * a.C4;
+#pragma unroll 8
+        for (int k = part * 4; k < a.C4; k += 32) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+                if (b < B) {
+                    const float* x = lds + b * a.C4 + k;
+                    acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
+                    acc[b] = fmaf(w[2], x[2], acc[b]); acc[b] = fmaf(w[3], x[3], acc[b]);
+                }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        acc[b] += __shfl_xor(acc[b], 1);
+        acc[b] += __shfl_xor(acc[b], 2);
+        acc[b] += __shfl_xor(acc[b], 4);
+    }
+    if (j < a.H1 && part == 0) {
+        const float bias = a.b0[j];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) acc[b] += bias;
+        float is;
+        bn1d(acc, y, B, a.training != 0, a.g1[j], a.be1[j], a.rm1 ? a.rm1 + j : nullptr, a.rv1 ? a.rv1 + j : nullptr, a.mom1,
+             a.eps1, is, true);
+        a.saved[sp.is1 + j] = is;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (b < B) {
+                a.saved[sp.xh1 + b * a.H1 + j] = acc[b];
+                float r = y[b] > 0.f ? y[b] : 0.f;
+                if (a.mask1 != nullptr) r *= a.mask1[b * a.H1 + j];
+                a.saved[sp.a1 + b * a.H1 + j] = r;
+            }
+    }
+}
+
+__global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
+    extern __shared__ float lds[];
+    const int t = threadIdx.x;
+    const int B = a.B;
+    const SavedPlan sp = saved_plan(B, a.dim, a.H1, a.H2, a.HD);
+    float* l_cls = lds;                          // [B][C4]
+    float* l_a1 = l_cls + B * a.C4;              // [B][H1]
+    float* l_a2 = l_a1 + B * a.H1;               // [B][H2]
+    float* l_v = l_a2 + B * a.H2;                // [2][B][dim]
+    float* l_r = l_v + 2 * B * a.dim;            // [2][B][HD]  (ReLU output of D's hidden layer)
+    float* l_st = l_r + 2 * B * a.HD;            // [2][HD][2]  batch mean / unbiased var of the two D calls
+    // ---- token means (token_mean_kernel) and the first hidden layer's output (heads_fc0_kernel) from `saved` ----
+    for (int e = t; e < 2 * B * a.dim; e += HT) l_v[e] = a.saved[sp.v + e];
+    for (int e = t; e < B * a.H1; e += HT) l_a1[e] = a.saved[sp.a1 + e];
+    __syncthreads();
+    // ---- fc_cls.4 / .5 / .6 / .7 : 8 threads per output feature split K ----
+    for (int j0 = 0; j0 < a.H2; j0 += HT / 8) {
+        const int j = j0 + (t >> 3), part = t & 7;
+        float acc[MAXB], y[MAXB];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+        if (j < a.H2) {
+            const int kper = (a.H1 + 7) / 8;
+            const int k0 = part * kper, k1 = k0 + kper < a.H1 ? k0 + kper : a.H1;
+            const float* wr = a.w4 + (size_t)j * a.H1;
+#pragma unroll 8
+            for (int k = k0; k < k1; k += 4) {                  // H1 % 32 == 0: every part is a whole number of float4s
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b)
+                    if (b < B) {
+                        const float* x = l_a1 + b * a.H1 + k;
+                        acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
+                        acc[b] = fmaf(w[2], x[2], acc[b]); acc[b] = fmaf(w[3], x[3], acc[b]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            acc[b] += __shfl_xor(acc[b], 1);
+            acc[b] += __shfl_xor(acc[b], 2);
+            acc[b] += __shfl_xor(acc[b], 4);
+        }
+        if (j < a.H2 && part == 0) {
+            const float bias = a.b4[j];
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) acc[b] += bias;
+            float is;
+            bn1d(acc, y, B, a.training != 0, a.g5[j], a.be5[j], a.rm5 ? a.rm5 + j : nullptr, a.rv5 ? a.rv5 + j : nullptr,
+                 a.mom5, a.eps5, is, true);
+            a.saved[sp.is2 + j] = is;
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+                if (b < B) {
+                    a.saved[sp.xh2 + b * a.H2 + j] = acc[b];
+                    float r = y[b] > 0.f ? y[b] : 0.f;
+                    if (a.mask2 != nullptr) r *= a.mask2[b * a.H2 + j];
+                    l_a2[b * a.H2 + j] = r;
+                    a.saved[sp.a2 + b * a.H2 + j] = r;
+                }
+        }
+    }
+    // ---- D.0 / .1 / .2 on both token means (independent of the fc_cls chain above) ----
+    for (int e = t; e < 2 * a.HD; e += HT) {
+        const int j = e % a.HD, m = e / a.HD;
+        float acc[MAXB], y[MAXB];
+        const float bias = a.db0[j];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) acc[b] = bias;
+        const float* wr = a.dw0 + (size_t)j * a.dim;
+#pragma unroll 8
+        for (int k = 0; k < a.dim; k += 4) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+                if (b < B) {
+                    const float* x = l_v + (m * B + b) * a.dim + k;
+                    acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
+                    acc[b] = fmaf(w[2], x[2], acc[b]); acc[b] = fmaf(w[3], x[3], acc[b]);
+                }
+        }
+        // batch statistics of THIS call; the running buffers are updated below, MRI call first, then PET
+        float mean = 0.f, q = 0.f;
+        if (a.training) {
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) if (b < B) mean += acc[b];
+            mean /= B;
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) if (b < B) { const float d = acc[b] - mean; q += d * d; }
+            l_st[(m * a.HD + j) * 2] = mean;
+            l_st[(m * a.HD + j) * 2 + 1] = B > 1 ? q / (B - 1) : q / B;
+        }
+        float is;
+        bn1d(acc, y, B, a.training != 0, a.dg1[j], a.dbe1[j], a.drm1 ? a.drm1 + j : nullptr, a.drv1 ? a.drv1 + j : nullptr,
+             a.dmom, a.deps, is, false);
+        a.saved[sp.isD + m * a.HD + j] = is;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (b < B) {
+                a.saved[sp.xhD + (m * B + b) * a.HD + j] = acc[b];
+                l_r[(m * B + b) * a.HD + j] = y[b] > 0.f ? y[b] : 0.f;
+            }
+    }
+    __syncthreads();
+    if (a.training && a.drm1 != nullptr)
+        for (int j = t; j < a.HD; j += HT) {
+            float rm = a.drm1[j], rv = a.drv1[j];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                rm = (1.f - a.dmom) * rm + a.dmom * l_st[(m * a.HD + j) * 2];
+                rv = (1.f - a.dmom) * rv + a.dmom * l_st[(m * a.HD + j) * 2 + 1];
+            }
+            a.drm1[j] = rm;
+            a.drv1[j] = rv;
+        }
+    // ---- the three output layers (their small weight matrices staged in LDS: l_a1 is free by now) ----
+    float* l_w8 = l_a1;                         // [NC][H2]
+    float* l_w3 = l_a1 + a.NC * a.H2;           // [NC][HD]
+    for (int e = t; e < a.NC * a.H2; e += HT) l_w8[e] = a.w8[e];
+    for (int e = t; e < a.NC * a.HD; e += HT) l_w3[e] = a.dw3[e];
+    __syncthreads();
+    for (int e = t; e < B * a.NC; e += HT) {
+        const int c = e % a.NC, b = e / a.NC;
+        float s = a.b8[c];
+        for (int k = 0; k < a.H2; ++k) s = fmaf(l_w8[c * a.H2 + k], l_a2[b * a.H2 + k], s);
+        a.logits[e] = s;
+    }
+    for (int e = t; e < 2 * B * a.NC; e += HT) {
+        const int c = e % a.NC, b = (e / a.NC) % B, m = e / (a.NC * B);
+        float s = a.db3[c];
+        for (int k = 0; k < a.HD; ++k) s = fmaf(l_w3[c * a.HD + k], l_r[(m * B + b) * a.HD + k], s);
+        a.dlog[m][b * a.NC + c] = s;
+    }
+}
+
+struct HeadsBwdArgs {
+    HeadsArgs f;                 // the forward's arguments (inputs, parameters, saved)
+    const float* d_logits;       // [B][NC]
+    const float* d_dlog[2];      // [B][NC]
+    // parameter gradients (same shapes as the parameters)
+    float *gw0, *gb0, *gg1, *gbe1, *gw4, *gb4, *gg5, *gbe5, *gw8, *gb8;
+    float *gdw0, *gdb0, *gdg1, *gdbe1, *gdw3, *gdb3;
+    float* d_cls;                // [B][C4]
+    float* d_tok[2];             // [B][N][dim]
+    float alpha;                 // gradient reversal factor (mymodel.py:209: 2.0)
+    float* s_dz1;                // scratch [B][H1], [B][H2], [2][B][dim]: inputs of heads_bwd_outer_kernel
+    float* s_dz2;
+    float* s_dv;
+};
+
+// backward of y = gamma*xhat + beta followed by ReLU (and an optional scaled keep-mask) for one feature:
+// in: dr[b] = gradient w.r.t. the masked ReLU output; out: dz[b] w.r.t. the BatchNorm input; dgamma, dbeta
+__device__ __forceinline__ void bn1d_relu_bwd(float (&dr)[MAXB], const float* xhat, int stride, const float* mask, int B,
+                                              bool training, float g, float be, float invstd, float& dgamma, float& dbeta) {
+    float sg = 0.f, sx = 0.f;
+    float xh[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b)
+        if (b < B) {
+            xh[b] = xhat[b * stride];
+            const float y = xh[b] * g + be;
+            float gr = y > 0.f ? dr[b] : 0.f;
+            if (mask != nullptr) gr *= mask[b * stride];
+            dr[b] = gr;
+            sg += gr;
+            sx += gr * xh[b];
+        }
+    dgamma = sx;
+    dbeta = sg;
+    const float k = g * invstd;
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b)
+        if (b < B) dr[b] = training ? k * (dr[b] - sg / B - xh[b] * (sx / B)) : k * dr[b];
+}
+
+__global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a) {
+    extern __shared__ float lds[];
+    const HeadsArgs& f = a.f;
+    const int t = threadIdx.x;
+    const int B = f.B;
+    const SavedPlan sp = saved_plan(B, f.dim, f.H1, f.H2, f.HD);
+    const bool tr = f.training != 0;
+    float* l_dz1 = lds;                       // [B][H1]
+    float* l_dz2 = l_dz1 + B * f.H1;          // [B][H2]
+    float* l_dzD = l_dz2 + B * f.H2;          // [2][B][HD]
+    float* l_dv = l_dzD + 2 * B * f.HD;       // [2][B][dim]
+    float* l_x = l_dv + 2 * B * f.dim;        // [B][max(C4, H1)]  cls, later reused
+    // ---- fc_cls.8 backward, then through Dropout / ReLU / BatchNorm1d(H2) ----
+    for (int e = t; e < f.NC * f.H2; e += HT) {          // dW8[c][k] = sum_b dlogits[b][c] a2[b][k]
+        const int k = e % f.H2, c = e / f.H2;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(a.d_logits[b * f.NC + c], f.saved[sp.a2 + b * f.H2 + k], s);
+        a.gw8[e] = s;
+    }
+    for (int c = t; c < f.NC; c += HT) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += a.d_logits[b * f.NC + c];
+        a.gb8[c] = s;
+    }
+    for (int j = t; j < f.H2; j += HT) {
+        float dr[MAXB];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            float s = 0.f;
+            if (b < B) for (int c = 0; c < f.NC; ++c) s = fmaf(a.d_logits[b * f.NC + c], f.w8[c * f.H2 + j], s);
+            dr[b] = s;
+        }
+        float dg, db;
+        bn1d_relu_bwd(dr, f.saved + sp.xh2 + j, f.H2, f.mask2 ? f.mask2 + j : nullptr, B, tr, f.g5[j], f.be5[j],
+                      f.saved[sp.is2 + j], dg, db);
+        a.gg5[j] = dg;
+        a.gbe5[j] = db;
+        float sb = 0.f;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dz2[b * f.H2 + j] = dr[b]; a.s_dz2[b * f.H2 + j] = dr[b]; sb += dr[b]; }
+        a.gb4[j] = sb;
+    }
+    __syncthreads();
+    // ---- fc_cls.4 backward: da1[b][k] = sum_j dz2[b][j] W4[j][k]  (dW4 = dz2^T a1: heads_bwd_outer_kernel) ----
+    for (int k = t; k < f.H1; k += HT) {
+        float dr[MAXB];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) dr[b] = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < f.H2; ++j) {
+            const float w = f.w4[(size_t)j * f.H1 + k];
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) if (b < B) dr[b] = fmaf(l_dz2[b * f.H2 + j], w, dr[b]);
+        }
+        float dg, db;
+        bn1d_relu_bwd(dr, f.saved + sp.xh1 + k, f.H1, f.mask1 ? f.mask1 + k : nullptr, B, tr, f.g1[k], f.be1[k],
+                      f.saved[sp.is1 + k], dg, db);
+        a.gg1[k] = dg;
+        a.gbe1[k] = db;
+        float sb = 0.f;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dz1[b * f.H1 + k] = dr[b]; a.s_dz1[b * f.H1 + k] = dr[b]; sb += dr[b]; }
+        a.gb0[k] = sb;
+    }
+    // (fc_cls.0 backward — dcls = dz1 W0 and dW0 = dz1^T cls — runs on many workgroups: heads_bwd_outer_kernel)
+    // ---- D.3 backward and through ReLU / BatchNorm1d(HD), both calls ----
+    for (int e = t; e < f.NC * f.HD; e += HT) {          // dW3[c][k] = sum_m sum_b dd[m][b][c] r[m][b][k]
+        const int k = e % f.HD, c = e / f.HD;
+        float s = 0.f;
+        for (int m = 0; m < 2; ++m)
+            for (int b = 0; b < B; ++b) {
+                const float y = f.saved[sp.xhD + (m * B + b) * f.HD + k] * f.dg1[k] + f.dbe1[k];
+                s = fmaf(a.d_dlog[m][b * f.NC + c], y > 0.f ? y : 0.f, s);
+            }
+        a.gdw3[e] = s;
+    }
+    for (int c = t; c < f.NC; c += HT) {
+        float s = 0.f;
+        for (int m = 0; m < 2; ++m) for (int b = 0; b < B; ++b) s += a.d_dlog[m][b * f.NC + c];
+        a.gdb3[c] = s;
+    }
+    float* l_pg = l_x;                                   // [2][HD][3]: per-call dgamma, dbeta, dbias partials
+    __syncthreads();                                     // l_x (cls) is free from here on
+    for (int e = t; e < 2 * f.HD; e += HT) {
+        const int j = e % f.HD, m = e / f.HD;
+        float dr[MAXB];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            float s = 0.f;
+            if (b < B) for (int c = 0; c < f.NC; ++c) s = fmaf(a.d_dlog[m][b * f.NC + c], f.dw3[c * f.HD + j], s);
+            dr[b] = s;
+        }
+        float dg, db;
+        bn1d_relu_bwd(dr, f.saved + sp.xhD + m * B * f.HD + j, f.HD, nullptr, B, tr, f.dg1[j], f.dbe1[j],
+                      f.saved[sp.isD + m * f.HD + j], dg, db);
+        float sb = 0.f;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dzD[(m * B + b) * f.HD + j] = dr[b]; sb += dr[b]; }
+        l_pg[(m * f.HD + j) * 3] = dg;
+        l_pg[(m * f.HD + j) * 3 + 1] = db;
+        l_pg[(m * f.HD + j) * 3 + 2] = sb;
+    }
+    __syncthreads();
+    for (int j = t; j < f.HD; j += HT) {                 // the shared D parameters collect both calls
+        a.gdg1[j] = l_pg[j * 3] + l_pg[(f.HD + j) * 3];
+        a.gdbe1[j] = l_pg[j * 3 + 1] + l_pg[(f.HD + j) * 3 + 1];
+        a.gdb0[j] = l_pg[j * 3 + 2] + l_pg[(f.HD + j) * 3 + 2];
+    }
+    // ---- D.0 backward: dW0D[j][i] = sum_m sum_b dzD[m][b][j] v[m][b][i];  dv[m][b][i] = sum_j dzD[m][b][j] W0D[j][i] ----
+    //      a thread = (input channel i, one of NS j-slices): all of its weight loads are in flight at once
+    float* l_dvp = l_x;                                 // [NS][2][B][dim] partial dv: NS <= 2 fits the B x 4*dim region
+    __syncthreads();                                    // (its previous contents, the per-call partials, are consumed)
+    {
+        const int NS = HT / f.dim >= 2 ? 2 : 1;
+        const int i = t % f.dim, sl = t / f.dim;
+        if (sl < NS && t < NS * f.dim) {
+            float v[2 * MAXB], dv[2 * MAXB];
+#pragma unroll
+            for (int q = 0; q < 2 * MAXB; ++q) {
+                const int m = q / MAXB, b = q % MAXB;
+                v[q] = b < B ? f.saved[sp.v + (m * B + b) * f.dim + i] : 0.f;
+                dv[q] = 0.f;
+            }
+            const int jper = (f.HD + NS - 1) / NS;
+            const int j0 = sl * jper, j1 = j0 + jper < f.HD ? j0 + jper : f.HD;
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) {
+                const float w = f.dw0[(size_t)j * f.dim + i];
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 2 * MAXB; ++q) {
+                    const int m = q / MAXB, b = q % MAXB;
+                    if (b < B) {
+                        const float dz = l_dzD[(m * B + b) * f.HD + j];
+                        s = fmaf(dz, v[q], s);
+                        dv[q] = fmaf(dz, w, dv[q]);
+                    }
+                }
+                a.gdw0[(size_t)j * f.dim + i] = s;
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * MAXB; ++q) {
+                const int m = q / MAXB, b = q % MAXB;
+                if (b < B) l_dvp[((sl * 2 + m) * B + b) * f.dim + i] = dv[q];
+            }
+        }
+        __syncthreads();
+        for (int e = t; e < 2 * B * f.dim; e += HT) {   // broadcast over the tokens: heads_bwd_outer_kernel
+            float sum = 0.f;
+            for (int q = 0; q < NS; ++q) sum += l_dvp[q * 2 * B * f.dim + e];
+            a.s_dv[e] = sum;
+        }
+    }
+}
+
+// The wide parts of the backward on many workgroups:
+//   blocks [0, nbc)        : dcls[b][k] = sum_j dz1[b][j] W0[j][k]        (64 columns per block, 8 j-slices)
+//   next nb0 blocks        : dW0[j][k] = sum_b dz1[b][j] cls[b][k]        (8 rows j per block, a thread per column k)
+//   next nb4 blocks        : dW4[j][k] = sum_b dz2[b][j] a1[b][k]
+//   the rest               : mean over tokens + gradient reversal: d tok[m][b][n][c] = -alpha * dv[m][b][c] / N
+__global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int nb0, int nb4, int nbc) {
+    __shared__ float part[8][MAXB][64];
+    const HeadsArgs& f = a.f;
+    const int t = threadIdx.x, B = f.B;
+    int blk = blockIdx.x;
+    if (blk < nbc) {
+        // dcls[b][k] = sum_j dz1[b][j] W0[j][k]: 64 columns per workgroup, 8 j-slices of H1 / 8 rows each
+        const int kk = t & 63, sl = t >> 6, k = blk * 64 + kk;
+        float dc[MAXB];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) dc[b] = 0.f;
+        const int jper = (f.H1 + 7) / 8;
+        const int j0 = sl * jper, j1 = j0 + jper < f.H1 ? j0 + jper : f.H1;
+        if (k < f.C4) {
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) {
+                const float w = f.w0[(size_t)j * f.C4 + k];
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b) if (b < B) dc[b] = fmaf(a.s_dz1[b * f.H1 + j], w, dc[b]);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) part[sl][b][kk] = dc[b];
+        __syncthreads();
+        for (int e = t; e < B * 64; e += HT) {
+            const int b = e >> 6, c = e & 63;
+            if (blk * 64 + c < f.C4) {
+                float sum = 0.f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sum += part[q][b][c];
+                a.d_cls[b * f.C4 + blk * 64 + c] = sum;
+            }
+        }
+        return;
+    }
+    blk -= nbc;
+    if (blk < nb0 + nb4) {
+        const bool first = blk < nb0;
+        if (!first) blk -= nb0;
+        const int rows = first ? f.H1 : f.H2, cols = first ? f.C4 : f.H1;
+        const float* dz = first ? a.s_dz1 : a.s_dz2;                         // [B][rows]
+        const SavedPlan sp = saved_plan(B, f.dim, f.H1, f.H2, f.HD);
+        const float* x = first ? f.cls : f.saved + sp.a1;                    // [B][cols]
+        float* gw = first ? a.gw0 : a.gw4;
+        for (int k = t; k < cols; k += HT) {
+            float xv[MAXB];
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) xv[b] = b < B ? x[b * cols + k] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int j = blk * 8 + r;
+                if (j < rows) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int b = 0; b < MAXB; ++b) if (b < B) s = fmaf(dz[b * rows + j], xv[b], s);
+                    gw[(size_t)j * cols + k] = s;
+                }
+            }
+        }
+        return;
+    }
+    blk -= nb0 + nb4;
+    const float sc = -a.alpha / f.N;
+    const size_t per = (size_t)B * f.N * f.dim, total = 2 * per;
+    for (size_t e = ((size_t)blk * HT + t) * 4; e < total; e += (size_t)(gridDim.x - nb0 - nb4 - nbc) * HT * 4) {
+        const int m = e >= per ? 1 : 0;
+        const size_t o = e - m * per;
+        const int c = o % f.dim, b = o / ((size_t)f.N * f.dim);              // dim % 4 == 0: the 4 elements share (m, b)
+        const float* dv = a.s_dv + ((size_t)m * B + b) * f.dim + c;
+        *reinterpret_cast<f32x4*>(a.d_tok[m] + o) = f32x4{sc * dv[0], sc * dv[1], sc * dv[2], sc * dv[3]};
+    }
+}
+
+int check_heads(const char* fn, const tmf_heads_desc* d) {
+    TMF_REQUIRE_PTR(d);
+    TMF_REQUIRE(d->B > 0 && d->B <= MAXB, TMF_E_SHAPE, "%s: batch %d (1..%d)", fn, d->B, MAXB);
+    TMF_REQUIRE(d->N > 0 && d->dim > 0 && d->H1 > 0 && d->H2 > 0 && d->HD > 0 && d->NC > 0 && d->NC <= 16, TMF_E_SHAPE,
+                "%s: non-positive dimension", fn);
+    TMF_REQUIRE(d->dim % 8 == 0 && d->H1 % 32 == 0, TMF_E_SHAPE, "%s: dim=%d must be a multiple of 8 and H1=%d of 32", fn,
+                d->dim, d->H1);
+    return TMF_OK;
+}
+size_t fwd_lds(const tmf_heads_desc& d) {
+    return (size_t)(d.B * 4 * d.dim + d.B * d.H1 + d.B * d.H2 + 2 * d.B * d.dim + 2 * d.B * d.HD + 4 * d.HD) * 4;
+}
+size_t bwd_lds(const tmf_heads_desc& d) {
+    const int c4 = 4 * d.dim;
+    const int lx = d.B * (c4 > d.H1 ? c4 : d.H1) > 6 * d.HD ? d.B * (c4 > d.H1 ? c4 : d.H1) : 6 * d.HD;
+    return (size_t)(d.B * d.H1 + d.B * d.H2 + 2 * d.B * d.HD + 2 * d.B * d.dim + lx) * 4;
+}
+HeadsArgs make_args(const tmf_heads_desc& d, const float* cls, const float* mri_tok, const float* pet_tok, const float* mask1,
+                    const float* mask2, const tmf_heads_params& p, float* saved) {
+    HeadsArgs a = {};
+    a.cls = cls; a.tok[0] = mri_tok; a.tok[1] = pet_tok; a.mask1 = mask1; a.mask2 = mask2;
+    a.w0 = p.fc0_w; a.b0 = p.fc0_b; a.g1 = p.bn1_g; a.be1 = p.bn1_b; a.rm1 = p.bn1_rm; a.rv1 = p.bn1_rv;
+    a.w4 = p.fc4_w; a.b4 = p.fc4_b; a.g5 = p.bn5_g; a.be5 = p.bn5_b; a.rm5 = p.bn5_rm; a.rv5 = p.bn5_rv;
+    a.w8 = p.fc8_w; a.b8 = p.fc8_b;
+    a.dw0 = p.d0_w; a.db0 = p.d0_b; a.dg1 = p.dbn_g; a.dbe1 = p.dbn_b; a.drm1 = p.dbn_rm; a.drv1 = p.dbn_rv;
+    a.dw3 = p.d3_w; a.db3 = p.d3_b;
+    a.saved = saved;
+    a.B = d.B; a.N = d.N; a.dim = d.dim; a.C4 = 4 * d.dim; a.H1 = d.H1; a.H2 = d.H2; a.HD = d.HD; a.NC = d.NC;
+    a.training = d.training;
+    a.mom1 = d.momentum[0]; a.eps1 = d.eps[0]; a.mom5 = d.momentum[1]; a.eps5 = d.eps[1]; a.dmom = d.momentum[2]; a.deps = d.eps[2];
+    return a;
+}
+int check_params(const char* fn, const tmf_heads_params* p) {
+    TMF_REQUIRE_PTR(p);
+    TMF_REQUIRE(p->fc0_w && p->fc0_b && p->bn1_g && p->bn1_b && p->fc4_w && p->fc4_b && p->bn5_g && p->bn5_b && p->fc8_w &&
+                p->fc8_b && p->d0_w && p->d0_b && p->dbn_g && p->dbn_b && p->d3_w && p->d3_b, TMF_E_NULL,
+                "%s: a parameter pointer is NULL", fn);
+    return TMF_OK;
+}
+
+}  // namespace
+
+extern "C" size_t tmf_heads_saved_bytes(const tmf_heads_desc* d) {
+    if (check_heads("tmf_heads_saved_bytes", d) != TMF_OK) return 0;
+    return (size_t)saved_plan(d->B, d->dim, d->H1, d->H2, d->HD).total * 4;
+}
+
+extern "C" int tmf_heads_fwd(const tmf_heads_desc* d, const float* cls, const float* mri_tok, const float* pet_tok,
+                             const float* mask1, const float* mask2, const tmf_heads_params* p, float* logits,
+                             float* d_mri_logits, float* d_pet_logits, void* saved, size_t saved_bytes, void* stream) {
+    int rc;
+    if ((rc = check_heads("tmf_heads_fwd", d))) return rc;
+    if ((rc = check_params("tmf_heads_fwd", p))) return rc;
+    TMF_REQUIRE_PTR(cls); TMF_REQUIRE_PTR(mri_tok); TMF_REQUIRE_PTR(pet_tok); TMF_REQUIRE_PTR(logits);
+    TMF_REQUIRE_PTR(d_mri_logits); TMF_REQUIRE_PTR(d_pet_logits); TMF_REQUIRE_PTR(saved);
+    TMF_REQUIRE(d->training || (p->bn1_rm && p->bn1_rv && p->bn5_rm && p->bn5_rv && p->dbn_rm && p->dbn_rv), TMF_E_NULL,
+                "tmf_heads_fwd: eval mode needs the running statistics");
+    TMF_REQUIRE(saved_bytes >= tmf_heads_saved_bytes(d), TMF_E_WORKSPACE, "tmf_heads_fwd: saved %zu B < required %zu B",
+                saved_bytes, tmf_heads_saved_bytes(d));
+    TMF_REQUIRE_ALIGNED(cls); TMF_REQUIRE_ALIGNED(p->fc0_w);
+    HeadsArgs a = make_args(*d, cls, mri_tok, pet_tok, mask1, mask2, *p, (float*)saved);
+    a.logits = logits; a.dlog[0] = d_mri_logits; a.dlog[1] = d_pet_logits;
+    const size_t lds = fwd_lds(*d);
+    TMF_REQUIRE(lds <= 150 * 1024, TMF_E_SHAPE, "tmf_heads_fwd: %zu B of LDS needed (batch x widths too large)", lds);
+    if ((rc = tmf_allow_lds(heads_fwd_kernel, lds, "tmf_heads_fwd"))) return rc;
+    hipLaunchKernelGGL(token_mean_kernel, dim3(2 * d->B), dim3(HT), 0, (hipStream_t)stream, mri_tok, pet_tok,
+                       (float*)saved + saved_plan(d->B, d->dim, d->H1, d->H2, d->HD).v, d->B, d->N, d->dim);
+    if ((rc = tmf_launch_result("tmf_heads_fwd(token mean)"))) return rc;
+    const size_t lds0 = (size_t)d->B * 4 * d->dim * 4;
+    if ((rc = tmf_allow_lds(heads_fc0_kernel, lds0, "tmf_heads_fwd(fc0)"))) return rc;
+    hipLaunchKernelGGL(heads_fc0_kernel, dim3(tmf_cdiv(d->H1, 64)), dim3(HT), lds0, (hipStream_t)stream, a);
+    if ((rc = tmf_launch_result("tmf_heads_fwd(fc0)"))) return rc;
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3(1), dim3(HT), lds, (hipStream_t)stream, a);
+    return tmf_launch_result("tmf_heads_fwd");
+}
+
+extern "C" size_t tmf_heads_bwd_scratch_bytes(const tmf_heads_desc* d) {
+    if (check_heads("tmf_heads_bwd_scratch_bytes", d) != TMF_OK) return 0;
+    return (size_t)(d->B * d->H1 + d->B * d->H2 + 2 * d->B * d->dim) * 4;
+}
+
+extern "C" int tmf_heads_bwd(const tmf_heads_desc* d, const float* cls, const float* mask1, const float* mask2,
+                             const tmf_heads_params* p, const void* saved, size_t saved_bytes, const float* d_logits,
+                             const float* d_d_mri_logits, const float* d_d_pet_logits, const tmf_heads_grads* g,
+                             float* d_cls, float* d_mri_tok, float* d_pet_tok, float revgrad_alpha,
+                             void* scratch, size_t scratch_bytes, void* stream) {
+    int rc;
+    if ((rc = check_heads("tmf_heads_bwd", d))) return rc;
+    if ((rc = check_params("tmf_heads_bwd", p))) return rc;
+    TMF_REQUIRE_PTR(cls); TMF_REQUIRE_PTR(saved); TMF_REQUIRE_PTR(d_logits); TMF_REQUIRE_PTR(d_d_mri_logits);
+    TMF_REQUIRE_PTR(d_d_pet_logits); TMF_REQUIRE_PTR(g); TMF_REQUIRE_PTR(d_cls); TMF_REQUIRE_PTR(d_mri_tok); TMF_REQUIRE_PTR(d_pet_tok);
+    TMF_REQUIRE(g->fc0_w && g->fc0_b && g->bn1_g && g->bn1_b && g->fc4_w && g->fc4_b && g->bn5_g && g->bn5_b && g->fc8_w &&
+                g->fc8_b && g->d0_w && g->d0_b && g->dbn_g && g->dbn_b && g->d3_w && g->d3_b, TMF_E_NULL,
+                "tmf_heads_bwd: a gradient pointer is NULL");
+    TMF_REQUIRE(saved_bytes >= tmf_heads_saved_bytes(d), TMF_E_WORKSPACE, "tmf_heads_bwd: saved %zu B < required %zu B",
+                saved_bytes, tmf_heads_saved_bytes(d));
+    HeadsBwdArgs a = {};
+    a.f = make_args(*d, cls, nullptr, nullptr, mask1, mask2, *p, (float*)const_cast<void*>(saved));
+    a.d_logits = d_logits; a.d_dlog[0] = d_d_mri_logits; a.d_dlog[1] = d_d_pet_logits;
+    a.gw0 = g->fc0_w; a.gb0 = g->fc0_b; a.gg1 = g->bn1_g; a.gbe1 = g->bn1_b; a.gw4 = g->fc4_w; a.gb4 = g->fc4_b;
+    a.gg5 = g->bn5_g; a.gbe5 = g->bn5_b; a.gw8 = g->fc8_w; a.gb8 = g->fc8_b;
+    a.gdw0 = g->d0_w; a.gdb0 = g->d0_b; a.gdg1 = g->dbn_g; a.gdbe1 = g->dbn_b; a.gdw3 = g->d3_w; a.gdb3 = g->d3_b;
+    a.d_cls = d_cls; a.d_tok[0] = d_mri_tok; a.d_tok[1] = d_pet_tok; a.alpha = revgrad_alpha;
+    TMF_REQUIRE_PTR(scratch);
+    TMF_REQUIRE(scratch_bytes >= tmf_heads_bwd_scratch_bytes(d), TMF_E_WORKSPACE, "tmf_heads_bwd: scratch %zu B < required %zu B",
+                scratch_bytes, tmf_heads_bwd_scratch_bytes(d));
+    TMF_REQUIRE_ALIGNED(d_mri_tok); TMF_REQUIRE_ALIGNED(d_pet_tok); TMF_REQUIRE_ALIGNED(scratch);
+    a.s_dz1 = (float*)scratch; a.s_dz2 = a.s_dz1 + (size_t)d->B * d->H1; a.s_dv = a.s_dz2 + (size_t)d->B * d->H2;
+    const size_t lds = bwd_lds(*d);
+    TMF_REQUIRE(lds <= 150 * 1024, TMF_E_SHAPE, "tmf_heads_bwd: %zu B of LDS needed (batch x widths too large)", lds);
+    if ((rc = tmf_allow_lds(heads_bwd_kernel, lds, "tmf_heads_bwd"))) return rc;
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3(1), dim3(HT), lds, (hipStream_t)stream, a);
+    if ((rc = tmf_launch_result("tmf_heads_bwd"))) return rc;
+    const int nb0 = tmf_cdiv(d->H1, 8), nb4 = tmf_cdiv(d->H2, 8);
+    int nbt = tmf_cdiv((long)2 * d->B * d->N * d->dim, (long)HT * 4 * 4);
+    if (nbt > 256) nbt = 256;
+    if (nbt < 1) nbt = 1;
+    const int nbc = tmf_cdiv(4 * d->dim, 64);
+    hipLaunchKernelGGL(heads_bwd_outer_kernel, dim3(nbc + nb0 + nb4 + nbt), dim3(HT), 0, (hipStream_t)stream, a, nb0, nb4, nbc);
+    return tmf_launch_result("tmf_heads_bwd(outer)");
+}

@@ -203,6 +203,49 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
     return TMF_OK;
 }
 
+// Inference (val_step, kfold_train_adversarial.py:144-161): BatchNorm is affine in eval mode, so a block is ONE kernel
+// (conv + folded BatchNorm + LeakyReLU + pool, tmf_conv3d_fwd_affine; the fused first-block forward for block 0) — seven
+// launches + seven weight packs + seven coefficient kernels per encoder, enqueued by one call.  fp32 precision only.
+extern "C" size_t tmf_snet_eval_workspace_bytes(const tmf_snet_desc* d) {
+    if (check_desc("tmf_snet_eval_workspace_bytes", d) != TMF_OK) return 0;
+    tmf_snet_desc e = *d;
+    e.precision = TMF_PREC_FP32; e.storage_bf16 = 0;
+    return make_plan(e).saved_bytes;            // same carving: block outputs, per-block vectors, packed weights
+}
+
+extern "C" int tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const tmf_snet_params* prm,
+                                 void* workspace, size_t workspace_bytes, float* out, void* stream) {
+    TMF_TRY(check_desc("tmf_snet_eval_fwd", d));
+    TMF_REQUIRE(d->precision == TMF_PREC_FP32, TMF_E_ARG, "tmf_snet_eval_fwd: fp32 precision only");
+    TMF_REQUIRE_PTR(vol); TMF_REQUIRE_PTR(prm); TMF_REQUIRE_PTR(workspace); TMF_REQUIRE_PTR(out);
+    TMF_REQUIRE_ALIGNED(vol); TMF_REQUIRE_ALIGNED(workspace); TMF_REQUIRE_ALIGNED(out);
+    const Plan p = make_plan(*d);
+    TMF_REQUIRE(workspace_bytes >= p.saved_bytes, TMF_E_WORKSPACE, "tmf_snet_eval_fwd: workspace %zu B < required %zu B",
+                workspace_bytes, p.saved_bytes);
+    for (int l = 0; l < NL; ++l)
+        TMF_REQUIRE(prm->weight[l] && prm->gamma[l] && prm->beta[l] && prm->running_mean[l] && prm->running_var[l], TMF_E_NULL,
+                    "tmf_snet_eval_fwd: weight / gamma / beta / running statistics of block %d is NULL", l);
+    char* base = (char*)workspace;
+    const void* x = vol;
+    for (int l = 0; l < NL; ++l) {
+        const LayerPlan& L = p.L[l];
+        const Vecs v = vecs_of(base, L);
+        float* o = l == NL - 1 ? out : (float*)(base + L.off_out);
+        float* wf = (float*)(base + L.off_wf);
+        TMF_TRY(tmf_pack_conv_weights(prm->weight[l], wf, nullptr, L.cout, L.cin, L.k * L.k * L.k, stream));
+        TMF_TRY(tmf_bn_eval_coeffs(prm->gamma[l], prm->beta[l], prm->bias[l], prm->running_mean[l], prm->running_var[l],
+                                   d->eps[l], L.cout, v.scale, v.shift, stream));
+        if ((size_t)L.oD * L.oH * L.oW == 0) continue;
+        if (l == 0)
+            TMF_TRY(tmf_c1_bn_pool_fwd(vol, wf, v.scale, v.shift, o, d->B, L.D, L.H, L.W, L.cout, d->slope[l], stream));
+        else
+            TMF_TRY(tmf_conv3d_fwd_affine((const float*)x, wf, v.scale, v.shift, o, d->B, L.D, L.H, L.W, L.cin, L.cout, L.k,
+                                          L.pool, d->slope[l], stream));
+        x = o;
+    }
+    return TMF_OK;
+}
+
 extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, const void* saved, size_t saved_bytes,
                                   const float* dout, const tmf_snet_grads* g, void* scratch, size_t scratch_bytes,
                                   void* stream) {

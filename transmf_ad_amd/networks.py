@@ -74,6 +74,12 @@ class sNet(nn.Module):
             if nbt:
                 torch._foreach_add_(nbt, 1)
         blocks = [(getattr(self, n)[i], getattr(self, n)[i + 1], getattr(self, n)[i + 2]) for n, i, _ in self._PLAN]
+        if (not self.training and not torch.is_grad_enabled() and ops.get_conv_precision() == "fp32" and ops.FUSE_EVAL_BLOCKS
+                and all(bn.track_running_stats for _c, bn, _a in blocks) and self._one_call_ok(vol, blocks, eval_mode=True)):
+            return ops.snet_eval_one_call(
+                vol, blocks[-1][0].out_channels, tuple(float(bn.eps) for _c, bn, _a in blocks),
+                tuple(float(a.negative_slope) for _c, _b, a in blocks),
+                [(c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var) for c, bn, _a in blocks])
         if self._one_call_ok(vol, blocks):
             params, buffers = [], []
             for conv, bn, _act in blocks:
@@ -102,7 +108,7 @@ class sNet(nn.Module):
                                      out_bf16=out16)
         return x                                 # (B, d, h, w, dim)
 
-    def _one_call_ok(self, vol, blocks):
+    def _one_call_ok(self, vol, blocks, eval_mode=False):
         """Train-mode batch statistics in every block, the standard sNet(dim) geometry, no gradient wanted for the
         input: the whole pass is one library call (ops.SNetTrain); anything else goes block by block."""
         if vol.requires_grad or not vol.is_cuda or vol.dtype != torch.float32:
@@ -116,7 +122,7 @@ class sNet(nn.Module):
         for (conv, bn, _act), (ci, co, k) in zip(blocks, want):
             if (conv.in_channels, conv.out_channels, conv.kernel_size) != (ci, co, (k, k, k)):
                 return False
-            if not (self.training or not bn.track_running_stats) or bn.momentum is None or not bn.affine:
+            if not bn.affine or (not eval_mode and (not (self.training or not bn.track_running_stats) or bn.momentum is None)):
                 return False
         return True
 

@@ -473,6 +473,25 @@ def snet_one_call_supported(B, D, H, W, dim):
             and min(D, H, W) >= 16 and B > 0)
 
 
+def snet_eval_one_call(vol, dim, eps, slope, blocks):
+    """Eval-mode sNet forward as ONE library call (tmf_snet_eval_fwd): no autograd graph (val_step runs under no_grad).
+    blocks: 7 x (conv weight, conv bias | None, bn weight, bn bias, running_mean, running_var)."""
+    import ctypes as C
+    vol = _chk(vol, "vol")
+    B, _, D, H, W = vol.shape
+    desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision=0, storage_bf16=0)
+    prm = _lib.SnetParams()
+    for l, (w, b, g, be, rm, rv) in enumerate(blocks):
+        desc.eps[l], desc.slope[l], desc.momentum[l] = eps[l], slope[l], 0.0
+        prm.weight[l], prm.bias[l], prm.gamma[l], prm.beta[l] = w.data_ptr(), _ptr(b), g.data_ptr(), be.data_ptr()
+        prm.running_mean[l], prm.running_var[l] = rm.data_ptr(), rv.data_ptr()
+    nws = _lib.query("tmf_snet_eval_workspace_bytes", C.byref(desc))
+    ws = torch.empty(nws, device=vol.device, dtype=torch.uint8)
+    out = torch.empty((B, D // 16, H // 16, W // 16, dim), device=vol.device, dtype=_f32)
+    _lib.call("tmf_snet_eval_fwd", C.byref(desc), vol.data_ptr(), C.byref(prm), ws.data_ptr(), nws, out.data_ptr(), _stream())
+    return out
+
+
 class SNetTrain(torch.autograd.Function):
     """Train-mode sNet forward / backward as ONE library call each (tmf_snet_train_fwd / _bwd: csrc/snet_path.hip): the
     same kernels in the same order as the block-by-block path, every intermediate tensor inside one workspace tensor,
@@ -519,13 +538,18 @@ class SNetTrain(torch.autograd.Function):
         dout = _chk(dout, "grad_output")
         sizes = [0 if s is None else s.numel() for s in ctx.shapes]
         flat = torch.empty(sum(sizes), device=vol.device, dtype=_f32)        # all 28 gradients in one allocation
-        grads = [None if s is None else t.view(s) for t, s in zip(flat.split(sizes), ctx.shapes)]
+        parts = flat.split(sizes)
+        grads = [None if s is None else (t if len(s) == 1 else t.view(s)) for t, s in zip(parts, ctx.shapes)]
+        ptr, o = [], flat.data_ptr()
+        for n in sizes:
+            ptr.append(o)
+            o += 4 * n
         g = _lib.SnetGrads()
+        need = ctx.needs_input_grad
         for l in range(7):
-            dw, db, dg, dbe = grads[4 * l:4 * l + 4]
-            g.dweight[l] = dw.data_ptr() if ctx.needs_input_grad[3 + 4 * l] else None
-            g.dbias[l] = None if db is None else db.data_ptr()
-            g.dgamma[l], g.dbeta[l] = dg.data_ptr(), dbe.data_ptr()
+            g.dweight[l] = ptr[4 * l] if need[3 + 4 * l] else None
+            g.dbias[l] = None if ctx.shapes[4 * l + 1] is None else ptr[4 * l + 1]
+            g.dgamma[l], g.dbeta[l] = ptr[4 * l + 2], ptr[4 * l + 3]
         nscr = _lib.query("tmf_snet_bwd_scratch_bytes", C.byref(desc))
         scratch = torch.empty(nscr, device=vol.device, dtype=torch.uint8)
         _lib.call("tmf_snet_train_bwd", C.byref(desc), vol.data_ptr(), saved.data_ptr(), saved.numel(), dout.data_ptr(),
@@ -810,41 +834,39 @@ class FusionTrain(torch.autograd.Function):
         cls = torch.empty((B, 4 * dim), device=mri.device, dtype=_f32)
         _lib.call("tmf_fusion_train_fwd", C.byref(desc), mri.data_ptr(), pet.data_ptr(), inst, saved.data_ptr(), nsaved,
                   cls.data_ptr(), _stream())
-        ctx.save_for_backward(mri, pet, saved, *params)
-        ctx.desc, ctx.eps = desc, eps
-        return cls
+        ctx.save_for_backward(mri, pet, saved, *params)     # parameters too: autograd then rejects an in-place update
+        ctx.desc, ctx.inst = desc, inst                     # between forward and backward; their pointers stay valid:
+        return cls                                          # the ctypes structs are reused as they are
 
     @staticmethod
     def backward(ctx, dcls):
         import ctypes as C
         mri, pet, saved = ctx.saved_tensors[:3]
-        params = ctx.saved_tensors[3:]
-        desc = ctx.desc
+        desc, inst = ctx.desc, ctx.inst
         depth, dim, mlp = desc.depth, desc.dim, desc.mlp
         inner = desc.heads * desc.dim_head
         dcls = _chk(dcls, "grad_output")
-        inst = (_lib.XformerParams * (2 * depth))()
-        grads = (_lib.XformerGrads * (2 * depth))()
-        # per instance ONE flat gradient buffer: [small (6*dim + mlp) | lnf (2*dim) | dwq | dwkv | dwo | dw1 | dw2]
-        sizes = [6 * dim + mlp, 2 * dim, inner * dim, 2 * inner * dim, dim * inner, mlp * dim, dim * mlp]
+        n_inst = 2 * depth
+        grads = (_lib.XformerGrads * n_inst)()
+        # ONE flat gradient buffer for the whole fusion, cut by ONE split call; per instance
+        # [b2 | b1 | bo | ln2 g | ln2 b | ln1 g | ln1 b | lnf g | lnf b | dwq | dwkv | dwo | dw1 | dw2]
+        # (the first seven are the contiguous `small` region of tmf_xformer_grads, the next two its `lnf`)
+        sizes = [dim, mlp, dim, dim, dim, dim, dim, dim, dim, inner * dim, 2 * inner * dim, dim * inner, mlp * dim, dim * mlp]
         per = sum(sizes)
-        flat = torch.empty(2 * depth * per, device=mri.device, dtype=_f32)
-        out = [None, None, None]
+        flat = torch.empty(n_inst * per, device=mri.device, dtype=_f32)
+        parts = flat.split(sizes * n_inst)
         base = flat.data_ptr()
-        for i in range(2 * depth):
-            for j, name in enumerate(_lib.XFORMER_PTRS):
-                setattr(inst[i], name, params[14 * i + j].data_ptr())
-            inst[i].eps1, inst[i].eps2, inst[i].epsf = ctx.eps[i]
-            o = i * per
-            ptrs = []
-            for n in sizes:
-                ptrs.append(base + 4 * o)
-                o += n
-            (grads[i].small, grads[i].lnf, grads[i].dwq, grads[i].dwkv, grads[i].dwo, grads[i].dw1, grads[i].dw2) = ptrs
-            f = flat[i * per:(i + 1) * per]
-            small, lnf, dwq, dwkv, dwo, dw1, dw2 = f.split(sizes)
-            b2, b1, bo, g2, be2, g1, be1 = small.split([dim, mlp, dim, dim, dim, dim, dim])
-            gf, bf = lnf.split([dim, dim])
+        o_lnf = 4 * (6 * dim + mlp)
+        o_w = [o_lnf + 4 * 2 * dim]
+        for n in sizes[9:13]:
+            o_w.append(o_w[-1] + 4 * n)
+        out = [None, None, None]
+        for i in range(n_inst):
+            g = grads[i]
+            b0 = base + 4 * i * per
+            g.small, g.lnf = b0, b0 + o_lnf
+            g.dwq, g.dwkv, g.dwo, g.dw1, g.dw2 = (b0 + o for o in o_w)
+            b2, b1, bo, g2, be2, g1, be1, gf, bf, dwq, dwkv, dwo, dw1, dw2 = parts[14 * i:14 * i + 14]
             # order of _lib.XFORMER_PTRS
             out += [g1, be1, dwq.view(inner, dim), dwkv.view(2 * inner, dim), dwo.view(dim, inner), bo, g2, be2,
                     dw1.view(mlp, dim), b1, dw2.view(dim, mlp), b2, gf, bf]
@@ -856,6 +878,87 @@ class FusionTrain(torch.autograd.Function):
                   saved.numel(), dcls.data_ptr(), grads, dm.data_ptr(), dp.data_ptr(), scratch.data_ptr(), nscr, _stream())
         out[0], out[1] = dm, dp
         return tuple(out)
+
+
+# --------------------------------------------------------------------------------------
+# the dense heads of model_ad in one launch per direction            (mymodel.py:190-194, 209-221)
+# --------------------------------------------------------------------------------------
+
+HEADS_ONE_CALL = os.environ.get("TMF_HEADS_C", "1") != "0"
+
+
+class HeadsAD(torch.autograd.Function):
+    """fc_cls(cls) and D(revgrad(mean_n mri_tok)), D(revgrad(mean_n pet_tok)) as ONE kernel forward and ONE backward
+    (tmf_heads_fwd / _bwd, csrc/heads.hip).  forward(cls, mri_tok, pet_tok, mask1, mask2, cfg, buffers, *params) with
+    params in _lib.HEADS_PARAMS order, buffers in _lib.HEADS_BUFFERS order (None = no running statistics), masks = scaled
+    Dropout keep-masks or None, cfg = (training, (momentum x3), (eps x3), revgrad alpha) -> (logits, D_MRI, D_PET)."""
+
+    @staticmethod
+    def forward(ctx, cls, mri, pet, mask1, mask2, cfg, buffers, *params):
+        import ctypes as C
+        cls, mri, pet = _chk(cls, "cls"), _chk(mri, "mri_tokens"), _chk(pet, "pet_tokens")
+        training, momentum, eps, alpha = cfg
+        B, N, dim = mri.shape
+        P = dict(zip(_lib.HEADS_PARAMS, params))
+        desc = _lib.HeadsDesc(B=B, N=N, dim=dim, H1=P["fc0_w"].shape[0], H2=P["fc4_w"].shape[0], HD=P["d0_w"].shape[0],
+                              NC=P["fc8_w"].shape[0], training=int(training))
+        for i in range(3):
+            desc.momentum[i], desc.eps[i] = momentum[i], eps[i]
+        prm = _lib.HeadsParams()
+        for name, t in P.items():
+            if not (t.is_cuda and t.dtype == _f32 and t.is_contiguous()):
+                raise _lib.TmfError(f"heads: {name} must be a contiguous float32 tensor on the HIP device")
+            setattr(prm, name, t.data_ptr())
+        for name, t in zip(_lib.HEADS_BUFFERS, buffers):
+            setattr(prm, name, _ptr(t))
+        m1 = None if mask1 is None else _chk(mask1, "mask1")
+        m2 = None if mask2 is None else _chk(mask2, "mask2")
+        nsaved = _lib.query("tmf_heads_saved_bytes", C.byref(desc))
+        if nsaved == 0:
+            raise _lib.TmfError("tmf_heads_saved_bytes: " + (_lib.load().tmf_last_error_string() or b"").decode())
+        saved = torch.empty(nsaved // 4, device=cls.device, dtype=_f32)
+        outs = torch.empty((3, B, desc.NC), device=cls.device, dtype=_f32)
+        _lib.call("tmf_heads_fwd", C.byref(desc), cls.data_ptr(), mri.data_ptr(), pet.data_ptr(), _ptr(m1), _ptr(m2),
+                  C.byref(prm), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), saved.data_ptr(), nsaved, _stream())
+        ctx.save_for_backward(cls, saved, *params)
+        ctx.masks = (m1, m2)
+        ctx.desc, ctx.prm, ctx.alpha = desc, prm, float(alpha)
+        ctx.tok_shape = tuple(mri.shape)
+        return outs[0], outs[1], outs[2]
+
+    @staticmethod
+    def backward(ctx, dlo, ddm, ddp):
+        import ctypes as C
+        cls, saved = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        desc = ctx.desc
+        B, NC = desc.B, desc.NC
+        dev = cls.device
+        dl = torch.zeros((3, B, NC), device=dev, dtype=_f32) if (dlo is None or ddm is None or ddp is None) else None
+        if dl is None:
+            dl = torch.stack([dlo, ddm, ddp]).to(_f32).contiguous()
+        else:
+            for i, g in enumerate((dlo, ddm, ddp)):
+                if g is not None:
+                    dl[i].copy_(g)
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes), device=dev, dtype=_f32)
+        parts = flat.split(sizes)
+        g = _lib.HeadsGrads()
+        o = flat.data_ptr()
+        for name, n in zip(_lib.HEADS_PARAMS, sizes):
+            setattr(g, name, o)
+            o += 4 * n
+        d_cls = torch.empty_like(cls)
+        d_tok = torch.empty((2,) + ctx.tok_shape, device=dev, dtype=_f32)
+        m1, m2 = ctx.masks
+        nscr = _lib.query("tmf_heads_bwd_scratch_bytes", C.byref(desc))
+        scratch = torch.empty(nscr // 4, device=dev, dtype=_f32)
+        _lib.call("tmf_heads_bwd", C.byref(desc), cls.data_ptr(), _ptr(m1), _ptr(m2), C.byref(ctx.prm), saved.data_ptr(),
+                  saved.numel() * 4, dl[0].data_ptr(), dl[1].data_ptr(), dl[2].data_ptr(), C.byref(g), d_cls.data_ptr(),
+                  d_tok[0].data_ptr(), d_tok[1].data_ptr(), ctx.alpha, scratch.data_ptr(), nscr, _stream())
+        grads = [t if p.dim() == 1 else t.view(p.shape) for t, p in zip(parts, params)]
+        return (d_cls, d_tok[0], d_tok[1], None, None, None, None, *grads)
 
 
 # --------------------------------------------------------------------------------------
