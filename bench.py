@@ -147,7 +147,8 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             kd = _lib.query("tmf_conv3d_fwd_bf16_kernel_name", B, D, H, W, co, ci, io).decode()
             fns = (("fwd", kf, lambda: ops.conv3d_bf16_raw(x, wf, ci, co, True, out_bf16=s16)),
                    ("dgrad", kd, lambda: ops.conv3d_bf16_raw(dz, wd, co, ci, False, out_bf16=s16)),
-                   ("wgrad", f"conv3d_wgrad_bf16_kernel<{'true' if s16 else 'false'}>", lambda: ops.conv3d_wgrad_bf16(x, dz, ci, co)))
+                   ("wgrad", _lib.query("tmf_conv3d_wgrad_bf16_kernel_name", B, D, H, W, ci, co, 1 if s16 else 0).decode(),
+                    lambda: ops.conv3d_wgrad_bf16(x, dz, ci, co)))
         else:
             wf, wd = ops.pack_weights_both(w, True)
             kf = _lib.query("tmf_conv3d_fwd_kernel_name", B, D, H, W, ci, co, 3).decode()

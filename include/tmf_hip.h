@@ -52,8 +52,10 @@ const char* tmf_last_error_string(void);
  * convolution kernels (16, the default: two 8-wave workgroups per CU).  "conv_ws" = 1: the experimental wave-specialised
  * forward kernel for eligible 3x3x3 layers (default 0; higher values are its timing ablations).  "bf16_v2" = 0 | 1 | 2:
  * bf16 forward / data-gradient kernel with 8x8x8 bricks and 2 x 2 register tiles never / by brick count (default) /
- * always (results equal up to fp32 summation order; tmf_conv3d_bf16_stat_blocks follows the choice).  "debug": timing ablations
- * only (results are garbage when set).
+ * always (results equal up to fp32 summation order; tmf_conv3d_bf16_stat_blocks follows the choice).  "wgrad_tr" = 0 | 1 | 2:
+ * bf16 weight-gradient kernel with LDS transposing reads never / where it is the faster one (default) / wherever its
+ * shape rule allows (cin, cout multiples of 8); equal up to fp32 summation order.  "debug": timing ablations only, live in
+ * -DTMF_ABLATE builds (results are garbage when set).
  * Size limits of the convolution entries: one sample of a layer (D*H*W*max(cin, cout)) and one weight tensor stay below
  * 2^29 elements — offsets inside a sample are 32-bit byte offsets of buffer resources; violating shapes return TMF_E_SHAPE. */
 int         tmf_set_option(const char* name, int value);
@@ -110,6 +112,7 @@ int    tmf_conv3d_wgrad_bf16(const float* x, const float* dz, float* dw, void* w
 int    tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z, float* stat_partial,
                              int B, int D, int H, int W, int cin, int cout, int io, void* stream);
 const char* tmf_conv3d_fwd_bf16_kernel_name(int B, int D, int H, int W, int cin, int cout, int io);   /* as tmf_conv3d_fwd_kernel_name */
+const char* tmf_conv3d_wgrad_bf16_kernel_name(int B, int D, int H, int W, int cin, int cout, int io); /* io: 1 = bf16 tensors */
 int    tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
                                int B, int D, int H, int W, int cin, int cout, int io, int dw_layout, void* stream);
 /* fp32-ACCURATE variant on the bf16 matrix cores: operands split exactly into three bf16 numbers (hi+mid+lo), the

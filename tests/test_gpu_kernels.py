@@ -497,11 +497,21 @@ def test_conv3d_bf16_mfma(shape, bf16_kernel_choice):
         assert _relerr(_ncdhw(dx.cpu()), xr.grad) < 2e-6
 
 
-@pytest.mark.parametrize("shape", BF16_SHAPES)
-def test_conv3d_wgrad_bf16_mfma(shape):
+@pytest.fixture(params=[2, 0], ids=["tr-read", "reg-transpose"])
+def wgrad_kernel_choice(request):
+    """Both bf16 weight-gradient kernels: the transposing-read one (cin, cout multiples of 8) and the register-transposing one."""
+    from transmf_ad_amd import _lib
+    _lib.call("tmf_set_option", b"wgrad_tr", request.param)
+    yield request.param
+    _lib.call("tmf_set_option", b"wgrad_tr", 1)
+
+
+@pytest.mark.parametrize("shape", BF16_SHAPES + [(1, 20, 9, 17, 32, 64), (2, 8, 16, 8, 72, 136)])
+def test_conv3d_wgrad_bf16_mfma(shape, wgrad_kernel_choice):
     """bf16 matrix-core weight gradient: operands that ARE bf16 numbers give exact products, so the result is held
-    to fp32-accumulation accuracy against fp64; general fp32 operands are rounded in the kernel exactly as torch's
-    .bfloat16() does (bit-identical result), and stay within bf16-operand accuracy of the fp32 gradient."""
+    to fp32-accumulation accuracy against fp64 (fp32 tensors and bf16 tensors); general fp32 operands are rounded in the
+    kernel exactly as torch's .bfloat16() does (bit-identical result), and stay within bf16-operand accuracy of the
+    fp32 gradient."""
     ops = _ops()
     B, D, H, W, cin, cout = shape
     x = _rand(B, cin, D, H, W, seed=81)
@@ -515,6 +525,11 @@ def test_conv3d_wgrad_bf16_mfma(shape):
     assert _relerr(got, wr.grad) < 5e-6
     dw2 = ops.conv3d_wgrad_bf16(_ndhwc(x).to(DEV), _ndhwc(dz).to(DEV), cin, cout)
     assert torch.equal(dw2, dw)
+    if cin % 2 == 0 and cout % 2 == 0:
+        dw3 = ops.conv3d_wgrad_bf16(_ndhwc(x).to(DEV).bfloat16(), _ndhwc(dz).to(DEV).bfloat16(), cin, cout)
+        assert _relerr(ops.unpack_wgrad(dw3, cout, cin, 3).cpu(), wr.grad) < 5e-6
+        dw4 = ops.conv3d_wgrad_bf16(_ndhwc(x).to(DEV).bfloat16(), _ndhwc(dz).to(DEV).bfloat16(), cin, cout, reference_layout=True)
+        assert _relerr(dw4.cpu(), wr.grad) < 5e-6
     wr2 = torch.zeros(cout, cin, 3, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv3d(x.double(), wr2, padding=1).backward(dz.double())
     assert _relerr(got, wr2.grad) < 1e-2

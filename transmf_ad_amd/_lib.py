@@ -41,6 +41,7 @@ PROTOTYPES = {
     "tmf_conv3d_bf16_stat_blocks": (_i, [_i, _i, _i, _i]),
     "tmf_conv3d_split_stat_blocks": (_i, [_i, _i, _i, _i]),
     "tmf_conv3d_fwd_bf16_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
+    "tmf_conv3d_wgrad_bf16_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_c1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tmf_conv3d_c1_stat_blocks": (_i, [_i, _i, _i, _i, _i]),
     "tmf_conv3d_c1_wgrad_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),

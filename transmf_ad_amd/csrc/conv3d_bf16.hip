@@ -986,12 +986,346 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_kernel(
     }
 }
 
-struct WgBfPlan { int tilesD, tilesH, tilesW, ntiles, gy, gz, tps, nsplit; };
-WgBfPlan plan_wgrad_bf16(int B, int D, int H, int W, int cin, int cout) {
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient, second form: the operands stay in their NATURAL channels-last order in LDS and the transposition
+// the matrix instruction needs (8 consecutive VOXELS of one channel per lane) is done by the LDS unit itself:
+// ds_read_b64_tr_b16 hands lane l channel l % 32 of four voxels when the 16 lanes of a group address a [4 voxel][16
+// channel] block (tools/microbench/tr16.hip prints the mapping).  So
+//   * staging is a plain 16-byte copy (halo voxels are 64-B rows of 32 channels; no register transposes, no three
+//     pre-shifted images: a tap shift along w is a 64-B address offset like the shifts along d / h), 38 KB + 16 KB per
+//     32 output channels per brick instead of 110 KB;
+//   * the brick is double-buffered in LDS with ONE barrier per brick, and the two waves that share a SIMD run the
+//     staging of brick n+1 at opposite ends of their matrix loops (waves 0-3: stage, then multiply; waves 4-7:
+//     multiply, then stage), so the matrix pipe always has a wave feeding it;
+//   * a workgroup covers 32 x (32 * NH) channels: with NH = 2 every x fragment feeds two MFMAs.
+// Needs cin % 8 == 0 and cout % 8 == 0 (16-byte channel groups); other shapes use the kernel above.
+// ------------------------------------------------------------------------------------------------------------
+namespace wtr {
+constexpr int XB = HD * HH * HW * 64;                  // bytes of one halo image: [600 voxels][32 ci] bf16
+constexpr int DZB = TD * TH * TW * 64;                 // bytes of one 32-channel dz image: [256 voxels][32 co] bf16
+constexpr int XCH = HD * HH * HW * 4;                  // 16-byte chunks of the halo image
+constexpr int XQ = (XCH + NTHR - 1) / NTHR;            // 5 per thread
+constexpr size_t lds_bytes(int nh) { return (size_t)2 * (XB + nh * DZB); }
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ bf16x8 tr8(const unsigned char* p) {      // voxels 0-3 at p, voxels 4-7 at p + 4 * 64
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(p + 256));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+// LDS-DMA of 16 bytes per lane: LDS byte = lds_wave_base (wave-uniform LDS address) + 16 * lane.  Written as inline
+// assembly on purpose: with __builtin_amdgcn_global_load_lds the compiler cannot tell that the copy fills the OTHER
+// buffer and waits vmcnt(0) before the first fragment read of every brick, which serialises copy and multiply (the
+// first build did: 61 us of 240 exposed).  The price is that the compiler does not see the copies at all: the kernel
+// waits for them itself (dma_wait) before the barrier that publishes the buffer.
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+}  // namespace wtr
+__device__ __attribute__((aligned(16))) const unsigned int tmf_zero16[4] = {0u, 0u, 0u, 0u};
+
+template <int NH, bool IN16>
+__global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_tr_kernel(
+    const void* __restrict__ x_, const void* __restrict__ dz_, float* __restrict__ partial,
+    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles, int tiles_per_split) {
+    using namespace wtr;
+    // timing ablations (compile-time: -DTMF_ABLATE_WG=bits builds made by tools/wgrad_ablate.py; results are garbage
+    // when set): 1 = no staging copies, 2 = no LDS fragment reads, 4 = no MFMAs, 8 = no barriers
+#ifdef TMF_ABLATE_WG
+    constexpr int dbg = TMF_ABLATE_WG;
+#else
+    constexpr int dbg = 0;
+#endif
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    constexpr int BUFB = XB + NH * DZB;
+    constexpr int DQ = NH * 2;                                // dz chunks per thread (NH images x 256 voxels x 4 chunks)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const int split = blockIdx.x;
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.z * 32 * NH;
+
+    // Seven taps per SIMD, shared by its two waves (w and w + 4).  NH = 2 (two 32-channel halves of dz): each wave owns
+    // three taps with both halves and ONE half of the SIMD's seventh tap - seven MFMAs per wave and k-step, identical
+    // instruction streams (SIMD 3 has only six taps: its seventh is a repeat whose result is dropped; the other SIMDs
+    // take seven anyway).  NH = 1: four taps for wave w, three for wave w + 4.
+    constexpr int NACC = NH == 2 ? 7 : 4;
+    const int simd = wave & 3, pair = wave >> 2;
+    const bool four = NH == 2 || pair == 0;                   // the fourth fragment slot is in use
+    int tap_of[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        tap_of[t] = NH == 2 ? (t < 3 ? 7 * simd + 3 * pair + t : 7 * simd + 6) : 7 * simd + 4 * pair + t;
+    // the lane's 8 bytes inside a [4 voxel][32 channel] block: voxel i16 / 4, channels 16 * g16 + 4 * (i16 % 4) ...
+    const int lane_off = (i16 >> 2) * 64 + (i16 & 3) * 8 + g16 * 32;
+    int a_off[4];                                             // byte offset of tap t's fragment at k-step 0
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int tap = tap_of[t] > 26 ? 26 : tap_of[t];
+        const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+        a_off[t] = (((kd * HH + kh + hsel) * HW) + kw) * 64 + lane_off;
+    }
+    const int b_off = XB + hsel * TW * 64 + lane_off;
+
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int t = 0; t < NACC; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // Which bricks: with a multiple of 8 workgroups per channel block, workgroup s runs on XCD s % 8 (round-robin
+    // dispatch), so XCD x takes the x-th eighth of the bricks and its workgroups walk it INTERLEAVED (brick j, j + n,
+    // j + 2n, ...): at any moment the workgroups that share an L2 hold neighbouring bricks, whose halos overlap (a
+    // brick's halo is 2.3x its voxels; with contiguous ranges per workgroup every overlap was fetched again from HBM).
+    int tile_begin, tile_end, tile_step;
+    if ((gridDim.x & 7) == 0) {
+        const int per_xcd = (ntiles + 7) >> 3, xcd = split & 7;
+        tile_begin = xcd * per_xcd + (split >> 3);
+        tile_step = gridDim.x >> 3;
+        tile_end = (xcd + 1) * per_xcd;
+    } else {
+        tile_begin = split * tiles_per_split;
+        tile_step = 1;
+        tile_end = tile_begin + tiles_per_split;
+    }
+    if (tile_end > ntiles) tile_end = ntiles;
+
+    // One staging chunk = 16 bytes of the LDS image = 8 channels of one voxel.  Chunk c of the halo image is voxel c / 4,
+    // channels 8 * (c % 4); chunk c of the dz images is image c / 1024, voxel (c % 1024) / 4 — LDS byte 16 * c in both,
+    // which is what an LDS-DMA wants (wave-uniform base + 16 * lane).  Per thread and chunk, brick-independent: the
+    // element offset relative to the brick origin and the packed halo coordinates for the bounds test.
+    // The bounds test is two operations per chunk: each chunk carries one-hot bits of its halo coordinates (bit 31 for a
+    // chunk that never exists), each brick a mask of the coordinates that fall inside the volume.
+    int xrel[XQ], drel[DQ];
+    unsigned xoh[XQ], doh[DQ];
+#pragma unroll
+    for (int i = 0; i < XQ; ++i) {
+        const int c = tid + i * NTHR;
+        const int hv = c >> 2, part = c & 3;
+        const int hd = hv / (HH * HW), r2 = hv - hd * (HH * HW);
+        const int hh = r2 / HW, hw = r2 - hh * HW;
+        const int ch = ci0 + part * 8;
+        xrel[i] = (((hd - 1) * H + (hh - 1)) * W + (hw - 1)) * Cin + ch;
+        xoh[i] = (c < XCH && ch < Cin) ? ((1u << hd) | (1u << (8 + hh)) | (1u << (20 + hw))) : 0x80000000u;
+    }
+#pragma unroll
+    for (int i = 0; i < DQ; ++i) {
+        const int c = tid + i * NTHR;
+        const int img = c >> 10, v = (c & 1023) >> 2, part = c & 3;
+        const int vd = v >> 6, vh = (v >> 3) & 7, vw = v & 7;
+        const int ch = co0 + img * 32 + part * 8;
+        drel[i] = ((vd * H + vh) * W + vw) * Cout + ch;
+        doh[i] = ch < Cout ? ((1u << vd) | (1u << (8 + vh)) | (1u << (20 + vw))) : 0x80000000u;
+    }
+    struct Origin { size_t vox; unsigned xmask, dmask; };
+    auto bits = [](int lo, int hi) { return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u; };   // bits lo .. hi-1
+    auto imin = [](int a_, int b_) { return a_ < b_ ? a_ : b_; };
+    auto origin = [&](int tile) {
+        int tt = tile;
+        const int tw = tt % tilesW; tt /= tilesW;
+        const int th = tt % tilesH; tt /= tilesH;
+        const int td = tt % tilesD;
+        const int b = tt / tilesD;
+        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+        Origin o;
+        o.vox = (((size_t)b * D + d0) * H + h0) * W + w0;
+        // halo coordinate q is voxel origin + q - 1: inside the volume for 1 - origin <= q < extent - origin + 1
+        o.xmask = bits(d0 ? 0 : 1, imin(HD, D - d0 + 1)) | (bits(h0 ? 0 : 1, imin(HH, H - h0 + 1)) << 8) |
+                  (bits(w0 ? 0 : 1, imin(HW, W - w0 + 1)) << 20);
+        o.dmask = bits(0, imin(TD, D - d0)) | (bits(0, imin(TH, H - h0)) << 8) | (bits(0, imin(TW, W - w0)) << 20);
+        return o;
+    };
+    auto x_ok = [&](const Origin& o, int i) { return (xoh[i] & o.xmask) == xoh[i]; };
+    auto dz_ok = [&](const Origin& o, int i) { return (doh[i] & o.dmask) == doh[i]; };
+
+    // The k-loop of one brick, fully unrolled and software-pipelined by hand: the fragments of k-step ks + 1 are
+    // requested BEFORE the MFMAs of k-step ks are issued (left to the compiler they were requested behind all but the
+    // last two: both waves of a SIMD then sat out the LDS latency together, 50 us of a 240 us launch).  `mid` runs after
+    // the second k-step: the copies of the next brick are issued in the shadow of queued MFMAs, not in front of them.
+    struct Frag { bf16x8 a[4]; bf16x8 b[NH]; };
+    auto load = [&](const unsigned char* base, int ks, Frag& f) {
+        if constexpr ((dbg & 2) != 0) {
+            bf16x8 c;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) c[e] = (__bf16)(float)(ks + e);
+#pragma unroll
+            for (int n = 0; n < NH; ++n) f.b[n] = c;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f.a[t] = c;
+            return;
+        }
+        const int d = ks / (TH / 2), hp = (ks % (TH / 2)) * 2;       // 16 voxels per step: brick rows 2*ks and 2*ks + 1
+        const unsigned char* bb = base + b_off + (d * TH + hp) * TW * 64;
+        const unsigned char* ab = base + (d * HH + hp) * HW * 64;
+#pragma unroll
+        for (int n = 0; n < NH; ++n) f.b[n] = tr8(bb + n * DZB);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) f.a[t] = tr8(ab + a_off[t]);
+        if (four) f.a[3] = tr8(ab + a_off[3]);
+    };
+    auto mul = [&](const Frag& f) {
+        if constexpr ((dbg & 4) != 0) {
+#pragma unroll
+            for (int t = 0; t < NACC; ++t) acc[t][0] += (float)f.a[t & 3][0] * (float)f.b[t % NH][1];
+            return;
+        }
+        if constexpr (NH == 2) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[2 * t + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[t], f.b[n], acc[2 * t + n], 0, 0, 0);
+            const bf16x8 bs = pair ? f.b[1] : f.b[0];
+            acc[6] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[3], bs, acc[6], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[t], f.b[0], acc[t], 0, 0, 0);
+            if (four) acc[3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[3], f.b[0], acc[3], 0, 0, 0);
+        }
+    };
+    auto mma = [&](int buf, auto&& mid) {
+        const unsigned char* base = smem_raw + buf * BUFB;
+        constexpr int KS = TD * TH / 2;
+        Frag f0, f1;
+        load(base, 0, f0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ks += 2) {
+            load(base, ks + 1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(f0);
+            if (ks + 2 < KS) load(base, ks + 2, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(f1);
+            if (ks == 0) mid();
+        }
+    };
+
+    if constexpr (IN16) {
+        // bf16 tensors: the images are byte copies of global memory -> LDS-DMA, no staging registers; voxels outside the
+        // volume (and channels past the end) are copied from 16 zero bytes.  Brick n+1 streams into the other buffer
+        // while brick n is multiplied; the barrier at the end of the brick waits for it.
+        const u16* xg = reinterpret_cast<const u16*>(x_);
+        const u16* dg = reinterpret_cast<const u16*>(dz_);
+        auto issue = [&](int tile, int buf) {
+            if (dbg & 1) return;
+            const Origin o = origin(tile);
+            const unsigned wbase = __builtin_amdgcn_readfirstlane(lds_addr(smem_raw) + buf * BUFB + wave * 1024);   // this wave's 64 chunks of pass 0
+            const size_t xo = o.vox * Cin, dzo = o.vox * Cout;
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) {
+                const void* src = x_ok(o, i) ? (const void*)(xg + (ptrdiff_t)xo + xrel[i]) : (const void*)tmf_zero16;
+                if (tid + i * NTHR < XCH) glds16(src, wbase + i * (NTHR * 16));
+            }
+#pragma unroll
+            for (int i = 0; i < DQ; ++i) {
+                const void* src = dz_ok(o, i) ? (const void*)(dg + (ptrdiff_t)dzo + drel[i]) : (const void*)tmf_zero16;
+                glds16(src, wbase + XB + i * (NTHR * 16));
+            }
+        };
+        int cur = 0;
+        if (tile_begin < tile_end) issue(tile_begin, 0);
+        dma_wait();
+        __syncthreads();
+        for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
+            mma(cur, [&]() { if (tile + tile_step < tile_end) issue(tile + tile_step, cur ^ 1); });
+            dma_wait();                          // this wave's copies of brick n+1 have landed ...
+            if (!(dbg & 8)) __syncthreads();     // ... and so have everybody else's
+            cur ^= 1;
+        }
+    } else {
+        // fp32 tensors: rounded to bf16 on the way (two 16-byte loads -> one 16-byte LDS write per chunk).  The two waves
+        // that share a SIMD stage brick n+1 at opposite ends of their matrix loops (waves 0-3: stage, then multiply;
+        // waves 4-7: multiply, then stage), so the matrix pipe always has a wave feeding it.
+        const float* xg = reinterpret_cast<const float*>(x_);
+        const float* dg = reinterpret_cast<const float*>(dz_);
+        u32x4 xr[XQ], dr[DQ];
+        auto load8 = [&](const float* p8, bool ok) -> u32x4 {
+            if (!ok) return u32x4{0u, 0u, 0u, 0u};
+            const float4 a = *reinterpret_cast<const float4*>(p8);
+            const float4 b_ = *reinterpret_cast<const float4*>(p8 + 4);
+            return u32x4{pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b_.x, b_.y), pack_bf16(b_.z, b_.w)};
+        };
+        auto fetch = [&](int tile) {
+            const Origin o = origin(tile);
+            const size_t xo = o.vox * Cin, dzo = o.vox * Cout;
+#pragma unroll
+            for (int i = 0; i < XQ; ++i) xr[i] = load8(xg + (ptrdiff_t)xo + xrel[i], x_ok(o, i));
+#pragma unroll
+            for (int i = 0; i < DQ; ++i) dr[i] = load8(dg + (ptrdiff_t)dzo + drel[i], dz_ok(o, i));
+        };
+        auto commit = [&](int buf) {
+            unsigned char* base = smem_raw + buf * BUFB + tid * 16;
+#pragma unroll
+            for (int i = 0; i < XQ; ++i)
+                if (tid + i * NTHR < XCH) *reinterpret_cast<u32x4*>(base + i * (NTHR * 16)) = xr[i];
+#pragma unroll
+            for (int i = 0; i < DQ; ++i) *reinterpret_cast<u32x4*>(base + XB + i * (NTHR * 16)) = dr[i];
+        };
+        int cur = 0;
+        if (tile_begin < tile_end) {
+            fetch(tile_begin);
+            commit(0);
+            if (tile_begin + tile_step < tile_end) fetch(tile_begin + tile_step);
+        }
+        __syncthreads();
+        for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
+            const bool more = tile + tile_step < tile_end;
+            auto stage = [&]() {
+                commit(cur ^ 1);
+                if (tile + 2 * tile_step < tile_end) fetch(tile + 2 * tile_step);
+            };
+            if (pair == 0 && more) stage();
+            mma(cur, []() {});
+            if (pair != 0 && more) stage();
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+
+    // partial[split][tap][ci][co]; D fragment: row = ci, column = co
+#pragma unroll
+    for (int u = 0; u < NACC; ++u) {
+        const int t = NH == 2 ? (u < 6 ? u >> 1 : 3) : u;
+        const int n = NH == 2 ? (u < 6 ? (u & 1) : pair) : 0;
+        const int tap = tap_of[t];
+        if (tap < 27 && (t < 3 || four)) {
+            const int co = co0 + n * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * hsel;
+                if (ci < Cin && co < Cout)
+                    partial[(((size_t)split * 27 + tap) * Cin + ci) * Cout + co] = acc[u][r];
+            }
+        }
+    }
+}
+
+struct WgBfPlan { int tilesD, tilesH, tilesW, ntiles, gy, gz, tps, nsplit, nh; };
+// nh = 0: the register-transposing kernel (any channel counts); 1 / 2: the transposing-read kernel with 32 / 64 output
+// channels per workgroup (cin % 8 == 0 and cout % 8 == 0)
+int wgrad_tr_nh(int cin, int cout, int io) {
+    if (tmf_g_wgrad_tr == 0 || cin % 8 != 0 || cout % 8 != 0) return 0;
+    if (io) return cout > 32 ? 2 : 1;
+    // fp32 tensors are rounded on the way and so staged through registers (32 output channels per workgroup): measured
+    // ahead of the register-transposing kernel from 64 input channels on, level with it or behind below
+    return (cin >= 64 || tmf_g_wgrad_tr == 2) ? 1 : 0;
+}
+WgBfPlan plan_wgrad_bf16(int B, int D, int H, int W, int cin, int cout, int io) {
     WgBfPlan p;
+    p.nh = wgrad_tr_nh(cin, cout, io);
     p.tilesD = tmf_cdiv(D, TD); p.tilesH = tmf_cdiv(H, TH); p.tilesW = tmf_cdiv(W, TW);
     p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
-    p.gy = tmf_cdiv(cin, 32); p.gz = tmf_cdiv(cout, 32);
+    p.gy = tmf_cdiv(cin, 32); p.gz = tmf_cdiv(cout, p.nh == 2 ? 64 : 32);
     int want = 256 / (p.gy * p.gz);                     // one workgroup per CU and group; each walks ntiles / want bricks
     if (want < 1) want = 1;
     if (want > p.ntiles) want = p.ntiles;
@@ -1007,6 +1341,7 @@ WgBfPlan plan_wgrad_bf16(int B, int D, int H, int W, int cin, int cout) {
 // tmf_set_option("bf16_v2", 0) / TMF_BF_V2=0 selects the small-brick kernel everywhere, 2 the large-brick kernel
 // everywhere (A/B runs, tests), 1 (default) by the brick count.
 int tmf_g_debug = 0;             // tmf_set_option("debug", bits): timing ablations (results are garbage when set)
+int tmf_g_wgrad_tr = 1;          // tmf_set_option("wgrad_tr", 0 | 1)
 int tmf_g_bf16_v2 = -1;          // tmf_set_option("bf16_v2", 0 | 1 | 2); -1 = not set yet: TMF_BF_V2 or 1
 static bool use_v2(int B, int D, int H, int W) {
     if (tmf_g_bf16_v2 < 0) { const char* e = getenv("TMF_BF_V2"); tmf_g_bf16_v2 = e == nullptr ? 1 : atoi(e); }
@@ -1130,10 +1465,25 @@ extern "C" int tmf_conv3d_fwd_split(const float* x, const void* w3_bf16, float* 
     return tmf_launch_result("tmf_conv3d_fwd_split");
 }
 
+// kernel-trace name of the instance tmf_conv3d_wgrad_bf16_t launches for a shape (measurement aid)
+extern "C" const char* tmf_conv3d_wgrad_bf16_kernel_name(int B, int D, int H, int W, int cin, int cout, int io) {
+    static thread_local char buf[64];
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return "?";
+    const int nh = wgrad_tr_nh(cin, cout, io);
+    if (nh) snprintf(buf, sizeof buf, "conv3d_wgrad_bf16_tr_kernel<%d, %s>", nh, io ? "true" : "false");
+    else snprintf(buf, sizeof buf, "conv3d_wgrad_bf16_kernel<%s>", io ? "true" : "false");
+    return buf;
+}
+
 extern "C" size_t tmf_conv3d_wgrad_bf16_workspace_bytes(int B, int D, int H, int W, int cin, int cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
-    const WgBfPlan p = plan_wgrad_bf16(B, D, H, W, cin, cout);
-    return (size_t)(p.nsplit + tmf_reduce_groups(p.nsplit)) * 27 * cin * cout * 4;
+    size_t need = 0;                                    // no tensor-type argument: enough for either kernel choice
+    for (int io = 0; io < 2; ++io) {
+        const WgBfPlan p = plan_wgrad_bf16(B, D, H, W, cin, cout, io);
+        const size_t n = (size_t)(p.nsplit + tmf_reduce_groups(p.nsplit)) * 27 * cin * cout * 4;
+        if (n > need) need = n;
+    }
+    return need;
 }
 
 extern "C" int tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw, void* workspace, size_t workspace_bytes,
@@ -1151,19 +1501,26 @@ extern "C" int tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw,
     const size_t need = tmf_conv3d_wgrad_bf16_workspace_bytes(B, D, H, W, cin, cout);
     TMF_REQUIRE(workspace_bytes >= need, TMF_E_WORKSPACE, "tmf_conv3d_wgrad_bf16: workspace %zu B < required %zu B",
                 workspace_bytes, need);
-    const WgBfPlan p = plan_wgrad_bf16(B, D, H, W, cin, cout);
+    const WgBfPlan p = plan_wgrad_bf16(B, D, H, W, cin, cout, io);
     hipStream_t s = (hipStream_t)stream;
     int rc;
     float* partial = (float*)workspace;
-    if (io == 0) {
-        if ((rc = tmf_allow_lds(conv3d_wgrad_bf16_kernel<false>, WG_LDS_BYTES, "tmf_conv3d_wgrad_bf16"))) return rc;
-        hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<false>, dim3(p.nsplit, p.gy, p.gz), dim3(NTHR), WG_LDS_BYTES, s, x, dz,
-                           partial, D, H, W, cin, cout, p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);
+#define TMF_WG_LAUNCH(KERNEL, LDSB)                                                                                      \
+    do {                                                                                                                \
+        if ((rc = tmf_allow_lds(KERNEL, LDSB, "tmf_conv3d_wgrad_bf16"))) return rc;                                     \
+        hipLaunchKernelGGL(KERNEL, dim3(p.nsplit, p.gy, p.gz), dim3(NTHR), LDSB, s, x, dz, partial, D, H, W, cin, cout, \
+                           p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);                                              \
+    } while (0)
+    if (p.nh == 2) {
+        TMF_WG_LAUNCH((conv3d_wgrad_bf16_tr_kernel<2, true>), wtr::lds_bytes(2));
+    } else if (p.nh == 1) {
+        if (io == 0) TMF_WG_LAUNCH((conv3d_wgrad_bf16_tr_kernel<1, false>), wtr::lds_bytes(1));
+        else TMF_WG_LAUNCH((conv3d_wgrad_bf16_tr_kernel<1, true>), wtr::lds_bytes(1));
     } else {
-        if ((rc = tmf_allow_lds(conv3d_wgrad_bf16_kernel<true>, WG_LDS_BYTES, "tmf_conv3d_wgrad_bf16"))) return rc;
-        hipLaunchKernelGGL(conv3d_wgrad_bf16_kernel<true>, dim3(p.nsplit, p.gy, p.gz), dim3(NTHR), WG_LDS_BYTES, s, x, dz,
-                           partial, D, H, W, cin, cout, p.tilesD, p.tilesH, p.tilesW, p.ntiles, p.tps);
+        if (io == 0) TMF_WG_LAUNCH(conv3d_wgrad_bf16_kernel<false>, WG_LDS_BYTES);
+        else TMF_WG_LAUNCH(conv3d_wgrad_bf16_kernel<true>, WG_LDS_BYTES);
     }
+#undef TMF_WG_LAUNCH
     if ((rc = tmf_launch_result("tmf_conv3d_wgrad_bf16"))) return rc;
     const long n = 27L * cin * cout;
     return tmf_reduce_slabs(partial, p.nsplit, n, partial + (size_t)p.nsplit * n, dw, s, "tmf_conv3d_wgrad_bf16(reduce)",
