@@ -30,14 +30,17 @@ def _ncdhw(x):
     return x.permute(0, 4, 1, 2, 3).contiguous()
 
 
-@pytest.fixture(params=[0, 2], ids=["small-brick", "8x8x8-brick"])
+@pytest.fixture(params=[(0, 1), (2, 1), (2, 0)], ids=["small-brick", "8x8x8-brick", "8x8x8-brick-register-staged"])
 def bf16_kernel_choice(request):
     """Run a test with the bf16 forward kernel forced to the 4x8x8-brick variant (0) and to the 8x8x8-brick, 2 x NT
-    register-tile variant (2); the default (1) picks by brick count."""
+    register-tile variant (2; with bf16 tensors in its LDS-DMA form, and with that switched off); the default (1) picks by
+    brick count."""
     from transmf_ad_amd import _lib
-    _lib.call("tmf_set_option", b"bf16_v2", request.param)
-    yield request.param
+    _lib.call("tmf_set_option", b"bf16_v2", request.param[0])
+    _lib.call("tmf_set_option", b"bf16_dma", request.param[1])
+    yield request.param[0]
     _lib.call("tmf_set_option", b"bf16_v2", 1)
+    _lib.call("tmf_set_option", b"bf16_dma", 1)
 
 
 def _relerr(got, ref):

@@ -294,6 +294,22 @@ __global__ __launch_bounds__(NTHR, 4) void conv3d_fwd_bf16_kernel(
 }
 
 
+namespace dma {
+// LDS-DMA of 16 bytes per lane: LDS byte = lds_wave_base (wave-uniform LDS address) + 16 * lane.  Written as inline
+// assembly on purpose: with __builtin_amdgcn_global_load_lds the compiler cannot tell that the copy fills the OTHER
+// buffer and waits vmcnt(0) before the first fragment read of every brick, which serialises copy and multiply (the
+// first build did: 61 us of 240 exposed).  The price is that the compiler does not see the copies at all: the kernel
+// waits for them itself (dma_wait) before the barrier that publishes the buffer.
+__device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+}  // namespace dma
+__device__ __attribute__((aligned(16))) const unsigned int tmf_zero16[4] = {0u, 0u, 0u, 0u};
+
 // ------------------------------------------------------------------------------------------------------------
 // Large-layer variant: 8x8x8 bricks, a 2 x NT REGISTER TILE per wave.
 //
@@ -326,10 +342,24 @@ struct Cfg {
     static constexpr int NB = 32 * NT;
     static constexpr int WSTAGE = TPS * NB * RP;      // bf16 elements per weight stage
     static constexpr size_t LDS_BYTES = (size_t)(NHALO * RP + 2 * WSTAGE) * 2;     // statistics scratch aliases the halo
+    // DMA form: unpadded 32-byte rows, two halo buffers, two weight stages
+    static constexpr int TPSD = 9, NSTD = 3;           // taps per weight stage, stages per chunk
+    static constexpr int HBYTES = NHALO * 32, WBYTES = TPSD * NB * 32;
+    static constexpr size_t LDS_BYTES_DMA = (size_t)HBYTES + 2 * WBYTES;           // 68 864 B at NT = 2: two workgroups per CU
 };
 }  // namespace v2
 
-template <int NT, bool IN16, bool OUT16>
+// DMA = true (bf16 input tensors only): the operands are byte copies of global memory, so both are filled by LDS-DMA
+// instead of through registers, and the halo of input-channel chunk c + 1 streams into a second buffer while chunk c is
+// multiplied (with register staging the kernel spent a third of a launch waiting for the halo and weight loads of the
+// chunk it was about to multiply: tools/bf16_ablate.py).  An LDS-DMA image is lane-linear, so the 48-byte padded rows
+// become 32-byte rows and the bank spread comes from a swizzle on the SOURCE side instead: the two 16-byte halves of a
+// halo row are swapped where bit 1 of the row's plane index is set, of a weight row where bit 3 of its output channel
+// is set (both maps verified conflict-free for ds_read_b128's 16-lane groups: tests/test_swizzle_maps.py).  vmcnt
+// retires in order per wave, so the two streams are issued by different waves: waves 0-3 copy the weight stage one
+// stage ahead (L2-warm, lands within a stage) and wait for it at every stage barrier; waves 4-7 copy the next chunk's
+// halo and wait once per chunk.
+template <int NT, bool IN16, bool OUT16, bool DMA = false>
 __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     const void* __restrict__ x_, const u16* __restrict__ w, void* __restrict__ z_,
     float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
@@ -380,6 +410,89 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     const float* xb = reinterpret_cast<const float*>(x_) + (IN16 ? 0 : (size_t)b * D * H * W * Cin);
     const u16* xb16 = reinterpret_cast<const u16*>(x_) + (IN16 ? (size_t)b * D * H * W * Cin : 0);
 
+    if constexpr (DMA) {
+        static_assert(IN16, "the DMA form copies bf16 tensors");
+        using namespace dma;
+        constexpr int HBYTES = v2::Cfg<NT>::HBYTES, WBYTES = v2::Cfg<NT>::WBYTES;
+        constexpr int MT2B = 4 * HH * HW * 32;                 // bytes to the wave's second M-tile (planes 4-7)
+        const unsigned lds0 = lds_addr(smem_raw);
+        const bool wrole = wave < 4;
+        const int rt = tid & 255;                              // thread index inside its role
+        // fragment addresses: a halo row keeps channels 8 (hd >> 1 & 1) .. first; plane hd = (l31 & 3) + kd (+ 4)
+        const int pd = l31 & 3;
+        const int a_vox = ((pd * HH + wave) * HW + (l31 >> 2)) * 32;
+        int a_kd[3];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd) a_kd[kd] = a_vox + ((hsel ^ (((pd + kd) >> 1) & 1)) * 16);
+        const int b_row = l31 * 32 + ((hsel ^ ((l31 >> 3) & 1)) * 16);
+        // copy descriptors.  Halo: piece e = rt + 256 i is LDS bytes 16 e .. of the buffer: row e / 2, half e % 2, which
+        // holds channel group (e % 2) ^ (hd >> 1 & 1).  Weights: piece e is row e / 2 = tap * NB + co, channel group
+        // (e % 2) ^ (co >> 3 & 1).
+        constexpr int TPSD = v2::Cfg<NT>::TPSD, NSTD = v2::Cfg<NT>::NSTD;
+        constexpr int HQ = (NHALO * 2 + 255) / 256;            // 8
+        constexpr int WQ = (TPSD * NB * 2 + 255) / 256;        // 5 | 3
+        // the descriptors are recomputed per copy (a handful of integer operations per 16 bytes, on waves that would
+        // otherwise idle at the barrier): keeping them in registers costs the NT = 2 kernel its 128-register fit
+        auto issue_h = [&](int c0) {                           // waves 4-7
+            const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (wave - 4) * 1024);
+            int rt_ = rt;
+            asm volatile("" : "+v"(rt_));                      // (or the optimiser hoists all of it out of the chunk loop)
+#pragma unroll
+            for (int i = 0; i < HQ; ++i) {
+                const int e = rt_ + i * 256, hp = e >> 1;
+                const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
+                const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+                const int ch = c0 + 8 * ((e & 1) ^ ((hd >> 1) & 1));
+                const bool ok = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W && ch < Cin;
+                const void* src = ok ? (const void*)(xb16 + ((gd * H + gh) * W + gw) * Cin + ch) : (const void*)tmf_zero16;
+                if (e < NHALO * 2) glds16(src, base + i * 4096);
+            }
+        };
+        auto issue_w = [&](int c0, int st, int wbuf) {         // waves 0-3
+            const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + HBYTES + wbuf * WBYTES + wave * 1024);
+            const u16* ws = w + (size_t)st * TPSD * Cout * Cin;
+            int rt_ = rt;
+            asm volatile("" : "+v"(rt_));
+#pragma unroll
+            for (int i = 0; i < WQ; ++i) {
+                const int e = rt_ + i * 256, row = e >> 1;
+                const int tp = row / NB, col = row % NB;
+                const int ch = c0 + 8 * ((e & 1) ^ ((col >> 3) & 1));
+                const bool ok = n0 + col < Cout && ch < Cin;
+                const void* src = ok ? (const void*)(ws + (tp * Cout + n0 + col) * Cin + ch) : (const void*)tmf_zero16;
+                if (e < TPSD * NB * 2) glds16(src, base + i * 4096);
+            }
+        };
+        if (wrole) issue_w(0, 0, 0);
+        int par = 0;                                           // parity of the chunk index: 3 stages flip the weight ring
+        for (int c0 = 0; c0 < Cin; c0 += CINC, par ^= 1) {
+            if (c0 > 0) __syncthreads();                       // the halo of the previous chunk is read out
+            if (!wrole) { issue_h(c0); dma_wait(); }
+#pragma unroll
+            for (int st = 0; st < NSTD; ++st) {
+                const int wb = (st & 1) ^ par;
+                if (wrole) dma_wait();                         // this wave's share of stage st has landed ...
+                __syncthreads();                               // ... everybody's has (and the halo), and stage st - 1 is read out
+                if (wrole) {
+                    if (st + 1 < NSTD) issue_w(c0, st + 1, wb ^ 1);
+                    else if (c0 + CINC < Cin) issue_w(c0 + CINC, 0, wb ^ 1);
+                }
+                const unsigned char* wsb = smem_raw + HBYTES + wb * WBYTES + b_row;
+#pragma unroll
+                for (int tp = 0; tp < TPSD; ++tp) {                                                    // kh = tp / 3, kw = tp % 3
+                    const unsigned char* ap = smem_raw + ((st * HH + tp / 3) * HW + tp % 3) * 32 + a_kd[st];   // kd = st
+                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap);
+                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + MT2B);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(wsb + (tp * NB + j * 32) * 32);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0][j], 0, 0, 0);
+                        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    } else {
     // halo pieces of 16 B: bf16 tensors 2 per position (8 channels each), fp32 tensors 4 per position (4 channels each)
     constexpr int PPP = IN16 ? 2 : 4;                         // pieces per position
     constexpr int PSH = IN16 ? 1 : 2;
@@ -473,6 +586,8 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
             }
         }
     }
+
+    }   // register-staged form
 
     // ---- epilogue: NDHWC store (fp32, or bf16 as channel-pair dwords) + BatchNorm statistic partials ----
     float s1[NT], s2[NT];
@@ -1016,20 +1131,8 @@ __device__ __forceinline__ bf16x8 tr8(const unsigned char* p) {      // voxels 0
     const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, v);
 }
-// LDS-DMA of 16 bytes per lane: LDS byte = lds_wave_base (wave-uniform LDS address) + 16 * lane.  Written as inline
-// assembly on purpose: with __builtin_amdgcn_global_load_lds the compiler cannot tell that the copy fills the OTHER
-// buffer and waits vmcnt(0) before the first fragment read of every brick, which serialises copy and multiply (the
-// first build did: 61 us of 240 exposed).  The price is that the compiler does not see the copies at all: the kernel
-// waits for them itself (dma_wait) before the barrier that publishes the buffer.
-__device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "memory");
-}
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
-}
+using namespace dma;
 }  // namespace wtr
-__device__ __attribute__((aligned(16))) const unsigned int tmf_zero16[4] = {0u, 0u, 0u, 0u};
 
 template <int NH, bool IN16>
 __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_tr_kernel(
@@ -1341,7 +1444,8 @@ WgBfPlan plan_wgrad_bf16(int B, int D, int H, int W, int cin, int cout, int io) 
 // tmf_set_option("bf16_v2", 0) / TMF_BF_V2=0 selects the small-brick kernel everywhere, 2 the large-brick kernel
 // everywhere (A/B runs, tests), 1 (default) by the brick count.
 int tmf_g_debug = 0;             // tmf_set_option("debug", bits): timing ablations (results are garbage when set)
-int tmf_g_wgrad_tr = 1;          // tmf_set_option("wgrad_tr", 0 | 1)
+int tmf_g_wgrad_tr = 1;          // tmf_set_option("wgrad_tr", 0 | 1 | 2)
+int tmf_g_bf16_dma = 1;          // tmf_set_option("bf16_dma", 0 | 1): LDS-DMA form of the 8x8x8-brick bf16 forward (bf16 tensors)
 int tmf_g_bf16_v2 = -1;          // tmf_set_option("bf16_v2", 0 | 1 | 2); -1 = not set yet: TMF_BF_V2 or 1
 static bool use_v2(int B, int D, int H, int W) {
     if (tmf_g_bf16_v2 < 0) { const char* e = getenv("TMF_BF_V2"); tmf_g_bf16_v2 = e == nullptr ? 1 : atoi(e); }
@@ -1368,7 +1472,9 @@ extern "C" const char* tmf_conv3d_fwd_bf16_kernel_name(int B, int D, int H, int 
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return "?";
     const char* i16 = (io & 1) ? "true" : "false";
     const char* o16 = (io & 2) ? "true" : "false";
-    if (use_v2(B, D, H, W)) snprintf(buf, sizeof buf, "conv3d_fwd_bf16_v2_kernel<%d, %s, %s>", cout > 32 ? 2 : 1, i16, o16);
+    if (use_v2(B, D, H, W))
+        snprintf(buf, sizeof buf, "conv3d_fwd_bf16_v2_kernel<%d, %s, %s, %s>", cout > 32 ? 2 : 1, i16, o16,
+                 ((io & 1) && tmf_g_bf16_dma) ? "true" : "false");
     else {
         static const bool nt2 = [] { const char* e = getenv("TMF_BF_NT2"); return e == nullptr || atoi(e) != 0; }();
         snprintf(buf, sizeof buf, "conv3d_fwd_bf16_kernel<%d, %s, %s>", (nt2 && cout % 64 == 0) ? 2 : 1, i16, o16);
@@ -1393,19 +1499,22 @@ extern "C" int tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z,
     if (use_v2(B, D, H, W)) {
         const int tD = tmf_cdiv(D, v2::TD), tH = tmf_cdiv(H, v2::TH), tW = tmf_cdiv(W, v2::TW);
         const int ntiles = B * tD * tH * tW;
-#define TMF_BF2_LAUNCH(NT, I16, O16)                                                                                 \
+#define TMF_BF2_LAUNCH(NT, I16, O16, DMA_)                                                                           \
     do {                                                                                                             \
-        auto k = conv3d_fwd_bf16_v2_kernel<NT, I16, O16>;                                                            \
-        if ((rc = tmf_allow_lds(k, v2::Cfg<NT>::LDS_BYTES, "tmf_conv3d_fwd_bf16"))) return rc;                       \
-        hipLaunchKernelGGL(k, dim3(ntiles, tmf_cdiv(cout, 32 * NT)), dim3(v2::NTHR), v2::Cfg<NT>::LDS_BYTES, s, x,    \
+        auto k = conv3d_fwd_bf16_v2_kernel<NT, I16, O16, DMA_>;                                                      \
+        const size_t ldsb = DMA_ ? v2::Cfg<NT>::LDS_BYTES_DMA : v2::Cfg<NT>::LDS_BYTES;                              \
+        if ((rc = tmf_allow_lds(k, ldsb, "tmf_conv3d_fwd_bf16"))) return rc;                                         \
+        hipLaunchKernelGGL(k, dim3(ntiles, tmf_cdiv(cout, 32 * NT)), dim3(v2::NTHR), ldsb, s, x,                      \
                            (const u16*)w_bf16, z, stat_partial, D, H, W, cin, cout, tD, tH, tW, ntiles, tmf_g_debug); \
     } while (0)
 #define TMF_BF2_IO(NT)                                                                                               \
     do {                                                                                                             \
-        if (io == 0) TMF_BF2_LAUNCH(NT, false, false);                                                               \
-        else if (io == 1) TMF_BF2_LAUNCH(NT, true, false);                                                           \
-        else if (io == 2) TMF_BF2_LAUNCH(NT, false, true);                                                           \
-        else TMF_BF2_LAUNCH(NT, true, true);                                                                         \
+        if (io == 0) TMF_BF2_LAUNCH(NT, false, false, false);                                                        \
+        else if (io == 1 && tmf_g_bf16_dma) TMF_BF2_LAUNCH(NT, true, false, true);                                   \
+        else if (io == 1) TMF_BF2_LAUNCH(NT, true, false, false);                                                    \
+        else if (io == 2) TMF_BF2_LAUNCH(NT, false, true, false);                                                    \
+        else if (tmf_g_bf16_dma) TMF_BF2_LAUNCH(NT, true, true, true);                                               \
+        else TMF_BF2_LAUNCH(NT, true, true, false);                                                                  \
     } while (0)
         if (cout > 32) TMF_BF2_IO(2);
         else TMF_BF2_IO(1);

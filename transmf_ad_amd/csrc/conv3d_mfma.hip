@@ -1566,6 +1566,11 @@ extern "C" int tmf_set_option(const char* name, int value) {
         tmf_g_bf16_v2 = value;
         return TMF_OK;
     }
+    if (strcmp(name, "bf16_dma") == 0) {
+        TMF_REQUIRE(value == 0 || value == 1, TMF_E_ARG, "tmf_set_option: bf16_dma must be 0 or 1, got %d", value);
+        tmf_g_bf16_dma = value;
+        return TMF_OK;
+    }
     if (strcmp(name, "wgrad_tr") == 0) {
         TMF_REQUIRE(value >= 0 && value <= 2, TMF_E_ARG, "tmf_set_option: wgrad_tr must be 0, 1 or 2, got %d", value);
         tmf_g_wgrad_tr = value;
