@@ -53,7 +53,7 @@ def test_bf16_large_brick_kernels_fit_128_registers(kernels):
     and no scratch in the bf16-tensor variants that configs[2] uses (the fp32-tensor NT = 2 variant is allowed its few
     spilled halo offsets: 36 B per lane, touched once per 16-channel chunk)."""
     ks = _find(kernels, "conv3d_bf16.o", "conv3d_fwd_bf16_v2_kernel")
-    assert len(ks) == 8
+    assert len(ks) == 12                            # 2 NT x 4 tensor-type pairs, + the LDS-DMA form of the 4 bf16-input ones
     for k in ks:
         assert k["vgpr"] <= 128, k
         if "ILi2ELb0E" not in k["name"]:
