@@ -458,6 +458,45 @@ def test_full_size_conv_properties():
     assert abs(a - b) <= 1e-6 * scale and abs(a - c) <= 1e-6 * scale, (a, b, c, scale)
 
 
+def test_full_size_bf16_conv_properties():
+    """configs[2]-size layer (conv2.3 at 128^3 input: 8 x 64^3, 32 -> 64 channels, bf16 tensors) through size-independent
+    properties, no oracle: (i) the two forms of the large-brick forward kernel (register-staged, LDS-DMA) accumulate in
+    the same order: bit-identical outputs and statistics; (ii) exact homogeneity under a power-of-two scale; (iii) the
+    two weight-gradient kernels (register transpose, LDS transposing reads) agree to fp32 summation order; (iv)
+    adjointness <dz, conv(x, w)> == <wgrad(x, dz), w> == <dgrad(dz, w), x> with bf16-exact operands."""
+    ops = _ops()
+    from transmf_ad_amd import _lib
+    B, S, cin, cout = 8, 64, 32, 64
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x = torch.randn((B, S, S, S, cin), device=DEV, generator=g).bfloat16()
+    dz = torch.randn((B, S, S, S, cout), device=DEV, generator=g).bfloat16()
+    w = (torch.randn((cout, cin, 3, 3, 3), device=DEV, generator=g) * (27 * cin) ** -0.5).bfloat16().float()
+    wf, wd = ops.pack_weight_bf16(w), ops.pack_weight_dgrad_bf16(w)
+    try:
+        _lib.call("tmf_set_option", b"bf16_dma", 0)
+        z0, p0, _ = ops.conv3d_bf16_raw(x, wf, cin, cout, True, out_bf16=False)
+        _lib.call("tmf_set_option", b"bf16_dma", 1)
+        z, part, _ = ops.conv3d_bf16_raw(x, wf, cin, cout, True, out_bf16=False)
+        assert torch.equal(z, z0) and torch.equal(part, p0)
+        z4, _, _ = ops.conv3d_bf16_raw(x * 4.0, wf, cin, cout, False, out_bf16=False)
+        assert torch.equal(z4, z * 4.0)
+        _lib.call("tmf_set_option", b"wgrad_tr", 0)
+        dw0 = ops.conv3d_wgrad_bf16(x, dz, cin, cout)
+        _lib.call("tmf_set_option", b"wgrad_tr", 1)
+        dwt = ops.conv3d_wgrad_bf16(x, dz, cin, cout)
+    finally:
+        _lib.call("tmf_set_option", b"bf16_dma", 1)
+        _lib.call("tmf_set_option", b"wgrad_tr", 1)
+    assert _relerr(dwt, dw0.cpu()) < 2e-6
+    dw = ops.unpack_wgrad(dwt, cout, cin, 3)
+    dx, _, _ = ops.conv3d_bf16_raw(dz, wd, cout, cin, False, out_bf16=False)
+    a = (dz.double() * z.double()).sum().item()
+    b = (dw.double() * w.double()).sum().item()
+    c = (dx.double() * x.double()).sum().item()
+    scale = (dz.double().abs() * z.double().abs()).sum().item()
+    assert abs(a - b) <= 1e-6 * scale and abs(a - c) <= 1e-6 * scale, (a, b, c, scale)
+
+
 BF16_SHAPES = [
     # B, D, H, W, cin, cout
     (2, 8, 8, 8, 8, 16),
