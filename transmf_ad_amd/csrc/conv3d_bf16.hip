@@ -429,38 +429,56 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
         // holds channel group (e % 2) ^ (hd >> 1 & 1).  Weights: piece e is row e / 2 = tap * NB + co, channel group
         // (e % 2) ^ (co >> 3 & 1).
         constexpr int TPSD = v2::Cfg<NT>::TPSD, NSTD = v2::Cfg<NT>::NSTD;
-        constexpr int HQ = (NHALO * 2 + 255) / 256;            // 8
+        // Copy descriptors.  The kernel is ISSUE-bound (PMC: 6.7 vector instructions per MFMA; a 32-cycle MFMA slot hides
+        // about five other issues), so the pieces are laid out to need almost no arithmetic per copy:
+        //  * halo: one instruction per halo PLANE - thread rt < 200 of the role copies piece rt of the plane's 10 rows x
+        //    10 voxels x 2 halves (LDS bytes 16 (200 hd + rt): lane-linear).  Row / column / half of a thread never
+        //    change: in-plane offset and validity are computed once; the plane's validity and base are scalars, the
+        //    swizzle bit (hd >> 1 & 1) is a compile-time constant of the unrolled plane loop.
+        //  * weights: piece e = rt + 256 i is row e / 2 = tap * NB + co, half e % 2: column, half and tap-in-instruction
+        //    of a thread never change either; a stage / chunk / instruction step is a scalar offset.
+        constexpr int PPL = HH * HW * 2;                       // 200 pieces per halo plane
         constexpr int WQ = (TPSD * NB * 2 + 255) / 256;        // 5 | 3
-        // the descriptors are recomputed per copy (a handful of integer operations per 16 bytes, on waves that would
-        // otherwise idle at the barrier): keeping them in registers costs the NT = 2 kernel its 128-register fit
+        // (one register set for both roles: a wave is a halo copier or a weight copier for the whole kernel)
+        int r_off, r_q8, r_tp = 0;
+        bool r_ok;
+        if (wrole) {
+            const int col = (rt >> 1) % NB;
+            r_tp = (rt >> 1) / NB;
+            r_ok = n0 + col < Cout;
+            r_q8 = 8 * ((rt & 1) ^ ((col >> 3) & 1));
+            r_off = (r_tp * Cout + n0 + col) * Cin + r_q8;
+        } else {
+            const int hh = rt / (HW * 2), hw = (rt % (HW * 2)) >> 1;
+            const int gh = h0 + hh - 1, gw = w0 + hw - 1;
+            r_ok = rt < PPL && gh >= 0 && gh < H && gw >= 0 && gw < W;
+            r_q8 = 8 * (rt & 1);
+            r_off = (gh * W + gw) * Cin + r_q8;            // channel group q; the swapped planes use r_off ^ 8
+        }
+        constexpr int TPI = 256 / (2 * NB);                    // taps per copy instruction: 2 | 4
         auto issue_h = [&](int c0) {                           // waves 4-7
             const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (wave - 4) * 1024);
-            int rt_ = rt;
-            asm volatile("" : "+v"(rt_));                      // (or the optimiser hoists all of it out of the chunk loop)
+            const bool ch_ok0 = c0 + r_q8 < Cin, ch_ok1 = c0 + (r_q8 ^ 8) < Cin;
 #pragma unroll
-            for (int i = 0; i < HQ; ++i) {
-                const int e = rt_ + i * 256, hp = e >> 1;
-                const int hw = hp % HW, hh = (hp / HW) % HH, hd = hp / (HW * HH);
-                const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
-                const int ch = c0 + 8 * ((e & 1) ^ ((hd >> 1) & 1));
-                const bool ok = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W && ch < Cin;
-                const void* src = ok ? (const void*)(xb16 + ((gd * H + gh) * W + gw) * Cin + ch) : (const void*)tmf_zero16;
-                if (e < NHALO * 2) glds16(src, base + i * 4096);
+            for (int hd = 0; hd < v2::HD; ++hd) {
+                const int gd = d0 + hd - 1;                    // scalar
+                const bool pl_ok = gd >= 0 && gd < D;
+                const bool sw = (hd >> 1) & 1;                 // compile-time
+                const bool ok = r_ok && pl_ok && (sw ? ch_ok1 : ch_ok0);
+                const u16* plane = xb16 + (size_t)gd * H * W * Cin + c0;
+                const void* src = ok ? (const void*)(plane + (sw ? (r_off ^ 8) : r_off)) : (const void*)tmf_zero16;
+                if (rt < PPL) glds16(src, base + hd * (PPL * 16));
             }
         };
         auto issue_w = [&](int c0, int st, int wbuf) {         // waves 0-3
             const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + HBYTES + wbuf * WBYTES + wave * 1024);
-            const u16* ws = w + (size_t)st * TPSD * Cout * Cin;
-            int rt_ = rt;
-            asm volatile("" : "+v"(rt_));
+            const u16* ws = w + (size_t)st * TPSD * Cout * Cin + c0;
+            const bool ok0 = r_ok && c0 + r_q8 < Cin;
 #pragma unroll
             for (int i = 0; i < WQ; ++i) {
-                const int e = rt_ + i * 256, row = e >> 1;
-                const int tp = row / NB, col = row % NB;
-                const int ch = c0 + 8 * ((e & 1) ^ ((col >> 3) & 1));
-                const bool ok = n0 + col < Cout && ch < Cin;
-                const void* src = ok ? (const void*)(ws + (tp * Cout + n0 + col) * Cin + ch) : (const void*)tmf_zero16;
-                if (e < TPSD * NB * 2) glds16(src, base + i * 4096);
+                const bool in_stage = i * TPI + TPI <= TPSD || i * TPI + r_tp < TPSD;      // the last instruction is half empty
+                const void* src = (ok0 && in_stage) ? (const void*)(ws + (size_t)i * TPI * Cout * Cin + r_off) : (const void*)tmf_zero16;
+                if (in_stage) glds16(src, base + i * 4096);
             }
         };
         if (wrole) issue_w(0, 0, 0);
