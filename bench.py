@@ -274,7 +274,9 @@ def main():
                     help="ad: model_ad (headline); cnn: model_CNN_ad; single: model_single (MRI only) — BASELINE configs[4]")
     ap.add_argument("--eval", action="store_true",
                     help="time the reference's val_step instead (eval mode, no_grad forward + CE; kfold_train_adversarial.py:144-161)")
-    ap.add_argument("--no-fused-adam", action="store_true")
+    ap.add_argument("--no-fused-adam", action="store_true", help="torch.optim.Adam(fused=False)")
+    ap.add_argument("--torch-adam", action="store_true",
+                    help="torch.optim.Adam(fused=True) (~10 launches) instead of the one-launch tmf_adam_step")
     ap.add_argument("--from-host", action="store_true",
                     help="feed every step from HOST memory: raw volumes staged in pinned buffers, copied on a side stream "
                          "(double-buffered) and scaled / flipped on the device (transmf_ad_amd.pipeline, the device form of "
@@ -322,9 +324,14 @@ def main():
         net = GradAllReduce(net)
     if world > 1:
         net = GradAllReduce(net)
-    # same update rule as the reference's getOptimizer (utils/utils.py:38-39: Adam, lr 1e-4, wd 0), multi-tensor form
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=args.graph and world == 1,
-                           fused=not args.graph and not args.no_fused_adam)
+    # same update rule as the reference's getOptimizer (utils/utils.py:38-39: Adam, lr 1e-4, wd 0): every parameter
+    # tensor in ONE launch (transmf_ad_amd.optim.Adam -> tmf_adam_step); --torch-adam: torch's multi-tensor form
+    if args.torch_adam or args.graph or args.no_fused_adam:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=args.graph and world == 1,
+                               fused=not args.graph and not args.no_fused_adam)
+    else:
+        from transmf_ad_amd.optim import Adam as OneLaunchAdam
+        opt = OneLaunchAdam(net.parameters(), lr=1e-4)
     crit = nn.CrossEntropyLoss()
     B, S = args.batch, args.size
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -526,6 +533,8 @@ def main():
                                ("zero_grad+fwd+loss+bwd+allreduce+Adam" if args.no_item_sync or args.model == "single" else
                                 "zero_grad+fwd+loss+2x loss.item()+bwd+allreduce+Adam (kfold_train_adversarial.py:101-136)"),
                        "dispatch": mode,
+                       "optimizer": type(opt).__module__ + "." + type(opt).__name__ +
+                                    (" (one launch: tmf_adam_step)" if type(opt).__module__.startswith("transmf_ad_amd") else ""),
                        "input": ("host: raw volumes -> pinned staging -> H2D on a copy stream (double-buffered) -> device "
                                  f"ScaleIntensity + RandFlip(0.3), every step (PCIe-inclusive); {2 * B * vol[0] * vol[1] * vol[2] * 4 / 1e6:.1f} "
                                  f"MB per step over a host link measured at {h2d_gbps:.1f} GB/s pinned -> device on this box"

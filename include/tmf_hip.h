@@ -450,6 +450,20 @@ int    tmf_heads_bwd(const tmf_heads_desc* d, const float* cls, const float* mas
                      float* d_cls, float* d_mri_tok, float* d_pet_tok, float revgrad_alpha,
                      void* scratch, size_t scratch_bytes, void* stream);
 
+/* ---- optimizer step: torch.optim.Adam over ALL parameter tensors in one launch --------------------------------------
+ * reference: kfold_train_adversarial.py:135 (optimizer.step()), utils/utils.py:38-39 (Adam, lr 1e-4, weight decay 0).
+ * params[i] / grads[i]: device pointers of tensor i (numel[i] contiguous floats); grads[i] == NULL skips the tensor, as
+ * torch does for a parameter without a gradient.  exp_avg / exp_avg_sq: the two moment estimates of ALL tensors in two
+ * flat caller-owned buffers of tmf_adam_state_elems(n, numel) floats, zero before the first step (tensor i's slice
+ * starts at the sum of the preceding numel, each rounded up to a multiple of 4).  step: the update count INCLUDING this
+ * one (1 on the first call).  weight_decay is torch's L2 form (added to the gradient).  n <= TMF_ADAM_MAX_TENSORS per
+ * call (the tensor table is a kernel argument); larger sets take several calls with their own state slices. */
+#define TMF_ADAM_MAX_TENSORS 160
+long   tmf_adam_state_elems(int n, const long* numel);
+int    tmf_adam_step(int n, float* const* params, const float* const* grads, const long* numel,
+                     float* exp_avg, float* exp_avg_sq, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -912,3 +912,44 @@ def test_one_launch_heads_are_taken_by_default_and_with_real_dropout():
         a = net(mri, pet)
         b = net(mri, pet)
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_one_launch_adam_matches_torch_adam():
+    """transmf_ad_amd.optim.Adam (tmf_adam_step: every parameter tensor in one launch) against torch.optim.Adam on the same
+    model and gradients, three steps: parameters and both moment estimates agree to fp32 round-off; a parameter without a
+    gradient is left alone (and keeps its own step count); the state_dict loads into torch.optim.Adam and back."""
+    import copy
+    import transmf_ad_amd as T
+    g = Golden("ad_tiny")
+    net_a = build(g)
+    net_b = copy.deepcopy(net_a)
+    opt_a = T.optim.Adam(net_a.parameters(), lr=1e-3)
+    opt_b = torch.optim.Adam(net_b.parameters(), lr=1e-3)
+    frozen = "fc_cls.8.bias"
+    for it in range(3):
+        # identical gradients on both sides: take them from net_b's backward and copy
+        step(net_b, g, train=True)
+        for (ka, pa), (kb, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+            pa.grad = None if (ka == frozen and it == 0) else pb.grad.clone()
+            if kb == frozen and it == 0:
+                pb.grad = None
+        opt_a.step(); opt_b.step()
+        for (k, pa), (_k, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+            err = (pa - pb).abs().max().item() / max(pb.abs().max().item(), 1e-30)
+            assert err <= 2e-6, (it, k, err)
+        for pb_ in net_b.parameters():
+            pb_.grad = None
+    sa, sb = opt_a.state, opt_b.state
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        assert float(sa[pa]["step"]) == float(sb[pb]["step"])
+        for key in ("exp_avg", "exp_avg_sq"):
+            ref = sb[pb][key]
+            assert (sa[pa][key] - ref).abs().max().item() <= 2e-6 * max(ref.abs().max().item(), 1e-30) + 1e-12
+    # checkpoint interchange
+    opt_c = torch.optim.Adam(net_a.parameters(), lr=1e-3)
+    opt_c.load_state_dict(opt_a.state_dict())
+    opt_d = T.optim.Adam(net_a.parameters(), lr=1e-3)
+    opt_d.load_state_dict(opt_c.state_dict())
+    for pa in net_a.parameters():
+        assert torch.equal(opt_d.state[pa]["exp_avg"], opt_a.state[pa]["exp_avg"])
+        assert float(opt_d.state[pa]["step"]) == float(opt_a.state[pa]["step"])

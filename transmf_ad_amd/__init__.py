@@ -12,6 +12,7 @@ from .gradient_reversal import GradientReversal, revgrad            # noqa: F401
 from .mymodel import model_ad, model_CNN_ad, model_single           # noqa: F401
 from .ops import get_conv_precision, set_activation_storage, set_conv_precision   # noqa: F401
 from .pipeline import DevicePrefetcher, scale_intensity_flip         # noqa: F401
+from . import optim                                                  # noqa: F401
 from .networks import (Attention, CrossTransformer_MOD_AVG, FeedForward, PreNorm,   # noqa: F401
                        Transformer, sNet)
 

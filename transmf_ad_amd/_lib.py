@@ -166,7 +166,10 @@ PROTOTYPES.update({
     "tmf_heads_fwd": (_i, [C.POINTER(HeadsDesc), _p, _p, _p, _p, _p, C.POINTER(HeadsParams), _p, _p, _p, _p, _z, _p]),
     "tmf_heads_bwd": (_i, [C.POINTER(HeadsDesc), _p, _p, _p, C.POINTER(HeadsParams), _p, _z, _p, _p, _p,
                            C.POINTER(HeadsGrads), _p, _p, _p, _f, _p, _z, _p]),
+    "tmf_adam_state_elems": (_l, [_i, C.POINTER(_l)]),
+    "tmf_adam_step": (_i, [_i, C.POINTER(_p), C.POINTER(_p), C.POINTER(_l), _p, _p, _d, _d, _d, _d, _d, _i, _p]),
 })
+ADAM_MAX_TENSORS = 160
 
 _lib = None
 

@@ -1,0 +1,103 @@
+"""Adam with the whole update in ONE launch (csrc/adam.hip, tmf_adam_step).
+
+reference: utils/utils.py:38-39 (getOptimizer -> torch.optim.Adam(net.parameters(), lr=1e-4, betas default, weight decay 0)),
+stepped once per train step at kfold_train_adversarial.py:135.  Same constructor arguments, update rule and skipping of
+parameters without a gradient as torch.optim.Adam (amsgrad / maximize / capturable / foreach are not offered); the
+moment estimates of a parameter group live in two flat buffers, `state_dict()` exposes them per parameter in torch's
+layout (`step`, `exp_avg`, `exp_avg_sq` views) so a checkpoint loads into torch.optim.Adam and back.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError(f"invalid Adam hyper-parameters lr={lr} betas={betas} eps={eps} weight_decay={weight_decay}")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self._flat = {}                      # id(group) -> (exp_avg, exp_avg_sq, offsets, numel array, param pointer array)
+
+    def _group_state(self, group):
+        st = self._flat.get(id(group))
+        if st is not None:
+            return st
+        ps = group["params"]
+        if not ps:
+            return None
+        dev = ps[0].device
+        for p in ps:
+            if p.dtype != torch.float32 or p.device != dev or not p.is_cuda or not p.is_contiguous():
+                raise _lib.TmfError("transmf_ad_amd.optim.Adam: parameters must be contiguous float32 tensors on one HIP device")
+        chunks = []
+        for s in range(0, len(ps), _lib.ADAM_MAX_TENSORS):
+            sub = ps[s:s + _lib.ADAM_MAX_TENSORS]
+            numel = (C.c_long * len(sub))(*[p.numel() for p in sub])
+            total = _lib.query("tmf_adam_state_elems", len(sub), numel)
+            m = torch.zeros(total, device=dev, dtype=torch.float32)
+            v = torch.zeros(total, device=dev, dtype=torch.float32)
+            off, offs = 0, []
+            for p in sub:
+                offs.append(off)
+                off += (p.numel() + 3) & ~3
+            pptr = (C.c_void_p * len(sub))(*[p.data_ptr() for p in sub])
+            chunks.append((sub, m, v, offs, numel, pptr))
+            for p, o in zip(sub, offs):          # torch's per-parameter layout, as views of the flat buffers
+                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m[o:o + p.numel()].view_as(p),
+                                 "exp_avg_sq": v[o:o + p.numel()].view_as(p)}
+        self._flat[id(group)] = chunks
+        return chunks
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            chunks = self._group_state(group)
+            if not chunks:
+                continue
+            b1, b2 = group["betas"]
+            for sub, m, v, _offs, numel, pptr in chunks:
+                grads, steps = [], []
+                for i, p in enumerate(sub):
+                    if p.data_ptr() != pptr[i]:
+                        pptr[i] = p.data_ptr()                      # parameter storage replaced (e.g. by .to())
+                    g = p.grad
+                    if g is None:
+                        grads.append(None); steps.append(None)
+                        continue
+                    if g.is_sparse or g.dtype != torch.float32 or g.device != p.device:
+                        raise _lib.TmfError("transmf_ad_amd.optim.Adam: gradients must be dense float32 on the parameter's device")
+                    grads.append(g if g.is_contiguous() else g.contiguous())
+                    st = self.state[p]
+                    st["step"] += 1
+                    steps.append(int(st["step"].item()))              # a CPU scalar: no device sync
+                # one launch per distinct step count (one, unless some parameter sat out earlier steps: the bias
+                # correction is per parameter in torch)
+                for step in sorted({s_ for s_ in steps if s_ is not None}):
+                    gptr = (C.c_void_p * len(sub))(*[g.data_ptr() if (g is not None and s_ == step) else None
+                                                     for g, s_ in zip(grads, steps)])
+                    with torch.cuda.device(m.device):
+                        _lib.call("tmf_adam_step", len(sub), pptr, gptr, numel, m.data_ptr(), v.data_ptr(), float(group["lr"]),
+                                  float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step,
+                                  torch.cuda.current_stream().cuda_stream)
+        return loss
+
+    def load_state_dict(self, state_dict):
+        """torch's loader replaces the per-parameter state tensors: copy them back into the flat buffers the kernel uses."""
+        super().load_state_dict(state_dict)
+        self._flat = {}
+        loaded = {p: dict(st) for p, st in self.state.items()}
+        for group in self.param_groups:
+            for sub, m, v, offs, _numel, _pptr in self._group_state(group) or ():
+                for p, o in zip(sub, offs):
+                    old = loaded.get(p)
+                    if old and "exp_avg" in old:
+                        m[o:o + p.numel()].copy_(old["exp_avg"].reshape(-1))
+                        v[o:o + p.numel()].copy_(old["exp_avg_sq"].reshape(-1))
+                        self.state[p]["step"] = torch.as_tensor(float(old.get("step", 0.0))).cpu()
