@@ -265,6 +265,27 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
     void* ws = sc + p.off_ws;
     hipStream_t s = (hipStream_t)stream;
     const bool b16 = d->precision == TMF_PREC_BF16;
+    // a bias ahead of a batch-statistics BatchNorm has an exactly-zero gradient (the reference returns noise): one fill
+    // when the caller laid the bias gradients out back to back (ops.SNetTrain does), one per block otherwise
+    bool bias_filled = false;
+    {
+        float* first = nullptr;
+        const float* expect = nullptr;
+        size_t total = 0;
+        bool contiguous = true;
+        for (int l = 0; l < NL; ++l) {
+            if (g->dbias[l] == nullptr) continue;
+            if (first == nullptr) first = g->dbias[l];
+            else if (g->dbias[l] != expect) contiguous = false;
+            expect = g->dbias[l] + p.L[l].cout;
+            total += (size_t)p.L[l].cout;
+        }
+        if (first != nullptr && contiguous) {
+            hipError_t e = hipMemsetAsync(first, 0, total * 4, s);
+            TMF_REQUIRE(e == hipSuccess, (int)e, "tmf_snet_train_bwd: memset failed: %s", hipGetErrorString(e));
+            bias_filled = true;
+        }
+    }
     const void* go = dout;              // gradient w.r.t. the current block's output
     for (int l = NL - 1; l >= 0; --l) {
         const LayerPlan& L = p.L[l];
@@ -274,8 +295,7 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
         const void* wd = base + L.off_wd;
         const void* z = base + L.off_z;
         const double count = (double)d->B * L.D * L.H * L.W;
-        if (g->dbias[l] != nullptr) {
-            // a bias ahead of a batch-statistics BatchNorm has an exactly-zero gradient (the reference returns noise)
+        if (g->dbias[l] != nullptr && !bias_filled) {
             hipError_t e = hipMemsetAsync(g->dbias[l], 0, (size_t)L.cout * 4, s);
             TMF_REQUIRE(e == hipSuccess, (int)e, "tmf_snet_train_bwd: memset failed: %s", hipGetErrorString(e));
         }

@@ -538,12 +538,11 @@ class SNetTrain(torch.autograd.Function):
         dout = _chk(dout, "grad_output")
         sizes = [0 if s is None else s.numel() for s in ctx.shapes]
         flat = torch.empty(sum(sizes), device=vol.device, dtype=_f32)        # all 28 gradients in one allocation
-        parts = flat.split(sizes)
-        grads = [None if s is None else (t if len(s) == 1 else t.view(s)) for t, s in zip(parts, ctx.shapes)]
-        ptr, o = [], flat.data_ptr()
-        for n in sizes:
-            ptr.append(o)
-            o += 4 * n
+        # the seven conv-bias gradients (exact zeros) sit back to back at the end: the library fills them with one memset
+        order = [i for i in range(len(sizes)) if i % 4 != 1] + [i for i in range(len(sizes)) if i % 4 == 1]
+        parts = dict(zip(order, flat.split([sizes[i] for i in order])))
+        grads = [None if s is None else (parts[i] if len(s) == 1 else parts[i].view(s)) for i, s in enumerate(ctx.shapes)]
+        ptr = [parts[i].data_ptr() for i in range(len(sizes))]
         g = _lib.SnetGrads()
         need = ctx.needs_input_grad
         for l in range(7):
