@@ -15,7 +15,7 @@ import re
 ap = argparse.ArgumentParser()
 ap.add_argument("csv")
 ap.add_argument("--last-ms", type=float, default=0.0, help="window = the last N ms of the trace")
-ap.add_argument("--steps", type=int, default=8, help="window = the last N train steps (delimited by the fused-Adam launches)")
+ap.add_argument("--steps", type=int, default=8, help="window = the last N train steps (delimited by the Adam launches)")
 ap.add_argument("--top", type=int, default=25)
 a = ap.parse_args()
 
@@ -28,8 +28,8 @@ if a.last_ms > 0:
     t_end = max(r[1] for r in rows)
     t0 = t_end - int(a.last_ms * 1e6)
 else:
-    # step boundaries: the end of each group of FusedAdam launches (groups are > 1 ms apart)
-    adam = [r for r in rows if "FusedAdam" in r[2]]
+    # step boundaries: the end of each group of Adam launches (torch FusedAdam or adam_step_kernel) (groups are > 1 ms apart)
+    adam = [r for r in rows if "FusedAdam" in r[2] or "adam_step_kernel" in r[2]]
     ends = []
     for r in adam:
         if ends and r[0] - ends[-1] < 1_000_000:
