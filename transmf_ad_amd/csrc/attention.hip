@@ -11,6 +11,12 @@
 // leaves the registers.  Keys stream in chunks of 128 with an online softmax, the score
 // matrix is never materialised (networks.py:169-173 materialises (B,h,N,N)).
 //
+// Round 2: a workgroup is 4 waves = 2 row tiles x 2 SPLITS of the streamed side (key chunks in the forward and dQ, query
+// tiles in dK/dV).  At 216 / 512 tokens a launch is only 224 / 512 row tiles for the chip's 1 024 SIMDs and a wave's
+// serial chain (MFMAs + softmax arithmetic, one wave per SIMD) is the critical path: splitting it puts every tile on two
+// SIMDs (the two splits of a tile are adjacent waves, i.e. different SIMDs of the CU).  The two partial results of a tile
+// are merged through LDS (online-softmax merge in the forward, plain sums in the backward), in a fixed order.
+//
 // Replaces, at /root/reference/models/networks.py:166-174: the three rearranges, einsum
 // 'bhid,bhjd->bhij' * scale, Softmax(dim=-1), einsum 'bhij,bhjd->bhid' and their backward.
 #include "tmf_common.h"
@@ -85,7 +91,8 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_fwd_kernel(   // 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int ksp = wave & 1;                                // which half of the key chunks this wave takes
+    const int q0 = (blockIdx.x * 2 + (wave >> 1)) * 32;
     const float* qb = q + (size_t)b * N * q_stride;
     const float* kb = k + (size_t)b * M * kv_stride;
     const float* vb = v + (size_t)b * M * kv_stride;
@@ -103,6 +110,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_fwd_kernel(   // 
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
+    int chunk = 0;                                           // key chunks are dealt out alternately
 
     for (int sb0 = 0; sb0 < M; sb0 += sb) {
         const int nrows = (M - sb0) < sb ? (M - sb0) : sb;
@@ -113,6 +121,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_fwd_kernel(   // 
         __syncthreads();
         if (q0 < N) {
             for (int kt0 = 0; kt0 < nrows_pad / 32; kt0 += KC) {
+                if ((chunk++ & 1) != ksp) continue;
                 f32x16 sT[KC];
                 float mx = m_run;
 #pragma unroll
@@ -159,6 +168,31 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_fwd_kernel(   // 
             }
         }
     }
+    // merge the two key halves of a query tile: (o, m, l) of the second through LDS (the panels are dead by now)
+    constexpr int XW = 16 * DT + 2;
+    __syncthreads();
+    float* xch = smem + ((wave >> 1) * 64 + lane) * XW;
+    if (ksp == 1) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[dt * 16 + r] = o[dt][r];
+        xch[16 * DT] = m_run;
+        xch[16 * DT + 1] = l_run;
+    }
+    __syncthreads();
+    if (ksp == 1) return;
+    {
+        const float m1 = xch[16 * DT], l1 = xch[16 * DT + 1];
+        const float mx = fmaxf(m_run, m1);                   // this half always holds chunk 0: finite
+        const float a0 = exp2f(m_run - mx), a1 = exp2f(m1 - mx);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] = o[dt][r] * a0 + xch[dt * 16 + r] * a1;
+        l_run = l_run * a0 + l1 * a1;
+        m_run = mx;
+    }
     const int qi = q0 + l31;
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     if (qi < N) {
@@ -191,7 +225,8 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_bwd_dq_kernel(
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const int ksp = wave & 1;                                // which half of the key tiles this wave takes
+    const int q0 = (blockIdx.x * 2 + (wave >> 1)) * 32;
     const int qi = q0 + l31;
     const float* qb = q + (size_t)b * N * q_stride;
     const float* kb = k + (size_t)b * M * kv_stride;
@@ -227,7 +262,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_bwd_dq_kernel(
         stage_rows<DH>(Vs, vb, kv_stride, h * DH, sb0, nrows_pad, M, tid, 256);
         __syncthreads();
         if (q0 < N) {
-            for (int kt = 0; kt < nrows_pad / 32; ++kt) {
+            for (int kt = ksp; kt < nrows_pad / 32; kt += 2) {
                 f32x16 sT, dpT;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { sT[r] = 0.f; dpT[r] = 0.f; }
@@ -243,6 +278,23 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_bwd_dq_kernel(
                 for (int dt = 0; dt < DT; ++dt) mma_cols<DH>(dqT[dt], Ks, kt * 32, sT, dt, l31, hsel);
             }
         }
+    }
+    // sum the two key halves of a query tile through LDS (the panels are dead by now)
+    __syncthreads();
+    {
+        float* xch = smem + ((wave >> 1) * 64 + lane) * (16 * DT);
+        if (ksp == 1) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[dt * 16 + r] = dqT[dt][r];
+        }
+        __syncthreads();
+        if (ksp == 1) return;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dqT[dt][r] += xch[dt * 16 + r];
     }
     if (qi < N) {
         float* ob = dq + ((size_t)b * N + qi) * inner + h * DH;
@@ -275,7 +327,8 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_bwd_dkv_kernel(
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hsel = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.y, b = blockIdx.z;
-    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    const int ksp = wave & 1;                                // which half of the query tiles this wave takes
+    const int k0 = (blockIdx.x * 2 + (wave >> 1)) * 32;
     const int ki = k0 + l31;
     const float* qb = q + (size_t)b * N * q_stride;
     const float* kb = k + (size_t)b * M * kv_stride;
@@ -322,7 +375,7 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_bwd_dkv_kernel(
         }
         __syncthreads();
         if (k0 < M) {
-            for (int qt = 0; qt < nrows_pad / 32; ++qt) {
+            for (int qt = ksp; qt < nrows_pad / 32; qt += 2) {
                 f32x16 s, dp;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
@@ -342,6 +395,23 @@ __global__ __launch_bounds__(256, DH <= 32 ? 2 : 1) void xattn_bwd_dkv_kernel(
                 }
             }
         }
+    }
+    // sum the two query halves of a key tile through LDS (the panels are dead by now)
+    __syncthreads();
+    {
+        float* xch = smem + ((wave >> 1) * 64 + lane) * (32 * DT);
+        if (ksp == 1) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { xch[dt * 32 + r] = dkT[dt][r]; xch[dt * 32 + 16 + r] = dvT[dt][r]; }
+        }
+        __syncthreads();
+        if (ksp == 1) return;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dkT[dt][r] += xch[dt * 32 + r]; dvT[dt][r] += xch[dt * 32 + 16 + r]; }
     }
     if (ki < M) {
         float* dkb = dk + ((size_t)b * M + ki) * dkv_stride + h * DH;
@@ -367,8 +437,15 @@ int resident_rows(int n, int dh) {
     const int need = (n + 31) & ~31;
     return need < cap ? need : cap;
 }
-size_t lds_two(int sb, int dh) { return (size_t)(2 * (sb + 1) * (dh + 1) + 64) * 4; }
-size_t lds_dkv(int sb, int dh) { return (size_t)(2 * (sb + 1) * (dh + 1) + 2 * sb + 64) * 4; }
+// panels, or the merge area of the two splits (2 row tiles x 64 lanes x the accumulators of a lane) if that is larger
+size_t lds_two(int sb, int dh) {
+    const size_t panels = (size_t)(2 * (sb + 1) * (dh + 1) + 64) * 4, merge = (size_t)2 * 64 * (16 * ((dh + 31) / 32) + 2) * 4;
+    return panels > merge ? panels : merge;
+}
+size_t lds_dkv(int sb, int dh) {
+    const size_t panels = (size_t)(2 * (sb + 1) * (dh + 1) + 2 * sb + 64) * 4, merge = (size_t)2 * 64 * (32 * ((dh + 31) / 32)) * 4;
+    return panels > merge ? panels : merge;
+}
 
 int check_attn(const char* fn, int B, int heads, int N, int M, int dh, int q_stride, int kv_stride) {
     TMF_REQUIRE(B > 0 && heads > 0 && N > 0 && M > 0, TMF_E_SHAPE, "%s: non-positive dimension", fn);
@@ -399,7 +476,7 @@ extern "C" int tmf_xattn_fwd(const float* q, const float* k, const float* v, flo
     TMF_REQUIRE((heads * dh) % 4 == 0, TMF_E_SHAPE, "tmf_xattn_fwd: heads*dh must be a multiple of 4");
     const int sb = resident_rows(M, dh);
     const size_t lds = lds_two(sb, dh);
-    dim3 grid(tmf_cdiv(N, 128), heads, B), block(256);
+    dim3 grid(tmf_cdiv(N, 64), heads, B), block(256);
 #define CALL(DH)                                                                                     \
     auto kf = xattn_fwd_kernel<DH>;                                                                  \
     if ((rc = tmf_allow_lds(kf, lds, "tmf_xattn_fwd"))) return rc;                                   \
@@ -429,10 +506,10 @@ extern "C" int tmf_xattn_bwd(const float* q, const float* k, const float* v, con
     auto k2 = xattn_bwd_dkv_kernel<DH>;                                                                   \
     if ((rc = tmf_allow_lds(k1, lds_q, "tmf_xattn_bwd"))) return rc;                                      \
     if ((rc = tmf_allow_lds(k2, lds_kv, "tmf_xattn_bwd"))) return rc;                                     \
-    hipLaunchKernelGGL(k1, dim3(tmf_cdiv(N, 128), heads, B), dim3(256), lds_q, s, q, k, v, out, lse, dout, dq, \
+    hipLaunchKernelGGL(k1, dim3(tmf_cdiv(N, 64), heads, B), dim3(256), lds_q, s, q, k, v, out, lse, dout, dq, \
                        heads, N, M, q_stride, kv_stride, scale, sbk);                                     \
     if ((rc = tmf_launch_result("tmf_xattn_bwd(dq)"))) return rc;                                         \
-    hipLaunchKernelGGL(k2, dim3(tmf_cdiv(M, 128), heads, B), dim3(256), lds_kv, s, q, k, v, out, lse, dout, dk, dv, \
+    hipLaunchKernelGGL(k2, dim3(tmf_cdiv(M, 64), heads, B), dim3(256), lds_kv, s, q, k, v, out, lse, dout, dk, dv, \
                        heads, N, M, q_stride, kv_stride, dkv_stride, scale, sbq);
     TMF_DH_SWITCH(dh, CALL)
 #undef CALL
