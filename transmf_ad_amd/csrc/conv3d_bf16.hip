@@ -465,7 +465,7 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
                 const bool pl_ok = gd >= 0 && gd < D;
                 const bool sw = (hd >> 1) & 1;                 // compile-time
                 const bool ok = r_ok && pl_ok && (sw ? ch_ok1 : ch_ok0);
-                const u16* plane = xb16 + (size_t)gd * H * W * Cin + c0;
+                const u16* plane = xb16 + (ptrdiff_t)gd * H * W * Cin + c0;     // (gd = -1 or D: never dereferenced)
                 const void* src = ok ? (const void*)(plane + (sw ? (r_off ^ 8) : r_off)) : (const void*)tmf_zero16;
                 if (rt < PPL) glds16(src, base + hd * (PPL * 16));
             }
