@@ -117,8 +117,8 @@ __global__ __launch_bounds__(HT) void token_mean_kernel(const float* __restrict_
     }
 }
 
-// fc_cls.0 / .1 / .2 / .3 on H1 / 64 workgroups: 64 output features per workgroup, 8 threads per feature split K in
-// interleaved 16-byte pieces (the 8 threads of a feature read 128 contiguous bytes of its weight row per step; all of a
+// fc_cls.0 / .1 / .2 / .3 on H1 / 32 workgroups: 32 output features per workgroup, 16 threads per feature split K in
+// interleaved 16-byte pieces (the 16 threads of a feature read 256 contiguous bytes of its weight row per step; all of a
 // thread's loads are in flight at once).  A feature's batch column ends up in one thread: BatchNorm1d is register-local.
 __global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
     extern __shared__ float lds[];
@@ -126,14 +126,14 @@ __global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
     const SavedPlan sp = saved_plan(B, a.dim, a.H1, a.H2, a.HD);
     for (int e = t; e < B * a.C4; e += HT) lds[e] = a.cls[e];
     __syncthreads();
-    const int j = blockIdx.x * 64 + (t >> 3), part = t & 7;
+    const int j = blockIdx.x * 32 + (t >> 4), part = t & 15;
     float acc[MAXB], y[MAXB];
 #pragma unroll
     for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
     if (j < a.H1) {
         const float* wr = a.w0 + (size_t)j * a.C4;
 #pragma unroll 8
-        for (int k = part * 4; k < a.C4; k += 32) {
+        for (int k = part * 4; k < a.C4; k += 64) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
 #pragma unroll
             for (int b = 0; b < MAXB; ++b)
@@ -149,6 +149,7 @@ __global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
         acc[b] += __shfl_xor(acc[b], 1);
         acc[b] += __shfl_xor(acc[b], 2);
         acc[b] += __shfl_xor(acc[b], 4);
+        acc[b] += __shfl_xor(acc[b], 8);
     }
     if (j < a.H1 && part == 0) {
         const float bias = a.b0[j];
@@ -180,10 +181,13 @@ __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
     float* l_v = l_a2 + B * a.H2;                // [2][B][dim]
     float* l_r = l_v + 2 * B * a.dim;            // [2][B][HD]  (ReLU output of D's hidden layer)
     float* l_st = l_r + 2 * B * a.HD;            // [2][HD][2]  batch mean / unbiased var of the two D calls
+    // two workgroups, two independent chains: block 0 = fc_cls.4 .. fc_cls.8 (logits), block 1 = D on both token means
+    const bool fc_role = blockIdx.x == 0;
     // ---- token means (token_mean_kernel) and the first hidden layer's output (heads_fc0_kernel) from `saved` ----
-    for (int e = t; e < 2 * B * a.dim; e += HT) l_v[e] = a.saved[sp.v + e];
-    for (int e = t; e < B * a.H1; e += HT) l_a1[e] = a.saved[sp.a1 + e];
+    if (fc_role) { for (int e = t; e < B * a.H1; e += HT) l_a1[e] = a.saved[sp.a1 + e]; }
+    else { for (int e = t; e < 2 * B * a.dim; e += HT) l_v[e] = a.saved[sp.v + e]; }
     __syncthreads();
+    if (fc_role) {
     // ---- fc_cls.4 / .5 / .6 / .7 : 8 threads per output feature split K ----
     for (int j0 = 0; j0 < a.H2; j0 += HT / 8) {
         const int j = j0 + (t >> 3), part = t & 7;
@@ -231,24 +235,49 @@ __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
                 }
         }
     }
-    // ---- D.0 / .1 / .2 on both token means (independent of the fc_cls chain above) ----
-    for (int e = t; e < 2 * a.HD; e += HT) {
-        const int j = e % a.HD, m = e / a.HD;
+        // ---- fc_cls.8 (its small weight matrix staged in LDS: l_a1 is free by now) ----
+        __syncthreads();
+        float* l_w8 = l_a1;                         // [NC][H2]
+        for (int e = t; e < a.NC * a.H2; e += HT) l_w8[e] = a.w8[e];
+        __syncthreads();
+        for (int e = t; e < B * a.NC; e += HT) {
+            const int c = e % a.NC, b = e / a.NC;
+            float s = a.b8[c];
+            for (int k = 0; k < a.H2; ++k) s = fmaf(l_w8[c * a.H2 + k], l_a2[b * a.H2 + k], s);
+            a.logits[e] = s;
+        }
+        return;
+    }
+    // ---- D.0 / .1 / .2 on both token means: 2 threads per (call, output feature) split K ----
+    for (int e0 = 0; e0 < 2 * a.HD; e0 += HT / 2) {
+        const int e = e0 + (t >> 1), part = t & 1;
+        const bool live = e < 2 * a.HD;
+        const int j = live ? e % a.HD : 0, m = live ? e / a.HD : 0;
         float acc[MAXB], y[MAXB];
-        const float bias = a.db0[j];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) acc[b] = bias;
-        const float* wr = a.dw0 + (size_t)j * a.dim;
+        for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+        if (live) {
+            const float* wr = a.dw0 + (size_t)j * a.dim;
+            const int kper = a.dim / 2;                       // dim % 8 == 0: whole float4s
 #pragma unroll 8
-        for (int k = 0; k < a.dim; k += 4) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
+            for (int k = part * kper; k < (part + 1) * kper; k += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b)
-                if (b < B) {
-                    const float* x = l_v + (m * B + b) * a.dim + k;
-                    acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
-                    acc[b] = fmaf(w[2], x[2], acc[b]); acc[b] = fmaf(w[3], x[3], acc[b]);
-                }
+                for (int b = 0; b < MAXB; ++b)
+                    if (b < B) {
+                        const float* x = l_v + (m * B + b) * a.dim + k;
+                        acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
+                        acc[b] = fmaf(w[2], x[2], acc[b]); acc[b] = fmaf(w[3], x[3], acc[b]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) acc[b] += __shfl_xor(acc[b], 1);
+        if (!live || part != 0) continue;
+        {
+            const float bias = a.db0[j];
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) acc[b] += bias;
         }
         // batch statistics of THIS call; the running buffers are updated below, MRI call first, then PET
         float mean = 0.f, q = 0.f;
@@ -284,18 +313,10 @@ __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
             a.drm1[j] = rm;
             a.drv1[j] = rv;
         }
-    // ---- the three output layers (their small weight matrices staged in LDS: l_a1 is free by now) ----
-    float* l_w8 = l_a1;                         // [NC][H2]
-    float* l_w3 = l_a1 + a.NC * a.H2;           // [NC][HD]
-    for (int e = t; e < a.NC * a.H2; e += HT) l_w8[e] = a.w8[e];
+    // ---- D.3 (its small weight matrix staged in LDS: l_a1 is unused by this block) ----
+    float* l_w3 = l_a1;                         // [NC][HD]
     for (int e = t; e < a.NC * a.HD; e += HT) l_w3[e] = a.dw3[e];
     __syncthreads();
-    for (int e = t; e < B * a.NC; e += HT) {
-        const int c = e % a.NC, b = e / a.NC;
-        float s = a.b8[c];
-        for (int k = 0; k < a.H2; ++k) s = fmaf(l_w8[c * a.H2 + k], l_a2[b * a.H2 + k], s);
-        a.logits[e] = s;
-    }
     for (int e = t; e < 2 * B * a.NC; e += HT) {
         const int c = e % a.NC, b = (e / a.NC) % B, m = e / (a.NC * B);
         float s = a.db3[c];
@@ -344,26 +365,36 @@ __device__ __forceinline__ void bn1d_relu_bwd(float (&dr)[MAXB], const float* xh
         if (b < B) dr[b] = training ? k * (dr[b] - sg / B - xh[b] * (sx / B)) : k * dr[b];
 }
 
-__global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a) {
+// Roles by workgroup: blocks 0 .. nA-1 run the fc_cls chain (every one recomputes the small fc_cls.8 / BatchNorm1d(H2) part,
+// block 0 stores its results; then block i takes H1 / nA of the fc_cls.4 / BatchNorm1d(H1) features, 8 j-slices per feature
+// so that a thread's chain of dependent weight loads is H2 / 8 long instead of H2); blocks nA .. nA + ND - 1 run the D path
+// (every one recomputes the small D.3 / BatchNorm1d(HD) part, the first stores its results; block q takes the q-th j-range
+// of the D.0 backward and writes its partial of the token-mean gradient, summed by heads_bwd_outer_kernel).
+constexpr int ND = 4;
+__global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
     extern __shared__ float lds[];
     const HeadsArgs& f = a.f;
     const int t = threadIdx.x;
     const int B = f.B;
     const SavedPlan sp = saved_plan(B, f.dim, f.H1, f.H2, f.HD);
     const bool tr = f.training != 0;
+    const int blk = blockIdx.x;
+    const bool d_role = blk >= nA, first = blk == 0 || blk == nA;
+    const int dq = blk - nA;                             // D role: which j-range of D.0
     float* l_dz1 = lds;                       // [B][H1]
     float* l_dz2 = l_dz1 + B * f.H1;          // [B][H2]
     float* l_dzD = l_dz2 + B * f.H2;          // [2][B][HD]
     float* l_dv = l_dzD + 2 * B * f.HD;       // [2][B][dim]
     float* l_x = l_dv + 2 * B * f.dim;        // [B][max(C4, H1)]  cls, later reused
+    if (!d_role) {
     // ---- fc_cls.8 backward, then through Dropout / ReLU / BatchNorm1d(H2) ----
-    for (int e = t; e < f.NC * f.H2; e += HT) {          // dW8[c][k] = sum_b dlogits[b][c] a2[b][k]
+    for (int e = t; first && e < f.NC * f.H2; e += HT) { // dW8[c][k] = sum_b dlogits[b][c] a2[b][k]
         const int k = e % f.H2, c = e / f.H2;
         float s = 0.f;
         for (int b = 0; b < B; ++b) s = fmaf(a.d_logits[b * f.NC + c], f.saved[sp.a2 + b * f.H2 + k], s);
         a.gw8[e] = s;
     }
-    for (int c = t; c < f.NC; c += HT) {
+    for (int c = t; first && c < f.NC; c += HT) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += a.d_logits[b * f.NC + c];
         a.gb8[c] = s;
@@ -379,38 +410,67 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a) {
         float dg, db;
         bn1d_relu_bwd(dr, f.saved + sp.xh2 + j, f.H2, f.mask2 ? f.mask2 + j : nullptr, B, tr, f.g5[j], f.be5[j],
                       f.saved[sp.is2 + j], dg, db);
-        a.gg5[j] = dg;
-        a.gbe5[j] = db;
         float sb = 0.f;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dz2[b * f.H2 + j] = dr[b]; a.s_dz2[b * f.H2 + j] = dr[b]; sb += dr[b]; }
-        a.gb4[j] = sb;
+        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dz2[b * f.H2 + j] = dr[b]; sb += dr[b]; }
+        if (first) {
+            a.gg5[j] = dg;
+            a.gbe5[j] = db;
+            a.gb4[j] = sb;
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) if (b < B) a.s_dz2[b * f.H2 + j] = dr[b];
+        }
     }
     __syncthreads();
     // ---- fc_cls.4 backward: da1[b][k] = sum_j dz2[b][j] W4[j][k]  (dW4 = dz2^T a1: heads_bwd_outer_kernel) ----
-    for (int k = t; k < f.H1; k += HT) {
+    //      this block's features k in chunks of 64: thread = (feature t & 63, j-slice t >> 6), partials through LDS
+    float* l_part = l_x;                                 // [8][B][64]
+    const int kper = (f.H1 + nA - 1) / nA;
+    const int kbeg = blk * kper, kend = kbeg + kper < f.H1 ? kbeg + kper : f.H1;
+    for (int kc = kbeg; kc < kend; kc += 64) {
+        const int kk = t & 63, sl = t >> 6, k = kc + kk;
+        const int jper = (f.H2 + 7) / 8;
+        const int j0 = sl * jper, j1 = j0 + jper < f.H2 ? j0 + jper : f.H2;
         float dr[MAXB];
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) dr[b] = 0.f;
+        if (k < kend) {
 #pragma unroll 8
-        for (int j = 0; j < f.H2; ++j) {
-            const float w = f.w4[(size_t)j * f.H1 + k];
+            for (int j = j0; j < j1; ++j) {
+                const float w = f.w4[(size_t)j * f.H1 + k];
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) if (b < B) dr[b] = fmaf(l_dz2[b * f.H2 + j], w, dr[b]);
+                for (int b = 0; b < MAXB; ++b) if (b < B) dr[b] = fmaf(l_dz2[b * f.H2 + j], w, dr[b]);
+            }
         }
-        float dg, db;
-        bn1d_relu_bwd(dr, f.saved + sp.xh1 + k, f.H1, f.mask1 ? f.mask1 + k : nullptr, B, tr, f.g1[k], f.be1[k],
-                      f.saved[sp.is1 + k], dg, db);
-        a.gg1[k] = dg;
-        a.gbe1[k] = db;
-        float sb = 0.f;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dz1[b * f.H1 + k] = dr[b]; a.s_dz1[b * f.H1 + k] = dr[b]; sb += dr[b]; }
-        a.gb0[k] = sb;
+        for (int b = 0; b < MAXB; ++b) if (b < B) l_part[(sl * B + b) * 64 + kk] = dr[b];
+        __syncthreads();
+        if (sl == 0 && k < kend) {
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+                if (b < B) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sum += l_part[(q * B + b) * 64 + kk];
+                    dr[b] = sum;
+                }
+            float dg, db;
+            bn1d_relu_bwd(dr, f.saved + sp.xh1 + k, f.H1, f.mask1 ? f.mask1 + k : nullptr, B, tr, f.g1[k], f.be1[k],
+                          f.saved[sp.is1 + k], dg, db);
+            a.gg1[k] = dg;
+            a.gbe1[k] = db;
+            float sb = 0.f;
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) if (b < B) { a.s_dz1[b * f.H1 + k] = dr[b]; sb += dr[b]; }
+            a.gb0[k] = sb;
+        }
+        __syncthreads();
+    }
+    return;
     }
     // (fc_cls.0 backward — dcls = dz1 W0 and dW0 = dz1^T cls — runs on many workgroups: heads_bwd_outer_kernel)
-    // ---- D.3 backward and through ReLU / BatchNorm1d(HD), both calls ----
-    for (int e = t; e < f.NC * f.HD; e += HT) {          // dW3[c][k] = sum_m sum_b dd[m][b][c] r[m][b][k]
+    // ---- the D path (block nA).  D.3 backward and through ReLU / BatchNorm1d(HD), both calls ----
+    for (int e = t; first && e < f.NC * f.HD; e += HT) { // dW3[c][k] = sum_m sum_b dd[m][b][c] r[m][b][k]
         const int k = e % f.HD, c = e / f.HD;
         float s = 0.f;
         for (int m = 0; m < 2; ++m)
@@ -420,7 +480,7 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a) {
             }
         a.gdw3[e] = s;
     }
-    for (int c = t; c < f.NC; c += HT) {
+    for (int c = t; first && c < f.NC; c += HT) {
         float s = 0.f;
         for (int m = 0; m < 2; ++m) for (int b = 0; b < B; ++b) s += a.d_dlog[m][b * f.NC + c];
         a.gdb3[c] = s;
@@ -447,7 +507,7 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a) {
         l_pg[(m * f.HD + j) * 3 + 2] = sb;
     }
     __syncthreads();
-    for (int j = t; j < f.HD; j += HT) {                 // the shared D parameters collect both calls
+    for (int j = t; first && j < f.HD; j += HT) {        // the shared D parameters collect both calls
         a.gdg1[j] = l_pg[j * 3] + l_pg[(f.HD + j) * 3];
         a.gdbe1[j] = l_pg[j * 3 + 1] + l_pg[(f.HD + j) * 3 + 1];
         a.gdb0[j] = l_pg[j * 3 + 2] + l_pg[(f.HD + j) * 3 + 2];
@@ -467,8 +527,10 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a) {
                 v[q] = b < B ? f.saved[sp.v + (m * B + b) * f.dim + i] : 0.f;
                 dv[q] = 0.f;
             }
-            const int jper = (f.HD + NS - 1) / NS;
-            const int j0 = sl * jper, j1 = j0 + jper < f.HD ? j0 + jper : f.HD;
+            const int jblk = (f.HD + ND - 1) / ND;          // this block's j-range, NS thread slices inside it
+            const int jb0 = dq * jblk, jb1 = jb0 + jblk < f.HD ? jb0 + jblk : f.HD;
+            const int jper = (jblk + NS - 1) / NS;
+            const int j0 = jb0 + sl * jper, j1 = j0 + jper < jb1 ? j0 + jper : jb1;
 #pragma unroll 8
             for (int j = j0; j < j1; ++j) {
                 const float w = f.dw0[(size_t)j * f.dim + i];
@@ -494,28 +556,29 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a) {
         for (int e = t; e < 2 * B * f.dim; e += HT) {   // broadcast over the tokens: heads_bwd_outer_kernel
             float sum = 0.f;
             for (int q = 0; q < NS; ++q) sum += l_dvp[q * 2 * B * f.dim + e];
-            a.s_dv[e] = sum;
+            a.s_dv[(size_t)dq * 2 * B * f.dim + e] = sum;
         }
     }
 }
 
 // The wide parts of the backward on many workgroups:
-//   blocks [0, nbc)        : dcls[b][k] = sum_j dz1[b][j] W0[j][k]        (64 columns per block, 8 j-slices)
+//   blocks [0, nbc)        : dcls[b][k] = sum_j dz1[b][j] W0[j][k]        (32 columns per block, 16 j-slices)
 //   next nb0 blocks        : dW0[j][k] = sum_b dz1[b][j] cls[b][k]        (8 rows j per block, a thread per column k)
 //   next nb4 blocks        : dW4[j][k] = sum_b dz2[b][j] a1[b][k]
 //   the rest               : mean over tokens + gradient reversal: d tok[m][b][n][c] = -alpha * dv[m][b][c] / N
 __global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int nb0, int nb4, int nbc) {
-    __shared__ float part[8][MAXB][64];
+    __shared__ float part[16][MAXB][32];
     const HeadsArgs& f = a.f;
     const int t = threadIdx.x, B = f.B;
     int blk = blockIdx.x;
     if (blk < nbc) {
-        // dcls[b][k] = sum_j dz1[b][j] W0[j][k]: 64 columns per workgroup, 8 j-slices of H1 / 8 rows each
-        const int kk = t & 63, sl = t >> 6, k = blk * 64 + kk;
+        // dcls[b][k] = sum_j dz1[b][j] W0[j][k]: 32 columns per workgroup, 16 j-slices of H1 / 16 rows each (a thread's
+        // chain of dependent weight loads is what this launch waits for)
+        const int kk = t & 31, sl = t >> 5, k = blk * 32 + kk;
         float dc[MAXB];
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) dc[b] = 0.f;
-        const int jper = (f.H1 + 7) / 8;
+        const int jper = (f.H1 + 15) / 16;
         const int j0 = sl * jper, j1 = j0 + jper < f.H1 ? j0 + jper : f.H1;
         if (k < f.C4) {
 #pragma unroll 8
@@ -528,13 +591,13 @@ __global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int
 #pragma unroll
         for (int b = 0; b < MAXB; ++b) part[sl][b][kk] = dc[b];
         __syncthreads();
-        for (int e = t; e < B * 64; e += HT) {
-            const int b = e >> 6, c = e & 63;
-            if (blk * 64 + c < f.C4) {
+        for (int e = t; e < B * 32; e += HT) {
+            const int b = e >> 5, c = e & 31;
+            if (blk * 32 + c < f.C4) {
                 float sum = 0.f;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) sum += part[q][b][c];
-                a.d_cls[b * f.C4 + blk * 64 + c] = sum;
+                for (int q = 0; q < 16; ++q) sum += part[q][b][c];
+                a.d_cls[b * f.C4 + blk * 32 + c] = sum;
             }
         }
         return;
@@ -573,7 +636,13 @@ __global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int
         const size_t o = e - m * per;
         const int c = o % f.dim, b = o / ((size_t)f.N * f.dim);              // dim % 4 == 0: the 4 elements share (m, b)
         const float* dv = a.s_dv + ((size_t)m * B + b) * f.dim + c;
-        *reinterpret_cast<f32x4*>(a.d_tok[m] + o) = f32x4{sc * dv[0], sc * dv[1], sc * dv[2], sc * dv[3]};
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < ND; ++q) {                        // the ND j-range partials of heads_bwd_kernel, fixed order
+            const float* dq_ = dv + (size_t)q * 2 * B * f.dim;
+            acc4[0] += dq_[0]; acc4[1] += dq_[1]; acc4[2] += dq_[2]; acc4[3] += dq_[3];
+        }
+        *reinterpret_cast<f32x4*>(a.d_tok[m] + o) = f32x4{sc * acc4[0], sc * acc4[1], sc * acc4[2], sc * acc4[3]};
     }
 }
 
@@ -591,7 +660,8 @@ size_t fwd_lds(const tmf_heads_desc& d) {
 }
 size_t bwd_lds(const tmf_heads_desc& d) {
     const int c4 = 4 * d.dim;
-    const int lx = d.B * (c4 > d.H1 ? c4 : d.H1) > 6 * d.HD ? d.B * (c4 > d.H1 ? c4 : d.H1) : 6 * d.HD;
+    int lx = d.B * (c4 > d.H1 ? c4 : d.H1) > 6 * d.HD ? d.B * (c4 > d.H1 ? c4 : d.H1) : 6 * d.HD;
+    if (lx < 8 * d.B * 64) lx = 8 * d.B * 64;          // the j-slice partials of the fc_cls.4 backward
     return (size_t)(d.B * d.H1 + d.B * d.H2 + 2 * d.B * d.HD + 2 * d.B * d.dim + lx) * 4;
 }
 HeadsArgs make_args(const tmf_heads_desc& d, const float* cls, const float* mri_tok, const float* pet_tok, const float* mask1,
@@ -647,15 +717,15 @@ extern "C" int tmf_heads_fwd(const tmf_heads_desc* d, const float* cls, const fl
     if ((rc = tmf_launch_result("tmf_heads_fwd(token mean)"))) return rc;
     const size_t lds0 = (size_t)d->B * 4 * d->dim * 4;
     if ((rc = tmf_allow_lds(heads_fc0_kernel, lds0, "tmf_heads_fwd(fc0)"))) return rc;
-    hipLaunchKernelGGL(heads_fc0_kernel, dim3(tmf_cdiv(d->H1, 64)), dim3(HT), lds0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(heads_fc0_kernel, dim3(tmf_cdiv(d->H1, 32)), dim3(HT), lds0, (hipStream_t)stream, a);
     if ((rc = tmf_launch_result("tmf_heads_fwd(fc0)"))) return rc;
-    hipLaunchKernelGGL(heads_fwd_kernel, dim3(1), dim3(HT), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(heads_fwd_kernel, dim3(2), dim3(HT), lds, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_heads_fwd");
 }
 
 extern "C" size_t tmf_heads_bwd_scratch_bytes(const tmf_heads_desc* d) {
     if (check_heads("tmf_heads_bwd_scratch_bytes", d) != TMF_OK) return 0;
-    return (size_t)(d->B * d->H1 + d->B * d->H2 + 2 * d->B * d->dim) * 4;
+    return (size_t)(d->B * d->H1 + d->B * d->H2 + ND * 2 * d->B * d->dim) * 4;
 }
 
 extern "C" int tmf_heads_bwd(const tmf_heads_desc* d, const float* cls, const float* mask1, const float* mask2,
@@ -688,13 +758,14 @@ extern "C" int tmf_heads_bwd(const tmf_heads_desc* d, const float* cls, const fl
     const size_t lds = bwd_lds(*d);
     TMF_REQUIRE(lds <= 150 * 1024, TMF_E_SHAPE, "tmf_heads_bwd: %zu B of LDS needed (batch x widths too large)", lds);
     if ((rc = tmf_allow_lds(heads_bwd_kernel, lds, "tmf_heads_bwd"))) return rc;
-    hipLaunchKernelGGL(heads_bwd_kernel, dim3(1), dim3(HT), lds, (hipStream_t)stream, a);
+    const int nA = d->H1 % 64 == 0 ? d->H1 / 64 : 1;              // workgroups of the fc_cls chain (+ one for the D path)
+    hipLaunchKernelGGL(heads_bwd_kernel, dim3(nA + ND), dim3(HT), lds, (hipStream_t)stream, a, nA);
     if ((rc = tmf_launch_result("tmf_heads_bwd"))) return rc;
     const int nb0 = tmf_cdiv(d->H1, 8), nb4 = tmf_cdiv(d->H2, 8);
     int nbt = tmf_cdiv((long)2 * d->B * d->N * d->dim, (long)HT * 4 * 4);
     if (nbt > 256) nbt = 256;
     if (nbt < 1) nbt = 1;
-    const int nbc = tmf_cdiv(4 * d->dim, 64);
+    const int nbc = tmf_cdiv(4 * d->dim, 32);
     hipLaunchKernelGGL(heads_bwd_outer_kernel, dim3(nbc + nb0 + nb4 + nbt), dim3(HT), 0, (hipStream_t)stream, a, nb0, nb4, nbc);
     return tmf_launch_result("tmf_heads_bwd(outer)");
 }
