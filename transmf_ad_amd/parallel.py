@@ -10,8 +10,9 @@ there is no call pattern to mirror; this is sized for the path itself:
   * gradients are packed into a few flat buckets in REVERSE registration order — the order
     backward produces them: heads and fusion transformer first, then conv4 ... conv1 — and
     each bucket's all-reduce is launched asynchronously from a post-accumulate-grad hook the
-    moment its last gradient lands, so the transfers ride under the long conv2/conv1
-    backward kernels.  xGMI is point-to-point (≈153 GB/s per link): a ring over 8 GPUs moves
+    moment its last gradient lands: the heads + fusion bucket rides under the encoders' backward;
+    the encoder buckets start when an encoder's (one-call) backward has been queued and are the
+    exposed tail of the step.  xGMI is point-to-point (≈153 GB/s per link): a ring over 8 GPUs moves
     2*(7/8)*16.7 MB ≈ 29 MB per GPU per step (≈0.2 ms on one link) — few, large buckets keep
     that bandwidth-bound rather than latency-bound;
   * a queued autograd callback waits for the buckets, averages, and re-points ``param.grad`` at views of
