@@ -75,3 +75,63 @@ def test_two_ranks_one_gpu_gradient_average(tmp_path):
         assert torch.equal(a, b)
         want = (l0 + l1) / 2
         assert (a - want).abs().max() <= 1e-6 * max(1.0, want.abs().max().item())
+
+
+def test_deep_block_gradients_carry_an_early_event():
+    """tmf_snet_train_bwd records an event behind the last kernel of blocks conv3.0 .. conv4.3; ops.grad_ready_event finds
+    it for exactly those gradients (and not for conv1 / conv2, nor for a buffer that is not the one of this backward), and
+    behind the event the deep gradients already hold their final values."""
+    from transmf_ad_amd import ops
+    net = _build().train()
+    ops.GRAD_READY_EVENTS.clear()
+    _loss(net, 0).backward()
+    deep = [p for n, p in net.named_parameters() if ".conv3." in n or ".conv4." in n]
+    shallow = [p for n, p in net.named_parameters() if ".conv1." in n or ".conv2." in n]
+    assert len(deep) == 2 * 16 and len(shallow) == 2 * 12
+    evs = [ops.grad_ready_event(p.grad) for p in deep]
+    assert all(e is not None for e in evs) and len({id(e) for e in evs}) == 2          # one event per encoder
+    assert all(ops.grad_ready_event(p.grad) is None for p in shallow)
+    assert all(ops.grad_ready_event(p.grad) is None for n, p in net.named_parameters() if "_cnn." not in n)
+    for e in {id(e): e for e in evs}.values():
+        e.synchronize()
+    early = [p.grad.clone() for p in deep]
+    torch.cuda.synchronize()
+    for a, p in zip(early, deep):
+        assert torch.equal(a, p.grad)
+    assert ops.grad_ready_event(deep[0].grad.clone()) is None                           # another buffer: no event
+    ops.GRAD_READY_EVENTS.clear()
+
+
+def test_bucket_groups_follow_the_deep_shallow_split(tmp_path):
+    """With the wrapper, the deep-block buckets of both encoders wait for their event, not for the producing stream; the
+    shared shallow bucket waits for both encoder streams."""
+    world = 1
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", TMF_DDP_FORCE="1")
+    try:
+        from transmf_ad_amd.parallel import GradAllReduce
+        dist.init_process_group("gloo", rank=0, world_size=world)
+        net = GradAllReduce(_build(), bucket_mb=64.0)
+        names = {p: n for n, p in net.module.named_parameters()}
+        kinds = []
+        for b in net._buckets:
+            ns = [names[p] for p in b.params]
+            kinds.append("deep" if all(".conv3." in n or ".conv4." in n for n in ns) else
+                         "shallow" if all(".conv1." in n or ".conv2." in n for n in ns) else "other")
+        assert kinds == ["other", "deep", "shallow", "deep"], kinds
+        seen = {}
+        orig = net._launch
+
+        def spy(b):
+            seen[id(b)] = (len(b.events), len(b.streams))
+            return orig(b)
+        net._launch = spy
+        net.train()
+        _loss(net, 0).backward()
+        torch.cuda.synchronize()
+        for b, k in zip(net._buckets, kinds):
+            ev, st = seen[id(b)]
+            assert (ev == 1 and st == 0) if k == "deep" else (ev == 0 and st >= 1), (k, ev, st)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        os.environ.pop("TMF_DDP_FORCE", None)

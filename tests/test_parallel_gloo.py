@@ -129,19 +129,25 @@ def _plan_worker(rank, world, port, out_dir):
 
 
 def test_bucket_plan_of_the_benchmark_model(tmp_path):
-    """model_ad(128, 3, 4, 32, 512) has 4 173 060 fp32 parameters = 16.69 MB of gradients; with the default 6 MB
-    cap that is 3 buckets, filled in REVERSE registration order (the order backward produces gradients: heads, fusion
-    transformer, conv4 ... conv1), every parameter in exactly one bucket."""
+    """model_ad(128, 3, 4, 32, 512) has 4 173 060 fp32 parameters = 16.69 MB of gradients, bucketed in REVERSE
+    registration order (the order backward produces gradients: heads, fusion transformer, then the encoders), every parameter
+    in exactly one bucket.  Heads + fusion fill one bucket under the 6 MB cap; each encoder's deep blocks (sNet tags conv3 /
+    conv4: 95 % of its bytes, complete long before the encoder's backward returns, so that bucket starts early) get a
+    bucket of their own and the shallow blocks of BOTH encoders share the last one — 4 buckets."""
     mp.spawn(_plan_worker, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
     r = torch.load(tmp_path / "plan.pt")
     sizes, plan, order = r["sizes"], r["plan"], r["order"]
     assert sum(sizes) == 4173060 * 4 and abs(sum(sizes) / 1e6 - 16.69) < 0.01
-    assert len(sizes) == 3 and all(s <= 6.0 * (1 << 20) + 3.6e6 for s in sizes)        # a bucket closes once it would exceed the cap
+    assert len(sizes) == 4 and all(s <= 6.0 * (1 << 20) + 3.6e6 for s in sizes)        # a bucket closes once it would exceed the cap
     flat = [n for b in plan for n in b]
-    assert flat == list(reversed(order))                                               # reverse registration order, no gaps
-    assert plan[0][0].startswith("D.") and plan[-1][-1] == "mri_cnn.conv1.0.weight"
-    # the LAST bucket is the one that closes latest in backward: it must hold the first-block gradients
-    assert any(n.startswith("mri_cnn.conv1.") for n in plan[-1])
+    assert sorted(flat) == sorted(order) and len(set(flat)) == len(flat)               # every parameter exactly once
+    assert plan[0] == list(reversed(order))[:len(plan[0])] and plan[0][0].startswith("D.")   # heads + fusion: reverse registration order
+    assert all(n.startswith(("pet_cnn.conv3.", "pet_cnn.conv4.")) for n in plan[1]) and len(plan[1]) == 16
+    assert all(n.startswith(("mri_cnn.conv3.", "mri_cnn.conv4.")) for n in plan[3]) and len(plan[3]) == 16
+    assert all(".conv1." in n or ".conv2." in n for n in plan[2]) and len(plan[2]) == 24
+    assert sizes[1] == sizes[3] and sizes[1] / (sizes[1] + sizes[2] / 2) > 0.93
+    # the bucket that closes latest in backward holds the first-block gradients of both encoders
+    assert any(n.startswith("mri_cnn.conv1.") for n in plan[2]) and any(n.startswith("pet_cnn.conv1.") for n in plan[2])
 
 
 def _unused_worker(rank, world, port, out_dir):

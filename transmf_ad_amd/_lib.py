@@ -101,7 +101,8 @@ class SnetParams(C.Structure):
 
 
 class SnetGrads(C.Structure):
-    _fields_ = [("dweight", _p * 7), ("dbias", _p * 7), ("dgamma", _p * 7), ("dbeta", _p * 7)]
+    _fields_ = [("dweight", _p * 7), ("dbias", _p * 7), ("dgamma", _p * 7), ("dbeta", _p * 7), ("deep_event", _p)]
+SNET_DEEP_FROM = 3
 
 
 PROTOTYPES.update({

@@ -339,6 +339,10 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
                                    L.k, stream));
         }
         go = dx;
+        if (l == TMF_SNET_DEEP_FROM && g->deep_event != nullptr) {       // blocks 6 .. l: every gradient is queued behind this point
+            hipError_t e = hipEventRecord((hipEvent_t)g->deep_event, s);
+            TMF_REQUIRE(e == hipSuccess, (int)e, "tmf_snet_train_bwd: hipEventRecord failed: %s", hipGetErrorString(e));
+        }
     }
     return TMF_OK;
 }

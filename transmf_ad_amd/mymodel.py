@@ -55,6 +55,13 @@ def _side_stream(device):
     return _SIDE[key]
 
 
+def backward_streams(device):
+    """The streams, besides the caller's, that a backward of these models runs on (the side stream of _two_streams):
+    what a data-parallel wrapper has to wait for before it reads gradients (parallel.GradAllReduce)."""
+    s = _SIDE.get((device.type, device.index))
+    return [] if s is None else [s]
+
+
 def _tokens(emb):
     """'b d x y z -> b (x y z) d' (mymodel.py:218).  sNet returns a (B, C, d, h, w) VIEW of its
     channels-last buffer, so this is a reshape of strides only — no transpose kernel, no copy."""
@@ -67,6 +74,10 @@ class _FastModeSwitch:
     sub-modules recursively (≈2.5 ms of host time — a quarter of a bf16-mode step here).  The cached list is checked
     against the live tree on every call (every child of every cached module must be cached, and nothing else) and
     rebuilt when a sub-module was added, removed or replaced anywhere below."""
+
+    def tmf_backward_streams(self, device):
+        """parallel.GradAllReduce asks the wrapped module which streams (besides the caller's) its backward uses."""
+        return backward_streams(device)
 
     def _flat(self):
         cache = self.__dict__.get("_flat_modules")

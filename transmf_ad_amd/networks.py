@@ -61,6 +61,10 @@ class sNet(nn.Module):
         self.conv3 = nn.Sequential(*_conv_block(h, h, 3), *_conv_block(h, dim, 3), nn.MaxPool3d(2, stride=2))
         self.conv4 = nn.Sequential(*_conv_block(dim, dim * 2, 3), *_conv_block(dim * 2, dim, 1),
                                    nn.AvgPool3d(2, stride=2))
+        # data-parallel bucketing hint (parallel.GradAllReduce): the gradients of conv3 / conv4 — 95 % of the encoder's bytes —
+        # are complete well before the encoder's backward returns (tmf_snet_grads.deep_event); they get buckets of their own
+        for name, p in self.named_parameters():
+            p.tmf_bucket_group = ("sNet deep", id(self)) if name.startswith(("conv3", "conv4")) else ("sNet shallow",)
 
     @device_guard
     def forward_channels_last(self, vol):

@@ -492,6 +492,24 @@ def snet_eval_one_call(vol, dim, eps, slope, blocks):
     return out
 
 
+# Gradient tensors whose producing kernels finish BEFORE the backward call that produced them returns: data pointer ->
+# (event recorded behind their last kernel, the flat buffer they are views of — held, so that its memory cannot be handed
+# to another tensor while the entry exists).  Filled by SNetTrain.backward for the deep blocks of an encoder, consumed by
+# parallel.GradAllReduce (which then waits for the event instead of for the whole producing stream); dropped at the end of
+# every backward under that wrapper and at the next encoder forward otherwise.
+GRAD_READY_EVENTS = {}
+
+
+def grad_ready_event(grad):
+    """The event behind the last kernel that writes `grad`, if one was recorded for exactly this buffer."""
+    ent = GRAD_READY_EVENTS.get(grad.data_ptr())
+    if ent is None:
+        return None
+    ev, flat = ent
+    same = grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+    return ev if same else None
+
+
 class SNetTrain(torch.autograd.Function):
     """Train-mode sNet forward / backward as ONE library call each (tmf_snet_train_fwd / _bwd: csrc/snet_path.hip): the
     same kernels in the same order as the block-by-block path, every intermediate tensor inside one workspace tensor,
@@ -501,6 +519,7 @@ class SNetTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vol, cfg, buffers, *params):
         import ctypes as C
+        GRAD_READY_EVENTS.clear()               # entries of the previous step's backward (nothing is pending in a forward)
         vol = _chk(vol, "vol")
         dim, momentum, eps, slope = cfg
         B, _, D, H, W = vol.shape
@@ -549,6 +568,16 @@ class SNetTrain(torch.autograd.Function):
             g.dweight[l] = ptr[4 * l] if need[3 + 4 * l] else None
             g.dbias[l] = None if ctx.shapes[4 * l + 1] is None else ptr[4 * l + 1]
             g.dgamma[l], g.dbeta[l] = ptr[4 * l + 2], ptr[4 * l + 3]
+        # an event behind the last kernel of the deep blocks (conv3.0 .. conv4.3): a data-parallel wrapper starts the
+        # all-reduce of their gradients there, under the backward of conv2 / conv1, instead of after this call
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(vol.device))        # (creates the handle; the library re-records it)
+        g.deep_event = ev.cuda_event
+        for l in range(_lib.SNET_DEEP_FROM, 7):
+            for j in range(4):
+                t_ = grads[4 * l + j]
+                if t_ is not None and t_.numel():
+                    GRAD_READY_EVENTS[t_.data_ptr()] = (ev, flat)
         nscr = _lib.query("tmf_snet_bwd_scratch_bytes", C.byref(desc))
         scratch = torch.empty(nscr, device=vol.device, dtype=torch.uint8)
         _lib.call("tmf_snet_train_bwd", C.byref(desc), vol.data_ptr(), saved.data_ptr(), saved.numel(), dout.data_ptr(),

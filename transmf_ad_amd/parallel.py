@@ -11,8 +11,9 @@ there is no call pattern to mirror; this is sized for the path itself:
     backward produces them: heads and fusion transformer first, then conv4 ... conv1 — and
     each bucket's all-reduce is launched asynchronously from a post-accumulate-grad hook the
     moment its last gradient lands: the heads + fusion bucket rides under the encoders' backward;
-    the encoder buckets start when an encoder's (one-call) backward has been queued and are the
-    exposed tail of the step.  xGMI is point-to-point (≈153 GB/s per link): a ring over 8 GPUs moves
+    an encoder's deep blocks (conv3, conv4: 95 % of its bytes) have a bucket of their own that
+    waits for the event tmf_snet_train_bwd records behind them and rides under conv2 / conv1;
+    the shallow blocks of both encoders share the small last bucket.  xGMI is point-to-point (≈153 GB/s per link): a ring over 8 GPUs moves
     2*(7/8)*16.7 MB ≈ 29 MB per GPU per step (≈0.2 ms on one link) — few, large buckets keep
     that bandwidth-bound rather than latency-bound;
   * a queued autograd callback waits for the buckets, averages, and re-points ``param.grad`` at views of
@@ -52,12 +53,15 @@ class _Bucket:
         self.filled = [False] * len(params)
         self.work = None
         self.streams = {}
+        self.events = []
+        self.tagged = all(getattr(p, "tmf_bucket_group", (None,))[0] == "sNet deep" for p in params)
 
     def reset(self):
         self.pending = len(self.params)
         self.filled = [False] * len(self.params)
         self.work = None
         self.streams = {}
+        self.events = []
 
 
 class GradAllReduce(nn.Module):
@@ -86,22 +90,44 @@ class GradAllReduce(nn.Module):
         self._timing_events = []
         # TMF_DDP_FORCE=1 keeps the bucket machinery live in a 1-rank group (to measure its overhead on one GPU)
         self._force = os.environ.get("TMF_DDP_FORCE", "0") == "1"
+        # TMF_DDP_EVENTS=0: every bucket waits for the whole producing stream (no early start of the deep-block buckets)
+        self._early = os.environ.get("TMF_DDP_EVENTS", "1") != "0"
+        self._live = self.world > 1 or self._force
+        # a module that runs parts of its backward on streams of its own says so (`tmf_backward_streams(device)` -> the
+        # streams besides the caller's): the hooks then need not look up the current stream for every gradient
+        self._known_streams = getattr(module, "tmf_backward_streams", None)
         params = [p for p in module.parameters() if p.requires_grad]
         if broadcast_from_rank0 and self.world > 1:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t, 0, group=process_group)
         cap = int(bucket_mb * (1 << 20))
-        cur, cur_bytes = [], 0
+        # Buckets fill in REVERSE registration order (the order backward produces gradients), a new one when the cap would
+        # be exceeded.  A module may tag parameters with `tmf_bucket_group`: tagged parameters only share a bucket with
+        # their own group (which may be spread over the model).  sNet tags its deep blocks (conv3, conv4: 95 % of an
+        # encoder's bytes, complete long before the encoder's backward call returns — ops.GRAD_READY_EVENTS — so their
+        # bucket starts its all-reduce under conv2 / conv1) per encoder, and the shallow blocks of ALL encoders as one group
+        # (one small bucket at the very end instead of one per encoder).
+        plan, sizes, named = [], [], {}
+        cur = None
         for p in reversed(params):
             nbytes = p.numel() * p.element_size()
-            if cur and (cur_bytes + nbytes > cap or p.dtype != cur[0].dtype or p.device != cur[0].device):
-                self._add_bucket(cur)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nbytes
-        if cur:
-            self._add_bucket(cur)
+            gk = getattr(p, "tmf_bucket_group", None)
+            i = cur if gk is None else named.get(gk)
+            if i is not None and (sizes[i] + nbytes > cap or p.dtype != plan[i][0].dtype or p.device != plan[i][0].device):
+                i = None
+            if i is None:
+                plan.append([]); sizes.append(0)
+                i = len(plan) - 1
+            plan[i].append(p)
+            sizes[i] += nbytes
+            if gk is None:
+                cur = i
+            else:
+                named[gk] = i
+                cur = None                       # an untagged run does not continue across tagged parameters
+        for b_ in plan:
+            self._add_bucket(b_)
         for p in params:
             p.register_post_accumulate_grad_hook(self._on_grad)
 
@@ -147,33 +173,65 @@ class GradAllReduce(nn.Module):
         b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p: torch.Tensor):
-        if not self.require_sync or (self.world == 1 and not self._force):
+        # Runs once per parameter in the middle of backward, and the start of backward (heads, fusion: ~100 small
+        # parameters) is launch-bound: every microsecond here is a microsecond of idle GPU.  So a hook only counts; what a
+        # bucket has to wait for is worked out once, when its last gradient lands.
+        if not (self._live and self.require_sync):
             return
-        if not self._callback_queued:
-            self._callback_queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
         b, i = self._where[p]
         if b.filled[i]:
             return
         b.filled[i] = True
         b.pending -= 1
-        if p.grad.is_cuda:
+        if not self._callback_queued:
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        if self._known_streams is None and p.grad.is_cuda:          # a module of unknown stream use: track per gradient
             cur = torch.cuda.current_stream(p.device)
             b.streams[cur.cuda_stream] = cur
-            if b.pending == 0:
-                st = self._staging(p.device)
-                for s_ in b.streams.values():
-                    st.wait_stream(s_)
-                with torch.cuda.stream(st):
-                    self._launch(b)
-                    for q in b.params:
-                        if q.grad is not None:
-                            q.grad.record_stream(st)
-        elif b.pending == 0:
+        if b.pending == 0:
+            self._complete(b, p)
+
+    def _complete(self, b, p):
+        if not p.grad.is_cuda:
             self._launch(b)
+            return
+        dev = p.device
+        st = self._staging(dev)
+        ev = None
+        if self._early and b.tagged:
+            # a tagged bucket's gradients come out of ONE backward call that recorded ONE event behind them (sNet deep
+            # blocks): take the event when the first and the last gradient of the bucket both carry it
+            from . import ops
+            g0, g1 = b.params[0].grad, b.params[-1].grad
+            e0 = ops.grad_ready_event(g0) if g0 is not None else None
+            e1 = ops.grad_ready_event(g1) if g1 is not None else None
+            if e0 is not None and e0 is e1:
+                ev = e0
+        if ev is not None:
+            b.events.append(ev)
+            st.wait_event(ev)
+        else:
+            cur = torch.cuda.current_stream(dev)
+            b.streams[cur.cuda_stream] = cur
+            if self._known_streams is not None:
+                for s_ in self._known_streams(dev):
+                    b.streams[s_.cuda_stream] = s_
+            for s_ in b.streams.values():
+                st.wait_stream(s_)
+        with torch.cuda.stream(st):
+            self._launch(b)
+            for q in b.params:
+                if q.grad is not None:
+                    q.grad.record_stream(st)
 
     def _finalize(self):
         self._callback_queued = False
+        try:
+            from . import ops
+            ops.GRAD_READY_EVENTS.clear()
+        except Exception:                        # pragma: no cover - CPU-only use without the HIP library
+            pass
         dev = self._buckets[0].flat.device
         cuda = dev.type == "cuda"
         st = self._staging(dev) if cuda else None
