@@ -429,7 +429,7 @@ def main():
     # the RCCL communicator / channel set-up on the first collectives (measured: 11.4 ms/step over steps 6-25 against
     # 7.3 ms from step 30 on in the host-bound bf16 mode; 23 vs 17.8 ms with a 1-rank RCCL group).  They run here as
     # set-up, before the W warm-up steps the contract asks for; the GPU-bound fp32 step does not change with them.
-    setup_steps = 30 if args.steps > 0 else 0
+    setup_steps = int(os.environ.get("TMF_BENCH_SETUP_STEPS", "30")) if args.steps > 0 else 0      # (env: profiling runs)
     for _ in range(setup_steps):
         step()
     for _ in range(args.warmup):

@@ -34,6 +34,17 @@ constexpr int NHALO = HD * HH * HW;
 
 enum { MODE_STATS = 0, MODE_FWD = 1, MODE_REDUCE = 2, MODE_WGRAD = 3 };
 
+// bf16 passes: the halo brick lives in LDS as bf16, TWICE — copy c stores element e at index e + c — so that the pair
+// (x[w], x[w + 1]) is one aligned dword for every w (even w: copy 0, odd w: copy 1).  A lane then fetches two taps per
+// ds_read_b32 with no conversion: 9 reads per M-tile instead of 16 fp32 reads + 8 packs.  With the fp32 halo these passes
+// were bound by the LDS port (PMC: half of all LDS cycles bank conflicts; no gather at all: 99 -> 37 us, stats, 128^3).
+// Pitches (dwords) are chosen so that the five lane bits of a fragment row land on five different address bits:
+//   w0 -> copy offset + 1 = 2 (mod 32), w1 -> 1, h0 -> 8, h1 -> 16, d0 -> 100 = 4 (mod 32): conflict-free ds_read_b32.
+constexpr int BROW = 16, BPLANE = 200, BCOPY = 2 * 609;         // elements: row, plane, copy pitch (609 = 19 * 32 + 1 dwords)
+constexpr int NHB_DW = 2 * 609;                                 // dwords of LDS for both copies (copy 1 ends at 609 + 600 + 1)
+static_assert(HD * BPLANE / 2 + 1 <= 609 && HH * BROW <= BPLANE && HW + 2 <= BROW, "bf16 halo layout");
+__device__ __forceinline__ constexpr int brow_off(int r) { return (r / 3) * BPLANE + (r % 3) * BROW; }   // tap row r = 3 dz + dy
+
 __device__ __forceinline__ constexpr int tapoff(int tap) {
     return tap >= 27 ? 0 : ((tap / 9) * HH + (tap / 3) % 3) * HW + tap % 3;
 }
@@ -71,7 +82,8 @@ __device__ __forceinline__ tmf_bf16x8 pack8(const float (&v)[8]) {
 // passes from matrix-bound into LDS / HBM-bound (the opt-in bf16 mode of BASELINE configs[2]).
 template <int MODE, bool BF16, bool P16 = false>     // P16: pooled / dpool are bf16 tensors (bf16 activation storage)
 __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Args a) {   // <= 256 registers: MFMA results in VGPRs (no v_accvgpr_read copies)
-    __shared__ float halo[NHALO];
+    __shared__ float halo[BF16 ? NHB_DW : NHALO];
+    const unsigned hb_base = (unsigned)(size_t)halo;        // LDS byte address of the bf16 copies (BF16)
     __shared__ float red[4 * 32 * 32];      // cross-wave reduction scratch (16 KB)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -83,15 +95,17 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
     const int OD = a.D / 2, OH = a.H / 2, OW = a.W / 2;
 
     float bw[BF16 ? 1 : 14];
-    tmf_bf16x8 bwb[2];                      // BF16: B[k = 16 m + 8 hsel + j][co], taps >= 27 are zero
+    // BF16: K = 48 = 3 MFMAs x (2 lane halves x 4 tap rows x 2 taps): k = 16 m + 8 hsel + 2 s + t is tap row r = 4 m + s
+    // (= 3 dz + dy), dx = 2 hsel + t — the lane half picks the pair (dx 0, 1) or (dx 2, pad); rows >= 9 and dx = 3 are zero
+    tmf_bf16x8 bwb[3];
     if (BF16) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < 3; ++m) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int tap = 16 * m + 8 * hsel + j;
-                v[j] = (tap < 27 && cv) ? a.w[tap * a.C + co] : 0.f;
+                const int r = 4 * m + (j >> 1), dx = 2 * hsel + (j & 1);
+                v[j] = (r < 9 && dx < 3 && cv) ? a.w[(3 * r + dx) * a.C + co] : 0.f;
             }
             bwb[m] = pack8(v);
         }
@@ -112,6 +126,10 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
 #pragma unroll
     for (int r = 0; r < 16; ++r) accw[r] = 0.f;
     const int a_tap = tapoff(l31);          // lanes >= 27 read tap 0's voxels; their rows are dropped
+    // BF16 wgrad gather: byte address of (this lane's tap, lane half's brick rows) in the copy of the tap's parity
+    const int wg_tap = l31 < 27 ? l31 : 0, wg_c = (wg_tap % 3) & 1;
+    const unsigned wg_b = hb_base + 2u * (unsigned)((wg_tap / 9) * BPLANE + ((wg_tap / 3) % 3) * BROW + wg_tap % 3 + wg_c +
+                                                    wg_c * BCOPY + 2 * hsel * BROW);
 
     const int tile_begin = blockIdx.x * a.tiles_per_block;
     int tile_end = tile_begin + a.tiles_per_block;
@@ -126,25 +144,51 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
     constexpr int OOB = (int)0x80000000u;
     constexpr int HVN = (NHALO + 255) / 256;
     float hv[HVN];
-    int hrel[HVN], hcrd[HVN];
+    int hrel[HVN], hcrd[HVN], hdst[HVN];
 #pragma unroll
     for (int q = 0; q < HVN; ++q) {
         const int e = tid + q * 256;
         const int hw = e % HW, hh = (e / HW) % HH, hd = e / (HW * HH);
         hrel[q] = e < NHALO ? ((hd * a.H + hh) * a.W + hw) * 4 : OOB;
         hcrd[q] = hd | hh << 8 | hw << 16;
+        hdst[q] = hd * BPLANE + hh * BROW + hw;          // BF16: element index in copy 0
+    }
+    if (BF16) {                                          // pad elements (row tails, plane gaps) are read against zero weights
+        for (int e = tid; e < NHB_DW; e += 256) halo[e] = 0.f;
+        __syncthreads();
     }
     auto min_i = [](int x_, int y_) { return x_ < y_ ? x_ : y_; };
-    auto fetch = [&](int tile) {
-        int t = tile;
-        const int tw = t % a.tilesW; t /= a.tilesW;
-        const int th = t % a.tilesH; t /= a.tilesH;
-        const int td = t % a.tilesD;
-        const int b = t / a.tilesD;
-        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
-        const float* org = a.x + (size_t)b * a.D * a.H * a.W + ((long)((d0 - 1) * a.H + (h0 - 1)) * a.W + (w0 - 1));
+    // Brick coordinates advance incrementally (a workgroup walks consecutive bricks): decoding the linear index with
+    // three runtime divisions per brick — once for the brick, once for its prefetch — was ~100 of the ~200 scalar
+    // instructions of an iteration, and the scalar unit (one issue per SIMD turn, in order with the wave's vector
+    // work) was 60 % busy in the bf16 passes (PMC, profiles/r02_pmc_c1_bf16.txt).
+    // ... and so do the halo origin (64-bit) and the "brick row is interior / complete" tests: per brick that is an add and
+    // two compares; everything else is redone only when a brick row wraps.
+    struct Crd { int tw, th, td, b; long xoff; bool in_dh, full_dh; };
+    const bool even_dims = (a.D % 2 == 0) && (a.H % 2 == 0) && (a.W % 2 == 0);
+    auto row_setup = [&](Crd& c) {          // the parts of a brick that depend on (b, td, th) only
+        const int d0 = c.td * TD, h0 = c.th * TH;
+        c.xoff = (long)c.b * a.D * a.H * a.W + ((long)((d0 - 1) * a.H + (h0 - 1)) * a.W + (c.tw * TW - 1));
+        c.in_dh = d0 >= 1 && d0 + TD < a.D && h0 >= 1 && h0 + TH < a.H;
+        c.full_dh = d0 + TD <= a.D && h0 + TH <= a.H && even_dims;
+    };
+    auto next_crd = [&](Crd c) {
+        c.xoff += TW;
+        if (++c.tw == a.tilesW) {
+            c.tw = 0;
+            if (++c.th == a.tilesH) {
+                c.th = 0;
+                if (++c.td == a.tilesD) { c.td = 0; ++c.b; }
+            }
+            row_setup(c);
+        }
+        return c;
+    };
+    auto fetch = [&](const Crd& c) {
+        const int d0 = c.td * TD, h0 = c.th * TH, w0 = c.tw * TW;
+        const float* org = a.x + c.xoff;
         const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(org), 0, 0x7FFFFFFF, 0x00020000);
-        if (d0 >= 1 && d0 + TD < a.D && h0 >= 1 && h0 + TH < a.H && w0 >= 1 && w0 + TW < a.W) {
+        if (c.in_dh && w0 >= 1 && w0 + TW < a.W) {
 #pragma unroll
             for (int q = 0; q < HVN; ++q)
                 hv[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xr, hrel[q], 0, 0));
@@ -165,30 +209,71 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
     // pooled / dpool addresses: lane part = (second brick row of the lane half, channel); everything else is scalar
     constexpr int PSZ = P16 ? 2 : 4;
     const int pl_lane = cv ? (hsel * OW * a.C + co) * PSZ : OOB;
-    if (tile_begin < tile_end) fetch(tile_begin);
+    Crd cur;
+    {
+        int t = tile_begin;
+        cur.tw = t % a.tilesW; t /= a.tilesW;
+        cur.th = t % a.tilesH; t /= a.tilesH;
+        cur.td = t % a.tilesD;
+        cur.b = t / a.tilesD;
+        row_setup(cur);
+    }
+    if (tile_begin < tile_end) fetch(cur);
     for (int tile = tile_begin; tile < tile_end; ++tile) {
-        int t = tile;
-        const int tw = t % a.tilesW; t /= a.tilesW;
-        const int th = t % a.tilesH; t /= a.tilesH;
-        const int td = t % a.tilesD;
-        const int b = t / a.tilesD;
-        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+        const int b = cur.b;
+        const int d0 = cur.td * TD, h0 = cur.th * TH, w0 = cur.tw * TW;
+        const bool full = cur.full_dh && w0 + TW <= a.W;
+        cur = next_crd(cur);                 // from here on: the NEXT brick (prefetch target, and the next iteration's own)
         if (tile > tile_begin) __syncthreads();
 #pragma unroll
         for (int q = 0; q < HVN; ++q) {
             const int e = tid + q * 256;
-            if (e < NHALO) halo[e] = hv[q];
+            if (BF16) {
+                if (e < NHALO) {
+                    const unsigned short h16 = (unsigned short)(tmf_pack_bf16(hv[q], 0.f) & 0xFFFFu);
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(halo) + hdst[q];
+                    dst[0] = h16;
+                    dst[BCOPY + 1] = h16;
+                }
+            } else {
+                if (e < NHALO) halo[e] = hv[q];
+            }
         }
         __syncthreads();
-        if (tile + 1 < tile_end) fetch(tile + 1);
+        if (tile + 1 < tile_end) fetch(cur);
 
         auto process = [&](auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;   // brick entirely inside the volume: no per-voxel checks
         // ---- z = conv(x) for BOTH M-tiles of this wave, interleaved (two independent MFMA chains) ----
         //      A[i = voxel][k = tap], voxel i = lane & 31 in fragment-row order
         f32x16 zt[NTI];
-        {
-            const int i = l31;
+        constexpr bool LAZY = BF16 && MODE == MODE_WGRAD;      // 128-register budget: one M-tile's z at a time
+        const int i = l31;
+        // BF16: A[i = voxel][k]: per MFMA four dwords = the lane half's tap pair of four tap rows (rows >= 9 repeat row 8
+        // against zero weights); the lane's byte address is loop-invariant up to the M-tile origin
+        const unsigned lane_b = hb_base + 2u * (unsigned)(((i >> 3) & 1) * BPLANE + (2 * ((i >> 2) & 1) + ((i >> 1) & 1)) * BROW +
+                                                        2 * ((i >> 4) & 1) + 2 * (i & 1) + (i & 1) * BCOPY + 2 * hsel);
+        auto load_rows = [&](int ti, unsigned (&pr)[9]) {
+            const int mt = wave * NTI + ti;
+            const unsigned tb = lane_b + 2u * (unsigned)((2 * (mt >> 2)) * BPLANE + 4 * ((mt >> 1) & 1) * BROW + 4 * (mt & 1));
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+                pr[r] = *reinterpret_cast<const __attribute__((address_space(3))) unsigned*>((size_t)(tb + 2u * (unsigned)brow_off(r)));
+        };
+        auto mma = [&](int ti, int m, const unsigned (&pr)[9]) {
+            const u32x4 av = {pr[4 * m < 9 ? 4 * m : 8], pr[4 * m + 1 < 9 ? 4 * m + 1 : 8],
+                              pr[4 * m + 2 < 9 ? 4 * m + 2 : 8], pr[4 * m + 3 < 9 ? 4 * m + 3 : 8]};
+            zt[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tmf_bf16x8, av), bwb[m], zt[ti], 0, 0, 0);
+        };
+        auto conv_one = [&](int ti) {
+            unsigned pr[9];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) zt[ti][r] = 0.f;
+            load_rows(ti, pr);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) mma(ti, m, pr);
+        };
+        if (!LAZY) {
             const int vox = (((i >> 3) & 1) * HH + 2 * ((i >> 2) & 1) + ((i >> 1) & 1)) * HW + 2 * ((i >> 4) & 1) + (i & 1);
             int a_vox[NTI];
 #pragma unroll
@@ -199,18 +284,13 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
                 for (int r = 0; r < 16; ++r) zt[ti][r] = 0.f;
             }
             if (BF16) {
-                // A[i = voxel][k = 16 m + 8 hsel + j]: eight taps of the lane's voxel per MFMA (taps >= 27 read a
-                // finite halo value against a zero weight)
+                unsigned pr[NTI][9];
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int ti = 0; ti < NTI; ++ti) load_rows(ti, pr[ti]);
 #pragma unroll
-                    for (int ti = 0; ti < NTI; ++ti) {
-                        float v[8];
+                for (int m = 0; m < 3; ++m) {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j)
-                            v[j] = halo[a_vox[ti] + (hsel ? tapoff(16 * m + 8 + j) : tapoff(16 * m + j))];
-                        zt[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(v), bwb[m], zt[ti], 0, 0, 0);
-                    }
+                    for (int ti = 0; ti < NTI; ++ti) mma(ti, m, pr[ti]);
                 }
             } else {
 #pragma unroll
@@ -226,6 +306,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
         for (int ti = 0; ti < NTI; ++ti) {
             const int mt = wave * NTI + ti;                     // M-tile of the brick (wave-uniform)
             const int org = ((2 * (mt >> 2)) * HH + 4 * ((mt >> 1) & 1)) * HW + 4 * (mt & 1);
+            if (LAZY) conv_one(ti);
             f32x16& z = zt[ti];
             // voxel coordinates of this lane's 16 rows (row r, lane half hsel), relative to the brick:
             //   d = 2*(mt>>2) + r[2],  h = 4*((mt>>1)&1) + 2*hsel + r[1],  w = 4*(mt&1) + 2*r[3] + r[0]
@@ -304,13 +385,21 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
                 const int a_row = org + hsel * 2 * HW + a_tap;
                 if (BF16) {
                     // K = the 16 voxels of fragment rows 8 m .. 8 m + 7 of both lane halves: B is the lane's own dz
-                    // registers, A the same voxels' inputs shifted by the lane's tap
+                    // registers, A the same voxels' inputs shifted by the lane's tap — rows 2 u, 2 u + 1 are w-neighbours,
+                    // i.e. one dword of the copy whose parity matches the tap's dx
+                    const unsigned wt = wg_b + 2u * (unsigned)((2 * (mt >> 2)) * BPLANE + 4 * ((mt >> 1) & 1) * BROW + 4 * (mt & 1));
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        float av[8], bv[8];
+                        float bv[8];
+                        unsigned ad[4];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) { av[j] = halo[a_row + row_off(8 * m + j)]; bv[j] = z[8 * m + j]; }
-                        accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pack8(av), pack8(bv), accw, 0, 0, 0);
+                        for (int u = 0; u < 4; ++u)
+                            ad[u] = *reinterpret_cast<const __attribute__((address_space(3))) unsigned*>(
+                                (size_t)(wt + 2u * (unsigned)((u >> 1) * BPLANE + (u & 1) * BROW + 2 * m)));
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) bv[j] = z[8 * m + j];
+                        const u32x4 av = {ad[0], ad[1], ad[2], ad[3]};
+                        accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tmf_bf16x8, av), pack8(bv), accw, 0, 0, 0);
                     }
                 } else {
 #pragma unroll
@@ -320,7 +409,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
             }
         }
         };
-        if (d0 + TD <= a.D && h0 + TH <= a.H && w0 + TW <= a.W && (a.D % 2 == 0) && (a.H % 2 == 0) && (a.W % 2 == 0))
+        if (full)
             process(std::true_type{});
         else
             process(std::false_type{});
