@@ -328,6 +328,14 @@ __device__ __attribute__((aligned(16))) const unsigned int tmf_zero16[4] = {0u, 
 // the small-brick kernel up to fp32 summation order (k runs 16-channel chunk -> tap here, 32-channel chunk -> tap -> half
 // there).
 // ------------------------------------------------------------------------------------------------------------
+// -DTMF_TRACE=<workgroup>: waves 0 and 4 of that workgroup of the LDS-DMA forward kernel log shader-clock stamps at their
+// phase boundaries (tools/v2_trace.py reads them through tmf_debug_trace_read); never in the shipped library.
+#ifdef TMF_TRACE
+__device__ unsigned long long tmf_trace_buf[2][256];
+#define TR(id) do { if (tr_on) { if (lane == 0) tmf_trace_buf[tr_slot][tr_n] = ((unsigned long long)(id) << 48) | (__builtin_readcyclecounter() & 0xFFFFFFFFFFFFull); ++tr_n; } } while (0)
+#else
+#define TR(id) do { } while (0)
+#endif
 namespace v2 {
 constexpr int TD = 8, TH = 8, TW = 8;
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
@@ -410,6 +418,12 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     const float* xb = reinterpret_cast<const float*>(x_) + (IN16 ? 0 : (size_t)b * D * H * W * Cin);
     const u16* xb16 = reinterpret_cast<const u16*>(x_) + (IN16 ? (size_t)b * D * H * W * Cin : 0);
 
+#ifdef TMF_TRACE
+    const bool tr_on = DMA && blockIdx.x == TMF_TRACE && (wave == 0 || wave == 4);
+    const int tr_slot = wave >> 2;
+    int tr_n = 0;
+#endif
+    TR(1);
     if constexpr (DMA) {
         static_assert(IN16, "the DMA form copies bf16 tensors");
         using namespace dma;
@@ -481,20 +495,27 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
                 if (in_stage) glds16(src, base + i * 4096);
             }
         };
+        TR(2);
         if (wrole) issue_w(0, 0, 0);
+        TR(3);
         int par = 0;                                           // parity of the chunk index: 3 stages flip the weight ring
         for (int c0 = 0; c0 < Cin; c0 += CINC, par ^= 1) {
             if (c0 > 0) __syncthreads();                       // the halo of the previous chunk is read out
-            if (!wrole) { issue_h(c0); dma_wait(); }
+            TR(10);
+            if (!wrole) { issue_h(c0); TR(11); dma_wait(); TR(12); }
 #pragma unroll
             for (int st = 0; st < NSTD; ++st) {
                 const int wb = (st & 1) ^ par;
+                TR(20);
                 if (wrole) dma_wait();                         // this wave's share of stage st has landed ...
+                TR(21);
                 __syncthreads();                               // ... everybody's has (and the halo), and stage st - 1 is read out
+                TR(22);
                 if (wrole) {
                     if (st + 1 < NSTD) issue_w(c0, st + 1, wb ^ 1);
                     else if (c0 + CINC < Cin) issue_w(c0 + CINC, 0, wb ^ 1);
                 }
+                TR(23);
                 const unsigned char* wsb = smem_raw + HBYTES + wb * WBYTES + b_row;
 #pragma unroll
                 for (int tp = 0; tp < TPSD; ++tp) {                                                    // kh = tp / 3, kw = tp % 3
@@ -608,6 +629,7 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     }   // register-staged form
 
     // ---- epilogue: NDHWC store (fp32, or bf16 as channel-pair dwords) + BatchNorm statistic partials ----
+    TR(30);
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
@@ -662,6 +684,7 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     };
     if (d0 + TD <= D && h0 + TH <= H && w0 + TW <= W && n0 + NB <= Cout) epilogue(std::true_type{});
     else epilogue(std::false_type{});
+    TR(31);
 
     if (stat_partial != nullptr) {
 #pragma unroll
@@ -689,6 +712,7 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
             }
         }
     }
+    TR(40);
 }
 
 
@@ -1473,6 +1497,11 @@ static bool use_v2(int B, int D, int H, int W) {
     return (long)B * tmf_cdiv(D, v2::TD) * tmf_cdiv(H, v2::TH) * tmf_cdiv(W, v2::TW) >= 384;
 }
 
+#ifdef TMF_TRACE
+extern "C" int tmf_debug_trace_read(void* dst, size_t bytes) {
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(tmf_trace_buf), bytes < sizeof(tmf_trace_buf) ? bytes : sizeof(tmf_trace_buf)) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" int tmf_conv3d_split_stat_blocks(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);          // the split kernel always uses 4x8x8 bricks
