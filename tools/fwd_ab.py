@@ -42,7 +42,7 @@ for name, ci, co, lvl in (("conv2.0", 32, 32, 1), ("conv2.3", 32, 64, 1), ("conv
         row = []
         for dma in (0, 1):
             _lib.call("tmf_set_option", b"bf16_dma", dma)
-            ms = t(lambda: ops.conv3d_bf16_raw(x, w, cin, cout, True, out_bf16=True))
+            ms = t(lambda: ops.conv3d_bf16_raw(x, w, cin, cout, tag == "fwd", out_bf16=True))     # data gradients take no statistics
             row.append(f"{'dma' if dma else 'reg'} {ms * 1e3:7.1f} us {fl / ms / 1e9:6.0f} TF")
         k = _lib.query("tmf_conv3d_fwd_bf16_kernel_name", a.B, s, s, s, cin, cout, 3).decode()
         print(f"{name} {tag:5s} ({cin}->{cout} @{s}^3) {k}: " + " | ".join(row), flush=True)
