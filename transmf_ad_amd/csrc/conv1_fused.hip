@@ -83,7 +83,7 @@ __device__ __forceinline__ tmf_bf16x8 pack8(const float (&v)[8]) {
 template <int MODE, bool BF16, bool P16 = false>     // P16: pooled / dpool are bf16 tensors (bf16 activation storage)
 __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Args a) {   // <= 256 registers: MFMA results in VGPRs (no v_accvgpr_read copies)
     __shared__ float halo[BF16 ? NHB_DW : NHALO];
-    const unsigned hb_base = (unsigned)(size_t)halo;        // LDS byte address of the bf16 copies (BF16)
+    const unsigned hb_base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)halo;   // LDS byte address of the bf16 copies (BF16)
     __shared__ float red[4 * 32 * 32];      // cross-wave reduction scratch (16 KB)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
