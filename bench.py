@@ -157,6 +157,11 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             fns = (("fwd", f"conv3d_fwd_kernel<{kf}>", lambda: ops.conv3d_raw(x, wf, ci, co, 3, True)),
                    ("dgrad", f"conv3d_fwd_kernel<{kd}>", lambda: ops.conv3d_raw(dz, wd, co, ci, 3, False)),
                    ("wgrad", f"conv3d_wgrad_kernel<{kw}>", lambda: ops.conv3d_wgrad(x, dz, ci, co, 3)))
+            if precision == "fp32x":      # forward / data gradient as the step runs them: six bf16 partial products per fp32 product
+                w3f = ops.split3_bf16(w.permute(2, 3, 4, 0, 1).contiguous())
+                w3d = ops.split3_bf16(w.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())
+                fns = (("fwd", "conv3d_fwd_split_kernel", lambda: ops.conv3d_split_raw(x, w3f, ci, co, True)),
+                       ("dgrad", "conv3d_fwd_split_kernel", lambda: ops.conv3d_split_raw(dz, w3d, co, ci, False)), fns[2])
         for pas, kern, fn in fns:
             ms = _time_launches(fn, reps)
             rows.append(dict(layer=name, **{"pass": pas}, kernel=kern, ms=ms, flops=fl, bytes=by))
@@ -243,6 +248,10 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
                                                  "hbm_frac": round(r["bytes"] / r["ms"] / 1e6 / PEAK_HBM_GBS, 3)}
                    for r in rows},
     }
+    if precision == "fp32x":
+        roof["peak_note"] = ("opt-in mode: fractions are ALGORITHMIC fp32 flops against the fp32-MFMA peak (157.3 TF); the "
+                             "forward / data-gradient kernel evaluates every fp32 product as six bf16 partial products, its own "
+                             f"ceiling is the bf16 peak / 6 = {PEAK_BF16_MFMA_TFLOPS / 6:.1f} TF, so its entries may exceed 1")
     if pairs_per_s is not None:
         per_gpu = pairs_per_s / world
         roof["whole_step"] = {

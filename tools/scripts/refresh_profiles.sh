@@ -18,6 +18,7 @@ timeout 300 python3 bench.py --size 128 --no-cpu-baseline > $O/b.log 2>&1; grep 
 timeout 300 python3 bench.py --shape 91 109 91 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_adni_shape.json
 timeout 300 python3 bench.py --model cnn --batch 16 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_cnn_b16.json
 timeout 300 python3 bench.py --model single --batch 16 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_single_b16.json
+timeout 300 python3 bench.py --precision fp32x --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_n1_fp32x.json
 timeout 300 python3 bench.py --eval --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_eval_n1.json
 # --- kernel-trace statistics of the SAME commands (roofline loop only: the averages the roofline object quotes) ---
 prof() { # name, bench flags...
