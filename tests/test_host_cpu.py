@@ -47,6 +47,29 @@ def test_queries_and_argument_validation_without_gpu():
         _lib.call("tmf_conv3d_fwd", 4, 16, 16, None, 1, 4, 4, 4, 8, 8, 3, None)
 
 
+def test_forward_brick_choice_follows_the_occupancy_model():
+    """plan_fwd (csrc/conv3d_mfma.hip) picks the brick per launch: the 8-wave 4x8x8 brick for the benchmark sizes (their
+    profiles must not move), the 4-wave 4x4x8 brick where 4x8x8 bricks leave a CU with an extra workgroup (the
+    reference's 91x109x91 volumes at the 22x27x22 level), 64-channel workgroups for the 11x13x11 level; the statistics
+    buffer is sized by the same plan."""
+    from transmf_ad_amd import _lib
+    name = lambda D, H, W, ci, co: _lib.query("tmf_conv3d_fwd_kernel_name", 8, D, H, W, ci, co, 3).decode()
+    big64, big32 = "FwdCfg<3, 16, 1, 2, 8, 1, 4, 8, 8, 3>", "FwdCfg<3, 16, 1, 1, 8, 1, 4, 8, 8, 3>"
+    for S in (96, 128):
+        assert name(S // 2, S // 2, S // 2, 32, 32) == big32 and name(S // 2, S // 2, S // 2, 64, 32) == big32
+        for ci, co in ((32, 64), ):
+            assert name(S // 2, S // 2, S // 2, ci, co) == big64
+        for ci, co in ((64, 64), (64, 128), (128, 64)):
+            assert name(S // 4, S // 4, S // 4, ci, co) == big64
+    assert name(12, 12, 12, 128, 256) == name(12, 12, 12, 256, 128) == "FwdCfg<3, 32, 1, 1, 2, 4, 4, 4, 4, 1>"
+    assert name(45, 54, 45, 32, 64) == big64
+    half = "FwdCfg<3, 32, 1, 2, 4, 1, 4, 4, 8, 1>"
+    assert name(22, 27, 22, 64, 64) == name(22, 27, 22, 64, 128) == name(22, 27, 22, 128, 64) == half
+    assert _lib.query("tmf_conv3d_stat_blocks", 8, 22, 27, 22, 64, 64, 3) == 8 * 6 * 7 * 3
+    assert name(11, 13, 11, 128, 256) == name(11, 13, 11, 256, 128) == "FwdCfg<3, 32, 1, 1, 2, 2, 4, 4, 4, 1>"
+    assert _lib.query("tmf_conv3d_stat_blocks", 8, 11, 13, 11, 128, 256, 3) == 8 * 3 * 4 * 3
+
+
 @pytest.mark.parametrize("name", ["ad_tiny", "cnn_tiny", "single_mid", "ad_mid"])
 def test_state_dict_keys_and_shapes_match_reference(name):
     """Keys/shapes recorded from the imported reference's state_dict() (fixture meta) == ours, in order."""

@@ -837,6 +837,9 @@ template <int KS, int CINC> using CfgS128 = FwdCfg<KS, CINC, 1, 2, 2, 2, 4, 4, 4
 template <int KS, int CINC> using CfgL32w8 = FwdCfg<KS, CINC, 1, 1, 8, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgL64w8 = FwdCfg<KS, CINC, 1, 2, 8, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgS128w8 = FwdCfg<KS, CINC, 1, 1, 2, 4, 4, 4, 4, 1>;
+// 4x4x4 brick x 64 output channels, 4 waves, 48 KB of LDS: three workgroups per CU — for launches whose 128-channel
+// workgroups would leave most of a round empty (plan_fwd)
+template <int KS, int CINC> using CfgS64 = FwdCfg<KS, CINC, 1, 1, 2, 2, 4, 4, 4, 1>;
 // 4x4x8 bricks, 4 waves, <= 78 KiB of LDS: TWO workgroups per CU whose phases (halo staging, weight-stage
 // barriers, epilogue) are independent, so one computes while the other stages or stores
 template <int KS, int CINC> using CfgM32 = FwdCfg<KS, CINC, 1, 1, 4, 1, 4, 4, 8, (KS == 3 ? 3 : 1)>;
@@ -875,8 +878,31 @@ FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks) {
     } else {
         p.cfg = 2; nb = 128; td = 4; th = 4; tw = 4;
     }
-    if (p.cinc == 32 && conv_waves() == 16 && p.cfg < 2) { p.cfg += 8; p.cinc = 16; }
-    else if (p.cinc == 32 && conv_waves() >= 8) p.cfg += 3;
+    // Equal workgroups spread over 256 CUs: a launch lasts as long as the CU with the most of them, ceil(n / 256) x the
+    // work of one — 576 workgroups (the reference's 22x27x22 level in 4x8x8 bricks) cost 3 units where 432 (24^3) cost 2.
+    // The half-size brick (4x4x8, four waves) costs ~8 % more per voxel but divides twice as finely and pads H to a
+    // multiple of 4 instead of 8: 1 008 workgroups = 4 half units (conv3.0 at that size: 0.31 -> 0.22 ms; conv3.3 0.51 ->
+    // 0.44, the model says 5 -> 4.3).  Chosen per launch by that model, the established brick on a tie; TMF_CONV_AUTO=0
+    // keeps the 8-wave brick everywhere.
+    static const bool auto_brick = [] { const char* e = getenv("TMF_CONV_AUTO"); return e == nullptr || atoi(e) != 0; }();
+    bool half_brick = false;
+    if (auto_brick && ks == 3 && p.cinc == 32 && conv_waves() == 16 && p.cfg < 2) {
+        const long nby = tmf_cdiv(cout, nb);
+        const long nL = (long)B * tmf_cdiv(D, 4) * tmf_cdiv(H, 8) * tmf_cdiv(W, 8) * nby;
+        const long nM = (long)B * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 8) * nby;
+        const double cL = (double)((nL + 255) / 256), cM = 0.54 * (double)((nM + 255) / 256);
+        half_brick = cM < 0.9 * cL;        // (0.945 at 24^3, 64 -> 128, measured 2 % slower: co-resident workgroups do overlap a little)
+    }
+    if (auto_brick && ks == 3 && p.cinc == 32 && conv_waves() == 16 && p.cfg == 2 && cout % 64 == 0) {
+        // small volumes: 128-channel workgroups against 64-channel ones of half the work (11x13x11, 128 -> 256: 576 vs
+        // 1 152 workgroups = 3 vs 2.5 units, 0.34 -> 0.28 ms; 256 -> 128: 2 vs 1.5, 0.43 -> 0.33)
+        const long n = (long)B * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 4);
+        const double c128 = (double)((n * tmf_cdiv(cout, 128) + 255) / 256), c64 = 0.5 * (double)((n * (cout / 64) + 255) / 256);
+        if (c64 < 0.9 * c128) { p.cfg = 11; nb = 64; }
+    }
+    if (half_brick) { p.cfg += 6; th = 4; }
+    else if (p.cinc == 32 && conv_waves() == 16 && p.cfg < 2) { p.cfg += 8; p.cinc = 16; }
+    else if (p.cinc == 32 && conv_waves() >= 8 && p.cfg < 11) p.cfg += 3;
     else if (p.cinc == 32 && conv_waves() == 2) {
         if (p.cfg == 2) p.cfg = 5;
         else { p.cfg += 6; th = 4; }
@@ -936,6 +962,7 @@ int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float
     if (p.cfg == 9) { TMF_FWD_CASE(CfgL64w8, 16) }
     if (p.cfg == 6) { TMF_FWD_CASE(CfgM32, 32) }
     if (p.cfg == 7) { TMF_FWD_CASE(CfgM64, 32) }
+    if (p.cfg == 11) { TMF_FWD_CASE(CfgS64, 32) }
 #undef TMF_FWD_CASE
     tmf_set_error("tmf_conv3d_fwd: no kernel for plan cfg=%d cinc=%d", p.cfg, p.cinc);
     return TMF_E_SHAPE;
@@ -962,6 +989,7 @@ const char* fwd_kernel_name(const FwdPlan& p) {
     if (p.cfg == 9) { TMF_FWD_CASE(CfgL64w8, 16) }
     if (p.cfg == 6) { TMF_FWD_CASE(CfgM32, 32) }
     if (p.cfg == 7) { TMF_FWD_CASE(CfgM64, 32) }
+    if (p.cfg == 11) { TMF_FWD_CASE(CfgS64, 32) }
 #undef TMF_FWD_CASE
     return p.cfg == 10 ? "conv3d_fwd_ws_kernel" : "?";
 }
