@@ -131,6 +131,8 @@ BLOCK_CASES = [
     (1, 6, 6, 6, 1, 8, 3, None),          # first layer without pool -> generic (stored-z) path
     (1, 5, 4, 3, 6, 10, 3, "max"),        # scalar channel path
     (2, 16, 16, 16, 32, 64, 3, "max"),
+    (8, 22, 27, 22, 64, 64, 3, "max"),    # the reference's third level at batch 8: plan_fwd takes the 4x4x8 half brick
+    (8, 11, 13, 11, 128, 256, 3, None),   # ... and its fourth: 64-channel instance of the 4x4x4-brick kernel (fwd and dgrad)
 ]
 
 
