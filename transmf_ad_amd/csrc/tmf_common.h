@@ -209,6 +209,59 @@ static __global__ __launch_bounds__(64 * TMF_RED_LANES) void tmf_slab_reduce_ker
     }
 }
 
+// The same sums, four consecutive elements per lane (16-byte loads: a quarter of the load instructions; 256 slabs of
+// 221 KB went 26.6 -> ~14 us).  Per element the order of additions is exactly the scalar kernel's, so the two are bitwise
+// interchangeable; used when n % 4 == 0 and the slabs are 16-byte aligned.
+static __global__ __launch_bounds__(64 * TMF_RED_LANES) void tmf_slab_reduce4_kernel(
+    const float* __restrict__ partial, float* __restrict__ out, int nsplit, long n, int slabs_per_group,
+    int tcin = 0, int tcout = 0) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ double red[TMF_RED_LANES][64][4];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long e = ((long)blockIdx.x * 64 + tx) * 4;
+    const int g = blockIdx.y;
+    const int s0 = g * slabs_per_group;
+    int s1 = s0 + slabs_per_group;
+    if (s1 > nsplit) s1 = nsplit;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    if (e < n) {
+        int s = s0 + ty;
+        for (; s + 3 * TMF_RED_LANES < s1; s += 4 * TMF_RED_LANES) {
+            const f4 v0 = *reinterpret_cast<const f4*>(partial + (size_t)s * n + e);
+            const f4 v1 = *reinterpret_cast<const f4*>(partial + (size_t)(s + TMF_RED_LANES) * n + e);
+            const f4 v2 = *reinterpret_cast<const f4*>(partial + (size_t)(s + 2 * TMF_RED_LANES) * n + e);
+            const f4 v3 = *reinterpret_cast<const f4*>(partial + (size_t)(s + 3 * TMF_RED_LANES) * n + e);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] += ((double)v0[c] + (double)v1[c]) + ((double)v2[c] + (double)v3[c]);
+        }
+        for (; s < s1; s += TMF_RED_LANES) {
+            const f4 v = *reinterpret_cast<const f4*>(partial + (size_t)s * n + e);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] += (double)v[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) red[ty][tx][c] = a[c];
+    __syncthreads();
+    if (ty == 0 && e < n) {
+#pragma unroll
+        for (int k = 1; k < TMF_RED_LANES; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] += red[k][tx][c];
+        if (tcin > 0) {
+            const int T = (int)(n / ((long)tcin * tcout));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const long ec = e + c;
+                const int co = (int)(ec % tcout), ci = (int)((ec / tcout) % tcin), t = (int)(ec / ((long)tcout * tcin));
+                out[((size_t)co * tcin + ci) * T + t] = (float)a[c];
+            }
+        } else {
+            *reinterpret_cast<f4*>(out + (size_t)g * n + e) = f4{(float)a[0], (float)a[1], (float)a[2], (float)a[3]};
+        }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -227,16 +280,19 @@ static inline int tmf_reduce_slabs(const float* partial, int nsplit, long n, flo
                                    hipStream_t s, const char* what, int tcin = 0, int tcout = 0) {
     const int G = tmf_reduce_groups(nsplit);
     const dim3 block(64 * TMF_RED_LANES);
-    const int gx = (int)((n + 63) / 64);
+    const bool v4 = n % 4 == 0 && n >= 1024 && ((size_t)partial & 15) == 0 && ((size_t)out & 15) == 0 &&
+                    (G == 1 || ((size_t)scratch & 15) == 0);
+    const int gx = v4 ? (int)((n / 4 + 63) / 64) : (int)((n + 63) / 64);
+    auto k = v4 ? tmf_slab_reduce4_kernel : tmf_slab_reduce_kernel;
     if (G == 1) {
-        hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, 1), block, 0, s, partial, out, nsplit, n, nsplit, tcin, tcout);
+        hipLaunchKernelGGL(k, dim3(gx, 1), block, 0, s, partial, out, nsplit, n, nsplit, tcin, tcout);
         return tmf_launch_result(what);
     }
     const int spg = (nsplit + G - 1) / G;
-    hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, G), block, 0, s, partial, scratch, nsplit, n, spg, 0, 0);
+    hipLaunchKernelGGL(k, dim3(gx, G), block, 0, s, partial, scratch, nsplit, n, spg, 0, 0);
     int rc = tmf_launch_result(what);
     if (rc) return rc;
-    hipLaunchKernelGGL(tmf_slab_reduce_kernel, dim3(gx, 1), block, 0, s, (const float*)scratch, out, G, n, G, tcin, tcout);
+    hipLaunchKernelGGL(k, dim3(gx, 1), block, 0, s, (const float*)scratch, out, G, n, G, tcin, tcout);
     return tmf_launch_result(what);
 }
 #endif
