@@ -293,7 +293,7 @@ int tmf_pack_conv_weights_bf16(const float* w, void* w_fwd_bf16, void* w_dgrad_b
 int tmf_layout_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, long voxels, void* stream);
 int tmf_layout_ndhwc_to_ncdhw(const float* src, float* dst, int B, int C, long voxels, void* stream);
 
-/* Weight gradients of up to 8 Linears in one launch (the backward of to_q / to_kv / to_out, networks.py:149-155, and of
+/* Weight gradients of up to 32 Linears in one launch (the backward of to_q / to_kv / to_out, networks.py:149-155, and of
  * the two FeedForward Linears, :129-132): dw[p][n][k] = sum_r dy[p][r][n] * x[p][r][k]
  * (dy[p]: [R[p]][N[p]], x[p]: [R[p]][K[p]], dw[p]: [N[p]][K[p]] = nn.Linear.weight layout; N, K multiples of 32).
  * dy / x / dw are HOST arrays of device pointers, R / N / K host arrays.  Split over 8 row ranges into `workspace`,
@@ -392,8 +392,8 @@ int    tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const tmf_sne
  * Whole-fusion entries (csrc/fusion_path.hip): ONE call enqueues every launch of CrossTransformer_MOD_AVG's train-mode
  * forward, or of its backward.  Replaces `self.fuse_transformer(mri_embeddings, pet_embeddings)` (models/mymodel.py:220
  * -> networks.py:272-281: depth x [mri <- Transformer(mri | pet) + mri; pet <- Transformer(pet | NEW mri) + pet], then
- * cat[mean, mean, max, max] over tokens) and its slice of `all_loss.backward()`.  Dropout must be inactive (p = 0, the
- * reference default options/option.py:39).  dim == 128; heads*dim_head and mlp multiples of 128.
+ * cat[mean, mean, max, max] over tokens) and its slice of `all_loss.backward()`.  Dropout (options/option.py:39) enters as
+ * keep-masks in tmf_xformer_params.  dim == 128; heads*dim_head and mlp multiples of 128.
  *
  * inst[2*l] / inst[2*l + 1] = the mri / pet Transformer(depth=1) of layer l, parameters = the reference's state_dict
  * tensors (nn.Linear weights (out, in)).  Gradients: small = [b2 (dim) | b1 (mlp) | bo (dim) | ln2 gamma | ln2 beta |
@@ -401,7 +401,12 @@ int    tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const tmf_sne
  * nn.Linear layout.  mri_tok / pet_tok: [B][N][dim]; cls: [B][4*dim]; dmri_tok / dpet_tok: [B][N][dim].
  * ---------------------------------------------------------------------------- */
 #define TMF_FUSION_MAX_DEPTH 16
-typedef struct tmf_fusion_desc { int B, N, dim, heads, dim_head, mlp, depth; } tmf_fusion_desc;
+/* flags: TMF_FUSION_PER_OP = enqueue one launch per Linear / attention / LayerNorm (token_gemm.hip, attention.hip,
+ * token_ops.hip: 7 forward + 13 backward launches per instance) even where the fused per-instance kernels of
+ * csrc/xformer_fused.hip apply (dim 128, 4 heads of 32, mlp 512, N <= 512: 1 forward + 2 backward launches per instance,
+ * all weight gradients in one launch at the end).  Forward and backward of one pass must see the same desc. */
+#define TMF_FUSION_PER_OP 1
+typedef struct tmf_fusion_desc { int B, N, dim, heads, dim_head, mlp, depth, flags; } tmf_fusion_desc;
 typedef struct tmf_xformer_params {
     const float *ln1_g, *ln1_b;         /* layers.0.0.norm                          (networks.py:117) */
     const float *wq, *wkv, *wo, *bo;    /* layers.0.0.fn.to_q / to_kv / to_out.0    (:149-155) */
@@ -409,6 +414,10 @@ typedef struct tmf_xformer_params {
     const float *w1, *b1, *w2, *b2;     /* layers.0.1.fn.net.0 / net.3              (:129-132) */
     const float *lnf_g, *lnf_b;         /* norm                                     (:219) */
     float eps1, eps2, epsf;
+    /* Dropout keep-masks of the instance ALREADY scaled by 1 / (1 - p), or NULL (eval, or p = 0): after to_out
+     * (networks.py:153) [B*N][dim], after GELU (:131) [B*N][mlp], after the second Linear (:133) [B*N][dim].  The random
+     * draw stays with the caller; the same pointers must be passed to forward and backward.  Fused kernels only. */
+    const float *mask_o, *mask_g, *mask_f;
 } tmf_xformer_params;
 typedef struct tmf_xformer_grads {
     float *small, *lnf, *dwq, *dwkv, *dwo, *dw1, *dw2;

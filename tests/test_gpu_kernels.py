@@ -802,6 +802,128 @@ def _transformer64_live(tr, x, ctx, residual):
     return y if residual is None else y + residual
 
 
+class _FixedMask(torch.nn.Module):
+    """Stands in for an nn.Dropout with a FIXED scaled keep-mask (what make_golden.py captures from the reference with
+    forward hooks): the HIP path asks it through ``tmf_keep_mask``, the fp64 formula multiplies by ``m``."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x):
+        return x * self.m.to(x.device, x.dtype).reshape(x.shape) if self.training else x
+
+    def tmf_keep_mask(self, training):
+        return self.m if training else None
+
+
+def _fusion64(fz, mri, pet):
+    """CrossTransformer_MOD_AVG.forward (networks.py:272-281) in fp64 on an fp64 CPU copy of the module, Dropout sites
+    (networks.py:131,133,153) included through the modules that sit there."""
+    def inst(tr, x, ctx):
+        attn_pre, ff_pre = tr.layers[0]
+        at, ff = attn_pre.fn, ff_pre.fn
+        xn = F.layer_norm(x, (x.shape[-1],), attn_pre.norm.weight, attn_pre.norm.bias, attn_pre.norm.eps)
+        q = xn @ at.to_q.weight.t()
+        k, v = (ctx @ at.to_kv.weight.t()).chunk(2, dim=-1)
+        B, N, inner = q.shape
+        h = at.heads
+        sp = lambda t: t.reshape(B, t.shape[1], h, inner // h).transpose(1, 2)
+        dots = torch.einsum("bhid,bhjd->bhij", sp(q), sp(k)) * at.scale
+        out = torch.einsum("bhij,bhjd->bhid", dots.softmax(dim=-1), sp(v)).transpose(1, 2).reshape(B, N, inner)
+        x1 = at.to_out[1](out @ at.to_out[0].weight.t() + at.to_out[0].bias) + x
+        xn = F.layer_norm(x1, (x.shape[-1],), ff_pre.norm.weight, ff_pre.norm.bias, ff_pre.norm.eps)
+        hdn = ff.net[2](_gelu64(xn @ ff.net[0].weight.t() + ff.net[0].bias))
+        x2 = ff.net[4](hdn @ ff.net[3].weight.t() + ff.net[3].bias) + x1
+        return F.layer_norm(x2, (x.shape[-1],), tr.norm.weight, tr.norm.bias, tr.norm.eps)
+    for mri_enc, pet_enc in fz.layers:
+        mri = inst(mri_enc, mri, pet) + mri
+        pet = inst(pet_enc, pet, mri) + pet
+    return torch.cat([mri.mean(dim=1), pet.mean(dim=1), mri.max(dim=1).values, pet.max(dim=1).values], dim=1)
+
+
+@pytest.mark.parametrize("B,N,depth,drop", [(2, 27, 2, False), (3, 216, 3, False), (2, 150, 1, True), (1, 512, 1, False),
+                                            (2, 16, 1, False), (8, 216, 3, True), (2, 5, 2, True)])
+def test_fused_fusion_kernels_match_fp64_formula(B, N, depth, drop):
+    """The whole fusion block on the fused per-instance kernels (csrc/xformer_fused.hip: 1 forward + 2 backward launches
+    per Transformer instance, all weight gradients in one launch) against an fp64 evaluation of the reference formula
+    (networks.py:114-175, 215-230, 272-281): cls, the gradients of both token tensors and of every parameter; ragged
+    token counts (partial 16-row tiles), one to 32 key tiles, and — `drop` — fixed Dropout keep-masks at the three
+    Dropout sites of every instance.  Also against the one-launch-per-Linear path of the same entry point (1e-5)."""
+    import copy
+    ops = _ops()
+    from transmf_ad_amd import networks
+    torch.manual_seed(7)
+    fz = networks.CrossTransformer_MOD_AVG(128, depth, 4, 32, 512, 0.).to(DEV).train()
+    with torch.no_grad():
+        for p in fz.parameters():
+            p.add_(torch.randn_like(p) * 0.05)
+    if drop:
+        rs = np.random.RandomState(3)
+        keep = lambda n: torch.from_numpy((rs.rand(B * N, n) >= 0.3).astype(np.float32) / 0.7)
+        for pair in fz.layers:
+            for tr in pair:
+                at, ff = tr.layers[0][0].fn, tr.layers[0][1].fn
+                at.to_out[1] = _FixedMask(keep(128))
+                ff.net[2] = _FixedMask(keep(512))
+                ff.net[4] = _FixedMask(keep(128))
+                tr._drops = None
+    m0, p0 = _rand(B, N, 128, seed=201), _rand(B, N, 128, seed=202)
+    go = _rand(B, 512, seed=203)
+    fz64 = copy.deepcopy(fz).cpu().double().train()
+    m64, p64 = m0.double().requires_grad_(True), p0.double().requires_grad_(True)
+    c64 = _fusion64(fz64, m64, p64)
+    c64.backward(go.double())
+    ref = [c64.detach(), m64.grad, p64.grad] + [p.grad for p in fz64.parameters()]
+    names = ["cls", "d mri", "d pet"] + [k for k, _ in fz64.named_parameters()]
+    res = {}
+    for fused in ((True, False) if not drop else (True,)):
+        ops.FUSION_FUSED_KERNELS = fused
+        try:
+            fz.zero_grad()
+            m, p = m0.to(DEV).requires_grad_(True), p0.to(DEV).requires_grad_(True)
+            c = fz(m, p)
+            assert type(c.grad_fn).__name__.startswith("FusionTrain"), c.grad_fn
+            c.backward(go.to(DEV))
+            torch.cuda.synchronize()
+            res[fused] = [c.detach().cpu(), m.grad.cpu(), p.grad.cpu()] + [q.grad.cpu() for q in fz.parameters()]
+        finally:
+            ops.FUSION_FUSED_KERNELS = True
+        assert len(res[fused]) == len(ref)
+        for name, a, r in zip(names, res[fused], ref):
+            assert torch.isfinite(a).all(), (fused, name)
+            assert _relerr(a, r) < 3e-5, (fused, name, _relerr(a, r))
+    if not drop:
+        for name, a, b in zip(names, res[True], res[False]):
+            assert _relerr(a, b) < 1e-5, (name, _relerr(a, b))
+
+
+def test_fused_fusion_kernels_are_deterministic_and_leave_no_trace():
+    """Two passes over the same inputs are bitwise equal (no atomics, fixed summation orders), also when the saved /
+    scratch workspaces start out filled with NaN (nothing uninitialised is read: padded token rows, transposed-copy
+    padding)."""
+    ops = _ops()
+    from transmf_ad_amd import networks
+    torch.manual_seed(9)
+    fz = networks.CrossTransformer_MOD_AVG(128, 2, 4, 32, 512, 0.).to(DEV).train()
+    m0, p0 = _rand(3, 27, 128, seed=211).to(DEV), _rand(3, 27, 128, seed=212).to(DEV)
+    go = _rand(3, 512, seed=213).to(DEV)
+    outs = []
+    for rep in range(2):
+        if rep == 1:            # poison the allocator's free blocks the next pass will be handed
+            junk = [torch.full((n,), float("nan"), device=DEV) for n in (1 << 22, 1 << 20, 1 << 18, 1 << 16)]
+            del junk
+        fz.zero_grad()
+        m, p = m0.clone().requires_grad_(True), p0.clone().requires_grad_(True)
+        c = fz(m, p)
+        c.backward(go)
+        torch.cuda.synchronize()
+        outs.append([c.detach().clone(), m.grad.clone(), p.grad.clone()] + [q.grad.clone() for q in fz.parameters()])
+    for a, b in zip(*outs):
+        assert torch.isfinite(a).all()
+        assert torch.equal(a, b)
+
+
 def test_layout_conversion_round_trip():
     from transmf_ad_amd import _lib as lib
     x = _rand(2, 5, 7, 9, 11, seed=121).to(DEV)                  # NCDHW, ragged against the 32 x 32 tiles

@@ -728,6 +728,9 @@ def test_one_call_fusion_matches_instance_by_instance(name):
     g = Golden(name)
     res = []
     try:
+        # the one-launch-per-Linear form of the one-call entry (TMF_FUSION_PER_OP); the fused per-instance kernels that
+        # the entry takes by default are compared with it in test_gpu_kernels.py::test_fused_fusion_kernels_match_fp64_formula
+        ops.FUSION_FUSED_KERNELS = False
         for one_call in (True, False):
             ops.FUSION_ONE_CALL = one_call
             net = build(g)
@@ -736,6 +739,7 @@ def test_one_call_fusion_matches_instance_by_instance(name):
             res.append((outs, loss, {k: p.grad.clone() for k, p in net.named_parameters()}))
     finally:
         ops.FUSION_ONE_CALL = True
+        ops.FUSION_FUSED_KERNELS = True
     (o1, l1, g1), (o2, l2, g2) = res
     assert torch.equal(l1, l2)
     for k in o1:

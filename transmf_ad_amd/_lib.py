@@ -120,14 +120,18 @@ PROTOTYPES.update({
 
 
 class FusionDesc(C.Structure):
-    _fields_ = [(n, _i) for n in ("B", "N", "dim", "heads", "dim_head", "mlp", "depth")]
+    _fields_ = [(n, _i) for n in ("B", "N", "dim", "heads", "dim_head", "mlp", "depth", "flags")]
+
+
+FUSION_PER_OP = 1
 
 
 XFORMER_PTRS = ("ln1_g", "ln1_b", "wq", "wkv", "wo", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2", "lnf_g", "lnf_b")
 
 
 class XformerParams(C.Structure):
-    _fields_ = [(n, _p) for n in XFORMER_PTRS] + [("eps1", _f), ("eps2", _f), ("epsf", _f)]
+    _fields_ = ([(n, _p) for n in XFORMER_PTRS] + [("eps1", _f), ("eps2", _f), ("epsf", _f)]
+                + [(n, _p) for n in ("mask_o", "mask_g", "mask_f")])
 
 
 class XformerGrads(C.Structure):

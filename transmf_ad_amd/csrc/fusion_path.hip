@@ -14,6 +14,25 @@
 // Pure host code.
 #include "tmf_common.h"
 
+// fused per-instance kernels (xformer_fused.hip)
+struct tmf_xf_fwd_io {
+    const float *x, *kv, *kvT, *wkv_next, *mask_o, *mask_g, *mask_f;
+    float *a, *q, *qT, *out, *lse, *x1, *f, *h, *g, *x2, *y, *m1, *r1, *m2, *r2, *mf, *rf, *kv_next, *kvT_next;
+};
+struct tmf_xf_bwd_io {
+    const float *dy, *x, *kv, *kvT, *mask_o, *mask_g, *mask_f;
+    const float *q, *qT, *out, *lse, *x1, *h, *x2, *m1, *r1, *m2, *r2, *mf, *rf;
+    float *dx2, *dh, *dx1, *dq, *dout, *doutT, *delta, *dx, *part, *dkv, *dctx;
+    const float* dctx_acc;
+};
+bool tmf_xf_supported(int N, int dim, int heads, int dim_head, int mlp);
+int tmf_xf_npad(int N);
+int tmf_xf_tiles(int N);
+int tmf_xf_part_stride(void);
+int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fwd_io* io, float scale, int only_kv, hipStream_t s);
+int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bwd_io* io, float scale, hipStream_t s);
+int tmf_xf_launch_colsum(int n_inst, const float* const* part, float* const* small, float* const* lnf, int nblk, hipStream_t s);
+
 namespace {
 
 inline size_t up256(size_t n) { return (n + 255) & ~(size_t)255; }
@@ -34,15 +53,21 @@ int check_desc(const char* fn, const tmf_fusion_desc* d) {
 
 // Saved tensors of ONE Transformer instance (floats), in this order inside the instance's slab.
 struct InstPlan {
-    size_t a, q, kv, out, lse, x1, f, h, g, x2, y, m1, r1, m2, r2, mf, rf, total;      // byte offsets
+    size_t a, q, kv, out, lse, x1, f, h, g, x2, y, m1, r1, m2, r2, mf, rf, qT, kvT, total;      // byte offsets
 };
+
+constexpr int WG_CHUNK = 30;    // weight-gradient problems per tmf_tok_wgrad_multi launch (6 instances)
 
 struct Plan {
     int R, inner, nblk, nblk_ln, stride;
+    bool fused;                 // one launch per instance and direction (xformer_fused.hip)
+    int npad, tiles;
     InstPlan I;                 // identical for every instance
     size_t off_arg, saved_bytes;
     // backward scratch (byte offsets)
     size_t s_dx2, s_dh, s_dx1, s_dout, s_dq, s_dkv, s_part, s_lnpart, s_G[4], s_ws, ws_bytes, scratch_bytes;
+    // fused backward: s_dx2 .. s_dkv and s_part are the first of `2 * depth` per-instance regions of inst_stride bytes
+    size_t s_doutT, s_delta, inst_stride;
 };
 
 Plan make_plan(const tmf_fusion_desc& d) {
@@ -53,10 +78,15 @@ Plan make_plan(const tmf_fusion_desc& d) {
     size_t o = 0;
     auto take = [&](size_t floats) { const size_t at = o; o += up256(floats * 4); return at; };
     InstPlan& I = p.I;
+    p.fused = !(d.flags & TMF_FUSION_PER_OP) && tmf_xf_supported(d.N, d.dim, d.heads, d.dim_head, d.mlp);
+    p.npad = tmf_xf_npad(d.N);
+    p.tiles = tmf_xf_tiles(d.N);
     I.a = take(R * dim); I.q = take(R * inner); I.kv = take(R * 2 * inner); I.out = take(R * inner);
-    I.lse = take((size_t)d.B * d.heads * d.N); I.x1 = take(R * dim); I.f = take(R * dim); I.h = take(R * mlp);
+    I.lse = take((size_t)d.B * d.heads * p.npad); I.x1 = take(R * dim); I.f = take(R * dim); I.h = take(R * mlp);
     I.g = take(R * mlp); I.x2 = take(R * dim); I.y = take(R * dim);
     I.m1 = take(R); I.r1 = take(R); I.m2 = take(R); I.r2 = take(R); I.mf = take(R); I.rf = take(R);
+    I.qT = I.kvT = o;
+    if (p.fused) { I.qT = take((size_t)d.B * inner * p.npad); I.kvT = take((size_t)d.B * 2 * inner * p.npad); }
     I.total = o;
     p.off_arg = 2 * (size_t)d.depth * I.total;
     p.saved_bytes = p.off_arg + up256((size_t)d.B * 2 * dim * 4);        // int32 argmax of the max pools
@@ -64,12 +94,33 @@ Plan make_plan(const tmf_fusion_desc& d) {
     p.nblk_ln = tmf_layernorm_bwd_blocks(p.R, d.dim);
     p.stride = 6 * d.dim + d.mlp;
     o = 0;
-    p.s_dx2 = take(R * dim); p.s_dh = take(R * mlp); p.s_dx1 = take(R * dim); p.s_dout = take(R * inner);
-    p.s_dq = take(R * inner); p.s_dkv = take(R * 2 * inner);
-    p.s_part = take((size_t)p.nblk * p.stride); p.s_lnpart = take((size_t)p.nblk_ln * 2 * dim);
-    for (int i = 0; i < 4; ++i) p.s_G[i] = take(R * dim);
     const int N5[5] = {d.dim, d.mlp, d.dim, 2 * p.inner, p.inner}, K5[5] = {d.mlp, d.dim, p.inner, d.dim, d.dim};
-    p.ws_bytes = tmf_tok_wgrad_multi_workspace_bytes(5, N5, K5);
+    if (p.fused) {
+        // per instance (kept until the one weight-gradient launch at the end): dx2, dh, dx1, dq, dkv, column-sum partials
+        p.stride = tmf_xf_part_stride();
+        p.s_dx2 = take(R * dim); p.s_dh = take(R * mlp); p.s_dx1 = take(R * dim); p.s_dq = take(R * inner);
+        p.s_dkv = take(R * 2 * inner); p.s_part = take((size_t)d.B * p.tiles * p.stride);
+        p.inst_stride = o;
+        o = p.inst_stride * (size_t)(2 * d.depth > 0 ? 2 * d.depth : 1);
+        p.s_dout = take(R * inner); p.s_doutT = take((size_t)d.B * inner * p.npad);
+        p.s_delta = take((size_t)d.B * d.heads * p.npad);
+        p.s_lnpart = o;
+        for (int i = 0; i < 4; ++i) p.s_G[i] = take(R * dim);
+        int n_inst = 2 * d.depth;
+        if (n_inst > WG_CHUNK / 5) n_inst = WG_CHUNK / 5;
+        if (n_inst < 1) n_inst = 1;
+        int Nc[WG_CHUNK], Kc[WG_CHUNK];
+        for (int i = 0; i < n_inst; ++i)
+            for (int j = 0; j < 5; ++j) { Nc[5 * i + j] = N5[j]; Kc[5 * i + j] = K5[j]; }
+        p.ws_bytes = tmf_tok_wgrad_multi_workspace_bytes(5 * n_inst, Nc, Kc);
+    } else {
+        p.s_dx2 = take(R * dim); p.s_dh = take(R * mlp); p.s_dx1 = take(R * dim); p.s_dout = take(R * inner);
+        p.s_dq = take(R * inner); p.s_dkv = take(R * 2 * inner);
+        p.s_part = take((size_t)p.nblk * p.stride); p.s_lnpart = take((size_t)p.nblk_ln * 2 * dim);
+        p.s_doutT = p.s_delta = p.inst_stride = 0;
+        for (int i = 0; i < 4; ++i) p.s_G[i] = take(R * dim);
+        p.ws_bytes = tmf_tok_wgrad_multi_workspace_bytes(5, N5, K5);
+    }
     if (p.ws_bytes < 16) p.ws_bytes = 16;
     p.s_ws = take(p.ws_bytes / 4 + 1);
     p.scratch_bytes = o;
@@ -135,6 +186,38 @@ extern "C" int tmf_fusion_train_fwd(const tmf_fusion_desc* d, const float* mri_t
     char* base = (char*)saved;
     const float* m = mri_tok;
     const float* q = pet_tok;
+    for (int i = 0; i < 2 * d->depth; ++i)
+        TMF_REQUIRE(p.fused || (!inst[i].mask_o && !inst[i].mask_g && !inst[i].mask_f), TMF_E_SHAPE,
+                    "tmf_fusion_train_fwd: Dropout masks need the fused kernels (dim 128, 4 heads of 32, mlp 512, N <= 512)");
+    if (p.fused && d->depth > 0) {
+        const float scale = 1.0f / sqrtf((float)d->dim_head);
+        hipStream_t s = (hipStream_t)stream;
+        const int n_inst = 2 * d->depth;
+        {   // K | V of the first instance's context (the pet tokens)
+            tmf_xf_fwd_io io = {};
+            io.x = pet_tok; io.wkv_next = inst[0].wkv;
+            io.kv_next = F(base, p.I.kv); io.kvT_next = F(base, p.I.kvT);
+            TMF_TRY(tmf_xf_launch_fwd(d->B, d->N, nullptr, &io, scale, 1, s));
+        }
+        for (int i = 0; i < n_inst; ++i) {
+            char* sv = base + (size_t)i * p.I.total;
+            const InstPlan& I = p.I;
+            tmf_xf_fwd_io io = {};
+            io.x = (i & 1) ? q : m;
+            io.kv = F(sv, I.kv); io.kvT = F(sv, I.kvT);
+            io.mask_o = inst[i].mask_o; io.mask_g = inst[i].mask_g; io.mask_f = inst[i].mask_f;
+            io.a = F(sv, I.a); io.q = F(sv, I.q); io.qT = F(sv, I.qT); io.out = F(sv, I.out); io.lse = F(sv, I.lse);
+            io.x1 = F(sv, I.x1); io.f = F(sv, I.f); io.h = F(sv, I.h); io.g = F(sv, I.g); io.x2 = F(sv, I.x2); io.y = F(sv, I.y);
+            io.m1 = F(sv, I.m1); io.r1 = F(sv, I.r1); io.m2 = F(sv, I.m2); io.r2 = F(sv, I.r2); io.mf = F(sv, I.mf); io.rf = F(sv, I.rf);
+            if (i + 1 < n_inst) {           // this output is the next instance's context
+                io.wkv_next = inst[i + 1].wkv;
+                io.kv_next = F(sv + p.I.total, I.kv); io.kvT_next = F(sv + p.I.total, I.kvT);
+            }
+            TMF_TRY(tmf_xf_launch_fwd(d->B, d->N, &inst[i], &io, scale, 0, s));
+            if (i & 1) q = F(sv, I.y); else m = F(sv, I.y);
+        }
+        return tmf_token_pool_fwd(m, q, cls, (int32_t*)(base + p.off_arg), d->B, d->N, d->dim, stream);
+    }
     for (int l = 0; l < d->depth; ++l) {
         char* sm = base + (size_t)(2 * l) * p.I.total;
         char* sp = base + (size_t)(2 * l + 1) * p.I.total;
@@ -185,6 +268,26 @@ static int instance_bwd(const tmf_fusion_desc& d, const Plan& p, const tmf_xform
     return tmf_tok_wgrad_multi(5, dys, xs, dws, Rs, Ns, Ks, sc + p.s_ws, p.ws_bytes, stream);
 }
 
+// Fused form of instance_bwd: two launches (query side, key side); weight gradients and column sums are left to the caller.
+static int instance_bwd_fused(const tmf_fusion_desc& d, const Plan& p, const tmf_xformer_params& w, int idx, const float* x,
+                              const char* sv_, const float* dy, const float* dctx_acc, float* dx_out, float* dctx_out,
+                              char* sc, void* stream) {
+    char* sv = const_cast<char*>(sv_);
+    const InstPlan& I = p.I;
+    char* si = sc + (size_t)idx * p.inst_stride;
+    tmf_xf_bwd_io io = {};
+    io.dy = dy; io.x = x; io.kv = F(sv, I.kv); io.kvT = F(sv, I.kvT);
+    io.mask_o = w.mask_o; io.mask_g = w.mask_g; io.mask_f = w.mask_f;
+    io.q = F(sv, I.q); io.qT = F(sv, I.qT); io.out = F(sv, I.out); io.lse = F(sv, I.lse); io.x1 = F(sv, I.x1); io.h = F(sv, I.h);
+    io.x2 = F(sv, I.x2); io.m1 = F(sv, I.m1); io.r1 = F(sv, I.r1); io.m2 = F(sv, I.m2); io.r2 = F(sv, I.r2);
+    io.mf = F(sv, I.mf); io.rf = F(sv, I.rf);
+    io.dx2 = F(si, p.s_dx2); io.dh = F(si, p.s_dh); io.dx1 = F(si, p.s_dx1); io.dq = F(si, p.s_dq); io.dkv = F(si, p.s_dkv);
+    io.part = F(si, p.s_part);
+    io.dout = F(sc, p.s_dout); io.doutT = F(sc, p.s_doutT); io.delta = F(sc, p.s_delta);
+    io.dx = dx_out; io.dctx = dctx_out; io.dctx_acc = dctx_acc;
+    return tmf_xf_launch_bwd(d.B, d.N, &w, &io, 1.0f / sqrtf((float)d.dim_head), (hipStream_t)stream);
+}
+
 extern "C" int tmf_fusion_train_bwd(const tmf_fusion_desc* d, const float* mri_tok, const float* pet_tok,
                                     const tmf_xformer_params* inst, const void* saved, size_t saved_bytes, const float* dcls,
                                     const tmf_xformer_grads* grads, float* dmri_tok, float* dpet_tok,
@@ -223,6 +326,15 @@ extern "C" int tmf_fusion_train_bwd(const tmf_fusion_desc* d, const float* mri_t
         // pet instance l: own input p_in, context m_new; its output gradient is Gp, the context has collected Gm so far
         float* Gp_own = G[2];                       // dy + d/d(p_in) through the pet instance
         float* Gm_full = G[3];                      // Gm + d/d(m_new) through the pet instance's keys / values
+        if (p.fused) {
+            TMF_TRY(instance_bwd_fused(*d, p, inst[2 * l + 1], 2 * l + 1, p_in, sp, Gp, Gm, Gp_own, Gm_full, sc, stream));
+            float* Gm_nx = l == 0 ? dmri_tok : G[0];
+            float* Gp_nx = l == 0 ? dpet_tok : G[1];
+            TMF_TRY(instance_bwd_fused(*d, p, inst[2 * l], 2 * l, m_in, sm, Gm_full, Gp_own, Gm_nx, Gp_nx, sc, stream));
+            Gm = Gm_nx;
+            Gp = Gp_nx;
+            continue;
+        }
         TMF_TRY(instance_bwd(*d, p, inst[2 * l + 1], grads[2 * l + 1], p_in, m_new, sp, Gp, Gm, Gp_own, Gm_full, sc, stream));
         // mri instance l: own input m_in, context p_in; output gradient Gm_full, the context has collected Gp_own
         float* Gm_next = l == 0 ? dmri_tok : G[0];
@@ -230,6 +342,45 @@ extern "C" int tmf_fusion_train_bwd(const tmf_fusion_desc* d, const float* mri_t
         TMF_TRY(instance_bwd(*d, p, inst[2 * l], grads[2 * l], m_in, p_in, sm, Gm_full, Gp_own, Gm_next, Gp_next, sc, stream));
         Gm = Gm_next;
         Gp = Gp_next;
+    }
+    if (p.fused && depth > 0) {
+        // every bias / LayerNorm gradient of every instance: one column-sum launch over the per-tile partials
+        const int n_inst = 2 * depth;
+        const float* parts[2 * TMF_FUSION_MAX_DEPTH];
+        float* smalls[2 * TMF_FUSION_MAX_DEPTH];
+        float* lnfs[2 * TMF_FUSION_MAX_DEPTH];
+        for (int i = 0; i < n_inst; ++i) {
+            parts[i] = F(sc + (size_t)i * p.inst_stride, p.s_part);
+            smalls[i] = grads[i].small;
+            lnfs[i] = grads[i].lnf;
+        }
+        TMF_TRY(tmf_xf_launch_colsum(n_inst, parts, smalls, lnfs, d->B * p.tiles, (hipStream_t)stream));
+        // the five weight gradients of every instance: table-driven launches of up to WG_CHUNK problems
+        const int R = p.R, dim = d->dim, inner = p.inner, mlp = d->mlp;
+        for (int i0 = 0; i0 < n_inst; i0 += WG_CHUNK / 5) {
+            const int ni = (n_inst - i0) < WG_CHUNK / 5 ? (n_inst - i0) : WG_CHUNK / 5;
+            const float* dys[WG_CHUNK];
+            const float* xs[WG_CHUNK];
+            float* dws[WG_CHUNK];
+            int Rs[WG_CHUNK], Ns[WG_CHUNK], Ks[WG_CHUNK];
+            for (int k = 0; k < ni; ++k) {
+                const int i = i0 + k, l = i >> 1;
+                char* sv = const_cast<char*>(base) + (size_t)i * p.I.total;
+                char* si = sc + (size_t)i * p.inst_stride;
+                // the context of instance i: pet tokens entering layer l (mri instance) / the NEW mri tokens (pet instance)
+                const float* ctx = (i & 1) ? (const float*)(base + (size_t)(2 * l) * p.I.total + p.I.y)
+                                           : (l == 0 ? pet_tok : (const float*)(base + (size_t)(2 * (l - 1) + 1) * p.I.total + p.I.y));
+                const float* dy5[5] = {F(si, p.s_dx2), F(si, p.s_dh), F(si, p.s_dx1), F(si, p.s_dkv), F(si, p.s_dq)};
+                const float* x5[5] = {F(sv, p.I.g), F(sv, p.I.f), F(sv, p.I.out), ctx, F(sv, p.I.a)};
+                float* dw5[5] = {grads[i].dw2, grads[i].dw1, grads[i].dwo, grads[i].dwkv, grads[i].dwq};
+                const int N5[5] = {dim, mlp, dim, 2 * inner, inner}, K5[5] = {mlp, dim, inner, dim, dim};
+                for (int j = 0; j < 5; ++j) {
+                    dys[5 * k + j] = dy5[j]; xs[5 * k + j] = x5[j]; dws[5 * k + j] = dw5[j];
+                    Rs[5 * k + j] = R; Ns[5 * k + j] = N5[j]; Ks[5 * k + j] = K5[j];
+                }
+            }
+            TMF_TRY(tmf_tok_wgrad_multi(5 * ni, dys, xs, dws, Rs, Ns, Ks, sc + p.s_ws, p.ws_bytes, stream));
+        }
     }
     return TMF_OK;
 }

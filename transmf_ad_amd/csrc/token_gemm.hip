@@ -295,7 +295,7 @@ extern "C" int tmf_tok_linear_bwd_input(const float* dy, const float* w, float* 
 
 // ------------------------------------------------------------------------------------------------------------
 // Weight gradients of the block's Linears, all in one launch:  dW_p[n][k] = sum_r dy_p[r][n] * x_p[r][k]  for up to
-// 8 problems p (the five of a Transformer block: to_q, to_kv, to_out, the two FeedForward layers).  One workgroup =
+// 32 problems p (the five of a Transformer block: to_q, to_kv, to_out, the two FeedForward layers).  One workgroup =
 // one 32 x 32 tile of one dW and one of NSPLIT row ranges; its 4 waves take a quarter of the range each (both
 // operands straight from L2: a lane reads dy[row][n0 + lane&31] / x[row][k0 + lane&31], rows 2 s + lane>>5 — coalesced
 // 128-B segments, no LDS staging), v_mfma_f32_32x32x2_f32, cross-wave sum in LDS, partial tile to the workspace; a
@@ -303,7 +303,7 @@ extern "C" int tmf_tok_linear_bwd_input(const float* dy, const float* w, float* 
 // ------------------------------------------------------------------------------------------------------------
 namespace {
 
-constexpr int WG_MAXP = 8, WG_NSPLIT = 8;
+constexpr int WG_MAXP = 32, WG_NSPLIT = 8;
 struct WgMulti {
     const float* dy[WG_MAXP]; const float* x[WG_MAXP]; float* dw[WG_MAXP];
     int R[WG_MAXP], N[WG_MAXP], K[WG_MAXP], tile0[WG_MAXP + 1], elem0[WG_MAXP + 1];

@@ -195,12 +195,15 @@ class Transformer(nn.Module):
                 PreNorm(dim, Attention(dim, heads=heads, dim_head=dim_head, dropout=dropout)),
                 PreNorm(dim, FeedForward(dim, mlp_dim, dropout=dropout))]))
 
-    def _fused(self, x):
+    def _dropout_active(self):
+        if self._drops is None:           # the module-tree walk costs ~0.5 ms: done once, the p values are read live
+            self._drops = [m for m in self.modules() if isinstance(m, nn.Dropout) or hasattr(m, "tmf_keep_mask")]
+        return any(m.training and (hasattr(m, "tmf_keep_mask") or m.p > 0) for m in self._drops)
+
+    def _fused(self, x, allow_dropout=False):
         attn, ff = self.layers[0]
         a, f = attn.fn, ff.fn
-        if self._drops is None:           # the module-tree walk costs ~0.5 ms: done once, the p values are read live
-            self._drops = [m for m in self.modules() if isinstance(m, nn.Dropout)]
-        drop = self.training and any(m.p > 0 for m in self._drops)
+        drop = (not allow_dropout) and self._dropout_active()
         return (not drop) and x.is_cuda and ops.fused_block_supported(x.shape[-1], a.to_q.out_features,
                                                                       f.net[0].out_features)
 
@@ -259,9 +262,13 @@ class CrossTransformer_MOD_AVG(nn.Module):
         if not ops.fusion_one_call_supported(mri_tokens.shape[-1], inner, f.net[0].out_features, inner // a.heads,
                                              len(self.layers)):
             return False
+        # Dropout (options/option.py:39) stays on the HIP path where the fused per-instance kernels take the masks
+        masks_ok = ops.fusion_fused_supported(mri_tokens.shape[1], mri_tokens.shape[-1], a.heads, inner // a.heads,
+                                              f.net[0].out_features)
         for pair in self.layers:
             for tr in pair:
-                if len(tr.layers) != 1 or not tr._fused(mri_tokens) or tr._forward_hooks or tr._forward_pre_hooks:
+                if (len(tr.layers) != 1 or not tr._fused(mri_tokens, allow_dropout=masks_ok) or tr._forward_hooks
+                        or tr._forward_pre_hooks):
                     return False
                 at = tr.layers[0][0].fn
                 if at.heads != a.heads or at.to_q.out_features != inner or at.scale != (inner // a.heads) ** -0.5:
@@ -271,18 +278,20 @@ class CrossTransformer_MOD_AVG(nn.Module):
     @device_guard
     def forward(self, mri_tokens, pet_tokens):
         if self._one_call_ok(mri_tokens):
-            params, eps = [], []
+            params, eps, drops = [], [], []
             for pair in self.layers:
                 for tr in pair:
                     pa, pf = tr.layers[0]
                     a, f = pa.fn, pf.fn
+                    drops.append((a.to_out[1], f.net[2], f.net[4]))
                     params += [pa.norm.weight, pa.norm.bias, a.to_q.weight, a.to_kv.weight, a.to_out[0].weight,
                                a.to_out[0].bias, pf.norm.weight, pf.norm.bias, f.net[0].weight, f.net[0].bias,
                                f.net[3].weight, f.net[3].bias, tr.norm.weight, tr.norm.bias]
                     eps.append((float(pa.norm.eps), float(pf.norm.eps), float(tr.norm.eps)))
             a0 = self.layers[0][0].layers[0][0].fn
             f0 = self.layers[0][0].layers[0][1].fn
-            cfg = (a0.heads, a0.to_q.out_features // a0.heads, f0.net[0].out_features, len(self.layers), tuple(eps))
+            cfg = (a0.heads, a0.to_q.out_features // a0.heads, f0.net[0].out_features, len(self.layers), tuple(eps),
+                   tuple(drops) if any(tr._dropout_active() for pair in self.layers for tr in pair) else None)
             return ops.FusionTrain.apply(mri_tokens, pet_tokens, cfg, *params)
         for mri_enc, pet_enc in self.layers:
             # (Transformer.forward can fold this "+ tokens" into its last LayerNorm pass via residual=; it is left

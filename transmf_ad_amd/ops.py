@@ -826,6 +826,28 @@ def transformer_layer(x, context, ln1, attn, ln2, ff):
 # --------------------------------------------------------------------------------------
 
 FUSION_ONE_CALL = os.environ.get("TMF_FUSION_C", "1") != "0"
+# the fused per-instance kernels (csrc/xformer_fused.hip) inside the one-call path; "0" keeps one launch per Linear
+FUSION_FUSED_KERNELS = os.environ.get("TMF_FUSION_FUSED", "1") != "0"
+
+
+def fusion_fused_supported(N, dim, heads, dim_head, mlp):
+    """Shapes the fused per-instance kernels take (tmf_xf_supported, csrc/xformer_fused.hip)."""
+    return (FUSION_ONE_CALL and FUSION_FUSED_KERNELS and dim == 128 and heads == 4 and dim_head == 32 and mlp == 512
+            and 1 <= N <= 512)
+
+
+def dropout_keep_mask(drop, shape, device):
+    """Scaled keep-mask of an nn.Dropout in train mode (None when inactive).  A module that provides
+    ``tmf_keep_mask(training)`` (tests: fixed masks captured from the reference) supplies its own."""
+    if hasattr(drop, "tmf_keep_mask"):
+        m = drop.tmf_keep_mask(drop.training)
+        return None if m is None else m.to(device=device, dtype=_f32).reshape(shape).contiguous()
+    p = float(getattr(drop, "p", 0.0))
+    if not drop.training or p <= 0.0:
+        return None
+    if p >= 1.0:
+        return torch.zeros(shape, device=device, dtype=_f32)
+    return torch.empty(shape, device=device, dtype=_f32).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
 def fusion_one_call_supported(dim, inner, mlp, dim_head, depth):
@@ -842,12 +864,15 @@ class FusionTrain(torch.autograd.Function):
     def forward(ctx, mri, pet, cfg, *params):
         import ctypes as C
         mri, pet = _chk(mri, "mri_tokens"), _chk(pet, "pet_tokens")
-        heads, dim_head, mlp, depth, eps = cfg
+        heads, dim_head, mlp, depth, eps = cfg[:5]
+        drops = cfg[5] if len(cfg) > 5 else None      # per instance the three nn.Dropout modules (to_out, GELU, Linear 2)
         B, N, dim = mri.shape
         if pet.shape != mri.shape:
             raise _lib.TmfError(f"token shapes differ: {tuple(mri.shape)} vs {tuple(pet.shape)}")
-        desc = _lib.FusionDesc(B=B, N=N, dim=dim, heads=heads, dim_head=dim_head, mlp=mlp, depth=depth)
+        desc = _lib.FusionDesc(B=B, N=N, dim=dim, heads=heads, dim_head=dim_head, mlp=mlp, depth=depth,
+                               flags=0 if FUSION_FUSED_KERNELS else _lib.FUSION_PER_OP)
         inst = (_lib.XformerParams * (2 * depth))()
+        masks = []
         for i in range(2 * depth):
             for j, name in enumerate(_lib.XFORMER_PTRS):
                 t = params[14 * i + j]
@@ -855,6 +880,12 @@ class FusionTrain(torch.autograd.Function):
                     raise _lib.TmfError(f"Transformer instance {i}: {name} must be a contiguous float32 HIP tensor")
                 setattr(inst[i], name, t.data_ptr())
             inst[i].eps1, inst[i].eps2, inst[i].epsf = eps[i]
+            if drops is not None:
+                for name, drop, width in zip(("mask_o", "mask_g", "mask_f"), drops[i], (dim, mlp, dim)):
+                    mk = dropout_keep_mask(drop, (B * N, width), mri.device)
+                    if mk is not None:
+                        masks.append(mk)
+                        setattr(inst[i], name, mk.data_ptr())
         nsaved = _lib.query("tmf_fusion_saved_bytes", C.byref(desc))
         if nsaved == 0:
             raise _lib.TmfError("tmf_fusion_saved_bytes: " + (_lib.load().tmf_last_error_string() or b"").decode())
@@ -864,7 +895,8 @@ class FusionTrain(torch.autograd.Function):
                   cls.data_ptr(), _stream())
         ctx.save_for_backward(mri, pet, saved, *params)     # parameters too: autograd then rejects an in-place update
         ctx.desc, ctx.inst = desc, inst                     # between forward and backward; their pointers stay valid:
-        return cls                                          # the ctypes structs are reused as they are
+        ctx.masks = masks                                   # the ctypes structs are reused as they are
+        return cls
 
     @staticmethod
     def backward(ctx, dcls):
