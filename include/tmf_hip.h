@@ -315,9 +315,18 @@ int tmf_token_pool_bwd(const float* dcls, const int32_t* argmax, float* dmri, fl
  * oracle/input_oracle.py):  minmax[b] = (min, max) of volume b;  dst = (src - min) / (max - min)  (a constant volume
  * gives zeros, as monai.transforms.utils.rescale_array);  flip_d[b] != 0 reverses the first spatial axis of volume b
  * (the random decision itself stays with the caller: MONAI draws it from its own RandomState).  vol / src / dst:
- * [B][D][H][W] fp32;  workspace >= tmf_scale_intensity_workspace_bytes(B).  RandRotated / RandZoomd are not provided.
+ * [B][D][H][W] fp32;  workspace >= tmf_scale_intensity_workspace_bytes(B).
  * ---------------------------------------------------------------------------- */
 size_t tmf_scale_intensity_workspace_bytes(int B);
+/* RandRotated(range_x=0.05, prob=0.3) / RandZoomd(min_zoom=0.95, max_zoom=1, prob=0.3) of datasets/ADNI.py:67-68 with the
+ * random decisions as inputs: dst[b] = Rotate(angle about the first spatial axis; bilinear, border padding, keep_size)
+ * of src[b] where do_rot[b] != 0 (cos_sin[b] = {cos, sin} of the angle in fp32), a copy otherwise;  dst[b] = Zoom(mode
+ * "area", edge padding, keep_size) to out_size[b] = {floor(D z), floor(H z), floor(W z)} (1 <= out <= size) where
+ * do_zoom[b] != 0, a copy otherwise.  Bit-identical to oracle/input_oracle.py rotate_x / zoom_area.  Not in place. */
+int    tmf_rotate_x(const float* src, float* dst, const float* cos_sin, const unsigned char* do_rot,
+                    int B, int D, int H, int W, void* stream);
+int    tmf_zoom_area(const float* src, float* dst, const int* out_size, const unsigned char* do_zoom,
+                     int B, int D, int H, int W, void* stream);
 int    tmf_volume_minmax(const float* vol, float* minmax, void* workspace, size_t workspace_bytes, int B, long voxels,
                          void* stream);
 int    tmf_scale_flip(const float* src, float* dst, const float* minmax, const unsigned char* flip_d,
@@ -422,6 +431,9 @@ typedef struct tmf_xformer_params {
 typedef struct tmf_xformer_grads {
     float *small, *lnf, *dwq, *dwkv, *dwo, *dw1, *dw2;
 } tmf_xformer_grads;
+/* Debugging hook (tools/xf_trace.py): when non-NULL, every wave of the fused kernels writes its phase time stamps
+ * (shader clock) to fwd / bwd_q / bwd_kv, each [workgroups][4][16] uint64.  NULL (the default) turns it off. */
+void   tmf_debug_xf_trace(void* fwd, void* bwd_q, void* bwd_kv);
 size_t tmf_fusion_saved_bytes(const tmf_fusion_desc* d);
 size_t tmf_fusion_bwd_scratch_bytes(const tmf_fusion_desc* d);
 int    tmf_fusion_train_fwd(const tmf_fusion_desc* d, const float* mri_tok, const float* pet_tok,

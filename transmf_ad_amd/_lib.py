@@ -109,6 +109,8 @@ PROTOTYPES.update({
     "tmf_scale_intensity_workspace_bytes": (_z, [_i]),
     "tmf_volume_minmax": (_i, [_p, _p, _p, _z, _i, _l, _p]),
     "tmf_scale_flip": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "tmf_rotate_x": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "tmf_zoom_area": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "tmf_snet_saved_bytes": (_z, [C.POINTER(SnetDesc)]),
     "tmf_snet_bwd_scratch_bytes": (_z, [C.POINTER(SnetDesc)]),
     "tmf_snet_train_fwd": (_i, [C.POINTER(SnetDesc), _p, C.POINTER(SnetParams), _p, _z, _p, _p]),
@@ -139,6 +141,7 @@ class XformerGrads(C.Structure):
 
 
 PROTOTYPES.update({
+    "tmf_debug_xf_trace": (None, [_p, _p, _p]),
     "tmf_fusion_saved_bytes": (_z, [C.POINTER(FusionDesc)]),
     "tmf_fusion_bwd_scratch_bytes": (_z, [C.POINTER(FusionDesc)]),
     "tmf_fusion_train_fwd": (_i, [C.POINTER(FusionDesc), _p, _p, C.POINTER(XformerParams), _p, _z, _p, _p]),

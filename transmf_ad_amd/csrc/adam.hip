@@ -4,7 +4,7 @@
 // lr 1e-4, betas (0.9, 0.999), eps 1e-8, weight decay 0) over the 156 parameter tensors of model_ad (4.17 M floats).
 // torch's multi-tensor Adam needs ~10 launches for them (its per-launch tensor table is a kernel argument of limited
 // size); here every tensor's pointers ride in ONE kernel-argument table (the two moment estimates live in two flat
-// buffers owned by the optimizer, so a tensor costs 8 + 8 + 4 + 4 bytes) and a workgroup finds its tensor by a binary
+// buffers owned by the optimizer, so a tensor costs 8 + 8 + 4 + 4 + 4 = 28 bytes of table) and a workgroup finds its tensor by a binary
 // search over the chunk prefix sums.  SURVEY.md §8f rank 2.
 //
 // Update (torch.optim.Adam, amsgrad = False, maximize = False; weight_decay is L2 as in torch):

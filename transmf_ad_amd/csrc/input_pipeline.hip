@@ -11,11 +11,17 @@
 //     mina, maxa = arr.min(), arr.max();  mina == maxa -> arr * minv;  else (arr - mina) / (maxa - mina) * (maxv - minv) + minv
 // and monai.transforms.Flip(spatial_axis=0) = torch.flip along the first spatial axis — restated in oracle/input_oracle.py.
 // Both are exact in fp32 (min / max are order-independent, the division is IEEE-correctly rounded), so the GPU result is
-// BIT-identical to the numpy restatement.  RandRotated / RandZoomd (ADNI.py:67-68) interpolate (MONAI: bilinear grid
-// sample / trilinear zoom with its own align-corners and padding conventions) and are NOT implemented: their parity
-// cannot be pinned without the library.
+// BIT-identical to the numpy restatement.
 //
-// HBM-bound streaming passes: 4 B read (min/max) + 4 B read + 4 B write (scale) per voxel.
+// Round 3: RandRotated(range_x=0.05, prob=0.3) and RandZoomd(min_zoom=0.95, max_zoom=1, prob=0.3) (ADNI.py:67-68) as
+// device kernels too.  Their published algorithm (MONAI Rotate: pull-direction rotation about the first spatial axis
+// around the volume centre, bilinear, border padding; Zoom: area interpolation = adaptive average to floor(S z) per axis,
+// edge padding back to the original size) is restated with a fixed fp32 operation order in oracle/input_oracle.py
+// (`rotate_x`, `zoom_area`; the latter bit-identical to torch's CPU interpolate(mode="area"), the former within 2e-5 of
+// torch's affine_grid + grid_sample route) and evaluated here with un-contracted __f*_rn operations in that order: the
+// device results are BIT-identical to that restatement.  The random decisions (apply?, angle, factor) are inputs.
+//
+// HBM-bound streaming passes: 4 B read (min/max) + 4 B read + 4 B write (scale) per voxel; rotate / zoom 4 B + 4 B.
 #include "tmf_common.h"
 
 namespace {
@@ -100,7 +106,88 @@ __global__ __launch_bounds__(256) void scale_flip_kernel(const float* __restrict
     }
 }
 
+// dst[b][d][h][w] = bilinear sample of plane d of src[b] at the rotated point (oracle/input_oracle.py rotate_x), or a
+// copy when do_rot[b] == 0.  cos_sin[b] = (cos, sin) of the angle, rounded to fp32 on the host.
+__global__ __launch_bounds__(256) void rotate_x_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                       const float* __restrict__ cos_sin, const unsigned char* __restrict__ do_rot,
+                                                       int D, int H, int W) {
+    const int b = blockIdx.z, d = blockIdx.y;
+    const long plane = (long)H * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= plane) return;
+    const float* s = src + ((size_t)b * D + d) * plane;
+    float* o = dst + ((size_t)b * D + d) * plane;
+    if (!do_rot[b]) { o[i] = s[i]; return; }
+    const int h = (int)(i / W), w = (int)(i - (long)h * W);
+    const float cs = cos_sin[2 * b], sn = cos_sin[2 * b + 1];
+    const float c1 = 0.5f * (float)(H - 1), c2 = 0.5f * (float)(W - 1);
+    const float o1 = __fsub_rn((float)h, c1), o2 = __fsub_rn((float)w, c2);
+    float s1 = __fadd_rn(c1, __fsub_rn(__fmul_rn(cs, o1), __fmul_rn(sn, o2)));
+    float s2 = __fadd_rn(c2, __fadd_rn(__fmul_rn(sn, o1), __fmul_rn(cs, o2)));
+    s1 = fminf(fmaxf(s1, 0.f), (float)(H - 1));
+    s2 = fminf(fmaxf(s2, 0.f), (float)(W - 1));
+    const float f1 = floorf(s1), f2 = floorf(s2);
+    const float t1 = __fsub_rn(s1, f1), t2 = __fsub_rn(s2, f2);
+    const float a = __fsub_rn(1.f, t1), bb = __fsub_rn(1.f, t2);
+    const int i1 = (int)f1, i2 = (int)f2;
+    const int j1 = i1 + 1 < H ? i1 + 1 : H - 1, j2 = i2 + 1 < W ? i2 + 1 : W - 1;
+    const float v00 = s[(long)i1 * W + i2], v01 = s[(long)i1 * W + j2], v10 = s[(long)j1 * W + i2], v11 = s[(long)j1 * W + j2];
+    float r = __fadd_rn(__fmul_rn(v00, __fmul_rn(a, bb)), __fmul_rn(v01, __fmul_rn(a, t2)));
+    r = __fadd_rn(r, __fmul_rn(v10, __fmul_rn(t1, bb)));
+    r = __fadd_rn(r, __fmul_rn(v11, __fmul_rn(t1, t2)));
+    o[i] = r;
+}
+
+// dst[b] = zoom_area(src[b]) (oracle/input_oracle.py): adaptive average to out_size[b] = (Od, Oh, Ow), edge padding back
+// to (D, H, W); a copy when do_zoom[b] == 0.
+__global__ __launch_bounds__(256) void zoom_area_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                        const int* __restrict__ out_size, const unsigned char* __restrict__ do_zoom,
+                                                        int D, int H, int W) {
+    const int b = blockIdx.z, d = blockIdx.y;
+    const long plane = (long)H * W;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= plane) return;
+    const float* s = src + (size_t)b * D * plane;
+    float* o = dst + ((size_t)b * D + d) * plane;
+    if (!do_zoom[b]) { o[i] = s[(size_t)d * plane + i]; return; }
+    const int h = (int)(i / W), w = (int)(i - (long)h * W);
+    const int Od = out_size[3 * b], Oh = out_size[3 * b + 1], Ow = out_size[3 * b + 2];
+    auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); };
+    const int zd = clampi(d - (D - Od) / 2, Od - 1), zh = clampi(h - (H - Oh) / 2, Oh - 1), zw = clampi(w - (W - Ow) / 2, Ow - 1);
+    const int d0 = (int)(((long)zd * D) / Od), d1 = (int)((((long)zd + 1) * D + Od - 1) / Od);
+    const int h0 = (int)(((long)zh * H) / Oh), h1 = (int)((((long)zh + 1) * H + Oh - 1) / Oh);
+    const int w0 = (int)(((long)zw * W) / Ow), w1 = (int)((((long)zw + 1) * W + Ow - 1) / Ow);
+    float acc = 0.f;
+    for (int a = d0; a < d1; ++a)
+        for (int bq = h0; bq < h1; ++bq)
+            for (int c = w0; c < w1; ++c) acc = __fadd_rn(acc, s[((size_t)a * H + bq) * W + c]);
+    acc = __fdiv_rn(acc, (float)(d1 - d0));
+    acc = __fdiv_rn(acc, (float)(h1 - h0));
+    acc = __fdiv_rn(acc, (float)(w1 - w0));
+    o[i] = acc;
+}
+
 }  // namespace
+
+extern "C" int tmf_rotate_x(const float* src, float* dst, const float* cos_sin, const unsigned char* do_rot,
+                            int B, int D, int H, int W, void* stream) {
+    TMF_REQUIRE_PTR(src); TMF_REQUIRE_PTR(dst); TMF_REQUIRE_PTR(cos_sin); TMF_REQUIRE_PTR(do_rot);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && B <= 65535 && D <= 65535, TMF_E_SHAPE, "tmf_rotate_x: B=%d D=%d H=%d W=%d", B, D, H, W);
+    TMF_REQUIRE(src != dst, TMF_E_ARG, "tmf_rotate_x: not in place");
+    hipLaunchKernelGGL(rotate_x_kernel, dim3((unsigned)tmf_cdiv((long)H * W, 256L), D, B), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, cos_sin, do_rot, D, H, W);
+    return tmf_launch_result("tmf_rotate_x");
+}
+
+extern "C" int tmf_zoom_area(const float* src, float* dst, const int* out_size, const unsigned char* do_zoom,
+                             int B, int D, int H, int W, void* stream) {
+    TMF_REQUIRE_PTR(src); TMF_REQUIRE_PTR(dst); TMF_REQUIRE_PTR(out_size); TMF_REQUIRE_PTR(do_zoom);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && B <= 65535 && D <= 65535, TMF_E_SHAPE, "tmf_zoom_area: B=%d D=%d H=%d W=%d", B, D, H, W);
+    TMF_REQUIRE(src != dst, TMF_E_ARG, "tmf_zoom_area: not in place");
+    hipLaunchKernelGGL(zoom_area_kernel, dim3((unsigned)tmf_cdiv((long)H * W, 256L), D, B), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, out_size, do_zoom, D, H, W);
+    return tmf_launch_result("tmf_zoom_area");
+}
 
 extern "C" size_t tmf_scale_intensity_workspace_bytes(int B) {
     return B > 0 ? (size_t)B * MM_BLOCKS * 2 * 4 : 0;

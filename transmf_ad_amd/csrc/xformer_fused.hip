@@ -51,6 +51,18 @@ constexpr float XLOG2E = 1.4426950408889634f;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// phase time stamps of every wave (shader clock) for tools/xf_trace.py: only in builds with -DTMF_XF_TRACE
+// (TMF_EXTRA_FLAGS=-DTMF_XF_TRACE python -m transmf_ad_amd.build); the product kernels carry none of it
+#ifdef TMF_XF_TRACE
+#define XF_STAMP(k)                                                                                                   \
+    do {                                                                                                              \
+        if (p.trace != nullptr && lane == 0)                                                                          \
+            p.trace[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define XF_STAMP(k) do { } while (0)
+#endif
+
 __device__ __forceinline__ float xgelu(float h) { return 0.5f * h * (1.f + erff(h * 0.70710678118654752f)); }
 __device__ __forceinline__ float xgelu_grad(float h) {
     return 0.5f * (1.f + erff(h * 0.70710678118654752f)) + h * 0.3989422804014327f * expf(-0.5f * h * h);
@@ -149,6 +161,7 @@ struct XfFwdArgs {
     float *a, *q, *qT, *out, *lse, *x1, *f, *h, *g, *x2, *y, *m1, *r1, *m2, *r2, *mf, *rf;     // saved for backward
     float *kv_next, *kvT_next;
     int B, N, Npad, tiles, only_kv;
+    unsigned long long* trace;
 };
 
 constexpr int XMLP = 512;
@@ -184,6 +197,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
     const int nv = (N - t0) < XT ? (N - t0) : XT;                 // valid rows of this tile
     const size_t row0 = (size_t)bz * N + t0;
 
+    XF_STAMP(0);
     // ---- P0: x tile, LayerNorm 1 ----
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -208,6 +222,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
     }
     __syncthreads();
 
+    XF_STAMP(1);
     if (!p.only_kv) {
         // ---- P1: q = LN1(x) Wq^T ----
         {
@@ -228,6 +243,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         }
         __syncthreads();
 
+        XF_STAMP(2);
         // ---- P2: attention, head = wave.  S^T[key][query] = K Q^T: a lane holds 4 keys per 16-key tile of ONE query ----
         {
             const int h = wave;
@@ -275,6 +291,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
                     sT[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 }
             }
+            XF_STAMP(3);
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float l = 0.f;
@@ -291,6 +308,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
             }
             l += __shfl_xor(l, 16);
             l += __shfl_xor(l, 32);
+            XF_STAMP(4);
             // O^T[d][query] = V^T P^T:  A = V^T (transposed copy: 4 consecutive keys of feature d per lane), B = P (own registers)
             const float* Vt = p.kvT + ((size_t)bz * (2 * XD) + XD + XDH * h + m) * Npad + 4 * kb;
             f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
@@ -324,6 +342,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         }
         __syncthreads();
 
+        XF_STAMP(5);
         // ---- P4: x1 = mask_o (out Wo^T + bo) + x ----
         {
             f32x4 acc[2];
@@ -348,6 +367,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         }
         __syncthreads();
 
+        XF_STAMP(6);
         // ---- LayerNorm 2 ----
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -366,6 +386,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         }
         __syncthreads();
 
+        XF_STAMP(7);
         // ---- P5: h = LN2(x1) W1^T + b1;  g = mask_g GELU(h) ----
         {
             f32x4 acc[8];
@@ -397,6 +418,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         }
         __syncthreads();
 
+        XF_STAMP(8);
         // ---- P6: x2 = mask_f (g W2^T + b2) + x1 ----
         {
             f32x4 acc[2];
@@ -421,6 +443,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         }
         __syncthreads();
 
+        XF_STAMP(9);
         // ---- final LayerNorm + the caller's "+ tokens" ----
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -442,6 +465,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         __syncthreads();
     }
 
+    XF_STAMP(10);
     // ---- P7: K | V of the next instance (its context = this output): row-major and transposed ----
     if (p.wkv_next != nullptr) {
         f32x4 acc[4];
@@ -456,6 +480,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) st4(p.kvT_next + ((size_t)bz * (2 * XD) + c0 + u) * Npad + t0 + 4 * kb, acc[u]);
     }
+    XF_STAMP(11);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -475,6 +500,7 @@ struct XfBwdQArgs {
     float* part;                    // [B*tiles][stride]: b2 | b1 | bo | ln2 g | ln2 b | ln1 g | ln1 b | lnf g | lnf b
     int stride;
     int B, N, Npad, tiles;
+    unsigned long long* trace;
 };
 
 __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
@@ -501,6 +527,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     float* part = p.part + ((size_t)bz * p.tiles + tile) * p.stride;
     const int o_b2 = 0, o_b1 = XD, o_bo = XD + XMLP, o_ln2 = 2 * XD + XMLP, o_ln1 = 4 * XD + XMLP, o_lnf = 6 * XD + XMLP;
 
+    XF_STAMP(0);
     // ---- S1: final LayerNorm backward (row-wise) ----
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -536,6 +563,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     tile_colsum(DY, XP, XD, part + o_lnf + XD, tid);
     tile_colsum(DX2M, XP, XD, part + o_b2, tid);
 
+    XF_STAMP(1);
     // ---- S2: dg = dx2m W2;  dh = dg * mask_g * GELU'(h) ----
     {
         f32x4 acc[8];
@@ -567,6 +595,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     __syncthreads();
     tile_colsum(DH, XGP, XMLP, part + o_b1, tid);
 
+    XF_STAMP(2);
     // ---- S3: df = dh W1 ----
     {
         f32x4 acc[2];
@@ -578,6 +607,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     }
     __syncthreads();
 
+    XF_STAMP(3);
     // ---- S4: LayerNorm 2 backward + the residual gradient dx2 ----
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -614,6 +644,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     tile_colsum(DF, XP, XD, part + o_ln2 + XD, tid);
     tile_colsum(DX1M, XP, XD, part + o_bo, tid);
 
+    XF_STAMP(4);
     // ---- S5: dout = dx1m Wo ----
     {
         f32x4 acc[2];
@@ -632,6 +663,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     }
     __syncthreads();
 
+    XF_STAMP(5);
     // ---- S6: dQ half of the attention backward, head = wave ----
     {
         const int h = wave;
@@ -709,6 +741,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     }
     __syncthreads();
 
+    XF_STAMP(6);
     // ---- S7: da = dq Wq ----
     {
         f32x4 acc[2];
@@ -720,6 +753,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     }
     __syncthreads();
 
+    XF_STAMP(7);
     // ---- S8: LayerNorm 1 backward + the residual gradients dx1 (attention block) and dy (the caller's "+ tokens") ----
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -747,6 +781,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     __syncthreads();
     tile_colsum(T1, XP, XD, part + o_ln1, tid);
     tile_colsum(DA, XP, XD, part + o_ln1 + XD, tid);
+    XF_STAMP(8);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -763,6 +798,7 @@ struct XfBwdKvArgs {
     float* dkv;                     // [R][256] (dy operand of to_kv's weight gradient)
     float* dctx;                    // [R][128]
     int B, N, Npad, tiles;
+    unsigned long long* trace;
 };
 
 constexpr int XKP = 2 * XD + 4;
@@ -778,6 +814,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
     const int t0 = tile * XT;
     const int nv = (N - t0) < XT ? (N - t0) : XT;
     const size_t row0 = (size_t)bz * N + t0;
+    XF_STAMP(0);
     {
         const int h = wave;
         const float c = p.scale * XLOG2E;
@@ -861,6 +898,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
             }
         }
     }
+    XF_STAMP(1);
     __syncthreads();
     // ---- dctx = dkv Wkv + what the context has collected ----
     {
@@ -881,6 +919,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
             }
         }
     }
+    XF_STAMP(2);
 }
 
 // Column sums of the per-tile partials of ALL instances in one launch: out = sum over the tile rows, fp64 accumulation in
@@ -920,6 +959,12 @@ constexpr size_t XF_BWDKV_LDS = (size_t)(XT * XKP) * 4;
 // ---------------------------------------------------------------------------------------------------------------------
 // host side: launchers used by fusion_path.hip (C++ linkage, declared there)
 // ---------------------------------------------------------------------------------------------------------------------
+static unsigned long long* g_xf_trace[3] = {nullptr, nullptr, nullptr};
+// debugging hook (tools/xf_trace.py): per-wave phase time stamps of the fused kernels, [workgroups][4 waves][16] uint64 each
+extern "C" void tmf_debug_xf_trace(void* fwd, void* bwd_q, void* bwd_kv) {
+    g_xf_trace[0] = (unsigned long long*)fwd; g_xf_trace[1] = (unsigned long long*)bwd_q; g_xf_trace[2] = (unsigned long long*)bwd_kv;
+}
+
 bool tmf_xf_supported(int N, int dim, int heads, int dim_head, int mlp) {
     return dim == XD && heads == XH && dim_head == XDH && mlp == XMLP && N >= 1 && N <= 512;
 }
@@ -947,6 +992,7 @@ int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fw
     a.x2 = io->x2; a.y = io->y; a.m1 = io->m1; a.r1 = io->r1; a.m2 = io->m2; a.r2 = io->r2; a.mf = io->mf; a.rf = io->rf;
     a.kv_next = io->kv_next; a.kvT_next = io->kvT_next;
     a.B = B; a.N = N; a.Npad = tmf_xf_npad(N); a.tiles = tmf_xf_tiles(N); a.only_kv = only_kv;
+    a.trace = only_kv ? nullptr : g_xf_trace[0];
     const dim3 grid(a.tiles, B), block(XTHR);
     const int mt = a.Npad / 16;
     int rc;
@@ -983,6 +1029,7 @@ int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bw
         a.dx2 = io->dx2; a.dh = io->dh; a.dx1 = io->dx1; a.dq = io->dq; a.dout = io->dout; a.doutT = io->doutT; a.delta = io->delta;
         a.dx = io->dx; a.part = io->part; a.stride = tmf_xf_part_stride();
         a.B = B; a.N = N; a.Npad = tmf_xf_npad(N); a.tiles = tmf_xf_tiles(N);
+        a.trace = g_xf_trace[1];
         auto kf = xf_bwd_q_kernel;
         if ((rc = tmf_allow_lds(kf, XF_BWDQ_LDS, "tmf_fusion_train_bwd(fused q)"))) return rc;
         hipLaunchKernelGGL(kf, dim3(a.tiles, B), dim3(XTHR), XF_BWDQ_LDS, s, a);
@@ -993,6 +1040,7 @@ int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bw
         a.q = io->q; a.qT = io->qT; a.kv = io->kv; a.lse = io->lse; a.delta = io->delta; a.dout = io->dout; a.doutT = io->doutT;
         a.wkv = w->wkv; a.dctx_acc = io->dctx_acc; a.scale = scale; a.dkv = io->dkv; a.dctx = io->dctx;
         a.B = B; a.N = N; a.Npad = tmf_xf_npad(N); a.tiles = tmf_xf_tiles(N);
+        a.trace = g_xf_trace[2];
         hipLaunchKernelGGL(xf_bwd_kv_kernel, dim3(a.tiles, B), dim3(XTHR), XF_BWDKV_LDS, s, a);
         if ((rc = tmf_launch_result("tmf_fusion_train_bwd(fused kv)"))) return rc;
     }

@@ -193,8 +193,15 @@ class model_ad(_FastModeSwitch, nn.Module):
         dim = tok.shape[-1]
         if fc[0].in_features != 4 * dim or D[0].in_features != dim or fc[4].in_features != fc[0].out_features \
                 or fc[8].in_features != fc[4].out_features or D[3].in_features != D[0].out_features \
-                or fc[8].out_features != D[3].out_features or dim % 4:
+                or fc[8].out_features != D[3].out_features:
             return False
+        # the library's own preconditions (csrc/heads.hip check_desc): other widths take the module path, they do not raise
+        if dim % 8 or fc[0].out_features % 32 or fc[8].out_features > 16:
+            return False
+        # one train / eval switch for the whole launch: a sub-module flipped on its own (model.D.eval()) takes the module path
+        for m in list(fc) + list(D) + [fc, D]:
+            if m.training != self.training:
+                return False
         for m in (fc[0], fc[4], fc[8], D[0], D[3]):
             if m.bias is None:
                 return False

@@ -27,11 +27,14 @@ def device_guard(forward):
     import functools
 
     @functools.wraps(forward)
-    def wrapped(self, x, *args, **kwargs):
-        if x.is_cuda and x.device.index != torch._C._cuda_getDevice():
+    def wrapped(self, *args, **kwargs):
+        x = next((a for a in args if isinstance(a, torch.Tensor)), None)
+        if x is None:                        # keyword-only calls: net(mri=a, pet=b), attn(x=t)
+            x = next((a for a in kwargs.values() if isinstance(a, torch.Tensor)), None)
+        if x is not None and x.is_cuda and x.device.index != torch._C._cuda_getDevice():
             with torch.cuda.device(x.device):
-                return forward(self, x, *args, **kwargs)
-        return forward(self, x, *args, **kwargs)
+                return forward(self, *args, **kwargs)
+        return forward(self, *args, **kwargs)
     return wrapped
 
 

@@ -7,6 +7,7 @@ fp32, contiguous, on a HIP device; activations are channels-last (B, D, H, W, C)
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 
@@ -493,19 +494,25 @@ def snet_eval_one_call(vol, dim, eps, slope, blocks):
 
 
 # Gradient tensors whose producing kernels finish BEFORE the backward call that produced them returns: data pointer ->
-# (event recorded behind their last kernel, the flat buffer they are views of — held, so that its memory cannot be handed
-# to another tensor while the entry exists).  Filled by SNetTrain.backward for the deep blocks of an encoder, consumed by
-# parallel.GradAllReduce (which then waits for the event instead of for the whole producing stream); dropped at the end of
-# every backward under that wrapper and at the next encoder forward otherwise.
+# (event recorded behind their last kernel, weak reference to the flat buffer they are views of).  Filled by
+# SNetTrain.backward for the deep blocks of an encoder, consumed by parallel.GradAllReduce (which then waits for the event
+# instead of for the whole producing stream).  An entry is only honoured while its flat buffer is alive (the memory
+# cannot have been handed to another tensor) and the queried tensor is a view of it; entries of dead buffers are dropped on
+# lookup and overwritten by the next backward — nothing depends on anybody clearing the table, and it pins no memory.
 GRAD_READY_EVENTS = {}
 
 
 def grad_ready_event(grad):
     """The event behind the last kernel that writes `grad`, if one was recorded for exactly this buffer."""
-    ent = GRAD_READY_EVENTS.get(grad.data_ptr())
+    key = grad.data_ptr()
+    ent = GRAD_READY_EVENTS.get(key)
     if ent is None:
         return None
-    ev, flat = ent
+    ev, flat_ref = ent
+    flat = flat_ref()
+    if flat is None:
+        del GRAD_READY_EVENTS[key]
+        return None
     same = grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
     return ev if same else None
 
@@ -519,7 +526,6 @@ class SNetTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vol, cfg, buffers, *params):
         import ctypes as C
-        GRAD_READY_EVENTS.clear()               # entries of the previous step's backward (nothing is pending in a forward)
         vol = _chk(vol, "vol")
         dim, momentum, eps, slope = cfg
         B, _, D, H, W = vol.shape
@@ -573,11 +579,12 @@ class SNetTrain(torch.autograd.Function):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(vol.device))        # (creates the handle; the library re-records it)
         g.deep_event = ev.cuda_event
+        flat_ref = weakref.ref(flat)
         for l in range(_lib.SNET_DEEP_FROM, 7):
             for j in range(4):
                 t_ = grads[4 * l + j]
                 if t_ is not None and t_.numel():
-                    GRAD_READY_EVENTS[t_.data_ptr()] = (ev, flat)
+                    GRAD_READY_EVENTS[t_.data_ptr()] = (ev, flat_ref)
         nscr = _lib.query("tmf_snet_bwd_scratch_bytes", C.byref(desc))
         scratch = torch.empty(nscr, device=vol.device, dtype=torch.uint8)
         _lib.call("tmf_snet_train_bwd", C.byref(desc), vol.data_ptr(), saved.data_ptr(), saved.numel(), dout.data_ptr(),

@@ -21,7 +21,15 @@ class Adam(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self._flat = {}                      # id(group) -> (exp_avg, exp_avg_sq, offsets, numel array, param pointer array)
 
+    def __setstate__(self, state):
+        """copy.deepcopy / pickle: torch serialises only defaults, state and param_groups — the kernel-side flat moment
+        buffers and pointer tables are rebuilt from the per-parameter state (as after load_state_dict)."""
+        super().__setstate__(state)
+        self._rebuild_flat()
+
     def _group_state(self, group):
+        if getattr(self, "_flat", None) is None:
+            self._flat = {}
         st = self._flat.get(id(group))
         if st is not None:
             return st
@@ -91,8 +99,13 @@ class Adam(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         """torch's loader replaces the per-parameter state tensors: copy them back into the flat buffers the kernel uses."""
         super().load_state_dict(state_dict)
+        self._rebuild_flat()
+
+    def _rebuild_flat(self):
         self._flat = {}
         loaded = {p: dict(st) for p, st in self.state.items()}
+        if not loaded:
+            return
         for group in self.param_groups:
             for sub, m, v, offs, _numel, _pptr in self._group_state(group) or ():
                 for p, o in zip(sub, offs):

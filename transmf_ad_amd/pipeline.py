@@ -1,15 +1,15 @@
 """Input pipeline ahead of the hot path, on the device.
 
 The reference feeds `train_step` from a MONAI `DataLoader(num_workers=0)` (datasets/__init__.py:56): NIfTI load,
-`ScaleIntensityd`, `RandFlipd(prob=0.3, spatial_axis=0)`, `RandRotated`, `RandZoomd` on the host (datasets/ADNI.py:59-70),
-then `batch['MRI'].to(device)` inside the step (kfold_train_adversarial.py:106-108).  Here the RAW volumes go to the
-device through pinned staging buffers on a copy stream (double-buffered: the copy of batch i + 1 overlaps the step of
-batch i) and the intensity scaling and the flip run there as HIP kernels (csrc/input_pipeline.hip, bit-identical to
-MONAI's published formulas as restated in oracle/input_oracle.py).  The random flip DECISIONS are drawn on the host with
-numpy (MONAI draws them from its own RandomState; only the probability is part of the reference's configuration).
-
-RandRotated / RandZoomd are not applied: their interpolation conventions cannot be pinned without MONAI (not installed,
-not vendored) — `DevicePrefetcher(..., strict_reference_aug=True)` raises instead of silently training without them.
+`ScaleIntensityd`, `RandFlipd(prob=0.3, spatial_axis=0)`, `RandRotated(prob=0.3, range_x=0.05)`,
+`RandZoomd(prob=0.3, min_zoom=0.95, max_zoom=1)` on the host (datasets/ADNI.py:59-70), then `batch['MRI'].to(device)`
+inside the step (kfold_train_adversarial.py:106-108).  Here the RAW volumes go to the device on a copy stream (the copy
+of batch i + 1 overlaps the step of batch i) and all four transforms run there as HIP kernels
+(csrc/input_pipeline.hip, bit-identical to MONAI's published algorithms as restated in oracle/input_oracle.py).  The
+random DECISIONS (flip?, rotate? and the angle, zoom? and the factor) are drawn on the host with numpy, one set per
+subject shared by MRI and PET as MONAI's dictionary transforms do (MONAI draws them from its own RandomState; only the
+probabilities and ranges are part of the reference's configuration).  `nifti.read_nifti` / `nifti_batches` read
+`.nii` / `.nii.gz` volumes in the prefetcher's worker thread (datasets/ADNI.py:62 LoadImaged).
 """
 from __future__ import annotations
 
@@ -47,6 +47,55 @@ def scale_intensity_flip(vol: torch.Tensor, flips: Optional[torch.Tensor] = None
     return out
 
 
+def rotate_zoom(vol: torch.Tensor, angles=None, zooms=None, stream: Optional[torch.cuda.Stream] = None) -> torch.Tensor:
+    """RandRotated / RandZoomd (datasets/ADNI.py:67-68) of a device batch (B, 1, D, H, W) with the decisions given: angles[b]
+    (radians about the first spatial axis; NaN / None = no rotation), zooms[b] (factor in (0, 1]; NaN / None = no zoom).
+    Bit-identical to oracle/input_oracle.py rotate_x / zoom_area."""
+    import math
+    if not vol.is_cuda or vol.dtype != torch.float32:
+        raise _lib.TmfError("rotate_zoom needs a float32 tensor on the HIP device (there is no CPU fallback)")
+    v = vol.contiguous()
+    B = v.shape[0]
+    D, H, W = v.shape[-3:]
+    if v.numel() != B * D * H * W:
+        raise _lib.TmfError(f"expected (B, 1, D, H, W) or (B, D, H, W), got {tuple(vol.shape)}")
+    def decisions(vals):
+        if vals is None:
+            return [None] * B
+        if len(vals) != B:
+            raise _lib.TmfError(f"expected {B} per-volume decisions, got {len(vals)}")
+        return [None if (x is None or math.isnan(float(x))) else float(x) for x in vals]
+    ang, zs = decisions(angles), decisions(zooms)
+    with torch.cuda.device(v.device), (torch.cuda.stream(stream) if stream is not None else _Null()):
+        s = torch.cuda.current_stream(v.device).cuda_stream
+        if any(a is not None for a in ang):
+            cs = np.zeros((B, 2), np.float32)
+            flag = np.zeros(B, np.uint8)
+            for b_, a in enumerate(ang):
+                if a is not None:
+                    cs[b_] = (np.float32(math.cos(a)), np.float32(math.sin(a)))
+                    flag[b_] = 1
+            out = torch.empty_like(v)
+            cs_d, flag_d = torch.from_numpy(cs).to(v.device), torch.from_numpy(flag).to(v.device)     # held until the call returns
+            _lib.call("tmf_rotate_x", v.data_ptr(), out.data_ptr(), cs_d.data_ptr(), flag_d.data_ptr(), B, D, H, W, s)
+            v = out
+        if any(z is not None for z in zs):
+            sz = np.zeros((B, 3), np.int32)
+            flag = np.zeros(B, np.uint8)
+            for b_, z in enumerate(zs):
+                if z is not None:
+                    o = [int(math.floor(float(n) * z)) for n in (D, H, W)]
+                    if min(o) < 1 or any(a > n for a, n in zip(o, (D, H, W))):
+                        raise _lib.TmfError(f"zoom factor {z}: only 0 < zoom <= 1 is provided (RandZoomd(0.95, 1))")
+                    sz[b_] = o
+                    flag[b_] = 1
+            out = torch.empty_like(v)
+            sz_d, flag_d = torch.from_numpy(sz).to(v.device), torch.from_numpy(flag).to(v.device)
+            _lib.call("tmf_zoom_area", v.data_ptr(), out.data_ptr(), sz_d.data_ptr(), flag_d.data_ptr(), B, D, H, W, s)
+            v = out
+    return v.view(vol.shape)
+
+
 class _Null:
     def __enter__(self):
         return self
@@ -61,14 +110,18 @@ class DevicePrefetcher:
     on a side stream while the caller trains on batch i; ScaleIntensity + flip run on that side stream too."""
 
     def __init__(self, batches: Iterable, device="cuda", flip_prob: float = 0.3, seed: Optional[int] = None,
-                 train: bool = True, strict_reference_aug: bool = False, pinned_staging: bool = False):
-        if strict_reference_aug and train:
-            raise NotImplementedError(
-                "RandRotated / RandZoomd (datasets/ADNI.py:67-68) are not implemented on the device: their MONAI "
-                "interpolation conventions cannot be verified without the library")
+                 train: bool = True, rotate_prob: float = 0.3, rotate_range: float = 0.05, zoom_prob: float = 0.3,
+                 zoom_range=(0.95, 1.0), pinned_staging: bool = False):
+        """train=True applies the reference's whole augmentation set with its probabilities and ranges
+        (datasets/ADNI.py:66-68); set a probability to 0 to leave a transform out.  train=False: ScaleIntensity only
+        (the reference's test_transform)."""
         self.batches = batches
         self.device = torch.device(device)
         self.flip_prob = flip_prob if train else 0.0
+        self.rotate_prob = rotate_prob if train else 0.0
+        self.rotate_range = float(rotate_range)
+        self.zoom_prob = zoom_prob if train else 0.0
+        self.zoom_range = (float(zoom_range[0]), float(zoom_range[1]))
         self.rs = np.random.RandomState(seed)
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._pinned = [dict(), dict()]          # two staging sets, reused while shapes stay the same
@@ -91,17 +144,33 @@ class DevicePrefetcher:
 
     def _launch(self, slot, host_batch):
         B = len(host_batch["label"])
-        flips = (self.rs.random_sample(B) < self.flip_prob).astype(np.uint8)      # one decision per subject
+        # one set of decisions per subject, shared by MRI and PET (MONAI dictionary transforms); per transform the "apply?"
+        # draw first, then its parameters (RandRotated draws x, y, z — y and z from (0, 0); RandZoomd one factor)
+        flips = (self.rs.random_sample(B) < self.flip_prob).astype(np.uint8)
+        angles = np.full(B, np.nan)
+        zooms = np.full(B, np.nan)
+        if self.rotate_prob > 0:
+            for b in range(B):
+                if self.rs.random_sample() < self.rotate_prob:
+                    angles[b] = self.rs.uniform(-self.rotate_range, self.rotate_range)
+                    self.rs.uniform(0.0, 0.0); self.rs.uniform(0.0, 0.0)
+        if self.zoom_prob > 0:
+            for b in range(B):
+                if self.rs.random_sample() < self.zoom_prob:
+                    zooms[b] = self.rs.uniform(*self.zoom_range)
         with torch.cuda.stream(self.copy_stream):
             out = {}
             nb = self.pinned_staging
             fl = self._stage(slot, "_flips", flips).to(self.device, non_blocking=nb)
             for key in ("MRI", "PET"):
                 raw = self._stage(slot, key, host_batch[key]).to(self.device, non_blocking=nb)
-                out[key] = scale_intensity_flip(raw, fl if self.flip_prob > 0 else None, stream=self.copy_stream)
+                x = scale_intensity_flip(raw, fl if self.flip_prob > 0 else None, stream=self.copy_stream)
+                if not (np.isnan(angles).all() and np.isnan(zooms).all()):
+                    x = rotate_zoom(x, angles, zooms, stream=self.copy_stream)
+                out[key] = x
             out["label"] = self._stage(slot, "label", np.asarray(host_batch["label"], dtype=np.int64)).to(
                 self.device, non_blocking=nb)
-            out["_flips"] = flips
+            out["_flips"], out["_angles"], out["_zooms"] = flips, angles, zooms
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         return out, ev
