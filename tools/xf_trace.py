@@ -45,7 +45,7 @@ bufs = [torch.zeros(B * tiles * 4 * 16, dtype=torch.int64, device=dev) for _ in 
 _lib.load().tmf_debug_xf_trace(bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr())
 one()
 _lib.load().tmf_debug_xf_trace(None, None, None)
-names = [["P0 load+LN1", "P1 q", "P2 S=KQ", "softmax", "(max/sum)", "PV+store", "P4 out-proj", "LN2", "P5 FF1+GELU", "P6 FF2", "LNf", "P7 kv_next"],
+names = [["P0 load+LN1", "P1 q", "P2 S=KQ", "softmax", "PV+store", "P4 out-proj", "LN2", "P5 FF1+GELU", "P6 FF2", "LNf", "P7 kv_next"],
          ["S1 LNf'", "S2 dg,dh", "S3 df", "S4 LN2'", "S5 dout", "S6 attn dq", "S7 da", "S8 LN1'"],
          ["attn dk,dv", "dctx"]]
 for k, (buf, nm) in enumerate(zip(bufs, names)):

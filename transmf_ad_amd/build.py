@@ -17,6 +17,10 @@ SOURCES = ["conv3d_mfma.hip", "conv3d_bf16.hip", "conv1_fused.hip", "bn_act_pool
 # bit-reproducible with and without the flag.)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-fno-slp-vectorize",
          "-Wall", "-Wno-unused-function", "-Wno-unused-variable"]
+# per-source additions.  input_pipeline.hip: its interpolation kernels are BIT-identical to a numpy restatement with one
+# rounding per written operation; -ffp-contract=fast fuses multiplies and adds across statements and ignores
+# `#pragma clang fp contract(off)`, so that file is compiled without contraction.
+FILE_FLAGS = {"input_pipeline.hip": ["-ffp-contract=off"]}
 # extra compile flags for one-off instrumented builds (e.g. TMF_EXTRA_FLAGS=-DTMF_ABLATE for tools/bf16_ablate.py); part
 # of the stamp, so such a library is only loaded by processes started with the same setting
 FLAGS += os.environ.get("TMF_EXTRA_FLAGS", "").split()
@@ -54,7 +58,7 @@ def _headers():
 def source_digest():
     """Digest of everything libtmf_hip.so is made from (all sources, headers, FLAGS).  build() writes it to
     libtmf_hip.so.stamp; _lib.load() refuses a library whose stamp does not match the sources next to it."""
-    return _digest([os.path.join(CSRC, s) for s in SOURCES] + _headers(), " ".join(FLAGS))
+    return _digest([os.path.join(CSRC, s) for s in SOURCES] + _headers(), " ".join(FLAGS) + repr(sorted(FILE_FLAGS.items())))
 
 
 def build(force=False, verbose=True):
@@ -69,9 +73,10 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(o)
-        dig = _digest([s] + hdrs, " ".join(FLAGS))
+        flags = FLAGS + FILE_FLAGS.get(src, [])
+        dig = _digest([s] + hdrs, " ".join(flags))
         if force or not os.path.exists(o) or _read(o + ".stamp") != dig:
-            cmd = [hipcc, "-x", "hip", "-c", s, "-o", o] + FLAGS
+            cmd = [hipcc, "-x", "hip", "-c", s, "-o", o] + flags
             if verbose:
                 print(" ".join(cmd), flush=True)
             if os.path.exists(o + ".stamp"):

@@ -16,19 +16,22 @@
 
 // fused per-instance kernels (xformer_fused.hip)
 struct tmf_xf_fwd_io {
-    const float *x, *kv, *kvT, *wkv_next, *mask_o, *mask_g, *mask_f;
-    float *a, *q, *qT, *out, *lse, *x1, *f, *h, *g, *x2, *y, *m1, *r1, *m2, *r2, *mf, *rf, *kv_next, *kvT_next;
+    const float *x, *KR, *VC, *pk, *pkv_next, *mask_o, *mask_g, *mask_f;
+    float *a, *QR, *QC, *out, *lse, *x1, *f, *h, *g, *x2, *y, *m1, *r1, *m2, *r2, *mf, *rf, *KRn, *KCn, *VRn, *VCn;
 };
 struct tmf_xf_bwd_io {
-    const float *dy, *x, *kv, *kvT, *mask_o, *mask_g, *mask_f;
-    const float *q, *qT, *out, *lse, *x1, *h, *x2, *m1, *r1, *m2, *r2, *mf, *rf;
-    float *dx2, *dh, *dx1, *dq, *dout, *doutT, *delta, *dx, *part, *dkv, *dctx;
+    const float *dy, *x, *KR, *KC, *VR, *pk, *mask_o, *mask_g, *mask_f;
+    const float *QR, *QC, *out, *lse, *x1, *h, *x2, *m1, *r1, *m2, *r2, *mf, *rf;
+    float *dx2, *dh, *dx1, *dq, *DR, *DC, *delta, *dx, *part, *dkv, *dctx;
     const float* dctx_acc;
 };
 bool tmf_xf_supported(int N, int dim, int heads, int dim_head, int mlp);
 int tmf_xf_npad(int N);
 int tmf_xf_tiles(int N);
 int tmf_xf_part_stride(void);
+int tmf_xf_pack_floats(void);
+int tmf_xf_pack_kv_offset(void);
+int tmf_xf_launch_pack(int n_inst, const tmf_xformer_params* inst, float* const* pk_fwd, float* const* pk_bwd, hipStream_t s);
 int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fwd_io* io, float scale, int only_kv, hipStream_t s);
 int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bwd_io* io, float scale, hipStream_t s);
 int tmf_xf_launch_colsum(int n_inst, const float* const* part, float* const* small, float* const* lnf, int nblk, hipStream_t s);
@@ -53,7 +56,8 @@ int check_desc(const char* fn, const tmf_fusion_desc* d) {
 
 // Saved tensors of ONE Transformer instance (floats), in this order inside the instance's slab.
 struct InstPlan {
-    size_t a, q, kv, out, lse, x1, f, h, g, x2, y, m1, r1, m2, r2, mf, rf, qT, kvT, total;      // byte offsets
+    size_t a, q, kv, out, lse, x1, f, h, g, x2, y, m1, r1, m2, r2, mf, rf, total;      // byte offsets
+    size_t QR, QC, KR, KC, VR, VC, pkf, pkb;      // fused kernels: fragment-order panels, weight packs
 };
 
 constexpr int WG_CHUNK = 30;    // weight-gradient problems per tmf_tok_wgrad_multi launch (6 instances)
@@ -67,7 +71,7 @@ struct Plan {
     // backward scratch (byte offsets)
     size_t s_dx2, s_dh, s_dx1, s_dout, s_dq, s_dkv, s_part, s_lnpart, s_G[4], s_ws, ws_bytes, scratch_bytes;
     // fused backward: s_dx2 .. s_dkv and s_part are the first of `2 * depth` per-instance regions of inst_stride bytes
-    size_t s_doutT, s_delta, inst_stride;
+    size_t s_DR, s_DC, s_delta, inst_stride;
 };
 
 Plan make_plan(const tmf_fusion_desc& d) {
@@ -85,8 +89,12 @@ Plan make_plan(const tmf_fusion_desc& d) {
     I.lse = take((size_t)d.B * d.heads * p.npad); I.x1 = take(R * dim); I.f = take(R * dim); I.h = take(R * mlp);
     I.g = take(R * mlp); I.x2 = take(R * dim); I.y = take(R * dim);
     I.m1 = take(R); I.r1 = take(R); I.m2 = take(R); I.r2 = take(R); I.mf = take(R); I.rf = take(R);
-    I.qT = I.kvT = o;
-    if (p.fused) { I.qT = take((size_t)d.B * inner * p.npad); I.kvT = take((size_t)d.B * 2 * inner * p.npad); }
+    I.QR = I.QC = I.KR = I.KC = I.VR = I.VC = I.pkf = I.pkb = o;
+    if (p.fused) {
+        const size_t panel = (size_t)d.B * p.npad * inner;
+        I.QR = take(panel); I.QC = take(panel); I.KR = take(panel); I.KC = take(panel); I.VR = take(panel); I.VC = take(panel);
+        I.pkf = take(tmf_xf_pack_floats()); I.pkb = take(tmf_xf_pack_floats());
+    }
     I.total = o;
     p.off_arg = 2 * (size_t)d.depth * I.total;
     p.saved_bytes = p.off_arg + up256((size_t)d.B * 2 * dim * 4);        // int32 argmax of the max pools
@@ -102,7 +110,8 @@ Plan make_plan(const tmf_fusion_desc& d) {
         p.s_dkv = take(R * 2 * inner); p.s_part = take((size_t)d.B * p.tiles * p.stride);
         p.inst_stride = o;
         o = p.inst_stride * (size_t)(2 * d.depth > 0 ? 2 * d.depth : 1);
-        p.s_dout = take(R * inner); p.s_doutT = take((size_t)d.B * inner * p.npad);
+        p.s_dout = o;
+        p.s_DR = take((size_t)d.B * p.npad * inner); p.s_DC = take((size_t)d.B * p.npad * inner);
         p.s_delta = take((size_t)d.B * d.heads * p.npad);
         p.s_lnpart = o;
         for (int i = 0; i < 4; ++i) p.s_G[i] = take(R * dim);
@@ -117,7 +126,7 @@ Plan make_plan(const tmf_fusion_desc& d) {
         p.s_dx2 = take(R * dim); p.s_dh = take(R * mlp); p.s_dx1 = take(R * dim); p.s_dout = take(R * inner);
         p.s_dq = take(R * inner); p.s_dkv = take(R * 2 * inner);
         p.s_part = take((size_t)p.nblk * p.stride); p.s_lnpart = take((size_t)p.nblk_ln * 2 * dim);
-        p.s_doutT = p.s_delta = p.inst_stride = 0;
+        p.s_DR = p.s_DC = p.s_delta = p.inst_stride = 0;
         for (int i = 0; i < 4; ++i) p.s_G[i] = take(R * dim);
         p.ws_bytes = tmf_tok_wgrad_multi_workspace_bytes(5, N5, K5);
     }
@@ -193,25 +202,32 @@ extern "C" int tmf_fusion_train_fwd(const tmf_fusion_desc* d, const float* mri_t
         const float scale = 1.0f / sqrtf((float)d->dim_head);
         hipStream_t s = (hipStream_t)stream;
         const int n_inst = 2 * d->depth;
+        const InstPlan& I = p.I;
+        {   // this step's weights in fragment order (forward and backward forms)
+            float* pf[2 * TMF_FUSION_MAX_DEPTH];
+            float* pb[2 * TMF_FUSION_MAX_DEPTH];
+            for (int i = 0; i < n_inst; ++i) { pf[i] = F(base + (size_t)i * I.total, I.pkf); pb[i] = F(base + (size_t)i * I.total, I.pkb); }
+            TMF_TRY(tmf_xf_launch_pack(n_inst, inst, pf, pb, s));
+        }
         {   // K | V of the first instance's context (the pet tokens)
             tmf_xf_fwd_io io = {};
-            io.x = pet_tok; io.wkv_next = inst[0].wkv;
-            io.kv_next = F(base, p.I.kv); io.kvT_next = F(base, p.I.kvT);
+            io.x = pet_tok; io.pkv_next = F(base, I.pkf) + tmf_xf_pack_kv_offset();
+            io.KRn = F(base, I.KR); io.KCn = F(base, I.KC); io.VRn = F(base, I.VR); io.VCn = F(base, I.VC);
             TMF_TRY(tmf_xf_launch_fwd(d->B, d->N, nullptr, &io, scale, 1, s));
         }
         for (int i = 0; i < n_inst; ++i) {
-            char* sv = base + (size_t)i * p.I.total;
-            const InstPlan& I = p.I;
+            char* sv = base + (size_t)i * I.total;
             tmf_xf_fwd_io io = {};
             io.x = (i & 1) ? q : m;
-            io.kv = F(sv, I.kv); io.kvT = F(sv, I.kvT);
+            io.KR = F(sv, I.KR); io.VC = F(sv, I.VC); io.pk = F(sv, I.pkf);
             io.mask_o = inst[i].mask_o; io.mask_g = inst[i].mask_g; io.mask_f = inst[i].mask_f;
-            io.a = F(sv, I.a); io.q = F(sv, I.q); io.qT = F(sv, I.qT); io.out = F(sv, I.out); io.lse = F(sv, I.lse);
+            io.a = F(sv, I.a); io.QR = F(sv, I.QR); io.QC = F(sv, I.QC); io.out = F(sv, I.out); io.lse = F(sv, I.lse);
             io.x1 = F(sv, I.x1); io.f = F(sv, I.f); io.h = F(sv, I.h); io.g = F(sv, I.g); io.x2 = F(sv, I.x2); io.y = F(sv, I.y);
             io.m1 = F(sv, I.m1); io.r1 = F(sv, I.r1); io.m2 = F(sv, I.m2); io.r2 = F(sv, I.r2); io.mf = F(sv, I.mf); io.rf = F(sv, I.rf);
             if (i + 1 < n_inst) {           // this output is the next instance's context
-                io.wkv_next = inst[i + 1].wkv;
-                io.kv_next = F(sv + p.I.total, I.kv); io.kvT_next = F(sv + p.I.total, I.kvT);
+                char* sn = sv + I.total;
+                io.pkv_next = F(sn, I.pkf) + tmf_xf_pack_kv_offset();
+                io.KRn = F(sn, I.KR); io.KCn = F(sn, I.KC); io.VRn = F(sn, I.VR); io.VCn = F(sn, I.VC);
             }
             TMF_TRY(tmf_xf_launch_fwd(d->B, d->N, &inst[i], &io, scale, 0, s));
             if (i & 1) q = F(sv, I.y); else m = F(sv, I.y);
@@ -276,14 +292,14 @@ static int instance_bwd_fused(const tmf_fusion_desc& d, const Plan& p, const tmf
     const InstPlan& I = p.I;
     char* si = sc + (size_t)idx * p.inst_stride;
     tmf_xf_bwd_io io = {};
-    io.dy = dy; io.x = x; io.kv = F(sv, I.kv); io.kvT = F(sv, I.kvT);
+    io.dy = dy; io.x = x; io.KR = F(sv, I.KR); io.KC = F(sv, I.KC); io.VR = F(sv, I.VR); io.pk = F(sv, I.pkb);
     io.mask_o = w.mask_o; io.mask_g = w.mask_g; io.mask_f = w.mask_f;
-    io.q = F(sv, I.q); io.qT = F(sv, I.qT); io.out = F(sv, I.out); io.lse = F(sv, I.lse); io.x1 = F(sv, I.x1); io.h = F(sv, I.h);
+    io.QR = F(sv, I.QR); io.QC = F(sv, I.QC); io.out = F(sv, I.out); io.lse = F(sv, I.lse); io.x1 = F(sv, I.x1); io.h = F(sv, I.h);
     io.x2 = F(sv, I.x2); io.m1 = F(sv, I.m1); io.r1 = F(sv, I.r1); io.m2 = F(sv, I.m2); io.r2 = F(sv, I.r2);
     io.mf = F(sv, I.mf); io.rf = F(sv, I.rf);
     io.dx2 = F(si, p.s_dx2); io.dh = F(si, p.s_dh); io.dx1 = F(si, p.s_dx1); io.dq = F(si, p.s_dq); io.dkv = F(si, p.s_dkv);
     io.part = F(si, p.s_part);
-    io.dout = F(sc, p.s_dout); io.doutT = F(sc, p.s_doutT); io.delta = F(sc, p.s_delta);
+    io.DR = F(sc, p.s_DR); io.DC = F(sc, p.s_DC); io.delta = F(sc, p.s_delta);
     io.dx = dx_out; io.dctx = dctx_out; io.dctx_acc = dctx_acc;
     return tmf_xf_launch_bwd(d.B, d.N, &w, &io, 1.0f / sqrtf((float)d.dim_head), (hipStream_t)stream);
 }

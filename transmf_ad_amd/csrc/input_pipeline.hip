@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void scale_flip_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void rotate_x_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                        const float* __restrict__ cos_sin, const unsigned char* __restrict__ do_rot,
                                                        int D, int H, int W) {
+    // one rounding per written operation, as in the numpy restatement: this file is compiled with -ffp-contract=off (build.py)
     const int b = blockIdx.z, d = blockIdx.y;
     const long plane = (long)H * W;
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -121,20 +122,24 @@ __global__ __launch_bounds__(256) void rotate_x_kernel(const float* __restrict__
     const int h = (int)(i / W), w = (int)(i - (long)h * W);
     const float cs = cos_sin[2 * b], sn = cos_sin[2 * b + 1];
     const float c1 = 0.5f * (float)(H - 1), c2 = 0.5f * (float)(W - 1);
-    const float o1 = __fsub_rn((float)h, c1), o2 = __fsub_rn((float)w, c2);
-    float s1 = __fadd_rn(c1, __fsub_rn(__fmul_rn(cs, o1), __fmul_rn(sn, o2)));
-    float s2 = __fadd_rn(c2, __fadd_rn(__fmul_rn(sn, o1), __fmul_rn(cs, o2)));
+    const float o1 = (float)h - c1, o2 = (float)w - c2;
+    const float p11 = cs * o1, p12 = sn * o2, p21 = sn * o1, p22 = cs * o2;
+    const float d1 = p11 - p12, d2 = p21 + p22;
+    float s1 = c1 + d1;
+    float s2 = c2 + d2;
     s1 = fminf(fmaxf(s1, 0.f), (float)(H - 1));
     s2 = fminf(fmaxf(s2, 0.f), (float)(W - 1));
     const float f1 = floorf(s1), f2 = floorf(s2);
-    const float t1 = __fsub_rn(s1, f1), t2 = __fsub_rn(s2, f2);
-    const float a = __fsub_rn(1.f, t1), bb = __fsub_rn(1.f, t2);
+    const float t1 = s1 - f1, t2 = s2 - f2;
+    const float a = 1.f - t1, bb = 1.f - t2;
     const int i1 = (int)f1, i2 = (int)f2;
     const int j1 = i1 + 1 < H ? i1 + 1 : H - 1, j2 = i2 + 1 < W ? i2 + 1 : W - 1;
     const float v00 = s[(long)i1 * W + i2], v01 = s[(long)i1 * W + j2], v10 = s[(long)j1 * W + i2], v11 = s[(long)j1 * W + j2];
-    float r = __fadd_rn(__fmul_rn(v00, __fmul_rn(a, bb)), __fmul_rn(v01, __fmul_rn(a, t2)));
-    r = __fadd_rn(r, __fmul_rn(v10, __fmul_rn(t1, bb)));
-    r = __fadd_rn(r, __fmul_rn(v11, __fmul_rn(t1, t2)));
+    const float w00 = a * bb, w01 = a * t2, w10 = t1 * bb, w11 = t1 * t2;
+    const float q00 = v00 * w00, q01 = v01 * w01, q10 = v10 * w10, q11 = v11 * w11;
+    float r = q00 + q01;
+    r = r + q10;
+    r = r + q11;
     o[i] = r;
 }
 
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(256) void zoom_area_kernel(const float* __restrict_
     float acc = 0.f;
     for (int a = d0; a < d1; ++a)
         for (int bq = h0; bq < h1; ++bq)
-            for (int c = w0; c < w1; ++c) acc = __fadd_rn(acc, s[((size_t)a * H + bq) * W + c]);
+            for (int c = w0; c < w1; ++c) acc = acc + s[((size_t)a * H + bq) * W + c];
     acc = __fdiv_rn(acc, (float)(d1 - d0));
     acc = __fdiv_rn(acc, (float)(h1 - h0));
     acc = __fdiv_rn(acc, (float)(w1 - w0));

@@ -23,16 +23,26 @@
 // at the end (tmf_tok_wgrad_multi).
 //
 // GEMMs: v_mfma_f32_16x16x4_f32, A = the 16-row tile from LDS (one ds_read_b128 per 4 MFMAs through the K-permutation
-// k = 16 s + 4 (lane >> 4) + j), B straight from L2: one 16-byte load per 4 MFMAs in the y = x W^T form (W rows = output
-// features), G-float loads in the dx = dy W form.  A lane's accumulator tiles are INTERLEAVED columns (tile u of a lane
-// with m = lane & 15 is column G m + u of its group), so a lane owns G consecutive columns of a row: wide row-major
-// stores, and the dx form reads G consecutive weights at once.
+// k = 16 s + 4 (lane >> 4) + j).  Every B operand comes from memory that is laid out in FRAGMENT ORDER — the 64 lanes of a
+// load instruction read 1 KB of consecutive bytes, lane l its own 16.  Measured on the first version (tools/xf_trace.py),
+// which read nn.Linear weights / row-major K, V panels in place: there a lane's 16 bytes sit in a cache line of their own
+// (rows are >= 512 bytes apart), such a gather costs the wave ~150 cycles where a lane-linear load costs ~30, and every
+// GEMM phase ran at 2-4x its matrix time with the weights already in L2.  So
+//   * the weights of an instance are re-packed once per step (xf_pack_kernel: [wave][k step][tile][lane][4], one pack for
+//     the y = x W^T products of the forward, one for the dx = dy W products of the backward);
+//   * the attention operands are WRITTEN in fragment order by their producers (a lane's accumulator registers are 4
+//     consecutive tokens of one feature, resp. — across its interleaved tiles — 4 consecutive features of one token: one
+//     16-byte store either way): per (batch element, head) a "row" fragment R[tile][s][lane][4] = X[token 16 tile + (lane
+//     & 15)][feature 16 s + 4 (lane >> 4) + j] (operand of products that contract over features: S = K Q^T, dP = V dO^T,
+//     and with Q / dO in that role for dK / dV) and a "column" fragment C[dt][tile][lane][4] = X[token 16 tile + 4 (lane
+//     >> 4) + j][feature 16 dt + (lane & 15)] (products that contract over tokens: O^T = V^T P^T, dQ^T = K^T dS^T, dV^T =
+//     dO^T P, dK^T = Q^T dS).  Rows past N are exact zeros.
+// A lane's accumulator tiles are INTERLEAVED columns (tile u of a lane with m = lane & 15 is column G m + u of its group),
+// so a lane owns G consecutive columns of a row: wide row-major stores.
 //
-// Attention operands in both orders: K row-major [token][feature] and V transposed [feature][token] for the forward
-// (S^T = K Q^T, O^T = V^T P^T: lane = one query, softmax reductions are two shuffles), K^T and V row-major for dQ, Q^T
-// and dO^T for dK / dV — every producer writes the transposed copy from its accumulator layout for free (a lane holds 4
-// consecutive tokens of one feature = one 16-byte store).  Transposed buffers are [B][features][Npad], Npad = 16 ceil(N /
-// 16), zero in the padding.
+// Workgroup -> XCD: all tiles of a batch element run on one XCD (xf_who), whose L2 then holds that element's panels and
+// one copy of the weights; the cold part of a launch's working set (weights: written by the optimizer; in backward the
+// saved panels) is requested cooperatively at kernel start (xf_prefetch).
 //
 // Dropout (options/option.py:39 `--dropout`; networks.py:131,133,153): the three keep-masks of an instance (after to_out,
 // after GELU, after the second Linear), already scaled by 1 / (1 - p), are INPUTS (NULL = inactive) — the random draw
@@ -57,7 +67,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define XF_STAMP(k)                                                                                                   \
     do {                                                                                                              \
         if (p.trace != nullptr && lane == 0)                                                                          \
-            p.trace[(((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+            p.trace[(((size_t)bz * p.tiles + tile) * 4 + wave) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
     } while (0)
 #else
 #define XF_STAMP(k) do { } while (0)
@@ -80,42 +90,22 @@ template <int TPW> struct TileMap {
     static __device__ __forceinline__ int col0(int cbase, int gq, int m) { return cbase + gq * (16 * G) + G * m; }
 };
 
-// acc[u] += A[16 x 16 KS] . B for the lane's TPW column tiles.
-//   NN == false:  B[k][c] = W[c * ldw + k]   (y = x W^T;  W [N][K] row-major)
-//   NN == true:   B[k][c] = W[k * ldw + c]   (dx = dy W;  W [K][N] row-major)
+// acc[u] += A[16 x 16 KS] . B for the lane's TPW column tiles; B from a weight pack in fragment order
+// P[wave][s][u][lane][j] = B[k = 16 s + 4 (lane >> 4) + j][TileMap<TPW>::col(16 TPW wave, u, lane & 15)]  (xf_pack_kernel).
 // A tile in LDS, row pitch KP floats.  B operands of PF steps are in flight ahead of the MFMAs (register ring).
-template <int TPW, int KS, bool NN>
-__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[TPW], const float* As, int KP, const float* __restrict__ W,
-                                          int ldw, int cbase, int m, int kb) {
-    constexpr int G = TileMap<TPW>::G, NG = TileMap<TPW>::NG;
-    constexpr int PF = (TPW <= 2) ? 3 : 2;
-    float b[PF + 1][TPW][4];
-    auto load = [&](int s, float (&dst)[TPW][4]) {
-        if (!NN) {
+template <int TPW, int KS>
+__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[TPW], const float* As, int KP, const float* __restrict__ P,
+                                          int wave, int lane) {
+    constexpr int PF = (TPW <= 2) ? 4 : 2;
+    f32x4 b[PF + 1][TPW];
+    const float* src = P + ((size_t)wave * KS * TPW * 64 + lane) * 4;
+    auto load = [&](int s, f32x4 (&dst)[TPW]) {
 #pragma unroll
-            for (int u = 0; u < TPW; ++u) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(W + (size_t)TileMap<TPW>::col(cbase, u, m) * ldw + 16 * s + 4 * kb);
-                dst[u][0] = v[0]; dst[u][1] = v[1]; dst[u][2] = v[2]; dst[u][3] = v[3];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int gq = 0; gq < NG; ++gq) {
-                    const float* src = W + (size_t)(16 * s + 4 * kb + j) * ldw + TileMap<TPW>::col0(cbase, gq, m);
-                    if (G == 4) {
-                        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
-                        dst[gq * 4 + 0][j] = v[0]; dst[gq * 4 + 1][j] = v[1]; dst[gq * 4 + 2][j] = v[2]; dst[gq * 4 + 3][j] = v[3];
-                    } else {
-                        const f32x2 v = *reinterpret_cast<const f32x2*>(src);
-                        dst[gq * 2 + 0][j] = v[0]; dst[gq * 2 + 1][j] = v[1];
-                    }
-                }
-        }
+        for (int u = 0; u < TPW; ++u) dst[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s * TPW + u) * 256);
     };
 #pragma unroll
     for (int s = 0; s < PF && s < KS; ++s) load(s, b[s]);
-    const float* arow = As + m * KP + 4 * kb;
+    const float* arow = As + (lane & 15) * KP + 4 * (lane >> 4);
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
         if (s + PF < KS) load(s + PF, b[(s + PF) % (PF + 1)]);
@@ -147,19 +137,99 @@ __device__ __forceinline__ void tile_colsum(const float* T, int pitch, int ncols
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// Fragment-order panels of the attention operands (floats; add 4 * lane):  T = tiles of 16 tokens
+__device__ __forceinline__ size_t frag_r(int b, int h, int t, int s, int T) { return ((((size_t)(b * XH + h) * T + t) * 2 + s) * 64) * 4; }
+__device__ __forceinline__ size_t frag_c(int b, int h, int dt, int t, int T) { return ((((size_t)(b * XH + h) * 2 + dt) * T + t) * 64) * 4; }
+
+// Producer side, TPW = 2 GEMM whose wave = head (to_q, to_out'): acc[u][r] = X[token 4 kb + r][feature 32 h + 2 m + u]
+__device__ __forceinline__ void store_frag_head(float* __restrict__ XR, float* __restrict__ XC, const f32x4 (&acc)[2], int b, int h,
+                                                int tile, int T, int m, int kb) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)             // column fragment: 4 consecutive tokens of feature 2 m + u
+        st4(XC + frag_c(b, h, m >> 3, tile, T) + (kb * 16 + 2 * (m & 7) + u) * 4, acc[u]);
+    float* dst = XR + frag_r(b, h, tile, m >> 3, T) + (((m & 7) >> 1) * 16 + 4 * kb) * 4 + 2 * (m & 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)             // row fragment: features 2 m, 2 m + 1 of token 4 kb + r
+        *reinterpret_cast<f32x2*>(dst + r * 4) = f32x2{acc[0][r], acc[1][r]};
+}
+// Producer side, the TPW = 4 to_kv GEMM: wave w holds features 64 w + 4 m + u of [K | V]: waves 0, 1 -> K, 2, 3 -> V
+__device__ __forceinline__ void store_frag_kv(float* __restrict__ KR, float* __restrict__ KC, float* __restrict__ VR,
+                                              float* __restrict__ VC, const f32x4 (&acc)[4], int b, int w, int tile, int T, int m, int kb) {
+    float* XR = w < 2 ? KR : VR;
+    float* XC = w < 2 ? KC : VC;
+    const int h = 2 * (w & 1) + (m >> 3), sd = (m & 7) >> 2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st4(XC + frag_c(b, h, sd, tile, T) + (kb * 16 + 4 * (m & 3) + u) * 4, acc[u]);
+    float* dst = XR + frag_r(b, h, tile, sd, T) + ((m & 3) * 16 + 4 * kb) * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st4(dst + r * 4, f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]});
+}
+
+// Workgroup id -> (batch element, tile).  The grid is 1-D, 8 * ns workgroups with ns = tiles * ceil(B / 8): workgroup id
+// runs on XCD id % 8 (observed dispatch order; a speed matter only), and ALL tiles of a batch element are given to one
+// XCD — its private L2 then holds that element's K / V / Q panels (read by every tile) and one copy of the instance's
+// weights, instead of every XCD pulling every panel.  `slot` numbers the workgroups of an XCD (0 .. ns - 1).
+struct XfWho { int bz, tile, slot, ns; bool live; };
+__device__ __forceinline__ XfWho xf_who(int B, int tiles) {
+    XfWho w;
+    const int id = blockIdx.x, xcd = id & 7;
+    w.slot = id >> 3;
+    w.ns = tiles * ((B + 7) >> 3);
+    w.bz = xcd + 8 * (w.slot / tiles);
+    w.tile = w.slot % tiles;
+    w.live = w.bz < B;
+    return w;
+}
+
+// Cooperative L2 warm-up.  What a launch reads that its XCD has not touched recently (the instance's weights: written by
+// the optimizer; in backward the saved panels of the batch element) comes from the Infinity Cache / HBM at ~2 us per
+// dependent round trip, and the GEMM operand rings look only a few hundred ns ahead: measured (tools/xf_trace.py), every
+// GEMM phase ran at 3-4x its matrix time, one cold round trip per ring refill.  So the ns workgroups of an XCD first
+// request one slice each of everything the launch will read (16-byte loads into registers that are only "used" by an
+// empty asm later): the cold latency is paid ONCE, overlapped with the tile's own prologue, and the phases then hit L2.
+constexpr int XPF = 20;                          // 16-byte pieces per thread (80 KB per workgroup)
+struct XfRegion { const float* p; int n4; };     // n4 = float4 pieces
+template <int NR>
+__device__ __forceinline__ void xf_prefetch(const XfRegion (&reg)[NR], int slot, int ns, int tid, f32x4 (&pf)[XPF]) {
+    long total = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) total += reg[r].p != nullptr ? reg[r].n4 : 0;
+    const long lo = total * slot / ns, hi = total * (slot + 1) / ns;
+#pragma unroll
+    for (int k = 0; k < XPF; ++k) {
+        long g = lo + tid + (long)XTHR * k;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (g < hi) {
+            const float* src = nullptr;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int n4 = reg[r].p != nullptr ? reg[r].n4 : 0;
+                if (src == nullptr && g < n4) src = reg[r].p + 4 * g;
+                if (src == nullptr) g -= n4;
+            }
+            if (src != nullptr) v = ld4(src);
+        }
+        pf[k] = v;
+    }
+}
+__device__ __forceinline__ void xf_prefetch_done(f32x4 (&pf)[XPF]) {
+#pragma unroll
+    for (int k = 0; k < XPF; ++k) asm volatile("" :: "v"(pf[k]));
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------------------------------
 struct XfFwdArgs {
     const float* x;                 // [B*N][128] input tokens of the instance (only_kv: the context tokens)
-    const float* kv;                // [B*N][256] K | V of the context, row-major
-    const float* kvT;               // [B][256][Npad] the same, transposed
-    const float *ln1_g, *ln1_b, *wq, *wo, *bo, *ln2_g, *ln2_b, *w1, *b1, *w2, *b2, *lnf_g, *lnf_b;
-    const float* wkv_next;          // to_kv weight of the instance that takes this output as context (NULL: none)
+    const float *KR, *VC;           // K row fragments / V column fragments of the context
+    const float *ln1_g, *ln1_b, *bo, *ln2_g, *ln2_b, *b1, *b2, *lnf_g, *lnf_b;
+    const float *pq, *po, *p1, *p2; // weight packs (y = x W^T form) of to_q, to_out, the two FeedForward Linears
+    const float* pkv_next;          // pack of the to_kv weight of the instance that takes this output as context (NULL: none)
     const float *mask_o, *mask_g, *mask_f;       // scaled Dropout keep-masks [R][128], [R][mlp], [R][128] or NULL
     float eps1, eps2, epsf, scale;
-    float *a, *q, *qT, *out, *lse, *x1, *f, *h, *g, *x2, *y, *m1, *r1, *m2, *r2, *mf, *rf;     // saved for backward
-    float *kv_next, *kvT_next;
+    float *a, *QR, *QC, *out, *lse, *x1, *f, *h, *g, *x2, *y, *m1, *r1, *m2, *r2, *mf, *rf;     // saved for backward
+    float *KRn, *KCn, *VRn, *VCn;   // K | V fragments of the next instance
     int B, N, Npad, tiles, only_kv;
     unsigned long long* trace;
 };
@@ -191,21 +261,36 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kb = lane >> 4, li = lane & 31;
-    const int tile = blockIdx.x, bz = blockIdx.y;
+    const XfWho who = xf_who(p.B, p.tiles);
+    if (!who.live) return;
+    const int tile = who.tile, bz = who.bz;
     const int N = p.N, Npad = p.Npad;
     const int t0 = tile * XT;
     const int nv = (N - t0) < XT ? (N - t0) : XT;                 // valid rows of this tile
     const size_t row0 = (size_t)bz * N + t0;
 
     XF_STAMP(0);
-    // ---- P0: x tile, LayerNorm 1 ----
+    // ---- P0: x tile (requested first), L2 warm-up of the instance's weights, LayerNorm 1 ----
+    f32x4 xin[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 8 + wave * 2 + (lane >> 5);
+        xin[pass] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (row < nv) xin[pass] = ld4(p.x + (row0 + row) * XD + li * 4);
+    }
+    f32x4 pf[XPF];
+    {
+        const XfRegion reg[5] = {{p.only_kv ? nullptr : p.pq, XD * XD / 4}, {p.only_kv ? nullptr : p.po, XD * XD / 4},
+                                 {p.only_kv ? nullptr : p.p1, XMLP * XD / 4}, {p.only_kv ? nullptr : p.p2, XMLP * XD / 4},
+                                 {p.pkv_next, 2 * XD * XD / 4}};
+        xf_prefetch<5>(reg, who.slot, who.ns, tid, pf);
+    }
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int row = pass * 8 + wave * 2 + (lane >> 5);
         const bool ok = row < nv;
         const size_t gr = row0 + row;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (ok) v = ld4(p.x + gr * XD + li * 4);
+        const f32x4 v = xin[pass];
         if (p.only_kv) {
             st4(Ys + row * XP + li * 4, v);
         } else {
@@ -221,6 +306,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         }
     }
     __syncthreads();
+    xf_prefetch_done(pf);
 
     XF_STAMP(1);
     if (!p.only_kv) {
@@ -228,18 +314,12 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         {
             f32x4 acc[2];
             zero_acc<2>(acc);
-            gemm_tile<2, 8, false>(acc, As, XP, p.wq, XD, 32 * wave, m, kb);
+            gemm_tile<2, 8>(acc, As, XP, p.pq, wave, lane);
             const int c0 = 32 * wave + 2 * m;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = 4 * kb + r;
-                const f32x2 v = {acc[0][r], acc[1][r]};
-                *reinterpret_cast<f32x2*>(Qs + row * XP + c0) = v;
-                if (row < nv) *reinterpret_cast<f32x2*>(p.q + (row0 + row) * XD + c0) = v;
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u)           // rows past nv are exact zeros (their A rows are)
-                st4(p.qT + ((size_t)bz * XD + c0 + u) * Npad + t0 + 4 * kb, acc[u]);
+            for (int r = 0; r < 4; ++r)
+                *reinterpret_cast<f32x2*>(Qs + (4 * kb + r) * XP + c0) = f32x2{acc[0][r], acc[1][r]};
+            store_frag_head(p.QR, p.QC, acc, bz, wave, tile, p.tiles, m, kb);     // rows past nv are exact zeros (their A rows are)
         }
         __syncthreads();
 
@@ -255,25 +335,25 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
                 qreg[s][0] = v[0] * c; qreg[s][1] = v[1] * c; qreg[s][2] = v[2] * c; qreg[s][3] = v[3] * c;
             }
             const int ntiles = Npad >> 4;
-            const float* Kb = p.kv + (size_t)bz * N * (2 * XD) + XDH * h + 4 * kb;
+            const float* Kb = p.KR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;       // + 512 floats per tile, 256 per s
             f32x4 sT[MT];
             float mx = -INFINITY;
-            f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0;
-            {
-                const int key = m < N ? m : N - 1;
-                k0 = ld4(Kb + (size_t)key * (2 * XD));
-                k1 = ld4(Kb + (size_t)key * (2 * XD) + 16);
+            constexpr int RD = 4;                    // key tiles in flight (register ring, static indices: t is unrolled)
+            f32x4 kr[RD][2];
+            auto load_k = [&](int t, f32x4 (&dst)[2]) {
+                dst[0] = ld4(Kb + t * 512);
+                dst[1] = ld4(Kb + t * 512 + 256);
+            };
+#pragma unroll
+            for (int t = 0; t < RD - 1; ++t) {
+                kr[t][0] = kr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (t < ntiles) load_k(t, kr[t]);
             }
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 if (t < ntiles) {
-                    f32x4 n0 = k0, n1 = k1;
-                    if (t + 1 < ntiles) {
-                        int key = 16 * (t + 1) + m;
-                        key = key < N ? key : N - 1;
-                        n0 = ld4(Kb + (size_t)key * (2 * XD));
-                        n1 = ld4(Kb + (size_t)key * (2 * XD) + 16);
-                    }
+                    if (t + RD - 1 < ntiles) load_k(t + RD - 1, kr[(t + RD - 1) % RD]);
+                    const f32x4 k0 = kr[t % RD][0], k1 = kr[t % RD][1];
                     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[j], qreg[0][j], s, 0, 0, 0);
@@ -286,12 +366,23 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
                         mx = fmaxf(mx, s[r]);
                     }
                     sT[t] = s;
-                    k0 = n0; k1 = n1;
                 } else {
                     sT[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 }
             }
             XF_STAMP(3);
+            // first V tiles requested before the softmax arithmetic
+            const float* Vt = p.VC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;       // + 256 floats per tile, 256 * tiles per dt
+            f32x4 vr[RD][2];
+            auto load_v = [&](int t, f32x4 (&dst)[2]) {
+                dst[0] = ld4(Vt + t * 256);
+                dst[1] = ld4(Vt + (size_t)(ntiles + t) * 256);
+            };
+#pragma unroll
+            for (int t = 0; t < RD - 1; ++t) {
+                vr[t][0] = vr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (t < ntiles) load_v(t, vr[t]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float l = 0.f;
@@ -310,23 +401,17 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
             l += __shfl_xor(l, 32);
             XF_STAMP(4);
             // O^T[d][query] = V^T P^T:  A = V^T (transposed copy: 4 consecutive keys of feature d per lane), B = P (own registers)
-            const float* Vt = p.kvT + ((size_t)bz * (2 * XD) + XD + XDH * h + m) * Npad + 4 * kb;
             f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-            f32x4 v0 = ld4(Vt), v1 = ld4(Vt + (size_t)16 * Npad);
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 if (t < ntiles) {
-                    f32x4 n0 = v0, n1 = v1;
-                    if (t + 1 < ntiles) {
-                        n0 = ld4(Vt + 16 * (t + 1));
-                        n1 = ld4(Vt + (size_t)16 * Npad + 16 * (t + 1));
-                    }
+                    if (t + RD - 1 < ntiles) load_v(t + RD - 1, vr[(t + RD - 1) % RD]);
+                    const f32x4 v0 = vr[t % RD][0], v1 = vr[t % RD][1];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[r], sT[t][r], o[0], 0, 0, 0);
                         o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[r], sT[t][r], o[1], 0, 0, 0);
                     }
-                    v0 = n0; v1 = n1;
                 }
             }
             // lane (m = query, kb): o[dt][r] = O[query m][feature 32 h + 16 dt + 4 kb + r]
@@ -347,7 +432,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         {
             f32x4 acc[2];
             zero_acc<2>(acc);
-            gemm_tile<2, 8, false>(acc, Os, XP, p.wo, XD, 32 * wave, m, kb);
+            gemm_tile<2, 8>(acc, Os, XP, p.po, wave, lane);
             const int c0 = 32 * wave + 2 * m;
             const f32x2 bo = *reinterpret_cast<const f32x2*>(p.bo + c0);
 #pragma unroll
@@ -391,7 +476,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         {
             f32x4 acc[8];
             zero_acc<8>(acc);
-            gemm_tile<8, 8, false>(acc, As, XP, p.w1, XD, 128 * wave, m, kb);
+            gemm_tile<8, 8>(acc, As, XP, p.p1, wave, lane);
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 const int c0 = 128 * wave + 64 * gq + 4 * m;
@@ -423,7 +508,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         {
             f32x4 acc[2];
             zero_acc<2>(acc);
-            gemm_tile<2, 32, false>(acc, Gs, XGP, p.w2, XMLP, 32 * wave, m, kb);
+            gemm_tile<2, 32>(acc, Gs, XGP, p.p2, wave, lane);
             const int c0 = 32 * wave + 2 * m;
             const f32x2 b2 = *reinterpret_cast<const f32x2*>(p.b2 + c0);
 #pragma unroll
@@ -467,18 +552,11 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
 
     XF_STAMP(10);
     // ---- P7: K | V of the next instance (its context = this output): row-major and transposed ----
-    if (p.wkv_next != nullptr) {
+    if (p.pkv_next != nullptr) {
         f32x4 acc[4];
         zero_acc<4>(acc);
-        gemm_tile<4, 8, false>(acc, Ys, XP, p.wkv_next, XD, 64 * wave, m, kb);
-        const int c0 = 64 * wave + 4 * m;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * kb + r;
-            if (row < nv) st4(p.kv_next + (row0 + row) * (2 * XD) + c0, f32x4{acc[0][r], acc[1][r], acc[2][r], acc[3][r]});
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) st4(p.kvT_next + ((size_t)bz * (2 * XD) + c0 + u) * Npad + t0 + 4 * kb, acc[u]);
+        gemm_tile<4, 8>(acc, Ys, XP, p.pkv_next, wave, lane);
+        store_frag_kv(p.KRn, p.KCn, p.VRn, p.VCn, acc, bz, wave, tile, p.tiles, m, kb);       // rows past nv: zeros
     }
     XF_STAMP(11);
 }
@@ -489,13 +567,14 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
 struct XfBwdQArgs {
     const float* dy;                // [R][128] gradient w.r.t. the instance's output
     const float* x;                 // the instance's input tokens
-    const float *kv, *kvT;          // K | V of the context (row-major, transposed)
-    const float *ln1_g, *wq, *wo, *ln2_g, *w1, *w2, *lnf_g;
+    const float *KR, *KC, *VR;      // fragments of the context's K (row, column) and V (row)
+    const float *ln1_g, *ln2_g, *lnf_g;
+    const float *b2, *b1, *bo, *bq; // weight packs (dx = dy W form) of Linear 2, Linear 1, to_out, to_q
     const float *mask_o, *mask_g, *mask_f;
     float scale;
-    const float *q, *out, *lse, *x1, *h, *x2, *m1, *r1, *m2, *r2, *mf, *rf;      // saved by the forward
+    const float *QR, *out, *lse, *x1, *h, *x2, *m1, *r1, *m2, *r2, *mf, *rf;      // saved by the forward
     float *dx2, *dh, *dx1, *dq;     // dy operands of the weight gradients ([R][128], [R][mlp], [R][128], [R][128])
-    float *dout, *doutT, *delta;    // for the key-side kernel: dO row-major, transposed; delta [B][heads][Npad]
+    float *DR, *DC, *delta;         // for the key-side kernel: dO fragments (row, column); delta [B][heads][Npad]
     float* dx;                      // [R][128] gradient w.r.t. the instance's input tokens
     float* part;                    // [B*tiles][stride]: b2 | b1 | bo | ln2 g | ln2 b | ln1 g | ln1 b | lnf g | lnf b
     int stride;
@@ -519,7 +598,9 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kb = lane >> 4, li = lane & 31;
-    const int tile = blockIdx.x, bz = blockIdx.y;
+    const XfWho who = xf_who(p.B, p.tiles);
+    if (!who.live) return;
+    const int tile = who.tile, bz = who.bz;
     const int N = p.N, Npad = p.Npad;
     const int t0 = tile * XT;
     const int nv = (N - t0) < XT ? (N - t0) : XT;
@@ -528,15 +609,58 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     const int o_b2 = 0, o_b1 = XD, o_bo = XD + XMLP, o_ln2 = 2 * XD + XMLP, o_ln1 = 4 * XD + XMLP, o_lnf = 6 * XD + XMLP;
 
     XF_STAMP(0);
+    // ---- everything the tile reads from the forward pass is requested NOW (cold: written a whole encoder backward ago),
+    //      in the register layout of the phase that uses it; then the L2 warm-up of the weights and the K / V panels ----
+    f32x4 dy_r[2], x2_r[2], x1_r[2], x_r[2];
+    float mf_r[2], rf_r[2], m2_r[2], r2_r[2], m1_r[2], r1_r[2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = pass * 8 + wave * 2 + (lane >> 5);
+        const size_t gr = row0 + row;
+        dy_r[pass] = x2_r[pass] = x1_r[pass] = x_r[pass] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mf_r[pass] = rf_r[pass] = m2_r[pass] = r2_r[pass] = m1_r[pass] = r1_r[pass] = 0.f;
+        if (row < nv) {
+            dy_r[pass] = ld4(p.dy + gr * XD + li * 4); x2_r[pass] = ld4(p.x2 + gr * XD + li * 4);
+            x1_r[pass] = ld4(p.x1 + gr * XD + li * 4); x_r[pass] = ld4(p.x + gr * XD + li * 4);
+            mf_r[pass] = p.mf[gr]; rf_r[pass] = p.rf[gr]; m2_r[pass] = p.m2[gr]; r2_r[pass] = p.r2[gr];
+            m1_r[pass] = p.m1[gr]; r1_r[pass] = p.r1[gr];
+        }
+    }
+    f32x4 h_r[2][4];                        // GELU pre-activations in the layout of S2's epilogue
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * kb + r;
+            h_r[gq][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < nv) h_r[gq][r] = ld4(p.h + (row0 + row) * XMLP + 128 * wave + 64 * gq + 4 * m);
+        }
+    f32x4 q_r[2], o_r[2];                   // this lane's query / attention-output features (head = wave) for S6
+    {
+        const size_t grm = row0 + (m < nv ? m : nv - 1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            q_r[s2] = ld4(p.QR + frag_r(bz, wave, tile, s2, p.tiles) + lane * 4);
+            o_r[s2] = ld4(p.out + grm * XD + XDH * wave + 16 * s2 + 4 * kb);
+        }
+    }
+    f32x4 pf[XPF];
+    {
+        const int panel = Npad * XD / 4;            // one fragment panel of a batch element: [heads][tiles][2][64] float4
+        const XfRegion reg[7] = {{p.b2, XMLP * XD / 4}, {p.b1, XMLP * XD / 4}, {p.bo, XD * XD / 4}, {p.bq, XD * XD / 4},
+                                 {p.KR + (size_t)bz * Npad * XD, panel}, {p.VR + (size_t)bz * Npad * XD, panel},
+                                 {p.KC + (size_t)bz * Npad * XD, panel}};
+        xf_prefetch<7>(reg, who.tile, p.tiles, tid, pf);
+    }
+
     // ---- S1: final LayerNorm backward (row-wise) ----
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int row = pass * 8 + wave * 2 + (lane >> 5);
         const bool ok = row < nv;
         const size_t gr = row0 + row;
-        f32x4 dyv = {0.f, 0.f, 0.f, 0.f}, xv = dyv;
-        float mu = 0.f, rs = 0.f;
-        if (ok) { dyv = ld4(p.dy + gr * XD + li * 4); xv = ld4(p.x2 + gr * XD + li * 4); mu = p.mf[gr]; rs = p.rf[gr]; }
+        const f32x4 dyv = dy_r[pass], xv = x2_r[pass];
+        const float mu = mf_r[pass], rs = rf_r[pass];
         const f32x4 gam = ld4(p.lnf_g + li * 4);
         f32x4 xh, gg;
 #pragma unroll
@@ -559,6 +683,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
         if (ok) st4(p.dx2 + gr * XD + li * 4, dm);
     }
     __syncthreads();
+    xf_prefetch_done(pf);
     tile_colsum(T1, XP, XD, part + o_lnf, tid);
     tile_colsum(DY, XP, XD, part + o_lnf + XD, tid);
     tile_colsum(DX2M, XP, XD, part + o_b2, tid);
@@ -568,7 +693,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     {
         f32x4 acc[8];
         zero_acc<8>(acc);
-        gemm_tile<8, 8, true>(acc, DX2M, XP, p.w2, XMLP, 128 * wave, m, kb);
+        gemm_tile<8, 8>(acc, DX2M, XP, p.b2, wave, lane);
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq) {
             const int c0 = 128 * wave + 64 * gq + 4 * m;
@@ -578,7 +703,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
                 const bool ok = row < nv;
                 f32x4 dv = {0.f, 0.f, 0.f, 0.f};
                 if (ok) {
-                    const f32x4 hv = ld4(p.h + (row0 + row) * XMLP + c0);
+                    const f32x4 hv = h_r[gq][r];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) dv[c] = acc[gq * 4 + c][r] * xgelu_grad(hv[c]);
                     if (p.mask_g != nullptr) {
@@ -600,7 +725,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     {
         f32x4 acc[2];
         zero_acc<2>(acc);
-        gemm_tile<2, 32, true>(acc, DH, XGP, p.w1, XD, 32 * wave, m, kb);
+        gemm_tile<2, 32>(acc, DH, XGP, p.b1, wave, lane);
         const int c0 = 32 * wave + 2 * m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x2*>(DF + (4 * kb + r) * XP + c0) = f32x2{acc[0][r], acc[1][r]};
@@ -614,9 +739,8 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
         const int row = pass * 8 + wave * 2 + (lane >> 5);
         const bool ok = row < nv;
         const size_t gr = row0 + row;
-        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-        float mu = 0.f, rs = 0.f;
-        if (ok) { xv = ld4(p.x1 + gr * XD + li * 4); mu = p.m2[gr]; rs = p.r2[gr]; }
+        const f32x4 xv = x1_r[pass];
+        const float mu = m2_r[pass], rs = r2_r[pass];
         const f32x4 dfv = ld4(DF + row * XP + li * 4);
         const f32x4 r2v = ld4(DX2 + row * XP + li * 4);
         const f32x4 gam = ld4(p.ln2_g + li * 4);
@@ -649,17 +773,12 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     {
         f32x4 acc[2];
         zero_acc<2>(acc);
-        gemm_tile<2, 8, true>(acc, DX1M, XP, p.wo, XD, 32 * wave, m, kb);
+        gemm_tile<2, 8>(acc, DX1M, XP, p.bo, wave, lane);
         const int c0 = 32 * wave + 2 * m;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 4 * kb + r;
-            const f32x2 v = {acc[0][r], acc[1][r]};
-            *reinterpret_cast<f32x2*>(DO + row * XP + c0) = v;
-            if (row < nv) *reinterpret_cast<f32x2*>(p.dout + (row0 + row) * XD + c0) = v;
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) st4(p.doutT + ((size_t)bz * XD + c0 + u) * Npad + t0 + 4 * kb, acc[u]);
+        for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<f32x2*>(DO + (4 * kb + r) * XP + c0) = f32x2{acc[0][r], acc[1][r]};
+        store_frag_head(p.DR, p.DC, acc, bz, wave, tile, p.tiles, m, kb);      // rows past nv are exact zeros
     }
     __syncthreads();
 
@@ -668,14 +787,13 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     {
         const int h = wave;
         const float c = p.scale * XLOG2E;
-        const size_t grm = row0 + (m < nv ? m : nv - 1);
         float qreg[2][4], doreg[2][4];
         float delta = 0.f;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int cc = XDH * h + 16 * s + 4 * kb;
-            const f32x4 qv = ld4(p.q + grm * XD + cc);
-            const f32x4 ov = ld4(p.out + grm * XD + cc);
+            const f32x4 qv = q_r[s];
+            const f32x4 ov = o_r[s];
             const f32x4 dv = ld4(DO + m * XP + cc);                 // zero rows past nv
 #pragma unroll
             for (int j = 0; j < 4; ++j) { qreg[s][j] = qv[j] * c; doreg[s][j] = dv[j]; delta += dv[j] * ov[j]; }
@@ -686,25 +804,23 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
         if (kb == 0) p.delta[sidx] = delta;
         const float lse2 = p.lse[sidx];                             // +inf past nv: p = 0 there
         const int ntiles = Npad >> 4;
-        const float* Kb = p.kv + (size_t)bz * N * (2 * XD) + XDH * h + 4 * kb;
-        const float* Kt = p.kvT + ((size_t)bz * (2 * XD) + XDH * h + m) * Npad + 4 * kb;
+        const float* Kb = p.KR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
+        const float* Vb = p.VR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
+        const float* Kt = p.KC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
         f32x4 dqT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        f32x4 k0, k1, v0, v1, kt0, kt1;
-        {
-            const int key = m < N ? m : N - 1;
-            const float* kr = Kb + (size_t)key * (2 * XD);
-            k0 = ld4(kr); k1 = ld4(kr + 16); v0 = ld4(kr + XD); v1 = ld4(kr + XD + 16);
-            kt0 = ld4(Kt); kt1 = ld4(Kt + (size_t)16 * Npad);
-        }
+        // operands of key tile t: K row (2), V row (2), K^T columns (2); two tiles in flight behind the one in use
+        f32x4 A[3][6];
+        auto load_t = [&](int t, f32x4 (&d)[6]) {
+            d[0] = ld4(Kb + t * 512); d[1] = ld4(Kb + t * 512 + 256);
+            d[2] = ld4(Vb + t * 512); d[3] = ld4(Vb + t * 512 + 256);
+            d[4] = ld4(Kt + t * 256); d[5] = ld4(Kt + (size_t)(ntiles + t) * 256);
+        };
+        load_t(0, A[0]);
+        load_t(ntiles > 1 ? 1 : 0, A[1]);
+#pragma unroll 3
         for (int t = 0; t < ntiles; ++t) {
-            f32x4 nk0 = k0, nk1 = k1, nv0 = v0, nv1 = v1, nt0 = kt0, nt1 = kt1;
-            if (t + 1 < ntiles) {
-                int key = 16 * (t + 1) + m;
-                key = key < N ? key : N - 1;
-                const float* kr = Kb + (size_t)key * (2 * XD);
-                nk0 = ld4(kr); nk1 = ld4(kr + 16); nv0 = ld4(kr + XD); nv1 = ld4(kr + XD + 16);
-                nt0 = ld4(Kt + 16 * (t + 1)); nt1 = ld4(Kt + (size_t)16 * Npad + 16 * (t + 1));
-            }
+            load_t(t + 2 < ntiles ? t + 2 : ntiles - 1, A[2]);
+            const f32x4 k0 = A[0][0], k1 = A[0][1], v0 = A[0][2], v1 = A[0][3], kt0 = A[0][4], kt1 = A[0][5];
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -728,7 +844,8 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
                 dqT[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt0[r], ds[r], dqT[0], 0, 0, 0);
                 dqT[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt1[r], ds[r], dqT[1], 0, 0, 0);
             }
-            k0 = nk0; k1 = nk1; v0 = nv0; v1 = nv1; kt0 = nt0; kt1 = nt1;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) { A[0][e] = A[1][e]; A[1][e] = A[2][e]; }
         }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -746,7 +863,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     {
         f32x4 acc[2];
         zero_acc<2>(acc);
-        gemm_tile<2, 8, true>(acc, DQ, XP, p.wq, XD, 32 * wave, m, kb);
+        gemm_tile<2, 8>(acc, DQ, XP, p.bq, wave, lane);
         const int c0 = 32 * wave + 2 * m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x2*>(DA + (4 * kb + r) * XP + c0) = f32x2{acc[0][r], acc[1][r]};
@@ -760,9 +877,8 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
         const int row = pass * 8 + wave * 2 + (lane >> 5);
         const bool ok = row < nv;
         const size_t gr = row0 + row;
-        f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-        float mu = 0.f, rs = 0.f;
-        if (ok) { xv = ld4(p.x + gr * XD + li * 4); mu = p.m1[gr]; rs = p.r1[gr]; }
+        const f32x4 xv = x_r[pass];
+        const float mu = m1_r[pass], rs = r1_r[pass];
         const f32x4 dav = ld4(DA + row * XP + li * 4);
         const f32x4 r1v = ld4(DX1 + row * XP + li * 4);
         const f32x4 ryv = ld4(DY + row * XP + li * 4);
@@ -788,11 +904,11 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
 // backward, key side
 // ---------------------------------------------------------------------------------------------------------------------
 struct XfBwdKvArgs {
-    const float *q, *qT;            // queries of the instance: row-major [R][128], transposed [B][128][Npad]
-    const float* kv;                // K | V of the context, row-major
+    const float *QR, *QC;           // fragments of the instance's queries
+    const float *KR, *VR;           // row fragments of the context's K, V (this tile's own keys)
     const float *lse, *delta;       // [B][heads][Npad]
-    const float *dout, *doutT;
-    const float* wkv;
+    const float *DR, *DC;           // dO fragments
+    const float* bkv;               // weight pack (dx = dy W form) of to_kv
     const float* dctx_acc;          // what the context tensor's gradient has collected so far, or NULL
     float scale;
     float* dkv;                     // [R][256] (dy operand of to_kv's weight gradient)
@@ -809,54 +925,58 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 15, kb = lane >> 4;
-    const int tile = blockIdx.x, bz = blockIdx.y;
+    const XfWho who = xf_who(p.B, p.tiles);
+    if (!who.live) return;
+    const int tile = who.tile, bz = who.bz;
     const int N = p.N, Npad = p.Npad;
     const int t0 = tile * XT;
     const int nv = (N - t0) < XT ? (N - t0) : XT;
     const size_t row0 = (size_t)bz * N + t0;
     XF_STAMP(0);
+    f32x4 pf[XPF];
+    {   // L2 warm-up: to_kv's weight and the batch element's Q panels (from the forward pass: cold); dO / delta were
+        // written by the query-side launch just before this one, on this XCD
+        const int panel = Npad * XD / 4;
+        const XfRegion reg[3] = {{p.bkv, 2 * XD * XD / 4}, {p.QR + (size_t)bz * Npad * XD, panel},
+                                 {p.QC + (size_t)bz * Npad * XD, panel}};
+        xf_prefetch<3>(reg, who.tile, p.tiles, tid, pf);
+    }
     {
         const int h = wave;
         const float c = p.scale * XLOG2E;
         // this lane's key (B operand column j = m): K row scaled, V row
         float kreg[2][4], vreg[2][4];
-        {
-            const float* kr = p.kv + (row0 + (m < nv ? m : nv - 1)) * (2 * XD) + XDH * h + 4 * kb;
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const f32x4 kv4 = ld4(kr + 16 * s), vv4 = ld4(kr + XD + 16 * s);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { kreg[s][j] = kv4[j] * c; vreg[s][j] = vv4[j]; }
-            }
-        }
         const int ntiles = Npad >> 4;
-        const float* Qb = p.q + (size_t)bz * N * XD + XDH * h + 4 * kb;
-        const float* Db = p.dout + (size_t)bz * N * XD + XDH * h + 4 * kb;
-        const float* Qt = p.qT + ((size_t)bz * XD + XDH * h + m) * Npad + 4 * kb;
-        const float* Dt = p.doutT + ((size_t)bz * XD + XDH * h + m) * Npad + 4 * kb;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const f32x4 kv4 = ld4(p.KR + frag_r(bz, h, tile, s, ntiles) + lane * 4);
+            const f32x4 vv4 = ld4(p.VR + frag_r(bz, h, tile, s, ntiles) + lane * 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { kreg[s][j] = kv4[j] * c; vreg[s][j] = vv4[j]; }
+        }
+        const float* Qb = p.QR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
+        const float* Db = p.DR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
+        const float* Qt = p.QC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
+        const float* Dt = p.DC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
         const float* Ls = p.lse + ((size_t)bz * XH + h) * Npad + 4 * kb;
         const float* Dl = p.delta + ((size_t)bz * XH + h) * Npad + 4 * kb;
         f32x4 dkT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dvT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        f32x4 qa0, qa1, da0, da1, qt0, qt1, dt0, dt1, ls4, dl4;
-        {
-            const int qr = m < N ? m : N - 1;
-            qa0 = ld4(Qb + (size_t)qr * XD); qa1 = ld4(Qb + (size_t)qr * XD + 16);
-            da0 = ld4(Db + (size_t)qr * XD); da1 = ld4(Db + (size_t)qr * XD + 16);
-            qt0 = ld4(Qt); qt1 = ld4(Qt + (size_t)16 * Npad);
-            dt0 = ld4(Dt); dt1 = ld4(Dt + (size_t)16 * Npad);
-            ls4 = ld4(Ls); dl4 = ld4(Dl);
-        }
+        // operands of query tile t: Q row (2), dO row (2), Q^T columns (2), dO^T columns (2), lse, delta; two tiles in flight
+        f32x4 A[3][10];
+        auto load_t = [&](int t, f32x4 (&d)[10]) {
+            d[0] = ld4(Qb + t * 512); d[1] = ld4(Qb + t * 512 + 256);
+            d[2] = ld4(Db + t * 512); d[3] = ld4(Db + t * 512 + 256);
+            d[4] = ld4(Qt + t * 256); d[5] = ld4(Qt + (size_t)(ntiles + t) * 256);
+            d[6] = ld4(Dt + t * 256); d[7] = ld4(Dt + (size_t)(ntiles + t) * 256);
+            d[8] = ld4(Ls + 16 * t); d[9] = ld4(Dl + 16 * t);
+        };
+        load_t(0, A[0]);
+        load_t(ntiles > 1 ? 1 : 0, A[1]);
+#pragma unroll 3
         for (int t = 0; t < ntiles; ++t) {
-            f32x4 nqa0 = qa0, nqa1 = qa1, nda0 = da0, nda1 = da1, nqt0 = qt0, nqt1 = qt1, ndt0 = dt0, ndt1 = dt1, nls = ls4, ndl = dl4;
-            if (t + 1 < ntiles) {
-                int qr = 16 * (t + 1) + m;
-                qr = qr < N ? qr : N - 1;
-                nqa0 = ld4(Qb + (size_t)qr * XD); nqa1 = ld4(Qb + (size_t)qr * XD + 16);
-                nda0 = ld4(Db + (size_t)qr * XD); nda1 = ld4(Db + (size_t)qr * XD + 16);
-                nqt0 = ld4(Qt + 16 * (t + 1)); nqt1 = ld4(Qt + (size_t)16 * Npad + 16 * (t + 1));
-                ndt0 = ld4(Dt + 16 * (t + 1)); ndt1 = ld4(Dt + (size_t)16 * Npad + 16 * (t + 1));
-                nls = ld4(Ls + 16 * (t + 1)); ndl = ld4(Dl + 16 * (t + 1));
-            }
+            load_t(t + 2 < ntiles ? t + 2 : ntiles - 1, A[2]);
+            const f32x4 qa0 = A[0][0], qa1 = A[0][1], da0 = A[0][2], da1 = A[0][3], qt0 = A[0][4], qt1 = A[0][5],
+                        dt0 = A[0][6], dt1 = A[0][7], ls4 = A[0][8], dl4 = A[0][9];
             // s[r] = S[query 16 t + 4 kb + r][key m];  dp likewise
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -882,7 +1002,8 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
                 dkT[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt0[r], ds[r], dkT[0], 0, 0, 0);
                 dkT[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt1[r], ds[r], dkT[1], 0, 0, 0);
             }
-            qa0 = nqa0; qa1 = nqa1; da0 = nda0; da1 = nda1; qt0 = nqt0; qt1 = nqt1; dt0 = ndt0; dt1 = ndt1; ls4 = nls; dl4 = ndl;
+#pragma unroll
+            for (int e = 0; e < 10; ++e) { A[0][e] = A[1][e]; A[1][e] = A[2][e]; }
         }
         // lane (m = key, kb): dkT[dt][r] = dK[key m][feature 32 h + 16 dt + 4 kb + r]
 #pragma unroll
@@ -900,11 +1021,12 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
     }
     XF_STAMP(1);
     __syncthreads();
+    xf_prefetch_done(pf);
     // ---- dctx = dkv Wkv + what the context has collected ----
     {
         f32x4 acc[2];
         zero_acc<2>(acc);
-        gemm_tile<2, 16, true>(acc, DKV, XKP, p.wkv, XD, 32 * wave, m, kb);
+        gemm_tile<2, 16>(acc, DKV, XKP, p.bkv, wave, lane);
         const int c0 = 32 * wave + 2 * m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -920,6 +1042,36 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
         }
     }
     XF_STAMP(2);
+}
+
+// Weight packs in fragment order (see gemm_tile): dst[wave][s][u][lane][j] = B[k = 16 s + 4 (lane >> 4) + j][c],
+// c = TileMap::col(16 tpw wave, u, lane & 15);  nn == 0: B[k][c] = src[c K + k] (y = x W^T, src = W [N][K]);
+// nn == 1: B[k][c] = src[k N + c] (dx = dy W, src = W [K][N]).  One thread per 16 bytes of a pack; a few MB per step.
+struct XfPackDesc { const float* src; float* dst; int N, K, tpw, ks, nn; };
+constexpr int XF_PACK_MAX = 60;
+struct XfPackArgs { XfPackDesc d[XF_PACK_MAX]; };
+
+__global__ __launch_bounds__(256) void xf_pack_kernel(const XfPackArgs p) {
+    const XfPackDesc d = p.d[blockIdx.y];
+    const int q4 = blockIdx.x * 256 + threadIdx.x;
+    if (q4 >= d.N * d.K / 4) return;
+    const int lane = q4 & 63;
+    int r = q4 >> 6;
+    const int u = r % d.tpw;
+    r /= d.tpw;
+    const int s = r % d.ks, w = r / d.ks;
+    const int m = lane & 15, kb = lane >> 4;
+    const int G = d.tpw < 4 ? d.tpw : 4;
+    const int c = w * 16 * d.tpw + (u / G) * (16 * G) + G * m + (u % G);
+    const int k = 16 * s + 4 * kb;
+    f32x4 v;
+    if (!d.nn) {
+        v = ld4(d.src + (size_t)c * d.K + k);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = d.src[(size_t)(k + j) * d.N + c];
+    }
+    st4(d.dst + (size_t)q4 * 4, v);
 }
 
 // Column sums of the per-tile partials of ALL instances in one launch: out = sum over the tile rows, fp64 accumulation in
@@ -972,28 +1124,64 @@ int tmf_xf_npad(int N) { return (N + XT - 1) / XT * XT; }
 int tmf_xf_tiles(int N) { return (N + XT - 1) / XT; }
 int tmf_xf_part_stride(void) { return 8 * XD + XMLP; }
 
+// float offsets of the packs inside an instance's forward / backward pack buffer (XF_PACK_FLOATS each)
+enum { XF_PK_Q = 0, XF_PK_O = XD * XD, XF_PK_1 = 2 * XD * XD, XF_PK_2 = 2 * XD * XD + XMLP * XD, XF_PK_KV = 2 * XD * XD + 2 * XMLP * XD,
+       XF_PACK_FLOATS = 4 * XD * XD + 2 * XMLP * XD };
+enum { XF_BK_2 = 0, XF_BK_1 = XMLP * XD, XF_BK_O = 2 * XMLP * XD, XF_BK_Q = 2 * XMLP * XD + XD * XD, XF_BK_KV = 2 * XMLP * XD + 2 * XD * XD };
+int tmf_xf_pack_floats(void) { return XF_PACK_FLOATS; }
+int tmf_xf_pack_kv_offset(void) { return XF_PK_KV; }
+
+// Re-pack the weights of n_inst instances: pk_fwd[i] / pk_bwd[i] = XF_PACK_FLOATS floats each.
+int tmf_xf_launch_pack(int n_inst, const tmf_xformer_params* inst, float* const* pk_fwd, float* const* pk_bwd, hipStream_t s) {
+    for (int i0 = 0; i0 < n_inst; i0 += XF_PACK_MAX / 10) {
+        const int ni = (n_inst - i0) < XF_PACK_MAX / 10 ? (n_inst - i0) : XF_PACK_MAX / 10;
+        XfPackArgs a = {};
+        for (int k = 0; k < ni; ++k) {
+            const tmf_xformer_params& w = inst[i0 + k];
+            float* f = pk_fwd[i0 + k];
+            float* b = pk_bwd[i0 + k];
+            XfPackDesc* d = a.d + 10 * k;
+            d[0] = {w.wq, f + XF_PK_Q, XD, XD, 2, 8, 0};
+            d[1] = {w.wo, f + XF_PK_O, XD, XD, 2, 8, 0};
+            d[2] = {w.w1, f + XF_PK_1, XMLP, XD, 8, 8, 0};
+            d[3] = {w.w2, f + XF_PK_2, XD, XMLP, 2, 32, 0};
+            d[4] = {w.wkv, f + XF_PK_KV, 2 * XD, XD, 4, 8, 0};
+            d[5] = {w.w2, b + XF_BK_2, XMLP, XD, 8, 8, 1};             // dg = dx2 W2:  W2 [dim][mlp]
+            d[6] = {w.w1, b + XF_BK_1, XD, XMLP, 2, 32, 1};            // df = dh W1:   W1 [mlp][dim]
+            d[7] = {w.wo, b + XF_BK_O, XD, XD, 2, 8, 1};               // dout = dx1 Wo
+            d[8] = {w.wq, b + XF_BK_Q, XD, XD, 2, 8, 1};               // da = dq Wq
+            d[9] = {w.wkv, b + XF_BK_KV, XD, 2 * XD, 2, 16, 1};        // dctx = dkv Wkv: Wkv [2 inner][dim]
+        }
+        hipLaunchKernelGGL(xf_pack_kernel, dim3(XMLP * XD / 4 / 256, 10 * ni), dim3(256), 0, s, a);
+        int rc = tmf_launch_result("tmf_fusion_train_fwd(weight packs)");
+        if (rc) return rc;
+    }
+    return TMF_OK;
+}
+
 struct tmf_xf_fwd_io {
-    const float *x, *kv, *kvT, *wkv_next, *mask_o, *mask_g, *mask_f;
-    float *a, *q, *qT, *out, *lse, *x1, *f, *h, *g, *x2, *y, *m1, *r1, *m2, *r2, *mf, *rf, *kv_next, *kvT_next;
+    const float *x, *KR, *VC, *pk, *pkv_next, *mask_o, *mask_g, *mask_f;      // pk: this instance's forward pack buffer
+    float *a, *QR, *QC, *out, *lse, *x1, *f, *h, *g, *x2, *y, *m1, *r1, *m2, *r2, *mf, *rf, *KRn, *KCn, *VRn, *VCn;
 };
 
 int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fwd_io* io, float scale, int only_kv,
                       hipStream_t s) {
     XfFwdArgs a = {};
-    a.x = io->x; a.kv = io->kv; a.kvT = io->kvT; a.wkv_next = io->wkv_next;
+    a.x = io->x; a.KR = io->KR; a.VC = io->VC; a.pkv_next = io->pkv_next;
     a.mask_o = io->mask_o; a.mask_g = io->mask_g; a.mask_f = io->mask_f;
     if (w != nullptr) {
-        a.ln1_g = w->ln1_g; a.ln1_b = w->ln1_b; a.wq = w->wq; a.wo = w->wo; a.bo = w->bo; a.ln2_g = w->ln2_g; a.ln2_b = w->ln2_b;
-        a.w1 = w->w1; a.b1 = w->b1; a.w2 = w->w2; a.b2 = w->b2; a.lnf_g = w->lnf_g; a.lnf_b = w->lnf_b;
+        a.ln1_g = w->ln1_g; a.ln1_b = w->ln1_b; a.bo = w->bo; a.ln2_g = w->ln2_g; a.ln2_b = w->ln2_b;
+        a.b1 = w->b1; a.b2 = w->b2; a.lnf_g = w->lnf_g; a.lnf_b = w->lnf_b;
         a.eps1 = w->eps1; a.eps2 = w->eps2; a.epsf = w->epsf;
+        a.pq = io->pk + XF_PK_Q; a.po = io->pk + XF_PK_O; a.p1 = io->pk + XF_PK_1; a.p2 = io->pk + XF_PK_2;
     }
     a.scale = scale;
-    a.a = io->a; a.q = io->q; a.qT = io->qT; a.out = io->out; a.lse = io->lse; a.x1 = io->x1; a.f = io->f; a.h = io->h; a.g = io->g;
+    a.a = io->a; a.QR = io->QR; a.QC = io->QC; a.out = io->out; a.lse = io->lse; a.x1 = io->x1; a.f = io->f; a.h = io->h; a.g = io->g;
     a.x2 = io->x2; a.y = io->y; a.m1 = io->m1; a.r1 = io->r1; a.m2 = io->m2; a.r2 = io->r2; a.mf = io->mf; a.rf = io->rf;
-    a.kv_next = io->kv_next; a.kvT_next = io->kvT_next;
+    a.KRn = io->KRn; a.KCn = io->KCn; a.VRn = io->VRn; a.VCn = io->VCn;
     a.B = B; a.N = N; a.Npad = tmf_xf_npad(N); a.tiles = tmf_xf_tiles(N); a.only_kv = only_kv;
     a.trace = only_kv ? nullptr : g_xf_trace[0];
-    const dim3 grid(a.tiles, B), block(XTHR);
+    const dim3 grid(8 * a.tiles * ((B + 7) / 8)), block(XTHR);
     const int mt = a.Npad / 16;
     int rc;
 #define XF_LAUNCH(MT)                                                                         \
@@ -1010,38 +1198,40 @@ int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fw
 }
 
 struct tmf_xf_bwd_io {
-    const float *dy, *x, *kv, *kvT, *mask_o, *mask_g, *mask_f;
-    const float *q, *qT, *out, *lse, *x1, *h, *x2, *m1, *r1, *m2, *r2, *mf, *rf;
-    float *dx2, *dh, *dx1, *dq, *dout, *doutT, *delta, *dx, *part, *dkv, *dctx;
+    const float *dy, *x, *KR, *KC, *VR, *pk, *mask_o, *mask_g, *mask_f;        // pk: this instance's backward pack buffer
+    const float *QR, *QC, *out, *lse, *x1, *h, *x2, *m1, *r1, *m2, *r2, *mf, *rf;
+    float *dx2, *dh, *dx1, *dq, *DR, *DC, *delta, *dx, *part, *dkv, *dctx;
     const float* dctx_acc;
 };
 
 int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bwd_io* io, float scale, hipStream_t s) {
     int rc;
+    const int grid = 8 * tmf_xf_tiles(N) * ((B + 7) / 8);
     {
         XfBwdQArgs a = {};
-        a.dy = io->dy; a.x = io->x; a.kv = io->kv; a.kvT = io->kvT;
-        a.ln1_g = w->ln1_g; a.wq = w->wq; a.wo = w->wo; a.ln2_g = w->ln2_g; a.w1 = w->w1; a.w2 = w->w2; a.lnf_g = w->lnf_g;
+        a.dy = io->dy; a.x = io->x; a.KR = io->KR; a.KC = io->KC; a.VR = io->VR;
+        a.ln1_g = w->ln1_g; a.ln2_g = w->ln2_g; a.lnf_g = w->lnf_g;
+        a.b2 = io->pk + XF_BK_2; a.b1 = io->pk + XF_BK_1; a.bo = io->pk + XF_BK_O; a.bq = io->pk + XF_BK_Q;
         a.mask_o = io->mask_o; a.mask_g = io->mask_g; a.mask_f = io->mask_f;
         a.scale = scale;
-        a.q = io->q; a.out = io->out; a.lse = io->lse; a.x1 = io->x1; a.h = io->h; a.x2 = io->x2;
+        a.QR = io->QR; a.out = io->out; a.lse = io->lse; a.x1 = io->x1; a.h = io->h; a.x2 = io->x2;
         a.m1 = io->m1; a.r1 = io->r1; a.m2 = io->m2; a.r2 = io->r2; a.mf = io->mf; a.rf = io->rf;
-        a.dx2 = io->dx2; a.dh = io->dh; a.dx1 = io->dx1; a.dq = io->dq; a.dout = io->dout; a.doutT = io->doutT; a.delta = io->delta;
+        a.dx2 = io->dx2; a.dh = io->dh; a.dx1 = io->dx1; a.dq = io->dq; a.DR = io->DR; a.DC = io->DC; a.delta = io->delta;
         a.dx = io->dx; a.part = io->part; a.stride = tmf_xf_part_stride();
         a.B = B; a.N = N; a.Npad = tmf_xf_npad(N); a.tiles = tmf_xf_tiles(N);
         a.trace = g_xf_trace[1];
         auto kf = xf_bwd_q_kernel;
         if ((rc = tmf_allow_lds(kf, XF_BWDQ_LDS, "tmf_fusion_train_bwd(fused q)"))) return rc;
-        hipLaunchKernelGGL(kf, dim3(a.tiles, B), dim3(XTHR), XF_BWDQ_LDS, s, a);
+        hipLaunchKernelGGL(kf, dim3(grid), dim3(XTHR), XF_BWDQ_LDS, s, a);
         if ((rc = tmf_launch_result("tmf_fusion_train_bwd(fused q)"))) return rc;
     }
     {
         XfBwdKvArgs a = {};
-        a.q = io->q; a.qT = io->qT; a.kv = io->kv; a.lse = io->lse; a.delta = io->delta; a.dout = io->dout; a.doutT = io->doutT;
-        a.wkv = w->wkv; a.dctx_acc = io->dctx_acc; a.scale = scale; a.dkv = io->dkv; a.dctx = io->dctx;
+        a.QR = io->QR; a.QC = io->QC; a.KR = io->KR; a.VR = io->VR; a.lse = io->lse; a.delta = io->delta; a.DR = io->DR; a.DC = io->DC;
+        a.bkv = io->pk + XF_BK_KV; a.dctx_acc = io->dctx_acc; a.scale = scale; a.dkv = io->dkv; a.dctx = io->dctx;
         a.B = B; a.N = N; a.Npad = tmf_xf_npad(N); a.tiles = tmf_xf_tiles(N);
         a.trace = g_xf_trace[2];
-        hipLaunchKernelGGL(xf_bwd_kv_kernel, dim3(a.tiles, B), dim3(XTHR), XF_BWDKV_LDS, s, a);
+        hipLaunchKernelGGL(xf_bwd_kv_kernel, dim3(grid), dim3(XTHR), XF_BWDKV_LDS, s, a);
         if ((rc = tmf_launch_result("tmf_fusion_train_bwd(fused kv)"))) return rc;
     }
     return TMF_OK;
