@@ -93,30 +93,40 @@ template <int TPW> struct TileMap {
 // acc[u] += A[16 x 16 KS] . B for the lane's TPW column tiles; B from a weight pack in fragment order
 // P[wave][s][u][lane][j] = B[k = 16 s + 4 (lane >> 4) + j][TileMap<TPW>::col(16 TPW wave, u, lane & 15)]  (xf_pack_kernel).
 // A tile in LDS, row pitch KP floats.  B operands of PF steps are in flight ahead of the MFMAs (register ring).
-template <int TPW, int KS>
-__device__ __forceinline__ void gemm_tile(f32x4 (&acc)[TPW], const float* As, int KP, const float* __restrict__ P,
-                                          int wave, int lane) {
-    constexpr int PF = (TPW <= 2) ? 4 : 2;
+// prime() issues the first PF steps' loads and is called BEFORE the previous phase's epilogue: on gfx9 stores count in
+// vmcnt like loads and retire in order, so operand loads issued behind an epilogue's 10-30 global stores would wait
+// for every one of them.
+template <int TPW, int KS> struct Gemm {
+    static constexpr int PF = (TPW <= 2) ? 4 : 2;
     f32x4 b[PF + 1][TPW];
-    const float* src = P + ((size_t)wave * KS * TPW * 64 + lane) * 4;
-    auto load = [&](int s, f32x4 (&dst)[TPW]) {
+    const float* src;
+    __device__ __forceinline__ void load(int s, f32x4 (&dst)[TPW]) {
 #pragma unroll
         for (int u = 0; u < TPW; ++u) dst[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s * TPW + u) * 256);
-    };
-#pragma unroll
-    for (int s = 0; s < PF && s < KS; ++s) load(s, b[s]);
-    const float* arow = As + (lane & 15) * KP + 4 * (lane >> 4);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        if (s + PF < KS) load(s + PF, b[(s + PF) % (PF + 1)]);
-        const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 16 * s);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int u = 0; u < TPW; ++u)
-                acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b[s % (PF + 1)][u][j], acc[u], 0, 0, 0);
     }
-}
+    __device__ __forceinline__ void prime(const float* __restrict__ P, int wave, int lane) {
+        src = P + ((size_t)wave * KS * TPW * 64 + lane) * 4;
+#pragma unroll
+        for (int s = 0; s < PF && s < KS; ++s) load(s, b[s]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __device__ __forceinline__ void run(f32x4 (&acc)[TPW], const float* As, int KP, int lane) {
+        const float* arow = As + (lane & 15) * KP + 4 * (lane >> 4);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + PF < KS) {
+                load(s + PF, b[(s + PF) % (PF + 1)]);
+                __builtin_amdgcn_sched_barrier(0);       // keep the request AHEAD of this step's MFMAs (the scheduler sinks it otherwise)
+            }
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 16 * s);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int u = 0; u < TPW; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[j], b[s % (PF + 1)][u][j], acc[u], 0, 0, 0);
+        }
+    }
+};
 
 template <int TPW>
 __device__ __forceinline__ void zero_acc(f32x4 (&acc)[TPW]) {
@@ -191,25 +201,30 @@ constexpr int XPF = 20;                          // 16-byte pieces per thread (8
 struct XfRegion { const float* p; int n4; };     // n4 = float4 pieces
 template <int NR>
 __device__ __forceinline__ void xf_prefetch(const XfRegion (&reg)[NR], int slot, int ns, int tid, f32x4 (&pf)[XPF]) {
+    int n4[NR];
     long total = 0;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) total += reg[r].p != nullptr ? reg[r].n4 : 0;
+    for (int r = 0; r < NR; ++r) { n4[r] = reg[r].p != nullptr ? reg[r].n4 : 0; total += n4[r]; }
+#pragma unroll
+    for (int k = 0; k < XPF; ++k) pf[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (total == 0) return;                              // (uniform)
     const long lo = total * slot / ns, hi = total * (slot + 1) / ns;
 #pragma unroll
     for (int k = 0; k < XPF; ++k) {
+        // always a load (no divergent branches: the waits around them stay exact): pieces past the slice re-read its last one
         long g = lo + tid + (long)XTHR * k;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (g < hi) {
-            const float* src = nullptr;
+        g = g < hi ? g : hi - 1;
+        g = g < lo ? lo : g;
+        const float* base = reg[0].p;
+        bool done = false;
 #pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                const int n4 = reg[r].p != nullptr ? reg[r].n4 : 0;
-                if (src == nullptr && g < n4) src = reg[r].p + 4 * g;
-                if (src == nullptr) g -= n4;
-            }
-            if (src != nullptr) v = ld4(src);
+        for (int r = 0; r < NR; ++r) {
+            const bool here = !done && g < n4[r];
+            base = here ? reg[r].p : base;
+            done = done || here;
+            g = done ? g : g - n4[r];
         }
-        pf[k] = v;
+        pf[k] = ld4(base + 4 * g);
     }
 }
 __device__ __forceinline__ void xf_prefetch_done(f32x4 (&pf)[XPF]) {
@@ -248,7 +263,10 @@ __device__ __forceinline__ f32x4 ln_row(const f32x4 v, const float* __restrict__
     return f32x4{d[0] * rs * gg[0] + bb[0], d[1] * rs * gg[1] + bb[1], d[2] * rs * gg[2] + bb[2], d[3] * rs * gg[3] + bb[3]};
 }
 
-template <int MT>
+// MT: key tiles held in registers (16 MT >= N).  EXACT: the launch has exactly MT key tiles — the attention loops then
+// carry no run-time guards; guarded loops make the compiler drain every outstanding load at each branch join, which
+// turned the operand rings into one L2 round trip per tile (measured: 890 cycles per 16-key tile against 320 of MFMA).
+template <int MT, bool EXACT>
 __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // input rows
@@ -268,6 +286,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
     const int t0 = tile * XT;
     const int nv = (N - t0) < XT ? (N - t0) : XT;                 // valid rows of this tile
     const size_t row0 = (size_t)bz * N + t0;
+    const int ntiles = EXACT ? MT : (Npad >> 4);
 
     XF_STAMP(0);
     // ---- P0: x tile (requested first), L2 warm-up of the instance's weights, LayerNorm 1 ----
@@ -285,6 +304,8 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
                                  {p.pkv_next, 2 * XD * XD / 4}};
         xf_prefetch<5>(reg, who.slot, who.ns, tid, pf);
     }
+    Gemm<2, 8> gq;
+    if (!p.only_kv) gq.prime(p.pq, wave, lane);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         const int row = pass * 8 + wave * 2 + (lane >> 5);
@@ -309,12 +330,32 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
     xf_prefetch_done(pf);
 
     XF_STAMP(1);
+    Gemm<4, 8> gkv;
     if (!p.only_kv) {
         // ---- P1: q = LN1(x) Wq^T ----
+        constexpr int RD = 4;                    // key tiles in flight (register ring, static indices: t is unrolled)
+        const int h = wave;
+        const float* Kb = p.KR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;       // + 512 floats per tile, 256 per s
+        const float* Vt = p.VC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;       // + 256 floats per tile, 256 * tiles per dt
+        f32x4 kr[RD][2], vr[RD][2];
+        auto load_k = [&](int t, f32x4 (&dst)[2]) {
+            dst[0] = ld4(Kb + t * 512);
+            dst[1] = ld4(Kb + t * 512 + 256);
+        };
+        auto load_v = [&](int t, f32x4 (&dst)[2]) {
+            dst[0] = ld4(Vt + t * 256);
+            dst[1] = ld4(Vt + (size_t)(ntiles + t) * 256);
+        };
         {
             f32x4 acc[2];
             zero_acc<2>(acc);
-            gemm_tile<2, 8>(acc, As, XP, p.pq, wave, lane);
+            gq.run(acc, As, XP, lane);
+            // the attention's first key tiles are requested ahead of this epilogue's stores
+#pragma unroll
+            for (int t = 0; t < RD - 1; ++t) {
+                kr[t][0] = kr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (EXACT || t < ntiles) load_k(t < ntiles ? t : 0, kr[t]);
+            }
             const int c0 = 32 * wave + 2 * m;
 #pragma unroll
             for (int r = 0; r < 4; ++r)
@@ -325,8 +366,8 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
 
         XF_STAMP(2);
         // ---- P2: attention, head = wave.  S^T[key][query] = K Q^T: a lane holds 4 keys per 16-key tile of ONE query ----
+        Gemm<2, 8> go;
         {
-            const int h = wave;
             const float c = p.scale * XLOG2E;
             float qreg[2][4];
 #pragma unroll
@@ -334,37 +375,21 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
                 const f32x4 v = ld4(Qs + m * XP + XDH * h + 16 * s + 4 * kb);
                 qreg[s][0] = v[0] * c; qreg[s][1] = v[1] * c; qreg[s][2] = v[2] * c; qreg[s][3] = v[3] * c;
             }
-            const int ntiles = Npad >> 4;
-            const float* Kb = p.KR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;       // + 512 floats per tile, 256 per s
             f32x4 sT[MT];
             float mx = -INFINITY;
-            constexpr int RD = 4;                    // key tiles in flight (register ring, static indices: t is unrolled)
-            f32x4 kr[RD][2];
-            auto load_k = [&](int t, f32x4 (&dst)[2]) {
-                dst[0] = ld4(Kb + t * 512);
-                dst[1] = ld4(Kb + t * 512 + 256);
-            };
-#pragma unroll
-            for (int t = 0; t < RD - 1; ++t) {
-                kr[t][0] = kr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (t < ntiles) load_k(t, kr[t]);
-            }
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                if (t < ntiles) {
-                    if (t + RD - 1 < ntiles) load_k(t + RD - 1, kr[(t + RD - 1) % RD]);
+                if (EXACT || t < ntiles) {
+                    if (t + RD - 1 < MT && (EXACT || t + RD - 1 < ntiles)) {
+                        load_k(t + RD - 1, kr[(t + RD - 1) % RD]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     const f32x4 k0 = kr[t % RD][0], k1 = kr[t % RD][1];
                     f32x4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[j], qreg[0][j], s, 0, 0, 0);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) s = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[j], qreg[1][j], s, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = 16 * t + 4 * kb + r;
-                        s[r] = key < N ? s[r] : -INFINITY;
-                        mx = fmaxf(mx, s[r]);
-                    }
                     sT[t] = s;
                 } else {
                     sT[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -372,40 +397,44 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
             }
             XF_STAMP(3);
             // first V tiles requested before the softmax arithmetic
-            const float* Vt = p.VC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;       // + 256 floats per tile, 256 * tiles per dt
-            f32x4 vr[RD][2];
-            auto load_v = [&](int t, f32x4 (&dst)[2]) {
-                dst[0] = ld4(Vt + t * 256);
-                dst[1] = ld4(Vt + (size_t)(ntiles + t) * 256);
-            };
 #pragma unroll
             for (int t = 0; t < RD - 1; ++t) {
                 vr[t][0] = vr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (t < ntiles) load_v(t, vr[t]);
+                if (EXACT || t < ntiles) load_v(t < ntiles ? t : 0, vr[t]);
             }
+            // keys past N (only in the last tile) do not take part
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 16 * t + 4 * kb + r;
+                    sT[t][r] = key < N ? sT[t][r] : -INFINITY;
+                    mx = fmaxf(mx, sT[t][r]);
+                }
             mx = fmaxf(mx, __shfl_xor(mx, 16));
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             float l = 0.f;
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                if (t < ntiles) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float e = exp2f(sT[t][r] - mx);
-                        sT[t][r] = e;
-                        l += e;
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const float e = exp2f(sT[t][r] - mx);
+                    sT[t][r] = e;
+                    l += e;
                 }
             }
             l += __shfl_xor(l, 16);
             l += __shfl_xor(l, 32);
             XF_STAMP(4);
-            // O^T[d][query] = V^T P^T:  A = V^T (transposed copy: 4 consecutive keys of feature d per lane), B = P (own registers)
+            // O^T[d][query] = V^T P^T:  A = V column fragments (4 consecutive keys of feature d per lane), B = P (own registers)
             f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                if (t < ntiles) {
-                    if (t + RD - 1 < ntiles) load_v(t + RD - 1, vr[(t + RD - 1) % RD]);
+                if (EXACT || t < ntiles) {
+                    if (t + RD - 1 < MT && (EXACT || t + RD - 1 < ntiles)) {
+                        load_v(t + RD - 1, vr[(t + RD - 1) % RD]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     const f32x4 v0 = vr[t % RD][0], v1 = vr[t % RD][1];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
@@ -414,6 +443,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
                     }
                 }
             }
+            go.prime(p.po, wave, lane);
             // lane (m = query, kb): o[dt][r] = O[query m][feature 32 h + 16 dt + 4 kb + r]
             const float inv = 1.f / l;
 #pragma unroll
@@ -429,10 +459,12 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
 
         XF_STAMP(5);
         // ---- P4: x1 = mask_o (out Wo^T + bo) + x ----
+        Gemm<8, 8> g1;
         {
             f32x4 acc[2];
             zero_acc<2>(acc);
-            gemm_tile<2, 8>(acc, Os, XP, p.po, wave, lane);
+            go.run(acc, Os, XP, lane);
+            g1.prime(p.p1, wave, lane);
             const int c0 = 32 * wave + 2 * m;
             const f32x2 bo = *reinterpret_cast<const f32x2*>(p.bo + c0);
 #pragma unroll
@@ -473,10 +505,12 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
 
         XF_STAMP(7);
         // ---- P5: h = LN2(x1) W1^T + b1;  g = mask_g GELU(h) ----
+        Gemm<2, 32> g2;
         {
             f32x4 acc[8];
             zero_acc<8>(acc);
-            gemm_tile<8, 8>(acc, As, XP, p.p1, wave, lane);
+            g1.run(acc, As, XP, lane);
+            g2.prime(p.p2, wave, lane);
 #pragma unroll
             for (int gq = 0; gq < 2; ++gq) {
                 const int c0 = 128 * wave + 64 * gq + 4 * m;
@@ -508,7 +542,8 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         {
             f32x4 acc[2];
             zero_acc<2>(acc);
-            gemm_tile<2, 32>(acc, Gs, XGP, p.p2, wave, lane);
+            g2.run(acc, Gs, XGP, lane);
+            if (p.pkv_next != nullptr) gkv.prime(p.pkv_next, wave, lane);
             const int c0 = 32 * wave + 2 * m;
             const f32x2 b2 = *reinterpret_cast<const f32x2*>(p.b2 + c0);
 #pragma unroll
@@ -548,14 +583,16 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
             }
         }
         __syncthreads();
+    } else if (p.pkv_next != nullptr) {
+        gkv.prime(p.pkv_next, wave, lane);
     }
 
     XF_STAMP(10);
-    // ---- P7: K | V of the next instance (its context = this output): row-major and transposed ----
+    // ---- P7: K | V of the next instance (its context = this output), in fragment order ----
     if (p.pkv_next != nullptr) {
         f32x4 acc[4];
         zero_acc<4>(acc);
-        gemm_tile<4, 8>(acc, Ys, XP, p.pkv_next, wave, lane);
+        gkv.run(acc, Ys, XP, lane);
         store_frag_kv(p.KRn, p.KCn, p.VRn, p.VCn, acc, bz, wave, tile, p.tiles, m, kb);       // rows past nv: zeros
     }
     XF_STAMP(11);
@@ -652,6 +689,8 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
                                  {p.KC + (size_t)bz * Npad * XD, panel}};
         xf_prefetch<7>(reg, who.tile, p.tiles, tid, pf);
     }
+    Gemm<8, 8> g2;
+    g2.prime(p.b2, wave, lane);             // S2's first operands: ahead of S1's stores
 
     // ---- S1: final LayerNorm backward (row-wise) ----
 #pragma unroll
@@ -690,10 +729,12 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
 
     XF_STAMP(1);
     // ---- S2: dg = dx2m W2;  dh = dg * mask_g * GELU'(h) ----
+    Gemm<2, 32> g1;
     {
         f32x4 acc[8];
         zero_acc<8>(acc);
-        gemm_tile<8, 8>(acc, DX2M, XP, p.b2, wave, lane);
+        g2.run(acc, DX2M, XP, lane);
+        g1.prime(p.b1, wave, lane);
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq) {
             const int c0 = 128 * wave + 64 * gq + 4 * m;
@@ -722,10 +763,12 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
 
     XF_STAMP(2);
     // ---- S3: df = dh W1 ----
+    Gemm<2, 8> go;
     {
         f32x4 acc[2];
         zero_acc<2>(acc);
-        gemm_tile<2, 32>(acc, DH, XGP, p.b1, wave, lane);
+        g1.run(acc, DH, XGP, lane);
+        go.prime(p.bo, wave, lane);
         const int c0 = 32 * wave + 2 * m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x2*>(DF + (4 * kb + r) * XP + c0) = f32x2{acc[0][r], acc[1][r]};
@@ -770,10 +813,26 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
 
     XF_STAMP(4);
     // ---- S5: dout = dx1m Wo ----
+    const int ntiles = Npad >> 4;
+    const float* Kb = p.KR + frag_r(bz, wave, 0, 0, ntiles) + lane * 4;
+    const float* Vb = p.VR + frag_r(bz, wave, 0, 0, ntiles) + lane * 4;
+    const float* Kt = p.KC + frag_c(bz, wave, 0, 0, ntiles) + lane * 4;
+    // operands of key tile t: K row (2), V row (2), K^T columns (2).  Three buffers in fixed roles (the loop below is
+    // unrolled by three): a tile is requested two tiles before its use and nothing is ever copied — a register ring that
+    // shifts its contents reads the newest load and so waits for it, one L2 round trip per tile (measured).
+    f32x4 A0[6], A1[6], A2[6];
+    auto load_t = [&](int t, f32x4 (&d)[6]) {
+        t = t < ntiles ? t : ntiles - 1;
+        d[0] = ld4(Kb + t * 512); d[1] = ld4(Kb + t * 512 + 256);
+        d[2] = ld4(Vb + t * 512); d[3] = ld4(Vb + t * 512 + 256);
+        d[4] = ld4(Kt + t * 256); d[5] = ld4(Kt + (size_t)(ntiles + t) * 256);
+    };
     {
         f32x4 acc[2];
         zero_acc<2>(acc);
-        gemm_tile<2, 8>(acc, DX1M, XP, p.bo, wave, lane);
+        go.run(acc, DX1M, XP, lane);
+        load_t(0, A0);                      // ahead of this epilogue's stores
+        load_t(1, A1);
         const int c0 = 32 * wave + 2 * m;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -784,6 +843,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
 
     XF_STAMP(5);
     // ---- S6: dQ half of the attention backward, head = wave ----
+    Gemm<2, 8> gq;
     {
         const int h = wave;
         const float c = p.scale * XLOG2E;
@@ -803,50 +863,41 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
         const size_t sidx = ((size_t)bz * XH + h) * Npad + t0 + m;
         if (kb == 0) p.delta[sidx] = delta;
         const float lse2 = p.lse[sidx];                             // +inf past nv: p = 0 there
-        const int ntiles = Npad >> 4;
-        const float* Kb = p.KR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
-        const float* Vb = p.VR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
-        const float* Kt = p.KC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
         f32x4 dqT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        // operands of key tile t: K row (2), V row (2), K^T columns (2); two tiles in flight behind the one in use
-        f32x4 A[3][6];
-        auto load_t = [&](int t, f32x4 (&d)[6]) {
-            d[0] = ld4(Kb + t * 512); d[1] = ld4(Kb + t * 512 + 256);
-            d[2] = ld4(Vb + t * 512); d[3] = ld4(Vb + t * 512 + 256);
-            d[4] = ld4(Kt + t * 256); d[5] = ld4(Kt + (size_t)(ntiles + t) * 256);
-        };
-        load_t(0, A[0]);
-        load_t(ntiles > 1 ? 1 : 0, A[1]);
-#pragma unroll 3
-        for (int t = 0; t < ntiles; ++t) {
-            load_t(t + 2 < ntiles ? t + 2 : ntiles - 1, A[2]);
-            const f32x4 k0 = A[0][0], k1 = A[0][1], v0 = A[0][2], v1 = A[0][3], kt0 = A[0][4], kt1 = A[0][5];
+        auto step = [&](int t, const f32x4 (&cur)[6], f32x4 (&nxt)[6]) {
+            load_t(t + 2, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool on = t < ntiles;                             // the last group of three may overhang: zero weight
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[j], qreg[0][j], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[j], doreg[0][j], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[0][j], qreg[0][j], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[2][j], doreg[0][j], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(k1[j], qreg[1][j], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(v1[j], doreg[1][j], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[1][j], qreg[1][j], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[3][j], doreg[1][j], dp, 0, 0, 0);
             }
             f32x4 ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = 16 * t + 4 * kb + r;
-                const float pr = key < N ? exp2f(s[r] - lse2) : 0.f;
+                const float pr = (on && key < N) ? exp2f(s[r] - lse2) : 0.f;
                 ds[r] = pr * (dp[r] - delta) * p.scale;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                dqT[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt0[r], ds[r], dqT[0], 0, 0, 0);
-                dqT[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(kt1[r], ds[r], dqT[1], 0, 0, 0);
+                dqT[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[4][r], ds[r], dqT[0], 0, 0, 0);
+                dqT[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[5][r], ds[r], dqT[1], 0, 0, 0);
             }
-#pragma unroll
-            for (int e = 0; e < 6; ++e) { A[0][e] = A[1][e]; A[1][e] = A[2][e]; }
+        };
+        for (int t = 0; t < ntiles; t += 3) {
+            step(t, A0, A2);
+            step(t + 1, A1, A0);
+            step(t + 2, A2, A1);
         }
+        gq.prime(p.bq, wave, lane);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const int cc = XDH * h + 16 * dt + 4 * kb;
@@ -863,7 +914,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     {
         f32x4 acc[2];
         zero_acc<2>(acc);
-        gemm_tile<2, 8>(acc, DQ, XP, p.bq, wave, lane);
+        gq.run(acc, DQ, XP, lane);
         const int c0 = 32 * wave + 2 * m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<f32x2*>(DA + (4 * kb + r) * XP + c0) = f32x2{acc[0][r], acc[1][r]};
@@ -932,21 +983,30 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
     const int t0 = tile * XT;
     const int nv = (N - t0) < XT ? (N - t0) : XT;
     const size_t row0 = (size_t)bz * N + t0;
+    const int ntiles = Npad >> 4;
     XF_STAMP(0);
-    f32x4 pf[XPF];
-    {   // L2 warm-up: to_kv's weight and the batch element's Q panels (from the forward pass: cold); dO / delta were
-        // written by the query-side launch just before this one, on this XCD
-        const int panel = Npad * XD / 4;
-        const XfRegion reg[3] = {{p.bkv, 2 * XD * XD / 4}, {p.QR + (size_t)bz * Npad * XD, panel},
-                                 {p.QC + (size_t)bz * Npad * XD, panel}};
-        xf_prefetch<3>(reg, who.tile, p.tiles, tid, pf);
-    }
+    const int h = wave;
+    const float* Qb = p.QR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
+    const float* Db = p.DR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
+    const float* Qt = p.QC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
+    const float* Dt = p.DC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
+    const float* Ls = p.lse + ((size_t)bz * XH + h) * Npad + 4 * kb;
+    const float* Dl = p.delta + ((size_t)bz * XH + h) * Npad + 4 * kb;
+    // operands of query tile t: Q row (2), dO row (2), Q^T columns (2), dO^T columns (2), lse, delta — three buffers in
+    // fixed roles, a tile is requested two tiles before its use (see xf_bwd_q_kernel)
+    f32x4 A0[10], A1[10], A2[10];
+    auto load_t = [&](int t, f32x4 (&d)[10]) {
+        t = t < ntiles ? t : ntiles - 1;
+        d[0] = ld4(Qb + t * 512); d[1] = ld4(Qb + t * 512 + 256);
+        d[2] = ld4(Db + t * 512); d[3] = ld4(Db + t * 512 + 256);
+        d[4] = ld4(Qt + t * 256); d[5] = ld4(Qt + (size_t)(ntiles + t) * 256);
+        d[6] = ld4(Dt + t * 256); d[7] = ld4(Dt + (size_t)(ntiles + t) * 256);
+        d[8] = ld4(Ls + 16 * t); d[9] = ld4(Dl + 16 * t);
+    };
+    // this lane's key (B operand column j = m): K row scaled, V row
+    float kreg[2][4], vreg[2][4];
     {
-        const int h = wave;
         const float c = p.scale * XLOG2E;
-        // this lane's key (B operand column j = m): K row scaled, V row
-        float kreg[2][4], vreg[2][4];
-        const int ntiles = Npad >> 4;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const f32x4 kv4 = ld4(p.KR + frag_r(bz, h, tile, s, ntiles) + lane * 4);
@@ -954,57 +1014,57 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
 #pragma unroll
             for (int j = 0; j < 4; ++j) { kreg[s][j] = kv4[j] * c; vreg[s][j] = vv4[j]; }
         }
-        const float* Qb = p.QR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
-        const float* Db = p.DR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
-        const float* Qt = p.QC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
-        const float* Dt = p.DC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
-        const float* Ls = p.lse + ((size_t)bz * XH + h) * Npad + 4 * kb;
-        const float* Dl = p.delta + ((size_t)bz * XH + h) * Npad + 4 * kb;
+    }
+    load_t(0, A0);
+    load_t(1, A1);
+    f32x4 pf[XPF];
+    {   // L2 warm-up: to_kv's weight pack and the batch element's Q panels (from the forward pass: cold); dO / delta were
+        // written by the query-side launch just before this one, on this XCD
+        const int panel = Npad * XD / 4;
+        const XfRegion reg[3] = {{p.bkv, 2 * XD * XD / 4}, {p.QR + (size_t)bz * Npad * XD, panel},
+                                 {p.QC + (size_t)bz * Npad * XD, panel}};
+        xf_prefetch<3>(reg, who.tile, p.tiles, tid, pf);
+    }
+    Gemm<2, 16> gkv;
+    {
         f32x4 dkT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dvT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        // operands of query tile t: Q row (2), dO row (2), Q^T columns (2), dO^T columns (2), lse, delta; two tiles in flight
-        f32x4 A[3][10];
-        auto load_t = [&](int t, f32x4 (&d)[10]) {
-            d[0] = ld4(Qb + t * 512); d[1] = ld4(Qb + t * 512 + 256);
-            d[2] = ld4(Db + t * 512); d[3] = ld4(Db + t * 512 + 256);
-            d[4] = ld4(Qt + t * 256); d[5] = ld4(Qt + (size_t)(ntiles + t) * 256);
-            d[6] = ld4(Dt + t * 256); d[7] = ld4(Dt + (size_t)(ntiles + t) * 256);
-            d[8] = ld4(Ls + 16 * t); d[9] = ld4(Dl + 16 * t);
-        };
-        load_t(0, A[0]);
-        load_t(ntiles > 1 ? 1 : 0, A[1]);
-#pragma unroll 3
-        for (int t = 0; t < ntiles; ++t) {
-            load_t(t + 2 < ntiles ? t + 2 : ntiles - 1, A[2]);
-            const f32x4 qa0 = A[0][0], qa1 = A[0][1], da0 = A[0][2], da1 = A[0][3], qt0 = A[0][4], qt1 = A[0][5],
-                        dt0 = A[0][6], dt1 = A[0][7], ls4 = A[0][8], dl4 = A[0][9];
+        auto step = [&](int t, const f32x4 (&cur)[10], f32x4 (&nxt)[10]) {
+            load_t(t + 2, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            const bool on = t < ntiles;                             // the last group of three may overhang: zero weight
             // s[r] = S[query 16 t + 4 kb + r][key m];  dp likewise
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa0[j], kreg[0][j], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(da0[j], vreg[0][j], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[0][j], kreg[0][j], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[2][j], vreg[0][j], dp, 0, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa1[j], kreg[1][j], s, 0, 0, 0);
-                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(da1[j], vreg[1][j], dp, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[1][j], kreg[1][j], s, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[3][j], vreg[1][j], dp, 0, 0, 0);
             }
             f32x4 pr, ds;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pr[r] = exp2f(s[r] - ls4[r]);                   // lse = +inf on padded queries: 0
-                ds[r] = pr[r] * (dp[r] - dl4[r]) * p.scale;
+                pr[r] = on ? exp2f(s[r] - cur[8][r]) : 0.f;         // lse = +inf on padded queries: 0
+                ds[r] = pr[r] * (dp[r] - cur[9][r]) * p.scale;
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                dvT[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(dt0[r], pr[r], dvT[0], 0, 0, 0);
-                dvT[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(dt1[r], pr[r], dvT[1], 0, 0, 0);
-                dkT[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt0[r], ds[r], dkT[0], 0, 0, 0);
-                dkT[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(qt1[r], ds[r], dkT[1], 0, 0, 0);
+                dvT[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[6][r], pr[r], dvT[0], 0, 0, 0);
+                dvT[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[7][r], pr[r], dvT[1], 0, 0, 0);
+                dkT[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[4][r], ds[r], dkT[0], 0, 0, 0);
+                dkT[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[5][r], ds[r], dkT[1], 0, 0, 0);
             }
-#pragma unroll
-            for (int e = 0; e < 10; ++e) { A[0][e] = A[1][e]; A[1][e] = A[2][e]; }
+        };
+        for (int t = 0; t < ntiles; t += 3) {
+            step(t, A0, A2);
+            step(t + 1, A1, A0);
+            step(t + 2, A2, A1);
         }
+        xf_prefetch_done(pf);
+        gkv.prime(p.bkv, wave, lane);
         // lane (m = key, kb): dkT[dt][r] = dK[key m][feature 32 h + 16 dt + 4 kb + r]
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -1021,12 +1081,11 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
     }
     XF_STAMP(1);
     __syncthreads();
-    xf_prefetch_done(pf);
     // ---- dctx = dkv Wkv + what the context has collected ----
     {
         f32x4 acc[2];
         zero_acc<2>(acc);
-        gemm_tile<2, 16>(acc, DKV, XKP, p.bkv, wave, lane);
+        gkv.run(acc, DKV, XKP, lane);
         const int c0 = 32 * wave + 2 * m;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1184,15 +1243,19 @@ int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fw
     const dim3 grid(8 * a.tiles * ((B + 7) / 8)), block(XTHR);
     const int mt = a.Npad / 16;
     int rc;
-#define XF_LAUNCH(MT)                                                                         \
+#define XF_LAUNCH(MT, EX)                                                                     \
     {                                                                                         \
-        auto kf = xf_fwd_kernel<MT>;                                                          \
+        auto kf = xf_fwd_kernel<MT, EX>;                                                      \
         if ((rc = tmf_allow_lds(kf, XF_FWD_LDS, "tmf_fusion_train_fwd(fused)"))) return rc;   \
         hipLaunchKernelGGL(kf, grid, block, XF_FWD_LDS, s, a);                                \
     }
-    if (mt <= 8) XF_LAUNCH(8)
-    else if (mt <= 16) XF_LAUNCH(16)
-    else XF_LAUNCH(32)
+    // exact instances for the token counts of the benchmark volumes (96^3 -> 216, 91x109x91 -> 150, 128^3 -> 512)
+    if (mt == 14) XF_LAUNCH(14, true)
+    else if (mt == 10) XF_LAUNCH(10, true)
+    else if (mt == 32) XF_LAUNCH(32, true)
+    else if (mt <= 8) XF_LAUNCH(8, false)
+    else if (mt <= 16) XF_LAUNCH(16, false)
+    else XF_LAUNCH(32, false)
 #undef XF_LAUNCH
     return tmf_launch_result("tmf_fusion_train_fwd(fused)");
 }
