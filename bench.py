@@ -273,7 +273,7 @@ def main():
     ap.add_argument("--shape", type=int, nargs=3, default=None, metavar=("D", "H", "W"),
                     help="non-cubic volumes, e.g. 91 109 91 (the ADNI volumes of the reference, datasets/ADNI.py:96)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8, help="pairs in the bounded CPU sample")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="pairs in the bounded CPU sample (default 8; 2 above 96^3)")
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--precision", choices=["fp32", "bf16", "fp32x"], default="fp32",
                     help="bf16: forward/dgrad 3x3x3 convs on the bf16 matrix cores (BASELINE configs[2] mode; not the headline)")
@@ -297,8 +297,6 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the train-step timing: only the dominant-kernel loop (so that a rocprofv3 --stats run "
                          "of this command averages exactly the launches the roofline entry quotes)")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step from a hipGraph (measured slower than eager on ROCm 7.2: 28.0 vs 16.8 ms)")
     args = ap.parse_args()
 
     from transmf_ad_amd import model_ad, ops, _lib
@@ -335,18 +333,27 @@ def main():
         net = GradAllReduce(net)
     # same update rule as the reference's getOptimizer (utils/utils.py:38-39: Adam, lr 1e-4, wd 0): every parameter
     # tensor in ONE launch (transmf_ad_amd.optim.Adam -> tmf_adam_step); --torch-adam: torch's multi-tensor form
-    if args.torch_adam or args.graph or args.no_fused_adam:
-        opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=args.graph and world == 1,
-                               fused=not args.graph and not args.no_fused_adam)
+    if args.torch_adam or args.no_fused_adam:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=not args.no_fused_adam)
     else:
         from transmf_ad_amd.optim import Adam as OneLaunchAdam
         opt = OneLaunchAdam(net.parameters(), lr=1e-4)
     crit = nn.CrossEntropyLoss()
+    # BASELINE.md section 3 "same run also performs the numerics gate": the product's eval-mode forward at the bench's own
+    # initial parameters and inputs against the CPU oracle (<= 1e-3 on logits and loss); evaluated in the cpu_baseline leg
+    gate_state = None
+    want_gate = (rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "ad" and not args.shape
+                 and args.precision == "fp32")
+    if want_gate:
+        gate_state = {k: v.detach().cpu().clone() for k, v in (net.module if hasattr(net, "module") else net).state_dict().items()}
     B, S = args.batch, args.size
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
     vol = tuple(args.shape) if args.shape else (S, S, S)
-    mri = mri0 = torch.rand((B, 1) + vol, device=dev, generator=g)
-    pet = pet0 = torch.rand((B, 1) + vol, device=dev, generator=g)
+    # BASELINE.md section 3 inputs: np.random.RandomState(1234).rand(...) float32 in [0, 1), MRI first, then PET, from one
+    # stream (rank r: seed 1234 + r); labels arange(B) % 2.  Generated on the host once, resident in HBM afterwards.
+    import numpy as np
+    rs_in = np.random.RandomState(1234 + rank)
+    mri = mri0 = torch.from_numpy(rs_in.rand(B, 1, *vol).astype(np.float32)).to(dev)
+    pet = pet0 = torch.from_numpy(rs_in.rand(B, 1, *vol).astype(np.float32)).to(dev)
     label = label0 = (torch.arange(B, device=dev) % 2).long()
     ones = torch.ones(B, dtype=torch.int64, device=dev)
     zeros = torch.zeros(B, dtype=torch.int64, device=dev)
@@ -359,7 +366,8 @@ def main():
         rs = np.random.RandomState(1234 + rank)
         pool = [dict(MRI=(rs.rand(B, 1, *vol) * 4000.0).astype(np.float32), PET=(rs.rand(B, 1, *vol) * 9.0).astype(np.float32),
                      label=np.arange(B) % 2) for _ in range(3)]              # raw intensities; 3 host batches, cycled
-        feeder = iter(DevicePrefetcher(itertools.cycle(pool), device=dev, flip_prob=0.3, seed=rank))
+        # the reference's whole train transform (ScaleIntensity, RandFlip 0.3, RandRotate 0.3 / 0.05 rad, RandZoom 0.3 / 0.95-1)
+        feeder = iter(DevicePrefetcher(itertools.cycle(pool), device=dev, seed=rank))
         # what the box's host link delivers (pinned -> device, 64 MB copies): the ceiling of this mode
         pin = torch.empty(16 << 20, dtype=torch.float32, pin_memory=True)
         pin.fill_(1.0)                       # touch the pages: an untouched pinned buffer copies at a fantasy rate
@@ -406,30 +414,19 @@ def main():
         return loss
 
     mode = "eager"
-    if args.graph:
-        # same kernels, same order, same numerics — replayed from a hipGraph instead of re-dispatched by Python
-        try:
-            from transmf_ad_amd.graphs import GraphedTrainStep
-
-            def loss_fn(out, lab):
-                lo, dm, dp = out
-                return (crit(dm, ones) + crit(dp, zeros)) / 2 + crit(lo, lab)
-
-            graphed = GraphedTrainStep(net, opt, loss_fn, (mri, pet, label))
-            eager_step = step
-
-            def step():                      # noqa: F811
-                return graphed(mri, pet, label)
-            mode = "hipgraph"
-        except Exception as e:               # capture unsupported: fall back to the eager step, and say so
-            print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    gate_gpu = None
+    if want_gate:
+        net.eval()
+        with torch.no_grad():
+            lo_g, _dm_g, _dp_g = net(mri0, pet0)
+            gate_gpu = (lo_g.cpu(), crit(lo_g, label0).item())
+        net.train()
     loss = torch.zeros((), device=dev)
     if args.roofline_only:
         args.warmup, args.steps = 0, 0
@@ -495,6 +492,9 @@ def main():
                                by_pair, B, vol)
 
     cpu = None
+    gate = None
+    if S > 96 and args.cpu_batch == 8:
+        args.cpu_batch = 2                 # bounded sample (the contract's 10-30 s of CPU work): 128^3 steps are 2.4x as long
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tmf_oracle as O         # test infrastructure, used ONLY as the timed CPU baseline
         # MKL-DNN conv3d scales poorly past a few dozen threads (256 SMT threads: 85 s/step vs ~8 s on 8): cap at 32
@@ -509,6 +509,18 @@ def main():
                         break
         except OSError:
             pass
+        gate = None
+        if gate_gpu is not None:
+            spec = O.state_spec("model_ad")
+            S_or = O.to_state({k: v.numpy() for k, v in gate_state.items()}, spec, requires_grad=False)
+            with torch.no_grad():
+                lo_c, _d1, _d2 = O.model_ad_forward(S_or, mri0.cpu(), pet0.cpu(), train=False)
+                loss_c = torch.nn.functional.cross_entropy(lo_c, label0.cpu()).item()
+            dl = (gate_gpu[0] - lo_c).abs().max().item()
+            gate = {"what": "eval-mode forward of the product at the bench's initial parameters and inputs vs the CPU oracle "
+                            "(BASELINE.md section 3; the train-mode gates with injected Dropout masks are tests/test_gpu_model.py)",
+                    "max_abs_dlogits": dl, "abs_dloss": abs(gate_gpu[1] - loss_c), "gpu_loss": gate_gpu[1], "cpu_loss": loss_c,
+                    "tolerance": 1e-3, "pass": bool(dl <= 1e-3 and abs(gate_gpu[1] - loss_c) <= 1e-3)}
         cpu = {"value": round(args.cpu_batch / sec, 4), "unit": "volume-pairs/s", "cores": threads, "kind": "port",
                "sample": f"oracle model_ad train-mode fwd+bwd, batch {args.cpu_batch} of 1x{S}^3 pairs "
                          f"(1/{max(1, B // args.cpu_batch)} of one batch-{B} step), 1 warm-up + 3 timed steps, "
@@ -544,8 +556,8 @@ def main():
                        "dispatch": mode,
                        "optimizer": type(opt).__module__ + "." + type(opt).__name__ +
                                     (" (one launch: tmf_adam_step)" if type(opt).__module__.startswith("transmf_ad_amd") else ""),
-                       "input": ("host: raw volumes -> pinned staging -> H2D on a copy stream (double-buffered) -> device "
-                                 f"ScaleIntensity + RandFlip(0.3), every step (PCIe-inclusive); {2 * B * vol[0] * vol[1] * vol[2] * 4 / 1e6:.1f} "
+                       "input": ("host: raw volumes -> H2D on a copy stream (double-buffered) -> device ScaleIntensity + RandFlip(0.3) "
+                                 f"+ RandRotate(0.3, 0.05 rad) + RandZoom(0.3, 0.95-1), every step (PCIe-inclusive); {2 * B * vol[0] * vol[1] * vol[2] * 4 / 1e6:.1f} "
                                  f"MB per step over a host link measured at {h2d_gbps:.1f} GB/s pinned -> device on this box"
                                  if args.from_host else "resident in HBM"),
                        "setup_steps_untimed": setup_steps},
@@ -553,6 +565,8 @@ def main():
             "loss": round(final_loss, 6),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if cpu is not None and gate is not None:
+            out["numerics_gate"] = gate
         if per_rank is not None:
             out["per_rank"] = per_rank
     if world > 1:

@@ -453,48 +453,6 @@ def test_128_cubed_tokens_512():
     assert torch.isfinite(lo).all() and all(torch.isfinite(p.grad).all() for p in net.parameters())
 
 
-def test_hipgraph_step_equals_eager_step():
-    """GraphedTrainStep replays exactly the eager train step: after two steps the loss and every parameter are
-    bitwise equal to two eager steps from the same start."""
-    from transmf_ad_amd.graphs import GraphedTrainStep
-    g = Golden("ad_tiny")
-    mri, pet, y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
-    crit = nn.CrossEntropyLoss()
-
-    def loss_fn(out, lab):
-        lo, dm, dp = out
-        return (crit(dm, torch.ones_like(lab)) + crit(dp, torch.zeros_like(lab))) / 2 + crit(lo, lab)
-
-    nets, losses = [], []
-    for graphed in (False, True):
-        net = build(g).train()
-        opt = torch.optim.Adam(net.parameters(), lr=1e-3, capturable=True)
-        if graphed:
-            sd0 = {k: v.clone() for k, v in net.state_dict().items()}
-            stepper = GraphedTrainStep(net, opt, loss_fn, (mri, pet, y), warmup=1)
-            net.load_state_dict(sd0)                       # undo the warm-up updates (weights and BN buffers)
-            for st in opt.state.values():                  # ... and Adam's moments / step counters, IN PLACE: the
-                for v in st.values():                      # graph holds pointers to these tensors
-                    if torch.is_tensor(v):
-                        v.zero_()
-            ls = [stepper(mri, pet, y).item() for _ in range(2)]
-        else:
-            ls = []
-            for _ in range(2):
-                opt.zero_grad()
-                loss = loss_fn(net(mri, pet), y)
-                loss.backward()
-                opt.step()
-                ls.append(loss.item())
-        nets.append(net)
-        losses.append(ls)
-    assert losses[0] == losses[1], losses
-    for (k, a), (_, b) in zip(nets[0].state_dict().items(), nets[1].state_dict().items()):
-        if k.endswith("num_batches_tracked"):
-            continue
-        assert torch.equal(a, b), k
-
-
 @pytest.mark.parametrize("name", ["ad_mid", "ad_full_b8"])
 def test_bf16_conv_precision_mode(name):
     """BASELINE configs[2] mode: forward / data-gradient 3x3x3 convolutions on the bf16 matrix cores (operands
@@ -957,3 +915,164 @@ def test_one_launch_adam_matches_torch_adam():
     for pa in net_a.parameters():
         assert torch.equal(opt_d.state[pa]["exp_avg"], opt_a.state[pa]["exp_avg"])
         assert float(opt_d.state[pa]["step"]) == float(opt_a.state[pa]["step"])
+
+
+def _adam_run(nets_cfg, steps, g):
+    """Interleaved train steps (reference train_step with Adam) of several models built from one fixture; returns per model
+    the logits of every step and the final parameters."""
+    import transmf_ad_amd as T
+    mri, pet, y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+    k1, k2 = g.masks()
+    nets, opts, outs = [], [], []
+    for conv, storage in nets_cfg:
+        net = build(g)
+        if conv is not None:
+            net.set_precision(conv, storage)
+        nets.append(net)
+        opts.append(T.optim.Adam(net.parameters(), lr=1e-3))
+        outs.append([])
+    ce = torch.nn.CrossEntropyLoss()
+    for _ in range(steps):
+        for net, opt, out in zip(nets, opts, outs):
+            net.train()
+            opt.zero_grad()
+            lo, dm, dp = net(mri, pet)
+            ((ce(dm, torch.ones_like(y)) + ce(dp, torch.zeros_like(y))) / 2 + ce(lo, y)).backward()
+            opt.step()
+            out.append(lo.detach().clone())
+    torch.cuda.synchronize()
+    return [(o, [p.detach().clone() for p in n.parameters()]) for o, n in zip(outs, nets)]
+
+
+def test_two_precisions_live_side_by_side():
+    """Precision belongs to the module (model.set_precision -> sNet.tmf_precision -> tmf_snet_desc.precision /
+    storage_bf16), not to the process: an fp32 and a bf16-storage model_ad stepping alternately in one process each
+    produce BITWISE what they produce alone, and the process default stays untouched."""
+    import transmf_ad_amd as T
+    g = Golden("ad_mid")
+    both = _adam_run([("fp32", "fp32"), ("bf16", "bf16")], 3, g)
+    solo_a = _adam_run([("fp32", "fp32")], 3, g)[0]
+    solo_b = _adam_run([("bf16", "bf16")], 3, g)[0]
+    assert T.get_conv_precision() == "fp32"
+    for (lo_t, p_t), (lo_s, p_s) in zip(both, (solo_a, solo_b)):
+        for a, b in zip(lo_t, lo_s):
+            assert torch.equal(a, b)
+        for a, b in zip(p_t, p_s):
+            assert torch.equal(a, b)
+    assert not torch.equal(both[0][0][0], both[1][0][0])          # the two precisions do differ
+    default = _adam_run([(None, None)], 1, g)[0]                  # no setting of its own: the process default (fp32)
+    assert torch.equal(default[0][0], solo_a[0][0])
+
+
+# Measured on MI355X (round 3, 30 Adam steps at lr 1e-3 from the fixture's parameters, fixed Dropout masks, structured
+# 48^3 volumes, B = 4): max |loss_bf16 - loss_fp32| over the trajectory and the final losses are printed by the test;
+# the bands below are ~3x the measured values.
+BF16_TRAJ_BAND = {"bf16": 0.05, "bf16s": 0.05}
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16s"])
+def test_bf16_training_follows_the_fp32_trajectory(mode):
+    """TRAINING in the bf16 modes (kfold_train_adversarial.py:101-136 with Adam, utils/utils.py:38-39): 30 steps of model_ad
+    (dim 128, 48^3 structured volumes, B = 4, fixed Dropout masks) from one start in fp32 and in the bf16 mode — the loss
+    trajectories stay within a stated band of each other, both fall, and the first three fp32 steps follow the fp64 CPU
+    oracle's trajectory (same Adam) to 2e-3.  A bf16 weight-gradient |.|-sum error of tens of percent (see
+    test_config3_128_b8...) is only acceptable next to this evidence."""
+    import transmf_ad_amd as T
+    from oracle import params as P
+    from oracle import tmf_oracle as O
+    kw = dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512)
+    spec = O.state_spec("model_ad", **kw)
+    arrs = P.init_arrays(spec, seed=11)
+    B = 4
+    mri, pet, y = P.make_inputs(B, (48, 48, 48), seed=77, kind="blobs")
+    k1, k2 = P.make_masks(B, seed=5)
+    STEPS, LR = 30, 1e-3
+
+    def run(conv, storage):
+        net = T.model_ad(dropout=0., **kw)
+        net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in arrs.items()}, strict=True)
+        net = net.to(DEV).train()
+        net.set_precision(conv, storage)
+        net.fc_cls[3], net.fc_cls[7] = _FixedMask(torch.from_numpy(k1).float() * 2.0), _FixedMask(torch.from_numpy(k2).float() * 2.0)
+        opt = T.optim.Adam(net.parameters(), lr=LR)
+        m, p_, yy = (torch.from_numpy(a).to(DEV) for a in (mri, pet, y))
+        ce = torch.nn.CrossEntropyLoss()
+        losses = []
+        for _ in range(STEPS):
+            net.train()
+            opt.zero_grad()
+            lo, dm, dp = net(m, p_)
+            loss = (ce(dm, torch.ones_like(yy)) + ce(dp, torch.zeros_like(yy))) / 2 + ce(lo, yy)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        return np.array(losses)
+
+    l32 = run("fp32", "fp32")
+    l16 = run("bf16", "bf16" if mode == "bf16s" else "fp32")
+    # fp64 oracle, three steps with torch's Adam on the oracle state
+    S = O.to_state(arrs, spec, dtype=torch.float64)
+    prm = [S[k] for k, (kind, _s) in spec.items() if kind == "param"]
+    opt = torch.optim.Adam(prm, lr=LR)
+    m64, p64, y64 = torch.from_numpy(mri).double(), torch.from_numpy(pet).double(), torch.from_numpy(y)
+    masks = (torch.from_numpy(k1), torch.from_numpy(k2))
+    l64 = []
+    for _ in range(3):
+        opt.zero_grad()
+        lo, dm, dp = O.model_ad_forward(S, m64, p64, train=True, dropout_masks=masks, **{k: kw[k] for k in ("dim", "depth", "heads")})
+        loss = O.adversarial_loss(lo, dm, dp, y64)
+        loss.backward()
+        opt.step()
+        l64.append(loss.item())
+    dev16 = np.abs(l16 - l32).max()
+    print(f"[{mode}] loss fp32 {l32[0]:.4f} -> {l32[-1]:.4f}; {mode} {l16[0]:.4f} -> {l16[-1]:.4f}; max |d| {dev16:.4f}; "
+          f"fp32 vs fp64 oracle first 3 steps {np.abs(l32[:3] - np.array(l64)).max():.2e}")
+    assert np.isfinite(l16).all() and np.isfinite(l32).all()
+    assert np.abs(l32[:3] - np.array(l64)).max() < 2e-3
+    assert l32[-1] < 0.7 * l32[0] and l16[-1] < 0.7 * l16[0]              # both train
+    assert dev16 < BF16_TRAJ_BAND[mode], (dev16, l32, l16)
+
+
+class _FixedMask(torch.nn.Module):
+    """nn.Dropout stand-in with a fixed, already scaled keep-mask (the one-launch heads ask for it via tmf_keep_mask)."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x):
+        return x * self.m.to(x.device) if self.training else x
+
+    def tmf_keep_mask(self, training):
+        return self.m if training else None
+
+
+def test_one_launch_adam_survives_deepcopy_and_pickle():
+    """copy.deepcopy / pickle of transmf_ad_amd.optim.Adam (torch serialises only defaults, state and param_groups): the
+    copy rebuilds its flat moment buffers from the per-parameter state and steps exactly like the original."""
+    import copy
+    import pickle
+    import transmf_ad_amd as T
+    torch.manual_seed(2)
+    ps = [torch.nn.Parameter(torch.randn(n, device=DEV)) for n in (7, 1024, 33)]
+    opt = T.optim.Adam(ps, lr=1e-2)
+    for _ in range(2):
+        for p in ps:
+            p.grad = torch.randn_like(p)
+        opt.step()
+    grads = [torch.randn_like(p) for p in ps]
+    clones = []
+    for make in (copy.deepcopy, lambda o: pickle.loads(pickle.dumps(o))):
+        o2 = make(opt)
+        p2 = [p for g_ in o2.param_groups for p in g_["params"]]
+        for p, gr in zip(p2, grads):
+            p.grad = gr.clone()
+        o2.step()
+        clones.append([p.detach().clone() for p in p2])
+    for p, gr in zip(ps, grads):
+        p.grad = gr.clone()
+    opt.step()
+    torch.cuda.synchronize()
+    for c in clones:
+        for a, b in zip(c, ps):
+            assert torch.equal(a, b.detach())

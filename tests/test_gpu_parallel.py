@@ -1,7 +1,8 @@
 """Data-parallel wrapper on the real HIP path: two ranks share the one GPU of the test box (gloo backend with
 device tensors — RCCL refuses two ranks on one device), each with its own minibatch shard.  Exercises the
 autograd hooks, the staging stream and the two-stream encoders together; the averaged gradients must equal
-the mean of single-process per-shard gradients."""
+the mean of single-process per-shard gradients.  The RCCL code path itself (backend "nccl": asynchronous work handles
+on the staging stream, event-driven deep buckets, record_stream) runs in a 1-rank group — all a 1-GPU box allows."""
 import os
 import socket
 
@@ -135,3 +136,67 @@ def test_bucket_groups_follow_the_deep_shallow_split(tmp_path):
         if dist.is_initialized():
             dist.destroy_process_group()
         os.environ.pop("TMF_DDP_FORCE", None)
+
+
+def _nccl_one_rank_worker(port, out_dir, full):
+    """3 train steps (Adam, zero_grad(set_to_none=False) from the second on) of the model wrapped in GradAllReduce over a
+    1-rank RCCL group, and of the same model unwrapped: saves parameters + gradients of both."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import transmf_ad_amd as T
+    from transmf_ad_amd.parallel import GradAllReduce
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    res = {}
+    for wrapped in (True, False):
+        if full:
+            torch.manual_seed(3)
+            net = T.model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to("cuda:0")
+            net.fc_cls[3] = torch.nn.Identity(); net.fc_cls[7] = torch.nn.Identity()
+            mri, pet, y = (torch.from_numpy(a).to("cuda:0") for a in P.make_inputs(2, (48, 48, 48), seed=5, kind="blobs"))
+        else:
+            net = _build()
+            mri, pet, y = (torch.from_numpy(a).to("cuda:0") for a in P.make_inputs(2, SIZE, seed=100))
+        model = GradAllReduce(net) if wrapped else net
+        model.train()
+        opt = T.optim.Adam(model.parameters(), lr=1e-3)
+        ce = torch.nn.functional.cross_entropy
+        launched = []
+        if wrapped:
+            model.timing = True
+            orig = model._launch
+
+            def spy(b, _o=orig):
+                launched.append((len(b.events), len(b.streams), b.tagged))
+                return _o(b)
+            model._launch = spy
+        for it in range(3):
+            opt.zero_grad(set_to_none=(it == 0))
+            lo, dm, dp = model(mri, pet)
+            (ce(lo, y) + (ce(dm, torch.ones_like(y)) + ce(dp, torch.zeros_like(y))) / 2).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        res[wrapped] = {"params": [p.detach().cpu() for p in net.parameters()], "grads": [p.grad.cpu() for p in net.parameters()],
+                        "launched": launched, "exposed": model.exposed_allreduce_ms() if wrapped else None,
+                        "nbuckets": len(model._buckets) if wrapped else 0}
+    torch.save(res, os.path.join(out_dir, "res.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("full", [False, True], ids=["tiny", "dim128"])
+def test_rccl_one_rank_group_matches_unwrapped_model(tmp_path, full):
+    """backend "nccl" (= RCCL) with ONE rank on the box's GPU: three Adam steps of the wrapped model are BITWISE the steps of
+    the unwrapped model (all-reduce over one rank and the division by 1 are exact), incl. zero_grad(set_to_none=False);
+    every bucket was launched every step, the deep-block buckets behind ONE event and no stream (the event path of
+    tmf_snet_train_bwd), the others behind streams; the exposed all-reduce times are finite numbers (no stream leak)."""
+    mp.spawn(_nccl_one_rank_worker, args=(_free_port(), str(tmp_path), full), nprocs=1, join=True)
+    res = torch.load(tmp_path / "res.pt", weights_only=False)
+    w, u = res[True], res[False]
+    for a, b in zip(w["params"], u["params"]):
+        assert torch.equal(a, b)
+    for a, b in zip(w["grads"], u["grads"]):
+        assert torch.equal(a, b)
+    assert len(w["launched"]) == 3 * w["nbuckets"] and w["nbuckets"] >= 3
+    deep = [l for l in w["launched"] if l[2]]
+    assert len(deep) == 3 * 2 and all(ev == 1 and st == 0 for ev, st, _t in deep), deep
+    assert all(ev == 0 and st >= 1 for ev, st, t in w["launched"] if not t)
+    assert len(w["exposed"]) == 3 and all(np.isfinite(x) and 0 <= x < 1e3 for x in w["exposed"]), w["exposed"]

@@ -587,249 +587,6 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------
-// Wave-specialised forward / data-gradient kernel (tmf_set_option("conv_ws", 1); 3x3x3, Cin % 8 == 0, Cout % 64 == 0).
-// One 8-wave workgroup per CU owns an 8x8x8 brick x 64 output channels:
-//   * waves 0-3, ONE PER SIMD, only multiply: 4 M-tiles x 2 N-tiles each (128 accumulator registers), so every SIMD's
-//     matrix pipe is fed by a single in-order MFMA stream of 8 independent chains — no inter-wave interleaving;
-//   * waves 4-7 only move data: the next 8-channel chunk's halo (10x10x10 x 8 ch) and the next kd-plane of weights
-//     (9 taps x 8 ch x 64 co) go global -> registers -> LDS into the idle halves of two double buffers while the compute
-//     waves run the current (chunk, kd-plane) stage: 288 MFMAs per compute wave between two barriers.
-// Same fragment mapping as conv3d_fwd_kernel (wave-local brick row h, lane = (d, w)), same K-permutation.
-// ------------------------------------------------------------------------------------
-constexpr int WS_HP = 10, WS_NHALO = 1000, WS_CP = 12;            // halo positions, floats per position (8 + pad)
-constexpr int WS_HBUF = WS_NHALO * WS_CP;                         // floats per halo buffer
-constexpr int WS_BBUF = 9 * 8 * 64;                               // floats per weight buffer (one kd plane, one chunk)
-constexpr size_t WS_LDS_BYTES = (size_t)(2 * WS_HBUF + 2 * WS_BBUF + 4 * 64 * 2) * 4;
-
-__global__ __launch_bounds__(512, 2) void conv3d_fwd_ws_kernel(
-    const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
-    float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
-    int tilesD, int tilesH, int tilesW, int ntiles, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* halo = smem;                                  // [2][WS_HBUF]
-    float* Bs = smem + 2 * WS_HBUF;                      // [2][WS_BBUF]
-    float* red = Bs + 2 * WS_BBUF;                       // [4][64][2]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hsel = lane >> 5;
-    const bool producer = wave >= 4;
-    const int n0 = blockIdx.y * 64;
-    const int nch = Cin >> 3, nstage = 3 * nch;
-    const int tstep = gridDim.x;                         // PERSISTENT: this workgroup walks bricks blockIdx.x, + gridDim.x, ...
-
-    auto locate = [&](int vt, int& b, int& d0, int& h0, int& w0) {
-        int t = xcd_contiguous(vt, ntiles);
-        const int tw = t % tilesW; t /= tilesW;
-        const int th = t % tilesH; t /= tilesH;
-        const int td = t % tilesD;
-        b = t / tilesD;
-        d0 = td * 8; h0 = th * 8; w0 = tw * 8;
-    };
-
-    // The two roles run DIFFERENT loops with the same number of barriers (wave-uniform branch: s_barrier only counts
-    // arrivals), so the 128 accumulator registers are live in the compute waves only.  Buffer parities run on global
-    // stage / chunk counters, so the producers fill the first chunk and stage of the NEXT brick during the last
-    // stage(s) of the current one: a compute wave goes from its last MFMA of one brick to its stores and straight into
-    // the first MFMA of the next.
-    if (producer) {
-        const int pt = tid - 256;
-        int hoff[8], hdst[8], boff[5], bdst[5];
-        size_t xbase = 0;
-        auto set_brick = [&](int vt) {                   // halo addressing of brick vt
-            int b, d0, h0, w0;
-            locate(vt, b, d0, h0, w0);
-            xbase = (size_t)b * D * H * W * Cin;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int e = pt + q * 256;
-                const int pos = e >> 1, c4 = e & 1;
-                const int hw = pos % WS_HP, hh = (pos / WS_HP) % WS_HP, hd = pos / (WS_HP * WS_HP);
-                const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
-                const bool ok = e < 2 * WS_NHALO && gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
-                hoff[q] = ok ? ((gd * H + gh) * W + gw) * Cin + c4 * 4 : -1;
-            }
-        };
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int e = pt + q * 256;
-            hdst[q] = e < 2 * WS_NHALO ? (e >> 1) * WS_CP + (e & 1) * 4 : -1;
-        }
-#pragma unroll
-        for (int q = 0; q < 5; ++q) {
-            const int e = pt + q * 256;                  // float4 index inside a weight buffer: row = tap*8 + ch, 16 per row
-            const int row = e >> 4, col4 = e & 15;
-            boff[q] = e < WS_BBUF / 4 ? ((row >> 3) * Cin + (row & 7)) * Cout + n0 + col4 * 4 : -1;
-            bdst[q] = e * 4;
-        }
-        f32x4 hreg[3], breg[5];
-        auto issue_weights = [&](int stage) {            // stage = 3 * chunk + kd plane (brick-independent)
-            const int c = stage / 3, pl = stage - 3 * c;
-            const float* ws_ = w + (size_t)(pl * 9 * Cin + c * 8) * Cout;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (boff[q] >= 0 && !(dbg & 1)) v = *reinterpret_cast<const f32x4*>(ws_ + boff[q]);
-                breg[q] = v;
-            }
-        };
-        auto commit_weights = [&](int buf) {
-#pragma unroll
-            for (int q = 0; q < 5; ++q)
-                if (boff[q] >= 0 && !(dbg & 2)) *reinterpret_cast<f32x4*>(Bs + buf * WS_BBUF + bdst[q]) = breg[q];
-        };
-        auto issue_halo = [&](int c, int part) {         // pieces 3*part .. (8 pieces per thread: 3 + 3 + 2)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int q = part * 3 + k < 8 ? part * 3 + k : 7;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (part * 3 + k < 8 && hoff[q] >= 0 && !(dbg & 1)) v = *reinterpret_cast<const f32x4*>(x + xbase + hoff[q] + c * 8);
-                hreg[k] = v;
-            }
-        };
-        auto commit_halo = [&](int buf, int part) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int q = part * 3 + k < 8 ? part * 3 + k : 7;
-                if (part * 3 + k < 8 && hdst[q] >= 0 && !(dbg & 2)) *reinterpret_cast<f32x4*>(halo + buf * WS_HBUF + hdst[q]) = hreg[k];
-            }
-        };
-
-        int gs = 0, gc = 0;                              // global stage / chunk counters (buffer parities)
-        set_brick(blockIdx.x);
-        issue_weights(0);
-#pragma unroll
-        for (int part = 0; part < 3; ++part) { issue_halo(0, part); commit_halo(0, part); }
-        commit_weights(0);
-        __syncthreads();
-        for (int vt = blockIdx.x; vt < ntiles; vt += tstep) {
-            const bool more = vt + tstep < ntiles;
-            for (int s_ = 0; s_ < nstage; ++s_) {
-                const int c = s_ / 3, pl = s_ - 3 * c;
-                const bool last_chunk = c + 1 == nch;
-                if (last_chunk && pl == 0 && more) set_brick(vt + tstep);      // from here on the halo pieces are the next brick's
-                const bool next_stage = s_ + 1 < nstage || more;
-                if (next_stage) issue_weights(s_ + 1 < nstage ? s_ + 1 : 0);
-                const bool next_halo = !last_chunk || more;
-                if (next_halo) issue_halo(last_chunk ? 0 : c + 1, pl);
-                if (next_stage) commit_weights((gs + 1) & 1);
-                if (next_halo) commit_halo((gc + 1) & 1, pl);
-                __syncthreads();
-                ++gs;
-                if (pl == 2) ++gc;
-            }
-            if (stat_partial != nullptr) __syncthreads();
-        }
-        return;
-    }
-
-    // ---- compute waves ----
-    int a_lane[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {                        // compute wave cw owns tiles (d half = cw >> 1, h = (cw & 1) * 4 + i)
-        const int dh = wave >> 1, hrow = (wave & 1) * 4 + i;
-        a_lane[i] = (((dh * 4 + (l31 & 3)) * WS_HP + hrow) * WS_HP + (l31 >> 2)) * WS_CP + hsel * 4;
-    }
-    const int b_lane = hsel * 4 * 64 + l31;
-    int gs = 0, gc = 0;
-    __syncthreads();                                     // prologue buffers are filled
-    for (int vt = blockIdx.x; vt < ntiles; vt += tstep) {
-        f32x16 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-        for (int s_ = 0; s_ < nstage; ++s_) {
-            const int pl = s_ % 3;
-            const float* hp_ = halo + (gc & 1) * WS_HBUF + pl * (WS_HP * WS_HP * WS_CP);
-            const float* bs = Bs + (gs & 1) * WS_BBUF + b_lane;
-            // operands of tap t + 1 are read from LDS before the 32 MFMAs of tap t are issued: the SIMD's single
-            // compute wave has nobody to cover an LDS round trip for it
-            f32x4 a[2][4];
-            float bv[2][4][2];
-            auto fetch = [&](int buf, int tp) {
-                const int off = ((tp / 3) * WS_HP + tp % 3) * WS_CP;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) a[buf][i] = *reinterpret_cast<const f32x4*>(hp_ + a_lane[i] + off);
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) bv[buf][k][j] = bs[(tp * 8 + k) * 64 + j * 32];
-            };
-            fetch(0, 0);
-#pragma unroll
-            for (int tp = 0; tp < 9; ++tp) {
-                const int cur = tp & 1;
-                if (tp + 1 < 9) fetch(cur ^ 1, tp + 1);
-                __builtin_amdgcn_sched_barrier(0);   // keep the next tap's LDS reads AHEAD of this tap's 32 MFMAs
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][k], bv[cur][k][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-            ++gs;
-            if (pl == 2) ++gc;
-        }
-
-        // ---- epilogue: store + BatchNorm statistic partials ----
-        int b, d0, h0, w0;
-        locate(vt, b, d0, h0, w0);
-        const int tile = xcd_contiguous(vt, ntiles);
-        float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
-        {
-            float* zb = z + (size_t)b * D * H * W * Cout;
-            const int dh = wave >> 1;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int gh = h0 + (wave & 1) * 4 + i;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gd = d0 + dh * 4 + (r & 3), gw = w0 + 2 * (r >> 2) + hsel;
-                    if (gd < D && gh < H && gw < W) {
-                        const int off = ((gd * H + gh) * W + gw) * Cout + n0 + l31;
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const float v = acc[i][j][r];
-                            if (!(dbg & 4) || v == 1.2345e37f) __builtin_nontemporal_store(v, &zb[off + j * 32]);
-                            s1[j] += v;
-                            s2[j] += v * v;
-                        }
-                    }
-                }
-            }
-        }
-        if (stat_partial != nullptr) {
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                s1[j] += __shfl_xor(s1[j], 32);
-                s2[j] += __shfl_xor(s2[j], 32);
-                if (hsel == 0) {
-                    red[(wave * 64 + j * 32 + l31) * 2] = s1[j];
-                    red[(wave * 64 + j * 32 + l31) * 2 + 1] = s2[j];
-                }
-            }
-            __syncthreads();
-            if (tid < 64) {
-                float a1 = 0.f, a2 = 0.f;
-#pragma unroll
-                for (int m = 0; m < 4; ++m) { a1 += red[(m * 64 + tid) * 2]; a2 += red[(m * 64 + tid) * 2 + 1]; }
-                stat_partial[((size_t)tile * 2 + 0) * Cout + n0 + tid] = a1;
-                stat_partial[((size_t)tile * 2 + 1) * Cout + n0 + tid] = a2;
-            }
-        }
-    }
-}
-
-// Config table.  Names: <brick><NB>.
-//  L32 / L64 : 4x8x8 brick (256 voxels), 32 / 64 output channels per workgroup, 3 taps per weight stage
-//  S128      : 4x4x4 brick (64 voxels), 128 output channels, 1 tap per stage (deep, small layers)
 template <int KS, int CINC> using CfgL32 = FwdCfg<KS, CINC, 2, 1, 4, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgL64 = FwdCfg<KS, CINC, 2, 2, 4, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgS128 = FwdCfg<KS, CINC, 1, 2, 2, 2, 4, 4, 4, 1>;
@@ -851,7 +608,6 @@ template <int KS, int CINC> using CfgM64 = FwdCfg<KS, CINC, 1, 2, 4, 1, 4, 4, 8,
 // stages / stores while the other multiplies (measured +3..7 % over 8 on the 48^3 layers)
 int g_debug = 0;          // timing ablations only (tmf_set_option("debug", bits)); results are garbage when set
 int g_conv_waves = 0;
-int g_conv_ws = 0;            // wave-specialised forward kernel for eligible layers (experiment)
 int conv_waves() {
     if (g_conv_waves == 0) {
         const char* e = getenv("TMF_CONV_WAVES");
@@ -906,10 +662,6 @@ FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks) {
     else if (p.cinc == 32 && conv_waves() == 2) {
         if (p.cfg == 2) p.cfg = 5;
         else { p.cfg += 6; th = 4; }
-    }
-    if (g_conv_ws && ks == 3 && (p.cfg == 8 || p.cfg == 9 || p.cfg == 3 || p.cfg == 4) && cin % 8 == 0 && cout % 64 == 0 &&
-        mind >= 16) {
-        p.cfg = 10; td = 8; th = 8; tw = 8; nb = 64;
     }
     p.tilesD = tmf_cdiv(D, td); p.tilesH = tmf_cdiv(H, th); p.tilesW = tmf_cdiv(W, tw);
     p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
@@ -991,7 +743,7 @@ const char* fwd_kernel_name(const FwdPlan& p) {
     if (p.cfg == 7) { TMF_FWD_CASE(CfgM64, 32) }
     if (p.cfg == 11) { TMF_FWD_CASE(CfgS64, 32) }
 #undef TMF_FWD_CASE
-    return p.cfg == 10 ? "conv3d_fwd_ws_kernel" : "?";
+    return "?";
 }
 
 // ------------------------------------------------------------------------------------
@@ -1588,7 +1340,6 @@ extern "C" int tmf_set_option(const char* name, int value) {
         return TMF_OK;
     }
     if (strcmp(name, "debug") == 0) { g_debug = value; tmf_g_debug = value; return TMF_OK; }
-    if (strcmp(name, "conv_ws") == 0) { g_conv_ws = value; return TMF_OK; }
     if (strcmp(name, "bf16_v2") == 0) {
         TMF_REQUIRE(value >= 0 && value <= 2, TMF_E_ARG, "tmf_set_option: bf16_v2 must be 0, 1 or 2, got %d", value);
         tmf_g_bf16_v2 = value;
@@ -1644,14 +1395,6 @@ extern "C" int tmf_conv3d_fwd(const float* x, const float* w, float* z, float* s
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w); TMF_REQUIRE_ALIGNED(z);
     const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize);
     hipStream_t s = (hipStream_t)stream;
-    if (p.cfg == 10) {
-        int rc;
-        if ((rc = tmf_allow_lds(conv3d_fwd_ws_kernel, WS_LDS_BYTES, "tmf_conv3d_fwd(ws)"))) return rc;
-        const int gx = p.ntiles * p.nby > 256 ? tmf_cdiv(256, p.nby) & ~7 : p.ntiles;        // one workgroup per CU, walking bricks
-        hipLaunchKernelGGL(conv3d_fwd_ws_kernel, dim3(gx > 0 ? gx : p.ntiles, p.nby), dim3(512), WS_LDS_BYTES, s, x, w, z,
-                           stat_partial, D, H, W, cin, cout, p.tilesD, p.tilesH, p.tilesW, p.ntiles, g_conv_ws >> 1);
-        return tmf_launch_result("tmf_conv3d_fwd(ws)");
-    }
     return ksize == 3 ? launch_fwd<3>(p, x, w, z, stat_partial, D, H, W, cin, cout, s)
                       : launch_fwd<1>(p, x, w, z, stat_partial, D, H, W, cin, cout, s);
 }

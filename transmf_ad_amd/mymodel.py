@@ -75,6 +75,14 @@ class _FastModeSwitch:
     against the live tree on every call (every child of every cached module must be cached, and nothing else) and
     rebuilt when a sub-module was added, removed or replaced anywhere below."""
 
+    def set_precision(self, conv="fp32", storage="fp32"):
+        """Convolution precision / activation storage of THIS model's encoders (sNet.set_precision), independent of other
+        models in the process; conv=None returns to the process default."""
+        for m in self.modules():
+            if isinstance(m, sNet):
+                m.set_precision(conv, storage)
+        return self
+
     def tmf_backward_streams(self, device):
         """parallel.GradAllReduce asks the wrapped module which streams (besides the caller's) its backward uses."""
         return backward_streams(device)

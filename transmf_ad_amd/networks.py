@@ -68,6 +68,14 @@ class sNet(nn.Module):
         # are complete well before the encoder's backward returns (tmf_snet_grads.deep_event); they get buckets of their own
         for name, p in self.named_parameters():
             p.tmf_bucket_group = ("sNet deep", id(self)) if name.startswith(("conv3", "conv4")) else ("sNet shallow",)
+        self.tmf_precision = None           # None: follow the process default (ops.set_conv_precision / set_activation_storage)
+
+    def set_precision(self, conv="fp32", storage="fp32"):
+        """Precision of THIS encoder's convolution products ("fp32" | "bf16" | "fp32x") and of the activations between its
+        blocks ("fp32" | "bf16", the latter with conv "bf16" only) — independent of any other module in the process;
+        conv=None returns to the process default."""
+        self.tmf_precision = None if conv is None else ops.make_precision(conv, storage)
+        return self
 
     @device_guard
     def forward_channels_last(self, vol):
@@ -81,21 +89,22 @@ class sNet(nn.Module):
             if nbt:
                 torch._foreach_add_(nbt, 1)
         blocks = [(getattr(self, n)[i], getattr(self, n)[i + 1], getattr(self, n)[i + 2]) for n, i, _ in self._PLAN]
-        if (not self.training and not torch.is_grad_enabled() and ops.get_conv_precision() == "fp32" and ops.FUSE_EVAL_BLOCKS
+        prec = ops.resolve_precision(self.tmf_precision)
+        if (not self.training and not torch.is_grad_enabled() and prec[0] == "fp32" and ops.FUSE_EVAL_BLOCKS
                 and all(bn.track_running_stats for _c, bn, _a in blocks) and self._one_call_ok(vol, blocks, eval_mode=True)):
             return ops.snet_eval_one_call(
                 vol, blocks[-1][0].out_channels, tuple(float(bn.eps) for _c, bn, _a in blocks),
                 tuple(float(a.negative_slope) for _c, _b, a in blocks),
                 [(c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var) for c, bn, _a in blocks])
-        if self._one_call_ok(vol, blocks):
+        if self._one_call_ok(vol, blocks, prec=prec):
             params, buffers = [], []
             for conv, bn, _act in blocks:
                 params += [conv.weight, conv.bias, bn.weight, bn.bias]
                 buffers.append((bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None))
             cfg = (blocks[-1][0].out_channels, tuple(float(bn.momentum) for _c, bn, _a in blocks),
-                   tuple(float(bn.eps) for _c, bn, _a in blocks), tuple(float(a.negative_slope) for _c, _b, a in blocks))
+                   tuple(float(bn.eps) for _c, bn, _a in blocks), tuple(float(a.negative_slope) for _c, _b, a in blocks), prec)
             return ops.SNetTrain.apply(vol, cfg, buffers, *params)
-        store16 = ops.activation_storage_bf16()
+        store16 = prec[1]
         for n_blk, (seq_name, i, pool) in enumerate(self._PLAN):
             seq = getattr(self, seq_name)
             conv, bn, act = seq[i], seq[i + 1], seq[i + 2]
@@ -112,17 +121,17 @@ class sNet(nn.Module):
             x = ops.conv_bn_act_pool(x, conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
                                      bn.running_var, self.training or not bn.track_running_stats,
                                      momentum=momentum, eps=bn.eps, slope=act.negative_slope, pool=pool,
-                                     out_bf16=out16)
+                                     out_bf16=out16, precision=prec)
         return x                                 # (B, d, h, w, dim)
 
-    def _one_call_ok(self, vol, blocks, eval_mode=False):
+    def _one_call_ok(self, vol, blocks, eval_mode=False, prec=None):
         """Train-mode batch statistics in every block, the standard sNet(dim) geometry, no gradient wanted for the
         input: the whole pass is one library call (ops.SNetTrain); anything else goes block by block."""
         if vol.requires_grad or not vol.is_cuda or vol.dtype != torch.float32:
             return False
         B, _, D, H, W = vol.shape
         dim = blocks[-1][0].out_channels
-        if not ops.snet_one_call_supported(B, D, H, W, dim):
+        if not ops.snet_one_call_supported(B, D, H, W, dim, prec):
             return False
         q, h = dim // 4, dim // 2
         want = ((1, q, 3), (q, q, 3), (q, h, 3), (h, h, 3), (h, dim, 3), (dim, 2 * dim, 3), (2 * dim, dim, 1))

@@ -7,7 +7,6 @@ fp32, contiguous, on a HIP device; activations are channels-last (B, D, H, W, C)
 from __future__ import annotations
 
 import os
-import weakref
 
 import torch
 
@@ -69,15 +68,22 @@ def unpack_wgrad(dw: torch.Tensor, cout: int, cin: int, k: int) -> torch.Tensor:
     return dw.view(k, k, k, cin, cout).permute(4, 3, 0, 1, 2).contiguous()
 
 
+# Precision of the convolution products is a property of the MODULE that runs them (sNet.set_precision / model.set_precision
+# -> sNet.tmf_precision), handed down explicitly to every op and into tmf_snet_desc.precision / .storage_bf16; two models with
+# different precisions live side by side in one process.  The two setters below only change the DEFAULT that modules
+# without a setting of their own follow (the round-1 API: bench.py --precision, the parity tests).
 _PRECISION = "fp32"
+_ACT16 = False
+_b16 = torch.bfloat16
+_CONV_MODES = ("fp32", "fp32x", "bf16")
 
 
 def set_conv_precision(precision: str) -> None:
-    """"fp32" (default: exact-fp32 MFMA everywhere); "bf16": the forward and data-gradient 3x3x3 convolutions
-    round their operands to bf16 and run on the bf16 matrix cores with fp32 accumulation (tensors stay fp32);
-    "fp32x": fp32-accurate 3-way bf16 split (six partial products) on the bf16 matrix cores."""
+    """Process DEFAULT for modules that have no precision of their own: "fp32" (exact-fp32 MFMA everywhere); "bf16": the
+    forward, data-gradient and weight-gradient 3x3x3 convolutions round their operands to bf16 and run on the bf16 matrix
+    cores with fp32 accumulation (tensors stay fp32); "fp32x": fp32-accurate 3-way bf16 split (six partial products)."""
     global _PRECISION
-    if precision not in ("fp32", "fp32x", "bf16"):
+    if precision not in _CONV_MODES:
         raise ValueError(precision)
     _PRECISION = precision
 
@@ -86,13 +92,9 @@ def get_conv_precision() -> str:
     return _PRECISION
 
 
-_ACT16 = False
-_b16 = torch.bfloat16
-
-
 def set_activation_storage(dtype: str) -> None:
-    """"fp32" (default) or "bf16": with conv precision "bf16", keep the sNet activations BETWEEN the conv blocks (raw
-    conv outputs z, block outputs, and their gradients) as bf16 tensors — BASELINE configs[2] "bf16 storage".  The
+    """Process DEFAULT: "fp32" or "bf16" — with conv precision "bf16", keep the sNet activations BETWEEN the conv blocks
+    (raw conv outputs z, block outputs, and their gradients) as bf16 tensors — BASELINE configs[2] "bf16 storage".  The
     network input, the BatchNorm statistics / parameters, the 1x1x1 layer and everything after the encoders stay fp32."""
     global _ACT16
     if dtype not in ("fp32", "bf16"):
@@ -100,8 +102,22 @@ def set_activation_storage(dtype: str) -> None:
     _ACT16 = dtype == "bf16"
 
 
-def activation_storage_bf16() -> bool:
-    return _ACT16 and _PRECISION == "bf16"
+def make_precision(conv: str = "fp32", storage: str = "fp32"):
+    """(conv mode, bf16 activation storage) as the ops take it; storage "bf16" only has an effect with conv "bf16"."""
+    if conv not in _CONV_MODES or storage not in ("fp32", "bf16"):
+        raise ValueError((conv, storage))
+    return (conv, storage == "bf16" and conv == "bf16")
+
+
+def resolve_precision(precision=None):
+    """None -> the process default; else a make_precision() pair."""
+    if precision is None:
+        return (_PRECISION, _ACT16 and _PRECISION == "bf16")
+    return precision
+
+
+def activation_storage_bf16(precision=None) -> bool:
+    return resolve_precision(precision)[1]
 
 
 def bf16_conv_capable(cin: int, k: int) -> bool:
@@ -228,15 +244,16 @@ class ConvBnActPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var,
-                training, momentum, eps, slope, pool, out_bf16=False):
+                training, momentum, eps, slope, pool, out_bf16=False, precision=None):
+        mode, act16 = resolve_precision(precision)
         x = _chk(x, "x", allow_bf16=True)
         cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
         B, D, H, W, C = x.shape
         if C != cin:
             raise _lib.TmfError(f"conv expects {cin} input channels, got {C}")
         weight = _chk(weight, "weight")
-        bf16 = _PRECISION if (_PRECISION != "fp32" and k == 3 and cin % 8 == 0 and cin > 1) else False
-        z16 = bf16 == "bf16" and _ACT16          # raw conv output (and dz) stored as bf16
+        bf16 = mode if (mode != "fp32" and k == 3 and cin % 8 == 0 and cin > 1) else False
+        z16 = bf16 == "bf16" and act16           # raw conv output (and dz) stored as bf16
         if x.dtype == _b16 and bf16 != "bf16":
             x = x.float()                         # only the bf16 kernels read bf16 tensors
         if out_bf16 and not z16:
@@ -336,7 +353,7 @@ class ConvBnActPool(torch.autograd.Function):
                 dx, _, _ = conv3d_raw(dzf, weight if ctx.packed_dgrad else pack_weight_dgrad(weight), cout, cin, k, False)
             if dx.dtype != x.dtype:
                 dx = dx.to(x.dtype)
-        return (dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None)
+        return (dx, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None, None)
 
 
 class Conv1BnPool(torch.autograd.Function):
@@ -345,7 +362,8 @@ class Conv1BnPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, training, momentum, eps, slope,
-                out_bf16=False):
+                out_bf16=False, precision=None):
+        mode, _act16 = resolve_precision(precision)
         x = _chk(x, "x")
         B, D, H, W, _ = x.shape
         C = weight.shape[0]
@@ -356,7 +374,7 @@ class Conv1BnPool(torch.autograd.Function):
         scale = torch.empty(C, device=dev, dtype=_f32)
         shift = torch.empty(C, device=dev, dtype=_f32)
         s = _stream()
-        sfx = "_bf16" if _PRECISION == "bf16" else ""      # both products on the bf16 matrix cores (opt-in mode)
+        sfx = "_bf16" if mode == "bf16" else ""            # both products on the bf16 matrix cores (opt-in mode)
         if training:
             nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
             part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
@@ -416,7 +434,7 @@ class Conv1BnPool(torch.autograd.Function):
                       ws.data_ptr(), nbytes, B, D, H, W, C, slope, *p16, _lib.DW_REFERENCE, s)
         if ctx.needs_input_grad[0]:
             raise _lib.TmfError("the fused first block has no data gradient (the network input needs none)")
-        return (None, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None)
+        return (None, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None)
 
 
 def conv_bn_act_pool_eval_fused(x, weight, bias, gamma, beta, running_mean, running_var, eps, slope, pool):
@@ -445,19 +463,22 @@ FUSE_EVAL_BLOCKS = os.environ.get("TMF_FUSE_EVAL", "1") != "0"
 
 
 def conv_bn_act_pool(x, weight, bias, gamma, beta, running_mean, running_var, training,
-                     momentum=0.1, eps=1e-5, slope=0.01, pool=None, out_bf16=False):
+                     momentum=0.1, eps=1e-5, slope=0.01, pool=None, out_bf16=False, precision=None):
+    """precision: make_precision(conv, storage) of the calling module, None = the process default."""
+    precision = resolve_precision(precision)
+    mode, act16 = precision
     needs_graph = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or gamma.requires_grad)
-    if (FUSE_EVAL_BLOCKS and not training and not needs_graph and _PRECISION == "fp32" and weight.shape[1] > 1
+    if (FUSE_EVAL_BLOCKS and not training and not needs_graph and mode == "fp32" and weight.shape[1] > 1
             and weight.shape[1] % 4 == 0 and weight.shape[0] % 4 == 0):
         return conv_bn_act_pool_eval_fused(x, weight, bias, gamma, beta, running_mean, running_var, eps, slope, pool)
     if (weight.shape[1] == 1 and weight.shape[2] == 3 and pool == "max" and not x.requires_grad):
-        if out_bf16 and _PRECISION != "bf16":
+        if out_bf16 and mode != "bf16":
             raise _lib.TmfError("a bf16 block output needs conv precision 'bf16'")
         return Conv1BnPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
-                                 training, momentum, eps, slope, out_bf16 and _PRECISION == "bf16")
-    can16 = out_bf16 and activation_storage_bf16() and bf16_conv_capable(weight.shape[1], weight.shape[2])
+                                 training, momentum, eps, slope, out_bf16 and mode == "bf16", precision)
+    can16 = out_bf16 and act16 and bf16_conv_capable(weight.shape[1], weight.shape[2])
     y = ConvBnActPool.apply(x, weight, bias, gamma, beta, running_mean, running_var,
-                            training, momentum, eps, slope, pool, can16)
+                            training, momentum, eps, slope, pool, can16, precision)
     return y.to(_b16) if (out_bf16 and not can16) else y
 
 
@@ -469,8 +490,8 @@ def conv_bn_act_pool(x, weight, bias, gamma, beta, running_mean, running_var, tr
 SNET_ONE_CALL = os.environ.get("TMF_SNET_C", "1") != "0"
 
 
-def snet_one_call_supported(B, D, H, W, dim):
-    return (SNET_ONE_CALL and _PRECISION in ("fp32", "bf16") and dim >= 32 and dim % 32 == 0
+def snet_one_call_supported(B, D, H, W, dim, precision=None):
+    return (SNET_ONE_CALL and resolve_precision(precision)[0] in ("fp32", "bf16") and dim >= 32 and dim % 32 == 0
             and min(D, H, W) >= 16 and B > 0)
 
 
@@ -494,27 +515,28 @@ def snet_eval_one_call(vol, dim, eps, slope, blocks):
 
 
 # Gradient tensors whose producing kernels finish BEFORE the backward call that produced them returns: data pointer ->
-# (event recorded behind their last kernel, weak reference to the flat buffer they are views of).  Filled by
-# SNetTrain.backward for the deep blocks of an encoder, consumed by parallel.GradAllReduce (which then waits for the event
-# instead of for the whole producing stream).  An entry is only honoured while its flat buffer is alive (the memory
-# cannot have been handed to another tensor) and the queried tensor is a view of it; entries of dead buffers are dropped on
-# lookup and overwritten by the next backward — nothing depends on anybody clearing the table, and it pins no memory.
+# (event recorded behind their last kernel, the flat buffer they are views of, owner).  Filled by SNetTrain.backward for
+# the deep blocks of an encoder, consumed by parallel.GradAllReduce (which then waits for the event instead of for the
+# whole producing stream).  An entry HOLDS its flat buffer, so the address cannot be handed to another tensor while the
+# entry exists (a stale event for a new tensor at the same address would be a race); entries are dropped by the wrapper
+# at the end of every backward, and an encoder's forward drops the entries of ITS OWN previous backward only (owner =
+# the encoder's first parameter) — another model's forward between a backward and the wrapper's hook takes nothing away.
 GRAD_READY_EVENTS = {}
 
 
 def grad_ready_event(grad):
     """The event behind the last kernel that writes `grad`, if one was recorded for exactly this buffer."""
-    key = grad.data_ptr()
-    ent = GRAD_READY_EVENTS.get(key)
+    ent = GRAD_READY_EVENTS.get(grad.data_ptr())
     if ent is None:
         return None
-    ev, flat_ref = ent
-    flat = flat_ref()
-    if flat is None:
-        del GRAD_READY_EVENTS[key]
-        return None
+    ev, flat, _owner = ent
     same = grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
     return ev if same else None
+
+
+def _drop_grad_events(owner):
+    for k in [k for k, v in GRAD_READY_EVENTS.items() if v[2] == owner]:
+        del GRAD_READY_EVENTS[k]
 
 
 class SNetTrain(torch.autograd.Function):
@@ -526,11 +548,13 @@ class SNetTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vol, cfg, buffers, *params):
         import ctypes as C
+        ctx.owner = params[0].data_ptr()
+        _drop_grad_events(ctx.owner)            # this encoder's previous backward (nothing of it is pending in its forward)
         vol = _chk(vol, "vol")
-        dim, momentum, eps, slope = cfg
+        dim, momentum, eps, slope = cfg[:4]
+        mode, act16 = resolve_precision(cfg[4] if len(cfg) > 4 else None)
         B, _, D, H, W = vol.shape
-        desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision=1 if _PRECISION == "bf16" else 0,
-                             storage_bf16=int(activation_storage_bf16()))
+        desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision=1 if mode == "bf16" else 0, storage_bf16=int(act16))
         prm = _lib.SnetParams()
         for l in range(7):
             desc.momentum[l], desc.eps[l], desc.slope[l] = momentum[l], eps[l], slope[l]
@@ -579,12 +603,11 @@ class SNetTrain(torch.autograd.Function):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(vol.device))        # (creates the handle; the library re-records it)
         g.deep_event = ev.cuda_event
-        flat_ref = weakref.ref(flat)
         for l in range(_lib.SNET_DEEP_FROM, 7):
             for j in range(4):
                 t_ = grads[4 * l + j]
                 if t_ is not None and t_.numel():
-                    GRAD_READY_EVENTS[t_.data_ptr()] = (ev, flat_ref)
+                    GRAD_READY_EVENTS[t_.data_ptr()] = (ev, flat, ctx.owner)
         nscr = _lib.query("tmf_snet_bwd_scratch_bytes", C.byref(desc))
         scratch = torch.empty(nscr, device=vol.device, dtype=torch.uint8)
         _lib.call("tmf_snet_train_bwd", C.byref(desc), vol.data_ptr(), saved.data_ptr(), saved.numel(), dout.data_ptr(),
