@@ -110,6 +110,14 @@ def make_masks(batch: int, seed: int = 99):
     return rs.rand(batch, 512) >= 0.5, rs.rand(batch, 64) >= 0.5
 
 
+def make_fusion_masks(rows: int, n_inst: int, p: float, dim: int = 128, mlp: int = 512, seed: int = 123):
+    """Keep-masks (booleans) for the three Dropout(p) modules of every Transformer instance of the fusion block
+    (networks.py:153 after to_out, :131 after GELU, :133 after the second Linear), instance order = execution order
+    (mri encoder of layer 0, pet encoder of layer 0, mri encoder of layer 1, ...): [(rows x dim, rows x mlp, rows x dim)]."""
+    rs = np.random.RandomState(seed)
+    return [(rs.rand(rows, dim) >= p, rs.rand(rows, mlp) >= p, rs.rand(rows, dim) >= p) for _ in range(n_inst)]
+
+
 def probe_indices(numel: int, k: int = 16, seed: int = 5):
     """Fixed flat indices at which tensors are sampled into the fixtures."""
     rs = np.random.RandomState(seed + (numel % 9973))

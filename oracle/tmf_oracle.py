@@ -308,7 +308,7 @@ def _snet_forward_bf16(S, pre, dim, x, train, probes, conv_mode):
     return x
 
 
-def attention_forward(S, p: str, x: Tensor, ctx: Tensor, heads: int) -> Tensor:
+def attention_forward(S, p: str, x: Tensor, ctx: Tensor, heads: int, mask_o: Optional[Tensor] = None) -> Tensor:
     """``Attention.forward`` (networks.py:157-175); p ends with 'fn.'.
 
     q from x (already layer-normed by the caller), k/v from the *raw* context.
@@ -327,29 +327,40 @@ def attention_forward(S, p: str, x: Tensor, ctx: Tensor, heads: int) -> Tensor:
     attn = torch.softmax(dots, dim=-1)                                # :171
     out = torch.matmul(attn, v)                                       # :173
     out = out.permute(0, 2, 1, 3).reshape(B, N, inner)
-    return F.linear(out, S[p + "to_out.0.weight"], S[p + "to_out.0.bias"])
+    y = F.linear(out, S[p + "to_out.0.weight"], S[p + "to_out.0.bias"])
+    return y if mask_o is None else y * mask_o.reshape(y.shape).to(y.dtype)      # to_out.1 = Dropout (:153), scaled keep-mask
 
 
-def transformer_forward(S, p: str, x: Tensor, ctx: Tensor, heads: int) -> Tensor:
+def transformer_forward(S, p: str, x: Tensor, ctx: Tensor, heads: int, masks=None) -> Tensor:
     """``Transformer(depth=1).forward`` (networks.py:226-230) with PreNorm
-    (:120-121: only x is normed, the context passes through untouched)."""
+    (:120-121: only x is normed, the context passes through untouched).
+    masks: None (Dropout inactive: p = 0 or eval) or the three SCALED keep-masks of the instance's Dropout modules
+    (after to_out :153, after GELU :131, after the second Linear :133)."""
     a, f = p + "layers.0.0.", p + "layers.0.1."
     D = x.shape[-1]
+    mo, mg, mf = masks if masks is not None else (None, None, None)
     xn = F.layer_norm(x, (D,), S[a + "norm.weight"], S[a + "norm.bias"], LN_EPS)
-    x = attention_forward(S, a + "fn.", xn, ctx, heads) + x
+    x = attention_forward(S, a + "fn.", xn, ctx, heads, mo) + x
     xn = F.layer_norm(x, (D,), S[f + "norm.weight"], S[f + "norm.bias"], LN_EPS)
     h = F.gelu(F.linear(xn, S[f + "fn.net.0.weight"], S[f + "fn.net.0.bias"]))   # erf GELU (:130)
-    x = F.linear(h, S[f + "fn.net.3.weight"], S[f + "fn.net.3.bias"]) + x
+    if mg is not None:
+        h = h * mg.reshape(h.shape).to(h.dtype)
+    y = F.linear(h, S[f + "fn.net.3.weight"], S[f + "fn.net.3.bias"])
+    if mf is not None:
+        y = y * mf.reshape(y.shape).to(y.dtype)
+    x = y + x
     return F.layer_norm(x, (D,), S[p + "norm.weight"], S[p + "norm.bias"], LN_EPS)
 
 
 def fusion_forward(S, p: str, mri: Tensor, pet: Tensor, depth: int, heads: int,
-                   probes: Optional[dict] = None) -> Tensor:
-    """``CrossTransformer_MOD_AVG.forward`` (networks.py:272-281) -> (B, 4*dim)."""
+                   probes: Optional[dict] = None, masks=None) -> Tensor:
+    """``CrossTransformer_MOD_AVG.forward`` (networks.py:272-281) -> (B, 4*dim).
+    masks: per Transformer instance in execution order (2 * depth entries) the three scaled Dropout keep-masks, or None."""
     for l in range(depth):
-        tm = transformer_forward(S, f"{p}layers.{l}.0.", mri, pet, heads)
+        tm = transformer_forward(S, f"{p}layers.{l}.0.", mri, pet, heads, None if masks is None else masks[2 * l])
         mri = tm + mri                                                                # :274
-        tp = transformer_forward(S, f"{p}layers.{l}.1.", pet, mri, heads)             # uses the NEW mri
+        tp = transformer_forward(S, f"{p}layers.{l}.1.", pet, mri, heads,             # uses the NEW mri
+                                 None if masks is None else masks[2 * l + 1])
         pet = tp + pet                                                                # :275
         if probes is not None:          # Transformer-instance outputs (before the outer residual)
             probes[f"{p}layers.{l}.0"] = tm
@@ -394,7 +405,7 @@ def _drop(x: Tensor, mask: Optional[Tensor], train: bool, p: float = 0.5) -> Ten
 
 def model_ad_forward(S, mri: Tensor, pet: Tensor, *, dim=128, depth=3, heads=4, train=True,
                      dropout_masks: Optional[Tuple[Tensor, Tensor]] = None,
-                     probes: Optional[dict] = None, conv_mode: str = "exact"):
+                     probes: Optional[dict] = None, conv_mode: str = "exact", fusion_masks=None):
     """``model_ad.forward`` (mymodel.py:204-222) -> (logits, D_MRI_logits, D_PET_logits)."""
     m = snet_forward(S, "mri_cnn.", dim, mri, train, probes, conv_mode)
     p = snet_forward(S, "pet_cnn.", dim, pet, train, probes, conv_mode)
@@ -405,7 +416,7 @@ def model_ad_forward(S, mri: Tensor, pet: Tensor, *, dim=128, depth=3, heads=4, 
     B, C = m.shape[:2]
     mt = m.reshape(B, C, -1).transpose(1, 2)                            # 'b d x y z -> b (x y z) d' :218
     pt = p.reshape(B, C, -1).transpose(1, 2)
-    cls = fusion_forward(S, "fuse_transformer.", mt, pt, depth, heads, probes)
+    cls = fusion_forward(S, "fuse_transformer.", mt, pt, depth, heads, probes, fusion_masks if train else None)
     if probes is not None:
         probes["cls"] = cls
     return fc_cls_forward(S, cls, train, dropout_masks), d_m, d_p

@@ -54,6 +54,19 @@ class Golden:
     def masks(self):
         return P.make_masks(self.batch, seed=self.meta["mask_seed"])
 
+    def fusion_dropout(self):
+        return float(self.meta.get("fusion_dropout", 0.0))
+
+    def fusion_masks(self):
+        """Scaled keep-masks (float32 arrays) of the fusion block's Dropout modules per Transformer instance, or None."""
+        p = self.fusion_dropout()
+        if p <= 0:
+            return None
+        tokens = (self.size[0] // 16) * (self.size[1] // 16) * (self.size[2] // 16)
+        keep = P.make_fusion_masks(self.batch * tokens, 2 * self.kw["depth"], p, self.kw["dim"], self.kw["mlp_dim"],
+                                   seed=self.meta["fusion_mask_seed"])
+        return [tuple((k.astype(np.float32) / np.float32(1.0 - p)) for k in trip) for trip in keep]
+
 
 def available(name):
     return os.path.exists(os.path.join(GOLDEN_DIR, name + ".npz"))
@@ -83,9 +96,12 @@ def run_oracle(g: Golden, dtype=torch.float32, train=True, backward=True, keep_g
     with ctx:
         if g.model == "model_ad":
             k1, k2 = g.masks()
+            fm = g.fusion_masks()
+            if fm is not None:
+                fm = [tuple(torch.from_numpy(k).to(dtype) for k in trip) for trip in fm]
             lo, dm, dp = O.model_ad_forward(S, mri, pet, dim=g.kw["dim"], depth=g.kw["depth"], heads=g.kw["heads"],
                                             train=train, dropout_masks=(torch.from_numpy(k1), torch.from_numpy(k2)),
-                                            probes=probes)
+                                            probes=probes, fusion_masks=fm)
             outs = dict(logits=lo, d_mri=dm, d_pet=dp)
             loss = O.adversarial_loss(lo, dm, dp, y)
         elif g.model == "model_CNN_ad":

@@ -46,6 +46,9 @@ CASES = {
     "ad_adni_b2": ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (91, 109, 91), 2, True, "blobs"),
     # BASELINE configs[2]: 128^3, batch 8 — fp32 reference run that the bf16 modes are gated against
     "ad_128_b8":  ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (128, 128, 128), 8, False, "blobs"),
+    # Dropout ACTIVE in the fusion block (options/option.py:39 --dropout; networks.py:131,133,153): the reference is built with
+    # dropout=0.3 and every Transformer Dropout module is forced to the regenerable masks of oracle/params.make_fusion_masks
+    "ad_mid_drop": ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (48, 48, 48), 2, True, "blobs", 0.3),
     "cnn_tiny":   ("model_CNN_ad", dict(dim=32), (32, 32, 32), 2, True),
     "cnn_mid":    ("model_CNN_ad", dict(dim=128), (48, 40, 48), 2, True),
     "single_mid": ("model_single", dict(dim=128), (48, 48, 48), 3, True),
@@ -53,10 +56,10 @@ CASES = {
 DEFAULT = [c for c in CASES if c not in ("ad_full_b8", "ad_128_b8")]
 
 
-def build_reference(model, kw):
+def build_reference(model, kw, dropout=0.):
     from models.mymodel import model_ad, model_CNN_ad, model_single
     if model == "model_ad":
-        return model_ad(dropout=0., **kw)
+        return model_ad(dropout=dropout, **kw)
     if model == "model_CNN_ad":
         return model_CNN_ad(**kw)
     return model_single(kw["dim"])
@@ -107,13 +110,14 @@ def attach_probes(net, model, store):
 def run_case(name):
     model, kw, size, B, do64 = CASES[name][:5]
     kind = CASES[name][5] if len(CASES[name]) > 5 else "uniform"
+    drop_p = CASES[name][6] if len(CASES[name]) > 6 else 0.0
     spec = spec_for(model, kw)
     arrays = P.init_arrays(spec, seed=7)
     mri, pet, y = P.make_inputs(B, size, seed=1234, kind=kind)
     k1, k2 = P.make_masks(B)
     out = {}
     meta = dict(case=name, model=model, kwargs=kw, size=list(size), batch=B, param_seed=7, input_seed=1234,
-                mask_seed=99, input_kind=kind, torch=torch.__version__,
+                mask_seed=99, input_kind=kind, torch=torch.__version__, fusion_dropout=drop_p, fusion_mask_seed=123,
                 keys=[[k, list(s)] for k, (_kind, s) in spec.items()])
 
     for prec, dt in (("f32", torch.float32), ("f64", torch.float64)):
@@ -121,7 +125,7 @@ def run_case(name):
             continue
         t0 = time.time()
         torch.manual_seed(0)
-        net = build_reference(model, kw)
+        net = build_reference(model, kw, drop_p)
         sd = net.state_dict()
         assert list(sd.keys()) == list(spec.keys()), "state_dict key order differs from oracle spec"
         for k, v in sd.items():
@@ -136,6 +140,19 @@ def run_case(name):
             m2 = torch.from_numpy(k2).to(dt)
             hooks.append(net.fc_cls[3].register_forward_hook(lambda _m, i, _o: i[0] * m1 * 2.0))
             hooks.append(net.fc_cls[7].register_forward_hook(lambda _m, i, _o: i[0] * m2 * 2.0))
+        if drop_p > 0:
+            tokens = (size[0] // 16) * (size[1] // 16) * (size[2] // 16)
+            fm = P.make_fusion_masks(B * tokens, 2 * kw["depth"], drop_p, kw["dim"], kw["mlp_dim"], seed=123)
+            inst = 0
+            for pair in net.fuse_transformer.layers:
+                for tr in pair:
+                    at, ff = tr.layers[0][0].fn, tr.layers[0][1].fn
+                    for mod, keep in zip((at.to_out[1], ff.net[2], ff.net[4]), fm[inst]):
+                        assert isinstance(mod, torch.nn.Dropout) and mod.p == drop_p
+                        # scaled keep-mask as the fp32 value the device path is handed (also in the fp64 run)
+                        mk = torch.from_numpy(keep.astype(np.float32) / np.float32(1.0 - drop_p)).to(dt)
+                        hooks.append(mod.register_forward_hook(lambda _m, i, _o, mk=mk: i[0] * mk.reshape(i[0].shape)))
+                    inst += 1
         xm, xp = torch.from_numpy(mri).to(dt), torch.from_numpy(pet).to(dt)
         yt = torch.from_numpy(y)
         crit = torch.nn.CrossEntropyLoss()
@@ -167,7 +184,7 @@ def run_case(name):
         del net
 
     # eval mode (val_step): fresh buffers from the fixture, fp32
-    net = build_reference(model, kw)
+    net = build_reference(model, kw, drop_p)
     net.load_state_dict({k: torch.from_numpy(np.asarray(arrays[k])) for k in spec}, strict=True)
     net.eval()
     with torch.no_grad():

@@ -38,7 +38,7 @@ class FixedMaskDropout(nn.Module):
 def build(g: Golden, inject_masks=True):
     import transmf_ad_amd as T
     if g.model == "model_ad":
-        net = T.model_ad(dropout=0., **g.kw)
+        net = T.model_ad(dropout=g.fusion_dropout(), **g.kw)
     elif g.model == "model_CNN_ad":
         net = T.model_CNN_ad(**g.kw)
     else:
@@ -50,7 +50,31 @@ def build(g: Golden, inject_masks=True):
         k1, k2 = g.masks()
         net.fc_cls[3] = FixedMaskDropout(torch.from_numpy(k1).float().to(DEV))
         net.fc_cls[7] = FixedMaskDropout(torch.from_numpy(k2).float().to(DEV))
+    fm = g.fusion_masks() if g.model == "model_ad" else None
+    if fm is not None:              # the fusion block's Dropout modules, forced to the fixture's masks
+        inst = 0
+        for pair in net.fuse_transformer.layers:
+            for tr in pair:
+                at, ff = tr.layers[0][0].fn, tr.layers[0][1].fn
+                mo, mg, mf = (ScaledMask(torch.from_numpy(k).to(DEV)) for k in fm[inst])
+                at.to_out[1], ff.net[2], ff.net[4] = mo, mg, mf
+                tr._drops = None
+                inst += 1
     return net
+
+
+class ScaledMask(nn.Module):
+    """nn.Dropout stand-in with a fixed keep-mask that is already scaled by 1 / (1 - p)."""
+
+    def __init__(self, m):
+        super().__init__()
+        self.m = m
+
+    def forward(self, x):
+        return x * self.m.reshape(x.shape) if self.training else x
+
+    def tmf_keep_mask(self, training):
+        return self.m if training else None
 
 
 def step(net, g: Golden, train=True):
@@ -76,7 +100,7 @@ def step(net, g: Golden, train=True):
 
 
 CASES = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid", "ad_full_b2", "ad_full_b2_blobs",
-         "ad_adni_b2"]
+         "ad_adni_b2", "ad_mid_drop"]
 # Logit tolerance per fixture.  Default: the north-star gate.  The structured-volume fixtures (oracle/params.
 # make_inputs_blobs: per-sample blobs, so the pooled features of the two samples differ by O(0.1) and the train-mode
 # BatchNorm1d heads are well conditioned) are held 5x tighter: they are the full-size B=2 cases the gate really
