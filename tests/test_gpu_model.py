@@ -988,52 +988,57 @@ def test_two_precisions_live_side_by_side():
     assert torch.equal(default[0][0], solo_a[0][0])
 
 
-# Measured on MI355X (round 3, 30 Adam steps at lr 1e-3 from the fixture's parameters, fixed Dropout masks, structured
-# 48^3 volumes, B = 4): max |loss_bf16 - loss_fp32| over the trajectory and the final losses are printed by the test;
-# the bands below are ~3x the measured values.
-BF16_TRAJ_BAND = {"bf16": 0.05, "bf16s": 0.05}
+# Measured on MI355X (round 3; 30 Adam steps at the reference's lr 1e-4 and batch 8 from the fixture-style parameters, fixed
+# Dropout masks, structured 48^3 volumes): max over the trajectory of |loss_mode - loss_fp32| = 0.029 (bf16) / 0.030 (bf16
+# storage) on a loss that moves from 1.32 to 2.79 (the adversarial term grows while the discriminator is being confused);
+# classification CE alone: 0.006 / 0.008 on 0.49 -> 0.013.  Bands = 3x the measured values.  (At batch 4 the batch-4
+# BatchNorm1d heads amplify every perturbation: 0.16 — that is a property of the model, not of the precision.)
+BF16_TRAJ_BAND = {"bf16": (0.09, 0.02), "bf16s": (0.09, 0.025)}
 
 
 @pytest.mark.parametrize("mode", ["bf16", "bf16s"])
 def test_bf16_training_follows_the_fp32_trajectory(mode):
-    """TRAINING in the bf16 modes (kfold_train_adversarial.py:101-136 with Adam, utils/utils.py:38-39): 30 steps of model_ad
-    (dim 128, 48^3 structured volumes, B = 4, fixed Dropout masks) from one start in fp32 and in the bf16 mode — the loss
-    trajectories stay within a stated band of each other, both fall, and the first three fp32 steps follow the fp64 CPU
-    oracle's trajectory (same Adam) to 2e-3.  A bf16 weight-gradient |.|-sum error of tens of percent (see
-    test_config3_128_b8...) is only acceptable next to this evidence."""
+    """TRAINING in the bf16 modes (kfold_train_adversarial.py:101-136 with Adam lr 1e-4, utils/utils.py:38-39; batch 8,
+    README.md:45): 30 steps of model_ad (dim 128, 48^3 structured volumes, fixed Dropout masks) from one start in fp32 and
+    in the bf16 mode — the loss and the classification-CE trajectories stay within a stated band of the fp32 ones, the CE
+    falls by > 10x in both, and the first three fp32 steps follow the fp64 CPU oracle's trajectory (same Adam) to 1e-3.
+    A bf16 weight-gradient |.|-sum error of tens of percent (test_config3_128_b8...) is only acceptable next to this."""
     import transmf_ad_amd as T
     from oracle import params as P
     from oracle import tmf_oracle as O
     kw = dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512)
     spec = O.state_spec("model_ad", **kw)
     arrs = P.init_arrays(spec, seed=11)
-    B = 4
+    B = 8
     mri, pet, y = P.make_inputs(B, (48, 48, 48), seed=77, kind="blobs")
     k1, k2 = P.make_masks(B, seed=5)
-    STEPS, LR = 30, 1e-3
+    STEPS, LR = 30, 1e-4
 
     def run(conv, storage):
         net = T.model_ad(dropout=0., **kw)
         net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in arrs.items()}, strict=True)
         net = net.to(DEV).train()
         net.set_precision(conv, storage)
-        net.fc_cls[3], net.fc_cls[7] = _FixedMask(torch.from_numpy(k1).float() * 2.0), _FixedMask(torch.from_numpy(k2).float() * 2.0)
+        net.fc_cls[3], net.fc_cls[7] = (_FixedMask(torch.from_numpy(k1).float().to(DEV) * 2.0),
+                                        _FixedMask(torch.from_numpy(k2).float().to(DEV) * 2.0))
         opt = T.optim.Adam(net.parameters(), lr=LR)
         m, p_, yy = (torch.from_numpy(a).to(DEV) for a in (mri, pet, y))
         ce = torch.nn.CrossEntropyLoss()
-        losses = []
+        losses, ces = [], []
         for _ in range(STEPS):
             net.train()
             opt.zero_grad()
             lo, dm, dp = net(m, p_)
-            loss = (ce(dm, torch.ones_like(yy)) + ce(dp, torch.zeros_like(yy))) / 2 + ce(lo, yy)
+            c = ce(lo, yy)
+            loss = (ce(dm, torch.ones_like(yy)) + ce(dp, torch.zeros_like(yy))) / 2 + c
             loss.backward()
             opt.step()
             losses.append(loss.item())
-        return np.array(losses)
+            ces.append(c.item())
+        return np.array(losses), np.array(ces)
 
-    l32 = run("fp32", "fp32")
-    l16 = run("bf16", "bf16" if mode == "bf16s" else "fp32")
+    l32, c32 = run("fp32", "fp32")
+    l16, c16 = run("bf16", "bf16" if mode == "bf16s" else "fp32")
     # fp64 oracle, three steps with torch's Adam on the oracle state
     S = O.to_state(arrs, spec, dtype=torch.float64)
     prm = [S[k] for k, (kind, _s) in spec.items() if kind == "param"]
@@ -1048,13 +1053,15 @@ def test_bf16_training_follows_the_fp32_trajectory(mode):
         loss.backward()
         opt.step()
         l64.append(loss.item())
-    dev16 = np.abs(l16 - l32).max()
-    print(f"[{mode}] loss fp32 {l32[0]:.4f} -> {l32[-1]:.4f}; {mode} {l16[0]:.4f} -> {l16[-1]:.4f}; max |d| {dev16:.4f}; "
+    dl, dc = np.abs(l16 - l32).max(), np.abs(c16 - c32).max()
+    print(f"[{mode}] loss fp32 {l32[0]:.4f} -> {l32[-1]:.4f}, {mode} {l16[0]:.4f} -> {l16[-1]:.4f}, max |d loss| {dl:.4f}; "
+          f"CE fp32 {c32[0]:.4f} -> {c32[-1]:.4f}, {mode} -> {c16[-1]:.4f}, max |d CE| {dc:.4f}; "
           f"fp32 vs fp64 oracle first 3 steps {np.abs(l32[:3] - np.array(l64)).max():.2e}")
     assert np.isfinite(l16).all() and np.isfinite(l32).all()
-    assert np.abs(l32[:3] - np.array(l64)).max() < 2e-3
-    assert l32[-1] < 0.7 * l32[0] and l16[-1] < 0.7 * l16[0]              # both train
-    assert dev16 < BF16_TRAJ_BAND[mode], (dev16, l32, l16)
+    assert np.abs(l32[:3] - np.array(l64)).max() < 1e-3
+    assert c32[-1] < 0.1 * c32[0] and c16[-1] < 0.1 * c16[0]              # both learn the classification
+    band_l, band_c = BF16_TRAJ_BAND[mode]
+    assert dl < band_l and dc < band_c, (dl, dc)
 
 
 class _FixedMask(torch.nn.Module):
