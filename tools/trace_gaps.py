@@ -51,6 +51,21 @@ for s, e, _n, _st in rows[1:]:
     else:
         cur_e = max(cur_e, e)
 busy += cur_e - cur_s
+# the largest idle gaps of ONE step (the last one in the window), with the kernels on either side
+if a.last_ms <= 0:
+    s0 = ends[-2]
+    last = [r for r in rows if r[0] >= s0]
+    gaps = []
+    ce, prev = last[0][1], last[0][2]
+    for s_, e_, n_, _st in last[1:]:
+        if s_ > ce:
+            gaps.append((s_ - ce, (ce - s0) / 1e6, prev, n_))
+        if e_ >= ce:
+            ce, prev = e_, n_
+    short = lambda n: re.sub(r"\(.*", "", re.sub(r"\(anonymous namespace\)::|void |at::native::", "", n))[:48]
+    print(f"last step: idle {sum(g[0] for g in gaps) / 1e6:.3f} ms in {len(gaps)} gaps; the 14 largest (us, at ms into the step, after -> before):")
+    for g in sorted(gaps, reverse=True)[:14]:
+        print(f"   {g[0] / 1e3:7.1f} us  @{g[1]:6.2f}  {short(g[2])}  ->  {short(g[3])}")
 print(f"window {wall:.2f} ms: {len(rows)} launches, GPU busy (union) {busy / 1e6:.2f} ms = {busy / 1e6 / wall:.1%}, "
       f"idle {wall - busy / 1e6:.2f} ms in {len(idle_gaps)} gaps "
       f"({sum(1 for g in idle_gaps if g > 2000)} > 2 us: {sum(g for g in idle_gaps if g > 2000) / 1e6:.2f} ms, "

@@ -330,13 +330,23 @@ __global__ __launch_bounds__(256, 2) void tok_wgrad_multi_kernel(const WgMulti p
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int steps = rows >> 3;                             // row pairs per wave
-#pragma unroll 4
-    for (int s = 0; s < steps; ++s) {
-        const int row = rb + 2 * s + hsel;
-        const bool ok = row < R;
-        const float a = ok ? dy[(size_t)row * N] : 0.f;
-        const float b = ok ? xx[(size_t)row * K] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    // Operands straight from L2, one dword per lane and MFMA: the loop is a chain of load latencies, not of matrix work
+    // (a workgroup took ~12 us for 1.7 us of MFMA with 4 steps in flight).  16 steps are requested at once — rows past
+    // the range are clamped to a valid row and multiplied by zero, so the batch has no branches around its loads.
+    constexpr int UB = 16;
+    for (int s0 = 0; s0 < steps; s0 += UB) {
+        float a[UB], b[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const int row = rb + 2 * (s0 + u) + hsel;
+            const bool ok = (s0 + u) < steps && row < R;
+            const int rr = ok ? row : 0;
+            a[u] = dy[(size_t)rr * N];
+            b[u] = xx[(size_t)rr * K];
+            a[u] = ok ? a[u] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], acc, 0, 0, 0);
     }
     // D[i = n][j = k]: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 hsel
     if (wave > 0) {

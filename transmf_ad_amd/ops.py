@@ -926,16 +926,18 @@ class FusionTrain(torch.autograd.Function):
         ctx.save_for_backward(mri, pet, saved, *params)     # parameters too: autograd then rejects an in-place update
         ctx.desc, ctx.inst = desc, inst                     # between forward and backward; their pointers stay valid:
         ctx.masks = masks                                   # the ctypes structs are reused as they are
+        # Everything backward needs besides the incoming gradient is set up NOW, while the GPU is busy with the forward:
+        # backward starts right behind the reference step's two loss.item() host syncs (kfold_train_adversarial.py:127-128),
+        # where every microsecond of host preparation is a microsecond of idle GPU (measured: 140 us of gap in front of the
+        # first fusion-backward kernel).
+        ctx.bwd = FusionTrain._prepare_backward(desc, mri, pet) if any(ctx.needs_input_grad) else None
         return cls
 
     @staticmethod
-    def backward(ctx, dcls):
+    def _prepare_backward(desc, mri, pet):
         import ctypes as C
-        mri, pet, saved = ctx.saved_tensors[:3]
-        desc, inst = ctx.desc, ctx.inst
         depth, dim, mlp = desc.depth, desc.dim, desc.mlp
         inner = desc.heads * desc.dim_head
-        dcls = _chk(dcls, "grad_output")
         n_inst = 2 * depth
         grads = (_lib.XformerGrads * n_inst)()
         # ONE flat gradient buffer for the whole fusion, cut by ONE split call; per instance
@@ -964,9 +966,20 @@ class FusionTrain(torch.autograd.Function):
         dp = torch.empty_like(pet)
         nscr = _lib.query("tmf_fusion_bwd_scratch_bytes", C.byref(desc))
         scratch = torch.empty(nscr, device=mri.device, dtype=torch.uint8)
+        out[0], out[1] = dm, dp
+        return grads, flat, out, dm, dp, scratch, nscr
+
+    @staticmethod
+    def backward(ctx, dcls):
+        import ctypes as C
+        mri, pet, saved = ctx.saved_tensors[:3]
+        desc, inst = ctx.desc, ctx.inst
+        dcls = _chk(dcls, "grad_output")
+        prep = ctx.bwd if ctx.bwd is not None else FusionTrain._prepare_backward(desc, mri, pet)
+        ctx.bwd = None
+        grads, _flat, out, dm, dp, scratch, nscr = prep
         _lib.call("tmf_fusion_train_bwd", C.byref(desc), mri.data_ptr(), pet.data_ptr(), inst, saved.data_ptr(),
                   saved.numel(), dcls.data_ptr(), grads, dm.data_ptr(), dp.data_ptr(), scratch.data_ptr(), nscr, _stream())
-        out[0], out[1] = dm, dp
         return tuple(out)
 
 
@@ -1014,23 +1027,14 @@ class HeadsAD(torch.autograd.Function):
         ctx.masks = (m1, m2)
         ctx.desc, ctx.prm, ctx.alpha = desc, prm, float(alpha)
         ctx.tok_shape = tuple(mri.shape)
+        # backward's buffers and gradient table, set up while the GPU is still busy with the forward (see FusionTrain)
+        ctx.bwd = HeadsAD._prepare_backward(desc, cls, params, ctx.tok_shape) if any(ctx.needs_input_grad) else None
         return outs[0], outs[1], outs[2]
 
     @staticmethod
-    def backward(ctx, dlo, ddm, ddp):
+    def _prepare_backward(desc, cls, params, tok_shape):
         import ctypes as C
-        cls, saved = ctx.saved_tensors[:2]
-        params = ctx.saved_tensors[2:]
-        desc = ctx.desc
-        B, NC = desc.B, desc.NC
         dev = cls.device
-        dl = torch.zeros((3, B, NC), device=dev, dtype=_f32) if (dlo is None or ddm is None or ddp is None) else None
-        if dl is None:
-            dl = torch.stack([dlo, ddm, ddp]).to(_f32).contiguous()
-        else:
-            for i, g in enumerate((dlo, ddm, ddp)):
-                if g is not None:
-                    dl[i].copy_(g)
         sizes = [p.numel() for p in params]
         flat = torch.empty(sum(sizes), device=dev, dtype=_f32)
         parts = flat.split(sizes)
@@ -1040,14 +1044,29 @@ class HeadsAD(torch.autograd.Function):
             setattr(g, name, o)
             o += 4 * n
         d_cls = torch.empty_like(cls)
-        d_tok = torch.empty((2,) + ctx.tok_shape, device=dev, dtype=_f32)
-        m1, m2 = ctx.masks
+        d_tok = torch.empty((2,) + tok_shape, device=dev, dtype=_f32)
         nscr = _lib.query("tmf_heads_bwd_scratch_bytes", C.byref(desc))
         scratch = torch.empty(nscr // 4, device=dev, dtype=_f32)
+        zero = torch.zeros((desc.B, desc.NC), device=dev, dtype=_f32)      # stands in for an output nobody differentiated
+        grads = [t if p.dim() == 1 else t.view(p.shape) for t, p in zip(parts, params)]
+        return g, flat, grads, d_cls, d_tok, scratch, nscr, zero
+
+    @staticmethod
+    def backward(ctx, dlo, ddm, ddp):
+        import ctypes as C
+        cls, saved = ctx.saved_tensors[:2]
+        params = ctx.saved_tensors[2:]
+        desc = ctx.desc
+        prep = ctx.bwd if ctx.bwd is not None else HeadsAD._prepare_backward(desc, cls, params, ctx.tok_shape)
+        ctx.bwd = None
+        g, _flat, grads, d_cls, d_tok, scratch, nscr, zero = prep
+        # the three output gradients go to the library as they are (no stack / copy launch in front of the kernel)
+        dl = [zero if t is None else (t if (t.dtype == _f32 and t.is_contiguous()) else t.to(_f32).contiguous())
+              for t in (dlo, ddm, ddp)]
+        m1, m2 = ctx.masks
         _lib.call("tmf_heads_bwd", C.byref(desc), cls.data_ptr(), _ptr(m1), _ptr(m2), C.byref(ctx.prm), saved.data_ptr(),
                   saved.numel() * 4, dl[0].data_ptr(), dl[1].data_ptr(), dl[2].data_ptr(), C.byref(g), d_cls.data_ptr(),
                   d_tok[0].data_ptr(), d_tok[1].data_ptr(), ctx.alpha, scratch.data_ptr(), nscr, _stream())
-        grads = [t if p.dim() == 1 else t.view(p.shape) for t, p in zip(parts, params)]
         return (d_cls, d_tok[0], d_tok[1], None, None, None, None, *grads)
 
 
