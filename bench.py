@@ -81,16 +81,17 @@ def conv_bytes_per_pair(size, elem, dim=128):
 
 def _pmc_traffic(kernel, precision, storage, B, vol):
     """HBM bytes per launch of a kernel instance from the committed rocprofv3 --pmc passes (counters cannot be read
-    live): profiles/r02_pmc_traffic.json = {"precision|storage|B|DxHxW": {kernel instance: {"hbm_bytes_per_launch": ...}}};
+    live): profiles/r03_pmc_traffic.json = {"precision|storage|B|DxHxW": {kernel instance: {"hbm_bytes_per_launch": ...}}};
     None for configurations that were not profiled."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            tab = json.load(f).get(f"{precision}|{storage}|{B}|{'x'.join(map(str, vol))}", {})
-        for key, row in tab.items():
-            if key in kernel:
-                return row
-    except Exception:
-        pass
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):          # newest committed pass first
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                tab = json.load(f).get(f"{precision}|{storage}|{B}|{'x'.join(map(str, vol))}", {})
+            for key, row in tab.items():
+                if key in kernel:
+                    return dict(row, source=f"profiles/{name}")
+        except Exception:
+            pass
     return None
 
 
@@ -224,7 +225,7 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
         "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
         "frac": round((tf / peak_tf) if bound == "mfma" else (gbs / PEAK_HBM_GBS), 4),
         "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
-        "traffic_note": None if traffic is None else traffic.get("note"),
+        "traffic_note": None if traffic is None else f"{traffic.get('note')} [{traffic.get('source')}]",
         "launch_ms": round(dom["ms"] / dom["launches"], 4),
         "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
         "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],

@@ -52,6 +52,9 @@ CASES = {
     "cnn_tiny":   ("model_CNN_ad", dict(dim=32), (32, 32, 32), 2, True),
     "cnn_mid":    ("model_CNN_ad", dict(dim=128), (48, 40, 48), 2, True),
     "single_mid": ("model_single", dict(dim=128), (48, 48, 48), 3, True),
+    # BASELINE configs[4] at the full volume size (structured volumes, batch 2): the conv-only models against the reference
+    "cnn_full_b2":    ("model_CNN_ad", dict(dim=128), (96, 96, 96), 2, True, "blobs"),
+    "single_full_b2": ("model_single", dict(dim=128), (96, 96, 96), 2, True, "blobs"),
 }
 DEFAULT = [c for c in CASES if c not in ("ad_full_b8", "ad_128_b8")]
 

@@ -575,7 +575,30 @@ class SNetTrain(torch.autograd.Function):
         ctx.save_for_backward(vol, saved)
         ctx.desc = desc
         ctx.shapes = [None if p is None else p.shape for p in params]
+        # the gradient buffer, its views and the gradient table of backward, set up while the GPU is busy (see FusionTrain)
+        ctx.bwd = SNetTrain._prepare_backward(ctx.shapes, ctx.needs_input_grad, vol.device) if any(ctx.needs_input_grad[3:]) else None
         return out
+
+    @staticmethod
+    def _prepare_backward(shapes, need, dev):
+        sizes = [0 if s is None else s.numel() for s in shapes]
+        flat = torch.empty(sum(sizes), device=dev, dtype=_f32)        # all 28 gradients in one allocation
+        # the seven conv-bias gradients (exact zeros) sit back to back at the end: the library fills them with one memset
+        order = [i for i in range(len(sizes)) if i % 4 != 1] + [i for i in range(len(sizes)) if i % 4 == 1]
+        parts = dict(zip(order, flat.split([sizes[i] for i in order])))
+        grads = [None if s is None else (parts[i] if len(s) == 1 else parts[i].view(s)) for i, s in enumerate(shapes)]
+        ptr = [parts[i].data_ptr() for i in range(len(sizes))]
+        g = _lib.SnetGrads()
+        for l in range(7):
+            g.dweight[l] = ptr[4 * l] if need[3 + 4 * l] else None
+            g.dbias[l] = None if shapes[4 * l + 1] is None else ptr[4 * l + 1]
+            g.dgamma[l], g.dbeta[l] = ptr[4 * l + 2], ptr[4 * l + 3]
+        # an event behind the last kernel of the deep blocks (conv3.0 .. conv4.3): a data-parallel wrapper starts the
+        # all-reduce of their gradients there, under the backward of conv2 / conv1, instead of after this call
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))               # (creates the handle; the library re-records it in backward)
+        g.deep_event = ev.cuda_event
+        return flat, grads, g, ev
 
     @staticmethod
     def backward(ctx, dout):
@@ -585,24 +608,9 @@ class SNetTrain(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             raise _lib.TmfError("the one-call sNet has no data gradient (the network input needs none)")
         dout = _chk(dout, "grad_output")
-        sizes = [0 if s is None else s.numel() for s in ctx.shapes]
-        flat = torch.empty(sum(sizes), device=vol.device, dtype=_f32)        # all 28 gradients in one allocation
-        # the seven conv-bias gradients (exact zeros) sit back to back at the end: the library fills them with one memset
-        order = [i for i in range(len(sizes)) if i % 4 != 1] + [i for i in range(len(sizes)) if i % 4 == 1]
-        parts = dict(zip(order, flat.split([sizes[i] for i in order])))
-        grads = [None if s is None else (parts[i] if len(s) == 1 else parts[i].view(s)) for i, s in enumerate(ctx.shapes)]
-        ptr = [parts[i].data_ptr() for i in range(len(sizes))]
-        g = _lib.SnetGrads()
-        need = ctx.needs_input_grad
-        for l in range(7):
-            g.dweight[l] = ptr[4 * l] if need[3 + 4 * l] else None
-            g.dbias[l] = None if ctx.shapes[4 * l + 1] is None else ptr[4 * l + 1]
-            g.dgamma[l], g.dbeta[l] = ptr[4 * l + 2], ptr[4 * l + 3]
-        # an event behind the last kernel of the deep blocks (conv3.0 .. conv4.3): a data-parallel wrapper starts the
-        # all-reduce of their gradients there, under the backward of conv2 / conv1, instead of after this call
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(vol.device))        # (creates the handle; the library re-records it)
-        g.deep_event = ev.cuda_event
+        prep = ctx.bwd if ctx.bwd is not None else SNetTrain._prepare_backward(ctx.shapes, ctx.needs_input_grad, vol.device)
+        ctx.bwd = None
+        flat, grads, g, ev = prep
         for l in range(_lib.SNET_DEEP_FROM, 7):
             for j in range(4):
                 t_ = grads[4 * l + j]
