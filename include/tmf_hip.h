@@ -475,6 +475,30 @@ int    tmf_heads_bwd(const tmf_heads_desc* d, const float* cls, const float* mas
                      float* d_cls, float* d_mri_tok, float* d_pet_tok, float revgrad_alpha,
                      void* scratch, size_t scratch_bytes, void* stream);
 
+/* The heads of the CNN-only models, one launch per direction (csrc/heads.hip).
+ * reference: models/mymodel.py:143-178 model_CNN_ad — `fc_cls` = Linear(2 dim, H)-ReLU-Linear(H, NC) on
+ * cat[gap(mri), gap(pet)] and `D` (as in model_ad) on revgrad(gap(mri), 2), revgrad(gap(pet), 2): M = 2, HD = 128;
+ * models/mymodel.py:13-41 model_single — `fc` = Linear(dim, H)-ReLU-Linear(H, NC) on avgpool(cnn(img)): M = 1, HD = 0
+ * (pet_tok, the D parameters / outputs / gradients are then NULL).  Tokens [B][N][dim] = the encoder output, channels last;
+ * gap == mean over N.  B <= 16, dim % 16 == 0, M dim <= 512.  momentum / eps are D's BatchNorm1d's. */
+typedef struct tmf_heads_cnn_desc { int B, N, dim, M, H, HD, NC, training; float momentum, eps; } tmf_heads_cnn_desc;
+typedef struct tmf_heads_cnn_params {
+    const float *fc0_w, *fc0_b, *fc2_w, *fc2_b;              /* [H][M dim], [H], [NC][H], [NC] */
+    const float *d0_w, *d0_b, *dbn_g, *dbn_b;                /* [HD][dim], [HD], [HD], [HD] */
+    float *dbn_rm, *dbn_rv;                                  /* running statistics: updated twice per training call, or NULL */
+    const float *d3_w, *d3_b;                                /* [NC][HD], [NC] */
+} tmf_heads_cnn_params;
+typedef struct tmf_heads_cnn_grads { float *fc0_w, *fc0_b, *fc2_w, *fc2_b, *d0_w, *d0_b, *dbn_g, *dbn_b, *d3_w, *d3_b; } tmf_heads_cnn_grads;
+size_t tmf_heads_cnn_saved_bytes(const tmf_heads_cnn_desc* d);
+size_t tmf_heads_cnn_bwd_scratch_bytes(const tmf_heads_cnn_desc* d);
+int    tmf_heads_cnn_fwd(const tmf_heads_cnn_desc* d, const float* mri_tok, const float* pet_tok,
+                         const tmf_heads_cnn_params* params, float* logits, float* d_mri_logits, float* d_pet_logits,
+                         void* saved, size_t saved_bytes, void* stream);
+int    tmf_heads_cnn_bwd(const tmf_heads_cnn_desc* d, const tmf_heads_cnn_params* params, const void* saved, size_t saved_bytes,
+                         const float* d_logits, const float* d_d_mri_logits, const float* d_d_pet_logits,
+                         const tmf_heads_cnn_grads* grads, float* d_mri_tok, float* d_pet_tok, float revgrad_alpha,
+                         void* scratch, size_t scratch_bytes, void* stream);
+
 /* ---- optimizer step: torch.optim.Adam over ALL parameter tensors in one launch --------------------------------------
  * reference: kfold_train_adversarial.py:135 (optimizer.step()), utils/utils.py:38-39 (Adam, lr 1e-4, weight decay 0).
  * params[i] / grads[i]: device pointers of tensor i (numel[i] contiguous floats); grads[i] == NULL skips the tensor, as

@@ -881,6 +881,94 @@ def test_one_launch_heads_match_stock_modules(name, train):
             assert (b.double() - rb[k].double()).abs().max().item() <= 1e-6 * max(1.0, rb[k].double().abs().max().item()), k
 
 
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("kind,dim,B,N", [("cnn_ad", 128, 16, 216), ("cnn_ad", 32, 3, 8), ("single", 128, 16, 216),
+                                          ("single", 128, 1, 27)])
+def test_one_launch_cnn_heads_match_stock_modules(kind, dim, B, N, train):
+    """ops.HeadsCNN (csrc/heads.hip: the heads of model_CNN_ad / model_single as one kernel per direction) against the
+    stock torch modules it stands in for, on the same token tensors: outputs, token gradients, every head parameter's
+    gradient, and D's BatchNorm1d buffers (updated twice, MRI call first)."""
+    import copy
+    import transmf_ad_amd as T
+    from transmf_ad_amd import mymodel, revgrad
+    torch.manual_seed(11)
+    net = (T.model_CNN_ad(dim) if kind == "cnn_ad" else T.model_single(dim)).to(DEV)
+    fc = net.fc_cls if kind == "cnn_ad" else net.fc
+    D = net.D if kind == "cnn_ad" else None
+    if D is not None:
+        with torch.no_grad():                                  # non-trivial affine / running statistics
+            D[1].weight.uniform_(0.5, 1.5); D[1].bias.uniform_(-0.5, 0.5)
+            D[1].running_mean.uniform_(-0.2, 0.2); D[1].running_var.uniform_(0.5, 2.0)
+    net.train(train)
+    ref = copy.deepcopy(net).train(train)
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    m0 = torch.randn((B, N, dim), device=DEV, generator=gen)
+    p0 = torch.randn((B, N, dim), device=DEV, generator=gen) if kind == "cnn_ad" else None
+    go = [torch.randn((B, 2), device=DEV, generator=gen) for _ in range(3)]
+
+    def run(model, fused):
+        mfc = model.fc_cls if kind == "cnn_ad" else model.fc
+        mD = model.D if kind == "cnn_ad" else None
+        m = m0.clone().requires_grad_(True)
+        p = p0.clone().requires_grad_(True) if p0 is not None else None
+        if fused:
+            assert mymodel._cnn_heads_one_call_ok(model, mfc, mD, m, 2 if p is not None else 1)
+            out = mymodel._cnn_heads(model, mfc, mD, m, p)
+            outs = list(out) if isinstance(out, tuple) else [out]
+        elif p is not None:
+            dm = mD(revgrad(m.mean(dim=1), 2.0))
+            dp = mD(revgrad(p.mean(dim=1), 2.0))
+            outs = [mfc(torch.cat([m.mean(dim=1), p.mean(dim=1)], dim=1)), dm, dp]
+        else:
+            outs = [mfc(m.mean(dim=1))]
+        torch.autograd.backward(outs, go[:len(outs)])
+        torch.cuda.synchronize()
+        return outs, [m.grad] + ([p.grad] if p is not None else [])
+
+    o1, g1 = run(net, True)
+    o2, g2 = run(ref, False)
+    assert type(o1[0].grad_fn).__name__.startswith("HeadsCNN")
+    for a, b in zip(o1 + g1, o2 + g2):
+        assert a.shape == b.shape and (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+    rp = dict(ref.named_parameters())
+    heads = [(k, p) for k, p in net.named_parameters() if k.startswith(("fc_cls.", "fc.", "D."))]
+    assert len(heads) == (10 if kind == "cnn_ad" else 4)
+    for k, p in heads:
+        r = rp[k].grad
+        scale = max(r.abs().max().item(), rp[k[:-4] + "weight"].grad.abs().max().item() if k.endswith(".bias") else 0.0, 1e-3)
+        assert (p.grad - r).abs().max().item() <= 2e-5 * scale, k
+    rb = dict(ref.named_buffers())
+    for k, b in net.named_buffers():
+        if k.startswith("D."):
+            assert (b.double() - rb[k].double()).abs().max().item() <= 1e-6 * max(1.0, rb[k].double().abs().max().item()), k
+    if D is not None and train:
+        assert int(D[1].num_batches_tracked) == 2
+
+
+def test_cnn_models_take_the_one_launch_heads_and_fall_back_for_foreign_heads():
+    """model_CNN_ad / model_single as the reference constructs them go through ops.HeadsCNN; a head somebody replaced
+    (another width pattern, a hook) takes the module path instead of raising."""
+    import transmf_ad_amd as T
+    torch.manual_seed(2)
+    x = torch.rand((2, 1, 32, 32, 32), device=DEV)
+    net = T.model_CNN_ad(64).to(DEV).train()
+    lo, dm, dp = net(x, x.flip(2))
+    assert type(lo.grad_fn).__name__.startswith("HeadsCNN") and dm.grad_fn is lo.grad_fn
+    (lo.sum() + dm.sum() - dp.sum()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    net.fc_cls[1] = torch.nn.GELU()
+    lo2, _dm, _dp = net(x, x.flip(2))
+    assert not type(lo2.grad_fn).__name__.startswith("HeadsCNN")
+    one = T.model_single(128).to(DEV).train()
+    lo = one(x)
+    assert type(lo.grad_fn).__name__.startswith("HeadsCNN")
+    lo.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in one.parameters())
+    h = one.fc[0].register_forward_hook(lambda *_a: None)
+    assert not type(one(x).grad_fn).__name__.startswith("HeadsCNN")
+    h.remove()
+
+
 def test_one_launch_heads_are_taken_by_default_and_with_real_dropout():
     """model_ad as the reference constructs it (nn.Dropout(0.5) in fc_cls) goes through ops.HeadsAD; with real dropout
     the result is random but finite, and eval mode is deterministic."""

@@ -9,7 +9,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from transmf_ad_amd import _lib, ops          # noqa: E402
-from tools.kbench import LAYERS               # noqa: E402
+from tools.conv_ab import LAYERS              # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("what")
@@ -23,7 +23,7 @@ ap.add_argument("--v2", type=int, default=1, help="tmf_set_option('bf16_v2', v):
 a = ap.parse_args()
 _lib.call("tmf_set_option", b"conv_waves", a.waves)
 _lib.call("tmf_set_option", b"bf16_v2", a.v2)
-name, cin, cout, k, div, pool = [l for l in LAYERS if l[0] == a.layer][0]
+name, cin, cout, k, div = [l for l in LAYERS if l[0] == a.layer][0]
 s = a.S // div
 dev = "cuda:0"
 x = torch.randn((a.B, s, s, s, cin), device=dev)

@@ -179,6 +179,30 @@ PROTOTYPES.update({
 })
 ADAM_MAX_TENSORS = 160
 
+
+class HeadsCnnDesc(C.Structure):
+    _fields_ = [(n, _i) for n in ("B", "N", "dim", "M", "H", "HD", "NC", "training")] + [("momentum", _f), ("eps", _f)]
+
+
+HEADS_CNN_PARAMS = ("fc0_w", "fc0_b", "fc2_w", "fc2_b", "d0_w", "d0_b", "dbn_g", "dbn_b", "d3_w", "d3_b")
+
+
+class HeadsCnnParams(C.Structure):          # field order of tmf_heads_cnn_params (the two running buffers sit ahead of d3_*)
+    _fields_ = [(n, _p) for n in HEADS_CNN_PARAMS[:8] + ("dbn_rm", "dbn_rv") + HEADS_CNN_PARAMS[8:]]
+
+
+class HeadsCnnGrads(C.Structure):
+    _fields_ = [(n, _p) for n in HEADS_CNN_PARAMS]
+
+
+PROTOTYPES.update({
+    "tmf_heads_cnn_saved_bytes": (_z, [C.POINTER(HeadsCnnDesc)]),
+    "tmf_heads_cnn_bwd_scratch_bytes": (_z, [C.POINTER(HeadsCnnDesc)]),
+    "tmf_heads_cnn_fwd": (_i, [C.POINTER(HeadsCnnDesc), _p, _p, C.POINTER(HeadsCnnParams), _p, _p, _p, _p, _z, _p]),
+    "tmf_heads_cnn_bwd": (_i, [C.POINTER(HeadsCnnDesc), C.POINTER(HeadsCnnParams), _p, _z, _p, _p, _p,
+                               C.POINTER(HeadsCnnGrads), _p, _p, _f, _p, _z, _p]),
+})
+
 _lib = None
 
 

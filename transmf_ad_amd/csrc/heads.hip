@@ -20,6 +20,7 @@ namespace {
 
 constexpr int HT = 512;          // threads
 constexpr int MAXB = 16;
+constexpr int ND = 4;            // workgroups of the discriminator's backward (j-ranges of D.0)
 
 struct HeadsArgs {
     // inputs
@@ -170,6 +171,89 @@ __global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
     }
 }
 
+// The discriminator D = Linear(dim, HD)-BatchNorm1d-ReLU-Linear(HD, NC) applied to BOTH token means l_v [2][B][dim] by one
+// workgroup (mymodel.py:150-153 / :209-215: two calls, each with its own batch statistics, the running statistics updated
+// MRI call first, then PET).  l_r [2][B][HD], l_st [2][HD][2], l_w3 [NC][HD] are LDS scratch; o_isD / o_xhD = offsets of
+// the saved inverse standard deviations / normalised pre-activations in a.saved.
+__device__ __forceinline__ void disc_fwd(const HeadsArgs& a, int o_isD, int o_xhD, const float* l_v, float* l_r, float* l_st,
+                                         float* l_w3) {
+    const int t = threadIdx.x, B = a.B;
+    // ---- D.0 / .1 / .2 on both token means: 2 threads per (call, output feature) split K ----
+    for (int e0 = 0; e0 < 2 * a.HD; e0 += HT / 2) {
+        const int e = e0 + (t >> 1), part = t & 1;
+        const bool live = e < 2 * a.HD;
+        const int j = live ? e % a.HD : 0, m = live ? e / a.HD : 0;
+        float acc[MAXB], y[MAXB];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+        if (live) {
+            const float* wr = a.dw0 + (size_t)j * a.dim;
+            const int kper = a.dim / 2;                       // dim % 8 == 0: whole float4s
+#pragma unroll 8
+            for (int k = part * kper; k < (part + 1) * kper; k += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b)
+                    if (b < B) {
+                        const float* x = l_v + (m * B + b) * a.dim + k;
+                        acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
+                        acc[b] = fmaf(w[2], x[2], acc[b]); acc[b] = fmaf(w[3], x[3], acc[b]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) acc[b] += __shfl_xor(acc[b], 1);
+        if (!live || part != 0) continue;
+        {
+            const float bias = a.db0[j];
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) acc[b] += bias;
+        }
+        // batch statistics of THIS call; the running buffers are updated below, MRI call first, then PET
+        float mean = 0.f, q = 0.f;
+        if (a.training) {
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) if (b < B) mean += acc[b];
+            mean /= B;
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b) if (b < B) { const float d = acc[b] - mean; q += d * d; }
+            l_st[(m * a.HD + j) * 2] = mean;
+            l_st[(m * a.HD + j) * 2 + 1] = B > 1 ? q / (B - 1) : q / B;
+        }
+        float is;
+        bn1d(acc, y, B, a.training != 0, a.dg1[j], a.dbe1[j], a.drm1 ? a.drm1 + j : nullptr, a.drv1 ? a.drv1 + j : nullptr,
+             a.dmom, a.deps, is, false);
+        a.saved[o_isD + m * a.HD + j] = is;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b)
+            if (b < B) {
+                a.saved[o_xhD + (m * B + b) * a.HD + j] = acc[b];
+                l_r[(m * B + b) * a.HD + j] = y[b] > 0.f ? y[b] : 0.f;
+            }
+    }
+    __syncthreads();
+    if (a.training && a.drm1 != nullptr)
+        for (int j = t; j < a.HD; j += HT) {
+            float rm = a.drm1[j], rv = a.drv1[j];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                rm = (1.f - a.dmom) * rm + a.dmom * l_st[(m * a.HD + j) * 2];
+                rv = (1.f - a.dmom) * rv + a.dmom * l_st[(m * a.HD + j) * 2 + 1];
+            }
+            a.drm1[j] = rm;
+            a.drv1[j] = rv;
+        }
+    // ---- D.3 (its small weight matrix staged in LDS) ----
+    for (int e = t; e < a.NC * a.HD; e += HT) l_w3[e] = a.dw3[e];
+    __syncthreads();
+    for (int e = t; e < 2 * B * a.NC; e += HT) {
+        const int c = e % a.NC, b = (e / a.NC) % B, m = e / (a.NC * B);
+        float s = a.db3[c];
+        for (int k = 0; k < a.HD; ++k) s = fmaf(l_w3[c * a.HD + k], l_r[(m * B + b) * a.HD + k], s);
+        a.dlog[m][b * a.NC + c] = s;
+    }
+}
+
 __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
     extern __shared__ float lds[];
     const int t = threadIdx.x;
@@ -248,81 +332,7 @@ __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
         }
         return;
     }
-    // ---- D.0 / .1 / .2 on both token means: 2 threads per (call, output feature) split K ----
-    for (int e0 = 0; e0 < 2 * a.HD; e0 += HT / 2) {
-        const int e = e0 + (t >> 1), part = t & 1;
-        const bool live = e < 2 * a.HD;
-        const int j = live ? e % a.HD : 0, m = live ? e / a.HD : 0;
-        float acc[MAXB], y[MAXB];
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
-        if (live) {
-            const float* wr = a.dw0 + (size_t)j * a.dim;
-            const int kper = a.dim / 2;                       // dim % 8 == 0: whole float4s
-#pragma unroll 8
-            for (int k = part * kper; k < (part + 1) * kper; k += 4) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
-#pragma unroll
-                for (int b = 0; b < MAXB; ++b)
-                    if (b < B) {
-                        const float* x = l_v + (m * B + b) * a.dim + k;
-                        acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
-                        acc[b] = fmaf(w[2], x[2], acc[b]); acc[b] = fmaf(w[3], x[3], acc[b]);
-                    }
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) acc[b] += __shfl_xor(acc[b], 1);
-        if (!live || part != 0) continue;
-        {
-            const float bias = a.db0[j];
-#pragma unroll
-            for (int b = 0; b < MAXB; ++b) acc[b] += bias;
-        }
-        // batch statistics of THIS call; the running buffers are updated below, MRI call first, then PET
-        float mean = 0.f, q = 0.f;
-        if (a.training) {
-#pragma unroll
-            for (int b = 0; b < MAXB; ++b) if (b < B) mean += acc[b];
-            mean /= B;
-#pragma unroll
-            for (int b = 0; b < MAXB; ++b) if (b < B) { const float d = acc[b] - mean; q += d * d; }
-            l_st[(m * a.HD + j) * 2] = mean;
-            l_st[(m * a.HD + j) * 2 + 1] = B > 1 ? q / (B - 1) : q / B;
-        }
-        float is;
-        bn1d(acc, y, B, a.training != 0, a.dg1[j], a.dbe1[j], a.drm1 ? a.drm1 + j : nullptr, a.drv1 ? a.drv1 + j : nullptr,
-             a.dmom, a.deps, is, false);
-        a.saved[sp.isD + m * a.HD + j] = is;
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b)
-            if (b < B) {
-                a.saved[sp.xhD + (m * B + b) * a.HD + j] = acc[b];
-                l_r[(m * B + b) * a.HD + j] = y[b] > 0.f ? y[b] : 0.f;
-            }
-    }
-    __syncthreads();
-    if (a.training && a.drm1 != nullptr)
-        for (int j = t; j < a.HD; j += HT) {
-            float rm = a.drm1[j], rv = a.drv1[j];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                rm = (1.f - a.dmom) * rm + a.dmom * l_st[(m * a.HD + j) * 2];
-                rv = (1.f - a.dmom) * rv + a.dmom * l_st[(m * a.HD + j) * 2 + 1];
-            }
-            a.drm1[j] = rm;
-            a.drv1[j] = rv;
-        }
-    // ---- D.3 (its small weight matrix staged in LDS: l_a1 is unused by this block) ----
-    float* l_w3 = l_a1;                         // [NC][HD]
-    for (int e = t; e < a.NC * a.HD; e += HT) l_w3[e] = a.dw3[e];
-    __syncthreads();
-    for (int e = t; e < 2 * B * a.NC; e += HT) {
-        const int c = e % a.NC, b = (e / a.NC) % B, m = e / (a.NC * B);
-        float s = a.db3[c];
-        for (int k = 0; k < a.HD; ++k) s = fmaf(l_w3[c * a.HD + k], l_r[(m * B + b) * a.HD + k], s);
-        a.dlog[m][b * a.NC + c] = s;
-    }
+    disc_fwd(a, sp.isD, sp.xhD, l_v, l_r, l_st, l_a1);           // block 1 (l_a1 is unused by this block: D.3's weights)
 }
 
 struct HeadsBwdArgs {
@@ -365,12 +375,112 @@ __device__ __forceinline__ void bn1d_relu_bwd(float (&dr)[MAXB], const float* xh
         if (b < B) dr[b] = training ? k * (dr[b] - sg / B - xh[b] * (sx / B)) : k * dr[b];
 }
 
+// Backward of disc_fwd on ND workgroups (dq = 0 .. ND-1; `first` = the one that stores the small results): every one
+// recomputes the D.3 / BatchNorm1d(HD) part, then takes the dq-th j-range of the D.0 backward — its rows of dW0 and its
+// partial of the token-mean gradient, a.s_dv[dq][2][B][dim] (summed, scaled by -alpha / N and broadcast over the tokens by the
+// caller's second launch).  l_dzD [2][B][HD]; l_x: LDS scratch of max(6 HD, 2 B dim NS) floats.
+__device__ __forceinline__ void disc_bwd(const HeadsBwdArgs& a, int o_xhD, int o_isD, int o_v, bool first, int dq, float* l_dzD,
+                                         float* l_x) {
+    const HeadsArgs& f = a.f;
+    const int t = threadIdx.x, B = f.B;
+    const bool tr = f.training != 0;
+    // ---- D.3 backward and through ReLU / BatchNorm1d(HD), both calls ----
+    for (int e = t; first && e < f.NC * f.HD; e += HT) { // dW3[c][k] = sum_m sum_b dd[m][b][c] r[m][b][k]
+        const int k = e % f.HD, c = e / f.HD;
+        float s = 0.f;
+        for (int m = 0; m < 2; ++m)
+            for (int b = 0; b < B; ++b) {
+                const float y = f.saved[o_xhD + (m * B + b) * f.HD + k] * f.dg1[k] + f.dbe1[k];
+                s = fmaf(a.d_dlog[m][b * f.NC + c], y > 0.f ? y : 0.f, s);
+            }
+        a.gdw3[e] = s;
+    }
+    for (int c = t; first && c < f.NC; c += HT) {
+        float s = 0.f;
+        for (int m = 0; m < 2; ++m) for (int b = 0; b < B; ++b) s += a.d_dlog[m][b * f.NC + c];
+        a.gdb3[c] = s;
+    }
+    float* l_pg = l_x;                                   // [2][HD][3]: per-call dgamma, dbeta, dbias partials
+    __syncthreads();                                     // l_x (cls) is free from here on
+    for (int e = t; e < 2 * f.HD; e += HT) {
+        const int j = e % f.HD, m = e / f.HD;
+        float dr[MAXB];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            float s = 0.f;
+            if (b < B) for (int c = 0; c < f.NC; ++c) s = fmaf(a.d_dlog[m][b * f.NC + c], f.dw3[c * f.HD + j], s);
+            dr[b] = s;
+        }
+        float dg, db;
+        bn1d_relu_bwd(dr, f.saved + o_xhD + m * B * f.HD + j, f.HD, nullptr, B, tr, f.dg1[j], f.dbe1[j],
+                      f.saved[o_isD + m * f.HD + j], dg, db);
+        float sb = 0.f;
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dzD[(m * B + b) * f.HD + j] = dr[b]; sb += dr[b]; }
+        l_pg[(m * f.HD + j) * 3] = dg;
+        l_pg[(m * f.HD + j) * 3 + 1] = db;
+        l_pg[(m * f.HD + j) * 3 + 2] = sb;
+    }
+    __syncthreads();
+    for (int j = t; first && j < f.HD; j += HT) {        // the shared D parameters collect both calls
+        a.gdg1[j] = l_pg[j * 3] + l_pg[(f.HD + j) * 3];
+        a.gdbe1[j] = l_pg[j * 3 + 1] + l_pg[(f.HD + j) * 3 + 1];
+        a.gdb0[j] = l_pg[j * 3 + 2] + l_pg[(f.HD + j) * 3 + 2];
+    }
+    // ---- D.0 backward: dW0D[j][i] = sum_m sum_b dzD[m][b][j] v[m][b][i];  dv[m][b][i] = sum_j dzD[m][b][j] W0D[j][i] ----
+    //      a thread = (input channel i, one of NS j-slices): all of its weight loads are in flight at once
+    float* l_dvp = l_x;                                 // [NS][2][B][dim] partial dv: NS <= 2 fits the B x 4*dim region
+    __syncthreads();                                    // (its previous contents, the per-call partials, are consumed)
+    {
+        const int NS = HT / f.dim >= 2 ? 2 : 1;
+        const int i = t % f.dim, sl = t / f.dim;
+        if (sl < NS && t < NS * f.dim) {
+            float v[2 * MAXB], dv[2 * MAXB];
+#pragma unroll
+            for (int q = 0; q < 2 * MAXB; ++q) {
+                const int m = q / MAXB, b = q % MAXB;
+                v[q] = b < B ? f.saved[o_v + (m * B + b) * f.dim + i] : 0.f;
+                dv[q] = 0.f;
+            }
+            const int jblk = (f.HD + ND - 1) / ND;          // this block's j-range, NS thread slices inside it
+            const int jb0 = dq * jblk, jb1 = jb0 + jblk < f.HD ? jb0 + jblk : f.HD;
+            const int jper = (jblk + NS - 1) / NS;
+            const int j0 = jb0 + sl * jper, j1 = j0 + jper < jb1 ? j0 + jper : jb1;
+#pragma unroll 8
+            for (int j = j0; j < j1; ++j) {
+                const float w = f.dw0[(size_t)j * f.dim + i];
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 2 * MAXB; ++q) {
+                    const int m = q / MAXB, b = q % MAXB;
+                    if (b < B) {
+                        const float dz = l_dzD[(m * B + b) * f.HD + j];
+                        s = fmaf(dz, v[q], s);
+                        dv[q] = fmaf(dz, w, dv[q]);
+                    }
+                }
+                a.gdw0[(size_t)j * f.dim + i] = s;
+            }
+#pragma unroll
+            for (int q = 0; q < 2 * MAXB; ++q) {
+                const int m = q / MAXB, b = q % MAXB;
+                if (b < B) l_dvp[((sl * 2 + m) * B + b) * f.dim + i] = dv[q];
+            }
+        }
+        __syncthreads();
+        for (int e = t; e < 2 * B * f.dim; e += HT) {   // broadcast over the tokens: heads_bwd_outer_kernel
+            float sum = 0.f;
+            for (int q = 0; q < NS; ++q) sum += l_dvp[q * 2 * B * f.dim + e];
+            a.s_dv[(size_t)dq * 2 * B * f.dim + e] = sum;
+        }
+    }
+}
+
 // Roles by workgroup: blocks 0 .. nA-1 run the fc_cls chain (every one recomputes the small fc_cls.8 / BatchNorm1d(H2) part,
 // block 0 stores its results; then block i takes H1 / nA of the fc_cls.4 / BatchNorm1d(H1) features, 8 j-slices per feature
 // so that a thread's chain of dependent weight loads is H2 / 8 long instead of H2); blocks nA .. nA + ND - 1 run the D path
 // (every one recomputes the small D.3 / BatchNorm1d(HD) part, the first stores its results; block q takes the q-th j-range
 // of the D.0 backward and writes its partial of the token-mean gradient, summed by heads_bwd_outer_kernel).
-constexpr int ND = 4;
 __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
     extern __shared__ float lds[];
     const HeadsArgs& f = a.f;
@@ -469,96 +579,7 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
     return;
     }
     // (fc_cls.0 backward — dcls = dz1 W0 and dW0 = dz1^T cls — runs on many workgroups: heads_bwd_outer_kernel)
-    // ---- the D path (block nA).  D.3 backward and through ReLU / BatchNorm1d(HD), both calls ----
-    for (int e = t; first && e < f.NC * f.HD; e += HT) { // dW3[c][k] = sum_m sum_b dd[m][b][c] r[m][b][k]
-        const int k = e % f.HD, c = e / f.HD;
-        float s = 0.f;
-        for (int m = 0; m < 2; ++m)
-            for (int b = 0; b < B; ++b) {
-                const float y = f.saved[sp.xhD + (m * B + b) * f.HD + k] * f.dg1[k] + f.dbe1[k];
-                s = fmaf(a.d_dlog[m][b * f.NC + c], y > 0.f ? y : 0.f, s);
-            }
-        a.gdw3[e] = s;
-    }
-    for (int c = t; first && c < f.NC; c += HT) {
-        float s = 0.f;
-        for (int m = 0; m < 2; ++m) for (int b = 0; b < B; ++b) s += a.d_dlog[m][b * f.NC + c];
-        a.gdb3[c] = s;
-    }
-    float* l_pg = l_x;                                   // [2][HD][3]: per-call dgamma, dbeta, dbias partials
-    __syncthreads();                                     // l_x (cls) is free from here on
-    for (int e = t; e < 2 * f.HD; e += HT) {
-        const int j = e % f.HD, m = e / f.HD;
-        float dr[MAXB];
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
-            float s = 0.f;
-            if (b < B) for (int c = 0; c < f.NC; ++c) s = fmaf(a.d_dlog[m][b * f.NC + c], f.dw3[c * f.HD + j], s);
-            dr[b] = s;
-        }
-        float dg, db;
-        bn1d_relu_bwd(dr, f.saved + sp.xhD + m * B * f.HD + j, f.HD, nullptr, B, tr, f.dg1[j], f.dbe1[j],
-                      f.saved[sp.isD + m * f.HD + j], dg, db);
-        float sb = 0.f;
-#pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dzD[(m * B + b) * f.HD + j] = dr[b]; sb += dr[b]; }
-        l_pg[(m * f.HD + j) * 3] = dg;
-        l_pg[(m * f.HD + j) * 3 + 1] = db;
-        l_pg[(m * f.HD + j) * 3 + 2] = sb;
-    }
-    __syncthreads();
-    for (int j = t; first && j < f.HD; j += HT) {        // the shared D parameters collect both calls
-        a.gdg1[j] = l_pg[j * 3] + l_pg[(f.HD + j) * 3];
-        a.gdbe1[j] = l_pg[j * 3 + 1] + l_pg[(f.HD + j) * 3 + 1];
-        a.gdb0[j] = l_pg[j * 3 + 2] + l_pg[(f.HD + j) * 3 + 2];
-    }
-    // ---- D.0 backward: dW0D[j][i] = sum_m sum_b dzD[m][b][j] v[m][b][i];  dv[m][b][i] = sum_j dzD[m][b][j] W0D[j][i] ----
-    //      a thread = (input channel i, one of NS j-slices): all of its weight loads are in flight at once
-    float* l_dvp = l_x;                                 // [NS][2][B][dim] partial dv: NS <= 2 fits the B x 4*dim region
-    __syncthreads();                                    // (its previous contents, the per-call partials, are consumed)
-    {
-        const int NS = HT / f.dim >= 2 ? 2 : 1;
-        const int i = t % f.dim, sl = t / f.dim;
-        if (sl < NS && t < NS * f.dim) {
-            float v[2 * MAXB], dv[2 * MAXB];
-#pragma unroll
-            for (int q = 0; q < 2 * MAXB; ++q) {
-                const int m = q / MAXB, b = q % MAXB;
-                v[q] = b < B ? f.saved[sp.v + (m * B + b) * f.dim + i] : 0.f;
-                dv[q] = 0.f;
-            }
-            const int jblk = (f.HD + ND - 1) / ND;          // this block's j-range, NS thread slices inside it
-            const int jb0 = dq * jblk, jb1 = jb0 + jblk < f.HD ? jb0 + jblk : f.HD;
-            const int jper = (jblk + NS - 1) / NS;
-            const int j0 = jb0 + sl * jper, j1 = j0 + jper < jb1 ? j0 + jper : jb1;
-#pragma unroll 8
-            for (int j = j0; j < j1; ++j) {
-                const float w = f.dw0[(size_t)j * f.dim + i];
-                float s = 0.f;
-#pragma unroll
-                for (int q = 0; q < 2 * MAXB; ++q) {
-                    const int m = q / MAXB, b = q % MAXB;
-                    if (b < B) {
-                        const float dz = l_dzD[(m * B + b) * f.HD + j];
-                        s = fmaf(dz, v[q], s);
-                        dv[q] = fmaf(dz, w, dv[q]);
-                    }
-                }
-                a.gdw0[(size_t)j * f.dim + i] = s;
-            }
-#pragma unroll
-            for (int q = 0; q < 2 * MAXB; ++q) {
-                const int m = q / MAXB, b = q % MAXB;
-                if (b < B) l_dvp[((sl * 2 + m) * B + b) * f.dim + i] = dv[q];
-            }
-        }
-        __syncthreads();
-        for (int e = t; e < 2 * B * f.dim; e += HT) {   // broadcast over the tokens: heads_bwd_outer_kernel
-            float sum = 0.f;
-            for (int q = 0; q < NS; ++q) sum += l_dvp[q * 2 * B * f.dim + e];
-            a.s_dv[(size_t)dq * 2 * B * f.dim + e] = sum;
-        }
-    }
+    disc_bwd(a, sp.xhD, sp.isD, sp.v, first, dq, l_dzD, l_x);       // blocks nA .. nA + ND - 1
 }
 
 // The wide parts of the backward on many workgroups:
@@ -644,6 +665,207 @@ __global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int
         }
         *reinterpret_cast<f32x4*>(a.d_tok[m] + o) = f32x4{sc * acc4[0], sc * acc4[1], sc * acc4[2], sc * acc4[3]};
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// The heads of the CNN-only models in one launch per direction (+ the token mean / the broadcast over the tokens):
+//   model_CNN_ad (mymodel.py:143-178): fc_cls = Linear(2 dim, H)-ReLU-Linear(H, NC) on cat[gap(mri), gap(pet)], and D on
+//                                      revgrad(gap(mri), 2), revgrad(gap(pet), 2)  — M = 2, HD > 0;
+//   model_single (mymodel.py:13-41):   fc = Linear(dim, H)-ReLU-Linear(H, NC) on gap(img)                 — M = 1, HD = 0.
+// HeadsArgs is reused: tok[], w0 / b0 = the hidden layer [H1][C4] with C4 = M dim, w8 / b8 = the output layer [NC][H1], the
+// d* fields = D; saved = saved_plan(B, dim, H1, 0, HD) with `a1` = the ReLU output and `v` = the token means.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(HT) void cnn_heads_fwd_kernel(HeadsArgs a) {
+    extern __shared__ float lds[];
+    const int t = threadIdx.x, B = a.B, M = a.C4 / a.dim;
+    const SavedPlan sp = saved_plan(B, a.dim, a.H1, 0, a.HD);
+    const int wide = a.H1 > 2 * a.HD ? a.H1 : 2 * a.HD;
+    float* l_v = lds;                            // [M][B][dim]
+    float* l_h = l_v + 2 * B * a.dim;            // [B][H1]            (D role: [2][B][HD])
+    float* l_w = l_h + B * wide;                 // [NC][H1]           (D role: [NC][HD])
+    float* l_st = l_w + a.NC * wide;             // [2][HD][2]
+    for (int e = t; e < M * B * a.dim; e += HT) l_v[e] = a.saved[sp.v + e];
+    __syncthreads();
+    if (blockIdx.x == 1) { disc_fwd(a, sp.isD, sp.xhD, l_v, l_h, l_st, l_w); return; }
+    // ---- hidden layer + ReLU: 4 threads per feature split K; x[b][k] = v[k / dim][b][k % dim] is the concatenation ----
+    for (int j0 = 0; j0 < a.H1; j0 += HT / 4) {
+        const int j = j0 + (t >> 2), part = t & 3;
+        float acc[MAXB];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+        if (j < a.H1) {
+            const float* wr = a.w0 + (size_t)j * a.C4;
+            const int kper = a.C4 / 4;                          // C4 % 16 == 0: whole float4s, none straddles a modality
+#pragma unroll 8
+            for (int k = part * kper; k < (part + 1) * kper; k += 4) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
+                const float* xm = l_v + (size_t)(k / a.dim) * B * a.dim + k % a.dim;
+#pragma unroll
+                for (int b = 0; b < MAXB; ++b)
+                    if (b < B) {
+                        const float* x = xm + b * a.dim;
+                        acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
+                        acc[b] = fmaf(w[2], x[2], acc[b]); acc[b] = fmaf(w[3], x[3], acc[b]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            acc[b] += __shfl_xor(acc[b], 1);
+            acc[b] += __shfl_xor(acc[b], 2);
+        }
+        if (j < a.H1 && part == 0) {
+            const float bias = a.b0[j];
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+                if (b < B) {
+                    const float r = acc[b] + bias > 0.f ? acc[b] + bias : 0.f;
+                    l_h[b * a.H1 + j] = r;
+                    a.saved[sp.a1 + b * a.H1 + j] = r;
+                }
+        }
+    }
+    // ---- output layer ----
+    for (int e = t; e < a.NC * a.H1; e += HT) l_w[e] = a.w8[e];
+    __syncthreads();
+    for (int e = t; e < B * a.NC; e += HT) {
+        const int c = e % a.NC, b = e / a.NC;
+        float s = a.b8[c];
+        for (int k = 0; k < a.H1; ++k) s = fmaf(l_w[c * a.H1 + k], l_h[b * a.H1 + k], s);
+        a.logits[e] = s;
+    }
+}
+
+// block 0: the fc chain (output layer, ReLU, hidden layer: its weight gradient and the gradient of the concatenated means,
+// a.s_dz1 [B][C4]); blocks 1 .. ND: disc_bwd.  cnn_heads_bwd_tok_kernel then spreads both over the tokens.
+__global__ __launch_bounds__(HT) void cnn_heads_bwd_kernel(HeadsBwdArgs a) {
+    extern __shared__ float lds[];
+    const HeadsArgs& f = a.f;
+    const int t = threadIdx.x, B = f.B;
+    const SavedPlan sp = saved_plan(B, f.dim, f.H1, 0, f.HD);
+    float* l_dz = lds;                        // [B][H1]
+    float* l_dzD = l_dz + B * f.H1;           // [2][B][HD]
+    float* l_x = l_dzD + 2 * B * f.HD;        // scratch: [NS][B][C4] | disc_bwd's
+    if (blockIdx.x > 0) { disc_bwd(a, sp.xhD, sp.isD, sp.v, blockIdx.x == 1, (int)blockIdx.x - 1, l_dzD, l_x); return; }
+    const float* h = f.saved + sp.a1;
+    for (int e = t; e < f.NC * f.H1; e += HT) {          // dW2[c][k] = sum_b dlogits[b][c] h[b][k]
+        const int k = e % f.H1, c = e / f.H1;
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s = fmaf(a.d_logits[b * f.NC + c], h[b * f.H1 + k], s);
+        a.gw8[e] = s;
+    }
+    for (int c = t; c < f.NC; c += HT) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += a.d_logits[b * f.NC + c];
+        a.gb8[c] = s;
+    }
+    for (int k = t; k < f.H1; k += HT) {                 // through the ReLU
+        float sb = 0.f;
+        for (int b = 0; b < B; ++b) {
+            float s = 0.f;
+            for (int c = 0; c < f.NC; ++c) s = fmaf(a.d_logits[b * f.NC + c], f.w8[c * f.H1 + k], s);
+            s = h[b * f.H1 + k] > 0.f ? s : 0.f;
+            l_dz[b * f.H1 + k] = s;
+            sb += s;
+        }
+        a.gb0[k] = sb;
+    }
+    __syncthreads();
+    // hidden layer: dW0[k][i] = sum_b dz[b][k] x[b][i];  dx[b][i] = sum_k dz[b][k] W0[k][i]; thread = (column i, k-slice)
+    const int NS = HT / f.C4 >= 2 ? 2 : 1;
+    const int i = t % f.C4, sl = t / f.C4;
+    if (sl < NS) {
+        float x[MAXB], dx[MAXB];
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            x[b] = b < B ? f.saved[sp.v + ((size_t)(i / f.dim) * B + b) * f.dim + i % f.dim] : 0.f;
+            dx[b] = 0.f;
+        }
+        const int kper = (f.H1 + NS - 1) / NS;
+        const int k0 = sl * kper, k1 = k0 + kper < f.H1 ? k0 + kper : f.H1;
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) {
+            const float w = f.w0[(size_t)k * f.C4 + i];
+            float s = 0.f;
+#pragma unroll
+            for (int b = 0; b < MAXB; ++b)
+                if (b < B) {
+                    const float dz = l_dz[b * f.H1 + k];
+                    s = fmaf(dz, x[b], s);
+                    dx[b] = fmaf(dz, w, dx[b]);
+                }
+            a.gw0[(size_t)k * f.C4 + i] = s;
+        }
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) if (b < B) l_x[(sl * B + b) * f.C4 + i] = dx[b];
+    }
+    __syncthreads();
+    for (int e = t; e < B * f.C4; e += HT) {
+        float sum = 0.f;
+        for (int q = 0; q < NS; ++q) sum += l_x[q * B * f.C4 + e];
+        a.s_dz1[e] = sum;
+    }
+}
+
+// d tok[m][b][n][c] = (dx[b][m dim + c] - alpha * sum_q dvD[q][m][b][c]) / N: the mean over the tokens backwards, the
+// discriminator's part through the gradient reversal (mymodel.py:150-151)
+__global__ __launch_bounds__(HT) void cnn_heads_bwd_tok_kernel(HeadsBwdArgs a) {
+    const HeadsArgs& f = a.f;
+    const int B = f.B, M = f.C4 / f.dim;
+    const float inv = 1.0f / f.N, sc = -a.alpha / f.N;
+    const size_t per = (size_t)B * f.N * f.dim, total = (size_t)M * per;
+    for (size_t e = ((size_t)blockIdx.x * HT + threadIdx.x) * 4; e < total; e += (size_t)gridDim.x * HT * 4) {
+        const int m = e >= per ? 1 : 0;
+        const size_t o = e - m * per;
+        const int c = o % f.dim, b = o / ((size_t)f.N * f.dim);              // dim % 4 == 0: the 4 elements share (m, b)
+        const float* dx = a.s_dz1 + (size_t)b * f.C4 + m * f.dim + c;
+        f32x4 r = {inv * dx[0], inv * dx[1], inv * dx[2], inv * dx[3]};
+        if (f.HD > 0) {
+            const float* dv = a.s_dv + ((size_t)m * B + b) * f.dim + c;
+            f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < ND; ++q) {
+                const float* dq_ = dv + (size_t)q * 2 * B * f.dim;
+                acc4[0] += dq_[0]; acc4[1] += dq_[1]; acc4[2] += dq_[2]; acc4[3] += dq_[3];
+            }
+            r = f32x4{fmaf(sc, acc4[0], r[0]), fmaf(sc, acc4[1], r[1]), fmaf(sc, acc4[2], r[2]), fmaf(sc, acc4[3], r[3])};
+        }
+        *reinterpret_cast<f32x4*>(a.d_tok[m] + o) = r;
+    }
+}
+
+int check_cnn_heads(const char* fn, const tmf_heads_cnn_desc* d) {
+    TMF_REQUIRE_PTR(d);
+    TMF_REQUIRE(d->B > 0 && d->B <= MAXB, TMF_E_SHAPE, "%s: batch %d (1..%d)", fn, d->B, MAXB);
+    TMF_REQUIRE(d->M == 1 || d->M == 2, TMF_E_SHAPE, "%s: M=%d modalities (1 or 2)", fn, d->M);
+    TMF_REQUIRE(d->N > 0 && d->dim > 0 && d->H > 0 && d->HD >= 0 && d->NC > 0 && d->NC <= 16, TMF_E_SHAPE,
+                "%s: non-positive dimension", fn);
+    TMF_REQUIRE(d->dim % 16 == 0 && d->M * d->dim <= HT, TMF_E_SHAPE, "%s: dim=%d must be a multiple of 16 and M*dim <= %d", fn,
+                d->dim, HT);
+    TMF_REQUIRE(d->HD == 0 || d->M == 2, TMF_E_SHAPE, "%s: the discriminator takes both modalities (M=2)", fn);
+    return TMF_OK;
+}
+HeadsArgs make_cnn_args(const tmf_heads_cnn_desc& d, const float* mri_tok, const float* pet_tok, const tmf_heads_cnn_params& p,
+                        float* saved) {
+    HeadsArgs a = {};
+    a.tok[0] = mri_tok; a.tok[1] = pet_tok;
+    a.w0 = p.fc0_w; a.b0 = p.fc0_b; a.w8 = p.fc2_w; a.b8 = p.fc2_b;
+    a.dw0 = p.d0_w; a.db0 = p.d0_b; a.dg1 = p.dbn_g; a.dbe1 = p.dbn_b; a.drm1 = p.dbn_rm; a.drv1 = p.dbn_rv;
+    a.dw3 = p.d3_w; a.db3 = p.d3_b;
+    a.saved = saved;
+    a.B = d.B; a.N = d.N; a.dim = d.dim; a.C4 = d.M * d.dim; a.H1 = d.H; a.H2 = 0; a.HD = d.HD; a.NC = d.NC;
+    a.training = d.training; a.dmom = d.momentum; a.deps = d.eps;
+    return a;
+}
+size_t cnn_fwd_lds(const tmf_heads_cnn_desc& d) {
+    const int wide = d.H > 2 * d.HD ? d.H : 2 * d.HD;
+    return (size_t)(2 * d.B * d.dim + d.B * wide + d.NC * wide + 4 * d.HD) * 4;
+}
+size_t cnn_bwd_lds(const tmf_heads_cnn_desc& d) {
+    size_t lx = (size_t)2 * d.B * d.M * d.dim;                       // [NS][B][C4]
+    if (lx < (size_t)6 * d.HD) lx = (size_t)6 * d.HD;                // disc_bwd: per-call partials, then [NS][2][B][dim]
+    if (lx < (size_t)4 * d.B * d.dim) lx = (size_t)4 * d.B * d.dim;
+    return ((size_t)d.B * d.H + 2 * d.B * d.HD + lx) * 4;
 }
 
 int check_heads(const char* fn, const tmf_heads_desc* d) {
@@ -768,4 +990,86 @@ extern "C" int tmf_heads_bwd(const tmf_heads_desc* d, const float* cls, const fl
     const int nbc = tmf_cdiv(4 * d->dim, 32);
     hipLaunchKernelGGL(heads_bwd_outer_kernel, dim3(nbc + nb0 + nb4 + nbt), dim3(HT), 0, (hipStream_t)stream, a, nb0, nb4, nbc);
     return tmf_launch_result("tmf_heads_bwd(outer)");
+}
+
+extern "C" size_t tmf_heads_cnn_saved_bytes(const tmf_heads_cnn_desc* d) {
+    if (check_cnn_heads("tmf_heads_cnn_saved_bytes", d) != TMF_OK) return 0;
+    return (size_t)saved_plan(d->B, d->dim, d->H, 0, d->HD).total * 4;
+}
+
+extern "C" size_t tmf_heads_cnn_bwd_scratch_bytes(const tmf_heads_cnn_desc* d) {
+    if (check_cnn_heads("tmf_heads_cnn_bwd_scratch_bytes", d) != TMF_OK) return 0;
+    return (size_t)(d->B * d->M * d->dim + ND * 2 * d->B * d->dim) * 4;
+}
+
+extern "C" int tmf_heads_cnn_fwd(const tmf_heads_cnn_desc* d, const float* mri_tok, const float* pet_tok,
+                                 const tmf_heads_cnn_params* p, float* logits, float* d_mri_logits, float* d_pet_logits,
+                                 void* saved, size_t saved_bytes, void* stream) {
+    int rc;
+    if ((rc = check_cnn_heads("tmf_heads_cnn_fwd", d))) return rc;
+    TMF_REQUIRE_PTR(p); TMF_REQUIRE_PTR(mri_tok); TMF_REQUIRE_PTR(logits); TMF_REQUIRE_PTR(saved);
+    TMF_REQUIRE(p->fc0_w && p->fc0_b && p->fc2_w && p->fc2_b, TMF_E_NULL, "tmf_heads_cnn_fwd: a parameter pointer is NULL");
+    if (d->M == 2) TMF_REQUIRE_PTR(pet_tok);
+    if (d->HD > 0) {
+        TMF_REQUIRE(p->d0_w && p->d0_b && p->dbn_g && p->dbn_b && p->d3_w && p->d3_b, TMF_E_NULL,
+                    "tmf_heads_cnn_fwd: a discriminator parameter pointer is NULL");
+        TMF_REQUIRE(d->training || (p->dbn_rm && p->dbn_rv), TMF_E_NULL, "tmf_heads_cnn_fwd: eval mode needs the running statistics");
+        TMF_REQUIRE_PTR(d_mri_logits); TMF_REQUIRE_PTR(d_pet_logits);
+    }
+    TMF_REQUIRE(saved_bytes >= tmf_heads_cnn_saved_bytes(d), TMF_E_WORKSPACE, "tmf_heads_cnn_fwd: saved %zu B < required %zu B",
+                saved_bytes, tmf_heads_cnn_saved_bytes(d));
+    TMF_REQUIRE_ALIGNED(p->fc0_w); TMF_REQUIRE_ALIGNED(saved);
+    HeadsArgs a = make_cnn_args(*d, mri_tok, pet_tok, *p, (float*)saved);
+    a.logits = logits; a.dlog[0] = d_mri_logits; a.dlog[1] = d_pet_logits;
+    const size_t lds = cnn_fwd_lds(*d);
+    TMF_REQUIRE(lds <= 150 * 1024, TMF_E_SHAPE, "tmf_heads_cnn_fwd: %zu B of LDS needed (batch x widths too large)", lds);
+    if ((rc = tmf_allow_lds(cnn_heads_fwd_kernel, lds, "tmf_heads_cnn_fwd"))) return rc;
+    hipLaunchKernelGGL(token_mean_kernel, dim3(d->M * d->B), dim3(HT), 0, (hipStream_t)stream, mri_tok, pet_tok,
+                       (float*)saved + saved_plan(d->B, d->dim, d->H, 0, d->HD).v, d->B, d->N, d->dim);
+    if ((rc = tmf_launch_result("tmf_heads_cnn_fwd(token mean)"))) return rc;
+    hipLaunchKernelGGL(cnn_heads_fwd_kernel, dim3(d->HD > 0 ? 2 : 1), dim3(HT), lds, (hipStream_t)stream, a);
+    return tmf_launch_result("tmf_heads_cnn_fwd");
+}
+
+extern "C" int tmf_heads_cnn_bwd(const tmf_heads_cnn_desc* d, const tmf_heads_cnn_params* p, const void* saved, size_t saved_bytes,
+                                 const float* d_logits, const float* d_d_mri_logits, const float* d_d_pet_logits,
+                                 const tmf_heads_cnn_grads* g, float* d_mri_tok, float* d_pet_tok, float revgrad_alpha,
+                                 void* scratch, size_t scratch_bytes, void* stream) {
+    int rc;
+    if ((rc = check_cnn_heads("tmf_heads_cnn_bwd", d))) return rc;
+    TMF_REQUIRE_PTR(p); TMF_REQUIRE_PTR(saved); TMF_REQUIRE_PTR(d_logits); TMF_REQUIRE_PTR(g); TMF_REQUIRE_PTR(d_mri_tok);
+    TMF_REQUIRE_PTR(scratch);
+    TMF_REQUIRE(p->fc0_w && p->fc0_b && p->fc2_w && p->fc2_b, TMF_E_NULL, "tmf_heads_cnn_bwd: a parameter pointer is NULL");
+    TMF_REQUIRE(g->fc0_w && g->fc0_b && g->fc2_w && g->fc2_b, TMF_E_NULL, "tmf_heads_cnn_bwd: a gradient pointer is NULL");
+    if (d->M == 2) TMF_REQUIRE_PTR(d_pet_tok);
+    if (d->HD > 0) {
+        TMF_REQUIRE(p->d0_w && p->d0_b && p->dbn_g && p->dbn_b && p->d3_w && p->d3_b, TMF_E_NULL,
+                    "tmf_heads_cnn_bwd: a discriminator parameter pointer is NULL");
+        TMF_REQUIRE(g->d0_w && g->d0_b && g->dbn_g && g->dbn_b && g->d3_w && g->d3_b, TMF_E_NULL,
+                    "tmf_heads_cnn_bwd: a discriminator gradient pointer is NULL");
+        TMF_REQUIRE_PTR(d_d_mri_logits); TMF_REQUIRE_PTR(d_d_pet_logits);
+    }
+    TMF_REQUIRE(saved_bytes >= tmf_heads_cnn_saved_bytes(d), TMF_E_WORKSPACE, "tmf_heads_cnn_bwd: saved %zu B < required %zu B",
+                saved_bytes, tmf_heads_cnn_saved_bytes(d));
+    TMF_REQUIRE(scratch_bytes >= tmf_heads_cnn_bwd_scratch_bytes(d), TMF_E_WORKSPACE,
+                "tmf_heads_cnn_bwd: scratch %zu B < required %zu B", scratch_bytes, tmf_heads_cnn_bwd_scratch_bytes(d));
+    TMF_REQUIRE_ALIGNED(d_mri_tok); TMF_REQUIRE_ALIGNED(scratch);
+    if (d->M == 2) TMF_REQUIRE_ALIGNED(d_pet_tok);
+    HeadsBwdArgs a = {};
+    a.f = make_cnn_args(*d, nullptr, nullptr, *p, (float*)const_cast<void*>(saved));
+    a.d_logits = d_logits; a.d_dlog[0] = d_d_mri_logits; a.d_dlog[1] = d_d_pet_logits;
+    a.gw0 = g->fc0_w; a.gb0 = g->fc0_b; a.gw8 = g->fc2_w; a.gb8 = g->fc2_b;
+    a.gdw0 = g->d0_w; a.gdb0 = g->d0_b; a.gdg1 = g->dbn_g; a.gdbe1 = g->dbn_b; a.gdw3 = g->d3_w; a.gdb3 = g->d3_b;
+    a.d_tok[0] = d_mri_tok; a.d_tok[1] = d_pet_tok; a.alpha = revgrad_alpha;
+    a.s_dz1 = (float*)scratch; a.s_dv = a.s_dz1 + (size_t)d->B * d->M * d->dim;
+    const size_t lds = cnn_bwd_lds(*d);
+    TMF_REQUIRE(lds <= 150 * 1024, TMF_E_SHAPE, "tmf_heads_cnn_bwd: %zu B of LDS needed (batch x widths too large)", lds);
+    if ((rc = tmf_allow_lds(cnn_heads_bwd_kernel, lds, "tmf_heads_cnn_bwd"))) return rc;
+    hipLaunchKernelGGL(cnn_heads_bwd_kernel, dim3(d->HD > 0 ? 1 + ND : 1), dim3(HT), lds, (hipStream_t)stream, a);
+    if ((rc = tmf_launch_result("tmf_heads_cnn_bwd"))) return rc;
+    int nbt = tmf_cdiv((long)d->M * d->B * d->N * d->dim, (long)HT * 4 * 4);
+    if (nbt > 256) nbt = 256;
+    if (nbt < 1) nbt = 1;
+    hipLaunchKernelGGL(cnn_heads_bwd_tok_kernel, dim3(nbt), dim3(HT), 0, (hipStream_t)stream, a);
+    return tmf_launch_result("tmf_heads_cnn_bwd(tokens)");
 }

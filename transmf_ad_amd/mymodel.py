@@ -124,6 +124,56 @@ def _discriminator(dim):
     return nn.Sequential(nn.Linear(dim, 128), nn.BatchNorm1d(128), nn.ReLU(), nn.Linear(128, 2))
 
 
+def _plain(mods):
+    """Nobody hooked into these modules (a hook would not see the one-launch path's intermediate tensors)."""
+    return not any(m._forward_hooks or m._forward_pre_hooks or m._backward_hooks for m in mods)
+
+
+def _cnn_heads_one_call_ok(model, fc, D, tok, M):
+    """The heads of the CNN-only models as the reference builds them (mymodel.py:20, :148-151): fc = Linear-ReLU-Linear on the
+    M concatenated token means, D = Linear-BatchNorm1d-ReLU-Linear or None — then they are one launch per direction
+    (ops.HeadsCNN); anything else takes the module path."""
+    from . import ops
+    if not (ops.HEADS_ONE_CALL and tok.is_cuda and tok.dtype == torch.float32 and tok.shape[0] <= 16):
+        return False
+    dim = tok.shape[-1]
+    if not (isinstance(fc, nn.Sequential) and [type(m) for m in fc] == [nn.Linear, nn.ReLU, nn.Linear]):
+        return False
+    if fc[0].in_features != M * dim or fc[2].in_features != fc[0].out_features or fc[0].bias is None or fc[2].bias is None:
+        return False
+    if dim % 16 or M * dim > 512 or fc[2].out_features > 16:          # csrc/heads.hip check_cnn_heads
+        return False
+    mods = list(fc) + [fc]
+    if D is not None:
+        if not (isinstance(D, nn.Sequential) and [type(m) for m in D] == [nn.Linear, nn.BatchNorm1d, nn.ReLU, nn.Linear]):
+            return False
+        if D[0].in_features != dim or D[3].in_features != D[0].out_features or D[3].out_features != fc[2].out_features \
+                or D[0].bias is None or D[3].bias is None:
+            return False
+        bn = D[1]
+        if not bn.affine or bn.momentum is None or (not bn.track_running_stats and not model.training):
+            return False
+        mods += list(D) + [D]
+    if any(m.training != model.training for m in mods):               # one train / eval switch for the whole launch
+        return False
+    return _plain(mods)
+
+
+def _cnn_heads(model, fc, D, mri_tok, pet_tok):
+    from . import ops
+    params = [fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias]
+    buffers, momentum, eps = (None, None), 0.0, 0.0
+    if D is not None:
+        bn = D[1]
+        if model.training and bn.track_running_stats:
+            bn.num_batches_tracked += 2                                # D runs twice
+        if bn.track_running_stats:
+            buffers = (bn.running_mean, bn.running_var)
+        momentum, eps = float(bn.momentum), float(bn.eps)
+        params += [D[0].weight, D[0].bias, bn.weight, bn.bias, D[3].weight, D[3].bias]
+    return ops.HeadsCNN.apply(mri_tok, pet_tok, (model.training, momentum, eps, 2.0), buffers, *params)
+
+
 class model_single(_FastModeSwitch, nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -134,7 +184,10 @@ class model_single(_FastModeSwitch, nn.Module):
 
     @device_guard
     def forward(self, img):
-        return self.fc(_tokens(self.cnn(img)).mean(dim=1))
+        tok = _tokens(self.cnn(img))                            # (B, V, dim); avgpool + rearrange == mean over V
+        if _cnn_heads_one_call_ok(self, self.fc, None, tok, 1):
+            return _cnn_heads(self, self.fc, None, tok, None)
+        return self.fc(tok.mean(dim=1))
 
 
 class model_CNN_ad(_FastModeSwitch, nn.Module):
@@ -150,8 +203,11 @@ class model_CNN_ad(_FastModeSwitch, nn.Module):
     @device_guard
     def forward(self, mri, pet):
         mri_emb, pet_emb = _two_streams(self.mri_cnn, mri, self.pet_cnn, pet)
-        mri_feat = _tokens(mri_emb).mean(dim=1)                 # == AdaptiveAvgPool3d(1) + flatten
-        pet_feat = _tokens(pet_emb).mean(dim=1)
+        mri_tok, pet_tok = _tokens(mri_emb), _tokens(pet_emb)
+        if _cnn_heads_one_call_ok(self, self.fc_cls, self.D, mri_tok, 2):
+            return _cnn_heads(self, self.fc_cls, self.D, mri_tok, pet_tok)
+        mri_feat = mri_tok.mean(dim=1)                          # == AdaptiveAvgPool3d(1) + flatten
+        pet_feat = pet_tok.mean(dim=1)
         D_MRI_logits = self.D(revgrad(mri_feat, 2.0))
         D_PET_logits = self.D(revgrad(pet_feat, 2.0))
         output_logits = self.fc_cls(torch.cat([mri_feat, pet_feat], dim=1))

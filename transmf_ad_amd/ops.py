@@ -1078,6 +1078,87 @@ class HeadsAD(torch.autograd.Function):
         return (d_cls, d_tok[0], d_tok[1], None, None, None, None, *grads)
 
 
+class HeadsCNN(torch.autograd.Function):
+    """The heads of the CNN-only models as ONE kernel per direction (tmf_heads_cnn_fwd / _bwd, csrc/heads.hip):
+    model_CNN_ad: fc_cls(cat[mean_n mri, mean_n pet]), D(revgrad(mean_n mri)), D(revgrad(mean_n pet))   (mymodel.py:164-178)
+    model_single: fc(mean_n tok)                                                                          (mymodel.py:33-39).
+    forward(mri_tok, pet_tok | None, cfg, buffers, *params): params = fc0_w, fc0_b, fc2_w, fc2_b [, d0_w, d0_b, dbn_g, dbn_b,
+    d3_w, d3_b]; buffers = (running_mean, running_var) of D's BatchNorm1d or (None, None); cfg = (training, momentum, eps,
+    revgrad alpha) -> (logits, D_MRI, D_PET) or (logits,)."""
+
+    @staticmethod
+    def forward(ctx, mri, pet, cfg, buffers, *params):
+        import ctypes as C
+        mri = _chk(mri, "mri_tokens")
+        M = 1 if pet is None else 2
+        if M == 2:
+            pet = _chk(pet, "pet_tokens")
+            if pet.shape != mri.shape:
+                raise _lib.TmfError(f"token shapes differ: {tuple(mri.shape)} vs {tuple(pet.shape)}")
+        with_d = len(params) == len(_lib.HEADS_CNN_PARAMS)
+        if not with_d and len(params) != 4:
+            raise _lib.TmfError(f"heads_cnn: {len(params)} parameter tensors (4 without, 10 with the discriminator)")
+        training, momentum, eps, alpha = cfg
+        B, N, dim = mri.shape
+        P = dict(zip(_lib.HEADS_CNN_PARAMS, params))
+        desc = _lib.HeadsCnnDesc(B=B, N=N, dim=dim, M=M, H=P["fc0_w"].shape[0], HD=P["d0_w"].shape[0] if with_d else 0,
+                                 NC=P["fc2_w"].shape[0], training=int(training), momentum=momentum, eps=eps)
+        prm = _lib.HeadsCnnParams()
+        for name, t in P.items():
+            if not (t.is_cuda and t.dtype == _f32 and t.is_contiguous()):
+                raise _lib.TmfError(f"heads_cnn: {name} must be a contiguous float32 tensor on the HIP device")
+            setattr(prm, name, t.data_ptr())
+        prm.dbn_rm, prm.dbn_rv = _ptr(buffers[0]), _ptr(buffers[1])
+        nsaved = _lib.query("tmf_heads_cnn_saved_bytes", C.byref(desc))
+        if nsaved == 0:
+            raise _lib.TmfError("tmf_heads_cnn_saved_bytes: " + (_lib.load().tmf_last_error_string() or b"").decode())
+        saved = torch.empty(nsaved // 4, device=mri.device, dtype=_f32)
+        outs = torch.empty((3 if with_d else 1, B, desc.NC), device=mri.device, dtype=_f32)
+        _lib.call("tmf_heads_cnn_fwd", C.byref(desc), mri.data_ptr(), _ptr(pet), C.byref(prm), outs[0].data_ptr(),
+                  outs[1].data_ptr() if with_d else None, outs[2].data_ptr() if with_d else None, saved.data_ptr(), nsaved,
+                  _stream())
+        ctx.save_for_backward(saved, *params)
+        ctx.desc, ctx.prm, ctx.alpha, ctx.with_d = desc, prm, float(alpha), with_d
+        ctx.tok_shape = tuple(mri.shape)
+        ctx.bwd = HeadsCNN._prepare_backward(desc, mri.device, params, ctx.tok_shape) if any(ctx.needs_input_grad) else None
+        return (outs[0], outs[1], outs[2]) if with_d else outs[0]
+
+    @staticmethod
+    def _prepare_backward(desc, dev, params, tok_shape):
+        import ctypes as C
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes), device=dev, dtype=_f32)
+        parts = flat.split(sizes)
+        g = _lib.HeadsCnnGrads()
+        o = flat.data_ptr()
+        for name, n in zip(_lib.HEADS_CNN_PARAMS, sizes):
+            setattr(g, name, o)
+            o += 4 * n
+        d_tok = torch.empty((desc.M,) + tok_shape, device=dev, dtype=_f32)
+        nscr = _lib.query("tmf_heads_cnn_bwd_scratch_bytes", C.byref(desc))
+        scratch = torch.empty(nscr // 4, device=dev, dtype=_f32)
+        zero = torch.zeros((desc.B, desc.NC), device=dev, dtype=_f32)      # stands in for an output nobody differentiated
+        grads = [t if p.dim() == 1 else t.view(p.shape) for t, p in zip(parts, params)]
+        return g, flat, grads, d_tok, scratch, nscr, zero
+
+    @staticmethod
+    def backward(ctx, dlo, ddm=None, ddp=None):
+        import ctypes as C
+        saved = ctx.saved_tensors[0]
+        params = ctx.saved_tensors[1:]
+        desc = ctx.desc
+        prep = ctx.bwd if ctx.bwd is not None else HeadsCNN._prepare_backward(desc, saved.device, params, ctx.tok_shape)
+        ctx.bwd = None
+        g, _flat, grads, d_tok, scratch, nscr, zero = prep
+        dl = [zero if t is None else (t if (t.dtype == _f32 and t.is_contiguous()) else t.to(_f32).contiguous())
+              for t in (dlo, ddm, ddp)]
+        two = desc.M == 2
+        _lib.call("tmf_heads_cnn_bwd", C.byref(desc), C.byref(ctx.prm), saved.data_ptr(), saved.numel() * 4, dl[0].data_ptr(),
+                  dl[1].data_ptr() if ctx.with_d else None, dl[2].data_ptr() if ctx.with_d else None, C.byref(g),
+                  d_tok[0].data_ptr(), d_tok[1].data_ptr() if two else None, ctx.alpha, scratch.data_ptr(), nscr, _stream())
+        return (d_tok[0], d_tok[1] if two else None, None, None, *grads)
+
+
 # --------------------------------------------------------------------------------------
 # token pooling head                                                (networks.py:276-281)
 # --------------------------------------------------------------------------------------
