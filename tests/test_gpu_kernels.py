@@ -541,6 +541,39 @@ def test_conv3d_bf16_mfma(shape, bf16_kernel_choice):
         assert _relerr(_ncdhw(dx.cpu()), xr.grad) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 16, 16, 32, 64), (1, 11, 13, 9, 64, 32), (1, 9, 8, 11, 40, 72), (1, 17, 16, 24, 32, 32),
+                                   (2, 8, 24, 8, 16, 24), (1, 16, 8, 8, 64, 130)])
+def test_conv3d_bf16_tensor_modes_agree_bitwise(shape, bf16_kernel_choice):
+    """The four tensor-type modes of tmf_conv3d_fwd_bf16_t (io bit 0: bf16 input tensor, bit 1: bf16 output tensor) run the
+    same products in the same order: with an input that IS bf16-valued the fp32 outputs agree bit for bit, a bf16 output is
+    the round-to-nearest-even of the fp32 one (also where bricks overhang the volume and the channel tile is partial: the
+    lean buffer-store epilogue of the 8x8x8-brick kernel), and the BatchNorm statistic partials are identical."""
+    ops = _ops()
+    from transmf_ad_amd import _lib
+    B, D, H, W, cin, cout = shape
+    x = _ndhwc(_rand(B, cin, D, H, W, seed=71).bfloat16().float()).to(DEV)
+    w = ops.pack_weight_bf16((_rand(cout, cin, 3, 3, 3, seed=72, scale=(cin * 27) ** -0.5)).to(DEV))
+    nblk = _lib.query("tmf_conv3d_bf16_stat_blocks", B, D, H, W)
+    outs = []
+    for io in range(4):
+        xin = x.bfloat16() if io & 1 else x
+        z = torch.full((B, D, H, W, cout), float("nan"), device=DEV, dtype=torch.bfloat16 if io & 2 else torch.float32)
+        part = torch.zeros((nblk, 2, cout), device=DEV)
+        _lib.call("tmf_conv3d_fwd_bf16_t", xin.data_ptr(), w.data_ptr(), z.data_ptr(), part.data_ptr(),
+                  B, D, H, W, cin, cout, io, torch.cuda.current_stream().cuda_stream)
+        outs.append((z, part))
+    torch.cuda.synchronize()
+    z0, p0 = outs[0]
+    assert torch.isfinite(z0).all()
+    for io in range(1, 4):
+        z, part = outs[io]
+        if io & 2:
+            assert torch.equal(z, z0.bfloat16()), io
+        else:
+            assert torch.equal(z, z0), io
+        assert torch.equal(part, p0), io
+
+
 @pytest.fixture(params=[2, 0], ids=["tr-read", "reg-transpose"])
 def wgrad_kernel_choice(request):
     """Both bf16 weight-gradient kernels: the transposing-read one (cin, cout multiples of 8) and the register-transposing one."""

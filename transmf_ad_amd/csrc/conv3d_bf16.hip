@@ -303,6 +303,17 @@ namespace dma {
 __device__ __forceinline__ void glds16(const void* g, unsigned lds_wave_base) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "memory");
 }
+// The same through a buffer resource: LDS byte = lds_wave_base + 16 * lane <- resource base + voff (per lane) + soff (scalar).
+// A lane whose voff + soff is not below the resource's num_records delivers ZEROS to its LDS bytes (gfx950: the scalar
+// offset is part of the range check, tools/microbench/blds_probe.hip) — zero fill costs no pointer select, no compare.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void blds16(int voff, i32x4 rsrc, int soff, unsigned lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base) : "memory");
+}
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
     return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
@@ -384,6 +395,10 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     constexpr int TD = v2::TD, TH = v2::TH, TW = v2::TW, HH = v2::HH, HW = v2::HW, NHALO = v2::NHALO, CINC = v2::CINC,
                   RP = v2::RP, TPS = v2::TPS, NSTAGES = v2::NSTAGES, NTHR = v2::NTHR, MT2 = v2::MT2;
     constexpr int NB = v2::Cfg<NT>::NB, WSTAGE = v2::Cfg<NT>::WSTAGE;
+    // PERM (two N-tiles, bf16 outputs): weight row l of tile j holds output channel n0 + 2 l + j, so a lane's two
+    // accumulator tiles are the two halves of one stored dword (a channel pair): no exchange between lanes in the epilogue
+    // and 128 contiguous bytes per voxel and half-wave.  Only the SOURCE channel of a staged weight row changes.
+    constexpr bool PERM = NT == 2 && OUT16;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     u16* halo = reinterpret_cast<u16*>(smem_raw);
     u16* Ws = halo + NHALO * RP;
@@ -454,45 +469,53 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
         constexpr int PPL = HH * HW * 2;                       // 200 pieces per halo plane
         constexpr int WQ = (TPSD * NB * 2 + 255) / 256;        // 5 | 3
         // (one register set for both roles: a wave is a halo copier or a weight copier for the whole kernel)
-        int r_off, r_q8, r_tp = 0;
-        bool r_ok;
+        // Byte offsets inside the sample / the weight tensor; a lane that must deliver zeros (outside the volume, beyond
+        // Cout, an idle lane of the last plane piece) carries OOBV, a plane outside the volume an out-of-range SCALAR offset.
+        constexpr int OOBV = 0x7FFFFFF0;
+        int r_vo, r_vox = OOBV, r_q8, r_tp = 0;                 // r_vox: the halo row's OTHER 16-byte half (swapped planes)
         if (wrole) {
-            const int col = (rt >> 1) % NB;
+            const int col = (rt >> 1) % NB;                     // LDS row inside the tap
+            const int cs = PERM ? 2 * (col & 31) + (col >> 5) : col;   // the output channel it holds
             r_tp = (rt >> 1) / NB;
-            r_ok = n0 + col < Cout;
             r_q8 = 8 * ((rt & 1) ^ ((col >> 3) & 1));
-            r_off = (r_tp * Cout + n0 + col) * Cin + r_q8;
+            r_vo = n0 + cs < Cout ? ((r_tp * Cout + n0 + cs) * Cin + r_q8) * 2 : OOBV;
         } else {
             const int hh = rt / (HW * 2), hw = (rt % (HW * 2)) >> 1;
             const int gh = h0 + hh - 1, gw = w0 + hw - 1;
-            r_ok = rt < PPL && gh >= 0 && gh < H && gw >= 0 && gw < W;
+            const bool ok = rt < PPL && gh >= 0 && gh < H && gw >= 0 && gw < W;
             r_q8 = 8 * (rt & 1);
-            r_off = (gh * W + gw) * Cin + r_q8;            // channel group q; the swapped planes use r_off ^ 8
+            r_vo = ok ? ((gh * W + gw) * Cin + r_q8) * 2 : OOBV;           // channel group q; the swapped planes take the other
+            r_vox = ok ? ((gh * W + gw) * Cin + (r_q8 ^ 8)) * 2 : OOBV;    // (a row starts at an odd multiple of 8 when Cin % 16 == 8)
         }
+        const i32x4 xr = make_rsrc(xb16, (unsigned)(D * H * W * Cin * 2));
+        const i32x4 wr = make_rsrc(w, (unsigned)(27 * Cout * Cin * 2));
+        const bool ragged_c = (Cin & (CINC - 1)) != 0;         // the last chunk is partial: its missing channel groups read zeros
+        const int plane_b = H * W * Cin * 2;
         constexpr int TPI = 256 / (2 * NB);                    // taps per copy instruction: 2 | 4
         auto issue_h = [&](int c0) {                           // waves 4-7
+            if (dbg & 2) return;
             const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (wave - 4) * 1024);
-            const bool ch_ok0 = c0 + r_q8 < Cin, ch_ok1 = c0 + (r_q8 ^ 8) < Cin;
+            int vo = r_vo, vox = r_vox;
+            if (ragged_c) { vo = c0 + r_q8 < Cin ? vo : OOBV; vox = c0 + (r_q8 ^ 8) < Cin ? vox : OOBV; }
+            if (rt < PPL) {
 #pragma unroll
-            for (int hd = 0; hd < v2::HD; ++hd) {
-                const int gd = d0 + hd - 1;                    // scalar
-                const bool pl_ok = gd >= 0 && gd < D;
-                const bool sw = (hd >> 1) & 1;                 // compile-time
-                const bool ok = r_ok && pl_ok && (sw ? ch_ok1 : ch_ok0);
-                const u16* plane = xb16 + (ptrdiff_t)gd * H * W * Cin + c0;     // (gd = -1 or D: never dereferenced)
-                const void* src = ok ? (const void*)(plane + (sw ? (r_off ^ 8) : r_off)) : (const void*)tmf_zero16;
-                if (rt < PPL) glds16(src, base + hd * (PPL * 16));
+                for (int hd = 0; hd < v2::HD; ++hd) {
+                    const int gd = d0 + hd - 1;                    // scalar
+                    const int so = (gd >= 0 && gd < D) ? gd * plane_b + c0 * 2 : OOBV;
+                    blds16(((hd >> 1) & 1) ? vox : vo, xr, so, base + hd * (PPL * 16));   // the swizzle bit is compile-time
+                }
             }
         };
         auto issue_w = [&](int c0, int st, int wbuf) {         // waves 0-3
+            if (dbg & 1) return;
             const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + HBYTES + wbuf * WBYTES + wave * 1024);
-            const u16* ws = w + (size_t)st * TPSD * Cout * Cin + c0;
-            const bool ok0 = r_ok && c0 + r_q8 < Cin;
+            int vo = r_vo;
+            if (ragged_c) vo = c0 + r_q8 < Cin ? vo : OOBV;
+            const int so0 = (st * TPSD * Cout * Cin + c0) * 2;
 #pragma unroll
             for (int i = 0; i < WQ; ++i) {
                 const bool in_stage = i * TPI + TPI <= TPSD || i * TPI + r_tp < TPSD;      // the last instruction is half empty
-                const void* src = (ok0 && in_stage) ? (const void*)(ws + (size_t)i * TPI * Cout * Cin + r_off) : (const void*)tmf_zero16;
-                if (in_stage) glds16(src, base + i * 4096);
+                if (in_stage) blds16(vo, wr, so0 + i * TPI * Cout * Cin * 2, base + i * 4096);
             }
         };
         TR(2);
@@ -516,6 +539,7 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
                     else if (c0 + CINC < Cin) issue_w(c0 + CINC, 0, wb ^ 1);
                 }
                 TR(23);
+                if (dbg & 8) continue;
                 const unsigned char* wsb = smem_raw + HBYTES + wb * WBYTES + b_row;
 #pragma unroll
                 for (int tp = 0; tp < TPSD; ++tp) {                                                    // kh = tp / 3, kw = tp % 3
@@ -554,7 +578,8 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
         u32x4 wreg[PW];
         auto load_w = [&](int st, int slot) {
             const int row = tid >> 1, piece = tid & 1;        // row = tap_in_stage * NB + co
-            const int tap = st * TPS + row / NB, co = n0 + row % NB, ci = c0 + piece * 8;
+            const int col = row % NB;
+            const int tap = st * TPS + row / NB, co = n0 + (PERM ? 2 * (col & 31) + (col >> 5) : col), ci = c0 + piece * 8;
             u32x4 v = {0u, 0u, 0u, 0u};
             if (tid < NPIECE && co < Cout && ci < Cin && !(dbg & 1))
                 v = *reinterpret_cast<const u32x4*>(w + ((size_t)tap * Cout + co) * Cin + ci);
@@ -629,40 +654,79 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     }   // register-staged form
 
     // ---- epilogue: NDHWC store (fp32, or bf16 as channel-pair dwords) + BatchNorm statistic partials ----
+    // bf16 outputs: buffer stores — the lane part of the address is one VGPR per (M-tile, w pair), the plane travels in the
+    // scalar offset, a lane outside the volume or beyond Cout carries an out-of-range offset and is dropped by the hardware.
+    // Per stored dword: NT = 2 one v_cvt_pk (the lane holds both channels of the pair, PERM); NT = 1 one v_cvt_pk of the
+    // lane's planes (d, d + 1), one DPP move from the neighbouring channel and one v_perm — the even lane stores plane d,
+    // the odd one plane d + 1.  (Before: ≈ 15 vector instructions and a ds_bpermute per dword.)
     TR(30);
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
     float* zb = reinterpret_cast<float*>(z_) + (OUT16 ? 0 : (size_t)b * D * H * W * Cout);
     u16* zb16 = reinterpret_cast<u16*>(z_) + (OUT16 ? (size_t)b * D * H * W * Cout : 0);
-    auto epilogue = [&](auto full_c) {
-        constexpr bool FULL = decltype(full_c)::value;
+    auto epilogue = [&](auto full_c, auto stats_c) {
+        constexpr bool FULL = decltype(full_c)::value, STATS = decltype(stats_c)::value;
+        if constexpr (OUT16) {
+            constexpr int OOB16 = 0x7FFFFFF0;
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb16, 0, D * H * W * Cout * 2, 0x00020000);
+            const int plane = H * W * Cout * 2;                               // bytes
+            const int odd = lane & 1;
+            const int co = PERM ? n0 + 2 * l31 : n0 + (l31 & ~1);             // first channel of the stored pair
+            const int gh = h0 + wave;
+            const unsigned sel = odd ? 0x03020706u : 0x05040100u;             // v_perm: (other.hi, own.hi) | (own.lo, other.lo)
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            if constexpr (OUT16) {
-                const int odd = lane & 1;
+            for (int m = 0; m < 2; ++m) {
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    const int gh = h0 + wave, gw = w0 + 2 * (r >> 2) + hsel;
-                    const int dA = d0 + 4 * m + (r & 3);                      // plane of accumulator row r (r + 1: dA + 1)
-                    const int gd = dA + odd;                                  // the row this lane stores
-                    const bool pv = FULL || (gd < D && gh < H && gw < W);
-                    const int off = ((gd * H + gh) * W + gw) * Cout;
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int gw = w0 + 2 * q4 + hsel;
+                    const bool lane_ok = FULL || (gh < H && gw < W && co < Cout);
+                    const int vo = ((gh * W + gw) * Cout + co) * 2;
+                    if constexpr (PERM) {
+                        const int vof = lane_ok ? vo : OOB16;
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) {
-                        const int co = n0 + j * 32 + l31;
-                        const float a = acc[m][j][r], bq = acc[m][j][r + 1];
-                        const float other = __shfl_xor(odd ? a : bq, 1);
-                        const unsigned int pk = odd ? pack_bf16(other, bq) : pack_bf16(a, other);
-                        if ((FULL || (pv && co < Cout)) && !(dbg & 16))
-                            *reinterpret_cast<unsigned int*>(zb16 + off + (co & ~1)) = pk;
-                        const bool va = FULL || (dA < D && gh < H && gw < W && co < Cout);
-                        const bool vb = FULL || (dA + 1 < D && gh < H && gw < W && co < Cout);
-                        if (va) { s1[j] += a; s2[j] += a * a; }
-                        if (vb) { s1[j] += bq; s2[j] += bq * bq; }
+                        for (int pd = 0; pd < 4; ++pd) {
+                            const int r = q4 * 4 + pd, gd = d0 + 4 * m + pd;
+                            const bool d_ok = FULL || gd < D;                 // wave-uniform
+                            float v0 = acc[m][0][r], v1 = acc[m][NT - 1][r];
+                            if (d_ok && !(dbg & 16)) __builtin_amdgcn_raw_buffer_store_b32(pack_bf16(v0, v1), zr, vof, gd * plane, 0);
+                            if constexpr (STATS) {
+                                if (!FULL) { v0 = (lane_ok && d_ok) ? v0 : 0.f; v1 = (lane_ok && d_ok) ? v1 : 0.f; }
+                                s1[0] += v0; s2[0] += v0 * v0;
+                                s1[NT - 1] += v1; s2[NT - 1] += v1 * v1;
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            const bool lane_okj = FULL || (lane_ok && co + j * 32 < Cout);
+#pragma unroll
+                            for (int pd = 0; pd < 4; pd += 2) {
+                                const int r = q4 * 4 + pd, gd = d0 + 4 * m + pd;      // this lane stores plane gd + odd
+                                float a = acc[m][j][r], bq = acc[m][j][r + 1];
+                                const unsigned own = pack_bf16(a, bq);
+                                const unsigned oth = (unsigned)__builtin_amdgcn_mov_dpp((int)own, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                                const unsigned pk = __builtin_amdgcn_perm(oth, own, sel);
+                                int vof = vo + j * 64 + odd * plane;
+                                if (!FULL) vof = (lane_okj && gd + odd < D) ? vof : OOB16;
+                                if ((FULL || gd < D) && !(dbg & 16)) __builtin_amdgcn_raw_buffer_store_b32(pk, zr, vof, gd * plane, 0);
+                                if constexpr (STATS) {
+                                    if (!FULL) {
+                                        const bool cv = gh < H && gw < W && n0 + j * 32 + l31 < Cout;
+                                        a = (cv && gd < D) ? a : 0.f;
+                                        bq = (cv && gd + 1 < D) ? bq : 0.f;
+                                    }
+                                    s1[j] += a; s2[j] += a * a;
+                                    s1[j] += bq; s2[j] += bq * bq;
+                                }
+                            }
+                        }
                     }
                 }
-            } else {
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int gd = d0 + 4 * m + (r & 3), gh = h0 + wave, gw = w0 + 2 * (r >> 2) + hsel;
@@ -682,8 +746,16 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
             }
         }
     };
-    if (d0 + TD <= D && h0 + TH <= H && w0 + TW <= W && n0 + NB <= Cout) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    {
+        const bool full = d0 + TD <= D && h0 + TH <= H && w0 + TW <= W && n0 + NB <= Cout;
+        if (stat_partial != nullptr) {
+            if (full) epilogue(std::true_type{}, std::true_type{});
+            else epilogue(std::false_type{}, std::true_type{});
+        } else {
+            if (full) epilogue(std::true_type{}, std::false_type{});
+            else epilogue(std::false_type{}, std::false_type{});
+        }
+    }
     TR(31);
 
     if (stat_partial != nullptr) {
@@ -696,8 +768,9 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
         if (hsel == 0) {
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-                red[(wave * NB + j * 32 + l31) * 2 + 0] = s1[j];
-                red[(wave * NB + j * 32 + l31) * 2 + 1] = s2[j];
+                const int cr = PERM ? 2 * l31 + j : j * 32 + l31;            // channel of (tile j, lane) inside the workgroup's tile
+                red[(wave * NB + cr) * 2 + 0] = s1[j];
+                red[(wave * NB + cr) * 2 + 1] = s2[j];
             }
         }
         __syncthreads();
@@ -1538,8 +1611,8 @@ extern "C" int tmf_conv3d_fwd_bf16_t(const void* x, const void* w_bf16, void* z,
     TMF_REQUIRE(cin % 8 == 0, TMF_E_SHAPE, "tmf_conv3d_fwd_bf16: cin=%d must be a multiple of 8", cin);
     TMF_REQUIRE(io >= 0 && io <= 3, TMF_E_ARG, "tmf_conv3d_fwd_bf16: io mode %d", io);
     TMF_REQUIRE(!(io & 2) || cout % 2 == 0, TMF_E_SHAPE, "tmf_conv3d_fwd_bf16: a bf16 output needs an even cout (%d)", cout);
-    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 31), TMF_E_SHAPE,
-                "tmf_conv3d_fwd_bf16: one sample exceeds 2^31 elements");
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 30), TMF_E_SHAPE,
+                "tmf_conv3d_fwd_bf16: one sample exceeds 2^30 elements (32-bit byte offsets inside a sample)");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w_bf16); TMF_REQUIRE_ALIGNED(z);
     int rc;
     hipStream_t s = (hipStream_t)stream;
