@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
     a = ap.parse_args()
+    print("library:", os.environ.get("TMF_LIB", "in-tree"))
     variants = [int(v) for v in a.dbg.split(",")]
     dev = "cuda:0"
     tot = {v: 0.0 for v in variants}

@@ -423,12 +423,14 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
     const int b_lane = l31 * RP + hsel * 8;
 
     f32x16 acc[2][NT];
+    if (!DMA || (dbg & 8)) {                                  // (the DMA form's first products start from the literal 0)
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < 2; ++m)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+                for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+    }
 
     const float* xb = reinterpret_cast<const float*>(x_) + (IN16 ? 0 : (size_t)b * D * H * W * Cin);
     const u16* xb16 = reinterpret_cast<const u16*>(x_) + (IN16 ? (size_t)b * D * H * W * Cin : 0);
@@ -521,9 +523,11 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
         TR(2);
         if (wrole) issue_w(0, 0, 0);
         TR(3);
-        int par = 0;                                           // parity of the chunk index: 3 stages flip the weight ring
-        for (int c0 = 0; c0 < Cin; c0 += CINC, par ^= 1) {
-            if (c0 > 0) __syncthreads();                       // the halo of the previous chunk is read out
+        // one 16-channel chunk; FIRST: the very first product of every accumulator takes the literal 0 as its addend (no
+        // 32 / 64 zeroing moves per brick: every instruction of every wave is paid in SIMD issue time here)
+        auto chunk = [&](int c0, int par, auto first_c) {      // par: parity of the chunk index, 3 stages flip the weight ring
+            constexpr bool FIRST = decltype(first_c)::value;
+            if (!FIRST) __syncthreads();                       // the halo of the previous chunk is read out
             TR(10);
             if (!wrole) { issue_h(c0); TR(11); dma_wait(); TR(12); }
 #pragma unroll
@@ -541,20 +545,46 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
                 TR(23);
                 if (dbg & 8) continue;
                 const unsigned char* wsb = smem_raw + HBYTES + wb * WBYTES + b_row;
-#pragma unroll
-                for (int tp = 0; tp < TPSD; ++tp) {                                                    // kh = tp / 3, kw = tp % 3
+                // software pipeline over the 9 taps: the fragments of tap tp + 1 are requested BEFORE the products of tap tp
+                // are issued (left to the compiler a fragment was requested one product ahead of its use and every product
+                // had its own s_waitcnt: the waves of a SIMD then sit out the LDS latency together)
+                struct Frag { bf16x8 a0, a1, b[NT]; };
+                auto load = [&](int tp, Frag& f) {                                                     // kh = tp / 3, kw = tp % 3
                     const unsigned char* ap = smem_raw + ((st * HH + tp / 3) * HW + tp % 3) * 32 + a_kd[st];   // kd = st
-                    const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap);
-                    const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + MT2B);
+                    f.a0 = *reinterpret_cast<const bf16x8*>(ap);
+                    f.a1 = *reinterpret_cast<const bf16x8*>(ap + MT2B);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) f.b[j] = *reinterpret_cast<const bf16x8*>(wsb + (tp * NB + j * 32) * 32);
+                };
+                auto mul = [&](const Frag& f, bool zero_c) {
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
-                        const bf16x8 bb = *reinterpret_cast<const bf16x8*>(wsb + (tp * NB + j * 32) * 32);
-                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, bb, acc[0][j], 0, 0, 0);
-                        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, bb, acc[1][j], 0, 0, 0);
+                        if (zero_c) {
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0, f.b[j], zero, 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1, f.b[j], zero, 0, 0, 0);
+                        } else {
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a0, f.b[j], acc[0][j], 0, 0, 0);
+                            acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a1, f.b[j], acc[1][j], 0, 0, 0);
+                        }
                     }
+                };
+                Frag f0, f1;
+                load(0, f0);
+#pragma unroll
+                for (int tp = 0; tp < TPSD; tp += 2) {
+                    if (tp + 1 < TPSD) load(tp + 1, f1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mul(f0, FIRST && st == 0 && tp == 0);
+                    if (tp + 2 < TPSD) load(tp + 2, f0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tp + 1 < TPSD) mul(f1, false);
                 }
             }
-        }
+        };
+        chunk(0, 0, std::true_type{});
+        int par = 1;
+        for (int c0 = CINC; c0 < Cin; c0 += CINC, par ^= 1) chunk(c0, par, std::false_type{});
     } else {
     // halo pieces of 16 B: bf16 tensors 2 per position (8 channels each), fp32 tensors 4 per position (4 channels each)
     constexpr int PPP = IN16 ? 2 : 4;                         // pieces per position
