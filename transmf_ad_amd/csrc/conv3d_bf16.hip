@@ -1375,22 +1375,34 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_tr_kernel(
         drel[i] = ((vd * H + vh) * W + vw) * Cout + ch;
         doh[i] = ch < Cout ? ((1u << vd) | (1u << (8 + vh)) | (1u << (20 + vw))) : 0x80000000u;
     }
-    struct Origin { size_t vox; unsigned xmask, dmask; };
+    struct Origin { size_t vox; int b, vin; unsigned xmask, dmask; };   // vox = b * D H W + vin
     auto bits = [](int lo, int hi) { return hi > lo ? ((1u << hi) - 1u) & ~((1u << lo) - 1u) : 0u; };   // bits lo .. hi-1
     auto imin = [](int a_, int b_) { return a_ < b_ ? a_ : b_; };
-    auto origin = [&](int tile) {
-        int tt = tile;
-        const int tw = tt % tilesW; tt /= tilesW;
-        const int th = tt % tilesH; tt /= tilesH;
-        const int td = tt % tilesD;
-        const int b = tt / tilesD;
-        const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+    // The bricks of a workgroup are tile_begin, + tile_step, ...: their coordinates advance incrementally (the step's own
+    // (b, d, h, w) digits with carries) — three runtime divisions per brick were ~100 scalar instructions, and a scalar
+    // instruction costs a SIMD about as much issue time as a vector one.  origin_next() returns the cursor's
+    // brick and advances the cursor; both staging forms ask for the bricks strictly in order.
+    int cw, ch, cd, cb, sw, sh, sd, sb;
+    {
+        int tt = tile_begin;
+        cw = tt % tilesW; tt /= tilesW; ch = tt % tilesH; tt /= tilesH; cd = tt % tilesD; cb = tt / tilesD;
+        tt = tile_step;
+        sw = tt % tilesW; tt /= tilesW; sh = tt % tilesH; tt /= tilesH; sd = tt % tilesD; sb = tt / tilesD;
+    }
+    auto origin_next = [&]() {
+        const int d0 = cd * TD, h0 = ch * TH, w0 = cw * TW;
         Origin o;
-        o.vox = (((size_t)b * D + d0) * H + h0) * W + w0;
+        o.vox = (((size_t)cb * D + d0) * H + h0) * W + w0;
+        o.b = cb;
+        o.vin = (d0 * H + h0) * W + w0;
         // halo coordinate q is voxel origin + q - 1: inside the volume for 1 - origin <= q < extent - origin + 1
         o.xmask = bits(d0 ? 0 : 1, imin(HD, D - d0 + 1)) | (bits(h0 ? 0 : 1, imin(HH, H - h0 + 1)) << 8) |
                   (bits(w0 ? 0 : 1, imin(HW, W - w0 + 1)) << 20);
         o.dmask = bits(0, imin(TD, D - d0)) | (bits(0, imin(TH, H - h0)) << 8) | (bits(0, imin(TW, W - w0)) << 20);
+        cw += sw; if (cw >= tilesW) { cw -= tilesW; ++ch; }
+        ch += sh; if (ch >= tilesH) { ch -= tilesH; ++cd; }
+        cd += sd; if (cd >= tilesD) { cd -= tilesD; ++cb; }
+        cb += sb;
         return o;
     };
     auto x_ok = [&](const Origin& o, int i) { return (xoh[i] & o.xmask) == xoh[i]; };
@@ -1464,28 +1476,45 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_tr_kernel(
         // while brick n is multiplied; the barrier at the end of the brick waits for it.
         const u16* xg = reinterpret_cast<const u16*>(x_);
         const u16* dg = reinterpret_cast<const u16*>(dz_);
-        auto issue = [&](int tile, int buf) {
+        // Copies through buffer resources (blds16): the per-thread byte offsets xvo / dvo are fixed for the whole kernel, a
+        // brick contributes one scalar offset per tensor, and a chunk outside the volume (or past the channels) takes the
+        // out-of-range offset, which the hardware answers with zeros: and + compare + select per copy instead of a 64-bit
+        // address, a pointer select against a zero block and the exec juggling around it.  The x resource starts one halo
+        // margin AHEAD of the tensor (the first brick's halo offsets are negative; those chunks are masked anyway).
+        constexpr int OOBV = 0x7FFFFFF0;
+        const int xmargin = (H * W + W + 1) * Cin;                                   // elements
+        int xvo[XQ], dvo[DQ];
+#pragma unroll
+        for (int i = 0; i < XQ; ++i) xvo[i] = (xoh[i] & 0x80000000u) ? OOBV : (xrel[i] + xmargin) * 2;
+#pragma unroll
+        for (int i = 0; i < DQ; ++i) dvo[i] = (doh[i] & 0x80000000u) ? OOBV : drel[i] * 2;
+        const size_t sample_x = (size_t)D * H * W * Cin, sample_d = (size_t)D * H * W * Cout;
+        auto issue = [&](int buf) {
             if (dbg & 1) return;
-            const Origin o = origin(tile);
+            const Origin o = origin_next();
             const unsigned wbase = __builtin_amdgcn_readfirstlane(lds_addr(smem_raw) + buf * BUFB + wave * 1024);   // this wave's 64 chunks of pass 0
-            const size_t xo = o.vox * Cin, dzo = o.vox * Cout;
+            const size_t vs = (size_t)o.b;                                          // the brick's sample (scalar)
+            const int vin = o.vin;                                                   // its origin voxel inside the sample
+            const i32x4 xr = make_rsrc(xg + vs * sample_x - xmargin, (unsigned)((sample_x + 2 * (size_t)xmargin) * 2));
+            const i32x4 dr = make_rsrc(dg + vs * sample_d, (unsigned)(sample_d * 2));
+            const int xso = vin * Cin * 2, dso = vin * Cout * 2;
 #pragma unroll
             for (int i = 0; i < XQ; ++i) {
-                const void* src = x_ok(o, i) ? (const void*)(xg + (ptrdiff_t)xo + xrel[i]) : (const void*)tmf_zero16;
-                if (tid + i * NTHR < XCH) glds16(src, wbase + i * (NTHR * 16));
+                const int vo = x_ok(o, i) ? xvo[i] : OOBV;
+                if ((i + 1) * NTHR <= XCH || tid + i * NTHR < XCH) blds16(vo, xr, xso, wbase + i * (NTHR * 16));
             }
 #pragma unroll
             for (int i = 0; i < DQ; ++i) {
-                const void* src = dz_ok(o, i) ? (const void*)(dg + (ptrdiff_t)dzo + drel[i]) : (const void*)tmf_zero16;
-                glds16(src, wbase + XB + i * (NTHR * 16));
+                const int vo = dz_ok(o, i) ? dvo[i] : OOBV;
+                blds16(vo, dr, dso, wbase + XB + i * (NTHR * 16));
             }
         };
         int cur = 0;
-        if (tile_begin < tile_end) issue(tile_begin, 0);
+        if (tile_begin < tile_end) issue(0);
         dma_wait();
         __syncthreads();
         for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
-            mma(cur, [&]() { if (tile + tile_step < tile_end) issue(tile + tile_step, cur ^ 1); });
+            mma(cur, [&]() { if (tile + tile_step < tile_end) issue(cur ^ 1); });
             dma_wait();                          // this wave's copies of brick n+1 have landed ...
             if (!(dbg & 8)) __syncthreads();     // ... and so have everybody else's
             cur ^= 1;
@@ -1503,8 +1532,8 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_tr_kernel(
             const float4 b_ = *reinterpret_cast<const float4*>(p8 + 4);
             return u32x4{pack_bf16(a.x, a.y), pack_bf16(a.z, a.w), pack_bf16(b_.x, b_.y), pack_bf16(b_.z, b_.w)};
         };
-        auto fetch = [&](int tile) {
-            const Origin o = origin(tile);
+        auto fetch = [&]() {
+            const Origin o = origin_next();
             const size_t xo = o.vox * Cin, dzo = o.vox * Cout;
 #pragma unroll
             for (int i = 0; i < XQ; ++i) xr[i] = load8(xg + (ptrdiff_t)xo + xrel[i], x_ok(o, i));
@@ -1521,16 +1550,16 @@ __global__ __launch_bounds__(NTHR) void conv3d_wgrad_bf16_tr_kernel(
         };
         int cur = 0;
         if (tile_begin < tile_end) {
-            fetch(tile_begin);
+            fetch();
             commit(0);
-            if (tile_begin + tile_step < tile_end) fetch(tile_begin + tile_step);
+            if (tile_begin + tile_step < tile_end) fetch();
         }
         __syncthreads();
         for (int tile = tile_begin; tile < tile_end; tile += tile_step) {
             const bool more = tile + tile_step < tile_end;
             auto stage = [&]() {
                 commit(cur ^ 1);
-                if (tile + 2 * tile_step < tile_end) fetch(tile + 2 * tile_step);
+                if (tile + 2 * tile_step < tile_end) fetch();
             };
             if (pair == 0 && more) stage();
             mma(cur, []() {});
