@@ -359,25 +359,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 // ---------------------------------------------------------------------------------
 // finalize kernels (tiny)
 // ---------------------------------------------------------------------------------
-// One thread's share of a channel's column of partials (rows threadIdx.x, + blockDim.x, ...), summed in row order.  The rows
-// are 8 C bytes apart, so every load is its own L2 round trip: eight rows are requested before the first is added (a rolled
-// loop waited for them one by one — 16 round trips at 4096 bricks made these launches 8-11 us each, 28 of them per step).
-__device__ __forceinline__ void stat_column_sum(const float* __restrict__ part, int nblk, int C, int c, double& s1, double& s2) {
-    const int step = blockDim.x;
-    for (int i = threadIdx.x; i < nblk; i += 8 * step) {
-        float a[8], b[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const bool ok = i + q * step < nblk;
-            a[q] = ok ? part[((size_t)(i + q * step) * 2 + 0) * C + c] : 0.f;
-            b[q] = ok ? part[((size_t)(i + q * step) * 2 + 1) * C + c] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            if (i + q * step < nblk) { s1 += (double)a[q]; s2 += (double)b[q]; }
-    }
-}
-
 __global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int C, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    const float* __restrict__ conv_bias, float* __restrict__ rmean,
@@ -386,7 +367,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nblk, int
                                    float* __restrict__ scale, float* __restrict__ shift) {
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    stat_column_sum(part, nblk, C, c, s1, s2);
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        s1 += (double)part[((size_t)i * 2 + 0) * C + c];
+        s2 += (double)part[((size_t)i * 2 + 1) * C + c];
+    }
     __shared__ double r1[256], r2[256];
     r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
     __syncthreads();
@@ -431,7 +415,10 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nblk,
                                        float* __restrict__ coef) {
     const int c = blockIdx.x;
     double s1 = 0.0, s2 = 0.0;
-    stat_column_sum(part, nblk, C, c, s1, s2);
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        s1 += (double)part[((size_t)i * 2 + 0) * C + c];
+        s2 += (double)part[((size_t)i * 2 + 1) * C + c];
+    }
     __shared__ double r1[256], r2[256];
     r1[threadIdx.x] = s1; r2[threadIdx.x] = s2;
     __syncthreads();
