@@ -612,7 +612,7 @@ int conv_waves() {
     if (g_conv_waves == 0) {
         const char* e = getenv("TMF_CONV_WAVES");
         const int v = e ? atoi(e) : 0;
-        g_conv_waves = (v == 4 || v == 2 || v == 8 || v == 1) ? v : 16;
+        g_conv_waves = (v == 4 || v == 2 || v == 8) ? v : 16;
     }
     return g_conv_waves;
 }
@@ -657,7 +657,6 @@ FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks) {
         if (c64 < 0.9 * c128) { p.cfg = 11; nb = 64; }
     }
     if (half_brick) { p.cfg += 6; th = 4; }
-    else if (p.cinc == 32 && conv_waves() == 1 && p.cfg < 2) { p.cinc = 16; }      // experiment: 4 waves x 2 M-tiles, 16-channel chunks
     else if (p.cinc == 32 && conv_waves() == 16 && p.cfg < 2) { p.cfg += 8; p.cinc = 16; }
     else if (p.cinc == 32 && conv_waves() >= 8 && p.cfg < 11) p.cfg += 3;
     else if (p.cinc == 32 && conv_waves() == 2) {
@@ -1335,7 +1334,7 @@ C1Plan plan_c1(int B, int D, int H, int W, int cout) {
 extern "C" int tmf_set_option(const char* name, int value) {
     TMF_REQUIRE_PTR(name);
     if (strcmp(name, "conv_waves") == 0) {
-        TMF_REQUIRE(value == 4 || value == 8 || value == 2 || value == 16 || value == 1, TMF_E_ARG,
+        TMF_REQUIRE(value == 4 || value == 8 || value == 2 || value == 16, TMF_E_ARG,
                     "tmf_set_option: conv_waves must be 2, 4, 8 or 16, got %d", value);
         g_conv_waves = value;
         return TMF_OK;
