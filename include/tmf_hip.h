@@ -49,7 +49,10 @@ extern "C" {
 int         tmf_version(void);                 /* ABI version, currently 1 */
 const char* tmf_last_error_string(void);
 /* Process-wide tuning knobs (never change results).  "conv_waves" = 2 | 4 | 8 | 16: workgroup shape of the
- * convolution kernels (16, the default: two 8-wave workgroups per CU).  "bf16_v2" = 0 | 1 | 2:
+ * convolution kernels (16, the default: two 8-wave workgroups per CU).  "conv_rt" = 0 | 1 | 2: the register-tiled fp32
+ * forward / data-gradient kernel (6x6x12 bricks, csrc/conv3d_mfma.hip conv3d_fwd_rt_kernel) never (default) / for volumes of
+ * at most 24^3 voxels that its bricks tile exactly, cin and cout multiples of 16 / wherever the bricks fit (results equal
+ * up to fp32 summation order; tmf_conv3d_stat_blocks and tmf_conv3d_fwd_kernel_name follow the choice).  "bf16_v2" = 0 | 1 | 2:
  * bf16 forward / data-gradient kernel with 8x8x8 bricks and 2 x 2 register tiles never / by brick count (default) /
  * always (results equal up to fp32 summation order; tmf_conv3d_bf16_stat_blocks follows the choice).  "wgrad_tr" = 0 | 1 | 2:
  * bf16 weight-gradient kernel with LDS transposing reads never / where it is the faster one (default) / wherever its

@@ -102,6 +102,60 @@ def test_conv3d_wgrad_and_dgrad(shape):
         assert _relerr(_ncdhw(dx.cpu()), x.grad) < 1e-5
 
 
+RT_SHAPES = [
+    # volumes the 6 x 6 x 12 bricks of the register-tiled forward kernel tile exactly: B, D, H, W, cin, cout
+    (1, 6, 6, 12, 16, 16),            # one brick, one 16-channel tile (RtCfg<1>)
+    (2, 12, 6, 24, 32, 48),           # 48 output channels: 16-channel workgroups
+    (1, 12, 12, 12, 128, 256),        # the model's 12^3 layer: 8 chunks
+    (8, 24, 24, 24, 64, 64),          # 256 bricks x 2: RtCfg<2>, the model's 24^3 layer
+    (2, 18, 12, 36, 16, 32),
+]
+
+
+@pytest.mark.parametrize("shape", RT_SHAPES)
+def test_register_tiled_conv_matches_fp64_and_the_ring_kernel(shape):
+    """The register-tiled forward / data-gradient kernel (conv3d_fwd_rt_kernel: 6x6x12 bricks, 7 x NT tiles of
+    v_mfma_f32_16x16x4_f32 per wave) against fp64 — z, the BatchNorm statistic partials, the data gradient through the same
+    kernel — and against the ring kernel on the same inputs (tmf_set_option("conv_rt", 0)): same sums up to fp32 order."""
+    ops = _ops()
+    from transmf_ad_amd import _lib
+    B, D, H, W, cin, cout = shape
+    x = _rand(B, cin, D, H, W, seed=11)
+    w = _rand(cout, cin, 3, 3, 3, seed=12, scale=(cin * 27) ** -0.5)
+    ref = F.conv3d(x.double(), w.double(), padding=1)
+    xg, wp = _ndhwc(x).to(DEV), ops.pack_weight(w.to(DEV))
+    try:
+        _lib.call("tmf_set_option", b"conv_rt", 1)
+        assert _lib.query("tmf_conv3d_fwd_kernel_name", B, D, H, W, cin, cout, 3).decode().startswith("RtCfg")
+        z, part, nblk = ops.conv3d_raw(xg, wp, cin, cout, 3, True)
+        assert nblk == B * (D // 6) * (H // 6) * (W // 12)
+        _lib.call("tmf_set_option", b"conv_rt", 0)
+        assert not _lib.query("tmf_conv3d_fwd_kernel_name", B, D, H, W, cin, cout, 3).decode().startswith("RtCfg")
+        z0, part0, _ = ops.conv3d_raw(xg, wp, cin, cout, 3, True)
+        _lib.call("tmf_set_option", b"conv_rt", 2)
+        torch.cuda.synchronize()
+        assert _relerr(_ncdhw(z.cpu()), ref) < 1e-5
+        assert (z - z0).abs().max().item() <= 2e-5 * ref.abs().max().item()
+        s = part.double().sum(0).cpu()
+        r = ref.permute(1, 0, 2, 3, 4).reshape(cout, -1)
+        assert (s[0] - r.sum(1)).abs().max() <= 1e-4 * max(1.0, r.abs().sum(1).max().item())
+        assert (s[1] - (r * r).sum(1)).abs().max() <= 1e-5 * (r * r).sum(1).max().item()
+        # the statistic partials are those of the z the kernel stored
+        zc = z.double().reshape(-1, cout)
+        assert (part.double().sum(0)[0] - zc.sum(0)).abs().max().item() <= 1e-4 * max(1.0, zc.abs().sum(0).max().item())
+        # data gradient through the same kernel; and run to run bitwise
+        dz = _rand(B, cout, D, H, W, seed=13)
+        xr = x.double().requires_grad_(True)
+        F.conv3d(xr, w.double(), padding=1).backward(dz.double())
+        wd = ops.pack_weight_dgrad(w.to(DEV))
+        dx, _, _ = ops.conv3d_raw(_ndhwc(dz).to(DEV), wd, cout, cin, 3, False)
+        assert _relerr(_ncdhw(dx.cpu()), xr.grad) < 1e-5
+        z2, part2, _ = ops.conv3d_raw(xg, wp, cin, cout, 3, True)
+        assert torch.equal(z2, z) and torch.equal(part2, part)
+    finally:
+        _lib.call("tmf_set_option", b"conv_rt", 0)
+
+
 def test_mfma_layout_is_transpose_sensitive():
     """A = I-like probe with an asymmetric weight: catches swapped rows/columns of the MFMA fragments."""
     ops = _ops()
@@ -258,7 +312,7 @@ def test_eval_block_single_pass(case):
     if yr.numel() == 0:
         return
     assert _relerr(_ncdhw(y1.cpu()), yr.detach()) < 2e-5
-    assert _relerr(y1, y2.cpu()) < 2e-6
+    assert _relerr(y1, y2.cpu()) < 5e-6       # (with conv_rt on, the two-pass path runs another fp32 summation order, K up to 3456)
 
 
 def test_two_blocks_with_bf16_activation_storage(bf16_kernel_choice):

@@ -129,6 +129,22 @@ def test_train_step_matches_reference_golden_fp32x(name):
         T.set_conv_precision("fp32")
 
 
+@pytest.mark.parametrize("name", ["ad_mid", "ad_full_b2_blobs", "cnn_full_b2", "single_full_b2"])
+def test_train_step_matches_reference_golden_with_register_tiled_conv(name):
+    """tmf_set_option("conv_rt", 1): the pooled 24^3 / 12^3 layers' forward and data-gradient convolutions run the opt-in
+    register-tiled kernel (6x6x12 bricks, another fp32 summation order): the SAME golden comparison at the SAME tolerances."""
+    from transmf_ad_amd import _lib
+    _lib.call("tmf_set_option", b"conv_rt", 1)
+    try:
+        g = Golden(name) if available(name) else None
+        if g is not None:
+            s = g.size[0] // 4
+            assert _lib.query("tmf_conv3d_fwd_kernel_name", g.batch, s, s, s, 64, 64, 3).decode().startswith("RtCfg") == (s % 12 == 0)
+        _golden_train_step(name)
+    finally:
+        _lib.call("tmf_set_option", b"conv_rt", 0)
+
+
 def _golden_train_step(name):
     if not available(name):
         pytest.skip("fixture not generated")

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--opt", default="conv_waves", help="the tmf_set_option name the variants are values of (conv_waves, conv_rt)")
     a = ap.parse_args()
     variants = [int(v) for v in a.waves.split(",")]
     dev = "cuda:0"
@@ -42,7 +43,7 @@ def main():
             best = {v: 1e9 for v in variants}
             for _ in range(a.rounds):
                 for v in variants:
-                    _lib.call("tmf_set_option", b"conv_waves", v)
+                    _lib.call("tmf_set_option", a.opt.encode(), v)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     for i in range(a.reps + 2):
                         if i == 2:
@@ -57,6 +58,7 @@ def main():
             print(f"{name:8s} {what:5s} " + "  ".join(f"w{v}: {best[v] * 1e3:7.1f} us {flop / best[v] / 1e9 / 157.3:5.3f}" for v in variants),
                   flush=True)
     _lib.call("tmf_set_option", b"conv_waves", 16)
+    _lib.call("tmf_set_option", b"conv_rt", 0)
 
 
 if __name__ == "__main__":

@@ -587,6 +587,258 @@ __global__ __launch_bounds__(C::NTHR, C::MIN_WAVES) void conv3d_fwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------
+// forward / dgrad, REGISTER-TILED form (round 3): 6x6x12 bricks, 7 x NT tiles of 16x16 per wave
+// ------------------------------------------------------------------------------------
+// Why a second form.  (i) Balance: the pooled volumes are 27 * 2^k bricks of any power-of-two size, so a launch of the
+// ring kernel above fills 27/32 of its last workgroup round at 24^3 and 12^3 whatever brick is chosen (0.76 / 0.70 of
+// the peak in isolation against 0.86 at 48^3).  432-voxel bricks (6 x 6 x 12) divide 48^3, 24^3 and 12^3 into 2048 / 256 /
+// 32 bricks per batch of 8 — multiples of the chip's 256 CUs — and a brick is 27 M-tiles of 16 voxels, 28 with one tile
+// of padding = SEVEN per wave of a 4-wave workgroup: every SIMD of a CU carries the same number of tiles (3.6 % padding
+// instead of 16 % idle).  (ii) Instructions per MFMA: beside fp32 MFMAs every LDS / vector / memory instruction of any
+// wave on the SIMD is paid in matrix time; the ring kernel issues 2.6 of them per 64-cycle MFMA.  Here a
+// wave holds a 7 x NT register tile of v_mfma_f32_16x16x4_f32 accumulators (112 x 16 NT outputs): one ds_read_b128 per
+// M-tile and one per N-tile feed 4 k-steps = 28 NT MFMAs, 0.16 operand reads per 32-cycle MFMA at NT = 2, and staging a
+// 16-channel chunk (halo 57 KB + 27 taps of weights) is amortised over 6 048 MFMAs per wave.
+//   * K order inside a 16-channel chunk: lane group g = lane >> 4 owns channels 4 g .. 4 g + 3; k-step s of a tap takes
+//     element s of every lane's 16-byte fragment (A: [g][halo position][4], B: [tap][g][co][4] in LDS) — any order is
+//     right as long as A and B agree.
+//   * weights arrive tap-major [tap][ci][co] (the ring kernel's pack): a staged 16-byte piece is 4 output channels of one
+//     input channel and is written as four dwords into the [g][co][ci % 4] image (54 dword writes per thread and chunk
+//     against 1 512 MFMAs per wave and chunk).
+//   * two 4-wave workgroups per CU (70 KB of LDS each): 2 waves per SIMD, so the kernel may use 256 registers.
+template <int NT_>
+struct RtCfg {
+    static constexpr int NT = NT_, NB = 16 * NT;
+    static constexpr int BD = 6, BH = 6, BW = 12, NVOX = BD * BH * BW;              // 432 voxels
+    static constexpr int HD = BD + 2, HH = BH + 2, HW = BW + 2, NPOS = HD * HH * HW; // 896 halo positions
+    static constexpr int CINC = 16, NG = CINC / 4;
+    static constexpr int NW = 4, NTHR = 64 * NW, MT = 7;                             // 28 M-tiles of 16 voxels
+    static constexpr int TPS = 3, NSTAGES = 9;
+    static constexpr int HALO_F = NG * NPOS * 4;                                     // floats
+    static constexpr int WST_F = TPS * NG * NB * 4;                                  // floats per weight stage
+    static constexpr int RED_F = NW * NB * 2;
+    static constexpr size_t LDS_BYTES = (size_t)(HALO_F + 2 * WST_F + RED_F) * 4;
+    static constexpr int HV = NPOS * NG / NTHR;                                      // 14 halo pieces per thread
+    static constexpr int WPIECES = TPS * CINC * (NB / 4);                            // 16-byte pieces per weight stage
+    static constexpr int WV = (WPIECES + NTHR - 1) / NTHR;                           // 2 | 1 per thread
+    static_assert(NPOS * NG % NTHR == 0, "halo pieces divide evenly");
+    static_assert(MT * NW * 16 >= NVOX, "tiles cover the brick");
+};
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <class C>
+__global__ __launch_bounds__(C::NTHR, 2) void conv3d_fwd_rt_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ z,
+    float* __restrict__ stat_partial, int D, int H, int W, int Cin, int Cout,
+    int tilesD, int tilesH, int tilesW, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* halo = smem;
+    float* Ws = smem + C::HALO_F;
+    float* red = Ws + 2 * C::WST_F;
+    constexpr int NT = C::NT, NB = C::NB, MT = C::MT, NPOS = C::NPOS, NG = C::NG;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, g = lane >> 4;
+
+    const int tile = xcd_contiguous(blockIdx.x, ntiles);
+    int t = tile;
+    const int tw = t % tilesW; t /= tilesW;
+    const int th = t % tilesH; t /= tilesH;
+    const int td = t % tilesD;
+    const int b = t / tilesD;
+    const int d0 = td * C::BD, h0 = th * C::BH, w0 = tw * C::BW;
+    const int n0 = blockIdx.y * NB;
+
+    // LDS float index of the fragment this lane feeds to its M-tile m at tap (0, 0, 0): voxel 16 (wave + 4 m) + i16 of the
+    // brick (raster d, h, w), channel group g.  Voxels past the brick (the 28th tile) read voxel 431: results dropped.
+    int a_lane[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        int v = 16 * (wave + C::NW * m) + i16;
+        v = v < C::NVOX ? v : C::NVOX - 1;
+        const int pd = v / (C::BH * C::BW), ph = (v / C::BW) % C::BH, pw = v % C::BW;
+        a_lane[m] = (g * NPOS + (pd * C::HH + ph) * C::HW + pw) * 4;
+    }
+    const int b_lane = (g * NB + i16) * 4;
+
+    f32x4v acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[m][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    const float* xb = x + (size_t)b * D * H * W * Cin;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, D * H * W * Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(w), 0, C::TPS * C::NSTAGES * Cin * Cout * 4, 0x00020000);
+    constexpr int OOB = (int)0x80000000u;
+
+    // halo pieces: e = tid + 256 q -> channel group e & 3 (fastest: a position's 64 bytes are read by 4 neighbouring
+    // lanes), position e >> 2.  Byte offset inside the sample once per brick; the chunk base travels in the scalar offset.
+    int hoff[C::HV];
+#pragma unroll
+    for (int q = 0; q < C::HV; ++q) {
+        const int e = tid + q * C::NTHR;
+        const int hp = e >> 2, gg = e & 3;
+        const int hw = hp % C::HW, hh = (hp / C::HW) % C::HH, hd = hp / (C::HW * C::HH);
+        const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+        const bool ok = gd >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W;
+        hoff[q] = ok ? (((gd * H + gh) * W + gw) * Cin + gg * 4) * 4 : OOB;
+    }
+    // weight pieces of a 3-tap stage: e -> 4 output channels co4 .. co4 + 3 of (tap tp, input channel ci)
+    int woff[C::WV], wlds[C::WV];
+#pragma unroll
+    for (int q = 0; q < C::WV; ++q) {
+        const int e = tid + q * C::NTHR;
+        const int co4 = (e % (NB / 4)) * 4, ci = (e / (NB / 4)) % C::CINC, tp = e / ((NB / 4) * C::CINC);
+        const bool ok = e < C::WPIECES && n0 + co4 < Cout;
+        woff[q] = ok ? ((tp * Cin + ci) * Cout + n0 + co4) * 4 : OOB;
+        wlds[q] = ((tp * NG + (ci >> 2)) * NB + co4) * 4 + (ci & 3);
+    }
+
+    f32x4v wreg[2][C::WV];
+    auto load_w = [&](int c0, int st, int slot) {
+        const int sbase = (st * C::TPS * Cin + c0) * Cout * 4;
+#pragma unroll
+        for (int q = 0; q < C::WV; ++q)
+            wreg[slot][q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wr, woff[q], sbase, 0));
+    };
+    auto store_w = [&](int buf, int slot) {
+        float* dst = Ws + buf * C::WST_F;
+#pragma unroll
+        for (int q = 0; q < C::WV; ++q) {
+            if (C::WPIECES % C::NTHR == 0 || tid + q * C::NTHR < C::WPIECES) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dst[wlds[q] + 4 * u] = wreg[slot][q][u];
+            }
+        }
+    };
+
+    struct Frag { f32x4v a[MT]; f32x4v b[NT]; };
+    // The halo of chunk c + 1 is requested into registers ahead of the LAST 56 MFMAs of chunk c (where one of the two fragment
+    // sets is dead: the kernel stays under 256 registers) and written to LDS behind the barrier that ends the chunk: what
+    // stays exposed per chunk is the rest of the load round trip, 14 LDS writes and a barrier.
+    f32x4v hreg[C::HV];
+    auto load_halo = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < C::HV; ++q)
+            hreg[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, hoff[q], c0 * 4, 0));
+    };
+    // AHEAD (one N-tile, 212 registers): the next chunk's halo and its first two weight stages are requested before the current
+    // chunk ends.  With two N-tiles that costs 40 bytes of scratch and 2 % of speed: everything is requested at the chunk start.
+    constexpr bool AHEAD = NT == 1;
+    if (AHEAD) { load_halo(0); load_w(0, 0, 0); load_w(0, 1, 1); }
+    for (int c0 = 0; c0 < Cin; c0 += C::CINC) {
+        if (c0 > 0) __syncthreads();                       // the previous chunk's halo is read out
+        if (!AHEAD) { load_halo(c0); load_w(c0, 0, 0); load_w(c0, 1, 1); }
+        else if (c0 > 0) {
+            // nine stages per chunk: the two weight slots change roles at every chunk boundary (both requests are a
+            // stage or more old by now)
+#pragma unroll
+            for (int q = 0; q < C::WV; ++q) { const f32x4v tmp = wreg[0][q]; wreg[0][q] = wreg[1][q]; wreg[1][q] = tmp; }
+        }
+#pragma unroll
+        for (int q = 0; q < C::HV; ++q) {
+            const int e = tid + q * C::NTHR;
+            *reinterpret_cast<f32x4v*>(halo + ((e & 3) * NPOS + (e >> 2)) * 4) = hreg[q];
+        }
+        const bool more = c0 + C::CINC < Cin;
+#pragma unroll
+        for (int st = 0; st < C::NSTAGES; ++st) {
+            store_w(st & 1, st & 1);
+            __syncthreads();
+            // weight stages run two ahead, across the chunk boundary (stage 9 / 10 = stage 0 / 1 of the next chunk)
+            if (st + 2 < C::NSTAGES) load_w(c0, st + 2, st & 1);
+            else if (AHEAD && more) load_w(c0 + C::CINC, st + 2 - C::NSTAGES, st & 1);
+            const float* wsb = Ws + (st & 1) * C::WST_F + b_lane;
+            const int kd = st / 3, kh = st % 3;
+            auto load = [&](int kw, Frag& f) {
+                const int tapoff = ((kd * C::HH + kh) * C::HW + kw) * 4;
+#pragma unroll
+                for (int m = 0; m < MT; ++m) f.a[m] = *reinterpret_cast<const f32x4v*>(halo + a_lane[m] + tapoff);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) f.b[j] = *reinterpret_cast<const f32x4v*>(wsb + (kw * NG * NB + j * 16) * 4);
+            };
+            auto mul = [&](const Frag& f) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[m][s4], f.b[j][s4], acc[m][j], 0, 0, 0);
+            };
+            Frag f0, f1;
+            load(0, f0);
+            load(1, f1);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(f0);
+            load(2, f0);
+            __builtin_amdgcn_sched_barrier(0);
+            mul(f1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (AHEAD && st == C::NSTAGES - 1 && more) load_halo(c0 + C::CINC);      // (f1's registers are free from here on)
+            mul(f0);
+        }
+    }
+
+    // ---- epilogue: NDHWC store + BatchNorm statistic partials ----
+    // D fragment: column = lane & 15 (output channel), row 4 g + r -> voxel 16 (wave + 4 m) + 4 g + r of the brick
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) s1[j] = s2[j] = 0.f;
+    float* zb = z + (size_t)b * D * H * W * Cout;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int v = 16 * (wave + C::NW * m) + 4 * g + r;
+            const int pd = v / (C::BH * C::BW), ph = (v / C::BW) % C::BH, pw = v % C::BW;
+            const int gd = d0 + pd, gh = h0 + ph, gw = w0 + pw;
+            const bool pv = v < C::NVOX && gd < D && gh < H && gw < W;
+            const int off = ((gd * H + gh) * W + gw) * Cout;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int co = n0 + j * 16 + i16;
+                if (pv && co < Cout) {
+                    const float val = acc[m][j][r];
+                    __builtin_nontemporal_store(val, &zb[off + co]);
+                    s1[j] += val;
+                    s2[j] += val * val;
+                }
+            }
+        }
+    }
+    if (stat_partial != nullptr) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            s1[j] += __shfl_xor(s1[j], 16); s1[j] += __shfl_xor(s1[j], 32);
+            s2[j] += __shfl_xor(s2[j], 16); s2[j] += __shfl_xor(s2[j], 32);
+        }
+        if (g == 0) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                red[(wave * NB + j * 16 + i16) * 2 + 0] = s1[j];
+                red[(wave * NB + j * 16 + i16) * 2 + 1] = s2[j];
+            }
+        }
+        __syncthreads();
+        if (tid < NB) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < C::NW; ++q) { a1 += red[(q * NB + tid) * 2]; a2 += red[(q * NB + tid) * 2 + 1]; }
+            const int co = n0 + tid;
+            if (co < Cout) {
+                stat_partial[((size_t)tile * 2 + 0) * Cout + co] = a1;
+                stat_partial[((size_t)tile * 2 + 1) * Cout + co] = a2;
+            }
+        }
+    }
+}
+
 template <int KS, int CINC> using CfgL32 = FwdCfg<KS, CINC, 2, 1, 4, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgL64 = FwdCfg<KS, CINC, 2, 2, 4, 1, 4, 8, 8, (KS == 3 ? 3 : 1)>;
 template <int KS, int CINC> using CfgS128 = FwdCfg<KS, CINC, 1, 2, 2, 2, 4, 4, 4, 1>;
@@ -606,6 +858,19 @@ template <int KS, int CINC> using CfgM64 = FwdCfg<KS, CINC, 1, 2, 4, 1, 4, 4, 8,
 // layers: 4 = 4 waves, 1 workgroup per CU; 8 = 8 waves (two per SIMD); 2 = 4x4x8 bricks, two 4-wave workgroups
 // per CU; 16 (default) = 8 waves with 16-channel chunks (77 KB of LDS): two 8-wave workgroups per CU, so one
 // stages / stores while the other multiplies (measured +3..7 % over 8 on the 48^3 layers)
+// tmf_set_option("conv_rt", 0 | 1 | 2) / TMF_CONV_RT: the register-tiled forward kernel never (default) / for the pooled
+// volumes / wherever its bricks fit.  Off by default: in isolation it is 9 % faster than the ring kernel at 24^3 and 12^3
+// (no 27/32 round), but the two encoder streams of a train step already fill those rounds with each other's kernels —
+// model_ad steps at 14.75 ms either way; what has ONE stream gains (model_single, B = 16: 13.73 -> 13.59 ms; model_ad
+// with TMF_STREAMS=1: 15.84 -> 15.37).  DESIGN.md 3.1.
+int g_conv_rt = -1;
+int conv_rt() {
+    if (g_conv_rt < 0) {
+        const char* e = getenv("TMF_CONV_RT");
+        g_conv_rt = e == nullptr ? 0 : (atoi(e) == 2 ? 2 : (atoi(e) == 1 ? 1 : 0));
+    }
+    return g_conv_rt;
+}
 int g_debug = 0;          // timing ablations only (tmf_set_option("debug", bits)); results are garbage when set
 int g_conv_waves = 0;
 int conv_waves() {
@@ -623,8 +888,23 @@ struct FwdPlan {
     int tilesD, tilesH, tilesW, ntiles, nby;
 };
 
-FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks) {
+FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks, bool allow_rt = true) {
     FwdPlan p;
+    // Register-tiled form (cfg 12: 32 channels per workgroup, 13: 16): volumes its 6 x 6 x 12 bricks tile exactly, channel
+    // counts in whole 16-channel chunks / tiles.  16-channel workgroups where 32-channel ones would leave CUs without one.
+    // Taken for the pooled volumes (<= 24^3 voxels per sample: +9 % over the ring kernel at 24^3 and 12^3, B = 8, measured per
+    // layer with tools/conv_ab.py --opt conv_rt); at 48^3 the ring kernel's last round is 3/8 full and cheap, and its
+    // 0.81-0.86 stands against 0.79-0.81 here.  tmf_set_option("conv_rt", 2) takes this form wherever its bricks fit.
+    const bool rt_size = conv_rt() == 2 || (long)D * H * W <= 24L * 24 * 24;
+    if (allow_rt && conv_rt() && rt_size && ks == 3 && cin % 16 == 0 && cout % 16 == 0 && D % 6 == 0 && H % 6 == 0 && W % 12 == 0) {
+        p.tilesD = D / 6; p.tilesH = H / 6; p.tilesW = W / 12;
+        p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
+        const bool nt2 = cout % 32 == 0 && (long)p.ntiles * (cout / 32) >= 512;
+        p.cfg = nt2 ? 12 : 13;
+        p.cinc = 16;
+        p.nby = cout / (nt2 ? 32 : 16);
+        return p;
+    }
     p.cinc = cin <= 8 ? 8 : (cin <= 16 ? 16 : 32);
     const int mind = D < H ? (D < W ? D : W) : (H < W ? H : W);
     int td, th, tw, nb;
@@ -699,9 +979,25 @@ int launch_fwd_cfg(const FwdPlan& p, const float* x, const float* w, float* z, f
     return tmf_launch_result("tmf_conv3d_fwd");
 }
 
+template <class C>
+int launch_fwd_rt(const FwdPlan& p, const float* x, const float* w, float* z, float* sp,
+                  int D, int H, int W, int cin, int cout, hipStream_t s) {
+    auto k = conv3d_fwd_rt_kernel<C>;
+    int rc;
+    if ((rc = tmf_allow_lds(k, C::LDS_BYTES, "tmf_conv3d_fwd"))) return rc;
+    hipLaunchKernelGGL(k, dim3(p.ntiles, p.nby), dim3(C::NTHR), C::LDS_BYTES, s, x, w, z, sp, D, H, W, cin, cout,
+                       p.tilesD, p.tilesH, p.tilesW, p.ntiles);
+    return tmf_launch_result("tmf_conv3d_fwd");
+}
+
 template <int KS>
 int launch_fwd(const FwdPlan& p, const float* x, const float* w, float* z, float* sp,
                int D, int H, int W, int cin, int cout, hipStream_t s, const Affine* aff = nullptr) {
+    if (p.cfg == 12 || p.cfg == 13) {
+        TMF_REQUIRE(aff == nullptr, TMF_E_ARG, "tmf_conv3d_fwd_affine: internal error: register-tiled plan");
+        return p.cfg == 12 ? launch_fwd_rt<RtCfg<2>>(p, x, w, z, sp, D, H, W, cin, cout, s)
+                           : launch_fwd_rt<RtCfg<1>>(p, x, w, z, sp, D, H, W, cin, cout, s);
+    }
 #define TMF_FWD_CASE(CFG, CINC)                                                                   \
     if (p.cinc == CINC) return launch_fwd_cfg<CFG<KS, CINC>>(p, x, w, z, sp, D, H, W, cin, cout, s, aff);
     if (p.cfg == 0) { TMF_FWD_CASE(CfgL32, 8) TMF_FWD_CASE(CfgL32, 16) TMF_FWD_CASE(CfgL32, 32) }
@@ -730,6 +1026,8 @@ const char* cfg_name(const FwdCfg<KS, CINC, MT, NT, WM, WN, TD, TH, TW, TPS>*) {
 }
 template <int KS>
 const char* fwd_kernel_name(const FwdPlan& p) {
+    if (p.cfg == 12) return "RtCfg<2>";
+    if (p.cfg == 13) return "RtCfg<1>";
 #define TMF_FWD_CASE(CFG, CINC) if (p.cinc == CINC) return cfg_name((const CFG<KS, CINC>*)nullptr);
     if (p.cfg == 0) { TMF_FWD_CASE(CfgL32, 8) TMF_FWD_CASE(CfgL32, 16) TMF_FWD_CASE(CfgL32, 32) }
     if (p.cfg == 1) { TMF_FWD_CASE(CfgL64, 8) TMF_FWD_CASE(CfgL64, 16) TMF_FWD_CASE(CfgL64, 32) }
@@ -1339,6 +1637,11 @@ extern "C" int tmf_set_option(const char* name, int value) {
         g_conv_waves = value;
         return TMF_OK;
     }
+    if (strcmp(name, "conv_rt") == 0) {
+        TMF_REQUIRE(value >= 0 && value <= 2, TMF_E_ARG, "tmf_set_option: conv_rt must be 0, 1 or 2, got %d", value);
+        g_conv_rt = value;
+        return TMF_OK;
+    }
     if (strcmp(name, "debug") == 0) { g_debug = value; tmf_g_debug = value; return TMF_OK; }
     if (strcmp(name, "bf16_v2") == 0) {
         TMF_REQUIRE(value >= 0 && value <= 2, TMF_E_ARG, "tmf_set_option: bf16_v2 must be 0, 1 or 2, got %d", value);
@@ -1413,7 +1716,7 @@ extern "C" int tmf_conv3d_fwd_affine(const float* x, const float* w, const float
     TMF_REQUIRE((long)ksize * ksize * ksize * cin * cout < (1L << 29), TMF_E_SHAPE, "tmf_conv3d_fwd_affine: weight tensor exceeds 2^29 elements");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w); TMF_REQUIRE_ALIGNED(y);
     if (pool != TMF_POOL_NONE && (D / 2 == 0 || H / 2 == 0 || W / 2 == 0)) return TMF_OK;      // empty output
-    const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize);
+    const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize, false);      // (the fused epilogue lives in the ring kernel)
     const Affine aff = {scale, shift, slope, pool};
     hipStream_t s = (hipStream_t)stream;
     return ksize == 3 ? launch_fwd<3>(p, x, w, y, nullptr, D, H, W, cin, cout, s, &aff)
