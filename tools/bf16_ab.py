@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=6)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--opt", default="debug", help="the tmf_set_option name the variants are values of (debug, bf16_w4)")
     a = ap.parse_args()
     print("library:", os.environ.get("TMF_LIB", "in-tree"))
     variants = [int(v) for v in a.dbg.split(",")]
@@ -38,7 +39,7 @@ def main():
             best = {v: 1e9 for v in variants}
             for _ in range(a.rounds):
                 for v in variants:
-                    _lib.call("tmf_set_option", b"debug", v)
+                    _lib.call("tmf_set_option", a.opt.encode(), v)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     for i in range(a.reps + 2):
                         if i == 2:
@@ -55,7 +56,7 @@ def main():
             print(f"{name:8s} {what:5s} " + "  ".join(f"d{v}: {best[v] * 1e3:7.1f} us {flop / best[v] / 1e9 / 2500:5.3f}" for v in variants),
                   flush=True)
     print("sum      " + "  ".join(f"d{v}: {tot[v] * 1e3:7.1f} us" for v in variants))
-    _lib.call("tmf_set_option", b"debug", 0)
+    _lib.call("tmf_set_option", a.opt.encode(), 0)
 
 
 if __name__ == "__main__":
