@@ -68,6 +68,18 @@ def test_forward_brick_choice_follows_the_occupancy_model():
     assert _lib.query("tmf_conv3d_stat_blocks", 8, 22, 27, 22, 64, 64, 3) == 8 * 6 * 7 * 3
     assert name(11, 13, 11, 128, 256) == name(11, 13, 11, 256, 128) == "FwdCfg<3, 32, 1, 1, 2, 2, 4, 4, 4, 1>"
     assert _lib.query("tmf_conv3d_stat_blocks", 8, 11, 13, 11, 128, 256, 3) == 8 * 3 * 4 * 3
+    # the opt-in register-tiled form: off by default; conv_rt = 1 takes it for volumes <= 24^3 its 6x6x12 bricks tile, 16-channel
+    # workgroups where 32-channel ones would be fewer than 512; conv_rt = 2 wherever the bricks fit; the statistics buffer follows
+    try:
+        _lib.call("tmf_set_option", b"conv_rt", 1)
+        assert name(24, 24, 24, 64, 64) == name(24, 24, 24, 64, 128) == "RtCfg<2>" and name(12, 12, 12, 128, 256) == "RtCfg<1>"
+        assert name(48, 48, 48, 32, 64) == big64 and name(22, 27, 22, 64, 64) == half and name(24, 24, 24, 64, 40) == big64
+        assert _lib.query("tmf_conv3d_stat_blocks", 8, 24, 24, 24, 64, 64, 3) == 8 * 4 * 4 * 2
+        _lib.call("tmf_set_option", b"conv_rt", 2)
+        assert name(48, 48, 48, 32, 64) == "RtCfg<2>"
+    finally:
+        _lib.call("tmf_set_option", b"conv_rt", 0)
+    assert name(24, 24, 24, 64, 64) == big64
 
 
 @pytest.mark.parametrize("name", ["ad_tiny", "cnn_tiny", "single_mid", "ad_mid"])
