@@ -1168,6 +1168,57 @@ def test_bf16_training_follows_the_fp32_trajectory(mode):
     assert dl < band_l and dc < band_c, (dl, dc)
 
 
+@pytest.mark.parametrize("kind", ["ad", "ad_drop", "cnn", "single"])
+def test_steady_state_steps_do_not_grow_device_memory(kind):
+    """63 train steps (the reference's step: zero_grad, forward, three losses, a .item() sync, backward, Adam) plus eval
+    forwards and forwards whose graph is dropped without a backward: device memory allocated after step 62 <= after step 20,
+    the early-event table of the encoder nodes stays empty without a consumer, and an abandoned forward leaves nothing behind."""
+    import gc
+    import transmf_ad_amd as T
+    from transmf_ad_amd import ops
+    torch.manual_seed(0)
+    if kind.startswith("ad"):
+        net = T.model_ad(dim=128, depth=2, heads=4, dim_head=32, mlp_dim=512, dropout=0.1 if kind == "ad_drop" else 0.0)
+    else:
+        net = T.model_CNN_ad(128) if kind == "cnn" else T.model_single(128)
+    net = net.to(DEV)
+    opt = T.optim.Adam(net.parameters(), lr=1e-4)
+    crit = nn.CrossEntropyLoss()
+    B, S = 4, 32
+    mri, pet = torch.rand((B, 1, S, S, S), device=DEV), torch.rand((B, 1, S, S, S), device=DEV)
+    y = torch.randint(0, 2, (B,), device=DEV)
+    ones, zeros = torch.ones_like(y), torch.zeros_like(y)
+
+    def fwd():
+        if kind == "single":
+            return crit(net(mri), y)
+        lo, dm, dp = net(mri, pet)
+        return crit(lo, y) + (crit(dm, ones) + crit(dp, zeros)) / 2
+
+    def one(i):
+        net.train()
+        opt.zero_grad()
+        loss = fwd()
+        loss.item()
+        loss.backward()
+        opt.step()
+        if i % 7 == 0:                      # a forward nobody differentiates, and an eval pass
+            fwd()
+            net.eval()
+            with torch.no_grad():
+                fwd()
+    marks = {}
+    for i in range(63):
+        one(i)
+        if i in (20, 62):                   # the same phase of the 7-step cycle of extra forwards
+            torch.cuda.synchronize()
+            gc.collect()
+            marks[i] = torch.cuda.memory_allocated()
+    assert marks[62] <= marks[20], marks
+    assert ops.TRACK_GRAD_EVENTS or not ops.GRAD_READY_EVENTS          # no data-parallel wrapper: the early-event table stays empty
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+
+
 class _FixedMask(torch.nn.Module):
     """nn.Dropout stand-in with a fixed, already scaled keep-mask (the one-launch heads ask for it via tmf_keep_mask)."""
 

@@ -85,6 +85,11 @@ def test_deep_block_gradients_carry_an_early_event():
     from transmf_ad_amd import ops
     net = _build().train()
     ops.GRAD_READY_EVENTS.clear()
+    ops.TRACK_GRAD_EVENTS = False
+    _loss(net, 0).backward()
+    assert not ops.GRAD_READY_EVENTS            # nobody consumes them: nothing is published (and nothing is held)
+    net.zero_grad()
+    ops.TRACK_GRAD_EVENTS = True                # what parallel.GradAllReduce switches on
     _loss(net, 0).backward()
     deep = [p for n, p in net.named_parameters() if ".conv3." in n or ".conv4." in n]
     shallow = [p for n, p in net.named_parameters() if ".conv1." in n or ".conv2." in n]
@@ -101,6 +106,7 @@ def test_deep_block_gradients_carry_an_early_event():
         assert torch.equal(a, p.grad)
     assert ops.grad_ready_event(deep[0].grad.clone()) is None                           # another buffer: no event
     ops.GRAD_READY_EVENTS.clear()
+    ops.TRACK_GRAD_EVENTS = False
 
 
 def test_bucket_groups_follow_the_deep_shallow_split(tmp_path):

@@ -522,6 +522,10 @@ def snet_eval_one_call(vol, dim, eps, slope, blocks):
 # at the end of every backward, and an encoder's forward drops the entries of ITS OWN previous backward only (owner =
 # the encoder's first parameter) — another model's forward between a backward and the wrapper's hook takes nothing away.
 GRAD_READY_EVENTS = {}
+# Entries are only written while somebody consumes them (parallel.GradAllReduce switches this on; it also clears the table at
+# the end of every backward): without a consumer a model that is never stepped again would leave its last entries — and the
+# gradient buffer they hold — behind for the life of the process (k-fold training builds one model per fold).
+TRACK_GRAD_EVENTS = False
 
 
 def grad_ready_event(grad):
@@ -611,7 +615,7 @@ class SNetTrain(torch.autograd.Function):
         prep = ctx.bwd if ctx.bwd is not None else SNetTrain._prepare_backward(ctx.shapes, ctx.needs_input_grad, vol.device)
         ctx.bwd = None
         flat, grads, g, ev = prep
-        for l in range(_lib.SNET_DEEP_FROM, 7):
+        for l in range(_lib.SNET_DEEP_FROM, 7 if TRACK_GRAD_EVENTS else 0):
             for j in range(4):
                 t_ = grads[4 * l + j]
                 if t_ is not None and t_.numel():

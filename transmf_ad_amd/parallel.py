@@ -74,6 +74,8 @@ class GradAllReduce(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, bucket_mb: float = 6.0,
                  broadcast_from_rank0: bool = True):
         super().__init__()
+        from . import ops
+        ops.TRACK_GRAD_EVENTS = True         # the encoder nodes publish their early events from now on (ops.GRAD_READY_EVENTS)
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("GradAllReduce needs an initialised torch.distributed process group")
         self.module = module
