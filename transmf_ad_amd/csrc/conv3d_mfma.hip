@@ -746,42 +746,53 @@ __global__ __launch_bounds__(C::NTHR, 2) void conv3d_fwd_rt_kernel(
             *reinterpret_cast<f32x4v*>(halo + ((e & 3) * NPOS + (e >> 2)) * 4) = hreg[q];
         }
         const bool more = c0 + C::CINC < Cin;
+        // Two fragment sets P, Q.  A stage multiplies taps kw = 0, 1, 2 from (P, Q, P); the A fragments of the NEXT stage's
+        // first tap do not depend on the weight ring (the halo stays for the whole chunk), so they are requested into Q ahead
+        // of the stage's last products, i.e. AHEAD of the barrier: behind it only the NT weight fragments are waited for.
+        // The sets swap roles every stage (the stage loop is unrolled: all of this is static).
+        Frag fr[2];
+        auto load_a = [&](int st, int kw, Frag& f) {
+            const int tapoff = (((st / 3) * C::HH + st % 3) * C::HW + kw) * 4;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) f.a[m] = *reinterpret_cast<const f32x4v*>(halo + a_lane[m] + tapoff);
+        };
+        auto load_b = [&](int st, int kw, Frag& f) {
+            const float* wsb = Ws + (st & 1) * C::WST_F + b_lane;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) f.b[j] = *reinterpret_cast<const f32x4v*>(wsb + (kw * NG * NB + j * 16) * 4);
+        };
+        auto mul = [&](const Frag& f) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[m][s4], f.b[j][s4], acc[m][j], 0, 0, 0);
+        };
 #pragma unroll
         for (int st = 0; st < C::NSTAGES; ++st) {
+            Frag& P = fr[st & 1];
+            Frag& Q = fr[(st & 1) ^ 1];
             store_w(st & 1, st & 1);
             __syncthreads();
             // weight stages run two ahead, across the chunk boundary (stage 9 / 10 = stage 0 / 1 of the next chunk)
             if (st + 2 < C::NSTAGES) load_w(c0, st + 2, st & 1);
             else if (AHEAD && more) load_w(c0 + C::CINC, st + 2 - C::NSTAGES, st & 1);
-            const float* wsb = Ws + (st & 1) * C::WST_F + b_lane;
-            const int kd = st / 3, kh = st % 3;
-            auto load = [&](int kw, Frag& f) {
-                const int tapoff = ((kd * C::HH + kh) * C::HW + kw) * 4;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) f.a[m] = *reinterpret_cast<const f32x4v*>(halo + a_lane[m] + tapoff);
-#pragma unroll
-                for (int j = 0; j < NT; ++j) f.b[j] = *reinterpret_cast<const f32x4v*>(wsb + (kw * NG * NB + j * 16) * 4);
-            };
-            auto mul = [&](const Frag& f) {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                    for (int m = 0; m < MT; ++m)
-#pragma unroll
-                        for (int j = 0; j < NT; ++j)
-                            acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[m][s4], f.b[j][s4], acc[m][j], 0, 0, 0);
-            };
-            Frag f0, f1;
-            load(0, f0);
-            load(1, f1);
+            if (st == 0) load_a(st, 0, P);                  // (first stage of a chunk: the halo was written just now)
+            load_b(st, 0, P);
+            load_a(st, 1, Q);
+            load_b(st, 1, Q);
             __builtin_amdgcn_sched_barrier(0);
-            mul(f0);
-            load(2, f0);
+            mul(P);
+            load_a(st, 2, P);
+            load_b(st, 2, P);
             __builtin_amdgcn_sched_barrier(0);
-            mul(f1);
+            mul(Q);
             __builtin_amdgcn_sched_barrier(0);
-            if (AHEAD && st == C::NSTAGES - 1 && more) load_halo(c0 + C::CINC);      // (f1's registers are free from here on)
-            mul(f0);
+            if (st + 1 < C::NSTAGES) load_a(st + 1, 0, Q);  // next stage's first tap, ahead of the barrier
+            if (AHEAD && st == C::NSTAGES - 1 && more) load_halo(c0 + C::CINC);      // (Q's registers are free from here on)
+            mul(P);
         }
     }
 
