@@ -1222,6 +1222,44 @@ def test_steady_state_steps_do_not_grow_device_memory(kind):
     assert all(torch.isfinite(p).all() for p in net.parameters())
 
 
+def test_single_encoder_model_asks_for_the_register_tiled_conv_per_call():
+    """model_single runs ONE encoder with nothing beside it: its sNet carries tmf_alone, the one-call encoder sets
+    tmf_snet_desc.flags = TMF_SNET_ALONE and the pooled layers' forward / data-gradient convolutions take the register-tiled
+    kernel for THAT call only — bitwise what tmf_set_option("conv_rt", 1) gives a model without the flag, a different fp32
+    summation order from the ring kernel, and the process-wide option stays untouched."""
+    import copy
+    import transmf_ad_amd as T
+    from transmf_ad_amd import _lib
+    torch.manual_seed(5)
+    net = T.model_single(128).to(DEV).train()
+    assert net.cnn.tmf_alone
+    x = torch.rand((2, 1, 96, 96, 96), device=DEV)
+    y = torch.tensor([0, 1], device=DEV)
+
+    def run(model):
+        model.zero_grad()
+        lo = model(x)
+        torch.nn.functional.cross_entropy(lo, y).backward()
+        torch.cuda.synchronize()
+        return lo.detach().clone(), model.cnn.conv3[0].weight.grad.clone(), model.cnn.conv2[0].weight.grad.clone()
+
+    ref = copy.deepcopy(net)
+    ref.cnn.tmf_alone = False
+    a = run(net)
+    b = run(ref)                                             # ring kernels everywhere
+    try:
+        _lib.call("tmf_set_option", b"conv_rt", 1)
+        c = run(ref)                                         # the same kernels as `net`, chosen process-wide
+    finally:
+        _lib.call("tmf_set_option", b"conv_rt", 0)
+    assert all(torch.equal(p, q) for p, q in zip(a, c))
+    assert not torch.equal(a[1], b[1])                       # another summation order in the 24^3 layers ...
+    assert (a[0] - b[0]).abs().max().item() < 1e-4           # ... and nothing more than that
+    for p, q in zip(a[1:], b[1:]):              # (max-pool routing may flip on near-ties: the golden tests' gradient band)
+        assert (p - q).abs().max().item() <= 2e-2 * q.abs().max().item()
+    assert not _lib.query("tmf_conv3d_fwd_kernel_name", 2, 24, 24, 24, 64, 64, 3).decode().startswith("RtCfg")
+
+
 class _FixedMask(torch.nn.Module):
     """nn.Dropout stand-in with a fixed, already scaled keep-mask (the one-launch heads ask for it via tmf_keep_mask)."""
 

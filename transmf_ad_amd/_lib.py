@@ -92,7 +92,8 @@ PROTOTYPES = {
 class SnetDesc(C.Structure):
     """tmf_snet_desc (include/tmf_hip.h)"""
     _fields_ = [("B", _i), ("D", _i), ("H", _i), ("W", _i), ("dim", _i), ("precision", _i), ("storage_bf16", _i),
-                ("momentum", _f * 7), ("eps", _f * 7), ("slope", _f * 7)]
+                ("momentum", _f * 7), ("eps", _f * 7), ("slope", _f * 7), ("flags", _i)]
+SNET_ALONE = 1
 
 
 class SnetParams(C.Structure):

@@ -899,15 +899,16 @@ struct FwdPlan {
     int tilesD, tilesH, tilesW, ntiles, nby;
 };
 
-FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks, bool allow_rt = true) {
+FwdPlan plan_fwd(int B, int D, int H, int W, int cin, int cout, int ks, bool allow_rt = true, int rt_min = 0) {
     FwdPlan p;
     // Register-tiled form (cfg 12: 32 channels per workgroup, 13: 16): volumes its 6 x 6 x 12 bricks tile exactly, channel
     // counts in whole 16-channel chunks / tiles.  16-channel workgroups where 32-channel ones would leave CUs without one.
     // Taken for the pooled volumes (<= 24^3 voxels per sample: +9 % over the ring kernel at 24^3 and 12^3, B = 8, measured per
     // layer with tools/conv_ab.py --opt conv_rt); at 48^3 the ring kernel's last round is 3/8 full and cheap, and its
     // 0.81-0.86 stands against 0.79-0.81 here.  tmf_set_option("conv_rt", 2) takes this form wherever its bricks fit.
-    const bool rt_size = conv_rt() == 2 || (long)D * H * W <= 24L * 24 * 24;
-    if (allow_rt && conv_rt() && rt_size && ks == 3 && cin % 16 == 0 && cout % 16 == 0 && D % 6 == 0 && H % 6 == 0 && W % 12 == 0) {
+    const int rt_mode = conv_rt() > rt_min ? conv_rt() : rt_min;       // rt_min: the caller's per-call request (TMF_SNET_ALONE)
+    const bool rt_size = rt_mode == 2 || (long)D * H * W <= 24L * 24 * 24;
+    if (allow_rt && rt_mode && rt_size && ks == 3 && cin % 16 == 0 && cout % 16 == 0 && D % 6 == 0 && H % 6 == 0 && W % 12 == 0) {
         p.tilesD = D / 6; p.tilesH = H / 6; p.tilesW = W / 12;
         p.ntiles = B * p.tilesD * p.tilesH * p.tilesW;
         const bool nt2 = cout % 32 == 0 && (long)p.ntiles * (cout / 32) >= 512;
@@ -1693,12 +1694,20 @@ extern "C" const char* tmf_conv3d_wgrad_kernel_name(int B, int D, int H, int W, 
 }
 
 extern "C" int tmf_conv3d_stat_blocks(int B, int D, int H, int W, int cin, int cout, int ksize) {
+    return tmf_conv3d_stat_blocks_mode(B, D, H, W, cin, cout, ksize, 0);
+}
+// (internal, tmf_common.h) rt_min = 1: at least tmf_set_option("conv_rt", 1) for this call — the one-call encoder with TMF_SNET_ALONE
+int tmf_conv3d_stat_blocks_mode(int B, int D, int H, int W, int cin, int cout, int ksize, int rt_min) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || cin <= 0 || cout <= 0) return 0;
-    return plan_fwd(B, D, H, W, cin, cout, ksize).ntiles;
+    return plan_fwd(B, D, H, W, cin, cout, ksize, true, rt_min).ntiles;
 }
 
 extern "C" int tmf_conv3d_fwd(const float* x, const float* w, float* z, float* stat_partial,
                               int B, int D, int H, int W, int cin, int cout, int ksize, void* stream) {
+    return tmf_conv3d_fwd_mode(x, w, z, stat_partial, B, D, H, W, cin, cout, ksize, 0, stream);
+}
+int tmf_conv3d_fwd_mode(const float* x, const float* w, float* z, float* stat_partial,
+                        int B, int D, int H, int W, int cin, int cout, int ksize, int rt_min, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(z);
     TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && cin > 0 && cout > 0, TMF_E_SHAPE,
                 "tmf_conv3d_fwd: non-positive dimension (B=%d D=%d H=%d W=%d cin=%d cout=%d)", B, D, H, W, cin, cout);
@@ -1707,7 +1716,7 @@ extern "C" int tmf_conv3d_fwd(const float* x, const float* w, float* z, float* s
                 "tmf_conv3d_fwd: one sample exceeds 2^29 elements (32-bit byte offsets inside a sample)");
     TMF_REQUIRE((long)ksize * ksize * ksize * cin * cout < (1L << 29), TMF_E_SHAPE, "tmf_conv3d_fwd: weight tensor exceeds 2^29 elements");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(w); TMF_REQUIRE_ALIGNED(z);
-    const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize);
+    const FwdPlan p = plan_fwd(B, D, H, W, cin, cout, ksize, true, rt_min);
     hipStream_t s = (hipStream_t)stream;
     return ksize == 3 ? launch_fwd<3>(p, x, w, z, stat_partial, D, H, W, cin, cout, s)
                       : launch_fwd<1>(p, x, w, z, stat_partial, D, H, W, cin, cout, s);

@@ -11,7 +11,8 @@
 // arguments as the op-by-op path (results are bit-identical — tested), all intermediate tensors carved out of ONE
 // caller-allocated workspace, weight gradients reduced straight into the reference's nn.Conv3d layout.
 //
-// Pure host code: it only calls the library's own extern "C" entries (include/tmf_hip.h).
+// Pure host code: it only calls the library's own extern "C" entries (include/tmf_hip.h) — and the two *_mode forms of
+// tmf_conv3d_fwd / tmf_conv3d_stat_blocks (tmf_common.h) that carry tmf_snet_desc.flags' TMF_SNET_ALONE to the conv plan.
 #include "tmf_common.h"
 
 namespace {
@@ -96,7 +97,7 @@ Plan make_plan(const tmf_snet_desc& d) {
             ws = tmf_c1_bwd_wgrad_workspace_bytes(d.B, L.D, L.H, L.W, L.cout);
         } else {
             nblk = L.bf ? tmf_conv3d_bf16_stat_blocks(d.B, L.D, L.H, L.W)
-                        : tmf_conv3d_stat_blocks(d.B, L.D, L.H, L.W, L.cin, L.cout, L.k);
+                        : tmf_conv3d_stat_blocks_mode(d.B, L.D, L.H, L.W, L.cin, L.cout, L.k, (d.flags & TMF_SNET_ALONE) ? 1 : 0);
             nb2 = tmf_bn_act_pool_bwd_blocks(d.B, L.D, L.H, L.W, L.cout, L.pool);
             ws = L.bf ? tmf_conv3d_wgrad_bf16_workspace_bytes(d.B, L.D, L.H, L.W, L.cin, L.cout)
                       : tmf_conv3d_wgrad_workspace_bytes(d.B, L.D, L.H, L.W, L.cin, L.cout, L.k);
@@ -181,9 +182,10 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
                                           (L.x16 ? 1 : 0) | (L.z16 ? 2 : 0), stream));
         } else {
             TMF_TRY(tmf_pack_conv_weights(prm->weight[l], (float*)wf, (float*)wd, L.cout, L.cin, L.k * L.k * L.k, stream));
-            nblk = tmf_conv3d_stat_blocks(d->B, L.D, L.H, L.W, L.cin, L.cout, L.k);
-            TMF_TRY(tmf_conv3d_fwd((const float*)x, (const float*)wf, (float*)z, part, d->B, L.D, L.H, L.W, L.cin, L.cout, L.k,
-                                   stream));
+            const int rt_min = (d->flags & TMF_SNET_ALONE) ? 1 : 0;
+            nblk = tmf_conv3d_stat_blocks_mode(d->B, L.D, L.H, L.W, L.cin, L.cout, L.k, rt_min);
+            TMF_TRY(tmf_conv3d_fwd_mode((const float*)x, (const float*)wf, (float*)z, part, d->B, L.D, L.H, L.W, L.cin, L.cout,
+                                        L.k, rt_min, stream));
         }
         TMF_TRY(tmf_bn_finalize(part, nblk, L.cout, count, prm->gamma[l], prm->beta[l], prm->bias[l], prm->running_mean[l],
                                 prm->running_var[l], d->momentum[l], d->eps[l], v.mean, v.invstd, v.scale, v.shift, stream));
@@ -335,8 +337,8 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
             if (g->dweight[l] != nullptr)
                 TMF_TRY(tmf_conv3d_wgrad((const float*)x, (const float*)dz, g->dweight[l], ws, p.ws_bytes, d->B, L.D, L.H, L.W,
                                          L.cin, L.cout, L.k, TMF_DW_REFERENCE, stream));
-            TMF_TRY(tmf_conv3d_fwd((const float*)dz, (const float*)wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W, L.cout, L.cin,
-                                   L.k, stream));
+            TMF_TRY(tmf_conv3d_fwd_mode((const float*)dz, (const float*)wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W, L.cout,
+                                        L.cin, L.k, (d->flags & TMF_SNET_ALONE) ? 1 : 0, stream));
         }
         go = dx;
         if (l == TMF_SNET_DEEP_FROM && g->deep_event != nullptr) {       // blocks 6 .. l: every gradient is queued behind this point

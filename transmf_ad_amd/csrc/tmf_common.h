@@ -84,6 +84,10 @@ template <> struct TmfIO<tmf_bf16_t, 1> {
 void tmf_set_error(const char* fmt, ...);
 extern int tmf_g_debug;          // conv3d_bf16.hip: timing-ablation bits (tmf_set_option("debug", ..))
 extern int tmf_g_wgrad_tr;       // conv3d_bf16.hip: bf16 weight-gradient kernel choice, tmf_set_option("wgrad_tr", 0 never | 1 where faster | 2 wherever possible: the transposing-read kernel)
+// conv3d_mfma.hip: tmf_conv3d_fwd / tmf_conv3d_stat_blocks with a per-call minimum for the "conv_rt" mode (snet_path.hip: TMF_SNET_ALONE)
+int tmf_conv3d_fwd_mode(const float* x, const float* w, float* z, float* stat_partial, int B, int D, int H, int W, int cin,
+                        int cout, int ksize, int rt_min, void* stream);
+int tmf_conv3d_stat_blocks_mode(int B, int D, int H, int W, int cin, int cout, int ksize, int rt_min);
 extern int tmf_g_bf16_dma;       // conv3d_bf16.hip: LDS-DMA form of the large-brick bf16 forward kernel (tmf_set_option("bf16_dma", 0 | 1))
 extern int tmf_g_bf16_v2;        // conv3d_bf16.hip: kernel choice of the bf16 forward (tmf_set_option("bf16_v2", ..))
 

@@ -178,6 +178,7 @@ class model_single(_FastModeSwitch, nn.Module):
     def __init__(self, dim):
         super().__init__()
         self.cnn = sNet(dim)
+        self.cnn.tmf_alone = True               # one encoder, one stream: its pooled layers take the register-tiled conv kernel
         self.avgpool = nn.AdaptiveAvgPool3d((1, 1, 1))
         self.fc = nn.Sequential(nn.Linear(128, 64), nn.ReLU(), nn.Linear(64, 2))
         _init_like_reference(self)

@@ -69,6 +69,7 @@ class sNet(nn.Module):
         for name, p in self.named_parameters():
             p.tmf_bucket_group = ("sNet deep", id(self)) if name.startswith(("conv3", "conv4")) else ("sNet shallow",)
         self.tmf_precision = None           # None: follow the process default (ops.set_conv_precision / set_activation_storage)
+        self.tmf_alone = False              # True: nothing runs beside this encoder (model_single): tmf_snet_desc.flags = TMF_SNET_ALONE
 
     def set_precision(self, conv="fp32", storage="fp32"):
         """Precision of THIS encoder's convolution products ("fp32" | "bf16" | "fp32x") and of the activations between its
@@ -102,7 +103,8 @@ class sNet(nn.Module):
                 params += [conv.weight, conv.bias, bn.weight, bn.bias]
                 buffers.append((bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None))
             cfg = (blocks[-1][0].out_channels, tuple(float(bn.momentum) for _c, bn, _a in blocks),
-                   tuple(float(bn.eps) for _c, bn, _a in blocks), tuple(float(a.negative_slope) for _c, _b, a in blocks), prec)
+                   tuple(float(bn.eps) for _c, bn, _a in blocks), tuple(float(a.negative_slope) for _c, _b, a in blocks), prec,
+                   bool(getattr(self, "tmf_alone", False)))
             return ops.SNetTrain.apply(vol, cfg, buffers, *params)
         store16 = prec[1]
         for n_blk, (seq_name, i, pool) in enumerate(self._PLAN):

@@ -558,7 +558,8 @@ class SNetTrain(torch.autograd.Function):
         dim, momentum, eps, slope = cfg[:4]
         mode, act16 = resolve_precision(cfg[4] if len(cfg) > 4 else None)
         B, _, D, H, W = vol.shape
-        desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision=1 if mode == "bf16" else 0, storage_bf16=int(act16))
+        desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision=1 if mode == "bf16" else 0, storage_bf16=int(act16),
+                             flags=_lib.SNET_ALONE if (len(cfg) > 5 and cfg[5]) else 0)
         prm = _lib.SnetParams()
         for l in range(7):
             desc.momentum[l], desc.eps[l], desc.slope[l] = momentum[l], eps[l], slope[l]
