@@ -254,17 +254,23 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
                              "forward / data-gradient kernel evaluates every fp32 product as six bf16 partial products, its own "
                              f"ceiling is the bf16 peak / 6 = {PEAK_BF16_MFMA_TFLOPS / 6:.1f} TF, so its entries may exceed 1")
     if pairs_per_s is not None:
-        per_gpu = pairs_per_s / world
-        roof["whole_step"] = {
-            "what": "the train step itself: pairs/s per GPU x algorithmic figure per pair (SURVEY.md 8d)",
-            "conv_tflops": round(per_gpu * gf_pair / 1e12, 2), "mfma_frac": round(per_gpu * gf_pair / 1e12 / peak_tf, 4),
-            "hbm_GBps": round(per_gpu * bytes_pair / 1e9, 1), "hbm_frac": round(per_gpu * bytes_pair / 1e9 / PEAK_HBM_GBS, 4),
-            "algorithmic_GFLOP_per_pair": round(gf_pair / 1e9, 2), "algorithmic_GB_per_pair": round(bytes_pair / 1e9, 3),
-            "bound": "mfma" if gf_pair / peak_tf / 1e12 >= bytes_pair / PEAK_HBM_GBS / 1e9 else "hbm"}
+        roof["whole_step"] = whole_step_entry(pairs_per_s, world, gf_pair, bytes_pair, precision)
     return roof
 
 
-def main():
+def whole_step_entry(pairs_per_s, world, gf_pair, bytes_pair, precision):
+    """The train step itself against both ceilings: units/s per GPU x the algorithmic figure per unit."""
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    per_gpu = pairs_per_s / world
+    return {
+        "what": "the train step itself: pairs/s per GPU x algorithmic figure per pair (SURVEY.md 8d)",
+        "conv_tflops": round(per_gpu * gf_pair / 1e12, 2), "mfma_frac": round(per_gpu * gf_pair / 1e12 / peak_tf, 4),
+        "hbm_GBps": round(per_gpu * bytes_pair / 1e9, 1), "hbm_frac": round(per_gpu * bytes_pair / 1e9 / PEAK_HBM_GBS, 4),
+        "algorithmic_GFLOP_per_pair": round(gf_pair / 1e9, 2), "algorithmic_GB_per_pair": round(bytes_pair / 1e9, 3),
+        "bound": "mfma" if gf_pair / peak_tf / 1e12 >= bytes_pair / PEAK_HBM_GBS / 1e9 else "hbm"}
+
+
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -298,10 +304,36 @@ def main():
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the train-step timing: only the dominant-kernel loop (so that a rocprofv3 --stats run "
                          "of this command averages exactly the launches the roofline entry quotes)")
-    args = ap.parse_args()
+    ap.add_argument("--no-also", action="store_true",
+                    help="the default N=1 run measures the other BASELINE configurations in the same process after the headline "
+                         "(`also`: configs[2] 128^3 bf16, configs[4] both readings at batch 16, the fp32x mode); this skips them")
+    return ap
 
-    from transmf_ad_amd import model_ad, ops, _lib
-    from transmf_ad_amd.parallel import GradAllReduce, init_from_env
+
+# The other BASELINE.json configurations, measured in the SAME process after the headline when bench.py runs with its
+# default flags on one GPU (so that the driver's one run witnesses them): name -> argument overrides.
+ALSO = (
+    ("configs[2]: 128^3, batch 8, bf16 MFMA 3D conv + bf16 activation storage",
+     dict(precision="bf16", storage="bf16", size=128, batch=8, model="ad", cpu_batch=2)),
+    ("configs[4]: model_CNN_ad (dual-modality reading of --model CNN), batch 16, 96^3, fp32",
+     dict(model="cnn", batch=16, cpu_batch=2)),
+    ("configs[4]: model_single (MRI-only reading), batch 16, 96^3, fp32",
+     dict(model="single", batch=16, cpu_batch=2)),
+    ("configs[1] workload in the opt-in fp32x mode (fp32-accurate 3-way bf16 split on the bf16 matrix cores)",
+     dict(precision="fp32x")),
+)
+
+
+def _is_default_workload(args):
+    return (args.model == "ad" and args.precision == "fp32" and args.storage == "fp32" and args.size == 96 and args.batch == 8
+            and not args.shape and not args.eval and not args.from_host and not args.roofline_only and not args.no_item_sync
+            and not args.no_cpu_baseline and args.steps > 0)
+
+
+def main():
+    import copy
+    args = build_parser().parse_args()
+    from transmf_ad_amd.parallel import init_from_env
 
     rank, local, world = init_from_env()
     if world != args.gpus:
@@ -311,10 +343,47 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-
-    ops.set_conv_precision(args.precision)
     if args.storage == "bf16" and args.precision != "bf16":
         raise SystemExit("--storage bf16 needs --precision bf16")
+
+    cpu_cache = {}
+    out = run(args, rank, local, world, dev, cpu_cache, brief=False)
+    if rank == 0 and world == 1 and not args.no_also and _is_default_workload(args) \
+            and os.environ.get("TMF_DDP_FORCE", "0") != "1":
+        also = []
+        for title, over in ALSO:
+            a = copy.copy(args)
+            for k, v in over.items():
+                setattr(a, k, v)
+            try:
+                rec = run(a, rank, local, world, dev, cpu_cache, brief=True)
+                rec["config_name"] = title
+            except Exception as e:                       # an extra record must never cost the headline line
+                rec = {"config_name": title, "error": f"{type(e).__name__}: {e}"}
+            also.append(rec)
+        out["also"] = also
+    if world > 1:
+        dist.barrier()
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    if rank == 0:
+        # the ONE JSON line goes out last: RCCL's version banner sits in the C stdio buffer until then (piped stdout)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
+
+
+def run(args, rank, local, world, dev, cpu_cache, brief=False):
+    """One configuration: build the model, time the steps, measure the roofline / CPU baseline legs -> the record (rank 0;
+    None elsewhere).  brief: an `also` record — whole-step roofline only (no per-launch loop), no numerics gate."""
+    import statistics
+    from transmf_ad_amd import model_ad, ops, _lib
+    from transmf_ad_amd.parallel import GradAllReduce
+
+    ops.set_conv_precision(args.precision)
     ops.set_activation_storage(args.storage)
     torch.manual_seed(0)
     if args.model == "ad":
@@ -328,7 +397,8 @@ def main():
     if world == 1 and os.environ.get("TMF_DDP_FORCE", "0") == "1":     # overhead measurement of the N>1 machinery
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         net = GradAllReduce(net)
     if world > 1:
         net = GradAllReduce(net)
@@ -344,7 +414,7 @@ def main():
     # initial parameters and inputs against the CPU oracle (<= 1e-3 on logits and loss); evaluated in the cpu_baseline leg
     gate_state = None
     want_gate = (rank == 0 and world == 1 and not args.no_cpu_baseline and args.model == "ad" and not args.shape
-                 and args.precision == "fp32")
+                 and args.precision == "fp32" and not brief)
     if want_gate:
         gate_state = {k: v.detach().cpu().clone() for k, v in (net.module if hasattr(net, "module") else net).state_dict().items()}
     B, S = args.batch, args.size
@@ -362,7 +432,6 @@ def main():
     feeder = None
     if args.from_host:
         import itertools
-        import numpy as np
         from transmf_ad_amd import DevicePrefetcher
         rs = np.random.RandomState(1234 + rank)
         pool = [dict(MRI=(rs.rand(B, 1, *vol) * 4000.0).astype(np.float32), PET=(rs.rand(B, 1, *vol) * 9.0).astype(np.float32),
@@ -444,13 +513,19 @@ def main():
     fence()
     if isinstance(net, GradAllReduce):
         net.timing = True
+    # one event per step boundary on the stream the steps are issued on (torch's current stream; the side streams of a
+    # step join it before the optimizer): per-step times for ms_per_step_min / _median beside the wall-clock mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     dt_local = max(time.perf_counter() - t0, 1e-9)          # this rank's own time, before the barrier
     fence()
     dt = max(time.perf_counter() - t0, 1e-9)
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     per_rank = None
     if isinstance(net, GradAllReduce):
         net.timing = False
@@ -463,10 +538,13 @@ def main():
         per_rank = {"ms_per_step": [round(t[0].item(), 3) for t in allr],
                     "allreduce_exposed_ms_mean": [round(t[1].item(), 3) for t in allr],
                     "allreduce_exposed_ms_max": [round(t[2].item(), 3) for t in allr],
-                    "bucket_bytes": net.bucket_sizes_bytes,
+                    "collective_bytes": net.last_reduced_bytes, "collective_kinds": net.last_reduced_kinds,
                     "note": "ms_per_step: each rank's own time for the K steps before the final barrier; "
-                            "allreduce_exposed: time between the end of backward's compute and the last gradient bucket "
-                            "being reduced + scaled (RCCL time that did not hide under backward)"}
+                            "allreduce_exposed: time between the end of backward's compute and the last collective being "
+                            "done + scaled (RCCL time that did not hide under backward); collective_*: every all-reduce of "
+                            "the last step in launch order — stream / event: a node's flat gradient buffer reduced in place "
+                            "behind its stream / behind the encoder's deep-block event, end: in place at the end of backward, "
+                            "bucket: packed from .grad at the end of backward"}
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -479,6 +557,9 @@ def main():
 
     ms_per_step = dt / max(args.steps, 1) * 1e3
     pairs_per_s = world * B * args.steps / dt
+    # the timed region is over: give this configuration's memory back before the roofline / CPU legs and the next record
+    del net, opt
+    torch.cuda.empty_cache()
 
     # ---- roofline: every conv launch of a step timed live (HIP events on the launching stream), folded into the
     # time-dominant kernel instance (main entry), the FLOP-weighted step figure, and the whole-step fractions ----
@@ -486,21 +567,33 @@ def main():
     gf_pair = conv_flops_per_pair(vol) * (0.5 if args.model == "single" else 1.0)
     by_pair = conv_bytes_per_pair(vol, 2 if args.storage == "bf16" else 4) * (0.5 if args.model == "single" else 1.0)
     if rank == 0 and not args.eval:
-        _spin_up(dev, float(os.environ.get("TMF_ROOF_SPIN_S", "0.5")))
-        rows = measure_conv_launches(ops, _lib, dev, B, vol, args.precision, args.storage,
-                                     reps=int(os.environ.get("TMF_ROOF_REPS", "10")))
-        roof = roofline_report(rows, args.precision, args.storage, pairs_per_s if args.steps > 0 else None, world, gf_pair,
-                               by_pair, B, vol)
+        if brief:
+            roof = {"whole_step": whole_step_entry(pairs_per_s, world, gf_pair, by_pair, args.precision)}
+            if args.precision == "fp32x":
+                roof["peak_note"] = ("fractions are ALGORITHMIC fp32 flops against the fp32-MFMA peak (157.3 TF); the forward / "
+                                     "data-gradient kernel of this mode runs on the bf16 matrix cores (six partial products)")
+        else:
+            _spin_up(dev, float(os.environ.get("TMF_ROOF_SPIN_S", "0.5")))
+            rows = measure_conv_launches(ops, _lib, dev, B, vol, args.precision, args.storage,
+                                         reps=int(os.environ.get("TMF_ROOF_REPS", "10")))
+            roof = roofline_report(rows, args.precision, args.storage, pairs_per_s if args.steps > 0 else None, world, gf_pair,
+                                   by_pair, B, vol)
 
     cpu = None
     gate = None
-    if S > 96 and args.cpu_batch == 8:
-        args.cpu_batch = 2                 # bounded sample (the contract's 10-30 s of CPU work): 128^3 steps are 2.4x as long
+    vtxt = f"{S}^3" if not args.shape else "x".join(map(str, vol))
+    cpu_batch = args.cpu_batch
+    if S > 96 and cpu_batch == 8:
+        cpu_batch = 2                      # bounded sample (the contract's 10-30 s of CPU work): 128^3 steps are 2.4x as long
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import tmf_oracle as O         # test infrastructure, used ONLY as the timed CPU baseline
-        # MKL-DNN conv3d scales poorly past a few dozen threads (256 SMT threads: 85 s/step vs ~8 s on 8): cap at 32
-        sec, threads = O.cpu_train_step_seconds(args.cpu_batch, S, steps=3, warmup=1,
-                                                threads=min(args.cpu_threads, os.cpu_count()))
+        omodel = {"ad": "model_ad", "cnn": "model_CNN_ad", "single": "model_single"}[args.model]
+        key = (omodel, cpu_batch, vol)
+        if key not in cpu_cache:
+            # MKL-DNN conv3d scales poorly past a few dozen threads (256 SMT threads: 85 s/step vs ~8 s on 8): cap at 32
+            cpu_cache[key] = O.cpu_train_step_seconds(cpu_batch, vol, steps=3, warmup=1, model=omodel,
+                                                      threads=min(args.cpu_threads, os.cpu_count()))
+        sec, threads = cpu_cache[key]
         cpu_model = "unknown CPU"
         try:
             with open("/proc/cpuinfo") as f:
@@ -510,7 +603,6 @@ def main():
                         break
         except OSError:
             pass
-        gate = None
         if gate_gpu is not None:
             spec = O.state_spec("model_ad")
             S_or = O.to_state({k: v.numpy() for k, v in gate_state.items()}, spec, requires_grad=False)
@@ -522,66 +614,67 @@ def main():
                             "(BASELINE.md section 3; the train-mode gates with injected Dropout masks are tests/test_gpu_model.py)",
                     "max_abs_dlogits": dl, "abs_dloss": abs(gate_gpu[1] - loss_c), "gpu_loss": gate_gpu[1], "cpu_loss": loss_c,
                     "tolerance": 1e-3, "pass": bool(dl <= 1e-3 and abs(gate_gpu[1] - loss_c) <= 1e-3)}
-        cpu = {"value": round(args.cpu_batch / sec, 4), "unit": "volume-pairs/s", "cores": threads, "kind": "port",
-               "sample": f"oracle model_ad train-mode fwd+bwd, batch {args.cpu_batch} of 1x{S}^3 pairs "
-                         f"(1/{max(1, B // args.cpu_batch)} of one batch-{B} step), 1 warm-up + 3 timed steps, "
+        unit_txt = "volumes" if args.model == "single" else "pairs"
+        cpu = {"value": round(cpu_batch / sec, 4), "unit": "volumes/s" if args.model == "single" else "volume-pairs/s",
+               "cores": threads, "kind": "port",
+               "sample": f"oracle {omodel} train-mode fwd+bwd (exact fp32 on the host whatever the GPU mode), batch {cpu_batch} of "
+                         f"1x{vtxt} {unit_txt} (1/{max(1, B // cpu_batch)} of one batch-{B} step), 1 warm-up + 3 timed steps, "
                          f"{sec:.2f} s/step, {cpu_model}, host cpu_count={os.cpu_count()}, torch threads={threads}"}
 
-    if rank == 0:
-        gf = gf_pair
-        if args.eval:       # forward only: sum of F_l per stream
-            gf = gf * (32.219 / 95.125) if vol == (96, 96, 96) else gf / 3.0
-        vtxt = f"{S}^3" if not args.shape else "x".join(map(str, vol))
-        model_desc = {"ad": "model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512)",
-                      "cnn": "model_CNN_ad(dim=128) [BASELINE configs[4], dual-modality reading of --model CNN]",
-                      "single": "model_single(128), MRI only [BASELINE configs[4], single-modality reading]"}[args.model]
-        out = {
-            "metric": ((f"volume-pairs/sec fwd+bwd(+Adam), {vtxt} MRI+PET batch={B} per GPU" if args.model != "single"
-                        else f"volumes/sec fwd+bwd(+Adam), {vtxt} MRI only batch={B} per GPU") if not args.eval else
-                       f"volume-pairs/sec eval forward (val_step), {vtxt} batch={B} per GPU"),
-            "value": round(pairs_per_s, 3), "unit": "volume-pairs/s" if args.model != "single" else "volumes/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": ("bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate, bf16 activation storage between conv blocks"
-                               if args.storage == "bf16" else "bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate+storage"),
-                      "fp32x": "f32 via exact 3-way bf16 split on the bf16 MFMA (conv fwd/dgrad; wgrad exact f32 MFMA)"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": f"{model_desc} {'val_step' if args.eval else 'train step'}, "
-                                   f"batch {B} {'volumes' if args.model == 'single' else 'pairs'} of 1x"
-                                   + (f"{S}^3" if not args.shape else "x".join(map(str, vol))) + f" per GPU, {args.precision}"
-                                   + (_config_tag(B, S, args.precision) if args.model == "ad" else ""),
-                       "global_batch": B * world, "parallelism": f"dp{world}",
-                       "step": "val_step: eval-mode no_grad forward + CE" if args.eval else
-                               ("zero_grad+fwd+loss+bwd+allreduce+Adam" if args.no_item_sync or args.model == "single" else
-                                "zero_grad+fwd+loss+2x loss.item()+bwd+allreduce+Adam (kfold_train_adversarial.py:101-136)"),
-                       "dispatch": mode,
-                       "optimizer": type(opt).__module__ + "." + type(opt).__name__ +
-                                    (" (one launch: tmf_adam_step)" if type(opt).__module__.startswith("transmf_ad_amd") else ""),
-                       "input": ("host: raw volumes -> H2D on a copy stream (double-buffered) -> device ScaleIntensity + RandFlip(0.3) "
-                                 f"+ RandRotate(0.3, 0.05 rad) + RandZoom(0.3, 0.95-1), every step (PCIe-inclusive); {2 * B * vol[0] * vol[1] * vol[2] * 4 / 1e6:.1f} "
-                                 f"MB per step over a host link measured at {h2d_gbps:.1f} GB/s pinned -> device on this box"
-                                 if args.from_host else "resident in HBM"),
-                       "setup_steps_untimed": setup_steps},
-            "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
-            "loss": round(final_loss, 6),
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        if cpu is not None and gate is not None:
-            out["numerics_gate"] = gate
-        if per_rank is not None:
-            out["per_rank"] = per_rank
-    if world > 1:
-        dist.barrier()
-    if dist.is_initialized():
-        dist.destroy_process_group()
-    if rank == 0:
-        # the ONE JSON line goes out last: RCCL's version banner sits in the C stdio buffer until then (piped stdout)
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps(out), flush=True)
+    if rank != 0:
+        return None
+    gf = gf_pair
+    if args.eval:       # forward only: sum of F_l per stream
+        gf = gf * (32.219 / 95.125) if vol == (96, 96, 96) else gf / 3.0
+    model_desc = {"ad": "model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512)",
+                  "cnn": "model_CNN_ad(dim=128) [BASELINE configs[4], dual-modality reading of --model CNN]",
+                  "single": "model_single(128), MRI only [BASELINE configs[4], single-modality reading]"}[args.model]
+    out = {
+        "metric": ((f"volume-pairs/sec fwd+bwd(+Adam), {vtxt} MRI+PET batch={B} per GPU" if args.model != "single"
+                    else f"volumes/sec fwd+bwd(+Adam), {vtxt} MRI only batch={B} per GPU") if not args.eval else
+                   f"volume-pairs/sec eval forward (val_step), {vtxt} batch={B} per GPU"),
+        "value": round(pairs_per_s, 3), "unit": "volume-pairs/s" if args.model != "single" else "volumes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "ms_per_step_min": round(min(per_step), 3) if per_step else None,
+        "ms_per_step_median": round(statistics.median(per_step), 3) if per_step else None,
+        "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fp32": "f32", "bf16": ("bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate, bf16 activation storage between conv blocks"
+                           if args.storage == "bf16" else "bf16 MFMA operands (conv fwd/dgrad/wgrad), f32 accumulate+storage"),
+                  "fp32x": "f32 via exact 3-way bf16 split on the bf16 MFMA (conv fwd/dgrad; wgrad exact f32 MFMA)"}[args.precision],
+        "data": "synthetic",
+        "config": {"workload": f"{model_desc} {'val_step' if args.eval else 'train step'}, "
+                               f"batch {B} {'volumes' if args.model == 'single' else 'pairs'} of 1x"
+                               + (f"{S}^3" if not args.shape else "x".join(map(str, vol))) + f" per GPU, {args.precision}"
+                               + (_config_tag(B, S, args.precision) if args.model == "ad" else ""),
+                   "global_batch": B * world, "parallelism": f"dp{world}",
+                   "step": "val_step: eval-mode no_grad forward + CE" if args.eval else
+                           ("zero_grad+fwd+loss+bwd+allreduce+Adam" if args.no_item_sync or args.model == "single" else
+                            "zero_grad+fwd+loss+2x loss.item()+bwd+allreduce+Adam (kfold_train_adversarial.py:101-136)"),
+                   "dispatch": mode,
+                   "optimizer": ("transmf_ad_amd.optim.Adam (one launch: tmf_adam_step)" if not (args.torch_adam or args.no_fused_adam)
+                                 else "torch.optim.adam.Adam"),
+                   "input": ("host: raw volumes -> H2D on a copy stream (double-buffered) -> device ScaleIntensity + RandFlip(0.3) "
+                             f"+ RandRotate(0.3, 0.05 rad) + RandZoom(0.3, 0.95-1), every step (PCIe-inclusive); {2 * B * vol[0] * vol[1] * vol[2] * 4 / 1e6:.1f} "
+                             f"MB per step over a host link measured at {h2d_gbps:.1f} GB/s pinned -> device on this box"
+                             if args.from_host else "resident in HBM"),
+                   "setup_steps_untimed": setup_steps,
+                   "per_step_timing": "ms_per_step = wall clock of the K steps / K (the contract); _min / _median from one HIP "
+                                      "event per step boundary on the issuing stream"},
+        "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
+        "loss": round(final_loss, 6),
+        "roofline": roof, "cpu_baseline": cpu,
+    }
+    if cpu is not None and gate is not None:
+        out["numerics_gate"] = gate
+    if per_rank is not None:
+        out["per_rank"] = per_rank
+    if brief:           # an `also` record: the keys the headline carries, minus the contract boilerplate
+        for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "conv_tflops_whole_step"):
+            out.pop(k, None)
+        out["config"] = {"workload": out["config"]["workload"], "step": out["config"]["step"],
+                         "setup_steps_untimed": setup_steps}
+    return out
 
 
 if __name__ == "__main__":

@@ -487,18 +487,21 @@ def grads_of(S: Dict[str, Tensor], spec) -> Dict[str, Tensor]:
     return out
 
 
-def cpu_train_step_seconds(batch: int, size: int, steps: int = 1, warmup: int = 1, seed: int = 1234,
-                           threads: Optional[int] = None) -> Tuple[float, int]:
-    """Time ``steps`` train-mode fwd+bwd passes of model_ad(128,3,4,32,512) on the host
-    cores (the ``cpu_baseline`` leg of bench.py).  Returns (seconds per step, threads)."""
+def cpu_train_step_seconds(batch: int, size, steps: int = 1, warmup: int = 1, seed: int = 1234,
+                           threads: Optional[int] = None, model: str = "model_ad") -> Tuple[float, int]:
+    """Time ``steps`` train-mode fwd+bwd passes of the reference step on the host cores (the ``cpu_baseline`` leg of
+    bench.py): ``model_ad(128,3,4,32,512)`` / ``model_CNN_ad(128)`` with the adversarial loss
+    (kfold_train_adversarial.py:101-136), or ``model_single(128)`` with plain CE (kfold_train_single.py:91-113).
+    size: edge length or (D, H, W).  Returns (seconds per step, threads)."""
     import time
     import numpy as np
     from . import params as P
     if threads:
         torch.set_num_threads(threads)
-    spec = state_spec("model_ad")
+    spec = state_spec(model)
     S = to_state(P.init_arrays(spec, seed=7), spec)
-    mri, pet, y = P.make_inputs(batch, (size, size, size), seed)
+    vol = (size, size, size) if isinstance(size, int) else tuple(size)
+    mri, pet, y = P.make_inputs(batch, vol, seed)
     mri, pet, y = torch.from_numpy(mri), torch.from_numpy(pet), torch.from_numpy(y)
     dt = []
     for it in range(warmup + steps):
@@ -506,8 +509,12 @@ def cpu_train_step_seconds(batch: int, size: int, steps: int = 1, warmup: int = 
             if kind == "param":
                 S[k].grad = None
         t0 = time.perf_counter()
-        lo, dm, dp = model_ad_forward(S, mri, pet, train=True)
-        adversarial_loss(lo, dm, dp, y).backward()
+        if model == "model_single":
+            F.cross_entropy(model_single_forward(S, mri, train=True), y).backward()
+        else:
+            fwd = model_ad_forward if model == "model_ad" else model_cnn_ad_forward
+            lo, dm, dp = fwd(S, mri, pet, train=True)
+            adversarial_loss(lo, dm, dp, y).backward()
         t1 = time.perf_counter()
         if it >= warmup:
             dt.append(t1 - t0)

@@ -55,8 +55,12 @@ CASES = {
     # BASELINE configs[4] at the full volume size (structured volumes, batch 2): the conv-only models against the reference
     "cnn_full_b2":    ("model_CNN_ad", dict(dim=128), (96, 96, 96), 2, True, "blobs"),
     "single_full_b2": ("model_single", dict(dim=128), (96, 96, 96), 2, True, "blobs"),
+    # BASELINE configs[4] at its REAL batch (16, 96^3; structured volumes), both readings of "--model CNN": the batch the
+    # bench lines of these models are quoted on, pinned against the reference itself (fp32 and fp64 runs)
+    "cnn_full_b16":    ("model_CNN_ad", dict(dim=128), (96, 96, 96), 16, True, "blobs"),
+    "single_full_b16": ("model_single", dict(dim=128), (96, 96, 96), 16, True, "blobs"),
 }
-DEFAULT = [c for c in CASES if c not in ("ad_full_b8", "ad_128_b8")]
+DEFAULT = [c for c in CASES if c not in ("ad_full_b8", "ad_128_b8", "cnn_full_b16", "single_full_b16")]
 
 
 def build_reference(model, kw, dropout=0.):

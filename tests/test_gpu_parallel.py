@@ -1,6 +1,6 @@
 """Data-parallel wrapper on the real HIP path: two ranks share the one GPU of the test box (gloo backend with
-device tensors — RCCL refuses two ranks on one device), each with its own minibatch shard.  Exercises the
-autograd hooks, the staging stream and the two-stream encoders together; the averaged gradients must equal
+device tensors — RCCL refuses two ranks on one device), each with its own minibatch shard.  Exercises the in-place
+reduction of the nodes' flat gradient buffers, the staging stream and the two-stream encoders together; the averaged gradients must equal
 the mean of single-process per-shard gradients.  The RCCL code path itself (backend "nccl": asynchronous work handles
 on the staging stream, event-driven deep buckets, record_stream) runs in a 1-rank group — all a 1-GPU box allows."""
 import os
@@ -78,66 +78,91 @@ def test_two_ranks_one_gpu_gradient_average(tmp_path):
         assert (a - want).abs().max() <= 1e-6 * max(1.0, want.abs().max().item())
 
 
-def test_deep_block_gradients_carry_an_early_event():
-    """tmf_snet_train_bwd records an event behind the last kernel of blocks conv3.0 .. conv4.3; ops.grad_ready_event finds
-    it for exactly those gradients (and not for conv1 / conv2, nor for a buffer that is not the one of this backward), and
-    behind the event the deep gradients already hold their final values."""
+class _Spy:
+    """A flat-gradient consumer that only records what the whole-pass nodes publish."""
+
+    def __init__(self):
+        self.got = []
+
+    def tmf_flat_grads(self, flat, param_ptrs, views, segments):
+        self.got.append((flat, list(param_ptrs), list(views), list(segments)))
+
+
+def test_whole_pass_nodes_publish_their_flat_gradient_buffers():
+    """Every whole-pass node hands its ONE flat gradient buffer to the registered consumers at the end of its backward
+    (ops.add_flat_grad_consumer): the encoders as [shallow | deep | conv-bias zeros] with the deep range final at the event
+    tmf_snet_train_bwd records behind blocks conv3.0 .. conv4.3 (behind that event the range already holds its final values),
+    the heads as one range; `.grad` of every covered parameter IS the published view (autograd adopts it: no copy).  Without
+    a consumer nothing is published and nothing is held."""
     from transmf_ad_amd import ops
     net = _build().train()
-    ops.GRAD_READY_EVENTS.clear()
-    ops.TRACK_GRAD_EVENTS = False
+    assert not ops._FLAT_GRAD_CONSUMERS
     _loss(net, 0).backward()
-    assert not ops.GRAD_READY_EVENTS            # nobody consumes them: nothing is published (and nothing is held)
     net.zero_grad()
-    ops.TRACK_GRAD_EVENTS = True                # what parallel.GradAllReduce switches on
-    _loss(net, 0).backward()
-    deep = [p for n, p in net.named_parameters() if ".conv3." in n or ".conv4." in n]
-    shallow = [p for n, p in net.named_parameters() if ".conv1." in n or ".conv2." in n]
-    assert len(deep) == 2 * 16 and len(shallow) == 2 * 12
-    evs = [ops.grad_ready_event(p.grad) for p in deep]
-    assert all(e is not None for e in evs) and len({id(e) for e in evs}) == 2          # one event per encoder
-    assert all(ops.grad_ready_event(p.grad) is None for p in shallow)
-    assert all(ops.grad_ready_event(p.grad) is None for n, p in net.named_parameters() if "_cnn." not in n)
-    for e in {id(e): e for e in evs}.values():
-        e.synchronize()
-    early = [p.grad.clone() for p in deep]
-    torch.cuda.synchronize()
-    for a, p in zip(early, deep):
-        assert torch.equal(a, p.grad)
-    assert ops.grad_ready_event(deep[0].grad.clone()) is None                           # another buffer: no event
-    ops.GRAD_READY_EVENTS.clear()
-    ops.TRACK_GRAD_EVENTS = False
+    spy = _Spy()
+    ops.add_flat_grad_consumer(spy)
+    try:
+        _loss(net, 0).backward()
+    finally:
+        ops.remove_flat_grad_consumer(spy)
+    by_ptr = {p.data_ptr(): (n, p) for n, p in net.named_parameters()}
+    enc = [g for g in spy.got if any(ev is not None for _a, _b, ev in g[3])]
+    rest = [g for g in spy.got if not any(ev is not None for _a, _b, ev in g[3])]
+    assert len(enc) == 2 and len(rest) >= 1                      # two encoders; the heads (the dim-32 fusion goes op by op)
+    seen = set()
+    for flat, ptrs, views, segs in spy.got:
+        assert sorted((a, b) for a, b, _e in segs)[0][0] == 0 and max(b for _a, b, _e in segs) == flat.numel()
+        for ptr, v in zip(ptrs, views):
+            if ptr is None:
+                continue
+            n, p = by_ptr[ptr]
+            seen.add(n)
+            assert p.grad.data_ptr() == v.data_ptr() and p.grad.shape == p.shape          # adopted, not copied
+            assert flat.data_ptr() <= v.data_ptr() < flat.data_ptr() + 4 * flat.numel()
+    assert {n for n in by_ptr.values() for n in [n[0]] if "_cnn." in n} <= seen
+    assert any(n.startswith("fc_cls.") for n in seen) and any(n.startswith("D.") for n in seen)
+    for flat, ptrs, views, segs in enc:
+        (d0, d1, ev), (s0, s1, none) = segs
+        assert ev is not None and none is None and (s0, s1, d1) == (0, d0, flat.numel())
+        for ptr, v in zip(ptrs, views):
+            n = by_ptr[ptr][0]
+            off = (v.data_ptr() - flat.data_ptr()) // 4
+            deep = ".conv3." in n or ".conv4." in n or (n.endswith(".bias") and by_ptr[ptr][1].dim() == 1 and
+                                                        n.split(".")[-2] in ("0", "3"))        # conv biases: zeros, filled first
+            assert (off >= d0) == deep, (n, off, d0)
+        ev.synchronize()
+        early = flat[d0:d1].clone()
+        torch.cuda.synchronize()
+        assert torch.equal(early, flat[d0:d1])
+    del spy
+    assert not ops._FLAT_GRAD_CONSUMERS
 
 
-def test_bucket_groups_follow_the_deep_shallow_split(tmp_path):
-    """With the wrapper, the deep-block buckets of both encoders wait for their event, not for the producing stream; the
-    shared shallow bucket waits for both encoder streams."""
+def test_wrapper_reduces_the_flat_buffers_in_place(tmp_path):
+    """With the wrapper (1-rank gloo group, machinery forced live): heads behind their stream at once, each encoder's deep
+    range behind its event, the encoders' shallow ranges at the end of backward, and whatever has no flat buffer (the dim-32
+    fusion block runs op by op) through the end-of-backward buckets — no per-parameter hooks anywhere."""
     world = 1
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", TMF_DDP_FORCE="1")
     try:
         from transmf_ad_amd.parallel import GradAllReduce
         dist.init_process_group("gloo", rank=0, world_size=world)
-        net = GradAllReduce(_build(), bucket_mb=64.0)
-        names = {p: n for n, p in net.module.named_parameters()}
-        kinds = []
-        for b in net._buckets:
-            ns = [names[p] for p in b.params]
-            kinds.append("deep" if all(".conv3." in n or ".conv4." in n for n in ns) else
-                         "shallow" if all(".conv1." in n or ".conv2." in n for n in ns) else "other")
-        assert kinds == ["other", "deep", "shallow", "deep"], kinds
-        seen = {}
-        orig = net._launch
-
-        def spy(b):
-            seen[id(b)] = (len(b.events), len(b.streams))
-            return orig(b)
-        net._launch = spy
+        inner = _build()
+        net = GradAllReduce(inner, bucket_mb=64.0)
+        assert all(not p._post_accumulate_grad_hooks for p in inner.parameters())
         net.train()
+        ref = _build().train()
+        _loss(ref, 0).backward()
         _loss(net, 0).backward()
         torch.cuda.synchronize()
-        for b, k in zip(net._buckets, kinds):
-            ev, st = seen[id(b)]
-            assert (ev == 1 and st == 0) if k == "deep" else (ev == 0 and st >= 1), (k, ev, st)
+        kinds = net.last_reduced_kinds
+        assert kinds.count("event") == 2 and kinds.count("end") == 2 and kinds.count("stream") >= 1, kinds
+        assert kinds.count("bucket") >= 1 and kinds.index("stream") < kinds.index("event") < kinds.index("end"), kinds
+        names = {p: n for n, p in inner.named_parameters()}
+        covered = sum(b for b, k in zip(net.last_reduced_bytes, kinds) if k != "bucket")
+        assert covered == 4 * sum(p.numel() for p, n in names.items() if "_cnn." in n or n.startswith(("fc_cls.", "D.")))
+        for (n, p), q in zip(inner.named_parameters(), ref.parameters()):
+            assert torch.equal(p.grad, q.grad), n                          # one rank: the sum over ranks / 1 is exact
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -170,16 +195,12 @@ def _nccl_one_rank_worker(_rank, port, out_dir, full):
         launched = []
         if wrapped:
             model.timing = True
-            orig = model._launch
-
-            def spy(b, _o=orig):
-                launched.append((len(b.events), len(b.streams), b.tagged))
-                return _o(b)
-            model._launch = spy
         for it in range(3):
             opt.zero_grad(set_to_none=(it == 0))
             lo, dm, dp = model(mri, pet)
             (ce(lo, y) + (ce(dm, torch.ones_like(y)) + ce(dp, torch.zeros_like(y))) / 2).backward()
+            if wrapped:
+                launched.append(list(model.last_reduced_kinds))
             opt.step()
         torch.cuda.synchronize()
         res[wrapped] = {"params": [p.detach().cpu() for p in net.parameters()], "grads": [p.grad.cpu() for p in net.parameters()],
@@ -193,8 +214,8 @@ def _nccl_one_rank_worker(_rank, port, out_dir, full):
 def test_rccl_one_rank_group_matches_unwrapped_model(tmp_path, full):
     """backend "nccl" (= RCCL) with ONE rank on the box's GPU: three Adam steps of the wrapped model are BITWISE the steps of
     the unwrapped model (all-reduce over one rank and the division by 1 are exact), incl. zero_grad(set_to_none=False);
-    every bucket was launched every step, the deep-block buckets of the first step behind ONE event and no stream (the event
-    path of tmf_snet_train_bwd), everything else behind streams; the exposed all-reduce times are finite (no stream leak)."""
+    the first step reduces the nodes' flat gradient buffers in place (the encoders' deep ranges behind the event of
+    tmf_snet_train_bwd), the accumulating steps go through the buckets; the exposed all-reduce times are finite."""
     mp.spawn(_nccl_one_rank_worker, args=(_free_port(), str(tmp_path), full), nprocs=1, join=True)
     res = torch.load(tmp_path / "res.pt", weights_only=False)
     w, u = res[True], res[False]
@@ -202,12 +223,12 @@ def test_rccl_one_rank_group_matches_unwrapped_model(tmp_path, full):
         assert torch.equal(a, b)
     for a, b in zip(w["grads"], u["grads"]):
         assert torch.equal(a, b)
-    assert len(w["launched"]) == 3 * w["nbuckets"] and w["nbuckets"] >= 3
-    # step 1 (fresh gradients = views of tmf_snet_train_bwd's flat buffer): the deep buckets wait for ONE event and no
-    # stream; steps 2, 3 (set_to_none=False: autograd accumulates IN PLACE into the bucket views, on the producing stream):
-    # no event applies to that add, the buckets wait for the streams
-    deep = [l for l in w["launched"] if l[2]]
-    assert len(deep) == 3 * 2 and all(ev == 1 and st == 0 for ev, st, _t in deep[:2]), deep
-    assert all(ev == 0 and st >= 1 for ev, st, _t in deep[2:]), deep
-    assert all(ev == 0 and st >= 1 for ev, st, t in w["launched"] if not t)
+    # step 1 (fresh gradients: autograd adopts the nodes' views): heads (and, dim 128, the fusion block) in place behind their
+    # stream, the encoders' deep ranges behind ONE event each, their shallow ranges at the end; steps 2, 3 (set_to_none=False:
+    # autograd accumulates into the existing .grad tensors, on the producing stream): nothing may be reduced in place — every
+    # parameter goes through the end-of-backward buckets
+    first, later = w["launched"][0], w["launched"][1:]
+    assert first.count("event") == 2 and first.count("end") == 2 and first.count("stream") == (2 if full else 1), first
+    assert first.count("bucket") == (0 if full else first.count("bucket")) and (full or first.count("bucket") >= 1), first
+    assert all(k and set(k) == {"bucket"} and len(k) == w["nbuckets"] for k in later), later
     assert len(w["exposed"]) == 3 and all(np.isfinite(x) and 0 <= x < 1e3 for x in w["exposed"]), w["exposed"]

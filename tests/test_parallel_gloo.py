@@ -1,5 +1,5 @@
-"""The N>1 data-parallel path on CPU: world_size-2 gloo process group, bucketed asynchronous
-all-reduce from autograd hooks (transmf_ad_amd.parallel.GradAllReduce).  The wrapped module is the
+"""The N>1 data-parallel path on CPU: world_size-2 gloo process group, the end-of-backward bucket path of
+transmf_ad_amd.parallel.GradAllReduce (a wrapped module that is not one of the HIP models has no flat gradient buffers).  The wrapped module is the
 CPU oracle of model_ad (tiny configuration), one different minibatch shard per rank; the averaged
 gradients must equal the mean of the per-shard single-process gradients (BatchNorm stays per
 replica)."""
@@ -156,12 +156,15 @@ def _unused_worker(rank, world, port, out_dir):
     from transmf_ad_amd.parallel import GradAllReduce, init_from_env
     init_from_env("gloo")
     torch.manual_seed(0)
-    m = nn.Sequential(nn.Linear(4, 4), nn.Linear(4, 4), nn.Linear(4, 2))
-    extra = nn.Linear(4, 4)                       # registered but never used in forward
+    class Net(nn.Sequential):
+        def forward(self, x):                     # `unused` is registered but takes no part in forward
+            return self[2](self[1](self[0](x)))
+    m = Net(nn.Linear(4, 4), nn.Linear(4, 4), nn.Linear(4, 2))
+    extra = nn.Linear(4, 4)
     m.add_module("unused", extra)
     net = GradAllReduce(m, bucket_mb=0.0001)
     x = torch.randn(3, 4) + rank
-    m[2](m[1](m[0](x))).sum().backward()
+    net(x).sum().backward()                       # through the wrapper, as with torch DDP
     ok = extra.weight.grad is None and extra.bias.grad is None and all(p.grad is not None for p in m[0].parameters())
     g0 = m[0].weight.grad.clone()
     torch.save(dict(ok=ok, g0=g0), os.path.join(out_dir, f"u{rank}.pt"))

@@ -514,33 +514,32 @@ def snet_eval_one_call(vol, dim, eps, slope, blocks):
     return out
 
 
-# Gradient tensors whose producing kernels finish BEFORE the backward call that produced them returns: data pointer ->
-# (event recorded behind their last kernel, the flat buffer they are views of, owner).  Filled by SNetTrain.backward for
-# the deep blocks of an encoder, consumed by parallel.GradAllReduce (which then waits for the event instead of for the
-# whole producing stream).  An entry HOLDS its flat buffer, so the address cannot be handed to another tensor while the
-# entry exists (a stale event for a new tensor at the same address would be a race); entries are dropped by the wrapper
-# at the end of every backward, and an encoder's forward drops the entries of ITS OWN previous backward only (owner =
-# the encoder's first parameter) — another model's forward between a backward and the wrapper's hook takes nothing away.
-GRAD_READY_EVENTS = {}
-# Entries are only written while somebody consumes them (parallel.GradAllReduce switches this on; it also clears the table at
-# the end of every backward): without a consumer a model that is never stepped again would leave its last entries — and the
-# gradient buffer they hold — behind for the life of the process (k-fold training builds one model per fold).
-TRACK_GRAD_EVENTS = False
+# Every whole-pass autograd node below (SNetTrain, FusionTrain, HeadsAD, HeadsCNN) writes ALL of its parameter gradients
+# into ONE flat buffer and hands autograd views of it.  A data-parallel wrapper (parallel.GradAllReduce) registers itself
+# here as a consumer and is told, at the end of each node's backward, about that buffer: it then all-reduces the buffer IN
+# PLACE on its own stream (no per-parameter hooks, no pack copies; `param.grad` ends up as a view of the reduced buffer).
+# A segment (start, stop, event) says when elements [start, stop) are final: behind `event` (recorded on the producing
+# stream in the middle of the node's backward: the deep blocks of an encoder, finished while conv2 / conv1 still run) or,
+# event None, behind everything the producing stream has been handed so far.  The set holds consumers WEAKLY: with no
+# wrapper alive nothing is published and nothing is kept (k-fold training builds and drops one model per fold).
+import weakref
+
+_FLAT_GRAD_CONSUMERS = weakref.WeakSet()
 
 
-def grad_ready_event(grad):
-    """The event behind the last kernel that writes `grad`, if one was recorded for exactly this buffer."""
-    ent = GRAD_READY_EVENTS.get(grad.data_ptr())
-    if ent is None:
-        return None
-    ev, flat, _owner = ent
-    same = grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
-    return ev if same else None
+def add_flat_grad_consumer(consumer) -> None:
+    """consumer.tmf_flat_grads(flat, param_ptrs, views, segments) is called at the end of every whole-pass backward."""
+    _FLAT_GRAD_CONSUMERS.add(consumer)
 
 
-def _drop_grad_events(owner):
-    for k in [k for k, v in GRAD_READY_EVENTS.items() if v[2] == owner]:
-        del GRAD_READY_EVENTS[k]
+def remove_flat_grad_consumer(consumer) -> None:
+    _FLAT_GRAD_CONSUMERS.discard(consumer)
+
+
+def _publish_flat_grads(flat, param_ptrs, views, segments) -> None:
+    """param_ptrs[i]: data pointer of the parameter whose gradient is views[i] (None: that input got no gradient)."""
+    for c in list(_FLAT_GRAD_CONSUMERS):
+        c.tmf_flat_grads(flat, param_ptrs, views, segments)
 
 
 class SNetTrain(torch.autograd.Function):
@@ -552,8 +551,6 @@ class SNetTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vol, cfg, buffers, *params):
         import ctypes as C
-        ctx.owner = params[0].data_ptr()
-        _drop_grad_events(ctx.owner)            # this encoder's previous backward (nothing of it is pending in its forward)
         vol = _chk(vol, "vol")
         dim, momentum, eps, slope = cfg[:4]
         mode, act16 = resolve_precision(cfg[4] if len(cfg) > 4 else None)
@@ -580,6 +577,7 @@ class SNetTrain(torch.autograd.Function):
         ctx.save_for_backward(vol, saved)
         ctx.desc = desc
         ctx.shapes = [None if p is None else p.shape for p in params]
+        ctx.param_ptrs = [None if p is None else p.data_ptr() for p in params]
         # the gradient buffer, its views and the gradient table of backward, set up while the GPU is busy (see FusionTrain)
         ctx.bwd = SNetTrain._prepare_backward(ctx.shapes, ctx.needs_input_grad, vol.device) if any(ctx.needs_input_grad[3:]) else None
         return out
@@ -588,9 +586,14 @@ class SNetTrain(torch.autograd.Function):
     def _prepare_backward(shapes, need, dev):
         sizes = [0 if s is None else s.numel() for s in shapes]
         flat = torch.empty(sum(sizes), device=dev, dtype=_f32)        # all 28 gradients in one allocation
-        # the seven conv-bias gradients (exact zeros) sit back to back at the end: the library fills them with one memset
-        order = [i for i in range(len(sizes)) if i % 4 != 1] + [i for i in range(len(sizes)) if i % 4 == 1]
+        # layout [shallow blocks 0 .. DEEP_FROM-1 | deep blocks DEEP_FROM .. 6 | the seven conv-bias gradients]: the bias
+        # gradients (exact zeros) sit back to back at the end — the library fills them with ONE memset at the START of
+        # backward — so [deep | biases] is one contiguous range that is final at `deep_event`
+        shallow = [i for i in range(4 * _lib.SNET_DEEP_FROM) if i % 4 != 1]
+        order = shallow + [i for i in range(4 * _lib.SNET_DEEP_FROM, len(sizes)) if i % 4 != 1] + \
+            [i for i in range(len(sizes)) if i % 4 == 1]
         parts = dict(zip(order, flat.split([sizes[i] for i in order])))
+        o_deep = sum(sizes[i] for i in shallow)
         grads = [None if s is None else (parts[i] if len(s) == 1 else parts[i].view(s)) for i, s in enumerate(shapes)]
         ptr = [parts[i].data_ptr() for i in range(len(sizes))]
         g = _lib.SnetGrads()
@@ -603,7 +606,7 @@ class SNetTrain(torch.autograd.Function):
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))               # (creates the handle; the library re-records it in backward)
         g.deep_event = ev.cuda_event
-        return flat, grads, g, ev
+        return flat, grads, g, ev, o_deep
 
     @staticmethod
     def backward(ctx, dout):
@@ -615,12 +618,7 @@ class SNetTrain(torch.autograd.Function):
         dout = _chk(dout, "grad_output")
         prep = ctx.bwd if ctx.bwd is not None else SNetTrain._prepare_backward(ctx.shapes, ctx.needs_input_grad, vol.device)
         ctx.bwd = None
-        flat, grads, g, ev = prep
-        for l in range(_lib.SNET_DEEP_FROM, 7 if TRACK_GRAD_EVENTS else 0):
-            for j in range(4):
-                t_ = grads[4 * l + j]
-                if t_ is not None and t_.numel():
-                    GRAD_READY_EVENTS[t_.data_ptr()] = (ev, flat, ctx.owner)
+        flat, grads, g, ev, o_deep = prep
         nscr = _lib.query("tmf_snet_bwd_scratch_bytes", C.byref(desc))
         scratch = torch.empty(nscr, device=vol.device, dtype=torch.uint8)
         _lib.call("tmf_snet_train_bwd", C.byref(desc), vol.data_ptr(), saved.data_ptr(), saved.numel(), dout.data_ptr(),
@@ -628,6 +626,9 @@ class SNetTrain(torch.autograd.Function):
         out = [None, None, None]
         for i, gr in enumerate(grads):
             out.append(gr if (gr is not None and ctx.needs_input_grad[3 + i]) else None)
+        if _FLAT_GRAD_CONSUMERS and all(ctx.needs_input_grad[3 + i] for i, gr in enumerate(grads) if gr is not None):
+            # shallow blocks: final when this call's last kernel is; deep blocks + bias zeros: final at the event
+            _publish_flat_grads(flat, ctx.param_ptrs, grads, [(o_deep, flat.numel(), ev), (0, o_deep, None)])
         return tuple(out)
 
 
@@ -939,6 +940,7 @@ class FusionTrain(torch.autograd.Function):
         ctx.save_for_backward(mri, pet, saved, *params)     # parameters too: autograd then rejects an in-place update
         ctx.desc, ctx.inst = desc, inst                     # between forward and backward; their pointers stay valid:
         ctx.masks = masks                                   # the ctypes structs are reused as they are
+        ctx.param_ptrs = [t.data_ptr() for t in params]
         # Everything backward needs besides the incoming gradient is set up NOW, while the GPU is busy with the forward:
         # backward starts right behind the reference step's two loss.item() host syncs (kfold_train_adversarial.py:127-128),
         # where every microsecond of host preparation is a microsecond of idle GPU (measured: 140 us of gap in front of the
@@ -990,9 +992,11 @@ class FusionTrain(torch.autograd.Function):
         dcls = _chk(dcls, "grad_output")
         prep = ctx.bwd if ctx.bwd is not None else FusionTrain._prepare_backward(desc, mri, pet)
         ctx.bwd = None
-        grads, _flat, out, dm, dp, scratch, nscr = prep
+        grads, flat, out, dm, dp, scratch, nscr = prep
         _lib.call("tmf_fusion_train_bwd", C.byref(desc), mri.data_ptr(), pet.data_ptr(), inst, saved.data_ptr(),
                   saved.numel(), dcls.data_ptr(), grads, dm.data_ptr(), dp.data_ptr(), scratch.data_ptr(), nscr, _stream())
+        if _FLAT_GRAD_CONSUMERS and all(ctx.needs_input_grad[3:]):
+            _publish_flat_grads(flat, ctx.param_ptrs, out[3:], [(0, flat.numel(), None)])
         return tuple(out)
 
 
@@ -1040,6 +1044,7 @@ class HeadsAD(torch.autograd.Function):
         ctx.masks = (m1, m2)
         ctx.desc, ctx.prm, ctx.alpha = desc, prm, float(alpha)
         ctx.tok_shape = tuple(mri.shape)
+        ctx.param_ptrs = [t.data_ptr() for t in params]
         # backward's buffers and gradient table, set up while the GPU is still busy with the forward (see FusionTrain)
         ctx.bwd = HeadsAD._prepare_backward(desc, cls, params, ctx.tok_shape) if any(ctx.needs_input_grad) else None
         return outs[0], outs[1], outs[2]
@@ -1072,7 +1077,7 @@ class HeadsAD(torch.autograd.Function):
         desc = ctx.desc
         prep = ctx.bwd if ctx.bwd is not None else HeadsAD._prepare_backward(desc, cls, params, ctx.tok_shape)
         ctx.bwd = None
-        g, _flat, grads, d_cls, d_tok, scratch, nscr, zero = prep
+        g, flat, grads, d_cls, d_tok, scratch, nscr, zero = prep
         # the three output gradients go to the library as they are (no stack / copy launch in front of the kernel)
         dl = [zero if t is None else (t if (t.dtype == _f32 and t.is_contiguous()) else t.to(_f32).contiguous())
               for t in (dlo, ddm, ddp)]
@@ -1080,6 +1085,8 @@ class HeadsAD(torch.autograd.Function):
         _lib.call("tmf_heads_bwd", C.byref(desc), cls.data_ptr(), _ptr(m1), _ptr(m2), C.byref(ctx.prm), saved.data_ptr(),
                   saved.numel() * 4, dl[0].data_ptr(), dl[1].data_ptr(), dl[2].data_ptr(), C.byref(g), d_cls.data_ptr(),
                   d_tok[0].data_ptr(), d_tok[1].data_ptr(), ctx.alpha, scratch.data_ptr(), nscr, _stream())
+        if _FLAT_GRAD_CONSUMERS and all(ctx.needs_input_grad[7:]):
+            _publish_flat_grads(flat, ctx.param_ptrs, grads, [(0, flat.numel(), None)])
         return (d_cls, d_tok[0], d_tok[1], None, None, None, None, *grads)
 
 
@@ -1125,6 +1132,7 @@ class HeadsCNN(torch.autograd.Function):
         ctx.save_for_backward(saved, *params)
         ctx.desc, ctx.prm, ctx.alpha, ctx.with_d = desc, prm, float(alpha), with_d
         ctx.tok_shape = tuple(mri.shape)
+        ctx.param_ptrs = [t.data_ptr() for t in params]
         ctx.bwd = HeadsCNN._prepare_backward(desc, mri.device, params, ctx.tok_shape) if any(ctx.needs_input_grad) else None
         return (outs[0], outs[1], outs[2]) if with_d else outs[0]
 
@@ -1154,13 +1162,15 @@ class HeadsCNN(torch.autograd.Function):
         desc = ctx.desc
         prep = ctx.bwd if ctx.bwd is not None else HeadsCNN._prepare_backward(desc, saved.device, params, ctx.tok_shape)
         ctx.bwd = None
-        g, _flat, grads, d_tok, scratch, nscr, zero = prep
+        g, flat, grads, d_tok, scratch, nscr, zero = prep
         dl = [zero if t is None else (t if (t.dtype == _f32 and t.is_contiguous()) else t.to(_f32).contiguous())
               for t in (dlo, ddm, ddp)]
         two = desc.M == 2
         _lib.call("tmf_heads_cnn_bwd", C.byref(desc), C.byref(ctx.prm), saved.data_ptr(), saved.numel() * 4, dl[0].data_ptr(),
                   dl[1].data_ptr() if ctx.with_d else None, dl[2].data_ptr() if ctx.with_d else None, C.byref(g),
                   d_tok[0].data_ptr(), d_tok[1].data_ptr() if two else None, ctx.alpha, scratch.data_ptr(), nscr, _stream())
+        if _FLAT_GRAD_CONSUMERS and all(ctx.needs_input_grad[4:]):
+            _publish_flat_grads(flat, ctx.param_ptrs, grads, [(0, flat.numel(), None)])
         return (d_tok[0], d_tok[1] if two else None, None, None, *grads)
 
 

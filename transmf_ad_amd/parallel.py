@@ -7,18 +7,23 @@ there is no call pattern to mirror; this is sized for the path itself:
   * the replica is whole (4.17 M parameters = 16.7 MB of fp32 gradients for model_ad), each rank
     runs the reference batch of 8 pairs, BatchNorm statistics stay per replica (reference
     semantics at batch 8 — no SyncBN);
-  * gradients are packed into a few flat buckets in REVERSE registration order — the order
-    backward produces them: heads and fusion transformer first, then conv4 ... conv1 — and
-    each bucket's all-reduce is launched asynchronously from a post-accumulate-grad hook the
-    moment its last gradient lands: the heads + fusion bucket rides under the encoders' backward;
-    an encoder's deep blocks (conv3, conv4: 95 % of its bytes) have a bucket of their own that
-    waits for the event tmf_snet_train_bwd records behind them and rides under conv2 / conv1;
-    the shallow blocks of both encoders share the small last bucket.  xGMI is point-to-point (≈153 GB/s per link): a ring over 8 GPUs moves
-    2*(7/8)*16.7 MB ≈ 29 MB per GPU per step (≈0.2 ms on one link) — few, large buckets keep
-    that bandwidth-bound rather than latency-bound;
-  * a queued autograd callback waits for the buckets, averages, and re-points ``param.grad`` at views of
-    the reduced buckets before ``optimizer.step()`` — the reference's train_step is unchanged.  Per step this
-    costs one multi-tensor pack, one all-reduce and one scale per bucket (no per-parameter kernels).
+  * every whole-pass autograd node of the models (heads, fusion transformer, each encoder) already writes ALL of its
+    parameter gradients into ONE flat buffer and hands autograd views of it (ops.SNetTrain / FusionTrain / HeadsAD /
+    HeadsCNN).  The wrapper is told about each buffer at the end of the node's backward (ops.add_flat_grad_consumer) and
+    all-reduces it IN PLACE, asynchronously, on a staging stream: no per-parameter hooks, no pack copies, and
+    ``param.grad`` simply is a view of the reduced buffer.  Order = the order backward produces them: heads (1.3 MB) and
+    fusion (4.7 MB) first — they ride under the encoders' backward; an encoder's deep blocks (conv3, conv4: 95 % of its
+    bytes) are final at the event tmf_snet_train_bwd records behind them and ride under conv2 / conv1; only the shallow
+    blocks of the two encoders (0.33 MB each) are reduced after backward's last kernel.  xGMI is
+    point-to-point (≈153 GB/s per link): a ring over 8 GPUs moves 2*(7/8)*16.7 MB ≈ 29 MB per GPU per step (≈0.2 ms on
+    one link) — six collectives per step, four of them large;
+  * anything that does not arrive that way — a module on the op-per-launch path, a wrapped module that is not one of ours
+    (the CPU tests wrap the oracle), a backward that accumulates into existing ``.grad`` tensors
+    (``zero_grad(set_to_none=False)``) — is reduced at the END of backward from ``param.grad`` through a few flat buckets
+    (reverse registration order, ``bucket_mb`` each); correct for every module, without overlap;
+  * one tensor hook per model output queues the end-of-backward callback (three hooks for model_ad instead of one per
+    parameter); the callback waits for the collectives, averages, and hands the step back to the caller's stream — the
+    reference's train_step is unchanged.
 """
 from __future__ import annotations
 
@@ -39,6 +44,8 @@ class _NullCtx:
 
 
 class _Bucket:
+    """Fallback path: a flat buffer for the gradients of `params`, allocated on first use."""
+
     def __init__(self, params: List[nn.Parameter]):
         self.params = params
         self.numel = sum(p.numel() for p in params)
@@ -47,21 +54,25 @@ class _Bucket:
         for p in params:
             self.offsets.append(o)
             o += p.numel()
-        p0 = params[0]
-        self.flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
-        self.pending = len(params)
-        self.filled = [False] * len(params)
-        self.work = None
-        self.streams = {}
-        self.events = []
-        self.tagged = all(getattr(p, "tmf_bucket_group", (None,))[0] == "sNet deep" for p in params)
+        self._flat = None
+        self._views = None
 
-    def reset(self):
-        self.pending = len(self.params)
-        self.filled = [False] * len(self.params)
-        self.work = None
-        self.streams = {}
-        self.events = []
+    @property
+    def nbytes(self):
+        return self.numel * self.params[0].element_size()
+
+    def flat(self):
+        if self._flat is None:
+            p0 = self.params[0]
+            self._flat = torch.zeros(self.numel, dtype=p0.dtype, device=p0.device)
+        return self._flat
+
+    def views(self):
+        # built once per bucket (the flat buffer lives as long as the wrapper): ~100 small parameters cost ~200 us to slice
+        if self._views is None:
+            f = self.flat()
+            self._views = [f[o:o + p.numel()].view_as(p) for o, p in zip(self.offsets, self.params)]
+        return self._views
 
 
 class GradAllReduce(nn.Module):
@@ -74,42 +85,40 @@ class GradAllReduce(nn.Module):
     def __init__(self, module: nn.Module, process_group=None, bucket_mb: float = 6.0,
                  broadcast_from_rank0: bool = True):
         super().__init__()
-        from . import ops
-        ops.TRACK_GRAD_EVENTS = True         # the encoder nodes publish their early events from now on (ops.GRAD_READY_EVENTS)
         if not dist.is_available() or not dist.is_initialized():
             raise RuntimeError("GradAllReduce needs an initialised torch.distributed process group")
         self.module = module
         self.group = process_group
         self.world = dist.get_world_size(process_group)
         self._buckets: List[_Bucket] = []
-        self._where = {}
         self._callback_queued = False
         self._streams = {}
         self.require_sync = True
-        # timing = True: record a pair of events per step around "all buckets reduced" on the staging stream — the time
+        # timing = True: record a pair of events per step around "all collectives done" on the staging stream — the time
         # backward's END has to wait for the collectives that did not hide under it (exposed_allreduce_ms())
         self.timing = False
         self._timing_events = []
-        # TMF_DDP_FORCE=1 keeps the bucket machinery live in a 1-rank group (to measure its overhead on one GPU)
+        # TMF_DDP_FORCE=1 keeps the machinery live in a 1-rank group (to measure its overhead on one GPU)
         self._force = os.environ.get("TMF_DDP_FORCE", "0") == "1"
-        # TMF_DDP_EVENTS=0: every bucket waits for the whole producing stream (no early start of the deep-block buckets)
+        # TMF_DDP_EVENTS=0: an encoder's deep-block range waits for the whole producing stream like everything else
         self._early = os.environ.get("TMF_DDP_EVENTS", "1") != "0"
+        # TMF_DDP_INPLACE=0: ignore the nodes' flat gradient buffers — everything goes through the end-of-backward buckets
+        self._inplace_ok = os.environ.get("TMF_DDP_INPLACE", "1") != "0"
         self._live = self.world > 1 or self._force
         # a module that runs parts of its backward on streams of its own says so (`tmf_backward_streams(device)` -> the
-        # streams besides the caller's): the hooks then need not look up the current stream for every gradient
+        # streams besides the caller's); without it the end-of-backward reduction waits for the caller's stream only
         self._known_streams = getattr(module, "tmf_backward_streams", None)
         params = [p for p in module.parameters() if p.requires_grad]
+        self._params = params
+        self._by_ptr = None                     # data pointer -> Parameter, rebuilt when a lookup misses (.to(), load)
         if broadcast_from_rank0 and self.world > 1:
             with torch.no_grad():
                 for t in list(module.parameters()) + list(module.buffers()):
                     dist.broadcast(t, 0, group=process_group)
         cap = int(bucket_mb * (1 << 20))
-        # Buckets fill in REVERSE registration order (the order backward produces gradients), a new one when the cap would
-        # be exceeded.  A module may tag parameters with `tmf_bucket_group`: tagged parameters only share a bucket with
-        # their own group (which may be spread over the model).  sNet tags its deep blocks (conv3, conv4: 95 % of an
-        # encoder's bytes, complete long before the encoder's backward call returns — ops.GRAD_READY_EVENTS — so their
-        # bucket starts its all-reduce under conv2 / conv1) per encoder, and the shallow blocks of ALL encoders as one group
-        # (one small bucket at the very end instead of one per encoder).
+        # Fallback buckets fill in REVERSE registration order (the order backward produces gradients), a new one when the cap
+        # would be exceeded.  A module may tag parameters with `tmf_bucket_group`: tagged parameters only share a bucket with
+        # their own group (sNet tags its deep blocks per encoder and the shallow blocks of ALL encoders as one group).
         plan, sizes, named = [], [], {}
         cur = None
         for p in reversed(params):
@@ -128,153 +137,199 @@ class GradAllReduce(nn.Module):
             else:
                 named[gk] = i
                 cur = None                       # an untagged run does not continue across tagged parameters
+        self._where = {}
         for b_ in plan:
-            self._add_bucket(b_)
-        for p in params:
-            p.register_post_accumulate_grad_hook(self._on_grad)
-
-    # -- construction ----------------------------------------------------------------------
-    def _add_bucket(self, params):
-        b = _Bucket(list(params))
-        for i, p in enumerate(b.params):
-            self._where[p] = (b, i)
-        self._buckets.append(b)
+            b = _Bucket(list(b_))
+            for i, p in enumerate(b.params):
+                self._where[p] = (b, i)
+            self._buckets.append(b)
+        # this backward's in-place reductions: (flat, params, views, [work, ...]) per published buffer
+        self._inplace = []
+        self._covered = set()
+        self._checked_steps = 0
+        self.last_reduced_bytes = []            # bytes of every collective of the last backward, in launch order
+        self.last_reduced_kinds = []            # "event" | "stream" | "end" (in place) | "bucket" per collective
+        if self._live and self._inplace_ok:
+            from . import ops
+            ops.add_flat_grad_consumer(self)    # held weakly: nothing is published once the wrapper is gone
 
     @property
     def bucket_sizes_bytes(self):
-        return [b.numel * b.flat.element_size() for b in self._buckets]
+        """Sizes of the fallback buckets (the end-of-backward path)."""
+        return [b.nbytes for b in self._buckets]
 
     # -- backward-time machinery -----------------------------------------------------------
     # Gradients are produced on more than one HIP stream (the MRI and PET encoders run on two streams and
-    # autograd replays each backward on its forward stream).  All bucket traffic therefore goes through ONE
-    # staging stream per device: it waits for the producing stream, packs the gradient, and issues the
-    # collective; RCCL orders itself against that stream.
+    # autograd replays each backward on its forward stream).  All collective traffic therefore goes through ONE
+    # staging stream per device: it waits for the producing stream (or event) and issues the collective; RCCL orders
+    # itself against that stream.
     def _staging(self, device):
         key = (device.type, device.index)
         if key not in self._streams:
             self._streams[key] = torch.cuda.Stream(device=device)
         return self._streams[key]
 
-    def _views(self, b):
-        # built once per bucket (the flat buffer lives as long as the wrapper): a bucket of ~100 small parameters costs
-        # ~200 us of Python to slice, and the heads + fusion bucket is packed while the GPU waits for the encoders' backward
-        v = getattr(b, "_view_cache", None)
-        if v is None:
-            v = b._view_cache = [b.flat[o:o + p.numel()].view_as(p) for o, p in zip(b.offsets, b.params)]
-        return v
+    def _param_of(self, ptr):
+        m = self._by_ptr
+        if m is None or ptr not in m:
+            m = self._by_ptr = {p.data_ptr(): p for p in self._params}
+        return m.get(ptr)
 
-    def _launch(self, b):
-        """Pack the bucket with ONE multi-tensor copy (all of its gradients exist by now) and start its all-reduce.
-        Gradients come from more than one stream (MRI / PET encoders): the staging stream waits on every stream a
-        hook of this bucket fired on."""
-        views = self._views(b)
-        grads, dst = [], []
-        for i, p in enumerate(b.params):
-            if b.filled[i] and p.grad is not None:
-                g = p.grad
-                grads.append(g if g.shape == p.shape else g.reshape(p.shape))
-                dst.append(views[i])
-            else:                               # no gradient this pass: contribute zeros
-                views[i].zero_()
-        if grads:
-            torch._foreach_copy_(dst, grads)
-        b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-
-    def _on_grad(self, p: torch.Tensor):
-        # Runs once per parameter in the middle of backward, and the start of backward (heads, fusion: ~100 small
-        # parameters) is launch-bound: every microsecond here is a microsecond of idle GPU.  So a hook only counts; what a
-        # bucket has to wait for is worked out once, when its last gradient lands.
-        if not (self._live and self.require_sync):
-            return
-        b, i = self._where[p]
-        if b.filled[i]:
-            return
-        b.filled[i] = True
-        b.pending -= 1
-        if not self._callback_queued:
+    def _on_backward_start(self, _grad):
+        """Tensor hook on the wrapped module's outputs: the first gradient of a backward pass queues the end-of-backward
+        callback.  Nothing else happens per gradient."""
+        if self._live and self.require_sync and not self._callback_queued:
             self._callback_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
-        if self._known_streams is None and p.grad.is_cuda:          # a module of unknown stream use: track per gradient
-            cur = torch.cuda.current_stream(p.device)
-            b.streams[cur.cuda_stream] = cur
-        if b.pending == 0:
-            self._complete(b, p)
+        return None
 
-    def _complete(self, b, p):
-        if not p.grad.is_cuda:
-            self._launch(b)
+    def tmf_flat_grads(self, flat, param_ptrs, views, segments):
+        """ops._publish_flat_grads: a whole-pass node finished enqueueing its backward; `views[i]` (a view of `flat`) is the
+        gradient of the parameter at `param_ptrs[i]`.  If every one of them is ours and autograd will ADOPT the views (no
+        ``.grad`` to accumulate into), all-reduce the ranges of `flat` in place, each behind its event / the producing
+        stream."""
+        if not (self._live and self.require_sync and flat.is_cuda):
             return
-        dev = p.device
+        params = []
+        for ptr, v in zip(param_ptrs, views):
+            if ptr is None or v is None:
+                continue
+            p = self._param_of(ptr)
+            if p is None or p.grad is not None or p in self._covered:
+                return                          # not ours / accumulation into an existing .grad: end-of-backward path
+            params.append((p, v))
+        if not params:
+            return
+        if not self._callback_queued:           # (a backward started from an output the wrapper never saw)
+            self._callback_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+        dev = flat.device
         st = self._staging(dev)
-        ev = None
-        if self._early and b.tagged:
-            # a tagged bucket's gradients come out of ONE backward call that recorded ONE event behind them (sNet deep
-            # blocks): take the event when the first and the last gradient of the bucket both carry it
-            from . import ops
-            g0, g1 = b.params[0].grad, b.params[-1].grad
-            e0 = ops.grad_ready_event(g0) if g0 is not None else None
-            e1 = ops.grad_ready_event(g1) if g1 is not None else None
-            if e0 is not None and e0 is e1:
-                ev = e0
-        if ev is not None:
-            b.events.append(ev)
-            st.wait_event(ev)
-        else:
-            cur = torch.cuda.current_stream(dev)
-            b.streams[cur.cuda_stream] = cur
-            if self._known_streams is not None:
-                for s_ in self._known_streams(dev):
-                    b.streams[s_.cuda_stream] = s_
-            for s_ in b.streams.values():
-                st.wait_stream(s_)
-        with torch.cuda.stream(st):
-            self._launch(b)
-            for q in b.params:
-                if q.grad is not None:
-                    q.grad.record_stream(st)
+        works, deferred = [], []
+        # A buffer with an event range (an encoder: deep blocks final at the event, shallow blocks at the end of the call)
+        # starts ONLY the event range now; its stream range would make the in-order staging stream wait for this encoder's
+        # whole backward — with the OTHER encoder's deep range queued behind it.  Those (small) ranges go out at the end of
+        # backward.  A buffer without an event range (heads, fusion: produced first) goes out at once behind its stream.
+        has_event = self._early and any(ev is not None for _a, _b, ev in segments)
+        for start, stop, ev in segments:
+            if stop <= start:
+                continue
+            if ev is not None and self._early:
+                st.wait_event(ev)
+                kind = "event"
+            elif has_event:
+                deferred.append((start, stop))
+                continue
+            else:
+                st.wait_stream(torch.cuda.current_stream(dev))
+                kind = "stream"
+            with torch.cuda.stream(st):
+                works.append(dist.all_reduce(flat[start:stop], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.last_reduced_bytes.append((stop - start) * flat.element_size())
+            self.last_reduced_kinds.append(kind)
+        flat.record_stream(st)
+        for p, _v in params:
+            self._covered.add(p)
+        self._inplace.append((flat, params, works, deferred))
+
+    def _reduce_rest(self, st):
+        """End-of-backward path: every parameter with a gradient that was not reduced in place, through the flat buckets."""
+        launched = []
+        for b in self._buckets:
+            todo = [(i, p) for i, p in enumerate(b.params) if p.grad is not None and p not in self._covered]
+            if not todo:
+                continue
+            views = b.views()
+            src, dst = [], []
+            have = {i for i, _p in todo}
+            for i, p in todo:
+                g = p.grad
+                if g.data_ptr() == views[i].data_ptr() and g.shape == p.shape:
+                    continue                    # .grad already IS the bucket view (in-place accumulation since the last step)
+                src.append(g if g.shape == p.shape else g.reshape(p.shape))
+                dst.append(views[i])
+            for i in range(len(b.params)):
+                if i not in have:
+                    views[i].zero_()            # no gradient this pass: contribute zeros
+            if src:
+                torch._foreach_copy_(dst, src)
+            work = dist.all_reduce(b.flat(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.last_reduced_bytes.append(b.nbytes)
+            self.last_reduced_kinds.append("bucket")
+            launched.append((b, todo, work))
+        return launched
 
     def _finalize(self):
         self._callback_queued = False
-        try:
-            from . import ops
-            ops.GRAD_READY_EVENTS.clear()
-        except Exception:                        # pragma: no cover - CPU-only use without the HIP library
-            pass
-        dev = self._buckets[0].flat.device
+        first = self._params[0] if self._params else None
+        dev = first.device if first is not None else torch.device("cpu")
         cuda = dev.type == "cuda"
         st = self._staging(dev) if cuda else None
         ctx = torch.cuda.stream(st) if cuda else _NullCtx()
         if cuda:
             st.wait_stream(torch.cuda.current_stream(dev))
+            if self._known_streams is not None:
+                for s_ in self._known_streams(dev):
+                    st.wait_stream(s_)
         with ctx:
-            for b in self._buckets:
-                if b.work is None:        # some parameter got no gradient this pass
-                    self._launch(b)
+            rest = self._reduce_rest(st)
             ev0 = ev1 = None
             if cuda and self.timing:
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record(st)
-            for b in self._buckets:
-                b.work.wait()
-                b.flat.div_(self.world)
+            flats = []
+            for flat, _params, works, deferred in self._inplace:          # (the staging stream waited for every stream above)
+                for start, stop in deferred:
+                    works.append(dist.all_reduce(flat[start:stop], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self.last_reduced_bytes.append((stop - start) * flat.element_size())
+                    self.last_reduced_kinds.append("end")
+            for flat, _params, works, _d in self._inplace:
+                for w in works:
+                    w.wait()
+                flats.append(flat)
+            for b, _todo, work in rest:
+                work.wait()
+                flats.append(b.flat())
+            if flats:
+                torch._foreach_div_(flats, float(self.world))
             if ev0 is not None:
                 ev1.record(st)
                 self._timing_events.append((ev0, ev1))
         if cuda:
             torch.cuda.current_stream(dev).wait_stream(st)
-        # .grad becomes a VIEW of the reduced bucket (no copy back); the next zero_grad() drops it and the next
-        # backward's pack — stream-ordered after the optimizer step that reads these views — refills the bucket.
-        # A parameter that received no gradient in this backward keeps ``.grad = None`` — exactly what a single-process
-        # run leaves, so Adam skips it there and here alike (its zero-filled slice still rode in the all-reduce).  As
-        # with torch DDP(find_unused_parameters=False) the set of used parameters must be the same on every rank.
-        for b in self._buckets:
-            for i, (p, v) in enumerate(zip(b.params, self._views(b))):
-                if b.filled[i]:
-                    p.grad = v
-            b.reset()
+        # In place: autograd ADOPTED the node's views as .grad (no kernel: the incoming gradient is kept as it is when there
+        # is nothing to accumulate into), so .grad already holds the reduced values.  Had autograd cloned or summed a view
+        # instead (a parameter that ALSO receives a gradient from elsewhere in the graph), that kernel would have read the
+        # buffer while it was being reduced — not recoverable afterwards, so it is an error, not a silent wrong gradient.
+        # Every parameter is checked in the wrapper's first steps (what autograd does with a given graph does not change
+        # from step to step), afterwards the first and last of each buffer.
+        full = self._checked_steps < 3
+        self._checked_steps += 1
+        for _flat, params, _works, _d in self._inplace:
+            for p, v in (params if full else (params[0], params[-1])):
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    raise RuntimeError(
+                        "GradAllReduce: a gradient view of a whole-pass node was not adopted as .grad (the parameter also "
+                        "receives a gradient from elsewhere in the graph?) — set TMF_DDP_INPLACE=0 to reduce everything at "
+                        "the end of backward instead")
+        # Buckets: .grad becomes a VIEW of the reduced bucket (no copy back); the next zero_grad() drops it, or a
+        # zero_grad(set_to_none=False) keeps it and the next backward accumulates into the bucket in place.  A parameter
+        # that received no gradient keeps ``.grad = None`` — exactly what a single-process run leaves, so Adam skips it
+        # there and here alike.  As with torch DDP(find_unused_parameters=False) the set of used parameters must be the
+        # same on every rank.
+        for b, todo, _work in rest:
+            views = b.views()
+            for i, p in todo:
+                p.grad = views[i]
+        self._inplace = []
+        self._covered = set()
+
+    def _begin_backward_bookkeeping(self):
+        self.last_reduced_bytes = []
+        self.last_reduced_kinds = []
 
     def exposed_allreduce_ms(self):
-        """Per recorded step: milliseconds between the end of backward's compute and the last bucket being reduced and
+        """Per recorded step: milliseconds between the end of backward's compute and the last collective being done and
         scaled (what the collectives cost on top of backward).  Synchronises; clears the record."""
         if not self._timing_events:
             return []
@@ -285,29 +340,36 @@ class GradAllReduce(nn.Module):
 
     def reduce_gradients(self):
         """Synchronous form (no overlap): all-reduce every bucket from the gradients currently in ``.grad``.
-        Used after a hipGraph replay of forward+backward, where the autograd hooks do not run."""
+        For callers that run forward + backward outside autograd's hooks (e.g. a replayed graph)."""
         if self.world == 1:
             return
         for b in self._buckets:
-            b.filled = [p.grad is not None for p in b.params]
-            self._launch(b)
-        for b in self._buckets:
-            b.work.wait()
-            b.flat.div_(self.world)
-            # copy back INTO the existing .grad tensors (a captured graph owns them and rewrites them on replay)
-            views = self._views(b)
-            dst = [p.grad for p in b.params if p.grad is not None]
-            src = [v for p, v in zip(b.params, views) if p.grad is not None]
-            if dst:
+            views = b.views()
+            src = [p.grad for p in b.params if p.grad is not None]
+            dst = [v for p, v in zip(b.params, views) if p.grad is not None]
+            for p, v in zip(b.params, views):
+                if p.grad is None:
+                    v.zero_()
+            if src:
                 torch._foreach_copy_(dst, src)
+            dist.all_reduce(b.flat(), op=dist.ReduceOp.SUM, group=self.group)
+            b.flat().div_(self.world)
+            # copy back INTO the existing .grad tensors (a captured graph owns them and rewrites them on replay)
+            if src:
+                torch._foreach_copy_(src, dst)
             for p, v in zip(b.params, views):
                 if p.grad is None:
                     p.grad = v.clone()
-            b.reset()
 
     # -- nn.Module surface -------------------------------------------------------------------
     def forward(self, *args, **kwargs):
-        return self.module(*args, **kwargs)
+        out = self.module(*args, **kwargs)
+        if self._live and self.require_sync and torch.is_grad_enabled():
+            self._begin_backward_bookkeeping()
+            for t in (out if isinstance(out, (tuple, list)) else (out,)):
+                if isinstance(t, torch.Tensor) and t.requires_grad:
+                    t.register_hook(self._on_backward_start)
+        return out
 
     def state_dict(self, *args, **kwargs):          # checkpoints interchange with the bare module
         return self.module.state_dict(*args, **kwargs)
