@@ -304,6 +304,9 @@ def build_parser():
     ap.add_argument("--roofline-only", action="store_true",
                     help="skip the train-step timing: only the dominant-kernel loop (so that a rocprofv3 --stats run "
                          "of this command averages exactly the launches the roofline entry quotes)")
+    ap.add_argument("--dropout", type=float, default=0.0,
+                    help="model_ad(dropout=p): Dropout in the fusion block's Transformer instances (options/option.py:39; the "
+                         "reference default and the headline are 0)")
     ap.add_argument("--no-also", action="store_true",
                     help="the default N=1 run measures the other BASELINE configurations in the same process after the headline "
                          "(`also`: configs[2] 128^3 bf16, configs[4] both readings at batch 16, the fp32x mode); this skips them")
@@ -327,7 +330,7 @@ ALSO = (
 def _is_default_workload(args):
     return (args.model == "ad" and args.precision == "fp32" and args.storage == "fp32" and args.size == 96 and args.batch == 8
             and not args.shape and not args.eval and not args.from_host and not args.roofline_only and not args.no_item_sync
-            and not args.no_cpu_baseline and args.steps > 0)
+            and not args.no_cpu_baseline and args.steps > 0 and args.dropout == 0.0)
 
 
 def main():
@@ -387,7 +390,7 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
     ops.set_activation_storage(args.storage)
     torch.manual_seed(0)
     if args.model == "ad":
-        net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.).to(dev)
+        net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=args.dropout).to(dev)
     elif args.model == "cnn":
         from transmf_ad_amd import model_CNN_ad
         net = model_CNN_ad(dim=128).to(dev)
@@ -626,7 +629,7 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
     gf = gf_pair
     if args.eval:       # forward only: sum of F_l per stream
         gf = gf * (32.219 / 95.125) if vol == (96, 96, 96) else gf / 3.0
-    model_desc = {"ad": "model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512)",
+    model_desc = {"ad": "model_ad(dim=128,depth=3,heads=4,dim_head=32,mlp_dim=512" + (f",dropout={args.dropout}" if args.dropout else "") + ")",
                   "cnn": "model_CNN_ad(dim=128) [BASELINE configs[4], dual-modality reading of --model CNN]",
                   "single": "model_single(128), MRI only [BASELINE configs[4], single-modality reading]"}[args.model]
     out = {

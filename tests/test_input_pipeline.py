@@ -194,6 +194,20 @@ def test_nifti_reader_round_trip_and_header_rules(tmp_path):
     assert np.array_equal(NI.read_nifti(str(tmp_path / "i.nii.gz")), (i16.astype(np.float64) * 0.5 - 3.0).astype(np.float32))
     NI.write_nifti(str(tmp_path / "n.nii"), i16, slope=float("nan"), inter=9.0)
     assert np.array_equal(NI.read_nifti(str(tmp_path / "n.nii")), i16.astype(np.float32))      # NaN slope: unscaled
+    NI.write_nifti(str(tmp_path / "inf.nii"), i16, slope=float("inf"), inter=9.0)
+    assert np.array_equal(NI.read_nifti(str(tmp_path / "inf.nii")), i16.astype(np.float32))    # non-finite slope: unscaled
+    NI.write_nifti(str(tmp_path / "badinter.nii"), i16, slope=2.0, inter=float("inf"))
+    with pytest.raises(NI.NiftiError):
+        NI.read_nifti(str(tmp_path / "badinter.nii"))                                          # valid slope, invalid intercept
+    # a 4-D file with a trailing singleton axis (dim[0] = 4, dim[4] = 1: common for ADNI exports) is ONE 3-D volume for
+    # nifti_batches, as for MONAI's LoadImaged + EnsureChannelFirstd; a real 4-D series is refused
+    NI.write_nifti(str(tmp_path / "t1.nii"), i16[..., None])
+    assert NI.read_nifti(str(tmp_path / "t1.nii")).shape == i16.shape + (1,)
+    b4 = next(NI.nifti_batches([str(tmp_path / "t1.nii")], [str(tmp_path / "t1.nii")], [0], 1))
+    assert b4["MRI"].shape == (1, 1) + i16.shape and np.array_equal(b4["MRI"][0, 0], i16.astype(np.float32))
+    NI.write_nifti(str(tmp_path / "t2.nii"), np.stack([i16, i16], axis=-1))
+    with pytest.raises(NI.NiftiError):
+        next(NI.nifti_batches([str(tmp_path / "t2.nii")], [str(tmp_path / "t2.nii")], [0], 1))
     u8 = rs.randint(0, 255, (3, 2, 4)).astype(np.uint8)
     NI.write_nifti(str(tmp_path / "u.nii"), u8)
     assert np.array_equal(NI.read_nifti(str(tmp_path / "u.nii")), u8.astype(np.float32))

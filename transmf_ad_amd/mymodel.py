@@ -143,6 +143,8 @@ def _cnn_heads_one_call_ok(model, fc, D, tok, M):
         return False
     if dim % 16 or M * dim > 512 or fc[2].out_features > 16:          # csrc/heads.hip check_cnn_heads
         return False
+    if D is not None and model.training and tok.shape[0] < 2:
+        return False        # train-mode BatchNorm1d over one sample: the module path raises as the reference's does
     mods = list(fc) + [fc]
     if D is not None:
         if not (isinstance(D, nn.Sequential) and [type(m) for m in D] == [nn.Linear, nn.BatchNorm1d, nn.ReLU, nn.Linear]):
@@ -156,6 +158,10 @@ def _cnn_heads_one_call_ok(model, fc, D, tok, M):
         mods += list(D) + [D]
     if any(m.training != model.training for m in mods):               # one train / eval switch for the whole launch
         return False
+    for m in mods:                                                    # what ops.HeadsCNN would refuse takes the module path
+        for t in m.parameters(recurse=False):
+            if not (t.is_cuda and t.device == tok.device and t.dtype == torch.float32 and t.is_contiguous()):
+                return False
     return _plain(mods)
 
 

@@ -69,13 +69,18 @@ def read_nifti(path: str, dtype=np.float32) -> np.ndarray:
     if dt.itemsize * 8 != bitpix:
         raise NiftiError(f"{path}: bitpix {bitpix} does not match datatype {code}")
     vox_offset, slope, inter = struct.unpack_from(bo + "3f", raw, 108)
+    # nibabel's Nifti1Header.get_slope_inter: slope 0 or non-finite (NaN, inf) = "no scaling"; a valid slope with a
+    # non-finite intercept is a header error
+    scaled = slope != 0.0 and np.isfinite(slope)
+    if scaled and not np.isfinite(inter):
+        raise NiftiError(f"{path}: valid scl_slope {slope} but non-finite scl_inter {inter}")
     off = int(vox_offset) if vox_offset >= 352 else 352
     n = int(np.prod(shape))
     if len(raw) < off + n * dt.itemsize:
         raise NiftiError(f"{path}: {len(raw)} bytes, need {off + n * dt.itemsize} for shape {shape}")
     data = np.frombuffer(raw, dtype=dt, count=n, offset=off).reshape(shape, order="F")
     # (X, Y, Z): first index fastest in the file.  Scaling as nibabel's array proxy: in float64, then the caller's dtype
-    if slope != 0.0 and not np.isnan(slope) and not (slope == 1.0 and inter == 0.0):
+    if scaled and not (slope == 1.0 and inter == 0.0):
         out = (data.astype(np.float64) * np.float64(slope) + np.float64(inter)).astype(dtype)
     else:
         out = data.astype(dtype)
@@ -109,6 +114,18 @@ def write_nifti(path: str, arr: np.ndarray, slope: float = 0.0, inter: float = 0
             f.write(payload)
 
 
+def _volume_3d(path: str) -> np.ndarray:
+    """One subject's (X, Y, Z) volume: trailing singleton axes of a 4-D+ file (dim[0] = 4 with dim[4] = 1, common for
+    ADNI exports) are dropped — what MONAI's LoadImaged + EnsureChannelFirstd make of such a file is (1, X, Y, Z) — and
+    anything that is not 3-D after that is an error rather than a volume whose axes the transforms would misread."""
+    a = read_nifti(path)
+    while a.ndim > 3 and a.shape[-1] == 1:
+        a = a[..., 0]
+    if a.ndim != 3:
+        raise NiftiError(f"{path}: shape {a.shape} is not a 3-D volume")
+    return a
+
+
 def nifti_batches(mri_paths: Sequence[str], pet_paths: Sequence[str], labels: Sequence[int], batch_size: int,
                   drop_last: bool = False, order: Iterable[int] = None) -> Iterator[dict]:
     """Host batches {'MRI': (B, 1, X, Y, Z) float32, 'PET': ..., 'label': (B,) int64} read from NIfTI files — what
@@ -121,6 +138,6 @@ def nifti_batches(mri_paths: Sequence[str], pet_paths: Sequence[str], labels: Se
         sel = idx[s:s + batch_size]
         if drop_last and len(sel) < batch_size:
             return
-        mri = np.stack([read_nifti(mri_paths[i])[None] for i in sel])
-        pet = np.stack([read_nifti(pet_paths[i])[None] for i in sel])
+        mri = np.stack([_volume_3d(mri_paths[i])[None] for i in sel])
+        pet = np.stack([_volume_3d(pet_paths[i])[None] for i in sel])
         yield {"MRI": mri, "PET": pet, "label": np.asarray([labels[i] for i in sel], dtype=np.int64)}

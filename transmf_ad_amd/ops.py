@@ -894,6 +894,27 @@ def dropout_keep_mask(drop, shape, device):
     return torch.empty(shape, device=device, dtype=_f32).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
+def dropout_keep_masks(requests, device):
+    """Scaled keep-masks for MANY Dropout modules in as few launches as possible: requests = [(drop, shape), ...] -> list of
+    masks (None where inactive).  All stock nn.Dropout modules with the same p share ONE flat buffer drawn by one
+    bernoulli_ + one div_ (the fusion block at depth 3 asks for 18 masks per step: 36 launches one by one, 2 this way);
+    modules that bring their own mask (``tmf_keep_mask``) and p >= 1 are served as in dropout_keep_mask."""
+    out = [None] * len(requests)
+    groups = {}
+    for i, (drop, shape) in enumerate(requests):
+        p = float(getattr(drop, "p", 0.0))
+        if hasattr(drop, "tmf_keep_mask") or p >= 1.0 or p <= 0.0 or not drop.training:
+            out[i] = dropout_keep_mask(drop, shape, device)
+        else:
+            groups.setdefault(p, []).append(i)
+    for p, idx in groups.items():
+        sizes = [int(torch.Size(requests[i][1]).numel()) for i in idx]
+        flat = torch.empty(sum(sizes), device=device, dtype=_f32).bernoulli_(1.0 - p).div_(1.0 - p)
+        for i, part in zip(idx, flat.split(sizes)):
+            out[i] = part.view(requests[i][1])
+    return out
+
+
 def fusion_one_call_supported(dim, inner, mlp, dim_head, depth):
     return (FUSION_ONE_CALL and FUSE_TOKEN_LINEARS and dim == 128 and inner % 128 == 0 and mlp % 128 == 0
             and dim_head in (8, 16, 32, 64) and 0 < depth <= 16)
@@ -924,12 +945,12 @@ class FusionTrain(torch.autograd.Function):
                     raise _lib.TmfError(f"Transformer instance {i}: {name} must be a contiguous float32 HIP tensor")
                 setattr(inst[i], name, t.data_ptr())
             inst[i].eps1, inst[i].eps2, inst[i].epsf = eps[i]
-            if drops is not None:
-                for name, drop, width in zip(("mask_o", "mask_g", "mask_f"), drops[i], (dim, mlp, dim)):
-                    mk = dropout_keep_mask(drop, (B * N, width), mri.device)
-                    if mk is not None:
-                        masks.append(mk)
-                        setattr(inst[i], name, mk.data_ptr())
+        if drops is not None:                    # every keep-mask of the step in one draw per distinct p
+            req = [(drop, (B * N, width)) for i in range(2 * depth) for drop, width in zip(drops[i], (dim, mlp, dim))]
+            for j, mk in enumerate(dropout_keep_masks(req, mri.device)):
+                if mk is not None:
+                    masks.append(mk)
+                    setattr(inst[j // 3], ("mask_o", "mask_g", "mask_f")[j % 3], mk.data_ptr())
         nsaved = _lib.query("tmf_fusion_saved_bytes", C.byref(desc))
         if nsaved == 0:
             raise _lib.TmfError("tmf_fusion_saved_bytes: " + (_lib.load().tmf_last_error_string() or b"").decode())

@@ -52,7 +52,10 @@ class Adam(torch.optim.Optimizer):
                 offs.append(off)
                 off += (p.numel() + 3) & ~3
             pptr = (C.c_void_p * len(sub))(*[p.data_ptr() for p in sub])
-            chunks.append((sub, m, v, offs, numel, pptr))
+            # step counts as Python ints: [0] = the count every parameter of the chunk shares, [1] = {index: count} of the
+            # parameters that sat out a step (torch's bias correction is per parameter); the per-parameter `step` tensors of
+            # torch's state layout are refreshed from them when somebody looks (state_dict, pickling)
+            chunks.append((sub, m, v, offs, numel, pptr, [0, None]))
             for p, o in zip(sub, offs):          # torch's per-parameter layout, as views of the flat buffers
                 self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m[o:o + p.numel()].view_as(p),
                                  "exp_avg_sq": v[o:o + p.numel()].view_as(p)}
@@ -70,31 +73,57 @@ class Adam(torch.optim.Optimizer):
             if not chunks:
                 continue
             b1, b2 = group["betas"]
-            for sub, m, v, _offs, numel, pptr in chunks:
-                grads, steps = [], []
+            for sub, m, v, _offs, numel, pptr, cnt in chunks:
+                grads = []
+                missing = False
                 for i, p in enumerate(sub):
                     if p.data_ptr() != pptr[i]:
                         pptr[i] = p.data_ptr()                      # parameter storage replaced (e.g. by .to())
                     g = p.grad
                     if g is None:
-                        grads.append(None); steps.append(None)
+                        grads.append(None)
+                        missing = True
                         continue
                     if g.is_sparse or g.dtype != torch.float32 or g.device != p.device:
                         raise _lib.TmfError("transmf_ad_amd.optim.Adam: gradients must be dense float32 on the parameter's device")
                     grads.append(g if g.is_contiguous() else g.contiguous())
-                    st = self.state[p]
-                    st["step"] += 1
-                    steps.append(int(st["step"].item()))              # a CPU scalar: no device sync
-                # one launch per distinct step count (one, unless some parameter sat out earlier steps: the bias
-                # correction is per parameter in torch)
-                for step in sorted({s_ for s_ in steps if s_ is not None}):
-                    gptr = (C.c_void_p * len(sub))(*[g.data_ptr() if (g is not None and s_ == step) else None
-                                                     for g, s_ in zip(grads, steps)])
+                if not missing and cnt[1] is None:                   # every step of a normal run: ONE count for the chunk
+                    cnt[0] += 1
+                    steps = None
+                    todo = (cnt[0],)
+                else:                                                # some parameter sat out a step, now or earlier
+                    if cnt[1] is None:
+                        cnt[1] = {i: cnt[0] for i in range(len(sub))}
+                    for i, g in enumerate(grads):
+                        if g is not None:
+                            cnt[1][i] += 1
+                    steps = [cnt[1][i] if g is not None else None for i, g in enumerate(grads)]
+                    todo = sorted({s_ for s_ in steps if s_ is not None})
+                # one launch per distinct step count (one, unless some parameter sat out earlier steps)
+                for step in todo:
+                    gptr = (C.c_void_p * len(sub))(*[g.data_ptr() if (g is not None and (steps is None or steps[i] == step))
+                                                     else None for i, g in enumerate(grads)])
                     with torch.cuda.device(m.device):
                         _lib.call("tmf_adam_step", len(sub), pptr, gptr, numel, m.data_ptr(), v.data_ptr(), float(group["lr"]),
                                   float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step,
                                   torch.cuda.current_stream().cuda_stream)
         return loss
+
+    def _sync_step_tensors(self):
+        """Write the Python-side step counts into torch's per-parameter `step` tensors."""
+        for chunks in (getattr(self, "_flat", None) or {}).values():
+            for sub, _m, _v, _offs, _numel, _pptr, cnt in chunks:
+                for i, p in enumerate(sub):
+                    n = cnt[0] if cnt[1] is None else cnt[1][i]
+                    self.state[p]["step"] = torch.tensor(float(n))
+
+    def state_dict(self):
+        self._sync_step_tensors()
+        return super().state_dict()
+
+    def __getstate__(self):
+        self._sync_step_tensors()
+        return super().__getstate__()
 
     def load_state_dict(self, state_dict):
         """torch's loader replaces the per-parameter state tensors: copy them back into the flat buffers the kernel uses."""
@@ -107,10 +136,18 @@ class Adam(torch.optim.Optimizer):
         if not loaded:
             return
         for group in self.param_groups:
-            for sub, m, v, offs, _numel, _pptr in self._group_state(group) or ():
+            for sub, m, v, offs, _numel, _pptr, cnt in self._group_state(group) or ():
+                counts = []
                 for p, o in zip(sub, offs):
                     old = loaded.get(p)
+                    n = 0
                     if old and "exp_avg" in old:
                         m[o:o + p.numel()].copy_(old["exp_avg"].reshape(-1))
                         v[o:o + p.numel()].copy_(old["exp_avg_sq"].reshape(-1))
-                        self.state[p]["step"] = torch.as_tensor(float(old.get("step", 0.0))).cpu()
+                        n = int(float(old.get("step", 0.0)))
+                        self.state[p]["step"] = torch.tensor(float(n))
+                    counts.append(n)
+                if len(set(counts)) <= 1:
+                    cnt[0], cnt[1] = (counts[0] if counts else 0), None
+                else:
+                    cnt[0], cnt[1] = max(counts), dict(enumerate(counts))
