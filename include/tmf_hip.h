@@ -288,6 +288,10 @@ int tmf_pack_conv_weights(const float* w, float* w_fwd, float* w_dgrad, int cout
  * reads) and, when w_dgrad_bf16 != NULL, w_dgrad_bf16[taps-1-t][ci][co] (its data-gradient call).  RNE rounding,
  * bit-identical to torch's .to(bfloat16).  cin (and cout, with a dgrad copy) even. */
 int tmf_pack_conv_weights_bf16(const float* w, void* w_fwd_bf16, void* w_dgrad_bf16, int cout, int cin, int taps, void* stream);
+/* The same for tmf_conv3d_fwd_split (the fp32x mode): every weight as its EXACT three-way bf16 decomposition,
+ * w3_fwd[p][t][co][ci] = part p (hi, mid, lo) of w[co][ci][t] and, when w3_dgrad != NULL, w3_dgrad[p][taps-1-t][ci][co];
+ * 3 * taps * cout * cin bf16 numbers each — the operand layout torch's split3 (.to(bfloat16), subtract, repeat) gives. */
+int tmf_pack_conv_weights_split3(const float* w, void* w3_fwd, void* w3_dgrad, int cout, int cin, int taps, void* stream);
 
 /* Layout conversion between the reference's NCDHW tensors and the channels-last tensors every kernel here uses
  * (voxels = D*H*W).  The model itself never needs it — its input has C == 1 (same bytes either way) and its output
@@ -358,6 +362,9 @@ int    tmf_scale_flip(const float* src, float* dst, const float* minmax, const u
 #define TMF_SNET_BLOCKS 7
 #define TMF_PREC_FP32 0
 #define TMF_PREC_BF16 1
+#define TMF_PREC_FP32X 2          /* fp32-accurate forward / data gradient on the bf16 matrix cores (exact 3-way bf16 split of both
+                                     operands, six partial products: tmf_conv3d_fwd_split); first block, 1x1x1 layer and weight
+                                     gradients exact fp32 */
 /* tmf_snet_desc.flags.  TMF_SNET_ALONE: the caller runs this encoder with nothing beside it on the device, so the partial
  * workgroup rounds of the pooled layers are not filled by a second stream: the fp32 forward / data-gradient convolutions
  * of those layers take the register-tiled kernel (as tmf_set_option("conv_rt", 1) would, for this call only; same results

@@ -706,6 +706,10 @@ def test_conv3d_fp32_accurate_split(shape):
     xg, wg = _ndhwc(x).to(DEV), w.to(DEV)
     w3 = ops.split3_bf16(wg.permute(2, 3, 4, 0, 1).contiguous())
     assert torch.equal(w3.float().sum(0), wg.permute(2, 3, 4, 0, 1))          # the decomposition is exact
+    # tmf_pack_conv_weights_split3 (one launch for both layouts) is bitwise torch's cast / subtract / cast / subtract / cast
+    p3f, p3d = ops.pack_weights_split3(wg, True)
+    assert torch.equal(p3f.reshape(w3.shape), w3)
+    assert torch.equal(p3d.reshape(3, 3, 3, 3, cin, cout), ops.split3_bf16(wg.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous()))
     z, part, _ = ops.conv3d_split_raw(xg, w3, cin, cout, True)
     z32, _, _ = ops.conv3d_raw(xg, ops.pack_weight(wg), cin, cout, 3, False)
     torch.cuda.synchronize()

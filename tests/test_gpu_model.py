@@ -653,15 +653,16 @@ def test_train_step_is_bit_reproducible_with_two_streams(mode):
         T.set_activation_storage("fp32")
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16s"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16s", "fp32x"])
 @pytest.mark.parametrize("name", ["ad_ragged", "ad_mid"])
 def test_one_call_encoder_is_bit_identical_to_block_by_block(name, mode):
     """tmf_snet_train_fwd / _bwd (one library call per encoder pass, csrc/snet_path.hip) enqueue exactly the launches of
-    the block-by-block path: logits, loss, every gradient and every BatchNorm buffer are bit-identical."""
+    the block-by-block path: logits, loss, every gradient and every BatchNorm buffer are bit-identical (fp32x since round 4:
+    TMF_PREC_FP32X, weights split by tmf_pack_conv_weights_split3)."""
     import transmf_ad_amd as T
     from transmf_ad_amd import ops
     g = Golden(name)
-    T.set_conv_precision("fp32" if mode == "fp32" else "bf16")
+    T.set_conv_precision(mode if mode in ("fp32", "fp32x") else "bf16")
     T.set_activation_storage("bf16" if mode == "bf16s" else "fp32")
     res = []
     try:

@@ -820,6 +820,19 @@ __global__ __launch_bounds__(v2::NTHR, 4) void conv3d_fwd_bf16_v2_kernel(
 
 
 // ------------------------------------------------------------------------------------------------------------
+// Round 4 — two more structures for the 32-channel layers were built, measured against the kernel above and REMOVED
+// (profiles/r04_bf16_r4_ab.txt, r04_bf16_r5_ab.txt, r04_bf16_data_probe.txt):
+//   * four waves per brick, a 4 x 1 register tile whose A fragments are shared between the kh taps of a brick column (0.75
+//     operand reads per MFMA instead of 1.5, twice the MFMAs per wave and brick, three workgroups per CU; bitwise-equal z):
+//     106 / 103 / 232 us against 112 / 102 / 234;
+//   * the halo's WHOLE channel depth fetched once per brick in 64-byte rows ((kd, kw) weight columns, output tiles walked
+//     inside the kernel; half the fabric traffic — the 16-channel chunks above request every 128-byte line once per chunk):
+//     103-112 us against 106-110 on conv2.0, 220 against 200 on conv2.3.
+// What the three have in common is the matrix work, and on random operands that is what the chip's POWER budget prices: the
+// same launches on zero operands run 18-34 % faster (conv2.0 110 -> 82 us = 0.57 of the nominal peak): the chip clocks to its
+// power budget (MI355X_MICROARCH.md, DVFS give-back; there a GEMM template gains 15-21 % the same way).
+// ------------------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------------------
 // fp32-ACCURATE convolution on the bf16 matrix cores ("3-way split"): every fp32 operand is written as
 // hi + mid + lo with three bf16 numbers (8 + 8 + 8 significand bits: the decomposition is EXACT), and the
 // product a*b is evaluated as the six partial products of order >= 2^-16 — (h,h) (h,m) (m,h) (h,l) (l,h) (m,m) —

@@ -26,6 +26,7 @@ struct LayerPlan {
     int D, H, W;            // conv input = conv output dims of the block
     int oD, oH, oW;         // block output dims (after the pool)
     bool bf;                // bf16 matrix-core kernels for this block's conv / dgrad / wgrad
+    bool sp;                // fp32x: forward / data gradient as six bf16 partial products per fp32 product, weight gradient exact fp32
     bool x16, z16, o16;     // bf16 storage of the block input, the raw conv output (and dz), the block output
     size_t off_z, off_out, off_vec, off_wf, off_wd;     // in the saved workspace
     size_t x_bytes, z_bytes, out_bytes;
@@ -45,8 +46,8 @@ int check_desc(const char* fn, const tmf_snet_desc* d) {
     TMF_REQUIRE(d->B > 0 && d->D >= 16 && d->H >= 16 && d->W >= 16, TMF_E_SHAPE,
                 "%s: volume %dx%dx%d (batch %d): every edge must be >= 16 (four 2x2x2 pools)", fn, d->D, d->H, d->W, d->B);
     TMF_REQUIRE(d->dim >= 32 && d->dim % 32 == 0, TMF_E_SHAPE, "%s: dim=%d must be a positive multiple of 32", fn, d->dim);
-    TMF_REQUIRE(d->precision == TMF_PREC_FP32 || d->precision == TMF_PREC_BF16, TMF_E_ARG, "%s: unknown precision %d", fn,
-                d->precision);
+    TMF_REQUIRE(d->precision == TMF_PREC_FP32 || d->precision == TMF_PREC_BF16 || d->precision == TMF_PREC_FP32X, TMF_E_ARG,
+                "%s: unknown precision %d", fn, d->precision);
     TMF_REQUIRE(!d->storage_bf16 || d->precision == TMF_PREC_BF16, TMF_E_ARG,
                 "%s: bf16 activation storage needs the bf16 precision", fn);
     return TMF_OK;
@@ -69,6 +70,8 @@ Plan make_plan(const tmf_snet_desc& d) {
         if (pool[l] != TMF_POOL_NONE) { D /= 2; H /= 2; W /= 2; }
         L.oD = D; L.oH = H; L.oW = W;
         L.bf = b16 && ks[l] == 3 && cin[l] > 1 && cin[l] % 8 == 0;
+        // (both channel counts multiples of 8: the data gradient is the same kernel with the roles swapped)
+        L.sp = d.precision == TMF_PREC_FP32X && ks[l] == 3 && cin[l] > 1 && cin[l] % 8 == 0 && cout[l] % 8 == 0;
     }
     for (int l = 0; l < NL; ++l) {
         LayerPlan& L = p.L[l];
@@ -87,8 +90,8 @@ Plan make_plan(const tmf_snet_desc& d) {
         L.off_out = off; off += up256(L.out_bytes);
         L.off_vec = off; off += (size_t)4 * L.cpad * 4;
         const size_t wn = (size_t)L.k * L.k * L.k * L.cin * L.cout;
-        L.off_wf = off; off += up256(wn * (L.bf ? 2 : 4));
-        L.off_wd = off; off += l == 0 ? 0 : up256(wn * (L.bf ? 2 : 4));
+        L.off_wf = off; off += up256(wn * (L.sp ? 6 : L.bf ? 2 : 4));
+        L.off_wd = off; off += l == 0 ? 0 : up256(wn * (L.sp ? 6 : L.bf ? 2 : 4));
         int nblk, nb2;
         size_t ws;
         if (l == 0) {
@@ -97,6 +100,7 @@ Plan make_plan(const tmf_snet_desc& d) {
             ws = tmf_c1_bwd_wgrad_workspace_bytes(d.B, L.D, L.H, L.W, L.cout);
         } else {
             nblk = L.bf ? tmf_conv3d_bf16_stat_blocks(d.B, L.D, L.H, L.W)
+                   : L.sp ? tmf_conv3d_split_stat_blocks(d.B, L.D, L.H, L.W)
                         : tmf_conv3d_stat_blocks_mode(d.B, L.D, L.H, L.W, L.cin, L.cout, L.k, (d.flags & TMF_SNET_ALONE) ? 1 : 0);
             nb2 = tmf_bn_act_pool_bwd_blocks(d.B, L.D, L.H, L.W, L.cout, L.pool);
             ws = L.bf ? tmf_conv3d_wgrad_bf16_workspace_bytes(d.B, L.D, L.H, L.W, L.cin, L.cout)
@@ -180,6 +184,10 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
             nblk = tmf_conv3d_bf16_stat_blocks(d->B, L.D, L.H, L.W);
             TMF_TRY(tmf_conv3d_fwd_bf16_t(x, wf, z, part, d->B, L.D, L.H, L.W, L.cin, L.cout,
                                           (L.x16 ? 1 : 0) | (L.z16 ? 2 : 0), stream));
+        } else if (L.sp) {
+            TMF_TRY(tmf_pack_conv_weights_split3(prm->weight[l], wf, wd, L.cout, L.cin, 27, stream));
+            nblk = tmf_conv3d_split_stat_blocks(d->B, L.D, L.H, L.W);
+            TMF_TRY(tmf_conv3d_fwd_split((const float*)x, wf, (float*)z, part, d->B, L.D, L.H, L.W, L.cin, L.cout, stream));
         } else {
             TMF_TRY(tmf_pack_conv_weights(prm->weight[l], (float*)wf, (float*)wd, L.cout, L.cin, L.k * L.k * L.k, stream));
             const int rt_min = (d->flags & TMF_SNET_ALONE) ? 1 : 0;
@@ -337,8 +345,9 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
             if (g->dweight[l] != nullptr)
                 TMF_TRY(tmf_conv3d_wgrad((const float*)x, (const float*)dz, g->dweight[l], ws, p.ws_bytes, d->B, L.D, L.H, L.W,
                                          L.cin, L.cout, L.k, TMF_DW_REFERENCE, stream));
-            TMF_TRY(tmf_conv3d_fwd_mode((const float*)dz, (const float*)wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W, L.cout,
-                                        L.cin, L.k, (d->flags & TMF_SNET_ALONE) ? 1 : 0, stream));
+            if (L.sp) TMF_TRY(tmf_conv3d_fwd_split((const float*)dz, wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W, L.cout, L.cin, stream));
+            else TMF_TRY(tmf_conv3d_fwd_mode((const float*)dz, (const float*)wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W, L.cout,
+                                             L.cin, L.k, (d->flags & TMF_SNET_ALONE) ? 1 : 0, stream));
         }
         go = dx;
         if (l == TMF_SNET_DEEP_FROM && g->deep_event != nullptr) {       // blocks 6 .. l: every gradient is queued behind this point

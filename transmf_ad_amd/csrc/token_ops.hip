@@ -226,6 +226,33 @@ __global__ __launch_bounds__(256) void pack_conv_weights_bf16_kernel(const float
     }
 }
 
+// The fp32x mode's weight layouts (conv3d_fwd_split_kernel: every fp32 number as hi + mid + lo, three bf16 numbers, EXACT):
+//   fwd3  [p][t][co][ci]     = part p of w[co][ci][t]     dgrad3[p][T-1-t][ci][co] = part p of w[co][ci][t]
+// (what the host side did with permute / flip / three casts / two subtractions / stack: ~8 launches per layer and pass).
+__device__ __forceinline__ unsigned short tmf_bf16_bits(float a) { return __builtin_bit_cast(unsigned short, (__bf16)a); }
+__global__ __launch_bounds__(256) void pack_conv_weights_split3_kernel(const float* __restrict__ w, unsigned short* __restrict__ fwd,
+                                                                       unsigned short* __restrict__ dgrad, int cout, int cin, int T) {
+    const long n = (long)cout * cin * T;
+    long e = (long)blockIdx.x * 256 + threadIdx.x;
+    unsigned short* dst = fwd;
+    float a;
+    if (e < n) {
+        const int ci = e % cin, co = (e / cin) % cout, t = e / ((long)cin * cout);
+        a = w[((long)co * cin + ci) * T + t];
+    } else {
+        e -= n;
+        if (dgrad == nullptr || e >= n) return;
+        const int co = e % cout, ci = (e / cout) % cin, tr = e / ((long)cin * cout);
+        a = w[((long)co * cin + ci) * T + (T - 1 - tr)];
+        dst = dgrad;
+    }
+    const unsigned short h = tmf_bf16_bits(a);
+    const float r1 = a - __builtin_bit_cast(float, (unsigned)h << 16);           // exact
+    const unsigned short m = tmf_bf16_bits(r1);
+    const float r2 = r1 - __builtin_bit_cast(float, (unsigned)m << 16);          // exact, fits bf16
+    dst[e] = h; dst[n + e] = m; dst[2 * n + e] = tmf_bf16_bits(r2);
+}
+
 // [B][R][C] <-> [B][C][R] through a 32 x 33 LDS tile (both sides coalesced); R = D*H*W voxels, C channels
 __global__ __launch_bounds__(256) void transpose_tile_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                              int rows, int cols, int tiles_c) {
@@ -276,6 +303,17 @@ extern "C" int tmf_pack_conv_weights_bf16(const float* w, void* w_fwd_bf16, void
     hipLaunchKernelGGL(pack_conv_weights_bf16_kernel, dim3((unsigned)tmf_cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream,
                        w, (unsigned int*)w_fwd_bf16, (unsigned int*)w_dgrad_bf16, cout, cin, taps);
     return tmf_launch_result("tmf_pack_conv_weights_bf16");
+}
+
+extern "C" int tmf_pack_conv_weights_split3(const float* w, void* w3_fwd, void* w3_dgrad, int cout, int cin, int taps, void* stream) {
+    TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(w3_fwd);
+    TMF_REQUIRE(cout > 0 && cin > 0 && (taps == 1 || taps == 27), TMF_E_SHAPE,
+                "tmf_pack_conv_weights_split3: cout=%d cin=%d taps=%d", cout, cin, taps);
+    const long n = (long)cout * cin * taps;
+    const long total = w3_dgrad != nullptr ? 2 * n : n;
+    hipLaunchKernelGGL(pack_conv_weights_split3_kernel, dim3((unsigned)tmf_cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream,
+                       w, (unsigned short*)w3_fwd, (unsigned short*)w3_dgrad, cout, cin, taps);
+    return tmf_launch_result("tmf_pack_conv_weights_split3");
 }
 
 extern "C" int tmf_layout_ncdhw_to_ndhwc(const float* src, float* dst, int B, int C, long voxels, void* stream) {

@@ -153,6 +153,16 @@ def split3_bf16(t: torch.Tensor) -> torch.Tensor:
     return torch.stack([hi, mid, lo]).contiguous()
 
 
+def pack_weights_split3(weight: torch.Tensor, want_dgrad: bool):
+    """split3_bf16 of the forward layout [27][cout][cin] and (optionally) of the data-gradient layout [27][cin][cout]
+    (flipped taps) of one (cout, cin, 3, 3, 3) weight tensor in ONE launch: (3, 27, cout, cin), (3, 27, cin, cout) bf16."""
+    cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    wf = torch.empty((3, k ** 3, cout, cin), device=weight.device, dtype=torch.bfloat16)
+    wd = torch.empty((3, k ** 3, cin, cout), device=weight.device, dtype=torch.bfloat16) if want_dgrad else None
+    _lib.call("tmf_pack_conv_weights_split3", weight.data_ptr(), wf.data_ptr(), _ptr(wd), cout, cin, k ** 3, _stream())
+    return wf, wd
+
+
 def conv3d_split_raw(x, w3, cin, cout, want_stats):
     """fp32-accurate conv on the bf16 matrix cores; w3 = split3_bf16(packed [27][cout][cin] fp32 weights)."""
     B, D, H, W = x.shape[:4]
@@ -263,12 +273,16 @@ class ConvBnActPool(torch.autograd.Function):
             wf, wd = pack_weights_both(weight, ctx.needs_input_grad[0])
         elif bf16 == "bf16":
             wf, wd = pack_weights_both_bf16(weight, ctx.needs_input_grad[0] and cout % 8 == 0)
+        elif ctx.needs_input_grad[0] and cout % 8 == 0:      # fp32x: both split layouts in one launch
+            wf, wd = pack_weights_split3(weight, True)
+        else:
+            wf, wd = pack_weights_split3(weight, False)
 
         def conv(stats):
             if bf16 == "bf16":
                 return conv3d_bf16_raw(x, wf, cin, cout, stats, out_bf16=z16)
             if bf16 == "fp32x":
-                return conv3d_split_raw(x, split3_bf16(weight.permute(2, 3, 4, 0, 1).contiguous()), cin, cout, stats)
+                return conv3d_split_raw(x, wf, cin, cout, stats)
             return conv3d_raw(x, wf, cin, cout, k, stats)
 
         dev = x.device
@@ -346,8 +360,7 @@ class ConvBnActPool(torch.autograd.Function):
             if ctx.bf16 == "bf16" and cout % 8 == 0:
                 dx, _, _ = conv3d_bf16_raw(dz, weight, cout, cin, False, out_bf16=x.dtype == _b16)    # weight = packed wd
             elif ctx.bf16 == "fp32x" and cout % 8 == 0:
-                w3 = split3_bf16(weight.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())
-                dx, _, _ = conv3d_split_raw(dz, w3, cout, cin, False)
+                dx, _, _ = conv3d_split_raw(dz, weight, cout, cin, False)             # weight = packed split wd
             else:
                 dzf = dz if dz.dtype == _f32 else dz.float()
                 dx, _, _ = conv3d_raw(dzf, weight if ctx.packed_dgrad else pack_weight_dgrad(weight), cout, cin, k, False)
@@ -491,7 +504,7 @@ SNET_ONE_CALL = os.environ.get("TMF_SNET_C", "1") != "0"
 
 
 def snet_one_call_supported(B, D, H, W, dim, precision=None):
-    return (SNET_ONE_CALL and resolve_precision(precision)[0] in ("fp32", "bf16") and dim >= 32 and dim % 32 == 0
+    return (SNET_ONE_CALL and resolve_precision(precision)[0] in ("fp32", "bf16", "fp32x") and dim >= 32 and dim % 32 == 0
             and min(D, H, W) >= 16 and B > 0)
 
 
@@ -537,7 +550,9 @@ def remove_flat_grad_consumer(consumer) -> None:
 
 
 def _publish_flat_grads(flat, param_ptrs, views, segments) -> None:
-    """param_ptrs[i]: data pointer of the parameter whose gradient is views[i] (None: that input got no gradient)."""
+    """param_ptrs[i]: data pointer of the parameter whose gradient is views[i] (None: that input got no gradient).
+    A consumer must not KEEP a reference to a view: autograd adopts an incoming gradient as ``.grad`` without a copy only
+    while it holds the last reference."""
     for c in list(_FLAT_GRAD_CONSUMERS):
         c.tmf_flat_grads(flat, param_ptrs, views, segments)
 
@@ -555,7 +570,7 @@ class SNetTrain(torch.autograd.Function):
         dim, momentum, eps, slope = cfg[:4]
         mode, act16 = resolve_precision(cfg[4] if len(cfg) > 4 else None)
         B, _, D, H, W = vol.shape
-        desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision=1 if mode == "bf16" else 0, storage_bf16=int(act16),
+        desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision={"fp32": 0, "bf16": 1, "fp32x": 2}[mode], storage_bf16=int(act16),
                              flags=_lib.SNET_ALONE if (len(cfg) > 5 and cfg[5]) else 0)
         prm = _lib.SnetParams()
         for l in range(7):

@@ -52,12 +52,14 @@ class Adam(torch.optim.Optimizer):
                 offs.append(off)
                 off += (p.numel() + 3) & ~3
             pptr = (C.c_void_p * len(sub))(*[p.data_ptr() for p in sub])
-            # step counts as Python ints: [0] = the count every parameter of the chunk shares, [1] = {index: count} of the
-            # parameters that sat out a step (torch's bias correction is per parameter); the per-parameter `step` tensors of
-            # torch's state layout are refreshed from them when somebody looks (state_dict, pickling)
-            chunks.append((sub, m, v, offs, numel, pptr, [0, None]))
+            # step counts as Python ints (no 156 x `.item()` per step): [0] = the count every parameter of the chunk shares,
+            # [1] = {index: count} once some parameter sat out a step (torch's bias correction is per parameter), [2] = the
+            # CPU tensor that every state[p]["step"] of the chunk IS while the counts agree (one add_ per step keeps torch's
+            # state layout current); after a divergence each parameter gets a tensor of its own
+            shared = torch.tensor(0.0)           # ONE `step` tensor for the whole chunk while the counts agree
+            chunks.append((sub, m, v, offs, numel, pptr, [0, None, shared]))
             for p, o in zip(sub, offs):          # torch's per-parameter layout, as views of the flat buffers
-                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": m[o:o + p.numel()].view_as(p),
+                self.state[p] = {"step": shared, "exp_avg": m[o:o + p.numel()].view_as(p),
                                  "exp_avg_sq": v[o:o + p.numel()].view_as(p)}
         self._flat[id(group)] = chunks
         return chunks
@@ -89,14 +91,18 @@ class Adam(torch.optim.Optimizer):
                     grads.append(g if g.is_contiguous() else g.contiguous())
                 if not missing and cnt[1] is None:                   # every step of a normal run: ONE count for the chunk
                     cnt[0] += 1
+                    cnt[2].add_(1.0)
                     steps = None
                     todo = (cnt[0],)
                 else:                                                # some parameter sat out a step, now or earlier
                     if cnt[1] is None:
                         cnt[1] = {i: cnt[0] for i in range(len(sub))}
+                        for p in sub:
+                            self.state[p]["step"] = torch.tensor(float(cnt[0]))
                     for i, g in enumerate(grads):
                         if g is not None:
                             cnt[1][i] += 1
+                            self.state[sub[i]]["step"] += 1
                     steps = [cnt[1][i] if g is not None else None for i, g in enumerate(grads)]
                     todo = sorted({s_ for s_ in steps if s_ is not None})
                 # one launch per distinct step count (one, unless some parameter sat out earlier steps)
@@ -108,22 +114,6 @@ class Adam(torch.optim.Optimizer):
                                   float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), step,
                                   torch.cuda.current_stream().cuda_stream)
         return loss
-
-    def _sync_step_tensors(self):
-        """Write the Python-side step counts into torch's per-parameter `step` tensors."""
-        for chunks in (getattr(self, "_flat", None) or {}).values():
-            for sub, _m, _v, _offs, _numel, _pptr, cnt in chunks:
-                for i, p in enumerate(sub):
-                    n = cnt[0] if cnt[1] is None else cnt[1][i]
-                    self.state[p]["step"] = torch.tensor(float(n))
-
-    def state_dict(self):
-        self._sync_step_tensors()
-        return super().state_dict()
-
-    def __getstate__(self):
-        self._sync_step_tensors()
-        return super().__getstate__()
 
     def load_state_dict(self, state_dict):
         """torch's loader replaces the per-parameter state tensors: copy them back into the flat buffers the kernel uses."""
@@ -149,5 +139,8 @@ class Adam(torch.optim.Optimizer):
                     counts.append(n)
                 if len(set(counts)) <= 1:
                     cnt[0], cnt[1] = (counts[0] if counts else 0), None
+                    cnt[2].fill_(float(cnt[0]))
+                    for p in sub:
+                        self.state[p]["step"] = cnt[2]
                 else:
                     cnt[0], cnt[1] = max(counts), dict(enumerate(counts))

@@ -197,7 +197,9 @@ class GradAllReduce(nn.Module):
             p = self._param_of(ptr)
             if p is None or p.grad is not None or p in self._covered:
                 return                          # not ours / accumulation into an existing .grad: end-of-backward path
-            params.append((p, v))
+            # (only the ADDRESS of the view is kept: autograd adopts an incoming gradient as .grad without a copy only
+            #  while nobody else holds a reference to it)
+            params.append((p, v.data_ptr()))
         if not params:
             return
         if not self._callback_queued:           # (a backward started from an output the wrapper never saw)
@@ -306,8 +308,8 @@ class GradAllReduce(nn.Module):
         full = self._checked_steps < 3
         self._checked_steps += 1
         for _flat, params, _works, _d in self._inplace:
-            for p, v in (params if full else (params[0], params[-1])):
-                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+            for p, vptr in (params if full else (params[0], params[-1])):
+                if p.grad is None or p.grad.data_ptr() != vptr:
                     raise RuntimeError(
                         "GradAllReduce: a gradient view of a whole-pass node was not adopted as .grad (the parameter also "
                         "receives a gradient from elsewhere in the graph?) — set TMF_DDP_INPLACE=0 to reduce everything at "
