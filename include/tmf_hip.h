@@ -491,6 +491,14 @@ int    tmf_heads_bwd(const tmf_heads_desc* d, const float* cls, const float* mas
                      float* d_cls, float* d_mri_tok, float* d_pet_tok, float revgrad_alpha,
                      void* scratch, size_t scratch_bytes, void* stream);
 
+/* Scaled keep-masks of several nn.Dropout modules in ONE launch (mymodel.py:190-191: the two Dropout(0.5) of fc_cls; the
+ * Dropout modules of the fusion block, networks.py:131,133,153): out[s][e] = 1 / keep[s] with probability keep[s], else 0,
+ * from a counter-based generator (Philox4x32-10 keyed by `seed`, counter = (element / 4, segment, offset)): the masks are a
+ * pure function of (seed, offset), `offset` distinguishes the calls of a run.  nseg <= TMF_MASK_SEGMENTS. */
+#define TMF_MASK_SEGMENTS 20
+int    tmf_dropout_keep_masks(int nseg, float* const* out, const long* numel, const float* keep,
+                              unsigned long long seed, unsigned long long offset, void* stream);
+
 /* The heads of the CNN-only models, one launch per direction (csrc/heads.hip).
  * reference: models/mymodel.py:143-178 model_CNN_ad — `fc_cls` = Linear(2 dim, H)-ReLU-Linear(H, NC) on
  * cat[gap(mri), gap(pet)] and `D` (as in model_ad) on revgrad(gap(mri), 2), revgrad(gap(pet), 2): M = 2, HD = 128;

@@ -1160,3 +1160,43 @@ def test_weight_gradients_write_only_output_and_workspace(shape):
         assert (wbig[:pad] == sent).all() and (wbig[pad + nws:] == sent).all(), entry
         assert (dbig[:pad] == sent).all() and (dbig[pad + ndw:] == sent).all(), entry
         assert int((dbig[pad:pad + ndw] == sent).sum()) == 0, entry
+
+
+def test_dropout_keep_masks_one_launch():
+    """tmf_dropout_keep_masks (ops.dropout_keep_masks): the scaled keep-masks of several nn.Dropout modules from ONE launch of a
+    counter-based Philox generator — values are 0 or 1 / keep, the keep rate is right to 4 sigma, segments and calls differ,
+    the same torch seed and call sequence reproduce the same masks, inactive modules get None, a stand-in's own mask passes
+    through."""
+    ops = _ops()
+    from torch import nn
+
+    class Fixed(nn.Module):
+        def tmf_keep_mask(self, training):
+            return torch.full((4, 8), 2.0) if training else None
+    drops = [nn.Dropout(0.5), nn.Dropout(0.3), nn.Dropout(0.0), nn.Dropout(0.5).eval(), Fixed(), nn.Dropout(1.0), nn.Dropout(0.5)]
+    shapes = [(8, 512), (1728, 128), (8, 64), (8, 64), (4, 8), (3, 5), (8, 64)]
+
+    def draw():
+        return ops.dropout_keep_masks(list(zip(drops, shapes)), torch.device(DEV))
+    torch.manual_seed(1234)
+    ops._MASK_CALLS = 0
+    m = draw()
+    m2 = draw()
+    torch.manual_seed(1234)
+    ops._MASK_CALLS = 0
+    r = draw()
+    torch.cuda.synchronize()
+    assert m[2] is None and m[3] is None and torch.equal(m[4].cpu(), torch.full((4, 8), 2.0)) and not m[5].any()
+    for i, keep in ((0, 0.5), (1, 0.7), (6, 0.5)):
+        v = m[i]
+        assert v.shape == shapes[i] and v.dtype == torch.float32 and v.is_contiguous()
+        inv = torch.tensor(1.0 / keep, dtype=torch.float32).item()
+        assert bool(((v == 0) | (v == inv)).all())
+        n = v.numel()
+        rate = (v != 0).float().mean().item()
+        assert abs(rate - keep) <= 4 * (keep * (1 - keep) / n) ** 0.5, (i, rate)
+        assert torch.equal(v, r[i])                                  # same seed, same call sequence: same masks
+        assert not torch.equal(v, m2[i])                             # the next call draws other masks
+    assert not torch.equal(m[0][:, :64], m[6])                       # segments of one call are independent streams
+    # rows are not copies of each other (the counter runs over the whole segment)
+    assert (m[1][0] != m[1][1]).any() and (m[0][0] != m[0][1]).any()

@@ -698,26 +698,38 @@ def test_one_call_encoder_is_taken_by_default():
     assert type(out.grad_fn.next_functions[0][0]).__name__.startswith("SNetTrain"), out.grad_fn.next_functions
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16s"])
 @pytest.mark.parametrize("name", ["ad_tiny", "ad_adni_b2"])
-def test_one_call_eval_encoder_is_bit_identical_to_block_by_block(name):
-    """tmf_snet_eval_fwd (val_step's encoder as one library call) enqueues the launches of the block-by-block eval path:
-    after one train step (so the running statistics are not the initial ones) the eval tokens of both are bit-identical."""
+def test_one_call_eval_encoder_is_bit_identical_to_block_by_block(name, mode):
+    """tmf_snet_eval_fwd (val_step's encoder as one library call; the bf16 modes since round 4) enqueues the launches of the
+    block-by-block eval path: after one train step (so the running statistics are not the initial ones) the eval tokens of
+    both are bit-identical, and the one-call path really is the one taken."""
+    import transmf_ad_amd as T
     from transmf_ad_amd import ops
     g = Golden(name)
-    net = build(g)
-    step(net, g, train=True)
-    net.eval()
-    mri, pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+    T.set_conv_precision("fp32" if mode == "fp32" else "bf16")
+    T.set_activation_storage("bf16" if mode == "bf16s" else "fp32")
     toks = []
+    calls = []
+    orig = ops.snet_eval_one_call
     try:
+        net = build(g)
+        step(net, g, train=True)
+        net.eval()
+        mri, pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+        ops.snet_eval_one_call = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
         for one_call in (True, False):
             ops.SNET_ONE_CALL = one_call
             with torch.no_grad():
                 toks.append((net.mri_cnn.forward_channels_last(mri), net.pet_cnn.forward_channels_last(pet)))
     finally:
+        ops.snet_eval_one_call = orig
         ops.SNET_ONE_CALL = True
+        T.set_activation_storage("fp32")
+        T.set_conv_precision("fp32")
+    assert len(calls) == 2                                    # both encoders of the first pass, none of the second
     assert torch.equal(toks[0][0], toks[1][0]) and torch.equal(toks[0][1], toks[1][1])
-    assert toks[0][0].abs().max().item() > 0
+    assert toks[0][0].abs().max().item() > 0 and toks[0][0].dtype == torch.float32
 
 
 @pytest.mark.parametrize("name", ["ad_mid", "ad_full_b2_blobs"])

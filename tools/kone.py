@@ -19,6 +19,7 @@ ap.add_argument("--S", type=int, default=96)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--waves", type=int, default=16)
 ap.add_argument("--spin", type=int, default=0, help="launches of another conv shape first (loaded clock state)")
+ap.add_argument("--fill", default="randn", help="operand data: randn | zeros (the chip clocks to its power budget: DVFS)")
 ap.add_argument("--v2", type=int, default=1, help="tmf_set_option('bf16_v2', v): 0 small-brick, 2 8x8x8-brick bf16 forward kernel")
 a = ap.parse_args()
 _lib.call("tmf_set_option", b"conv_waves", a.waves)
@@ -26,9 +27,10 @@ _lib.call("tmf_set_option", b"bf16_v2", a.v2)
 name, cin, cout, k, div = [l for l in LAYERS if l[0] == a.layer][0]
 s = a.S // div
 dev = "cuda:0"
-x = torch.randn((a.B, s, s, s, cin), device=dev)
-w = torch.randn((cout, cin, k, k, k), device=dev) * (cin * k ** 3) ** -0.5
-dz = torch.randn((a.B, s, s, s, cout), device=dev)
+gen = torch.zeros if a.fill == "zeros" else torch.randn
+x = gen((a.B, s, s, s, cin), device=dev)
+w = gen((cout, cin, k, k, k), device=dev) * (cin * k ** 3) ** -0.5
+dz = gen((a.B, s, s, s, cout), device=dev)
 wp, wd = ops.pack_weight(w), ops.pack_weight_dgrad(w)
 if a.spin:
     ws = torch.randn((27, 32, 32), device=dev) * 0.03

@@ -105,6 +105,7 @@ class SnetParams(C.Structure):
 class SnetGrads(C.Structure):
     _fields_ = [("dweight", _p * 7), ("dbias", _p * 7), ("dgamma", _p * 7), ("dbeta", _p * 7), ("deep_event", _p)]
 SNET_DEEP_FROM = 3
+MASK_SEGMENTS = 20           # TMF_MASK_SEGMENTS
 
 
 PROTOTYPES.update({
@@ -173,6 +174,7 @@ class HeadsGrads(C.Structure):
 PROTOTYPES.update({
     "tmf_heads_saved_bytes": (_z, [C.POINTER(HeadsDesc)]),
     "tmf_heads_bwd_scratch_bytes": (_z, [C.POINTER(HeadsDesc)]),
+    "tmf_dropout_keep_masks": (_i, [_i, _p, _p, _p, C.c_ulonglong, C.c_ulonglong, _p]),
     "tmf_heads_fwd": (_i, [C.POINTER(HeadsDesc), _p, _p, _p, _p, _p, C.POINTER(HeadsParams), _p, _p, _p, _p, _z, _p]),
     "tmf_heads_bwd": (_i, [C.POINTER(HeadsDesc), _p, _p, _p, C.POINTER(HeadsParams), _p, _z, _p, _p, _p,
                            C.POINTER(HeadsGrads), _p, _p, _p, _f, _p, _z, _p]),

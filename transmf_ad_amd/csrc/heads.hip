@@ -911,6 +911,66 @@ int check_params(const char* fn, const tmf_heads_params* p) {
 
 }  // namespace
 
+namespace {
+// Philox4x32-10 (Salmon et al., SC'11): counter (c0..c3), key (k0, k1) -> four 32-bit words.  Counter-based, so a keep-mask
+// is a pure function of (seed, call offset, element index): no generator state on the device, reproducible under a seed.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned (&out)[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+        c1 = (unsigned)p1; c3 = (unsigned)p0; c0 = n0; c2 = n2;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// Scaled Dropout keep-masks of up to TMF_MASK_SEGMENTS tensors in ONE launch: element e of segment s is 1 / keep_s with
+// probability keep_s, else 0 (u = 24 random bits; keep iff u < keep * 2^24).  Four elements per Philox call.
+struct MaskSeg { float* out; long n; float keep, inv; };
+struct MaskArgs { MaskSeg seg[TMF_MASK_SEGMENTS]; int nseg; unsigned long long seed, offset; };
+__global__ __launch_bounds__(256) void dropout_masks_kernel(MaskArgs a) {
+    long q = (long)blockIdx.x * 256 + threadIdx.x;            // quad index over all segments
+    for (int s = 0; s < a.nseg; ++s) {
+        const long nq = (a.seg[s].n + 3) >> 2;
+        if (q < nq) {
+            unsigned r[4];
+            philox4x32_10((unsigned)q, (unsigned)(q >> 32) ^ ((unsigned)s << 24), (unsigned)a.offset, (unsigned)(a.offset >> 32),
+                          (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
+            const float thr = a.seg[s].keep * 16777216.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long e = 4 * q + j;
+                if (e < a.seg[s].n) a.seg[s].out[e] = (float)(r[j] >> 8) < thr ? a.seg[s].inv : 0.f;
+            }
+            return;
+        }
+        q -= nq;
+    }
+}
+}  // namespace
+
+extern "C" int tmf_dropout_keep_masks(int nseg, float* const* out, const long* numel, const float* keep,
+                                      unsigned long long seed, unsigned long long offset, void* stream) {
+    TMF_REQUIRE(nseg > 0 && nseg <= TMF_MASK_SEGMENTS, TMF_E_ARG, "tmf_dropout_keep_masks: %d segments (1 .. %d)", nseg,
+                TMF_MASK_SEGMENTS);
+    TMF_REQUIRE_PTR(out); TMF_REQUIRE_PTR(numel); TMF_REQUIRE_PTR(keep);
+    MaskArgs a;
+    a.nseg = nseg; a.seed = seed; a.offset = offset;
+    long quads = 0;
+    for (int s = 0; s < nseg; ++s) {
+        TMF_REQUIRE(out[s] != nullptr && numel[s] > 0, TMF_E_ARG, "tmf_dropout_keep_masks: segment %d is empty", s);
+        TMF_REQUIRE(keep[s] > 0.f && keep[s] <= 1.f, TMF_E_ARG, "tmf_dropout_keep_masks: keep probability %g of segment %d",
+                    (double)keep[s], s);
+        a.seg[s] = MaskSeg{out[s], numel[s], keep[s], 1.0f / keep[s]};
+        quads += (numel[s] + 3) >> 2;
+    }
+    TMF_REQUIRE(quads < (1L << 31) * 256L, TMF_E_SHAPE, "tmf_dropout_keep_masks: too many elements");
+    hipLaunchKernelGGL(dropout_masks_kernel, dim3((unsigned)tmf_cdiv(quads, 256L)), dim3(256), 0, (hipStream_t)stream, a);
+    return tmf_launch_result("tmf_dropout_keep_masks");
+}
+
 extern "C" size_t tmf_heads_saved_bytes(const tmf_heads_desc* d) {
     if (check_heads("tmf_heads_saved_bytes", d) != TMF_OK) return 0;
     return (size_t)saved_plan(d->B, d->dim, d->H1, d->H2, d->HD).total * 4;

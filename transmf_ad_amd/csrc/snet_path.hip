@@ -213,20 +213,24 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
     return TMF_OK;
 }
 
-// Inference (val_step, kfold_train_adversarial.py:144-161): BatchNorm is affine in eval mode, so a block is ONE kernel
-// (conv + folded BatchNorm + LeakyReLU + pool, tmf_conv3d_fwd_affine; the fused first-block forward for block 0) — seven
-// launches + seven weight packs + seven coefficient kernels per encoder, enqueued by one call.  fp32 precision only.
+// Inference (val_step, kfold_train_adversarial.py:144-161): BatchNorm is affine in eval mode, so in the fp32 precision a block
+// is ONE kernel (conv + folded BatchNorm + LeakyReLU + pool, tmf_conv3d_fwd_affine; the fused first-block forward for block
+// 0) — seven launches + seven weight packs + seven coefficient kernels per encoder, enqueued by one call.  In the bf16
+// precisions (round 4) the blocks keep the train path's two kernels — the bf16 matrix-core convolution without statistics,
+// then normalise + LeakyReLU + pool with the folded coefficients — i.e. exactly the launches of the block-by-block path
+// (bit-identical, tested), issued by one call as well.
 extern "C" size_t tmf_snet_eval_workspace_bytes(const tmf_snet_desc* d) {
     if (check_desc("tmf_snet_eval_workspace_bytes", d) != TMF_OK) return 0;
     tmf_snet_desc e = *d;
-    e.precision = TMF_PREC_FP32; e.storage_bf16 = 0;
-    return make_plan(e).saved_bytes;            // same carving: block outputs, per-block vectors, packed weights
+    if (e.precision == TMF_PREC_FP32X) { e.precision = TMF_PREC_FP32; e.storage_bf16 = 0; }
+    return make_plan(e).saved_bytes;            // same carving: raw conv outputs (bf16 modes), block outputs, vectors, packed weights
 }
 
 extern "C" int tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const tmf_snet_params* prm,
                                  void* workspace, size_t workspace_bytes, float* out, void* stream) {
     TMF_TRY(check_desc("tmf_snet_eval_fwd", d));
-    TMF_REQUIRE(d->precision == TMF_PREC_FP32, TMF_E_ARG, "tmf_snet_eval_fwd: fp32 precision only");
+    TMF_REQUIRE(d->precision == TMF_PREC_FP32 || d->precision == TMF_PREC_BF16, TMF_E_ARG,
+                "tmf_snet_eval_fwd: fp32 and bf16 precisions only");
     TMF_REQUIRE_PTR(vol); TMF_REQUIRE_PTR(prm); TMF_REQUIRE_PTR(workspace); TMF_REQUIRE_PTR(out);
     TMF_REQUIRE_ALIGNED(vol); TMF_REQUIRE_ALIGNED(workspace); TMF_REQUIRE_ALIGNED(out);
     const Plan p = make_plan(*d);
@@ -236,21 +240,37 @@ extern "C" int tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const
         TMF_REQUIRE(prm->weight[l] && prm->gamma[l] && prm->beta[l] && prm->running_mean[l] && prm->running_var[l], TMF_E_NULL,
                     "tmf_snet_eval_fwd: weight / gamma / beta / running statistics of block %d is NULL", l);
     char* base = (char*)workspace;
+    const bool b16 = d->precision == TMF_PREC_BF16;
     const void* x = vol;
     for (int l = 0; l < NL; ++l) {
         const LayerPlan& L = p.L[l];
         const Vecs v = vecs_of(base, L);
-        float* o = l == NL - 1 ? out : (float*)(base + L.off_out);
-        float* wf = (float*)(base + L.off_wf);
-        TMF_TRY(tmf_pack_conv_weights(prm->weight[l], wf, nullptr, L.cout, L.cin, L.k * L.k * L.k, stream));
+        void* o = l == NL - 1 ? (void*)out : (void*)(base + L.off_out);
+        void* wf = base + L.off_wf;
+        if (L.bf) TMF_TRY(tmf_pack_conv_weights_bf16(prm->weight[l], wf, nullptr, L.cout, L.cin, 27, stream));
+        else TMF_TRY(tmf_pack_conv_weights(prm->weight[l], (float*)wf, nullptr, L.cout, L.cin, L.k * L.k * L.k, stream));
         TMF_TRY(tmf_bn_eval_coeffs(prm->gamma[l], prm->beta[l], prm->bias[l], prm->running_mean[l], prm->running_var[l],
                                    d->eps[l], L.cout, v.scale, v.shift, stream));
         if ((size_t)L.oD * L.oH * L.oW == 0) continue;
-        if (l == 0)
-            TMF_TRY(tmf_c1_bn_pool_fwd(vol, wf, v.scale, v.shift, o, d->B, L.D, L.H, L.W, L.cout, d->slope[l], stream));
-        else
-            TMF_TRY(tmf_conv3d_fwd_affine((const float*)x, wf, v.scale, v.shift, o, d->B, L.D, L.H, L.W, L.cin, L.cout, L.k,
-                                          L.pool, d->slope[l], stream));
+        if (l == 0) {
+            if (b16) TMF_TRY(tmf_c1_bn_pool_fwd_bf16(vol, (const float*)wf, v.scale, v.shift, o, d->B, L.D, L.H, L.W, L.cout,
+                                                     d->slope[l], L.o16 ? 1 : 0, stream));
+            else     TMF_TRY(tmf_c1_bn_pool_fwd(vol, (const float*)wf, v.scale, v.shift, (float*)o, d->B, L.D, L.H, L.W, L.cout,
+                                                d->slope[l], stream));
+        } else if (L.bf) {
+            void* z = base + L.off_z;
+            TMF_TRY(tmf_conv3d_fwd_bf16_t(x, wf, z, nullptr, d->B, L.D, L.H, L.W, L.cin, L.cout,
+                                          (L.x16 ? 1 : 0) | (L.z16 ? 2 : 0), stream));
+            TMF_TRY(tmf_bn_act_pool_fwd_t(z, v.scale, v.shift, o, d->B, L.D, L.H, L.W, L.cout, L.pool, d->slope[l],
+                                          (L.z16 ? 1 : 0) | (L.o16 ? 2 : 0), stream));
+        } else if (b16) {       // a block the bf16 kernels do not take (the 1x1x1 layer) inside a bf16 encoder: two kernels, fp32
+            float* z = (float*)(base + L.off_z);
+            TMF_TRY(tmf_conv3d_fwd((const float*)x, (const float*)wf, z, nullptr, d->B, L.D, L.H, L.W, L.cin, L.cout, L.k, stream));
+            TMF_TRY(tmf_bn_act_pool_fwd_t(z, v.scale, v.shift, o, d->B, L.D, L.H, L.W, L.cout, L.pool, d->slope[l], 0, stream));
+        } else {
+            TMF_TRY(tmf_conv3d_fwd_affine((const float*)x, (const float*)wf, v.scale, v.shift, (float*)o, d->B, L.D, L.H, L.W,
+                                          L.cin, L.cout, L.k, L.pool, d->slope[l], stream));
+        }
         x = o;
     }
     return TMF_OK;

@@ -288,16 +288,9 @@ class model_ad(_FastModeSwitch, nn.Module):
         from . import ops
         fc, D = self.fc_cls, self.D
         B = cls.shape[0]
-        masks = []
-        for drop, width in ((fc[3], fc[0].out_features), (fc[7], fc[4].out_features)):
-            if hasattr(drop, "tmf_keep_mask"):                 # test stand-in with a fixed mask
-                masks.append(drop.tmf_keep_mask(self.training))
-            elif self.training and drop.p > 0:                 # nn.Dropout: Bernoulli(1 - p) keep-mask, scaled (torch RNG)
-                keep = 1.0 - drop.p
-                masks.append(torch.bernoulli(torch.full((B, width), keep, device=cls.device)) / keep if keep > 0
-                             else torch.zeros((B, width), device=cls.device))
-            else:
-                masks.append(None)
+        # both keep-masks in ONE launch (ops.dropout_keep_masks -> tmf_dropout_keep_masks; a test stand-in with a fixed mask
+        # supplies its own) instead of full + bernoulli + divide per mask
+        masks = ops.dropout_keep_masks([(fc[3], (B, fc[0].out_features)), (fc[7], (B, fc[4].out_features))], cls.device)
         bns = (fc[1], fc[5], D[1])
         if self.training:
             nbt = [bn.num_batches_tracked for bn in bns if bn.track_running_stats]

@@ -91,12 +91,13 @@ class sNet(nn.Module):
                 torch._foreach_add_(nbt, 1)
         blocks = [(getattr(self, n)[i], getattr(self, n)[i + 1], getattr(self, n)[i + 2]) for n, i, _ in self._PLAN]
         prec = ops.resolve_precision(self.tmf_precision)
-        if (not self.training and not torch.is_grad_enabled() and prec[0] == "fp32" and ops.FUSE_EVAL_BLOCKS
-                and all(bn.track_running_stats for _c, bn, _a in blocks) and self._one_call_ok(vol, blocks, eval_mode=True)):
+        if (not self.training and not torch.is_grad_enabled() and prec[0] in ("fp32", "bf16") and ops.FUSE_EVAL_BLOCKS
+                and all(bn.track_running_stats for _c, bn, _a in blocks)
+                and self._one_call_ok(vol, blocks, eval_mode=True, prec=prec)):
             return ops.snet_eval_one_call(
                 vol, blocks[-1][0].out_channels, tuple(float(bn.eps) for _c, bn, _a in blocks),
                 tuple(float(a.negative_slope) for _c, _b, a in blocks),
-                [(c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var) for c, bn, _a in blocks])
+                [(c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var) for c, bn, _a in blocks], prec)
         if self._one_call_ok(vol, blocks, prec=prec):
             params, buffers = [], []
             for conv, bn, _act in blocks:

@@ -508,13 +508,15 @@ def snet_one_call_supported(B, D, H, W, dim, precision=None):
             and min(D, H, W) >= 16 and B > 0)
 
 
-def snet_eval_one_call(vol, dim, eps, slope, blocks):
+def snet_eval_one_call(vol, dim, eps, slope, blocks, precision=None):
     """Eval-mode sNet forward as ONE library call (tmf_snet_eval_fwd): no autograd graph (val_step runs under no_grad).
-    blocks: 7 x (conv weight, conv bias | None, bn weight, bn bias, running_mean, running_var)."""
+    blocks: 7 x (conv weight, conv bias | None, bn weight, bn bias, running_mean, running_var); precision: fp32 (a block is
+    one kernel) or bf16 [+ bf16 storage] (the block-by-block launches, enqueued by one call)."""
     import ctypes as C
     vol = _chk(vol, "vol")
     B, _, D, H, W = vol.shape
-    desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision=0, storage_bf16=0)
+    mode, act16 = resolve_precision(precision)
+    desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision={"fp32": 0, "bf16": 1}[mode], storage_bf16=int(act16))
     prm = _lib.SnetParams()
     for l, (w, b, g, be, rm, rv) in enumerate(blocks):
         desc.eps[l], desc.slope[l], desc.momentum[l] = eps[l], slope[l], 0.0
@@ -909,24 +911,39 @@ def dropout_keep_mask(drop, shape, device):
     return torch.empty(shape, device=device, dtype=_f32).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
+_MASK_CALLS = 0          # per-process call counter: the `offset` of tmf_dropout_keep_masks (distinct masks per call, reproducible
+#                          under torch.manual_seed for a given sequence of calls)
+
+
 def dropout_keep_masks(requests, device):
-    """Scaled keep-masks for MANY Dropout modules in as few launches as possible: requests = [(drop, shape), ...] -> list of
-    masks (None where inactive).  All stock nn.Dropout modules with the same p share ONE flat buffer drawn by one
-    bernoulli_ + one div_ (the fusion block at depth 3 asks for 18 masks per step: 36 launches one by one, 2 this way);
-    modules that bring their own mask (``tmf_keep_mask``) and p >= 1 are served as in dropout_keep_mask."""
+    """Scaled keep-masks for MANY Dropout modules in ONE launch (tmf_dropout_keep_masks: a counter-based Philox generator
+    keyed by torch.initial_seed(), so torch.manual_seed makes a run reproducible): requests = [(drop, shape), ...] -> list
+    of fp32 masks (None where the module is inactive).  The two Dropout(0.5) of fc_cls were 6 stock launches per step, the
+    18 masks of a depth-3 fusion block with dropout 36; modules that bring their own mask (``tmf_keep_mask``: the tests'
+    fixed masks) and p >= 1 are served as in dropout_keep_mask."""
+    import ctypes as C
+    global _MASK_CALLS
     out = [None] * len(requests)
-    groups = {}
+    live = []
     for i, (drop, shape) in enumerate(requests):
         p = float(getattr(drop, "p", 0.0))
         if hasattr(drop, "tmf_keep_mask") or p >= 1.0 or p <= 0.0 or not drop.training:
             out[i] = dropout_keep_mask(drop, shape, device)
         else:
-            groups.setdefault(p, []).append(i)
-    for p, idx in groups.items():
-        sizes = [int(torch.Size(requests[i][1]).numel()) for i in idx]
-        flat = torch.empty(sum(sizes), device=device, dtype=_f32).bernoulli_(1.0 - p).div_(1.0 - p)
-        for i, part in zip(idx, flat.split(sizes)):
-            out[i] = part.view(requests[i][1])
+            live.append((i, 1.0 - p, int(torch.Size(shape).numel())))
+    for s0 in range(0, len(live), _lib.MASK_SEGMENTS):
+        part = live[s0:s0 + _lib.MASK_SEGMENTS]
+        sizes = [(n + 3) & ~3 for _i, _k, n in part]                     # 16-byte aligned segments
+        flat = torch.empty(sum(sizes), device=device, dtype=_f32)
+        ptrs, off = [], 0
+        for (i, _k, n), sz in zip(part, sizes):
+            out[i] = flat[off:off + n].view(requests[i][1])
+            ptrs.append(flat.data_ptr() + 4 * off)
+            off += sz
+        _MASK_CALLS += 1
+        _lib.call("tmf_dropout_keep_masks", len(part), (C.c_void_p * len(part))(*ptrs), (C.c_long * len(part))(*[n for _i, _k, n in part]),
+                  (C.c_float * len(part))(*[k for _i, k, _n in part]), torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _MASK_CALLS,
+                  _stream())
     return out
 
 
