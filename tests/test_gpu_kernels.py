@@ -1165,7 +1165,7 @@ def test_weight_gradients_write_only_output_and_workspace(shape):
 def test_dropout_keep_masks_one_launch():
     """tmf_dropout_keep_masks (ops.dropout_keep_masks): the scaled keep-masks of several nn.Dropout modules from ONE launch of a
     counter-based Philox generator — values are 0 or 1 / keep, the keep rate is right to 4 sigma, segments and calls differ,
-    the same torch seed and call sequence reproduce the same masks, inactive modules get None, a stand-in's own mask passes
+    torch.manual_seed reproduces the masks (they are keyed by the device generator's seed and stream offset), inactive modules get None, a stand-in's own mask passes
     through."""
     ops = _ops()
     from torch import nn
@@ -1179,11 +1179,9 @@ def test_dropout_keep_masks_one_launch():
     def draw():
         return ops.dropout_keep_masks(list(zip(drops, shapes)), torch.device(DEV))
     torch.manual_seed(1234)
-    ops._MASK_CALLS = 0
     m = draw()
     m2 = draw()
-    torch.manual_seed(1234)
-    ops._MASK_CALLS = 0
+    torch.manual_seed(1234)                      # resets the device generator's stream offset the masks are keyed by
     r = draw()
     torch.cuda.synchronize()
     assert m[2] is None and m[3] is None and torch.equal(m[4].cpu(), torch.full((4, 8), 2.0)) and not m[5].any()

@@ -911,18 +911,31 @@ def dropout_keep_mask(drop, shape, device):
     return torch.empty(shape, device=device, dtype=_f32).bernoulli_(1.0 - p).div_(1.0 - p)
 
 
-_MASK_CALLS = 0          # per-process call counter: the `offset` of tmf_dropout_keep_masks (distinct masks per call, reproducible
-#                          under torch.manual_seed for a given sequence of calls)
+_MASK_CALLS = 0          # fallback call counter (a generator without an offset API)
+
+
+def _mask_stream(device):
+    """(seed, offset) of the next tmf_dropout_keep_masks call, taken from torch's OWN device generator — the Philox stream
+    position torch's dropout kernels consume — and advanced past it: `torch.manual_seed(s)` therefore reproduces the masks
+    of a run exactly as it reproduces nn.Dropout's (seed and offset are host-side integers: no synchronisation)."""
+    global _MASK_CALLS
+    try:
+        gen = torch.cuda.default_generators[device.index if device.index is not None else torch.cuda.current_device()]
+        off = gen.get_offset()
+        gen.set_offset(off + 4)                              # (torch's offsets move in multiples of 4)
+        return gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, off
+    except Exception:                                        # pragma: no cover
+        _MASK_CALLS += 1
+        return torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, (1 << 40) + _MASK_CALLS
 
 
 def dropout_keep_masks(requests, device):
     """Scaled keep-masks for MANY Dropout modules in ONE launch (tmf_dropout_keep_masks: a counter-based Philox generator
-    keyed by torch.initial_seed(), so torch.manual_seed makes a run reproducible): requests = [(drop, shape), ...] -> list
+    keyed by the seed and stream offset of torch's device generator, so torch.manual_seed makes a run reproducible): requests = [(drop, shape), ...] -> list
     of fp32 masks (None where the module is inactive).  The two Dropout(0.5) of fc_cls were 6 stock launches per step, the
     18 masks of a depth-3 fusion block with dropout 36; modules that bring their own mask (``tmf_keep_mask``: the tests'
     fixed masks) and p >= 1 are served as in dropout_keep_mask."""
     import ctypes as C
-    global _MASK_CALLS
     out = [None] * len(requests)
     live = []
     for i, (drop, shape) in enumerate(requests):
@@ -940,10 +953,9 @@ def dropout_keep_masks(requests, device):
             out[i] = flat[off:off + n].view(requests[i][1])
             ptrs.append(flat.data_ptr() + 4 * off)
             off += sz
-        _MASK_CALLS += 1
+        seed, offset = _mask_stream(device)
         _lib.call("tmf_dropout_keep_masks", len(part), (C.c_void_p * len(part))(*ptrs), (C.c_long * len(part))(*[n for _i, _k, n in part]),
-                  (C.c_float * len(part))(*[k for _i, k, _n in part]), torch.initial_seed() & 0xFFFFFFFFFFFFFFFF, _MASK_CALLS,
-                  _stream())
+                  (C.c_float * len(part))(*[k for _i, k, _n in part]), seed, offset, _stream())
     return out
 
 
