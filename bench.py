@@ -83,7 +83,7 @@ def _pmc_traffic(kernel, precision, storage, B, vol):
     """HBM bytes per launch of a kernel instance from the committed rocprofv3 --pmc passes (counters cannot be read
     live): profiles/r03_pmc_traffic.json = {"precision|storage|B|DxHxW": {kernel instance: {"hbm_bytes_per_launch": ...}}};
     None for configurations that were not profiled."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):          # newest committed pass first
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):          # newest committed pass first
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 tab = json.load(f).get(f"{precision}|{storage}|{B}|{'x'.join(map(str, vol))}", {})
@@ -519,6 +519,9 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
     # one event per step boundary on the stream the steps are issued on (torch's current stream; the side streams of a
     # step join it before the optimizer): per-step times for ms_per_step_min / _median beside the wall-clock mean
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    import gc
+    gc.collect()
+    gc.disable()                # (no collector pause inside the K timed steps: a full collection is milliseconds on a torch heap)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
@@ -526,6 +529,7 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
         marks[i + 1].record()
     torch.cuda.synchronize()
     dt_local = max(time.perf_counter() - t0, 1e-9)          # this rank's own time, before the barrier
+    gc.enable()
     fence()
     dt = max(time.perf_counter() - t0, 1e-9)
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
@@ -672,6 +676,8 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
         out["numerics_gate"] = gate
     if per_rank is not None:
         out["per_rank"] = per_rank
+    if os.environ.get("TMF_BENCH_STEP_TIMES", "0") == "1":      # diagnosis: every timed step's own time
+        out["ms_per_step_list"] = [round(t, 3) for t in per_step]
     if brief:           # an `also` record: the keys the headline carries, minus the contract boilerplate
         for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "conv_tflops_whole_step"):
             out.pop(k, None)
