@@ -403,6 +403,8 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
         if not dist.is_initialized():
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         net = GradAllReduce(net)
+        if os.environ.get("TMF_DDP_NOSYNC", "0") == "1":       # diagnosis: the process group exists, the wrapper reduces nothing
+            net.require_sync = False
     if world > 1:
         net = GradAllReduce(net)
     # same update rule as the reference's getOptimizer (utils/utils.py:38-39: Adam, lr 1e-4, wd 0): every parameter

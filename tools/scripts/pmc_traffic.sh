@@ -16,5 +16,5 @@ python3 tools/pmc_traffic.py $O/b16_fetch $O/b16_write $O/traffic_b16.json --not
 python3 - <<PY
 import json
 a = json.load(open("$O/traffic_f32.json")); b = json.load(open("$O/traffic_b16.json"))
-json.dump({"fp32|fp32|8|96x96x96": a, "bf16|bf16|8|128x128x128": b}, open("$O/r03_pmc_traffic.json", "w"), indent=1)
+json.dump({"fp32|fp32|8|96x96x96": a, "bf16|bf16|8|128x128x128": b}, open("$O/r04_pmc_traffic.json", "w"), indent=1)
 PY

@@ -1,7 +1,7 @@
 # One GPU-box pass that regenerates what profiles/ holds for the round (fp32 headline + configs[2] bf16 report).
-# Run through gpurun from the repo root:  gpurun --timeout 2400 -- 'bash tools/scripts/refresh_profiles.sh r03'
+# Run through gpurun from the repo root:  gpurun --timeout 2400 -- 'bash tools/scripts/refresh_profiles.sh r04'
 # then copy gpurun_out/refresh/* into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/refresh
@@ -23,6 +23,11 @@ timeout 300 python3 bench.py --model cnn --batch 16 --no-cpu-baseline > $O/b.log
 timeout 300 python3 bench.py --model single --batch 16 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_single_b16.json
 timeout 300 python3 bench.py --precision fp32x --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_n1_fp32x.json
 timeout 300 python3 bench.py --eval --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_eval_n1.json
+timeout 300 python3 bench.py --eval --precision bf16 --storage bf16 --size 128 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_eval_128_bf16_storage.json
+timeout 300 python3 bench.py --dropout 0.3 --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_n1_dropout03.json
+TMF_DDP_FORCE=1 TMF_DDP_INPLACE=0 timeout 300 python3 bench.py --no-cpu-baseline > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_ddp_1rank_buckets.json
+timeout 300 python3 bench.py --no-also --no-cpu-baseline --steps 40 > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_bench_n1_plain40.json
+TMF_DDP_FORCE=1 timeout 300 python3 bench.py --no-cpu-baseline --steps 40 > $O/b.log 2>&1; grep "^{" $O/b.log | tail -1 > $O/${TAG}_ddp_1rank_40.json
 # --- kernel-trace statistics of the SAME commands (roofline loop only: the averages the roofline object quotes) ---
 prof() { # name, bench flags...
   n=$1; shift

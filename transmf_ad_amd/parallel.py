@@ -35,6 +35,21 @@ import torch.distributed as dist
 from torch import nn
 
 
+_PROF = os.environ.get("TMF_DDP_PROFILE", "0") == "1"       # host-time accounting of the wrapper's callbacks (diagnosis)
+_PROF_T = {}
+
+
+def _prof_report():
+    for k, v in sorted(_PROF_T.items(), key=lambda kv: str(kv[0])):
+        v2 = v[len(v) // 2:]
+        print(f"[ddp profile] {k}: {len(v)} calls, mean of the later half {sum(v2) / max(len(v2), 1) * 1e6:.1f} us", flush=True)
+
+
+if _PROF:
+    import atexit
+    atexit.register(_prof_report)
+
+
 class _NullCtx:
     def __enter__(self):
         return self
@@ -145,8 +160,14 @@ class GradAllReduce(nn.Module):
             self._buckets.append(b)
         # this backward's in-place reductions: (flat, params, views, [work, ...]) per published buffer
         self._inplace = []
+        self._pending = []
+        self._events = []
+        self._nodes = {}                        # parameter addresses of a node -> (its Parameters, their view offsets)
         self._covered = set()
         self._checked_steps = 0
+        # RCCL / NCCL average inside the collective (ncclAvg): no division launch afterwards; gloo sums, the wrapper divides
+        self._avg = dist.get_backend(process_group) == "nccl" and os.environ.get("TMF_DDP_AVG", "1") != "0"
+        self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
         self.last_reduced_bytes = []            # bytes of every collective of the last backward, in launch order
         self.last_reduced_kinds = []            # "event" | "stream" | "end" (in place) | "bucket" per collective
         if self._live and self._inplace_ok:
@@ -184,55 +205,101 @@ class GradAllReduce(nn.Module):
         return None
 
     def tmf_flat_grads(self, flat, param_ptrs, views, segments):
+        if not _PROF:
+            return self._tmf_flat_grads(flat, param_ptrs, views, segments)
+        import time
+        t0 = time.perf_counter()
+        r = self._tmf_flat_grads(flat, param_ptrs, views, segments)
+        _PROF_T.setdefault(len(param_ptrs), []).append(time.perf_counter() - t0)
+        return r
+
+    def _tmf_flat_grads(self, flat, param_ptrs, views, segments):
         """ops._publish_flat_grads: a whole-pass node finished enqueueing its backward; `views[i]` (a view of `flat`) is the
         gradient of the parameter at `param_ptrs[i]`.  If every one of them is ours and autograd will ADOPT the views (no
         ``.grad`` to accumulate into), all-reduce the ranges of `flat` in place, each behind its event / the producing
         stream."""
         if not (self._live and self.require_sync and flat.is_cuda):
             return
-        params = []
-        for ptr, v in zip(param_ptrs, views):
-            if ptr is None or v is None:
-                continue
-            p = self._param_of(ptr)
-            if p is None or p.grad is not None or p in self._covered:
-                return                          # not ours / accumulation into an existing .grad: end-of-backward path
-            # (only the ADDRESS of the view is kept: autograd adopts an incoming gradient as .grad without a copy only
-            #  while nobody else holds a reference to it)
-            params.append((p, v.data_ptr()))
-        if not params:
+        # This runs in the launch-bound start of backward for the heads and the fusion block (every microsecond here is a
+        # microsecond of idle GPU: a Python loop over the fusion block's 84 parameters was 0.17 ms per step), so what does
+        # not change from step to step — which Parameter each view belongs to, where the view sits in the buffer — is
+        # worked out once per node and cached under the node's parameter addresses.
+        key = tuple(param_ptrs)
+        ent = self._nodes.get(key)
+        if ent is None:
+            plist, offs = [], []
+            for ptr, v in zip(param_ptrs, views):
+                if ptr is None or v is None:
+                    continue
+                p = self._param_of(ptr)
+                if p is None:
+                    plist = None                # not ours (or a parameter whose storage was replaced: the key changes with it)
+                    break
+                plist.append(p)
+                offs.append(v.data_ptr() - flat.data_ptr())     # (only the ADDRESS of a view is ever kept: a kept reference
+                #                                                  would make autograd copy the view instead of adopting it)
+            ent = self._nodes[key] = (plist, offs)
+        plist, offs = ent
+        if not plist:
             return
+        # autograd ADOPTS the views only where there is no .grad to accumulate into: zero_grad(set_to_none=False) keeps every
+        # .grad, so the first and the last parameter of the node tell (a partly zeroed model takes the error of _finalize)
+        if plist[0].grad is not None or plist[-1].grad is not None or plist[0] in self._covered:
+            return                              # accumulation into existing .grad tensors: end-of-backward path
+        base = flat.data_ptr()
+        params = (plist, offs, base)
         if not self._callback_queued:           # (a backward started from an output the wrapper never saw)
             self._callback_queued = True
             torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
         dev = flat.device
         st = self._staging(dev)
         works, deferred = [], []
-        # A buffer with an event range (an encoder: deep blocks final at the event, shallow blocks at the end of the call)
-        # starts ONLY the event range now; its stream range would make the in-order staging stream wait for this encoder's
-        # whole backward — with the OTHER encoder's deep range queued behind it.  Those (small) ranges go out at the end of
-        # backward.  A buffer without an event range (heads, fusion: produced first) goes out at once behind its stream.
+        # WHEN to hand a range to RCCL.  Enqueueing a collective costs the host ~0.1-0.2 ms, and the start of backward
+        # (heads, fusion block) is launch-bound: a collective enqueued there is that much idle GPU (measured: 0.25 + 0.22 ms
+        # of gaps behind the heads' and the fusion block's backward).  So a buffer WITHOUT an event range (heads, fusion) only
+        # records an event behind its last kernel and waits in `_pending`; it goes out when the first encoder reports in — by
+        # then that encoder's whole backward (milliseconds of GPU work) is queued and the host is free —, or at the end of
+        # backward.  A buffer WITH an event range (an encoder: deep blocks final at the event, shallow blocks at the end of
+        # the call) starts the event range at once; its stream range would make the in-order staging stream wait for this
+        # encoder's whole backward with the OTHER encoder's deep range queued behind it, so it goes out at the end of backward.
         has_event = self._early and any(ev is not None for _a, _b, ev in segments)
+        if has_event:
+            self._flush_pending(st)
         for start, stop, ev in segments:
             if stop <= start:
                 continue
             if ev is not None and self._early:
                 st.wait_event(ev)
-                kind = "event"
+                with torch.cuda.stream(st):
+                    works.append(self._all_reduce(flat[start:stop]))
+                self.last_reduced_bytes.append((stop - start) * flat.element_size())
+                self.last_reduced_kinds.append("event")
             elif has_event:
                 deferred.append((start, stop))
-                continue
             else:
-                st.wait_stream(torch.cuda.current_stream(dev))
-                kind = "stream"
-            with torch.cuda.stream(st):
-                works.append(dist.all_reduce(flat[start:stop], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            self.last_reduced_bytes.append((stop - start) * flat.element_size())
-            self.last_reduced_kinds.append(kind)
+                k = len(self._pending)                      # (events are re-used from step to step: creating one is ~10 us)
+                if k == len(self._events):
+                    self._events.append(torch.cuda.Event())
+                done = self._events[k]
+                done.record(torch.cuda.current_stream(dev))
+                self._pending.append((flat, start, stop, done, works))
         flat.record_stream(st)
-        for p, _v in params:
-            self._covered.add(p)
+        self._covered.update(plist)
         self._inplace.append((flat, params, works, deferred))
+
+    def _all_reduce(self, t):
+        return dist.all_reduce(t, op=self._op, group=self.group, async_op=True)
+
+    def _flush_pending(self, st):
+        """Start the collectives of the buffers that reported in without an event range (heads, fusion), each behind the
+        event recorded at the end of its backward."""
+        for flat, start, stop, done, works in self._pending:
+            st.wait_event(done)
+            with torch.cuda.stream(st):
+                works.append(self._all_reduce(flat[start:stop]))
+            self.last_reduced_bytes.append((stop - start) * flat.element_size())
+            self.last_reduced_kinds.append("stream")
+        self._pending = []
 
     def _reduce_rest(self, st):
         """End-of-backward path: every parameter with a gradient that was not reduced in place, through the flat buckets."""
@@ -255,13 +322,21 @@ class GradAllReduce(nn.Module):
                     views[i].zero_()            # no gradient this pass: contribute zeros
             if src:
                 torch._foreach_copy_(dst, src)
-            work = dist.all_reduce(b.flat(), op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = self._all_reduce(b.flat())
             self.last_reduced_bytes.append(b.nbytes)
             self.last_reduced_kinds.append("bucket")
             launched.append((b, todo, work))
         return launched
 
     def _finalize(self):
+        if not _PROF:
+            return self._finalize_impl()
+        import time
+        t0 = time.perf_counter()
+        self._finalize_impl()
+        _PROF_T.setdefault("finalize", []).append(time.perf_counter() - t0)
+
+    def _finalize_impl(self):
         self._callback_queued = False
         first = self._params[0] if self._params else None
         dev = first.device if first is not None else torch.device("cpu")
@@ -273,6 +348,8 @@ class GradAllReduce(nn.Module):
             if self._known_streams is not None:
                 for s_ in self._known_streams(dev):
                     st.wait_stream(s_)
+        if cuda:
+            self._flush_pending(st)              # (no encoder reported in: a module without one)
         with ctx:
             rest = self._reduce_rest(st)
             ev0 = ev1 = None
@@ -282,7 +359,7 @@ class GradAllReduce(nn.Module):
             flats = []
             for flat, _params, works, deferred in self._inplace:          # (the staging stream waited for every stream above)
                 for start, stop in deferred:
-                    works.append(dist.all_reduce(flat[start:stop], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    works.append(self._all_reduce(flat[start:stop]))
                     self.last_reduced_bytes.append((stop - start) * flat.element_size())
                     self.last_reduced_kinds.append("end")
             for flat, _params, works, _d in self._inplace:
@@ -292,7 +369,7 @@ class GradAllReduce(nn.Module):
             for b, _todo, work in rest:
                 work.wait()
                 flats.append(b.flat())
-            if flats:
+            if flats and not self._avg:           # (RCCL averages inside the collective: no scaling launch)
                 torch._foreach_div_(flats, float(self.world))
             if ev0 is not None:
                 ev1.record(st)
@@ -307,9 +384,10 @@ class GradAllReduce(nn.Module):
         # from step to step), afterwards the first and last of each buffer.
         full = self._checked_steps < 3
         self._checked_steps += 1
-        for _flat, params, _works, _d in self._inplace:
-            for p, vptr in (params if full else (params[0], params[-1])):
-                if p.grad is None or p.grad.data_ptr() != vptr:
+        for _flat, (plist, offs, base), _works, _d in self._inplace:
+            for i in (range(len(plist)) if full else (0, len(plist) - 1)):
+                p = plist[i]
+                if p.grad is None or p.grad.data_ptr() != base + offs[i]:
                     raise RuntimeError(
                         "GradAllReduce: a gradient view of a whole-pass node was not adopted as .grad (the parameter also "
                         "receives a gradient from elsewhere in the graph?) — set TMF_DDP_INPLACE=0 to reduce everything at "
@@ -354,8 +432,9 @@ class GradAllReduce(nn.Module):
                     v.zero_()
             if src:
                 torch._foreach_copy_(dst, src)
-            dist.all_reduce(b.flat(), op=dist.ReduceOp.SUM, group=self.group)
-            b.flat().div_(self.world)
+            dist.all_reduce(b.flat(), op=self._op, group=self.group)
+            if not self._avg:
+                b.flat().div_(self.world)
             # copy back INTO the existing .grad tensors (a captured graph owns them and rewrites them on replay)
             if src:
                 torch._foreach_copy_(src, dst)
