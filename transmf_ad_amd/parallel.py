@@ -283,7 +283,9 @@ class GradAllReduce(nn.Module):
                 done = self._events[k]
                 done.record(torch.cuda.current_stream(dev))
                 self._pending.append((flat, start, stop, done, works))
-        flat.record_stream(st)
+        # (no record_stream on the buffer: it lives until the next zero_grad — .grad holds views of it — and by then the
+        #  caller's stream has joined the staging stream in _finalize, so the allocator's ordinary stream-ordered re-use is
+        #  safe; record_stream would park the block behind an event query at every later allocation)
         self._covered.update(plist)
         self._inplace.append((flat, params, works, deferred))
 
