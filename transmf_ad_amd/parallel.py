@@ -152,13 +152,9 @@ class GradAllReduce(nn.Module):
             else:
                 named[gk] = i
                 cur = None                       # an untagged run does not continue across tagged parameters
-        self._where = {}
         for b_ in plan:
-            b = _Bucket(list(b_))
-            for i, p in enumerate(b.params):
-                self._where[p] = (b, i)
-            self._buckets.append(b)
-        # this backward's in-place reductions: (flat, params, views, [work, ...]) per published buffer
+            self._buckets.append(_Bucket(list(b_)))
+        # this backward's in-place reductions: (flat, (parameters, view offsets, base address), [work, ...], deferred ranges)
         self._inplace = []
         self._pending = []
         self._events = []
