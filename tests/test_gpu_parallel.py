@@ -102,9 +102,9 @@ class _Spy:
 
 def test_whole_pass_nodes_publish_their_flat_gradient_buffers():
     """Every whole-pass node hands its ONE flat gradient buffer to the registered consumers at the end of its backward
-    (ops.add_flat_grad_consumer): the encoders as [shallow | deep | conv-bias zeros] with the deep range final at the event
-    tmf_snet_train_bwd records behind blocks conv3.0 .. conv4.3 (behind that event the range already holds its final values),
-    the heads as one range; `.grad` of every covered parameter IS the published view (autograd adopts it: no copy).  Without
+    (ops.add_flat_grad_consumer): the encoders as [shallow | deep | conv-bias zeros] with the deep range ("now") final at the
+    event tmf_snet_train_bwd records behind blocks conv3.0 .. conv4.3 (behind that event the range already holds its final
+    values) and the shallow range at the "end", the heads as one "next" range; `.grad` of every covered parameter IS the published view (autograd adopts it: no copy).  Without
     a consumer nothing is published and nothing is held."""
     from transmf_ad_amd import ops
     net = _build().train()
@@ -118,12 +118,12 @@ def test_whole_pass_nodes_publish_their_flat_gradient_buffers():
     finally:
         ops.remove_flat_grad_consumer(spy)
     by_ptr = {p.data_ptr(): (n, p) for n, p in net.named_parameters()}
-    enc = [g for g in spy.got if any(ev is not None for _a, _b, ev in g[3])]
-    rest = [g for g in spy.got if not any(ev is not None for _a, _b, ev in g[3])]
+    enc = [g for g in spy.got if any(when == "now" for _a, _b, _e, when in g[3])]
+    rest = [g for g in spy.got if not any(when == "now" for _a, _b, _e, when in g[3])]
     assert len(enc) == 2 and len(rest) >= 1                      # two encoders; the heads (the dim-32 fusion goes op by op)
     seen = set()
     for flat, ptrs, views, segs in spy.got:
-        assert sorted((a, b) for a, b, _e in segs)[0][0] == 0 and max(b for _a, b, _e in segs) == flat.numel()
+        assert sorted((a, b) for a, b, _e, _w in segs)[0][0] == 0 and max(b for _a, b, _e, _w in segs) == flat.numel()
         for ptr, v in zip(ptrs, views):
             if ptr is None:
                 continue
@@ -134,8 +134,8 @@ def test_whole_pass_nodes_publish_their_flat_gradient_buffers():
     assert {n for n in by_ptr.values() for n in [n[0]] if "_cnn." in n} <= seen
     assert any(n.startswith("fc_cls.") for n in seen) and any(n.startswith("D.") for n in seen)
     for flat, ptrs, views, segs in enc:
-        (d0, d1, ev), (s0, s1, none) = segs
-        assert ev is not None and none is None and (s0, s1, d1) == (0, d0, flat.numel())
+        (d0, d1, ev, w_deep), (s0, s1, none, w_shallow) = segs
+        assert ev is not None and none is None and (s0, s1, d1) == (0, d0, flat.numel()) and (w_deep, w_shallow) == ("now", "end")
         for ptr, v in zip(ptrs, views):
             n = by_ptr[ptr][0]
             off = (v[0] - flat.data_ptr()) // 4

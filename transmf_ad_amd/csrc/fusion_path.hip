@@ -309,6 +309,7 @@ extern "C" int tmf_fusion_train_bwd(const tmf_fusion_desc* d, const float* mri_t
                                     const tmf_xformer_grads* grads, float* dmri_tok, float* dpet_tok,
                                     void* scratch, size_t scratch_bytes, void* stream) {
     TMF_TRY(check_desc("tmf_fusion_train_bwd", d));
+
     TMF_REQUIRE_PTR(mri_tok); TMF_REQUIRE_PTR(pet_tok); TMF_REQUIRE_PTR(saved); TMF_REQUIRE_PTR(dcls);
     TMF_REQUIRE_PTR(dmri_tok); TMF_REQUIRE_PTR(dpet_tok); TMF_REQUIRE_PTR(scratch);
     TMF_REQUIRE(d->depth == 0 || (inst != nullptr && grads != nullptr), TMF_E_NULL,

@@ -533,9 +533,11 @@ def snet_eval_one_call(vol, dim, eps, slope, blocks, precision=None):
 # into ONE flat buffer and hands autograd views of it.  A data-parallel wrapper (parallel.GradAllReduce) registers itself
 # here as a consumer and is told, at the end of each node's backward, about that buffer: it then all-reduces the buffer IN
 # PLACE on its own stream (no per-parameter hooks, no pack copies; `param.grad` ends up as a view of the reduced buffer).
-# A segment (start, stop, event) says when elements [start, stop) are final: behind `event` (recorded on the producing
-# stream in the middle of the node's backward: the deep blocks of an encoder, finished while conv2 / conv1 still run) or,
-# event None, behind everything the producing stream has been handed so far.  The set holds consumers WEAKLY: with no
+# A segment (start, stop, event, when) says that elements [start, stop) are final behind `event` (None: behind everything
+# the CURRENT stream has been handed so far) and when their collective should be handed to RCCL: "now" (an encoder's deep
+# blocks: the event is recorded in the middle of its backward, conv2 / conv1 still run behind it), "next" (heads, fusion:
+# they report in during the launch-bound start of backward, where the host time of an enqueue is idle GPU — they go out
+# together with the next "now" range) or "end" (an encoder's shallow blocks: the end of backward).  The set holds consumers WEAKLY: with no
 # wrapper alive nothing is published and nothing is kept (k-fold training builds and drops one model per fold).
 import weakref
 
@@ -645,7 +647,7 @@ class SNetTrain(torch.autograd.Function):
             out.append(gr if (gr is not None and ctx.needs_input_grad[3 + i]) else None)
         if _FLAT_GRAD_CONSUMERS and all(ctx.needs_input_grad[3 + i] for i, gr in enumerate(grads) if gr is not None):
             # shallow blocks: final when this call's last kernel is; deep blocks + bias zeros: final at the event
-            _publish_flat_grads(flat, ctx.param_ptrs, grads, [(o_deep, flat.numel(), ev), (0, o_deep, None)])
+            _publish_flat_grads(flat, ctx.param_ptrs, grads, [(o_deep, flat.numel(), ev, "now"), (0, o_deep, None, "end")])
         return tuple(out)
 
 
@@ -1060,8 +1062,12 @@ class FusionTrain(torch.autograd.Function):
         grads, flat, out, dm, dp, scratch, nscr = prep
         _lib.call("tmf_fusion_train_bwd", C.byref(desc), mri.data_ptr(), pet.data_ptr(), inst, saved.data_ptr(),
                   saved.numel(), dcls.data_ptr(), grads, dm.data_ptr(), dp.data_ptr(), scratch.data_ptr(), nscr, _stream())
+        # (Round 4 measured the parameter-gradient launches of this pass — column sums, the weight-gradient launch: 0.08 ms
+        #  of latency-bound work nothing in backward waits for — on a side stream beside the encoders' backward: 14.94-15.26 ms
+        #  per step against 14.62-14.71, 7.70-7.92 against 7.54-7.62 at 128^3 bf16.  A third stream costs the two encoder
+        #  streams more than the launches it hides; dropped.)
         if _FLAT_GRAD_CONSUMERS and all(ctx.needs_input_grad[3:]):
-            _publish_flat_grads(flat, ctx.param_ptrs, out[3:], [(0, flat.numel(), None)])
+            _publish_flat_grads(flat, ctx.param_ptrs, out[3:], [(0, flat.numel(), None, "next")])
         return tuple(out)
 
 
@@ -1151,7 +1157,7 @@ class HeadsAD(torch.autograd.Function):
                   saved.numel() * 4, dl[0].data_ptr(), dl[1].data_ptr(), dl[2].data_ptr(), C.byref(g), d_cls.data_ptr(),
                   d_tok[0].data_ptr(), d_tok[1].data_ptr(), ctx.alpha, scratch.data_ptr(), nscr, _stream())
         if _FLAT_GRAD_CONSUMERS and all(ctx.needs_input_grad[7:]):
-            _publish_flat_grads(flat, ctx.param_ptrs, grads, [(0, flat.numel(), None)])
+            _publish_flat_grads(flat, ctx.param_ptrs, grads, [(0, flat.numel(), None, "next")])
         return (d_cls, d_tok[0], d_tok[1], None, None, None, None, *grads)
 
 
@@ -1235,7 +1241,7 @@ class HeadsCNN(torch.autograd.Function):
                   dl[1].data_ptr() if ctx.with_d else None, dl[2].data_ptr() if ctx.with_d else None, C.byref(g),
                   d_tok[0].data_ptr(), d_tok[1].data_ptr() if two else None, ctx.alpha, scratch.data_ptr(), nscr, _stream())
         if _FLAT_GRAD_CONSUMERS and all(ctx.needs_input_grad[4:]):
-            _publish_flat_grads(flat, ctx.param_ptrs, grads, [(0, flat.numel(), None)])
+            _publish_flat_grads(flat, ctx.param_ptrs, grads, [(0, flat.numel(), None, "next")])
         return (d_tok[0], d_tok[1] if two else None, None, None, *grads)
 
 

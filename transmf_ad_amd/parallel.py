@@ -250,35 +250,35 @@ class GradAllReduce(nn.Module):
         dev = flat.device
         st = self._staging(dev)
         works, deferred = [], []
-        # WHEN to hand a range to RCCL.  Enqueueing a collective costs the host ~0.1-0.2 ms, and the start of backward
-        # (heads, fusion block) is launch-bound: a collective enqueued there is that much idle GPU (measured: 0.25 + 0.22 ms
-        # of gaps behind the heads' and the fusion block's backward).  So a buffer WITHOUT an event range (heads, fusion) only
-        # records an event behind its last kernel and waits in `_pending`; it goes out when the first encoder reports in — by
-        # then that encoder's whole backward (milliseconds of GPU work) is queued and the host is free —, or at the end of
-        # backward.  A buffer WITH an event range (an encoder: deep blocks final at the event, shallow blocks at the end of
-        # the call) starts the event range at once; its stream range would make the in-order staging stream wait for this
-        # encoder's whole backward with the OTHER encoder's deep range queued behind it, so it goes out at the end of backward.
-        has_event = self._early and any(ev is not None for _a, _b, ev in segments)
-        if has_event:
+        # WHEN to hand a range to RCCL (the node says: ops._publish_flat_grads).  Enqueueing a collective costs the host
+        # ~0.1-0.2 ms, and the start of backward (heads, fusion block) is launch-bound: a collective enqueued there is that much
+        # idle GPU (measured: 0.25 + 0.22 ms of gaps behind the heads' and the fusion block's backward).  So a "next" range
+        # (heads, fusion) only gets an event behind its last kernel and waits in `_pending`; it goes out when the first "now"
+        # range arrives (an encoder's deep blocks, final at the event recorded in the middle of its backward) — by then that
+        # encoder's whole backward, milliseconds of GPU work, is queued and the host is free —, or at the end of backward.  An
+        # "end" range (an encoder's shallow blocks) would make the in-order staging stream wait for this encoder's whole backward
+        # with the OTHER encoder's deep range queued behind it: it goes out at the end of backward.
+        if any(when == "now" for _a, _b, _e, when in segments) and self._early:
             self._flush_pending(st)
-        for start, stop, ev in segments:
+        for start, stop, ev, when in segments:
             if stop <= start:
                 continue
-            if ev is not None and self._early:
+            if when == "now" and ev is not None and self._early:
                 st.wait_event(ev)
                 with torch.cuda.stream(st):
                     works.append(self._all_reduce(flat[start:stop]))
                 self.last_reduced_bytes.append((stop - start) * flat.element_size())
                 self.last_reduced_kinds.append("event")
-            elif has_event:
+            elif when == "next":
+                if ev is None:                                   # final behind what the current stream holds now
+                    k = len(self._pending)                      # (events are re-used from step to step: creating one is ~10 us)
+                    while k >= len(self._events):
+                        self._events.append(torch.cuda.Event())
+                    ev = self._events[k]
+                    ev.record(torch.cuda.current_stream(dev))
+                self._pending.append((flat, start, stop, ev, works))
+            else:                                               # "end" (and "now" with TMF_DDP_EVENTS=0)
                 deferred.append((start, stop))
-            else:
-                k = len(self._pending)                      # (events are re-used from step to step: creating one is ~10 us)
-                if k == len(self._events):
-                    self._events.append(torch.cuda.Event())
-                done = self._events[k]
-                done.record(torch.cuda.current_stream(dev))
-                self._pending.append((flat, start, stop, done, works))
         # (no record_stream on the buffer: it lives until the next zero_grad — .grad holds views of it — and by then the
         #  caller's stream has joined the staging stream in _finalize, so the allocator's ordinary stream-ordered re-use is
         #  safe; record_stream would park the block behind an event query at every later allocation)
