@@ -1063,9 +1063,11 @@ class FusionTrain(torch.autograd.Function):
         _lib.call("tmf_fusion_train_bwd", C.byref(desc), mri.data_ptr(), pet.data_ptr(), inst, saved.data_ptr(),
                   saved.numel(), dcls.data_ptr(), grads, dm.data_ptr(), dp.data_ptr(), scratch.data_ptr(), nscr, _stream())
         # (Round 4 measured the parameter-gradient launches of this pass — column sums, the weight-gradient launch: 0.08 ms
-        #  of latency-bound work nothing in backward waits for — on a side stream beside the encoders' backward: 14.94-15.26 ms
-        #  per step against 14.62-14.71, 7.70-7.92 against 7.54-7.62 at 128^3 bf16.  A third stream costs the two encoder
-        #  streams more than the launches it hides; dropped.)
+        #  of latency-bound work nothing in backward waits for — on a side stream beside the encoders' backward: per-step
+        #  medians 14.54 / 14.60 / 14.60 ms against 14.64 / 14.56 / 14.55, and 7.41 / 7.44 / 7.41 against 7.42 / 7.44 / 7.39 at
+        #  128^3 bf16: level — what leaves the serial token phase is paid back as CU time beside the encoders' kernels.  Dropped.
+        #  A first, flawed version was 2-4 % SLOWER: its end-of-backward callback kept the gradient VIEWS alive, and autograd
+        #  adopts a view as .grad only while it holds the last reference — a kept view is cloned: 84 copy launches.)
         if _FLAT_GRAD_CONSUMERS and all(ctx.needs_input_grad[3:]):
             _publish_flat_grads(flat, ctx.param_ptrs, out[3:], [(0, flat.numel(), None, "next")])
         return tuple(out)
