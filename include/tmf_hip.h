@@ -124,6 +124,21 @@ int    tmf_conv3d_wgrad_bf16_t(const void* x, const void* dz, float* dw, void* w
 int  tmf_conv3d_fwd_split(const float* x, const void* w3_bf16, float* z, float* stat_partial,
                           int B, int D, int H, int W, int cin, int cout, void* stream);
 int  tmf_conv3d_split_stat_blocks(int B, int D, int H, int W);        /* rows of its stat_partial */
+/* WINOGRAD form F(2x2x2, 3x3x3) of the same convolution (csrc/conv3d_wino.hip), exact-fp32 arithmetic on the fp32 matrix
+ * pipe: 64 products per 2x2x2 output tile, input and output channel instead of 216.  Replaces aten::conv3d and the input
+ * gradient of convolution_backward at networks.py:28,31,37,40,46 for layers with cin % 8 == 0 and cout % 32 == 0
+ * (tmf_conv3d_wino_ok).  x [B][D][H][W][cin], z [B][D][H][W][cout] fp32 channels-last; u = the transformed weights from
+ * tmf_pack_conv_weights_wino (forward: u_fwd; data gradient: the same entry called with dz, u_dgrad and the channel
+ * counts swapped); stat_partial (may be NULL): [tmf_conv3d_wino_stat_blocks()][2][cout].  Results differ from the direct
+ * kernels' by fp32 rounding only (about twice their distance to the fp64 value).
+ * tmf_conv_wino_mode(): tmf_set_option("conv_wino", 0 | 1 | 2) / TMF_CONV_WINO — 0 never (default), 1 the data gradients,
+ * 2 forward and data gradients of the encoder blocks that qualify. */
+int    tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, float* stat_partial,
+                           int B, int D, int H, int W, int cin, int cout, void* stream);
+int    tmf_conv3d_wino_ok(int cin, int cout);
+int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);
+size_t tmf_conv3d_wino_weight_bytes(int cin, int cout);             /* 64 * cin * cout floats */
+int    tmf_conv_wino_mode(void);
 
 /* First layer, cin == 1 (networks.py:22): x[b][d][h][w], w[27][cout]. */
 int    tmf_conv3d_c1_fwd(const float* x, const float* w, float* z, float* stat_partial,
@@ -292,6 +307,11 @@ int tmf_pack_conv_weights_bf16(const float* w, void* w_fwd_bf16, void* w_dgrad_b
  * w3_fwd[p][t][co][ci] = part p (hi, mid, lo) of w[co][ci][t] and, when w3_dgrad != NULL, w3_dgrad[p][taps-1-t][ci][co];
  * 3 * taps * cout * cin bf16 numbers each — the operand layout torch's split3 (.to(bfloat16), subtract, repeat) gives. */
 int tmf_pack_conv_weights_split3(const float* w, void* w3_fwd, void* w3_dgrad, int cout, int cin, int taps, void* stream);
+/* The same for tmf_conv3d_fwd_wino: U = G g G^T along the three axes of every 3x3x3 filter (fp64 inside, rounded once),
+ * u_fwd[p][cin / 8][2][cout][4] (position p = (pd, ph, pw) of the 4x4x4 transformed tile; input channel 8 g + 4 hs + s) and
+ * u_dgrad[p][cout / 8][2][cin][4] (the flipped filter with the channel roles swapped).  Either may be NULL; the forward
+ * form needs tmf_conv3d_wino_ok(cin, cout), the data-gradient form tmf_conv3d_wino_ok(cout, cin). */
+int tmf_pack_conv_weights_wino(const float* w, float* u_fwd, float* u_dgrad, int cout, int cin, void* stream);
 
 /* Layout conversion between the reference's NCDHW tensors and the channels-last tensors every kernel here uses
  * (voxels = D*H*W).  The model itself never needs it — its input has C == 1 (same bytes either way) and its output

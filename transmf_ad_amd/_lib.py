@@ -40,6 +40,11 @@ PROTOTYPES = {
     "tmf_conv3d_fwd_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "tmf_conv3d_bf16_stat_blocks": (_i, [_i, _i, _i, _i]),
     "tmf_conv3d_split_stat_blocks": (_i, [_i, _i, _i, _i]),
+    "tmf_conv3d_fwd_wino": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "tmf_conv3d_wino_ok": (_i, [_i, _i]),
+    "tmf_conv3d_wino_stat_blocks": (_i, [_i, _i, _i, _i]),
+    "tmf_conv3d_wino_weight_bytes": (_z, [_i, _i]),
+    "tmf_conv_wino_mode": (_i, []),
     "tmf_conv3d_fwd_bf16_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad_bf16_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_c1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
@@ -75,6 +80,7 @@ PROTOTYPES = {
     "tmf_pack_conv_weights": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "tmf_pack_conv_weights_bf16": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "tmf_pack_conv_weights_split3": (_i, [_p, _p, _p, _i, _i, _i, _p]),
+    "tmf_pack_conv_weights_wino": (_i, [_p, _p, _p, _i, _i, _p]),
     "tmf_layout_ncdhw_to_ndhwc": (_i, [_p, _p, _i, _i, _l, _p]),
     "tmf_layout_ndhwc_to_ncdhw": (_i, [_p, _p, _i, _i, _l, _p]),
     "tmf_tok_row_blocks": (_i, [_i]),

@@ -1654,6 +1654,10 @@ extern "C" int tmf_set_option(const char* name, int value) {
         g_conv_rt = value;
         return TMF_OK;
     }
+    if (strcmp(name, "conv_wino") == 0) {
+        TMF_REQUIRE(value >= 0 && value <= 2, TMF_E_ARG, "tmf_set_option: conv_wino must be 0, 1 or 2, got %d", value);
+        return tmf_conv_wino_set(value);
+    }
     if (strcmp(name, "debug") == 0) { g_debug = value; tmf_g_debug = value; return TMF_OK; }
     if (strcmp(name, "bf16_v2") == 0) {
         TMF_REQUIRE(value >= 0 && value <= 2, TMF_E_ARG, "tmf_set_option: bf16_v2 must be 0, 1 or 2, got %d", value);

@@ -1,0 +1,416 @@
+// conv3d_wino.hip — 3x3x3 convolution (forward / data gradient) in the Winograd form F(2x2x2, 3x3x3), exact-fp32
+// arithmetic on v_mfma_f32_32x32x2_f32, for gfx950 (MI355X).
+//
+// Why.  The fp32 train step is bound by the fp32 matrix pipe (0.78 / 0.83 busy over a whole step, every
+// vector instruction paid in matrix time), and the direct kernels of conv3d_mfma.hip already run at 0.72-0.86 of it: the
+// only thing left to remove is the matrix work itself.  With 2x2x2 output tiles a 3x3x3 convolution needs 64 products per
+// tile, input and output channel instead of 216 (x 3.375 less), at the price of 192 additions per (tile, input channel) and
+// 112 per (tile, output channel) — 10-15 % of the remaining matrix time at 32-64 channels.
+//
+//   y = A^T [ (G g G^T) .* (B^T d B) ] A   along each of the three axes,
+//   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
+//
+// One workgroup (8 waves, one per CU: the accumulators are half the CU's register file) owns a 4x8x8 brick of output
+// voxels = 32 tiles and 32 output channels:
+//   * per chunk of 8 input channels the 6x10x10 halo goes global -> registers -> LDS (zero fill from the buffer range
+//     check), is transformed to V[64 positions][32 tiles][8 channels] in LDS (thread = (tile, channel pair, row pd of the
+//     d transform): 32 ds_read_b64, 48 packed adds, 16 ds_write_b64), and then multiplied: wave w owns the 8 positions
+//     (pd = w / 2, ph in {2 (w & 1), +1}, pw = 0..3) with one 32 x 32 accumulator each; A operand = one ds_read_b128 per
+//     position (the K permutation of conv3d_mfma.hip: lanes 0-31 channels 0-3, lanes 32-63 channels 4-7), B operand =
+//     the transformed weights straight from L2 (each position's weights are used by exactly one wave of the workgroup: a
+//     ring in LDS would share nothing), one buffer_load_b128 per position, requested before the transform phase;
+//   * epilogue: the w transform and this wave's half of the h transform in registers, one exchange through LDS (128 KB),
+//     the d transform on the reading side, 128-byte channel rows to z, BatchNorm statistic partials as in the direct
+//     kernels (fixed order: results are bit-reproducible run to run).
+//
+// The transformed weights U[p][cin/8][2][cout][4] come from tmf_pack_conv_weights_wino (computed in fp64, rounded once).
+// Numerics: transforms, products and sums in fp32; against the fp64 reference the error of z is about twice the direct
+// kernels' (cancellation in the output transform), measured on the fixtures in tools/winograd_numerics.py and gated by the
+// golden tests at the same tolerances as the direct path.
+//
+// Replaces aten::conv3d / convolution_backward (input gradient) at /root/reference/models/networks.py:28,31,37,40,46.
+#include <type_traits>
+#include "tmf_common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TD = 4, TH = 8, TW = 8;                 // output brick
+constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;  // input halo
+constexpr int NHALO = HD * HH * HW;                   // 600 voxels
+constexpr int CK = 8;                                 // input channels per chunk
+constexpr int NTHR = 512;
+constexpr int RAW_FLOATS = NHALO * CK;                // 4800
+constexpr int V_OFF = 4864;                           // V behind the raw halo (256-B aligned)
+constexpr int V_FLOATS = 64 * 256;                    // [p][hsel][tile ^ swizzle][4]
+constexpr int EX_FLOATS = 8 * 8 * 2 * 64 * 4;         // exchange [wave][r pair][ho][lane][wo, rr] — aliases raw + V
+constexpr int RED_OFF = EX_FLOATS;                    // statistic scratch [wave][32][2]
+constexpr int LDS_FLOATS = RED_OFF + 8 * 32 * 2;
+constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
+constexpr int RAW_PIECES = NHALO * 2;                 // 16-byte pieces per chunk
+constexpr int RV = (RAW_PIECES + NTHR - 1) / NTHR;    // 3 per thread
+static_assert(V_OFF >= RAW_FLOATS && V_OFF + V_FLOATS <= EX_FLOATS, "LDS carving");
+
+template <bool STATS>
+__global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
+    const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ z, float* __restrict__ stat_partial,
+    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* raw = smem;
+    float* V = smem + V_OFF;
+    float* ex = smem;
+    float* red = smem + RED_OFF;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+
+    const int tile = xcd_contiguous(blockIdx.x, ntiles);
+    int t = tile;
+    const int bw = t % tilesW; t /= tilesW;
+    const int bh = t % tilesH; t /= tilesH;
+    const int bd = t % tilesD;
+    const int b = t / tilesD;
+    const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
+    const int n0 = blockIdx.y * 32;
+    const int nchunk = Cin / CK;
+
+    constexpr int OOB = (int)0x80000000u;
+    const float* xb = x + (size_t)b * D * H * W * Cin;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, D * H * W * Cin * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(u), 0, 64 * Cin * Cout * 4, 0x00020000);
+
+    // ---- halo staging: piece e = tid + q * 512 is (voxel e / 2, channel quad e & 1) ----
+    int hoff[RV];
+#pragma unroll
+    for (int q = 0; q < RV; ++q) {
+        const int e = tid + q * NTHR;
+        const int vox = e >> 1, quad = e & 1;
+        const int hd = vox / (HH * HW), hh = (vox / HW) % HH, hw = vox % HW;
+        const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+        const bool ok = e < RAW_PIECES && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        hoff[q] = ok ? (((gd * H + gh) * W + gw) * Cin + quad * 4) * 4 : OOB;
+    }
+    f32x4 rreg[RV];
+    auto load_raw = [&](int c) {
+#pragma unroll
+        for (int q = 0; q < RV; ++q)
+            rreg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, hoff[q], c * (CK * 4), 0));
+    };
+    auto store_raw = [&]() {
+#pragma unroll
+        for (int q = 0; q < RV; ++q) {
+            const int e = tid + q * NTHR;
+            if (e < RAW_PIECES) *reinterpret_cast<f32x4*>(&raw[e * 4]) = rreg[q];
+        }
+    };
+
+    // ---- input transform: lane = (jlow, jhigh, tw, th), wave = (td, pd) ----
+    const int jlow = lane & 1, jhigh = (lane >> 1) & 1, ttw = (lane >> 2) & 3, tth = (lane >> 4) & 3;
+    const int ttd = wave & 1, tpd = wave >> 1;
+    // row pd of B^T along d: d_a + sgn * d_b
+    const int da = tpd == 0 ? 0 : (tpd == 2 ? 2 : 1);
+    const int db = tpd == 0 ? 2 : (tpd == 1 ? 2 : (tpd == 2 ? 1 : 3));
+    const float sgn = tpd == 1 ? 1.f : -1.f;
+    const int raw_base = (((2 * ttd) * HH + 2 * tth) * HW + 2 * ttw) * CK + (jhigh * 2 + jlow) * 2;
+    const int ra = raw_base + da * (HH * HW * CK), rb = raw_base + db * (HH * HW * CK);
+    const int ttile = ttd * 16 + tth * 4 + ttw;
+    const int vw_base = tpd * 16 * 256 + jhigh * 128 + ((ttile ^ (jhigh << 2)) * 4) + jlow * 2;
+
+    // ---- multiply: wave = (pd, half of ph); 8 positions, one 32 x 32 accumulator each ----
+    const int mpd = wave >> 1, mhh = wave & 1;
+    const int p0 = mpd * 16 + mhh * 8;                       // positions p0 .. p0 + 7 = (ph = 2 mhh + (q >> 2), pw = q & 3)
+    const int a_base = p0 * 256 + hsel * 128 + ((l31 ^ (hsel << 2)) * 4);
+    const int b_lane = (hsel * Cout + n0 + l31) * 16;        // bytes
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    load_raw(0);
+    store_raw();
+    __syncthreads();
+
+    for (int c = 0; c < nchunk; ++c) {
+        // requests of this chunk's weights and the next chunk's halo: in flight during the transform
+        f32x4 breg[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            breg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, b_lane, (((p0 + q) * nchunk + c) * 2 * Cout) * 16, 0));
+        if (c + 1 < nchunk) load_raw(c + 1);
+
+        // -- transform (raw -> V) --
+        {
+            f32x2 tt[4][4];
+            const f32x2 s2 = {sgn, sgn};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x2 a = *reinterpret_cast<const f32x2*>(&raw[ra + (i * HW + k) * CK]);
+                    const f32x2 bb = *reinterpret_cast<const f32x2*>(&raw[rb + (i * HW + k) * CK]);
+                    tt[i][k] = a + s2 * bb;
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                    // along w
+                const f32x2 x0 = tt[i][0], x1 = tt[i][1], x2 = tt[i][2], x3 = tt[i][3];
+                tt[i][0] = x0 - x2; tt[i][1] = x1 + x2; tt[i][2] = x2 - x1; tt[i][3] = x1 - x3;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                    // along h
+                const f32x2 x0 = tt[0][k], x1 = tt[1][k], x2 = tt[2][k], x3 = tt[3][k];
+                tt[0][k] = x0 - x2; tt[1][k] = x1 + x2; tt[2][k] = x2 - x1; tt[3][k] = x1 - x3;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<f32x2*>(&V[vw_base + (i * 4 + k) * 256]) = tt[i][k];
+        }
+        __syncthreads();                                     // V complete; every wave is done with the raw halo
+        if (c + 1 < nchunk) store_raw();
+
+        // -- multiply --
+        if (!(dbg & 2)) {
+#pragma unroll
+            for (int qp = 0; qp < 4; ++qp) {
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&V[a_base + (2 * qp) * 256]);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&V[a_base + (2 * qp + 1) * 256]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    acc[2 * qp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], breg[2 * qp][s], acc[2 * qp], 0, 0, 0);
+                    acc[2 * qp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], breg[2 * qp + 1][s], acc[2 * qp + 1], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                     // V consumed; the next halo is in LDS
+    }
+
+    // ---- output transform ----
+    // in registers: along w (complete), along h (this wave's two rows ph: the reader adds / subtracts the halves)
+    //   mhh = 0 (ph 0, 1): P[ho = 0] = y(ph0) + y(ph1), P[ho = 1] = y(ph1)
+    //   mhh = 1 (ph 2, 3): P[ho = 0] = y(ph2),          P[ho = 1] = y(ph2) + y(ph3)    (enters out_h1 with a minus)
+    // exchange float4 (wave, r pair rp, ho, lane) = {P[ho][wo 0][2 rp], P[ho][0][2 rp + 1], P[ho][1][2 rp], P[ho][1][2 rp + 1]}
+#pragma unroll
+    for (int rp = 0; rp < 8; ++rp) {
+        f32x4 o0, o1;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * rp + rr;
+            float y[2][2];                                   // [phl][wo]
+#pragma unroll
+            for (int phl = 0; phl < 2; ++phl) {
+                const float m0 = acc[phl * 4 + 0][r], m1 = acc[phl * 4 + 1][r], m2 = acc[phl * 4 + 2][r], m3 = acc[phl * 4 + 3][r];
+                y[phl][0] = (m0 + m1) + m2;
+                y[phl][1] = (m1 - m2) - m3;
+            }
+#pragma unroll
+            for (int wo = 0; wo < 2; ++wo) {
+                const float sum = y[0][wo] + y[1][wo];
+                o0[wo * 2 + rr] = mhh == 0 ? sum : y[0][wo];
+                o1[wo * 2 + rr] = mhh == 0 ? y[1][wo] : sum;
+            }
+        }
+        *reinterpret_cast<f32x4*>(&ex[(((wave * 8 + rp) * 2 + 0) * 64 + lane) * 4]) = o0;
+        *reinterpret_cast<f32x4*>(&ex[(((wave * 8 + rp) * 2 + 1) * 64 + lane) * 4]) = o1;
+    }
+    __syncthreads();
+
+    // reader: wave w' takes the accumulator rows r = 2 w' + rr; S_pd[ho] = P(pd, 0)[ho] +- P(pd, 1)[ho];
+    // out[do 0] = S_0 + S_1 + S_2, out[do 1] = S_1 - S_2 - S_3
+    f32x4 outv[2][2];                                        // [do][ho] -> {wo 0 rr 0, wo 0 rr 1, wo 1 rr 0, wo 1 rr 1}
+    {
+        f32x4 S[4][2];
+#pragma unroll
+        for (int pd = 0; pd < 4; ++pd)
+#pragma unroll
+            for (int ho = 0; ho < 2; ++ho) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&ex[((((2 * pd) * 8 + wave) * 2 + ho) * 64 + lane) * 4]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(&ex[((((2 * pd + 1) * 8 + wave) * 2 + ho) * 64 + lane) * 4]);
+                S[pd][ho] = ho == 0 ? lo + hi : lo - hi;
+            }
+#pragma unroll
+        for (int ho = 0; ho < 2; ++ho) {
+            outv[0][ho] = (S[0][ho] + S[1][ho]) + S[2][ho];
+            outv[1][ho] = (S[1][ho] - S[2][ho]) - S[3][ho];
+        }
+    }
+    // accumulator row r -> tile (r & 3) + 8 (r >> 2) + 4 hsel; with r = 2 w' + rr:
+    //   tile w = 2 (w' & 1) + rr, tile h = hsel + 2 ((w' >> 1) & 1), tile d = w' >> 2
+    // voxel w = w0 + 4 (w' & 1) + 2 rr + wo (four consecutive), h = h0 + 2 hsel + 4 ((w' >> 1) & 1) + ho, d = d0 + 2 (w' >> 2) + do
+    float s1 = 0.f, s2 = 0.f;
+    {
+        float* zb = z + (size_t)b * D * H * W * Cout;
+        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, D * H * W * Cout * 4, 0x00020000);
+        const int co = n0 + l31;
+        const int gwb = w0 + 4 * (wave & 1), ghb = h0 + 2 * hsel + 4 * ((wave >> 1) & 1), gdb = d0 + 2 * (wave >> 2);
+        const bool full = d0 + TD <= D && h0 + TH <= H && w0 + TW <= W;
+        auto put = [&](auto full_c) {
+            constexpr bool FULL = decltype(full_c)::value;
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                for (int ho = 0; ho < 2; ++ho) {
+                    const int gd = gdb + dd, gh = ghb + ho;
+                    const bool row_ok = FULL || (gd < D && gh < H);
+                    const int rowoff = ((gd * H + gh) * W + gwb) * Cout + co;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int wi = 2 * (e & 1) + (e >> 1);          // e = wo * 2 + rr -> w offset 2 rr + wo
+                        const bool ok = row_ok && (FULL || gwb + wi < W);
+                        float v = outv[dd][ho][e];
+                        if (!(dbg & 4))
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), zr, ok ? (rowoff + wi * Cout) * 4 : OOB, 0, 2);
+                        if (STATS) {
+                            if (!FULL) v = ok ? v : 0.f;
+                            s1 += v;
+                            s2 += v * v;
+                        }
+                    }
+                }
+        };
+        if (full) put(std::true_type{});
+        else put(std::false_type{});
+    }
+    if constexpr (STATS) {
+        if (stat_partial != nullptr) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (hsel == 0) {
+                red[(wave * 32 + l31) * 2 + 0] = s1;
+                red[(wave * 32 + l31) * 2 + 1] = s2;
+            }
+            __syncthreads();
+            if (tid < 32) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) { a1 += red[(m * 32 + tid) * 2]; a2 += red[(m * 32 + tid) * 2 + 1]; }
+                stat_partial[((size_t)tile * 2 + 0) * Cout + n0 + tid] = a1;
+                stat_partial[((size_t)tile * 2 + 1) * Cout + n0 + tid] = a2;
+            }
+        }
+    }
+}
+
+// Transformed weights from the reference tensor w[cout][cin][3][3][3], one thread per (co, ci), fp64 inside:
+//   fwd  [p][cin / 8][2][cout][4]  = U_p(w[co][ci])        input channel ci = 8 g + 4 hs + s
+//   dgrad[p'][cout / 8][2][cin][4] = U_p(w[co][ci])        p' = p with every axis index mapped 0 <-> 3 (the flipped
+//                                                           kernel: G's rows 0 / 3 swap, rows 1 / 2 are symmetric),
+//                                                           input channel co, output channel ci
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ fwd,
+                                                        float* __restrict__ dgrad, int cout, int cin) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= cout * cin) return;
+    const int co = e % cout, ci = e / cout;
+    const float* src = w + ((size_t)co * cin + ci) * 27;
+    double g[3][3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) g[a][i][j] = (double)src[(a * 3 + i) * 3 + j];
+    auto G = [](double x0, double x1, double x2, int row) {
+        return row == 0 ? x0 : (row == 1 ? 0.5 * (x0 + x1 + x2) : (row == 2 ? 0.5 * (x0 - x1 + x2) : x2));
+    };
+    double t1[4][3][3], t2[4][4][3];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t1[p][i][j] = G(g[0][i][j], g[1][i][j], g[2][i][j], p);
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) t2[p][q][j] = G(t1[p][0][j], t1[p][1][j], t1[p][2][j], q);
+    const int fl[4] = {3, 1, 2, 0};
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = (float)G(t2[p][q][0], t2[p][q][1], t2[p][q][2], r);
+                if (fwd != nullptr) {
+                    const int pos = (p * 4 + q) * 4 + r;
+                    fwd[((((size_t)pos * (cin / 8) + ci / 8) * 2 + (ci >> 2 & 1)) * cout + co) * 4 + (ci & 3)] = v;
+                }
+                if (dgrad != nullptr) {
+                    const int pos = (fl[p] * 4 + fl[q]) * 4 + fl[r];
+                    dgrad[((((size_t)pos * (cout / 8) + co / 8) * 2 + (co >> 2 & 1)) * cin + ci) * 4 + (co & 3)] = v;
+                }
+            }
+}
+
+int g_conv_wino = -1;
+
+}  // namespace
+
+// tmf_set_option("conv_wino", 0 | 1 | 2) / TMF_CONV_WINO: the Winograd form never / for the data gradients / for forward and
+// data gradients of the encoder's 3x3x3 blocks that qualify (tmf_conv3d_wino_ok); consulted by the whole-encoder entries
+// (snet_path.hip) and, through tmf_conv_wino_mode(), by the op-by-op path (ops.py)
+extern "C" int tmf_conv_wino_mode(void) {
+    if (g_conv_wino < 0) {
+        const char* e = getenv("TMF_CONV_WINO");
+        const int v = e ? atoi(e) : 0;
+        g_conv_wino = (v == 1 || v == 2) ? v : 0;
+    }
+    return g_conv_wino;
+}
+int tmf_conv_wino_set(int v) { g_conv_wino = v; return TMF_OK; }
+
+extern "C" int tmf_conv3d_wino_ok(int cin, int cout) { return cin > 0 && cout > 0 && cin % 8 == 0 && cout % 32 == 0; }
+
+extern "C" int tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
+}
+
+extern "C" size_t tmf_conv3d_wino_weight_bytes(int cin, int cout) { return (size_t)64 * cin * cout * 4; }
+
+extern "C" int tmf_pack_conv_weights_wino(const float* w, float* u_fwd, float* u_dgrad, int cout, int cin, void* stream) {
+    TMF_REQUIRE_PTR(w);
+    TMF_REQUIRE(u_fwd != nullptr || u_dgrad != nullptr, TMF_E_NULL, "tmf_pack_conv_weights_wino: both outputs are NULL");
+    TMF_REQUIRE(cout > 0 && cin > 0, TMF_E_SHAPE, "tmf_pack_conv_weights_wino: cout=%d cin=%d", cout, cin);
+    TMF_REQUIRE(u_fwd == nullptr || tmf_conv3d_wino_ok(cin, cout), TMF_E_SHAPE,
+                "tmf_pack_conv_weights_wino: forward form needs cin %% 8 == 0 and cout %% 32 == 0 (cin=%d cout=%d)", cin, cout);
+    TMF_REQUIRE(u_dgrad == nullptr || tmf_conv3d_wino_ok(cout, cin), TMF_E_SHAPE,
+                "tmf_pack_conv_weights_wino: data-gradient form needs cout %% 8 == 0 and cin %% 32 == 0 (cin=%d cout=%d)", cin, cout);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)tmf_cdiv((long)cout * cin, 256L)), dim3(256), 0, (hipStream_t)stream,
+                       w, u_fwd, u_dgrad, cout, cin);
+    return tmf_launch_result("tmf_pack_conv_weights_wino");
+}
+
+extern "C" int tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, float* stat_partial,
+                                   int B, int D, int H, int W, int cin, int cout, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(u); TMF_REQUIRE_PTR(z);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, TMF_E_SHAPE, "tmf_conv3d_fwd_wino: non-positive dimension (B=%d D=%d H=%d W=%d)", B, D, H, W);
+    TMF_REQUIRE(tmf_conv3d_wino_ok(cin, cout), TMF_E_SHAPE,
+                "tmf_conv3d_fwd_wino: needs cin %% 8 == 0 and cout %% 32 == 0 (cin=%d cout=%d)", cin, cout);
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 29), TMF_E_SHAPE,
+                "tmf_conv3d_fwd_wino: one sample exceeds 2^29 elements (32-bit byte offsets inside a sample)");
+    TMF_REQUIRE((long)64 * cin * cout < (1L << 29), TMF_E_SHAPE, "tmf_conv3d_fwd_wino: weight tensor exceeds 2^29 elements");
+    TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(u); TMF_REQUIRE_ALIGNED(z);
+    const int tilesD = tmf_cdiv(D, TD), tilesH = tmf_cdiv(H, TH), tilesW = tmf_cdiv(W, TW);
+    const int ntiles = B * tilesD * tilesH * tilesW;
+    dim3 grid(ntiles, cout / 32), block(NTHR);
+    int rc;
+    if (stat_partial != nullptr) {
+        auto k = conv3d_wino_kernel<true>;
+        if ((rc = tmf_allow_lds(k, LDS_BYTES, "tmf_conv3d_fwd_wino"))) return rc;
+        hipLaunchKernelGGL(k, grid, block, LDS_BYTES, (hipStream_t)stream, x, u, z, stat_partial, D, H, W, cin, cout,
+                           tilesD, tilesH, tilesW, ntiles, tmf_g_debug);
+    } else {
+        auto k = conv3d_wino_kernel<false>;
+        if ((rc = tmf_allow_lds(k, LDS_BYTES, "tmf_conv3d_fwd_wino"))) return rc;
+        hipLaunchKernelGGL(k, grid, block, LDS_BYTES, (hipStream_t)stream, x, u, z, stat_partial, D, H, W, cin, cout,
+                           tilesD, tilesH, tilesW, ntiles, tmf_g_debug);
+    }
+    return tmf_launch_result("tmf_conv3d_fwd_wino");
+}

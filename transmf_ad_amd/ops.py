@@ -163,6 +163,38 @@ def pack_weights_split3(weight: torch.Tensor, want_dgrad: bool):
     return wf, wd
 
 
+def conv_wino_mode() -> int:
+    """tmf_set_option("conv_wino", v) / TMF_CONV_WINO: 0 = direct kernels, 1 = Winograd data gradients, 2 = Winograd forward
+    and data gradients (layers with tmf_conv3d_wino_ok)."""
+    return _lib.query("tmf_conv_wino_mode")
+
+
+def wino_ok(cin: int, cout: int) -> bool:
+    return bool(_lib.query("tmf_conv3d_wino_ok", cin, cout))
+
+
+def pack_weights_wino(weight: torch.Tensor, want_fwd: bool = True, want_dgrad: bool = False):
+    """Winograd-transformed weights of one (cout, cin, 3, 3, 3) tensor in ONE launch: u_fwd [64][cin/8][2][cout][4] and
+    u_dgrad [64][cout/8][2][cin][4] (flipped filter, channel roles swapped); None for a form that is not asked for."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    uf = torch.empty((64, cin // 8, 2, cout, 4), device=weight.device, dtype=_f32) if want_fwd else None
+    ud = torch.empty((64, cout // 8, 2, cin, 4), device=weight.device, dtype=_f32) if want_dgrad else None
+    _lib.call("tmf_pack_conv_weights_wino", weight.data_ptr(), _ptr(uf), _ptr(ud), cout, cin, _stream())
+    return uf, ud
+
+
+def conv3d_wino_raw(x, u, cin, cout, want_stats):
+    """3x3x3 convolution in the Winograd form F(2x2x2, 3x3x3) (csrc/conv3d_wino.hip); u from pack_weights_wino."""
+    B, D, H, W = x.shape[:4]
+    z = torch.empty((B, D, H, W, cout), device=x.device, dtype=_f32)
+    part, nblk = None, 0
+    if want_stats:
+        nblk = _lib.query("tmf_conv3d_wino_stat_blocks", B, D, H, W)
+        part = torch.empty((nblk, 2, cout), device=x.device, dtype=_f32)
+    _lib.call("tmf_conv3d_fwd_wino", x.data_ptr(), u.data_ptr(), z.data_ptr(), _ptr(part), B, D, H, W, cin, cout, _stream())
+    return z, part, nblk
+
+
 def conv3d_split_raw(x, w3, cin, cout, want_stats):
     """fp32-accurate conv on the bf16 matrix cores; w3 = split3_bf16(packed [27][cout][cin] fp32 weights)."""
     B, D, H, W = x.shape[:4]
