@@ -131,8 +131,8 @@ int  tmf_conv3d_split_stat_blocks(int B, int D, int H, int W);        /* rows of
  * tmf_pack_conv_weights_wino (forward: u_fwd; data gradient: the same entry called with dz, u_dgrad and the channel
  * counts swapped); stat_partial (may be NULL): [tmf_conv3d_wino_stat_blocks()][2][cout].  Results differ from the direct
  * kernels' by fp32 rounding only (about twice their distance to the fp64 value).
- * tmf_conv_wino_mode(): tmf_set_option("conv_wino", 0 | 1 | 2) / TMF_CONV_WINO — 0 never (default), 1 the data gradients,
- * 2 forward and data gradients of the encoder blocks that qualify. */
+ * tmf_conv_wino_mode(): tmf_set_option("conv_wino", 0 | 1 | 2) / TMF_CONV_WINO — 0 never (the direct kernels), 1 the data
+ * gradients, 2 (default) forward and data gradients of the train-mode encoder blocks that qualify. */
 int    tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, float* stat_partial,
                            int B, int D, int H, int W, int cin, int cout, void* stream);
 int    tmf_conv3d_wino_ok(int cin, int cout);
@@ -297,7 +297,8 @@ int tmf_tok_linear_bwd_input(const float* dy, const float* w, float* dx, int R, 
 /* Conv weights from the reference layout (Cout, Cin, k, k, k) of nn.Conv3d (networks.py:22,28,31,37,40,46,49;
  * taps = k^3 = 1 | 27) into the forward / weight-gradient
  * layout w_fwd[t][ci][co] and, when w_dgrad != NULL, the data-gradient layout w_dgrad[taps-1-t][co][ci], in one launch
- * (what the host side otherwise does with permute / flip copies on every step). */
+ * (what the host side otherwise does with permute / flip copies on every step).  w_fwd may be NULL when only the
+ * data-gradient layout is wanted (the forward runs in the Winograd form). */
 int tmf_pack_conv_weights(const float* w, float* w_fwd, float* w_dgrad, int cout, int cin, int taps, void* stream);
 /* The same for the bf16 matrix-core kernels: w_fwd_bf16[t][co][ci] = bf16(w[co][ci][t]) (the layout tmf_conv3d_fwd_bf16
  * reads) and, when w_dgrad_bf16 != NULL, w_dgrad_bf16[taps-1-t][ci][co] (its data-gradient call).  RNE rounding,

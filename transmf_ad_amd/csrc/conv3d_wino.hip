@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
         if (c + 1 < nchunk) load_raw(c + 1);
 
         // -- transform (raw -> V) --
-        {
+        if (!(dbg & 8)) {
             f32x2 tt[4][4];
             const f32x2 s2 = {sgn, sgn};
 #pragma unroll
@@ -194,6 +194,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     //   mhh = 0 (ph 0, 1): P[ho = 0] = y(ph0) + y(ph1), P[ho = 1] = y(ph1)
     //   mhh = 1 (ph 2, 3): P[ho = 0] = y(ph2),          P[ho = 1] = y(ph2) + y(ph3)    (enters out_h1 with a minus)
     // exchange float4 (wave, r pair rp, ho, lane) = {P[ho][wo 0][2 rp], P[ho][0][2 rp + 1], P[ho][1][2 rp], P[ho][1][2 rp + 1]}
+    if (dbg & 16) return;
 #pragma unroll
     for (int rp = 0; rp < 8; ++rp) {
         f32x4 o0, o1;
@@ -352,14 +353,14 @@ int g_conv_wino = -1;
 
 }  // namespace
 
-// tmf_set_option("conv_wino", 0 | 1 | 2) / TMF_CONV_WINO: the Winograd form never / for the data gradients / for forward and
-// data gradients of the encoder's 3x3x3 blocks that qualify (tmf_conv3d_wino_ok); consulted by the whole-encoder entries
+// tmf_set_option("conv_wino", 0 | 1 | 2) / TMF_CONV_WINO: the Winograd form never / for the data gradients / (default) for forward
+// and data gradients of the encoder's 3x3x3 blocks that qualify (tmf_conv3d_wino_ok); consulted by the whole-encoder entries
 // (snet_path.hip) and, through tmf_conv_wino_mode(), by the op-by-op path (ops.py)
 extern "C" int tmf_conv_wino_mode(void) {
     if (g_conv_wino < 0) {
         const char* e = getenv("TMF_CONV_WINO");
-        const int v = e ? atoi(e) : 0;
-        g_conv_wino = (v == 1 || v == 2) ? v : 0;
+        const int v = e ? atoi(e) : 2;
+        g_conv_wino = (v == 0 || v == 1) ? v : 2;
     }
     return g_conv_wino;
 }

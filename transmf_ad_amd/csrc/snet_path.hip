@@ -27,6 +27,7 @@ struct LayerPlan {
     int oD, oH, oW;         // block output dims (after the pool)
     bool bf;                // bf16 matrix-core kernels for this block's conv / dgrad / wgrad
     bool sp;                // fp32x: forward / data gradient as six bf16 partial products per fp32 product, weight gradient exact fp32
+    bool wgf, wgd;          // fp32: forward / data gradient in the Winograd form (tmf_set_option("conv_wino", ..), conv3d_wino.hip)
     bool x16, z16, o16;     // bf16 storage of the block input, the raw conv output (and dz), the block output
     size_t off_z, off_out, off_vec, off_wf, off_wd;     // in the saved workspace
     size_t x_bytes, z_bytes, out_bytes;
@@ -72,6 +73,9 @@ Plan make_plan(const tmf_snet_desc& d) {
         L.bf = b16 && ks[l] == 3 && cin[l] > 1 && cin[l] % 8 == 0;
         // (both channel counts multiples of 8: the data gradient is the same kernel with the roles swapped)
         L.sp = d.precision == TMF_PREC_FP32X && ks[l] == 3 && cin[l] > 1 && cin[l] % 8 == 0 && cout[l] % 8 == 0;
+        const int wino = (d.precision == TMF_PREC_FP32 && ks[l] == 3 && cin[l] > 1) ? tmf_conv_wino_mode() : 0;
+        L.wgf = wino == 2 && tmf_conv3d_wino_ok(cin[l], cout[l]);
+        L.wgd = wino >= 1 && tmf_conv3d_wino_ok(cout[l], cin[l]);
     }
     for (int l = 0; l < NL; ++l) {
         LayerPlan& L = p.L[l];
@@ -90,8 +94,9 @@ Plan make_plan(const tmf_snet_desc& d) {
         L.off_out = off; off += up256(L.out_bytes);
         L.off_vec = off; off += (size_t)4 * L.cpad * 4;
         const size_t wn = (size_t)L.k * L.k * L.k * L.cin * L.cout;
-        L.off_wf = off; off += up256(wn * (L.sp ? 6 : L.bf ? 2 : 4));
-        L.off_wd = off; off += l == 0 ? 0 : up256(wn * (L.sp ? 6 : L.bf ? 2 : 4));
+        const size_t wino_b = tmf_conv3d_wino_weight_bytes(L.cin, L.cout);
+        L.off_wf = off; off += up256(L.wgf ? wino_b : wn * (L.sp ? 6 : L.bf ? 2 : 4));
+        L.off_wd = off; off += l == 0 ? 0 : up256(L.wgd ? wino_b : wn * (L.sp ? 6 : L.bf ? 2 : 4));
         int nblk, nb2;
         size_t ws;
         if (l == 0) {
@@ -101,6 +106,7 @@ Plan make_plan(const tmf_snet_desc& d) {
         } else {
             nblk = L.bf ? tmf_conv3d_bf16_stat_blocks(d.B, L.D, L.H, L.W)
                    : L.sp ? tmf_conv3d_split_stat_blocks(d.B, L.D, L.H, L.W)
+                   : L.wgf ? tmf_conv3d_wino_stat_blocks(d.B, L.D, L.H, L.W)
                         : tmf_conv3d_stat_blocks_mode(d.B, L.D, L.H, L.W, L.cin, L.cout, L.k, (d.flags & TMF_SNET_ALONE) ? 1 : 0);
             nb2 = tmf_bn_act_pool_bwd_blocks(d.B, L.D, L.H, L.W, L.cout, L.pool);
             ws = L.bf ? tmf_conv3d_wgrad_bf16_workspace_bytes(d.B, L.D, L.H, L.W, L.cin, L.cout)
@@ -189,11 +195,21 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
             nblk = tmf_conv3d_split_stat_blocks(d->B, L.D, L.H, L.W);
             TMF_TRY(tmf_conv3d_fwd_split((const float*)x, wf, (float*)z, part, d->B, L.D, L.H, L.W, L.cin, L.cout, stream));
         } else {
-            TMF_TRY(tmf_pack_conv_weights(prm->weight[l], (float*)wf, (float*)wd, L.cout, L.cin, L.k * L.k * L.k, stream));
-            const int rt_min = (d->flags & TMF_SNET_ALONE) ? 1 : 0;
-            nblk = tmf_conv3d_stat_blocks_mode(d->B, L.D, L.H, L.W, L.cin, L.cout, L.k, rt_min);
-            TMF_TRY(tmf_conv3d_fwd_mode((const float*)x, (const float*)wf, (float*)z, part, d->B, L.D, L.H, L.W, L.cin, L.cout,
-                                        L.k, rt_min, stream));
+            if (L.wgf || L.wgd)
+                TMF_TRY(tmf_pack_conv_weights_wino(prm->weight[l], L.wgf ? (float*)wf : nullptr, L.wgd ? (float*)wd : nullptr,
+                                                   L.cout, L.cin, stream));
+            if (!L.wgf || !L.wgd)
+                TMF_TRY(tmf_pack_conv_weights(prm->weight[l], L.wgf ? nullptr : (float*)wf, L.wgd ? nullptr : (float*)wd, L.cout,
+                                              L.cin, L.k * L.k * L.k, stream));
+            if (L.wgf) {
+                nblk = tmf_conv3d_wino_stat_blocks(d->B, L.D, L.H, L.W);
+                TMF_TRY(tmf_conv3d_fwd_wino((const float*)x, (const float*)wf, (float*)z, part, d->B, L.D, L.H, L.W, L.cin, L.cout, stream));
+            } else {
+                const int rt_min = (d->flags & TMF_SNET_ALONE) ? 1 : 0;
+                nblk = tmf_conv3d_stat_blocks_mode(d->B, L.D, L.H, L.W, L.cin, L.cout, L.k, rt_min);
+                TMF_TRY(tmf_conv3d_fwd_mode((const float*)x, (const float*)wf, (float*)z, part, d->B, L.D, L.H, L.W, L.cin, L.cout,
+                                            L.k, rt_min, stream));
+            }
         }
         TMF_TRY(tmf_bn_finalize(part, nblk, L.cout, count, prm->gamma[l], prm->beta[l], prm->bias[l], prm->running_mean[l],
                                 prm->running_var[l], d->momentum[l], d->eps[l], v.mean, v.invstd, v.scale, v.shift, stream));
@@ -366,6 +382,8 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
                 TMF_TRY(tmf_conv3d_wgrad((const float*)x, (const float*)dz, g->dweight[l], ws, p.ws_bytes, d->B, L.D, L.H, L.W,
                                          L.cin, L.cout, L.k, TMF_DW_REFERENCE, stream));
             if (L.sp) TMF_TRY(tmf_conv3d_fwd_split((const float*)dz, wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W, L.cout, L.cin, stream));
+            else if (L.wgd) TMF_TRY(tmf_conv3d_fwd_wino((const float*)dz, (const float*)wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W,
+                                                        L.cout, L.cin, stream));
             else TMF_TRY(tmf_conv3d_fwd_mode((const float*)dz, (const float*)wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W, L.cout,
                                              L.cin, L.k, (d->flags & TMF_SNET_ALONE) ? 1 : 0, stream));
         }

@@ -189,12 +189,14 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
                                                                 float* __restrict__ dgrad, int cout, int cin, int T) {
     const long n = (long)cout * cin * T;
     long e = (long)blockIdx.x * 256 + threadIdx.x;
-    if (e < n) {
-        const int co = e % cout, ci = (e / cout) % cin, t = e / ((long)cout * cin);
-        fwd[e] = w[((long)co * cin + ci) * T + t];
-        return;
+    if (fwd != nullptr) {
+        if (e < n) {
+            const int co = e % cout, ci = (e / cout) % cin, t = e / ((long)cout * cin);
+            fwd[e] = w[((long)co * cin + ci) * T + t];
+            return;
+        }
+        e -= n;
     }
-    e -= n;
     if (dgrad != nullptr && e < n) {
         const int ci = e % cin, co = (e / cin) % cout, tr = e / ((long)cout * cin);
         dgrad[e] = w[((long)co * cin + ci) * T + (T - 1 - tr)];
@@ -281,11 +283,12 @@ static int launch_transpose(const float* src, float* dst, int B, long rows, long
 }
 
 extern "C" int tmf_pack_conv_weights(const float* w, float* w_fwd, float* w_dgrad, int cout, int cin, int taps, void* stream) {
-    TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(w_fwd);
+    TMF_REQUIRE_PTR(w);
+    TMF_REQUIRE(w_fwd != nullptr || w_dgrad != nullptr, TMF_E_NULL, "tmf_pack_conv_weights: both outputs are NULL");
     TMF_REQUIRE(cout > 0 && cin > 0 && (taps == 1 || taps == 27), TMF_E_SHAPE,
                 "tmf_pack_conv_weights: cout=%d cin=%d taps=%d", cout, cin, taps);
     const long n = (long)cout * cin * taps;
-    const long total = w_dgrad != nullptr ? 2 * n : n;
+    const long total = (w_fwd != nullptr && w_dgrad != nullptr) ? 2 * n : n;
     hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((unsigned)tmf_cdiv(total, 256L)), dim3(256), 0, (hipStream_t)stream,
                        w, w_fwd, w_dgrad, cout, cin, taps);
     return tmf_launch_result("tmf_pack_conv_weights");

@@ -54,12 +54,14 @@ def pack_weight_dgrad(weight: torch.Tensor) -> torch.Tensor:
     return weight.flip(2, 3, 4).permute(2, 3, 4, 0, 1).contiguous()
 
 
-def pack_weights_both(weight: torch.Tensor, want_dgrad: bool):
+def pack_weights_both(weight: torch.Tensor, want_dgrad: bool, want_fwd: bool = True):
     """Forward layout [k^3][Cin][Cout] and (optionally) data-gradient layout [k^3][Cout][Cin] in one launch."""
     cout, cin, k = weight.shape[0], weight.shape[1], weight.shape[2]
-    wf = torch.empty((k ** 3, cin, cout), device=weight.device, dtype=_f32)
+    if not (want_fwd or want_dgrad):
+        return None, None
+    wf = torch.empty((k ** 3, cin, cout), device=weight.device, dtype=_f32) if want_fwd else None
     wd = torch.empty((k ** 3, cout, cin), device=weight.device, dtype=_f32) if want_dgrad else None
-    _lib.call("tmf_pack_conv_weights", weight.data_ptr(), wf.data_ptr(), _ptr(wd), cout, cin, k ** 3, _stream())
+    _lib.call("tmf_pack_conv_weights", weight.data_ptr(), _ptr(wf), _ptr(wd), cout, cin, k ** 3, _stream())
     return wf, wd
 
 
@@ -301,8 +303,18 @@ class ConvBnActPool(torch.autograd.Function):
         if out_bf16 and not z16:
             raise _lib.TmfError("a bf16 block output needs conv precision 'bf16' with bf16 activation storage")
         wf = wd = None
+        # Winograd form of the fp32 train-mode products (tmf_set_option("conv_wino", ..)): the same choice per layer and
+        # direction as the whole-encoder path (snet_path.hip make_plan), so the two stay bit-identical
+        wino = conv_wino_mode() if (not bf16 and k == 3 and cin > 1 and training) else 0
+        wino_f = wino == 2 and wino_ok(cin, cout)
+        wino_d = wino >= 1 and wino_ok(cout, cin)
         if not bf16:                      # both weight layouts in one launch; the dgrad one is kept for backward
-            wf, wd = pack_weights_both(weight, ctx.needs_input_grad[0])
+            want_d = ctx.needs_input_grad[0]
+            wf, wd = pack_weights_both(weight, want_d and not wino_d, want_fwd=not wino_f)
+            if wino_f or (wino_d and want_d):
+                uf, ud = pack_weights_wino(weight, wino_f, wino_d and want_d)
+                wf = uf if wino_f else wf
+                wd = ud if (wino_d and want_d) else wd
         elif bf16 == "bf16":
             wf, wd = pack_weights_both_bf16(weight, ctx.needs_input_grad[0] and cout % 8 == 0)
         elif ctx.needs_input_grad[0] and cout % 8 == 0:      # fp32x: both split layouts in one launch
@@ -315,6 +327,8 @@ class ConvBnActPool(torch.autograd.Function):
                 return conv3d_bf16_raw(x, wf, cin, cout, stats, out_bf16=z16)
             if bf16 == "fp32x":
                 return conv3d_split_raw(x, wf, cin, cout, stats)
+            if wino_f:
+                return conv3d_wino_raw(x, wf, cin, cout, stats)
             return conv3d_raw(x, wf, cin, cout, k, stats)
 
         dev = x.device
@@ -350,6 +364,7 @@ class ConvBnActPool(torch.autograd.Function):
         ctx.cfg = (training, float(slope), pc, cin, cout, k, bias is not None)
         ctx.bf16 = bf16
         ctx.packed_dgrad = wd is not None
+        ctx.wino_d = bool(wino_d and wd is not None)
         ctx.io = io
         return out
 
@@ -393,6 +408,8 @@ class ConvBnActPool(torch.autograd.Function):
                 dx, _, _ = conv3d_bf16_raw(dz, weight, cout, cin, False, out_bf16=x.dtype == _b16)    # weight = packed wd
             elif ctx.bf16 == "fp32x" and cout % 8 == 0:
                 dx, _, _ = conv3d_split_raw(dz, weight, cout, cin, False)             # weight = packed split wd
+            elif ctx.wino_d:
+                dx, _, _ = conv3d_wino_raw(dz, weight, cout, cin, False)              # weight = packed Winograd u_dgrad
             else:
                 dzf = dz if dz.dtype == _f32 else dz.float()
                 dx, _, _ = conv3d_raw(dzf, weight if ctx.packed_dgrad else pack_weight_dgrad(weight), cout, cin, k, False)
