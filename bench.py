@@ -158,6 +158,13 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             fns = (("fwd", f"conv3d_fwd_kernel<{kf}>", lambda: ops.conv3d_raw(x, wf, ci, co, 3, True)),
                    ("dgrad", f"conv3d_fwd_kernel<{kd}>", lambda: ops.conv3d_raw(dz, wd, co, ci, 3, False)),
                    ("wgrad", f"conv3d_wgrad_kernel<{kw}>", lambda: ops.conv3d_wgrad(x, dz, ci, co, 3)))
+            wino = ops.conv_wino_mode() if precision == "fp32" else 0       # as the step runs them (snet_path.hip make_plan)
+            if wino == 2 and ops.wino_ok(ci, co):
+                uf, _ = ops.pack_weights_wino(w, True, False)
+                fns = (("fwd", "conv3d_wino_kernel<true>", lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
+            if wino >= 1 and ops.wino_ok(co, ci):
+                _, ud = ops.pack_weights_wino(w, False, True)
+                fns = (fns[0], ("dgrad", "conv3d_wino_kernel<false>", lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
             if precision == "fp32x":      # forward / data gradient as the step runs them: six bf16 partial products per fp32 product
                 w3f = ops.split3_bf16(w.permute(2, 3, 4, 0, 1).contiguous())
                 w3d = ops.split3_bf16(w.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())
@@ -165,7 +172,10 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
                        ("dgrad", "conv3d_fwd_split_kernel", lambda: ops.conv3d_split_raw(dz, w3d, co, ci, False)), fns[2])
         for pas, kern, fn in fns:
             ms = _time_launches(fn, reps)
-            rows.append(dict(layer=name, **{"pass": pas}, kernel=kern, ms=ms, flops=fl, bytes=by))
+            # executed matrix flops: the Winograd form multiplies 64 numbers per 2x2x2 tile, input and output channel (bricks
+            # of 4x8x8 voxels, padded); the direct kernels execute the algorithmic count
+            ex = 2.0 * 64 * ci * co * 32 * B * -(-D // 4) * -(-H // 8) * -(-W // 8) if kern.startswith("conv3d_wino") else fl
+            rows.append(dict(layer=name, **{"pass": pas}, kernel=kern, ms=ms, flops=fl, bytes=by, exec_flops=ex))
         del x, dz, w, wf, wd
     # fused first block: statistics + normalise/pool forward, backward reduce + weight gradient (z never stored)
     D, H, W = vol
@@ -184,7 +194,7 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
     vox = B * D * H * W
     rows.append(dict(layer="conv1.0", **{"pass": "fwd+bwd (4 recompute passes)"},
                      kernel="conv1_fused_kernel<0..3>" + (" bf16" if b16 else ""), ms=ms, flops=2 * 2.0 * 27 * q * vox,
-                     bytes=float(2 * vox * 4 + 2 * (vox // 8) * q * el)))
+                     exec_flops=2 * 2.0 * 27 * q * vox, bytes=float(2 * vox * 4 + 2 * (vox // 8) * q * el)))
     return rows
 
 
@@ -197,8 +207,9 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
     peak_tf = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
     groups = {}
     for r in rows:
-        g = groups.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, members=[]))
+        g = groups.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, exec_flops=0.0, launches=0, members=[]))
         g["ms"] += r["ms"]; g["flops"] += r["flops"]; g["bytes"] += r["bytes"]; g["launches"] += 1
+        g["exec_flops"] += r.get("exec_flops", r["flops"])
         g["members"].append(f"{r['layer']} {r['pass']}")
     # the fused first block is four different kernels (+ their finalize launches) timed as one group: it stays in
     # `kernels` / `step_conv`, but the dominant INSTANCE is a single kernel
@@ -230,16 +241,19 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
         "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
         "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
         "mfma_frac": round(tf / peak_tf, 4), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
+        "executed_mfma_frac": round(dom["exec_flops"] / dom["ms"] / 1e9 / peak_tf, 4),
         "share_of_conv_time": round(dom["ms"] / tot_ms, 3),
         "kernels": {k: {"launches_per_encoder_step": g["launches"], "ms": round(g["ms"], 4),
                         "avg_launch_ms": round(g["ms"] / g["launches"], 4),
                         "tflops": round(g["flops"] / g["ms"] / 1e9, 1),
                         "mfma_frac": round(g["flops"] / g["ms"] / 1e9 / peak_tf, 4),
+                        "executed_mfma_frac": round(g["exec_flops"] / g["ms"] / 1e9 / peak_tf, 4),
                         "hbm_frac": round(g["bytes"] / g["ms"] / 1e6 / PEAK_HBM_GBS, 4)} for k, g in groups.items()},
         "step_conv": {"what": "FLOP-weighted over every conv launch of one train step (fwd + dgrad + wgrad of the five "
                               "Cin>1 layers + the fused first block; x2 encoders), launches timed back to back",
                       "ms_per_step": round(2 * tot_ms, 3), "tflops": round(tot_fl / tot_ms / 1e9, 2),
                       "mfma_frac": round(tot_fl / tot_ms / 1e9 / peak_tf, 4),
+                      "executed_mfma_frac": round(sum(r.get("exec_flops", r["flops"]) for r in rows) / tot_ms / 1e9 / peak_tf, 4),
                       "hbm_frac": round(tot_by / tot_ms / 1e6 / PEAK_HBM_GBS, 4)},
         "best_launch": {"layer": best["layer"], "pass": best["pass"], "kernel": best["kernel"],
                         "ms": round(best["ms"], 4), "tflops": round(best["flops"] / best["ms"] / 1e9, 2),
@@ -249,6 +263,12 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
                                                  "hbm_frac": round(r["bytes"] / r["ms"] / 1e6 / PEAK_HBM_GBS, 3)}
                    for r in rows},
     }
+    if any(k.startswith("conv3d_wino") for k in groups):
+        roof["peak_note"] = ("`achieved` / `frac` / `mfma_frac` are ALGORITHMIC flops (SURVEY.md 8d: 2*27*Cin*Cout per output voxel) "
+                             "against the fp32-MFMA peak; the forward / data-gradient launches named conv3d_wino_kernel run the "
+                             "Winograd form F(2x2x2, 3x3x3) — 64 instead of 216 products per 2x2x2 tile, exact-fp32 arithmetic on the "
+                             "same matrix pipe — so their algorithmic figures may exceed 1; `executed_mfma_frac` prices the matrix "
+                             "flops a launch really executes against the same peak (always < 1)")
     if precision == "fp32x":
         roof["peak_note"] = ("opt-in mode: fractions are ALGORITHMIC fp32 flops against the fp32-MFMA peak (157.3 TF); the "
                              "forward / data-gradient kernel evaluates every fp32 product as six bf16 partial products, its own "
@@ -307,6 +327,9 @@ def build_parser():
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="model_ad(dropout=p): Dropout in the fusion block's Transformer instances (options/option.py:39; the "
                          "reference default and the headline are 0)")
+    ap.add_argument("--conv-wino", type=int, choices=[0, 1, 2], default=2,
+                    help="fp32 3x3x3 convolutions of the encoders: 2 (default, the library's default) forward and data gradients "
+                         "in the Winograd form F(2x2x2, 3x3x3) on the fp32 matrix pipe, 1 data gradients only, 0 the direct kernels")
     ap.add_argument("--no-also", action="store_true",
                     help="the default N=1 run measures the other BASELINE configurations in the same process after the headline "
                          "(`also`: configs[2] 128^3 bf16, configs[4] both readings at batch 16, the fp32x mode); this skips them")
@@ -324,13 +347,15 @@ ALSO = (
      dict(model="single", batch=16, cpu_batch=2)),
     ("configs[1] workload in the opt-in fp32x mode (fp32-accurate 3-way bf16 split on the bf16 matrix cores)",
      dict(precision="fp32x")),
+    ("configs[1] workload with the direct fp32 convolution kernels (--conv-wino 0: rounds 1-3's path)",
+     dict(conv_wino=0)),
 )
 
 
 def _is_default_workload(args):
     return (args.model == "ad" and args.precision == "fp32" and args.storage == "fp32" and args.size == 96 and args.batch == 8
             and not args.shape and not args.eval and not args.from_host and not args.roofline_only and not args.no_item_sync
-            and not args.no_cpu_baseline and args.steps > 0 and args.dropout == 0.0)
+            and not args.no_cpu_baseline and args.steps > 0 and args.dropout == 0.0 and args.conv_wino == 2)
 
 
 def main():
@@ -388,6 +413,7 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
 
     ops.set_conv_precision(args.precision)
     ops.set_activation_storage(args.storage)
+    _lib.call("tmf_set_option", b"conv_wino", args.conv_wino)
     torch.manual_seed(0)
     if args.model == "ad":
         net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=args.dropout).to(dev)
@@ -578,6 +604,9 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
     if rank == 0 and not args.eval:
         if brief:
             roof = {"whole_step": whole_step_entry(pairs_per_s, world, gf_pair, by_pair, args.precision)}
+            if args.precision == "fp32" and args.conv_wino:
+                roof["peak_note"] = ("ALGORITHMIC fp32 flops against the fp32-MFMA peak (157.3 TF); forward / data-gradient "
+                                     "convolutions in the Winograd form execute 64/216 of them")
             if args.precision == "fp32x":
                 roof["peak_note"] = ("fractions are ALGORITHMIC fp32 flops against the fp32-MFMA peak (157.3 TF); the forward / "
                                      "data-gradient kernel of this mode runs on the bf16 matrix cores (six partial products)")
@@ -660,6 +689,12 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
                    "step": "val_step: eval-mode no_grad forward + CE" if args.eval else
                            ("zero_grad+fwd+loss+bwd+allreduce+Adam" if args.no_item_sync or args.model == "single" else
                             "zero_grad+fwd+loss+2x loss.item()+bwd+allreduce+Adam (kfold_train_adversarial.py:101-136)"),
+                   "conv_algorithm": ({2: "fp32: Winograd F(2x2x2,3x3x3) on the fp32 matrix pipe for forward and data gradients of the "
+                                          "Cin>1 3x3x3 blocks (exact-fp32 arithmetic, 64/216 of the products), direct implicit GEMM for "
+                                          "the weight gradients, the first block and the 1x1x1 block",
+                                       1: "fp32: Winograd F(2x2x2,3x3x3) data gradients, direct implicit GEMM otherwise",
+                                       0: "fp32: direct implicit GEMM (fp32 MFMA) everywhere"}[args.conv_wino]
+                                      if args.precision == "fp32" and not args.eval else "direct implicit GEMM"),
                    "dispatch": mode,
                    "optimizer": ("transmf_ad_amd.optim.Adam (one launch: tmf_adam_step)" if not (args.torch_adam or args.no_fused_adam)
                                  else "torch.optim.adam.Adam"),
@@ -684,7 +719,7 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
         for k in ("n_gpus", "higher_is_better", "scaling", "vs_baseline", "data", "conv_tflops_whole_step"):
             out.pop(k, None)
         out["config"] = {"workload": out["config"]["workload"], "step": out["config"]["step"],
-                         "setup_steps_untimed": setup_steps}
+                         "conv_algorithm": out["config"]["conv_algorithm"], "setup_steps_untimed": setup_steps}
     return out
 
 
