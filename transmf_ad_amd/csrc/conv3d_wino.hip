@@ -35,32 +35,51 @@
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TD = 4, TH = 8, TW = 8;                 // output brick
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;  // input halo
-constexpr int NHALO = HD * HH * HW;                   // 600 voxels
 constexpr int CK = 8;                                 // input channels per chunk
 constexpr int NTHR = 512;
-constexpr int RAW_FLOATS = NHALO * CK;                // 4800
-constexpr int V_OFF = 4864;                           // V behind the raw halo (256-B aligned)
-constexpr int V_FLOATS = 64 * 256;                    // [p][hsel][tile ^ swizzle][4]
-constexpr int EX_FLOATS = 8 * 8 * 2 * 64 * 4;         // exchange [wave][r pair][ho][lane][wo, rr] — aliases raw + V
-constexpr int RED_OFF = EX_FLOATS;                    // statistic scratch [wave][32][2]
+// Halo of one chunk in LDS, in 16-byte slots (4 channels of one voxel): two planes (channel quads), inside a plane the
+// voxels sorted by the PARITY of their halo coordinates and then by their halves,
+//     slot(hd, hh, hw, quad) = quad * 1536 + ((hd & 1) * 4 + (hh & 1) * 2 + (hw & 1)) * 192 + (hd >> 1) * 64 + (hh >> 1) * 12 + (hw >> 1)
+// so that the 32 tiles of the brick (origins 2 apart on every axis) read CONSECUTIVE slots along w, 12 apart along h and
+// 64 apart along d for any tap: a ds_read_b128 of the tiles' voxels is conflict-free in both 16-lane service groups
+// ({0-3,12-15,20-27} / {4-11,16-19,28-31} -> tile rows th {0,3,1,2} / {1,2,0,3}: residues 12 th + tw mod 16 all distinct).
+constexpr int SLOTS_PLANE = 1536, SLOTS = 2 * SLOTS_PLANE;        // 3072 slots = 48 KB per buffer (1 200 of them real)
+constexpr int RAW_BYTES = SLOTS * 16;
+constexpr int NDMA = SLOTS / NTHR;                                // 6 LDS-DMA instructions per wave and chunk
+constexpr int EX_FLOATS = 8 * 8 * 2 * 64 * 4;                     // exchange [wave][r pair][ho][lane][wo, rr] — aliases the halo buffers
+constexpr int RED_OFF = EX_FLOATS;                                // statistic scratch [wave][32][2]
 constexpr int LDS_FLOATS = RED_OFF + 8 * 32 * 2;
 constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
-constexpr int RAW_PIECES = NHALO * 2;                 // 16-byte pieces per chunk
-constexpr int RV = (RAW_PIECES + NTHR - 1) / NTHR;    // 3 per thread
-static_assert(V_OFF >= RAW_FLOATS && V_OFF + V_FLOATS <= EX_FLOATS, "LDS carving");
+static_assert(2 * RAW_BYTES <= EX_FLOATS * 4, "LDS carving");
+
+__device__ __forceinline__ constexpr int offd(int dd) { return (dd & 1) * 768 + (dd >> 1) * 64; }
+__device__ __forceinline__ constexpr int offh(int i) { return (i & 1) * 384 + (i >> 1) * 12; }
+__device__ __forceinline__ constexpr int offw(int k) { return (k & 1) * 192 + (k >> 1); }
+
+// LDS-DMA of 16 bytes per lane through a buffer resource: LDS byte = lds_wave_base + 16 * lane <- base + voff + soff; a
+// lane outside the range delivers zeros (the same helper and the same reasons as conv3d_bf16.hip: the compiler does not
+// see these copies, the kernel waits for them itself before the barrier that publishes the buffer)
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    return i32x4{(int)(unsigned)a, (int)((unsigned)(a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void blds16(int voff, i32x4 rsrc, int soff, unsigned lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <bool STATS>
 __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ z, float* __restrict__ stat_partial,
-    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles, int dbg) {
+    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* raw = smem;
-    float* V = smem + V_OFF;
     float* ex = smem;
     float* red = smem + RED_OFF;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -79,50 +98,43 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
 
     constexpr int OOB = (int)0x80000000u;
     const float* xb = x + (size_t)b * D * H * W * Cin;
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, D * H * W * Cin * 4, 0x00020000);
+    const i32x4 xr = make_rsrc(xb, (unsigned)(D * H * W * Cin * 4));
     const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(u), 0, 64 * Cin * Cout * 4, 0x00020000);
 
-    // ---- halo staging: piece e = tid + q * 512 is (voxel e / 2, channel quad e & 1) ----
-    int hoff[RV];
+    // ---- halo staging: DMA instruction q of wave w fills the slots (q * 8 + w) * 64 + lane ----
+    int hoff[NDMA];
 #pragma unroll
-    for (int q = 0; q < RV; ++q) {
-        const int e = tid + q * NTHR;
-        const int vox = e >> 1, quad = e & 1;
-        const int hd = vox / (HH * HW), hh = (vox / HW) % HH, hw = vox % HW;
+    for (int q = 0; q < NDMA; ++q) {
+        const int sl = (q * 8 + wave) * 64 + lane;
+        const int quad = sl / SLOTS_PLANE, par = (sl / 192) % 8, a = (sl / 64) % 3, r = sl % 64, bb = r / 12, c = r % 12;
+        const int hd = 2 * a + (par >> 2), hh = 2 * bb + ((par >> 1) & 1), hw = 2 * c + (par & 1);
         const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
-        const bool ok = e < RAW_PIECES && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+        const bool ok = bb < 5 && c < 5 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
         hoff[q] = ok ? (((gd * H + gh) * W + gw) * Cin + quad * 4) * 4 : OOB;
     }
-    f32x4 rreg[RV];
-    auto load_raw = [&](int c) {
+    auto stage = [&](int c) {                       // chunk c -> buffer c & 1
+        const unsigned base = lds0 + (c & 1) * RAW_BYTES + wave * 1024;
 #pragma unroll
-        for (int q = 0; q < RV; ++q)
-            rreg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, hoff[q], c * (CK * 4), 0));
-    };
-    auto store_raw = [&]() {
-#pragma unroll
-        for (int q = 0; q < RV; ++q) {
-            const int e = tid + q * NTHR;
-            if (e < RAW_PIECES) *reinterpret_cast<f32x4*>(&raw[e * 4]) = rreg[q];
-        }
+        for (int q = 0; q < NDMA; ++q) blds16(hoff[q], xr, c * (CK * 4), base + q * 8192);
     };
 
-    // ---- input transform: lane = (jlow, jhigh, tw, th), wave = (td, pd) ----
-    const int jlow = lane & 1, jhigh = (lane >> 1) & 1, ttw = (lane >> 2) & 3, tth = (lane >> 4) & 3;
-    const int ttd = wave & 1, tpd = wave >> 1;
-    // row pd of B^T along d: d_a + sgn * d_b
-    const int da = tpd == 0 ? 0 : (tpd == 2 ? 2 : 1);
-    const int db = tpd == 0 ? 2 : (tpd == 1 ? 2 : (tpd == 2 ? 1 : 3));
-    const float sgn = tpd == 1 ? 1.f : -1.f;
-    const int raw_base = (((2 * ttd) * HH + 2 * tth) * HW + 2 * ttw) * CK + (jhigh * 2 + jlow) * 2;
-    const int ra = raw_base + da * (HH * HW * CK), rb = raw_base + db * (HH * HW * CK);
-    const int ttile = ttd * 16 + tth * 4 + ttw;
-    const int vw_base = tpd * 16 * 256 + jhigh * 128 + ((ttile ^ (jhigh << 2)) * 4) + jlow * 2;
-
-    // ---- multiply: wave = (pd, half of ph); 8 positions, one 32 x 32 accumulator each ----
+    // ---- this wave's part of the input transform and of the products ----
+    // wave = (pd, half of ph): the 8 positions (pd, ph = 2 mhh + {0, 1}, pw = 0..3), one 32 x 32 accumulator each.  The lane
+    // computes the A operands of ITS tile (l31) and channel quad (hsel) in registers, straight from the halo:
+    //   along d: row pd of B^T = d_a + sgn d_b;   along w: all four;   along h: the two rows this wave multiplies —
+    //   mhh = 0: ph0 = x0 - x2, ph1 = x1 + x2 (keeper x2);  mhh = 1: ph2 = x2 - x1, ph3 = x1 - x3 = -(x3 - x1) (keeper x1)
     const int mpd = wave >> 1, mhh = wave & 1;
-    const int p0 = mpd * 16 + mhh * 8;                       // positions p0 .. p0 + 7 = (ph = 2 mhh + (q >> 2), pw = q & 3)
-    const int a_base = p0 * 256 + hsel * 128 + ((l31 ^ (hsel << 2)) * 4);
+    const int da = mpd == 0 ? 0 : (mpd == 2 ? 2 : 1);
+    const int db = mpd == 0 ? 2 : (mpd == 1 ? 2 : (mpd == 2 ? 1 : 3));
+    const float sgn = mpd == 1 ? 1.f : -1.f;
+    const int ik = mhh == 0 ? 2 : 1, ia = mhh == 0 ? 0 : 2, ib = mhh == 0 ? 1 : 3;
+    const float c1 = mhh == 0 ? 1.f : -1.f;                                  // A[1] = c1 * x_ib + x_keeper
+    const int td = l31 >> 4, th = (l31 >> 2) & 3, tw = l31 & 3;
+    const int lbase = (hsel * SLOTS_PLANE + td * 64 + th * 12 + tw) * 4;     // floats
+    const int rka = lbase + (offd(da) + offh(ik)) * 4, rkb = lbase + (offd(db) + offh(ik)) * 4;
+    const int raa = lbase + (offd(da) + offh(ia)) * 4, rab = lbase + (offd(db) + offh(ia)) * 4;
+    const int rba = lbase + (offd(da) + offh(ib)) * 4, rbb = lbase + (offd(db) + offh(ib)) * 4;
+    const int p0 = mpd * 16 + mhh * 8;
     const int b_lane = (hsel * Cout + n0 + l31) * 16;        // bytes
     f32x16 acc[8];
 #pragma unroll
@@ -130,63 +142,45 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
-    load_raw(0);
-    store_raw();
+    stage(0);
+    dma_wait();
     __syncthreads();
 
     for (int c = 0; c < nchunk; ++c) {
-        // requests of this chunk's weights and the next chunk's halo: in flight during the transform
+        if (c + 1 < nchunk) stage(c + 1);           // (its buffer was last read before the barrier that ended chunk c - 1)
         f32x4 breg[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q)
             breg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, b_lane, (((p0 + q) * nchunk + c) * 2 * Cout) * 16, 0));
-        if (c + 1 < nchunk) load_raw(c + 1);
 
-        // -- transform (raw -> V) --
-        if (!(dbg & 8)) {
-            f32x2 tt[4][4];
-            const f32x2 s2 = {sgn, sgn};
+        const float* R = smem + (c & 1) * (RAW_BYTES / 4);
+        const f32x4 s4 = {sgn, sgn, sgn, sgn};
+        auto wrow = [&](int pa, int pb, f32x4 (&wv)[4]) {                    // one h row: d combination, then the w transform
+            f32x4 tv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int k = 0; k < 4; ++k)
+                tv[k] = *reinterpret_cast<const f32x4*>(&R[pa + offw(k) * 4]) + s4 * *reinterpret_cast<const f32x4*>(&R[pb + offw(k) * 4]);
+            wv[0] = tv[0] - tv[2]; wv[1] = tv[1] + tv[2]; wv[2] = tv[2] - tv[1]; wv[3] = tv[1] - tv[3];
+        };
+        f32x4 wk[4], A0[4], A1[4];
+        wrow(rka, rkb, wk);
+        wrow(raa, rab, A0);
+        wrow(rba, rbb, A1);
+        const f32x4 c4 = {c1, c1, c1, c1};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x2 a = *reinterpret_cast<const f32x2*>(&raw[ra + (i * HW + k) * CK]);
-                    const f32x2 bb = *reinterpret_cast<const f32x2*>(&raw[rb + (i * HW + k) * CK]);
-                    tt[i][k] = a + s2 * bb;
-                }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {                    // along w
-                const f32x2 x0 = tt[i][0], x1 = tt[i][1], x2 = tt[i][2], x3 = tt[i][3];
-                tt[i][0] = x0 - x2; tt[i][1] = x1 + x2; tt[i][2] = x2 - x1; tt[i][3] = x1 - x3;
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {                    // along h
-                const f32x2 x0 = tt[0][k], x1 = tt[1][k], x2 = tt[2][k], x3 = tt[3][k];
-                tt[0][k] = x0 - x2; tt[1][k] = x1 + x2; tt[2][k] = x2 - x1; tt[3][k] = x1 - x3;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    *reinterpret_cast<f32x2*>(&V[vw_base + (i * 4 + k) * 256]) = tt[i][k];
+        for (int k = 0; k < 4; ++k) {
+            A0[k] = A0[k] - wk[k];
+            A1[k] = c4 * A1[k] + wk[k];
         }
-        __syncthreads();                                     // V complete; every wave is done with the raw halo
-        if (c + 1 < nchunk) store_raw();
-
-        // -- multiply --
-        if (!(dbg & 2)) {
 #pragma unroll
-            for (int qp = 0; qp < 4; ++qp) {
-                const f32x4 a0 = *reinterpret_cast<const f32x4*>(&V[a_base + (2 * qp) * 256]);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&V[a_base + (2 * qp + 1) * 256]);
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[2 * qp] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], breg[2 * qp][s], acc[2 * qp], 0, 0, 0);
-                    acc[2 * qp + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], breg[2 * qp + 1][s], acc[2 * qp + 1], 0, 0, 0);
-                }
+            for (int s = 0; s < 4; ++s) {
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[k][s], breg[k][s], acc[k], 0, 0, 0);
+                acc[4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[k][s], breg[4 + k][s], acc[4 + k], 0, 0, 0);
             }
-        }
-        __syncthreads();                                     // V consumed; the next halo is in LDS
+        dma_wait();
+        __syncthreads();                            // the next halo is in LDS; every wave is done with this one
     }
 
     // ---- output transform ----
@@ -194,30 +188,28 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     //   mhh = 0 (ph 0, 1): P[ho = 0] = y(ph0) + y(ph1), P[ho = 1] = y(ph1)
     //   mhh = 1 (ph 2, 3): P[ho = 0] = y(ph2),          P[ho = 1] = y(ph2) + y(ph3)    (enters out_h1 with a minus)
     // exchange float4 (wave, r pair rp, ho, lane) = {P[ho][wo 0][2 rp], P[ho][0][2 rp + 1], P[ho][1][2 rp], P[ho][1][2 rp + 1]}
-    if (dbg & 16) return;
+    auto exchange = [&](auto first_half) {
+        constexpr bool H0 = decltype(first_half)::value;
 #pragma unroll
-    for (int rp = 0; rp < 8; ++rp) {
-        f32x4 o0, o1;
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            const int r = 2 * rp + rr;
-            float y[2][2];                                   // [phl][wo]
+        for (int rp = 0; rp < 8; ++rp) {
+            f32x2 y[2][2];                                       // [phl][wo], the pair = accumulator rows 2 rp, 2 rp + 1
 #pragma unroll
             for (int phl = 0; phl < 2; ++phl) {
-                const float m0 = acc[phl * 4 + 0][r], m1 = acc[phl * 4 + 1][r], m2 = acc[phl * 4 + 2][r], m3 = acc[phl * 4 + 3][r];
-                y[phl][0] = (m0 + m1) + m2;
-                y[phl][1] = (m1 - m2) - m3;
-            }
+                f32x2 m[4];
 #pragma unroll
-            for (int wo = 0; wo < 2; ++wo) {
-                const float sum = y[0][wo] + y[1][wo];
-                o0[wo * 2 + rr] = mhh == 0 ? sum : y[0][wo];
-                o1[wo * 2 + rr] = mhh == 0 ? y[1][wo] : sum;
+                for (int pw = 0; pw < 4; ++pw) m[pw] = f32x2{acc[phl * 4 + pw][2 * rp], acc[phl * 4 + pw][2 * rp + 1]};
+                y[phl][0] = (m[0] + m[1]) + m[2];
+                y[phl][1] = (m[1] - m[2]) - m[3];
             }
+            const f32x2 sum0 = y[0][0] + y[1][0], sum1 = y[0][1] + y[1][1];
+            const f32x2 p00 = H0 ? sum0 : y[0][0], p01 = H0 ? sum1 : y[0][1];       // P[ho 0][wo]
+            const f32x2 p10 = H0 ? y[1][0] : sum0, p11 = H0 ? y[1][1] : sum1;       // P[ho 1][wo]
+            *reinterpret_cast<f32x4*>(&ex[(((wave * 8 + rp) * 2 + 0) * 64 + lane) * 4]) = f32x4{p00[0], p00[1], p01[0], p01[1]};
+            *reinterpret_cast<f32x4*>(&ex[(((wave * 8 + rp) * 2 + 1) * 64 + lane) * 4]) = f32x4{p10[0], p10[1], p11[0], p11[1]};
         }
-        *reinterpret_cast<f32x4*>(&ex[(((wave * 8 + rp) * 2 + 0) * 64 + lane) * 4]) = o0;
-        *reinterpret_cast<f32x4*>(&ex[(((wave * 8 + rp) * 2 + 1) * 64 + lane) * 4]) = o1;
-    }
+    };
+    if (mhh == 0) exchange(std::true_type{});
+    else exchange(std::false_type{});
     __syncthreads();
 
     // reader: wave w' takes the accumulator rows r = 2 w' + rr; S_pd[ho] = P(pd, 0)[ho] +- P(pd, 1)[ho];
@@ -263,8 +255,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
                         const int wi = 2 * (e & 1) + (e >> 1);          // e = wo * 2 + rr -> w offset 2 rr + wo
                         const bool ok = row_ok && (FULL || gwb + wi < W);
                         float v = outv[dd][ho][e];
-                        if (!(dbg & 4))
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), zr, ok ? (rowoff + wi * Cout) * 4 : OOB, 0, 2);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), zr, ok ? (rowoff + wi * Cout) * 4 : OOB, 0, 2);
                         if (STATS) {
                             if (!FULL) v = ok ? v : 0.f;
                             s1 += v;
@@ -406,12 +397,12 @@ extern "C" int tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, flo
         auto k = conv3d_wino_kernel<true>;
         if ((rc = tmf_allow_lds(k, LDS_BYTES, "tmf_conv3d_fwd_wino"))) return rc;
         hipLaunchKernelGGL(k, grid, block, LDS_BYTES, (hipStream_t)stream, x, u, z, stat_partial, D, H, W, cin, cout,
-                           tilesD, tilesH, tilesW, ntiles, tmf_g_debug);
+                           tilesD, tilesH, tilesW, ntiles);
     } else {
         auto k = conv3d_wino_kernel<false>;
         if ((rc = tmf_allow_lds(k, LDS_BYTES, "tmf_conv3d_fwd_wino"))) return rc;
         hipLaunchKernelGGL(k, grid, block, LDS_BYTES, (hipStream_t)stream, x, u, z, stat_partial, D, H, W, cin, cout,
-                           tilesD, tilesH, tilesW, ntiles, tmf_g_debug);
+                           tilesD, tilesH, tilesW, ntiles);
     }
     return tmf_launch_result("tmf_conv3d_fwd_wino");
 }
