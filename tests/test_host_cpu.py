@@ -176,3 +176,33 @@ def test_fast_mode_switch_matches_module_train():
     net.add_module("extra", torch.nn.Linear(2, 2))
     net.eval()
     assert not net.extra.training and not any(m.training for m in net.modules())
+
+
+def test_winograd_halo_slot_map_is_a_conflict_free_bijection():
+    """csrc/conv3d_wino.hip keeps the 6x10x10 halo of a chunk in LDS as 16-byte slots, slot(voxel, quad) = 2 G + (quad ^ ((hh >> 1) & 1)),
+    G = parity class * 96 + (hd >> 1) * 32 + (hh >> 1) * 6 + (hw >> 1).  Restated here: the map is injective into the 1 536 slots
+    of a buffer, the two quads of a voxel are neighbours (one 32-byte piece of global memory per DMA lane pair), and for every
+    tap the 32 tiles' ds_read_b128 is conflict-free in both 16-lane service groups (64 banks x 4 bytes = 16 slots)."""
+    def slot(hd, hh, hw, quad):
+        g = ((hd & 1) * 4 + (hh & 1) * 2 + (hw & 1)) * 96 + (hd >> 1) * 32 + (hh >> 1) * 6 + (hw >> 1)
+        return 2 * g + (quad ^ ((hh >> 1) & 1))
+    seen = set()
+    for hd in range(6):
+        for hh in range(10):
+            for hw in range(10):
+                a, b = slot(hd, hh, hw, 0), slot(hd, hh, hw, 1)
+                assert a // 2 == b // 2 and a != b and 0 <= a < 1536 and 0 <= b < 1536
+                assert a not in seen and b not in seen
+                seen.update((a, b))
+    assert len(seen) == 1200
+    groups = ([0, 1, 2, 3, 12, 13, 14, 15] + list(range(20, 28)), list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31])
+    for dd in range(4):
+        for i in range(4):
+            for k in range(4):
+                for quad in range(2):
+                    for lanes in groups:
+                        res = set()
+                        for tile in lanes:                       # lane l31 = tile: td = l31 >> 4, th = (l31 >> 2) & 3, tw = l31 & 3
+                            td, th, tw = tile >> 4, (tile >> 2) & 3, tile & 3
+                            res.add(slot(2 * td + dd, 2 * th + i, 2 * tw + k, quad) % 16)
+                        assert len(res) == 16, (dd, i, k, quad)

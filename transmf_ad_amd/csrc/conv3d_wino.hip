@@ -41,24 +41,30 @@ constexpr int TD = 4, TH = 8, TW = 8;                 // output brick
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;  // input halo
 constexpr int CK = 8;                                 // input channels per chunk
 constexpr int NTHR = 512;
-// Halo of one chunk in LDS, in 16-byte slots (4 channels of one voxel): two planes (channel quads), inside a plane the
-// voxels sorted by the PARITY of their halo coordinates and then by their halves,
-//     slot(hd, hh, hw, quad) = quad * 1536 + ((hd & 1) * 4 + (hh & 1) * 2 + (hw & 1)) * 192 + (hd >> 1) * 64 + (hh >> 1) * 12 + (hw >> 1)
-// so that the 32 tiles of the brick (origins 2 apart on every axis) read CONSECUTIVE slots along w, 12 apart along h and
-// 64 apart along d for any tap: a ds_read_b128 of the tiles' voxels is conflict-free in both 16-lane service groups
-// ({0-3,12-15,20-27} / {4-11,16-19,28-31} -> tile rows th {0,3,1,2} / {1,2,0,3}: residues 12 th + tw mod 16 all distinct).
-constexpr int SLOTS_PLANE = 1536, SLOTS = 2 * SLOTS_PLANE;        // 3072 slots = 48 KB per buffer (1 200 of them real)
+// Halo of one chunk in LDS, in 16-byte slots (4 channels of one voxel).  The two channel quads of a voxel sit side by side (one
+// 32-byte piece of global memory = two neighbouring DMA lanes), the voxels are sorted by the PARITY of their halo coordinates
+// and then by their halves, and every second h row stores its two quads swapped:
+//     G(hd, hh, hw) = ((hd & 1) * 4 + (hh & 1) * 2 + (hw & 1)) * 96 + (hd >> 1) * 32 + (hh >> 1) * 6 + (hw >> 1)
+//     slot(voxel, quad) = 2 G + (quad ^ ((hh >> 1) & 1))
+// The 32 tiles of the brick (origins 2 apart on every axis) then read, for any tap, groups G that are consecutive along w, 6
+// apart along h and 32 apart along d: in both 16-lane service groups of a ds_read_b128 ({0-3,12-15,20-27} / {4-11,16-19,
+// 28-31}: tile rows th {0,3,1,2} / {1,2,0,3}) the even rows hit the 8 even-or-odd slots 2 (6 th + tw mod 8) + e and the odd rows
+// the other 8 — conflict-free (tests/test_host_cpu.py checks the map exhaustively).
+constexpr int GROUPS = 768, SLOTS = 2 * GROUPS;                   // 1 536 slots = 24 KB per buffer (1 200 of them real)
 constexpr int RAW_BYTES = SLOTS * 16;
-constexpr int NDMA = SLOTS / NTHR;                                // 6 LDS-DMA instructions per wave and chunk
-constexpr int EX_FLOATS = 8 * 8 * 2 * 64 * 4;                     // exchange [wave][r pair][ho][lane][wo, rr] — aliases the halo buffers
+constexpr int NDMA = SLOTS / NTHR;                                // 3 LDS-DMA instructions per wave and chunk
+constexpr int B_OFF = 2 * RAW_BYTES;                              // transformed weights of the running chunk: [wave][position 8][lane 64][4]
+constexpr int B_BYTES = 8 * 8 * 64 * 16;                          // 64 KB (every wave reads only its own 8 KB: no barrier for it)
+constexpr int EX_FLOATS = 8 * 8 * 2 * 64 * 4;                     // exchange [wave][r pair][ho][lane][wo, rr] — aliases halo + weights
 constexpr int RED_OFF = EX_FLOATS;                                // statistic scratch [wave][32][2]
 constexpr int LDS_FLOATS = RED_OFF + 8 * 32 * 2;
 constexpr size_t LDS_BYTES = (size_t)LDS_FLOATS * 4;
-static_assert(2 * RAW_BYTES <= EX_FLOATS * 4, "LDS carving");
+static_assert(B_OFF + B_BYTES <= EX_FLOATS * 4, "LDS carving");
 
-__device__ __forceinline__ constexpr int offd(int dd) { return (dd & 1) * 768 + (dd >> 1) * 64; }
-__device__ __forceinline__ constexpr int offh(int i) { return (i & 1) * 384 + (i >> 1) * 12; }
-__device__ __forceinline__ constexpr int offw(int k) { return (k & 1) * 192 + (k >> 1); }
+// group offsets of a tap (dd, i, k) relative to the tile's own group td * 32 + th * 6 + tw
+__device__ __forceinline__ constexpr int ogd(int dd) { return (dd & 1) * 384 + (dd >> 1) * 32; }
+__device__ __forceinline__ constexpr int ogh(int i) { return (i & 1) * 192 + (i >> 1) * 6; }
+__device__ __forceinline__ constexpr int ogw(int k) { return (k & 1) * 96 + (k >> 1); }
 
 // LDS-DMA of 16 bytes per lane through a buffer resource: LDS byte = lds_wave_base + 16 * lane <- base + voff + soff; a
 // lane outside the range delivers zeros (the same helper and the same reasons as conv3d_bf16.hip: the compiler does not
@@ -71,6 +77,17 @@ __device__ __forceinline__ void blds16(int voff, i32x4 rsrc, int soff, unsigned 
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base) : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#ifdef TMF_WINO_TRACE
+// instrumented build (tools/wino_trace.py): shader-clock stamps of every block (start, end, hardware ids) and of the phases of one
+__device__ long long g_wino_blocks[8192 * 4];
+__device__ long long g_wino_phases[8 * 64];
+#define TRB(i, v) do { if (blockIdx.y == 0 && tid == 0 && blockIdx.x < 8192) g_wino_blocks[blockIdx.x * 4 + (i)] = (v); } while (0)
+#define TRP(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 1500 && blockIdx.y == 0 && lane == 0) g_wino_phases[wave * 64 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define TRB(i, v)
+#define TRP(i)
+#endif
 
 template <bool STATS>
 __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
@@ -85,6 +102,10 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hsel = lane >> 5;
+    TRB(0, (long long)__builtin_readcyclecounter());
+    TRB(2, (long long)__builtin_amdgcn_s_getreg(63492));
+    TRB(3, (long long)__builtin_amdgcn_s_getreg(63508));
+    TRP(0);
 
     const int tile = xcd_contiguous(blockIdx.x, ntiles);
     int t = tile;
@@ -99,20 +120,25 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     constexpr int OOB = (int)0x80000000u;
     const float* xb = x + (size_t)b * D * H * W * Cin;
     const i32x4 xr = make_rsrc(xb, (unsigned)(D * H * W * Cin * 4));
-    const __amdgpu_buffer_rsrc_t ur = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(u), 0, 64 * Cin * Cout * 4, 0x00020000);
 
-    // ---- halo staging: DMA instruction q of wave w fills the slots (q * 8 + w) * 64 + lane ----
+    // ---- halo staging: DMA instruction q of wave w fills the slots (q * 8 + w) * 64 + lane, i.e. the groups (q * 8 + w) * 32 +
+    // (lane >> 1): row (hh >> 1, hw >> 1) = the lane's own (lane >> 1) / 6, % 6 in every instruction, parity class and d half
+    // = (q * 8 + w) / 3, % 3 — wave-uniform ----
     int hoff[NDMA];
+    {
+        const int r = lane >> 1, bb = r / 6, c = r % 6;
+        const int quad = (lane & 1) ^ (bb & 1);
+        const bool real = bb < 5 && c < 5;
 #pragma unroll
-    for (int q = 0; q < NDMA; ++q) {
-        const int sl = (q * 8 + wave) * 64 + lane;
-        const int quad = sl / SLOTS_PLANE, par = (sl / 192) % 8, a = (sl / 64) % 3, r = sl % 64, bb = r / 12, c = r % 12;
-        const int hd = 2 * a + (par >> 2), hh = 2 * bb + ((par >> 1) & 1), hw = 2 * c + (par & 1);
-        const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
-        const bool ok = bb < 5 && c < 5 && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
-        hoff[q] = ok ? (((gd * H + gh) * W + gw) * Cin + quad * 4) * 4 : OOB;
+        for (int q = 0; q < NDMA; ++q) {
+            const int g32 = q * 8 + wave, par = g32 / 3, a = g32 % 3;
+            const int hd = 2 * a + (par >> 2), hh = 2 * bb + ((par >> 1) & 1), hw = 2 * c + (par & 1);
+            const int gd = d0 + hd - 1, gh = h0 + hh - 1, gw = w0 + hw - 1;
+            const bool ok = real && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+            hoff[q] = ok ? (((gd * H + gh) * W + gw) * Cin + quad * 4) * 4 : OOB;
+        }
     }
-    auto stage = [&](int c) {                       // chunk c -> buffer c & 1
+    auto stage = [&](int c) {                       // halo of chunk c -> buffer c & 1
         const unsigned base = lds0 + (c & 1) * RAW_BYTES + wave * 1024;
 #pragma unroll
         for (int q = 0; q < NDMA; ++q) blds16(hoff[q], xr, c * (CK * 4), base + q * 8192);
@@ -130,39 +156,48 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     const int ik = mhh == 0 ? 2 : 1, ia = mhh == 0 ? 0 : 2, ib = mhh == 0 ? 1 : 3;
     const float c1 = mhh == 0 ? 1.f : -1.f;                                  // A[1] = c1 * x_ib + x_keeper
     const int td = l31 >> 4, th = (l31 >> 2) & 3, tw = l31 & 3;
-    const int lbase = (hsel * SLOTS_PLANE + td * 64 + th * 12 + tw) * 4;     // floats
-    const int rka = lbase + (offd(da) + offh(ik)) * 4, rkb = lbase + (offd(db) + offh(ik)) * 4;
-    const int raa = lbase + (offd(da) + offh(ia)) * 4, rab = lbase + (offd(db) + offh(ia)) * 4;
-    const int rba = lbase + (offd(da) + offh(ib)) * 4, rbb = lbase + (offd(db) + offh(ib)) * 4;
+    // slot of the tile's voxel at tap (dd, i, k) = 2 (G0 + ogd + ogh + ogw) + (hsel ^ ((th + (i >> 1)) & 1)); in floats x 4
+    const int g0 = td * 32 + th * 6 + tw;
+    const int e0 = hsel ^ (th & 1);
+    auto row_base = [&](int dd, int i) { return (2 * (g0 + ogd(dd) + ogh(i)) + (e0 ^ (i >> 1))) * 4; };
+    const int rka = row_base(da, ik), rkb = row_base(db, ik);
+    const int raa = row_base(da, ia), rab = row_base(db, ia);
+    const int rba = row_base(da, ib), rbb = row_base(db, ib);
     const int p0 = mpd * 16 + mhh * 8;
     const int b_lane = (hsel * Cout + n0 + l31) * 16;        // bytes
+    const i32x4 ur = make_rsrc(u, (unsigned)(64 * Cin * Cout * 4));
+    const unsigned bl0 = lds0 + B_OFF + wave * 8192;
+    auto stage_b = [&](int c, int q) {              // this wave's weights of (chunk c, position q) -> its own 8 KB
+        blds16(b_lane, ur, (((p0 + q) * nchunk + c) * 2 * Cout) * 16, bl0 + q * 1024);
+    };
+    const float* Bl = smem + (B_OFF + wave * 8192) / 4 + lane * 4;
     f32x16 acc[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 
     stage(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) stage_b(0, q);
+    TRP(1);
     dma_wait();
     __syncthreads();
+    TRP(2);
 
-    for (int c = 0; c < nchunk; ++c) {
-        if (c + 1 < nchunk) stage(c + 1);           // (its buffer was last read before the barrier that ended chunk c - 1)
-        f32x4 breg[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-            breg[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ur, b_lane, (((p0 + q) * nchunk + c) * 2 * Cout) * 16, 0));
-
+    // Two waves share a SIMD (w and w + 4) and the matrix pipe is the resource to keep busy, so the two halves of the workgroup
+    // run the chunk loop half a period apart: between two barriers the waves 0-3 transform chunk c and THEN multiply it, the
+    // waves 4-7 FIRST multiply chunk c - 1 and then transform chunk c — on every SIMD one wave's loads / adds run beside the
+    // other wave's MFMAs (one more barrier interval per brick; measured on the in-kernel timeline: tools/wino_trace.py).
+    f32x4 A0[4], A1[4];
+    auto transform = [&](int c) {                   // halo buffer c & 1 -> this wave's A operands of chunk c
+        if (c + 1 < nchunk) stage(c + 1);           // (its buffer was last read before the barrier two intervals ago)
         const float* R = smem + (c & 1) * (RAW_BYTES / 4);
         const f32x4 s4 = {sgn, sgn, sgn, sgn};
         auto wrow = [&](int pa, int pb, f32x4 (&wv)[4]) {                    // one h row: d combination, then the w transform
             f32x4 tv[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                tv[k] = *reinterpret_cast<const f32x4*>(&R[pa + offw(k) * 4]) + s4 * *reinterpret_cast<const f32x4*>(&R[pb + offw(k) * 4]);
+                tv[k] = *reinterpret_cast<const f32x4*>(&R[pa + ogw(k) * 8]) + s4 * *reinterpret_cast<const f32x4*>(&R[pb + ogw(k) * 8]);
             wv[0] = tv[0] - tv[2]; wv[1] = tv[1] + tv[2]; wv[2] = tv[2] - tv[1]; wv[3] = tv[1] - tv[3];
         };
-        f32x4 wk[4], A0[4], A1[4];
+        f32x4 wk[4];
         wrow(rka, rkb, wk);
         wrow(raa, rab, A0);
         wrow(rba, rbb, A1);
@@ -172,15 +207,65 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
             A0[k] = A0[k] - wk[k];
             A1[k] = c4 * A1[k] + wk[k];
         }
+    };
+    auto multiply = [&](int c, auto first_c) {      // chunk c: A operands x the weights in this wave's LDS region
+        constexpr bool FIRST = decltype(first_c)::value;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[k][s], breg[k][s], acc[k], 0, 0, 0);
-                acc[4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[k][s], breg[4 + k][s], acc[4 + k], 0, 0, 0);
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(&Bl[k * 256]), b1 = *reinterpret_cast<const f32x4*>(&Bl[(4 + k) * 256]);
+            if (c + 1 < nchunk) {                   // both reads have returned: the next chunk's weights for these two positions
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                stage_b(c + 1, k);
+                stage_b(c + 1, 4 + k);
             }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {           // (the first chunk starts its sums from the literal 0: no zeroing moves)
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0[k][s], b0[s], (FIRST && s == 0) ? zero : acc[k], 0, 0, 0);
+                acc[4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1[k][s], b1[s], (FIRST && s == 0) ? zero : acc[4 + k], 0, 0, 0);
+            }
+        }
+    };
+    auto sync = [&]() {
         dma_wait();
-        __syncthreads();                            // the next halo is in LDS; every wave is done with this one
+        __syncthreads();                            // the next halo and weights are in LDS; every wave is done with the running halo
+    };
+    if (wave < 4) {
+        TRP(3);
+        transform(0);
+        TRP(4);
+        multiply(0, std::true_type{});
+        TRP(5);
+        sync();
+        for (int c = 1; c < nchunk; ++c) {
+            TRP(3 + 5 * (c & 3));
+            transform(c);
+            TRP(4 + 5 * (c & 3));
+            multiply(c, std::false_type{});
+            TRP(5 + 5 * (c & 3));
+            sync();
+        }
+        TRP(23);
+        sync();
+    } else {
+        TRP(3);
+        transform(0);
+        TRP(4);
+        sync();
+        TRP(5);
+        multiply(0, std::true_type{});
+        TRP(6);
+        if (nchunk > 1) transform(1);
+        TRP(7);
+        sync();
+        for (int c = 2; c <= nchunk; ++c) {
+            TRP(3 + 5 * ((c - 1) & 3));
+            multiply(c - 1, std::false_type{});
+            TRP(4 + 5 * ((c - 1) & 3));
+            if (c < nchunk) transform(c);
+            TRP(5 + 5 * ((c - 1) & 3));
+            sync();
+        }
     }
 
     // ---- output transform ----
@@ -208,9 +293,12 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
             *reinterpret_cast<f32x4*>(&ex[(((wave * 8 + rp) * 2 + 1) * 64 + lane) * 4]) = f32x4{p10[0], p10[1], p11[0], p11[1]};
         }
     };
+    TRP(30);
     if (mhh == 0) exchange(std::true_type{});
     else exchange(std::false_type{});
+    TRP(31);
     __syncthreads();
+    TRP(32);
 
     // reader: wave w' takes the accumulator rows r = 2 w' + rr; S_pd[ho] = P(pd, 0)[ho] +- P(pd, 1)[ho];
     // out[do 0] = S_0 + S_1 + S_2, out[do 1] = S_1 - S_2 - S_3
@@ -231,6 +319,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
             outv[1][ho] = (S[1][ho] - S[2][ho]) - S[3][ho];
         }
     }
+    TRP(33);
     // accumulator row r -> tile (r & 3) + 8 (r >> 2) + 4 hsel; with r = 2 w' + rr:
     //   tile w = 2 (w' & 1) + rr, tile h = hsel + 2 ((w' >> 1) & 1), tile d = w' >> 2
     // voxel w = w0 + 4 (w' & 1) + 2 rr + wo (four consecutive), h = h0 + 2 hsel + 4 ((w' >> 1) & 1) + ho, d = d0 + 2 (w' >> 2) + do
@@ -267,6 +356,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
         if (full) put(std::true_type{});
         else put(std::false_type{});
     }
+    TRP(34);
     if constexpr (STATS) {
         if (stat_partial != nullptr) {
             s1 += __shfl_xor(s1, 32);
@@ -285,6 +375,8 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
             }
         }
     }
+    TRP(35);
+    TRB(1, (long long)__builtin_readcyclecounter());
 }
 
 // Transformed weights from the reference tensor w[cout][cin][3][3][3], one thread per (co, ci), fp64 inside:
@@ -343,6 +435,14 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 int g_conv_wino = -1;
 
 }  // namespace
+
+#ifdef TMF_WINO_TRACE
+extern "C" int tmf_wino_trace_read(long long* blocks, long long* phases) {
+    hipError_t e = hipMemcpyFromSymbol(blocks, HIP_SYMBOL(g_wino_blocks), sizeof(long long) * 8192 * 4);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(phases, HIP_SYMBOL(g_wino_phases), sizeof(long long) * 8 * 64);
+    return (int)e;
+}
+#endif
 
 // tmf_set_option("conv_wino", 0 | 1 | 2) / TMF_CONV_WINO: the Winograd form never / for the data gradients / (default) for forward
 // and data gradients of the encoder's 3x3x3 blocks that qualify (tmf_conv3d_wino_ok); consulted by the whole-encoder entries
