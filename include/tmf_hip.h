@@ -139,6 +139,13 @@ int    tmf_conv3d_wino_ok(int cin, int cout);
 int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);
 size_t tmf_conv3d_wino_weight_bytes(int cin, int cout);             /* 64 * cin * cout floats */
 int    tmf_conv_wino_mode(void);
+/* Weight gradient in the same form: dU_p = V_p^T Z_p per position of the transformed tile (V = the forward's input transform of
+ * x, Z = A dz A^T), summed over all tiles on the fp32 matrix pipe, then dw = G^T dU G (fp64) — replaces the weight gradient of
+ * convolution_backward at networks.py:28,31,37,40,46 for cin % 32 == 0 and cout % 32 == 0.  Arguments as tmf_conv3d_wgrad. */
+int    tmf_conv3d_wgrad_wino_ok(int cin, int cout);
+size_t tmf_conv3d_wgrad_wino_workspace_bytes(int B, int D, int H, int W, int cin, int cout);
+int    tmf_conv3d_wgrad_wino(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
+                             int B, int D, int H, int W, int cin, int cout, int dw_layout, void* stream);
 
 /* First layer, cin == 1 (networks.py:22): x[b][d][h][w], w[27][cout]. */
 int    tmf_conv3d_c1_fwd(const float* x, const float* w, float* z, float* stat_partial,

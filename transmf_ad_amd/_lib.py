@@ -45,6 +45,9 @@ PROTOTYPES = {
     "tmf_conv3d_wino_stat_blocks": (_i, [_i, _i, _i, _i]),
     "tmf_conv3d_wino_weight_bytes": (_z, [_i, _i]),
     "tmf_conv_wino_mode": (_i, []),
+    "tmf_conv3d_wgrad_wino_ok": (_i, [_i, _i]),
+    "tmf_conv3d_wgrad_wino_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
+    "tmf_conv3d_wgrad_wino": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p]),
     "tmf_conv3d_fwd_bf16_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad_bf16_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_c1_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -379,6 +379,223 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     TRB(1, (long long)__builtin_readcyclecounter());
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Weight gradient in the Winograd form.  y = A^T [(G g) .* (B^T d)] gives  dL/d(G g)_p = (B^T d)_p (A dy)_p: per position p of
+// the 4x4x4 transformed tile a plain product of the TRANSFORMED INPUT V (the forward's own input transform) and the
+// transformed output gradient Z = A dz A^T (1-D: z0 = y0, z1 = y0 + y1, z2 = y0 - y1, z3 = -y1), summed over all tiles:
+//     dU_p[ci][co] = sum_tiles V_p[tile][ci] Z_p[tile][co]        (64 GEMMs with K = tiles instead of 27 with K = voxels)
+//     dW = G^T dU G along the three axes                          (64 -> 27, once, in the reduction kernel)
+// — 64 products per 2x2x2 tile, input and output channel instead of 216, like the forward.
+// A workgroup (8 waves) owns a 32 x 32 block of (ci, co) and walks a contiguous range of 4x4x8 half bricks (16 tiles):
+// per stage the 6x6x10 halo of x (32 channels, 46 KB) and the dz half brick (16 KB) come in by LDS-DMA (whole 128-byte voxel
+// rows), double-buffered, one barrier per stage; wave w owns the 8 positions (pd = w / 2, ph = 2 (w & 1) + {0, 1}, pw) as in
+// the forward, the lane = (channel, tile parity) transforms ITS tile's taps in registers — A operand V_p[tile 2 j + hsel][ci],
+// B operand Z_p[tile 2 j + hsel][co] — and every step j is 8 MFMAs (K = 2 tiles).  No barrier inside a stage: the two waves
+// of a SIMD drift apart and one's loads / adds run beside the other's MFMAs.  Each workgroup leaves one partial slab
+// [64][32][32]; tmf_reduce_slabs (fp64, fixed order) and wino_wgrad_finish_kernel (G^T . G in fp64) turn them into dw.
+constexpr int WX_SLOTS = 3072, WX_REAL = 360 * 8, WZ_SLOTS = 1024;        // 16-byte pieces: x halo 6x6x10 voxels x 8, dz 4x4x8 x 8
+constexpr int WBUF_BYTES = (WX_SLOTS + WZ_SLOTS) * 16;                      // 64 KB per stage buffer
+constexpr int WZ_OFF = WX_SLOTS * 4;                                        // floats
+constexpr size_t WG_LDS_BYTES = 2 * (size_t)WBUF_BYTES;
+
+__global__ __launch_bounds__(NTHR) void conv3d_wino_wgrad_kernel(
+    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
+    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int per_split, int ncob) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int split = blockIdx.x, blk = blockIdx.y;
+    const int ci0 = (blk / ncob) * 32, co0 = (blk % ncob) * 32;
+    const int st0 = split * per_split;
+    const int st1 = st0 + per_split < nbricks ? st0 + per_split : nbricks;
+    constexpr int OOB = (int)0x80000000u;
+
+    // ---- staging plan of this thread: 6 pieces of the x halo, 2 of dz; everything that does not depend on the brick ----
+    int relx[6], pcx[6], relz[2], pcz[2];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int e = (q * 8 + wave) * 64 + lane, v = e >> 3, piece = e & 7;
+        const int hd = v / 60, hh = (v / 10) % 6, hw = v % 10;
+        relx[q] = (((hd - 1) * H + (hh - 1)) * W + (hw - 1)) * Cin * 4 + piece * 16;
+        pcx[q] = e < WX_REAL ? (hd | (hh << 8) | (hw << 16)) : -1;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = (q * 8 + wave) * 64 + lane, v = e >> 3, piece = e & 7;
+        const int od = v >> 5, oh = (v >> 3) & 3, ow = v & 7;
+        relz[q] = ((od * H + oh) * W + ow) * Cout * 4 + piece * 16;
+        pcz[q] = od | (oh << 8) | (ow << 16);
+    }
+    auto stage = [&](int st) {                      // half brick st -> buffer (st - st0) & 1
+        int t = st;
+        const int bw = t % tilesW; t /= tilesW;
+        const int bh = t % tilesH; t /= tilesH;
+        const int bd = t % tilesD;
+        const int b = t / tilesD;
+        const int d0 = bd * 4, h0 = bh * 4, w0 = bw * 8;
+        const i32x4 xr = make_rsrc(x + (size_t)b * D * H * W * Cin, (unsigned)(D * H * W * Cin * 4));
+        const i32x4 zr = make_rsrc(dz + (size_t)b * D * H * W * Cout, (unsigned)(D * H * W * Cout * 4));
+        const int xbase = ((d0 * H + h0) * W + w0) * Cin * 4 + ci0 * 4, zbase = ((d0 * H + h0) * W + w0) * Cout * 4 + co0 * 4;
+        const unsigned base = lds0 + ((st - st0) & 1) * WBUF_BYTES + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int hd = pcx[q] & 255, hh = (pcx[q] >> 8) & 255, hw = (pcx[q] >> 16) & 255;
+            const bool ok = pcx[q] >= 0 && (unsigned)(d0 - 1 + hd) < (unsigned)D && (unsigned)(h0 - 1 + hh) < (unsigned)H &&
+                            (unsigned)(w0 - 1 + hw) < (unsigned)W;
+            blds16(ok ? relx[q] + xbase : OOB, xr, 0, base + q * 8192);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int od = pcz[q] & 255, oh = (pcz[q] >> 8) & 255, ow = (pcz[q] >> 16) & 255;
+            const bool ok = d0 + od < D && h0 + oh < H && w0 + ow < W;
+            blds16(ok ? relz[q] + zbase : OOB, zr, 0, base + WX_SLOTS * 16 + q * 8192);
+        }
+    };
+
+    // ---- this wave's positions and transform rows (as the forward kernel) ----
+    const int mpd = wave >> 1, mhh = wave & 1;
+    const int da = mpd == 0 ? 0 : (mpd == 2 ? 2 : 1);
+    const int db = mpd == 0 ? 2 : (mpd == 1 ? 2 : (mpd == 2 ? 1 : 3));
+    const float sgn = mpd == 1 ? 1.f : -1.f;
+    const int ik = mhh == 0 ? 2 : 1, ia = mhh == 0 ? 0 : 2, ib = mhh == 0 ? 1 : 3;
+    const float c1 = mhh == 0 ? 1.f : -1.f;
+    const float ca = mpd == 3 ? 0.f : 1.f, cb = mpd == 0 ? 0.f : (mpd == 1 ? 1.f : -1.f);      // z_d = ca y[do 0] + cb y[do 1]
+    const float e0 = mhh == 0 ? 0.f : -1.f, f0 = mhh == 0 ? 1.f : 0.f, f1 = mhh == 0 ? 1.f : -1.f;
+    const int lx = l31 + hsel * 64;                                                          // tile 2 j + hsel: w origin 2 hsel more
+    auto xrow = [&](int dd, int i) { return lx + (dd * 60 + i * 10) * 32; };
+    const int rka = xrow(da, ik), rkb = xrow(db, ik), raa = xrow(da, ia), rab = xrow(db, ia), rba = xrow(da, ib), rbb = xrow(db, ib);
+    const int lz = WZ_OFF + l31 + hsel * 64;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    if (st0 < st1) {
+        stage(st0);
+        dma_wait();
+        __syncthreads();
+    }
+    for (int st = st0; st < st1; ++st) {
+        if (st + 1 < st1) stage(st + 1);            // (its buffer was last read before the barrier that ended stage st - 1)
+        const float* R = smem + ((st - st0) & 1) * (WBUF_BYTES / 4);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int td = j >> 2, th = (j >> 1) & 1, twb = (j & 1) * 2;
+            const int xo = ((2 * td * 6 + 2 * th) * 10 + 2 * twb) * 32, zo = ((2 * td * 4 + 2 * th) * 8 + 2 * twb) * 32;
+            // input transform of the lane's tile and channel: rows keeper / a / b, all four w positions
+            auto wrow = [&](int pa, int pb, float (&wv)[4]) {
+                float tv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tv[k] = R[pa + xo + k * 32] + sgn * R[pb + xo + k * 32];
+                wv[0] = tv[0] - tv[2]; wv[1] = tv[1] + tv[2]; wv[2] = tv[2] - tv[1]; wv[3] = tv[1] - tv[3];
+            };
+            float wk[4], A0[4], A1[4];
+            wrow(rka, rkb, wk);
+            wrow(raa, rab, A0);
+            wrow(rba, rbb, A1);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                A0[k] = A0[k] - wk[k];
+                A1[k] = c1 * A1[k] + wk[k];
+            }
+            // transform of the lane's dz tile and channel: Z[pd][ph = 2 mhh + phl][pw]
+            float u[2][2];
+#pragma unroll
+            for (int wo = 0; wo < 2; ++wo) {
+                float zd[2];
+#pragma unroll
+                for (int ho = 0; ho < 2; ++ho)
+                    zd[ho] = ca * R[lz + zo + ((0 * 4 + ho) * 8 + wo) * 32] + cb * R[lz + zo + ((1 * 4 + ho) * 8 + wo) * 32];
+                u[0][wo] = zd[0] + e0 * zd[1];
+                u[1][wo] = f0 * zd[0] + f1 * zd[1];
+            }
+#pragma unroll
+            for (int phl = 0; phl < 2; ++phl) {
+                const float b0 = u[phl][0], b1 = u[phl][0] + u[phl][1], b2 = u[phl][0] - u[phl][1], b3 = -u[phl][1];
+                const float* Ap = phl == 0 ? A0 : A1;
+                acc[phl * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap[0], b0, acc[phl * 4 + 0], 0, 0, 0);
+                acc[phl * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap[1], b1, acc[phl * 4 + 1], 0, 0, 0);
+                acc[phl * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap[2], b2, acc[phl * 4 + 2], 0, 0, 0);
+                acc[phl * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ap[3], b3, acc[phl * 4 + 3], 0, 0, 0);
+            }
+        }
+        dma_wait();
+        __syncthreads();                            // the next stage is in LDS; every wave is done with this one
+    }
+
+    // ---- partial slab [split][blk][p][ci 32][co 32]: accumulator row r -> ci = (r & 3) + 8 (r >> 2) + 4 hsel, column co = l31 ----
+    float* out = partial + (((size_t)split * gridDim.y + blk) * 64 + (mpd * 16 + mhh * 8)) * 1024;
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[q * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + l31] = acc[q][r];
+}
+
+// dU (reduced over the slabs) [blk][p][ci 32][co 32] -> dw = G^T dU G along the three axes, one thread per (ci, co), fp64:
+// 1-D: w0 = u0 + (u1 + u2) / 2, w1 = (u1 - u2) / 2, w2 = (u1 + u2) / 2 + u3.  dw_ref: nn.Conv3d's [co][ci][27], else [27][ci][co].
+__global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ du, float* __restrict__ dw,
+                                                                int cin, int cout, int ncob, int dw_ref) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= cin * cout) return;
+    const int co = e % cout, ci = e / cout;
+    const int blk = (ci / 32) * ncob + co / 32;
+    const float* src = du + (size_t)blk * 64 * 1024 + (ci % 32) * 32 + (co % 32);
+    double u[4][4][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) u[p][q][r] = (double)src[((p * 4 + q) * 4 + r) * 1024];
+    auto GT = [](double u0, double u1, double u2, double u3, int a) {
+        return a == 0 ? u0 + 0.5 * (u1 + u2) : (a == 1 ? 0.5 * (u1 - u2) : 0.5 * (u1 + u2) + u3);
+    };
+    double t1[3][4][4], t2[3][3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t1[a][q][r] = GT(u[0][q][r], u[1][q][r], u[2][q][r], u[3][q][r], a);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bq = 0; bq < 3; ++bq)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t2[a][bq][r] = GT(t1[a][0][r], t1[a][1][r], t1[a][2][r], t1[a][3][r], bq);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bq = 0; bq < 3; ++bq)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v = (float)GT(t2[a][bq][0], t2[a][bq][1], t2[a][bq][2], t2[a][bq][3], c);
+                const int tap = (a * 3 + bq) * 3 + c;
+                if (dw_ref) dw[((size_t)co * cin + ci) * 27 + tap] = v;
+                else dw[((size_t)tap * cin + ci) * cout + co] = v;
+            }
+}
+
+struct WinoWgPlan { int tilesD, tilesH, tilesW, nbricks, nblk, ncob, nsplit, per; };
+WinoWgPlan plan_wino_wgrad(int B, int D, int H, int W, int cin, int cout) {
+    WinoWgPlan p;
+    p.tilesD = tmf_cdiv(D, 4); p.tilesH = tmf_cdiv(H, 4); p.tilesW = tmf_cdiv(W, 8);
+    p.nbricks = B * p.tilesD * p.tilesH * p.tilesW;
+    p.ncob = cout / 32;
+    p.nblk = (cin / 32) * p.ncob;
+    int ns = p.nblk >= 256 ? 1 : 256 / p.nblk;             // one round of workgroups over the 256 CUs
+    if (ns > p.nbricks) ns = p.nbricks;
+    p.per = tmf_cdiv(p.nbricks, ns);
+    p.nsplit = tmf_cdiv(p.nbricks, p.per);
+    return p;
+}
+
 // Transformed weights from the reference tensor w[cout][cin][3][3][3], one thread per (co, ci), fp64 inside:
 //   fwd  [p][cin / 8][2][cout][4]  = U_p(w[co][ci])        input channel ci = 8 g + 4 hs + s
 //   dgrad[p'][cout / 8][2][cin][4] = U_p(w[co][ci])        p' = p with every axis index mapped 0 <-> 3 (the flipped
@@ -505,4 +722,44 @@ extern "C" int tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, flo
                            tilesD, tilesH, tilesW, ntiles);
     }
     return tmf_launch_result("tmf_conv3d_fwd_wino");
+}
+
+extern "C" int tmf_conv3d_wgrad_wino_ok(int cin, int cout) { return cin > 0 && cout > 0 && cin % 32 == 0 && cout % 32 == 0; }
+
+extern "C" size_t tmf_conv3d_wgrad_wino_workspace_bytes(int B, int D, int H, int W, int cin, int cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || !tmf_conv3d_wgrad_wino_ok(cin, cout)) return 0;
+    const WinoWgPlan p = plan_wino_wgrad(B, D, H, W, cin, cout);
+    const size_t n = (size_t)p.nblk * 64 * 1024;
+    return (size_t)(p.nsplit + tmf_reduce_groups(p.nsplit) + 1) * n * 4;
+}
+
+extern "C" int tmf_conv3d_wgrad_wino(const float* x, const float* dz, float* dw, void* workspace, size_t workspace_bytes,
+                                     int B, int D, int H, int W, int cin, int cout, int dw_layout, void* stream) {
+    TMF_REQUIRE(dw_layout == TMF_DW_TAPMAJOR || dw_layout == TMF_DW_REFERENCE, TMF_E_ARG,
+                "tmf_conv3d_wgrad_wino: unknown dw_layout %d", dw_layout);
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(dz); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, TMF_E_SHAPE, "tmf_conv3d_wgrad_wino: non-positive dimension");
+    TMF_REQUIRE(tmf_conv3d_wgrad_wino_ok(cin, cout), TMF_E_SHAPE,
+                "tmf_conv3d_wgrad_wino: needs cin %% 32 == 0 and cout %% 32 == 0 (cin=%d cout=%d)", cin, cout);
+    TMF_REQUIRE((long)(D + 2) * (H + 2) * (W + 2) * (cin > cout ? cin : cout) < (1L << 29), TMF_E_SHAPE,
+                "tmf_conv3d_wgrad_wino: one sample exceeds 2^29 elements (32-bit byte offsets inside a sample)");
+    TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(dz); TMF_REQUIRE_ALIGNED(dw); TMF_REQUIRE_ALIGNED(workspace);
+    const size_t need = tmf_conv3d_wgrad_wino_workspace_bytes(B, D, H, W, cin, cout);
+    TMF_REQUIRE(workspace_bytes >= need, TMF_E_WORKSPACE, "tmf_conv3d_wgrad_wino: workspace %zu B < required %zu B", workspace_bytes, need);
+    const WinoWgPlan p = plan_wino_wgrad(B, D, H, W, cin, cout);
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    const long n = (long)p.nblk * 64 * 1024;
+    int rc;
+    auto k = conv3d_wino_wgrad_kernel;
+    if ((rc = tmf_allow_lds(k, WG_LDS_BYTES, "tmf_conv3d_wgrad_wino"))) return rc;
+    hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(NTHR), WG_LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,
+                       p.tilesD, p.tilesH, p.tilesW, p.nbricks, p.per, p.ncob);
+    if ((rc = tmf_launch_result("tmf_conv3d_wgrad_wino"))) return rc;
+    float* scratch = partial + (size_t)p.nsplit * n;
+    float* du = scratch + (size_t)tmf_reduce_groups(p.nsplit) * n;
+    if ((rc = tmf_reduce_slabs(partial, p.nsplit, n, scratch, du, s, "tmf_conv3d_wgrad_wino(reduce)"))) return rc;
+    hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)tmf_cdiv((long)cin * cout, 256L)), dim3(256), 0, s,
+                       (const float*)du, dw, cin, cout, p.ncob, dw_layout == TMF_DW_REFERENCE ? 1 : 0);
+    return tmf_launch_result("tmf_conv3d_wgrad_wino(finish)");
 }

@@ -197,6 +197,21 @@ def conv3d_wino_raw(x, u, cin, cout, want_stats):
     return z, part, nblk
 
 
+def wgrad_wino_ok(cin: int, cout: int) -> bool:
+    return bool(_lib.query("tmf_conv3d_wgrad_wino_ok", cin, cout))
+
+
+def conv3d_wgrad_wino(x, dz, cin, cout, reference_layout=False):
+    """3x3x3 weight gradient in the Winograd form (csrc/conv3d_wino.hip): tap-major [27][cin][cout] or nn.Conv3d's layout."""
+    B, D, H, W = x.shape[:4]
+    dw = torch.empty((cout, cin, 3, 3, 3) if reference_layout else (27, cin, cout), device=x.device, dtype=_f32)
+    nbytes = _lib.query("tmf_conv3d_wgrad_wino_workspace_bytes", B, D, H, W, cin, cout)
+    ws = torch.empty((max(nbytes, 16) // 4,), device=x.device, dtype=_f32)
+    _lib.call("tmf_conv3d_wgrad_wino", x.data_ptr(), dz.data_ptr(), dw.data_ptr(), ws.data_ptr(), nbytes,
+              B, D, H, W, cin, cout, int(reference_layout), _stream())
+    return dw
+
+
 def conv3d_split_raw(x, w3, cin, cout, want_stats):
     """fp32-accurate conv on the bf16 matrix cores; w3 = split3_bf16(packed [27][cout][cin] fp32 weights)."""
     B, D, H, W = x.shape[:4]
