@@ -159,12 +159,14 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
                    ("dgrad", f"conv3d_fwd_kernel<{kd}>", lambda: ops.conv3d_raw(dz, wd, co, ci, 3, False)),
                    ("wgrad", f"conv3d_wgrad_kernel<{kw}>", lambda: ops.conv3d_wgrad(x, dz, ci, co, 3)))
             wino = ops.conv_wino_mode() if precision == "fp32" else 0       # as the step runs them (snet_path.hip make_plan)
-            if wino == 2 and ops.wino_ok(ci, co):
+            if wino >= 2 and ops.wino_ok(ci, co):
                 uf, _ = ops.pack_weights_wino(w, True, False)
                 fns = (("fwd", "conv3d_wino_kernel<true>", lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
             if wino >= 1 and ops.wino_ok(co, ci):
                 _, ud = ops.pack_weights_wino(w, False, True)
                 fns = (fns[0], ("dgrad", "conv3d_wino_kernel<false>", lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
+            if wino >= 3 and ops.wgrad_wino_ok(ci, co):
+                fns = fns[:2] + (("wgrad", "conv3d_wino_wgrad_kernel", lambda: ops.conv3d_wgrad_wino(x, dz, ci, co)),)
             if precision == "fp32x":      # forward / data gradient as the step runs them: six bf16 partial products per fp32 product
                 w3f = ops.split3_bf16(w.permute(2, 3, 4, 0, 1).contiguous())
                 w3d = ops.split3_bf16(w.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())
@@ -174,7 +176,11 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             ms = _time_launches(fn, reps)
             # executed matrix flops: the Winograd form multiplies 64 numbers per 2x2x2 tile, input and output channel (bricks
             # of 4x8x8 voxels, padded); the direct kernels execute the algorithmic count
-            ex = 2.0 * 64 * ci * co * 32 * B * -(-D // 4) * -(-H // 8) * -(-W // 8) if kern.startswith("conv3d_wino") else fl
+            ex = fl
+            if kern.startswith("conv3d_wino_wgrad"):
+                ex = 2.0 * 64 * ci * co * 16 * B * -(-D // 4) * -(-H // 4) * -(-W // 8)
+            elif kern.startswith("conv3d_wino"):
+                ex = 2.0 * 64 * ci * co * 32 * B * -(-D // 4) * -(-H // 8) * -(-W // 8)
             rows.append(dict(layer=name, **{"pass": pas}, kernel=kern, ms=ms, flops=fl, bytes=by, exec_flops=ex))
         del x, dz, w, wf, wd
     # fused first block: statistics + normalise/pool forward, backward reduce + weight gradient (z never stored)
@@ -265,7 +271,7 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
     }
     if any(k.startswith("conv3d_wino") for k in groups):
         roof["peak_note"] = ("`achieved` / `frac` / `mfma_frac` are ALGORITHMIC flops (SURVEY.md 8d: 2*27*Cin*Cout per output voxel) "
-                             "against the fp32-MFMA peak; the forward / data-gradient launches named conv3d_wino_kernel run the "
+                             "against the fp32-MFMA peak; the launches named conv3d_wino_kernel / conv3d_wino_wgrad_kernel run the "
                              "Winograd form F(2x2x2, 3x3x3) — 64 instead of 216 products per 2x2x2 tile, exact-fp32 arithmetic on the "
                              "same matrix pipe — so their algorithmic figures may exceed 1; `executed_mfma_frac` prices the matrix "
                              "flops a launch really executes against the same peak (always < 1)")
@@ -327,9 +333,10 @@ def build_parser():
     ap.add_argument("--dropout", type=float, default=0.0,
                     help="model_ad(dropout=p): Dropout in the fusion block's Transformer instances (options/option.py:39; the "
                          "reference default and the headline are 0)")
-    ap.add_argument("--conv-wino", type=int, choices=[0, 1, 2], default=2,
-                    help="fp32 3x3x3 convolutions of the encoders: 2 (default, the library's default) forward and data gradients "
-                         "in the Winograd form F(2x2x2, 3x3x3) on the fp32 matrix pipe, 1 data gradients only, 0 the direct kernels")
+    ap.add_argument("--conv-wino", type=int, choices=[0, 1, 2, 3], default=3,
+                    help="fp32 3x3x3 convolutions of the encoders: 3 (default, the library's default) forward, data and weight "
+                         "gradients in the Winograd form F(2x2x2, 3x3x3) on the fp32 matrix pipe, 2 forward and data gradients, "
+                         "1 data gradients only, 0 the direct kernels")
     ap.add_argument("--no-also", action="store_true",
                     help="the default N=1 run measures the other BASELINE configurations in the same process after the headline "
                          "(`also`: configs[2] 128^3 bf16, configs[4] both readings at batch 16, the fp32x mode); this skips them")
@@ -355,7 +362,7 @@ ALSO = (
 def _is_default_workload(args):
     return (args.model == "ad" and args.precision == "fp32" and args.storage == "fp32" and args.size == 96 and args.batch == 8
             and not args.shape and not args.eval and not args.from_host and not args.roofline_only and not args.no_item_sync
-            and not args.no_cpu_baseline and args.steps > 0 and args.dropout == 0.0 and args.conv_wino == 2)
+            and not args.no_cpu_baseline and args.steps > 0 and args.dropout == 0.0 and args.conv_wino == 3)
 
 
 def main():
@@ -689,7 +696,10 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
                    "step": "val_step: eval-mode no_grad forward + CE" if args.eval else
                            ("zero_grad+fwd+loss+bwd+allreduce+Adam" if args.no_item_sync or args.model == "single" else
                             "zero_grad+fwd+loss+2x loss.item()+bwd+allreduce+Adam (kfold_train_adversarial.py:101-136)"),
-                   "conv_algorithm": ({2: "fp32: Winograd F(2x2x2,3x3x3) on the fp32 matrix pipe for forward and data gradients of the "
+                   "conv_algorithm": ({3: "fp32: Winograd F(2x2x2,3x3x3) on the fp32 matrix pipe for forward, data and weight gradients "
+                                          "of the Cin>1 3x3x3 blocks (exact-fp32 arithmetic, 64/216 of the products), direct implicit "
+                                          "GEMM for the first block and the 1x1x1 block",
+                                       2: "fp32: Winograd F(2x2x2,3x3x3) on the fp32 matrix pipe for forward and data gradients of the "
                                           "Cin>1 3x3x3 blocks (exact-fp32 arithmetic, 64/216 of the products), direct implicit GEMM for "
                                           "the weight gradients, the first block and the 1x1x1 block",
                                        1: "fp32: Winograd F(2x2x2,3x3x3) data gradients, direct implicit GEMM otherwise",

@@ -131,8 +131,9 @@ int  tmf_conv3d_split_stat_blocks(int B, int D, int H, int W);        /* rows of
  * tmf_pack_conv_weights_wino (forward: u_fwd; data gradient: the same entry called with dz, u_dgrad and the channel
  * counts swapped); stat_partial (may be NULL): [tmf_conv3d_wino_stat_blocks()][2][cout].  Results differ from the direct
  * kernels' by fp32 rounding only (about twice their distance to the fp64 value).
- * tmf_conv_wino_mode(): tmf_set_option("conv_wino", 0 | 1 | 2) / TMF_CONV_WINO — 0 never (the direct kernels), 1 the data
- * gradients, 2 (default) forward and data gradients of the train-mode encoder blocks that qualify. */
+ * tmf_conv_wino_mode(): tmf_set_option("conv_wino", 0 | 1 | 2 | 3) / TMF_CONV_WINO — 0 never (the direct kernels), 1 the data
+ * gradients, 2 forward and data gradients, 3 (default) forward, data and weight gradients of the train-mode encoder blocks
+ * that qualify. */
 int    tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, float* stat_partial,
                            int B, int D, int H, int W, int cin, int cout, void* stream);
 int    tmf_conv3d_wino_ok(int cin, int cout);

@@ -1278,3 +1278,40 @@ def test_conv3d_winograd_form_refuses_other_channel_counts():
     x = torch.zeros((1, 4, 8, 8, 12), device=DEV)
     with pytest.raises(T.TmfError, match="cin % 8"):
         ops.conv3d_wino_raw(x, torch.zeros(64 * 12 * 32, device=DEV), 12, 32, False)
+
+
+WINO_WGRAD_SHAPES = [
+    # B, D, H, W, cin, cout
+    (1, 4, 4, 8, 32, 32),           # one stage of one workgroup
+    (2, 7, 9, 13, 32, 64),          # every half brick ragged, two output-channel blocks
+    (2, 6, 10, 12, 64, 32),         # two input-channel blocks
+    (3, 12, 12, 12, 128, 64),       # more (ci, co) blocks than slabs per block
+    (2, 24, 24, 24, 32, 32),        # 256 slabs -> two-stage reduction
+]
+
+
+@pytest.mark.parametrize("shape", WINO_WGRAD_SHAPES)
+def test_conv3d_winograd_weight_gradient(shape):
+    """tmf_conv3d_wgrad_wino (dU_p = V_p^T Z_p on the fp32 matrix pipe, dw = G^T dU G in fp64) against fp64 torch and the direct
+    kernel, both output layouts, run-to-run bit reproducibility."""
+    ops = _ops()
+    B, D, H, W, cin, cout = shape
+    x = _rand(B, cin, D, H, W, seed=311)
+    dz = _rand(B, cout, D, H, W, seed=312)
+    xg, dzg = _ndhwc(x).to(DEV), _ndhwc(dz).to(DEV)
+    dw = ops.conv3d_wgrad_wino(xg, dzg, cin, cout, reference_layout=True)
+    ref = torch.nn.grad.conv3d_weight(x.double(), (cout, cin, 3, 3, 3), dz.double(), stride=1, padding=1)
+    assert _relerr(dw, ref) < 5e-6
+    dd = ops.conv3d_wgrad(xg, dzg, cin, cout, 3, reference_layout=True)
+    assert _relerr(dw, dd.cpu()) < 5e-6
+    dt = ops.conv3d_wgrad_wino(xg, dzg, cin, cout, reference_layout=False)
+    assert torch.equal(dt.view(3, 3, 3, cin, cout).permute(4, 3, 0, 1, 2).contiguous(), dw)
+    assert torch.equal(dw, ops.conv3d_wgrad_wino(xg, dzg, cin, cout, reference_layout=True))
+
+
+def test_conv3d_winograd_weight_gradient_refuses_other_channel_counts():
+    import transmf_ad_amd as T
+    ops = _ops()
+    assert ops.wgrad_wino_ok(32, 64) and not ops.wgrad_wino_ok(16, 32) and not ops.wgrad_wino_ok(32, 48)
+    with pytest.raises(T.TmfError, match="cin % 32"):
+        ops.conv3d_wgrad_wino(torch.zeros((1, 4, 4, 8, 16), device=DEV), torch.zeros((1, 4, 4, 8, 32), device=DEV), 16, 32)

@@ -148,23 +148,23 @@ def test_train_step_matches_reference_golden_with_register_tiled_conv(name):
         _golden_train_step(name)
     finally:
         _lib.call("tmf_set_option", b"conv_rt", 0)
-        _lib.call("tmf_set_option", b"conv_wino", 2)
+        _lib.call("tmf_set_option", b"conv_wino", 3)
 
 
-@pytest.mark.parametrize("wino", [0, 1])
+@pytest.mark.parametrize("wino", [0, 1, 2])
 @pytest.mark.parametrize("name", ["ad_ragged", "ad_mid", "ad_full_b2", "ad_full_b2_blobs", "ad_adni_b2", "cnn_full_b2", "single_full_b16"])
 def test_train_step_matches_reference_golden_with_direct_conv(name, wino):
-    """The default train step runs forward and data-gradient convolutions in the Winograd form (tmf_set_option("conv_wino", 2));
-    the direct kernels (0) and the mixed mode (1: Winograd data gradients only) stay selectable and pass the SAME golden
-    comparison at the SAME tolerances."""
+    """The default train step runs forward, data-gradient and weight-gradient convolutions in the Winograd form
+    (tmf_set_option("conv_wino", 3)); the direct kernels (0) and the mixed modes (1: Winograd data gradients only, 2: forward
+    and data gradients) stay selectable and pass the SAME golden comparison at the SAME tolerances."""
     from transmf_ad_amd import _lib, ops
-    assert ops.conv_wino_mode() == 2
+    assert ops.conv_wino_mode() == 3
     _lib.call("tmf_set_option", b"conv_wino", wino)
     try:
         assert ops.conv_wino_mode() == wino
         _golden_train_step(name)
     finally:
-        _lib.call("tmf_set_option", b"conv_wino", 2)
+        _lib.call("tmf_set_option", b"conv_wino", 3)
 
 
 def _golden_train_step(name):
@@ -1288,7 +1288,7 @@ def test_single_encoder_model_asks_for_the_register_tiled_conv_per_call():
         c = run(ref)                                         # the same kernels as `net`, chosen process-wide
     finally:
         _lib.call("tmf_set_option", b"conv_rt", 0)
-        _lib.call("tmf_set_option", b"conv_wino", 2)
+        _lib.call("tmf_set_option", b"conv_wino", 3)
     assert all(torch.equal(p, q) for p, q in zip(a, c))
     assert not torch.equal(a[1], b[1])                       # another summation order in the 24^3 layers ...
     assert (a[0] - b[0]).abs().max().item() < 1e-4           # ... and nothing more than that

@@ -1655,7 +1655,7 @@ extern "C" int tmf_set_option(const char* name, int value) {
         return TMF_OK;
     }
     if (strcmp(name, "conv_wino") == 0) {
-        TMF_REQUIRE(value >= 0 && value <= 2, TMF_E_ARG, "tmf_set_option: conv_wino must be 0, 1 or 2, got %d", value);
+        TMF_REQUIRE(value >= 0 && value <= 3, TMF_E_ARG, "tmf_set_option: conv_wino must be 0, 1, 2 or 3, got %d", value);
         return tmf_conv_wino_set(value);
     }
     if (strcmp(name, "debug") == 0) { g_debug = value; tmf_g_debug = value; return TMF_OK; }

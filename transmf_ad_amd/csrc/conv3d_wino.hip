@@ -661,14 +661,14 @@ extern "C" int tmf_wino_trace_read(long long* blocks, long long* phases) {
 }
 #endif
 
-// tmf_set_option("conv_wino", 0 | 1 | 2) / TMF_CONV_WINO: the Winograd form never / for the data gradients / (default) for forward
-// and data gradients of the encoder's 3x3x3 blocks that qualify (tmf_conv3d_wino_ok); consulted by the whole-encoder entries
+// tmf_set_option("conv_wino", 0 | 1 | 2 | 3) / TMF_CONV_WINO: the Winograd form never / for the data gradients / for forward and
+// data gradients / (default) for forward, data and weight gradients of the encoder's 3x3x3 blocks that qualify (tmf_conv3d_wino_ok); consulted by the whole-encoder entries
 // (snet_path.hip) and, through tmf_conv_wino_mode(), by the op-by-op path (ops.py)
 extern "C" int tmf_conv_wino_mode(void) {
     if (g_conv_wino < 0) {
         const char* e = getenv("TMF_CONV_WINO");
-        const int v = e ? atoi(e) : 2;
-        g_conv_wino = (v == 0 || v == 1) ? v : 2;
+        const int v = e ? atoi(e) : 3;
+        g_conv_wino = (v >= 0 && v <= 2) ? v : 3;
     }
     return g_conv_wino;
 }

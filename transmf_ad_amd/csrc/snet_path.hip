@@ -27,7 +27,7 @@ struct LayerPlan {
     int oD, oH, oW;         // block output dims (after the pool)
     bool bf;                // bf16 matrix-core kernels for this block's conv / dgrad / wgrad
     bool sp;                // fp32x: forward / data gradient as six bf16 partial products per fp32 product, weight gradient exact fp32
-    bool wgf, wgd;          // fp32: forward / data gradient in the Winograd form (tmf_set_option("conv_wino", ..), conv3d_wino.hip)
+    bool wgf, wgd, wgw;     // fp32: forward / data gradient / weight gradient in the Winograd form (tmf_set_option("conv_wino", ..), conv3d_wino.hip)
     bool x16, z16, o16;     // bf16 storage of the block input, the raw conv output (and dz), the block output
     size_t off_z, off_out, off_vec, off_wf, off_wd;     // in the saved workspace
     size_t x_bytes, z_bytes, out_bytes;
@@ -74,8 +74,9 @@ Plan make_plan(const tmf_snet_desc& d) {
         // (both channel counts multiples of 8: the data gradient is the same kernel with the roles swapped)
         L.sp = d.precision == TMF_PREC_FP32X && ks[l] == 3 && cin[l] > 1 && cin[l] % 8 == 0 && cout[l] % 8 == 0;
         const int wino = (d.precision == TMF_PREC_FP32 && ks[l] == 3 && cin[l] > 1) ? tmf_conv_wino_mode() : 0;
-        L.wgf = wino == 2 && tmf_conv3d_wino_ok(cin[l], cout[l]);
+        L.wgf = wino >= 2 && tmf_conv3d_wino_ok(cin[l], cout[l]);
         L.wgd = wino >= 1 && tmf_conv3d_wino_ok(cout[l], cin[l]);
+        L.wgw = wino >= 3 && tmf_conv3d_wgrad_wino_ok(cin[l], cout[l]);
     }
     for (int l = 0; l < NL; ++l) {
         LayerPlan& L = p.L[l];
@@ -110,6 +111,7 @@ Plan make_plan(const tmf_snet_desc& d) {
                         : tmf_conv3d_stat_blocks_mode(d.B, L.D, L.H, L.W, L.cin, L.cout, L.k, (d.flags & TMF_SNET_ALONE) ? 1 : 0);
             nb2 = tmf_bn_act_pool_bwd_blocks(d.B, L.D, L.H, L.W, L.cout, L.pool);
             ws = L.bf ? tmf_conv3d_wgrad_bf16_workspace_bytes(d.B, L.D, L.H, L.W, L.cin, L.cout)
+                 : L.wgw ? tmf_conv3d_wgrad_wino_workspace_bytes(d.B, L.D, L.H, L.W, L.cin, L.cout)
                       : tmf_conv3d_wgrad_workspace_bytes(d.B, L.D, L.H, L.W, L.cin, L.cout, L.k);
         }
         const size_t pb = (size_t)nblk * 2 * L.cout * 4, pb2 = (size_t)nb2 * 2 * L.cout * 4;
@@ -378,9 +380,12 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
             TMF_TRY(tmf_conv3d_fwd_bf16_t(dz, wd, dx, nullptr, d->B, L.D, L.H, L.W, L.cout, L.cin,
                                           (L.z16 ? 1 : 0) | (L.x16 ? 2 : 0), stream));
         } else {
-            if (g->dweight[l] != nullptr)
-                TMF_TRY(tmf_conv3d_wgrad((const float*)x, (const float*)dz, g->dweight[l], ws, p.ws_bytes, d->B, L.D, L.H, L.W,
-                                         L.cin, L.cout, L.k, TMF_DW_REFERENCE, stream));
+            if (g->dweight[l] != nullptr) {
+                if (L.wgw) TMF_TRY(tmf_conv3d_wgrad_wino((const float*)x, (const float*)dz, g->dweight[l], ws, p.ws_bytes, d->B, L.D, L.H,
+                                                         L.W, L.cin, L.cout, TMF_DW_REFERENCE, stream));
+                else TMF_TRY(tmf_conv3d_wgrad((const float*)x, (const float*)dz, g->dweight[l], ws, p.ws_bytes, d->B, L.D, L.H, L.W,
+                                              L.cin, L.cout, L.k, TMF_DW_REFERENCE, stream));
+            }
             if (L.sp) TMF_TRY(tmf_conv3d_fwd_split((const float*)dz, wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W, L.cout, L.cin, stream));
             else if (L.wgd) TMF_TRY(tmf_conv3d_fwd_wino((const float*)dz, (const float*)wd, (float*)dx, nullptr, d->B, L.D, L.H, L.W,
                                                         L.cout, L.cin, stream));

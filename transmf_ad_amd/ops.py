@@ -167,7 +167,7 @@ def pack_weights_split3(weight: torch.Tensor, want_dgrad: bool):
 
 def conv_wino_mode() -> int:
     """tmf_set_option("conv_wino", v) / TMF_CONV_WINO: 0 = direct kernels, 1 = Winograd data gradients, 2 = Winograd forward
-    and data gradients (layers with tmf_conv3d_wino_ok)."""
+    and data gradients (layers with tmf_conv3d_wino_ok), 3 (default) = the weight gradients as well (tmf_conv3d_wgrad_wino_ok)."""
     return _lib.query("tmf_conv_wino_mode")
 
 
@@ -321,8 +321,9 @@ class ConvBnActPool(torch.autograd.Function):
         # Winograd form of the fp32 train-mode products (tmf_set_option("conv_wino", ..)): the same choice per layer and
         # direction as the whole-encoder path (snet_path.hip make_plan), so the two stay bit-identical
         wino = conv_wino_mode() if (not bf16 and k == 3 and cin > 1 and training) else 0
-        wino_f = wino == 2 and wino_ok(cin, cout)
+        wino_f = wino >= 2 and wino_ok(cin, cout)
         wino_d = wino >= 1 and wino_ok(cout, cin)
+        ctx.wino_w = wino >= 3 and wgrad_wino_ok(cin, cout)
         if not bf16:                      # both weight layouts in one launch; the dgrad one is kept for backward
             want_d = ctx.needs_input_grad[0]
             wf, wd = pack_weights_both(weight, want_d and not wino_d, want_fwd=not wino_f)
@@ -415,6 +416,8 @@ class ConvBnActPool(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if ctx.bf16 == "bf16":
                 dweight = conv3d_wgrad_bf16(x, dz, cin, cout, reference_layout=True)
+            elif ctx.wino_w:
+                dweight = conv3d_wgrad_wino(x, dz, cin, cout, reference_layout=True)
             else:
                 dweight = conv3d_wgrad(x, dz, cin, cout, k, reference_layout=True)
         dx = None
