@@ -189,23 +189,29 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     auto transform = [&](int c) {                   // halo buffer c & 1 -> this wave's A operands of chunk c
         if (c + 1 < nchunk) stage(c + 1);           // (its buffer was last read before the barrier two intervals ago)
         const float* R = smem + (c & 1) * (RAW_BYTES / 4);
-        const f32x4 s4 = {sgn, sgn, sgn, sgn};
-        auto wrow = [&](int pa, int pb, f32x4 (&wv)[4]) {                    // one h row: d combination, then the w transform
-            f32x4 tv[4];
+        // (float2 halves on purpose: <2 x float> arithmetic is one v_pk_*_f32 per pair, <4 x float> is split into scalars)
+        const f32x2 s2 = {sgn, sgn}, c2 = {c1, c1};
+        auto wrow = [&](int pa, int pb, f32x2 (&lo)[4], f32x2 (&hi)[4]) {     // one h row: d combination, then the w transform
+            f32x2 tl[4], th2[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                tv[k] = *reinterpret_cast<const f32x4*>(&R[pa + ogw(k) * 8]) + s4 * *reinterpret_cast<const f32x4*>(&R[pb + ogw(k) * 8]);
-            wv[0] = tv[0] - tv[2]; wv[1] = tv[1] + tv[2]; wv[2] = tv[2] - tv[1]; wv[3] = tv[1] - tv[3];
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(&R[pa + ogw(k) * 8]), bq = *reinterpret_cast<const f32x4*>(&R[pb + ogw(k) * 8]);
+                tl[k] = f32x2{a[0], a[1]} + s2 * f32x2{bq[0], bq[1]};
+                th2[k] = f32x2{a[2], a[3]} + s2 * f32x2{bq[2], bq[3]};
+            }
+            lo[0] = tl[0] - tl[2]; lo[1] = tl[1] + tl[2]; lo[2] = tl[2] - tl[1]; lo[3] = tl[1] - tl[3];
+            hi[0] = th2[0] - th2[2]; hi[1] = th2[1] + th2[2]; hi[2] = th2[2] - th2[1]; hi[3] = th2[1] - th2[3];
         };
-        f32x4 wk[4];
-        wrow(rka, rkb, wk);
-        wrow(raa, rab, A0);
-        wrow(rba, rbb, A1);
-        const f32x4 c4 = {c1, c1, c1, c1};
+        f32x2 kl[4], kh[4], al[4], ah[4], bl[4], bh[4];
+        wrow(rka, rkb, kl, kh);
+        wrow(raa, rab, al, ah);
+        wrow(rba, rbb, bl, bh);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            A0[k] = A0[k] - wk[k];
-            A1[k] = c4 * A1[k] + wk[k];
+            al[k] = al[k] - kl[k]; ah[k] = ah[k] - kh[k];
+            bl[k] = c2 * bl[k] + kl[k]; bh[k] = c2 * bh[k] + kh[k];
+            A0[k] = f32x4{al[k][0], al[k][1], ah[k][0], ah[k][1]};
+            A1[k] = f32x4{bl[k][0], bl[k][1], bh[k][0], bh[k][1]};
         }
     };
     auto multiply = [&](int c, auto first_c) {      // chunk c: A operands x the weights in this wave's LDS region
