@@ -546,17 +546,21 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
     setup_steps = int(os.environ.get("TMF_BENCH_SETUP_STEPS", "30")) if args.steps > 0 else 0      # (env: profiling runs)
     for _ in range(setup_steps):
         step()
+    # (the collector runs HERE, ahead of the W warm-up steps, and stays off until the K timed steps are over: a full collection
+    # is tens of milliseconds on a torch heap — inside the timed region it is a step-sized pause, between the fence and the
+    # first timed step it idles the GPU long enough for the clocks to drop: the first three timed steps of a process measured
+    # 11.3 / 10.1 / 10.0 ms against 9.5 for the rest)
+    import gc
+    gc.collect()
+    gc.disable()
+    # one event per step boundary on the stream the steps are issued on (torch's current stream; the side streams of a
+    # step join it before the optimizer): per-step times for ms_per_step_min / _median beside the wall-clock mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     for _ in range(args.warmup):
         step()
     fence()
     if isinstance(net, GradAllReduce):
         net.timing = True
-    # one event per step boundary on the stream the steps are issued on (torch's current stream; the side streams of a
-    # step join it before the optimizer): per-step times for ms_per_step_min / _median beside the wall-clock mean
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    import gc
-    gc.collect()
-    gc.disable()                # (no collector pause inside the K timed steps: a full collection is milliseconds on a torch heap)
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
