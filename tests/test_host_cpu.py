@@ -206,3 +206,36 @@ def test_winograd_halo_slot_map_is_a_conflict_free_bijection():
                             td, th, tw = tile >> 4, (tile >> 2) & 3, tile & 3
                             res.add(slot(2 * td + dd, 2 * th + i, 2 * tw + k, quad) % 16)
                         assert len(res) == 16, (dd, i, k, quad)
+
+
+def test_winograd_form_is_the_default_plan_of_the_encoder():
+    """tmf_set_option("conv_wino", ..): default 3; the whole-encoder plan (tmf_snet_saved_bytes — host arithmetic, no GPU) carries
+    the 64-position transformed weights (64 x cin x cout floats per layout) exactly for the layers and directions a mode puts on
+    the Winograd kernels, and the weight-gradient workspace grows to the kernel's [splits + groups + 1][blocks][64][32][32] slabs."""
+    from transmf_ad_amd import _lib
+    lib = _lib.load()
+    assert lib.tmf_conv_wino_mode() == 3
+    assert lib.tmf_conv3d_wino_ok(8, 32) and not lib.tmf_conv3d_wino_ok(8, 16) and not lib.tmf_conv3d_wino_ok(4, 32)
+    assert lib.tmf_conv3d_wgrad_wino_ok(32, 64) and not lib.tmf_conv3d_wgrad_wino_ok(16, 32)
+    assert lib.tmf_conv3d_wino_stat_blocks(8, 48, 48, 48) == 8 * 12 * 6 * 6 and lib.tmf_conv3d_wino_stat_blocks(2, 7, 9, 13) == 2 * 2 * 2 * 2
+    assert lib.tmf_conv3d_wino_weight_bytes(32, 64) == 64 * 32 * 64 * 4
+    # conv2.0 at B = 8, 48^3: one (ci, co) block -> 256 slabs in 16 groups
+    assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 32, 32) == (256 + 16 + 1) * 64 * 1024 * 4
+    assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 16, 32) == 0
+    desc = _lib.SnetDesc(B=8, D=96, H=96, W=96, dim=128, precision=0, storage_bf16=0)
+    desc.momentum[:] = [0.1] * 7
+    desc.eps[:] = [1e-5] * 7
+    desc.slope[:] = [0.01] * 7
+    layers = [(32, 32), (32, 64), (64, 64), (64, 128), (128, 256)]          # the five Cin > 1 3x3x3 blocks of sNet(128)
+    try:
+        size = {}
+        for mode in (0, 1, 2, 3):
+            assert lib.tmf_set_option(b"conv_wino", mode) == 0
+            size[mode] = lib.tmf_snet_saved_bytes(ctypes.byref(desc)), lib.tmf_snet_bwd_scratch_bytes(ctypes.byref(desc))
+        per_layout = sum((64 - 27) * ci * co * 4 for ci, co in layers)     # every size here is a multiple of 256
+        assert size[1][0] - size[0][0] == per_layout                       # data-gradient layouts
+        assert size[2][0] - size[1][0] == per_layout                       # + forward layouts
+        assert size[3][0] == size[2][0] and size[3][1] > size[2][1]        # + the weight-gradient slabs in backward's scratch
+        assert lib.tmf_set_option(b"conv_wino", 4) != 0
+    finally:
+        lib.tmf_set_option(b"conv_wino", 3)
