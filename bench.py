@@ -161,10 +161,10 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             wino = ops.conv_wino_mode() if precision == "fp32" else 0       # as the step runs them (snet_path.hip make_plan)
             if wino >= 2 and ops.wino_ok(ci, co):
                 uf, _ = ops.pack_weights_wino(w, True, False)
-                fns = (("fwd", "conv3d_wino_kernel<true>", lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
+                fns = (("fwd", "conv3d_wino_kernel<1>", lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
             if wino >= 1 and ops.wino_ok(co, ci):
                 _, ud = ops.pack_weights_wino(w, False, True)
-                fns = (fns[0], ("dgrad", "conv3d_wino_kernel<false>", lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
+                fns = (fns[0], ("dgrad", "conv3d_wino_kernel<0>", lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
             if wino >= 3 and ops.wgrad_wino_ok(ci, co):
                 fns = fns[:2] + (("wgrad", "conv3d_wino_wgrad_kernel", lambda: ops.conv3d_wgrad_wino(x, dz, ci, co)),)
             if precision == "fp32x":      # forward / data gradient as the step runs them: six bf16 partial products per fp32 product

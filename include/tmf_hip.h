@@ -137,6 +137,10 @@ int  tmf_conv3d_split_stat_blocks(int B, int D, int H, int W);        /* rows of
 int    tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, float* stat_partial,
                            int B, int D, int H, int W, int cin, int cout, void* stream);
 int    tmf_conv3d_wino_ok(int cin, int cout);
+/* ... and the eval-mode block in one pass (tmf_conv3d_fwd_affine's Winograd form, val_step: kfold_train_adversarial.py:144-161):
+ * y = LeakyReLU(scale * conv(x, w) + shift), pool TMF_POOL_NONE | TMF_POOL_MAX2 (floor mode) applied before the store. */
+int    tmf_conv3d_fwd_wino_affine(const float* x, const float* u, const float* scale, const float* shift, float* y,
+                                  int B, int D, int H, int W, int cin, int cout, int pool, float slope, void* stream);
 int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);
 size_t tmf_conv3d_wino_weight_bytes(int cin, int cout);             /* 64 * cin * cout floats */
 int    tmf_conv_wino_mode(void);

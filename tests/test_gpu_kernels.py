@@ -1315,3 +1315,33 @@ def test_conv3d_winograd_weight_gradient_refuses_other_channel_counts():
     assert ops.wgrad_wino_ok(32, 64) and not ops.wgrad_wino_ok(16, 32) and not ops.wgrad_wino_ok(32, 48)
     with pytest.raises(T.TmfError, match="cin % 32"):
         ops.conv3d_wgrad_wino(torch.zeros((1, 4, 4, 8, 16), device=DEV), torch.zeros((1, 4, 4, 8, 32), device=DEV), 16, 32)
+
+
+@pytest.mark.parametrize("shape,pool", [((2, 7, 9, 13, 8, 32), "max"), ((2, 7, 9, 13, 8, 32), None), ((2, 12, 16, 16, 32, 64), "max"),
+                                        ((1, 24, 24, 24, 64, 64), None)])
+def test_conv3d_winograd_eval_block_in_one_pass(shape, pool):
+    """tmf_conv3d_fwd_wino_affine: the eval-mode block (conv + folded BatchNorm + LeakyReLU + max pool) in ONE Winograd kernel —
+    bitwise what the two-kernel sequence (Winograd conv, then tmf_bn_act_pool_fwd) gives, and fp32-close to fp64 torch."""
+    from transmf_ad_amd import _lib
+    ops = _ops()
+    B, D, H, W, cin, cout = shape
+    x = _rand(B, cin, D, H, W, seed=321)
+    w = _rand(cout, cin, 3, 3, 3, seed=322, scale=(cin * 27) ** -0.5)
+    sc, sh = 1 + _rand(cout, seed=323, scale=0.2), _rand(cout, seed=324, scale=0.2)
+    xg = _ndhwc(x).to(DEV)
+    uf, _ = ops.pack_weights_wino(w.to(DEV), True, False)
+    scg, shg = sc.to(DEV), sh.to(DEV)
+    pc = _lib.pool_code(pool)
+    oshape = (B, D // 2, H // 2, W // 2, cout) if pool else (B, D, H, W, cout)
+    y = torch.full(oshape, float("nan"), device=DEV)
+    _lib.call("tmf_conv3d_fwd_wino_affine", xg.data_ptr(), uf.data_ptr(), scg.data_ptr(), shg.data_ptr(), y.data_ptr(),
+              B, D, H, W, cin, cout, pc, 0.01, ops._stream())
+    z, _, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, False)
+    y2 = torch.empty(oshape, device=DEV)
+    _lib.call("tmf_bn_act_pool_fwd_t", z.data_ptr(), scg.data_ptr(), shg.data_ptr(), y2.data_ptr(), B, D, H, W, cout, pc, 0.01, 0,
+              ops._stream())
+    assert torch.equal(y, y2)
+    ref = F.leaky_relu(F.conv3d(x.double(), w.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1), 0.01)
+    if pool:
+        ref = F.max_pool3d(ref, 2, 2)
+    assert _relerr(_ncdhw(y.cpu()), ref) < 3e-6

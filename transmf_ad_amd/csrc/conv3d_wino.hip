@@ -89,10 +89,15 @@ __device__ long long g_wino_phases[8 * 64];
 #define TRP(i)
 #endif
 
-template <bool STATS>
+// MODE 0: z only (data gradient, eval-mode z); 1: z + BatchNorm statistic partials (train forward); 2: the eval-mode block in
+// ONE pass — y = LeakyReLU(scale z + shift), optionally 2x2x2 max-pooled, is what gets stored (BatchNorm is affine in eval mode;
+// a pooling window — d pair x h pair x w pair — lies inside ONE lane's 16 outputs, so the pool costs no exchange at all)
+template <int MODE>
 __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ z, float* __restrict__ stat_partial,
-    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles) {
+    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int ntiles,
+    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr, float slope = 0.f, int pool = 0) {
+    constexpr bool STATS = MODE == 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ex = smem;
     float* red = smem + RED_OFF;
@@ -330,6 +335,43 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     //   tile w = 2 (w' & 1) + rr, tile h = hsel + 2 ((w' >> 1) & 1), tile d = w' >> 2
     // voxel w = w0 + 4 (w' & 1) + 2 rr + wo (four consecutive), h = h0 + 2 hsel + 4 ((w' >> 1) & 1) + ho, d = d0 + 2 (w' >> 2) + do
     float s1 = 0.f, s2 = 0.f;
+    if constexpr (MODE == 2) {
+        const int co = n0 + l31;
+        const float sc = aff_scale[co], sh = aff_shift[co];
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int ho = 0; ho < 2; ++ho)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float y = outv[dd][ho][e] * sc + sh;
+                    outv[dd][ho][e] = y > 0.f ? y : y * slope;
+                }
+        const int gwb = w0 + 4 * (wave & 1), ghb = h0 + 2 * hsel + 4 * ((wave >> 1) & 1), gdb = d0 + 2 * (wave >> 2);
+        if (pool == TMF_POOL_MAX2) {
+            const int OD = D / 2, OH = H / 2, OW = W / 2;
+            float* yb = z + (size_t)b * OD * OH * OW * Cout;
+            const int od = gdb >> 1, oh = ghb >> 1, ow = gwb >> 1;
+#pragma unroll
+            for (int wp = 0; wp < 2; ++wp) {               // w pair wp = outputs e = wp (w offset 2 wp) and e = wp + 2 (2 wp + 1)
+                float m = fmaxf(fmaxf(outv[0][0][wp], outv[0][0][wp + 2]), fmaxf(outv[0][1][wp], outv[0][1][wp + 2]));
+                m = fmaxf(m, fmaxf(fmaxf(outv[1][0][wp], outv[1][0][wp + 2]), fmaxf(outv[1][1][wp], outv[1][1][wp + 2])));
+                if (od < OD && oh < OH && ow + wp < OW) yb[((size_t)(od * OH + oh) * OW + ow + wp) * Cout + co] = m;
+            }
+        } else {
+            float* yb = z + (size_t)b * D * H * W * Cout;
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                for (int ho = 0; ho < 2; ++ho)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int gd = gdb + dd, gh = ghb + ho, gw = gwb + 2 * (e & 1) + (e >> 1);
+                        if (gd < D && gh < H && gw < W) yb[((size_t)(gd * H + gh) * W + gw) * Cout + co] = outv[dd][ho][e];
+                    }
+        }
+        return;
+    }
     {
         float* zb = z + (size_t)b * D * H * W * Cout;
         const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, D * H * W * Cout * 4, 0x00020000);
@@ -717,15 +759,15 @@ extern "C" int tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, flo
     dim3 grid(ntiles, cout / 32), block(NTHR);
     int rc;
     if (stat_partial != nullptr) {
-        auto k = conv3d_wino_kernel<true>;
+        auto k = conv3d_wino_kernel<1>;
         if ((rc = tmf_allow_lds(k, LDS_BYTES, "tmf_conv3d_fwd_wino"))) return rc;
         hipLaunchKernelGGL(k, grid, block, LDS_BYTES, (hipStream_t)stream, x, u, z, stat_partial, D, H, W, cin, cout,
-                           tilesD, tilesH, tilesW, ntiles);
+                           tilesD, tilesH, tilesW, ntiles, (const float*)nullptr, (const float*)nullptr, 0.f, 0);
     } else {
-        auto k = conv3d_wino_kernel<false>;
+        auto k = conv3d_wino_kernel<0>;
         if ((rc = tmf_allow_lds(k, LDS_BYTES, "tmf_conv3d_fwd_wino"))) return rc;
         hipLaunchKernelGGL(k, grid, block, LDS_BYTES, (hipStream_t)stream, x, u, z, stat_partial, D, H, W, cin, cout,
-                           tilesD, tilesH, tilesW, ntiles);
+                           tilesD, tilesH, tilesW, ntiles, (const float*)nullptr, (const float*)nullptr, 0.f, 0);
     }
     return tmf_launch_result("tmf_conv3d_fwd_wino");
 }
@@ -768,4 +810,28 @@ extern "C" int tmf_conv3d_wgrad_wino(const float* x, const float* dz, float* dw,
     hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)tmf_cdiv((long)cin * cout, 256L)), dim3(256), 0, s,
                        (const float*)du, dw, cin, cout, p.ncob, dw_layout == TMF_DW_REFERENCE ? 1 : 0);
     return tmf_launch_result("tmf_conv3d_wgrad_wino(finish)");
+}
+
+// Eval-mode block in one pass (tmf_conv3d_fwd_affine's Winograd form): y = LeakyReLU(scale * conv(x, w) + shift), optionally
+// 2x2x2 max-pooled (floor mode).  pool: TMF_POOL_NONE | TMF_POOL_MAX2 (the average pool of the network follows its 1x1x1 block).
+extern "C" int tmf_conv3d_fwd_wino_affine(const float* x, const float* u, const float* scale, const float* shift, float* y,
+                                          int B, int D, int H, int W, int cin, int cout, int pool, float slope, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(u); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(y);
+    TMF_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, TMF_E_SHAPE, "tmf_conv3d_fwd_wino_affine: non-positive dimension");
+    TMF_REQUIRE(tmf_conv3d_wino_ok(cin, cout), TMF_E_SHAPE,
+                "tmf_conv3d_fwd_wino_affine: needs cin %% 8 == 0 and cout %% 32 == 0 (cin=%d cout=%d)", cin, cout);
+    TMF_REQUIRE(pool == TMF_POOL_NONE || pool == TMF_POOL_MAX2, TMF_E_ARG, "tmf_conv3d_fwd_wino_affine: pool must be none or max, got %d", pool);
+    TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 29), TMF_E_SHAPE,
+                "tmf_conv3d_fwd_wino_affine: one sample exceeds 2^29 elements (32-bit byte offsets inside a sample)");
+    TMF_REQUIRE((long)64 * cin * cout < (1L << 29), TMF_E_SHAPE, "tmf_conv3d_fwd_wino_affine: weight tensor exceeds 2^29 elements");
+    TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(u); TMF_REQUIRE_ALIGNED(y);
+    if (pool != TMF_POOL_NONE && (D / 2 == 0 || H / 2 == 0 || W / 2 == 0)) return TMF_OK;      // empty output
+    const int tilesD = tmf_cdiv(D, TD), tilesH = tmf_cdiv(H, TH), tilesW = tmf_cdiv(W, TW);
+    const int ntiles = B * tilesD * tilesH * tilesW;
+    auto k = conv3d_wino_kernel<2>;
+    int rc;
+    if ((rc = tmf_allow_lds(k, LDS_BYTES, "tmf_conv3d_fwd_wino_affine"))) return rc;
+    hipLaunchKernelGGL(k, dim3(ntiles, cout / 32), dim3(NTHR), LDS_BYTES, (hipStream_t)stream, x, u, y, (float*)nullptr, D, H, W, cin, cout,
+                       tilesD, tilesH, tilesW, ntiles, scale, shift, slope, pool);
+    return tmf_launch_result("tmf_conv3d_fwd_wino_affine");
 }

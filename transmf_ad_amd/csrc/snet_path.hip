@@ -265,7 +265,9 @@ extern "C" int tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const
         const Vecs v = vecs_of(base, L);
         void* o = l == NL - 1 ? (void*)out : (void*)(base + L.off_out);
         void* wf = base + L.off_wf;
+        const bool wino = L.wgf && L.pool != TMF_POOL_AVG2;       // the Winograd form of the one-kernel block (fp32 only: make_plan)
         if (L.bf) TMF_TRY(tmf_pack_conv_weights_bf16(prm->weight[l], wf, nullptr, L.cout, L.cin, 27, stream));
+        else if (wino) TMF_TRY(tmf_pack_conv_weights_wino(prm->weight[l], (float*)wf, nullptr, L.cout, L.cin, stream));
         else TMF_TRY(tmf_pack_conv_weights(prm->weight[l], (float*)wf, nullptr, L.cout, L.cin, L.k * L.k * L.k, stream));
         TMF_TRY(tmf_bn_eval_coeffs(prm->gamma[l], prm->beta[l], prm->bias[l], prm->running_mean[l], prm->running_var[l],
                                    d->eps[l], L.cout, v.scale, v.shift, stream));
@@ -285,6 +287,9 @@ extern "C" int tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const
             float* z = (float*)(base + L.off_z);
             TMF_TRY(tmf_conv3d_fwd((const float*)x, (const float*)wf, z, nullptr, d->B, L.D, L.H, L.W, L.cin, L.cout, L.k, stream));
             TMF_TRY(tmf_bn_act_pool_fwd_t(z, v.scale, v.shift, o, d->B, L.D, L.H, L.W, L.cout, L.pool, d->slope[l], 0, stream));
+        } else if (wino) {
+            TMF_TRY(tmf_conv3d_fwd_wino_affine((const float*)x, (const float*)wf, v.scale, v.shift, (float*)o, d->B, L.D, L.H, L.W,
+                                               L.cin, L.cout, L.pool, d->slope[l], stream));
         } else {
             TMF_TRY(tmf_conv3d_fwd_affine((const float*)x, (const float*)wf, v.scale, v.shift, (float*)o, d->B, L.D, L.H, L.W,
                                           L.cin, L.cout, L.k, L.pool, d->slope[l], stream));

@@ -318,9 +318,9 @@ class ConvBnActPool(torch.autograd.Function):
         if out_bf16 and not z16:
             raise _lib.TmfError("a bf16 block output needs conv precision 'bf16' with bf16 activation storage")
         wf = wd = None
-        # Winograd form of the fp32 train-mode products (tmf_set_option("conv_wino", ..)): the same choice per layer and
+        # Winograd form of the fp32 products (tmf_set_option("conv_wino", ..)): the same choice per layer and
         # direction as the whole-encoder path (snet_path.hip make_plan), so the two stay bit-identical
-        wino = conv_wino_mode() if (not bf16 and k == 3 and cin > 1 and training) else 0
+        wino = conv_wino_mode() if (not bf16 and k == 3 and cin > 1) else 0
         wino_f = wino >= 2 and wino_ok(cin, cout)
         wino_d = wino >= 1 and wino_ok(cout, cin)
         ctx.wino_w = wino >= 3 and wgrad_wino_ok(cin, cout)
@@ -534,8 +534,13 @@ def conv_bn_act_pool_eval_fused(x, weight, bias, gamma, beta, running_mean, runn
     shape = (B, D, H, W, cout) if pc == _lib.POOL_NONE else (B, D // 2, H // 2, W // 2, cout)
     out = torch.empty(shape, device=dev, dtype=_f32)
     if out.numel() > 0:
-        _lib.call("tmf_conv3d_fwd_affine", x.data_ptr(), pack_weight(weight).data_ptr(), scale.data_ptr(),
-                  shift.data_ptr(), out.data_ptr(), B, D, H, W, cin, cout, k, pc, float(slope), s)
+        if k == 3 and conv_wino_mode() >= 2 and wino_ok(cin, cout) and pool != "avg":       # as tmf_snet_eval_fwd chooses
+            uf, _ = pack_weights_wino(weight, True, False)
+            _lib.call("tmf_conv3d_fwd_wino_affine", x.data_ptr(), uf.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                      out.data_ptr(), B, D, H, W, cin, cout, pc, float(slope), s)
+        else:
+            _lib.call("tmf_conv3d_fwd_affine", x.data_ptr(), pack_weight(weight).data_ptr(), scale.data_ptr(),
+                      shift.data_ptr(), out.data_ptr(), B, D, H, W, cin, cout, k, pc, float(slope), s)
     return out
 
 
