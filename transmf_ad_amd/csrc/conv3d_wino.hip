@@ -123,6 +123,17 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     const int nchunk = Cin / CK;
 
     constexpr int OOB = (int)0x80000000u;
+    // this wave's first weights are requested before anything else is computed (one workgroup per CU: nothing else hides the round trip)
+    const int mpd = wave >> 1, mhh = wave & 1;
+    const int p0 = mpd * 16 + mhh * 8;
+    const int b_lane = (hsel * Cout + n0 + l31) * 16;        // bytes
+    const i32x4 ur = make_rsrc(u, (unsigned)(64 * Cin * Cout * 4));
+    const unsigned bl0 = lds0 + B_OFF + wave * 8192;
+    auto stage_b = [&](int c, int q) {              // this wave's weights of (chunk c, position q) -> its own 8 KB
+        blds16(b_lane, ur, (((p0 + q) * nchunk + c) * 2 * Cout) * 16, bl0 + q * 1024);
+    };
+#pragma unroll
+    for (int q = 0; q < 8; ++q) stage_b(0, q);
     const float* xb = x + (size_t)b * D * H * W * Cin;
     const i32x4 xr = make_rsrc(xb, (unsigned)(D * H * W * Cin * 4));
 
@@ -148,13 +159,13 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
 #pragma unroll
         for (int q = 0; q < NDMA; ++q) blds16(hoff[q], xr, c * (CK * 4), base + q * 8192);
     };
+    stage(0);                                       // (the rest of the address plan below runs under this round trip)
 
     // ---- this wave's part of the input transform and of the products ----
     // wave = (pd, half of ph): the 8 positions (pd, ph = 2 mhh + {0, 1}, pw = 0..3), one 32 x 32 accumulator each.  The lane
     // computes the A operands of ITS tile (l31) and channel quad (hsel) in registers, straight from the halo:
     //   along d: row pd of B^T = d_a + sgn d_b;   along w: all four;   along h: the two rows this wave multiplies —
     //   mhh = 0: ph0 = x0 - x2, ph1 = x1 + x2 (keeper x2);  mhh = 1: ph2 = x2 - x1, ph3 = x1 - x3 = -(x3 - x1) (keeper x1)
-    const int mpd = wave >> 1, mhh = wave & 1;
     const int da = mpd == 0 ? 0 : (mpd == 2 ? 2 : 1);
     const int db = mpd == 0 ? 2 : (mpd == 1 ? 2 : (mpd == 2 ? 1 : 3));
     const float sgn = mpd == 1 ? 1.f : -1.f;
@@ -168,19 +179,8 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
     const int rka = row_base(da, ik), rkb = row_base(db, ik);
     const int raa = row_base(da, ia), rab = row_base(db, ia);
     const int rba = row_base(da, ib), rbb = row_base(db, ib);
-    const int p0 = mpd * 16 + mhh * 8;
-    const int b_lane = (hsel * Cout + n0 + l31) * 16;        // bytes
-    const i32x4 ur = make_rsrc(u, (unsigned)(64 * Cin * Cout * 4));
-    const unsigned bl0 = lds0 + B_OFF + wave * 8192;
-    auto stage_b = [&](int c, int q) {              // this wave's weights of (chunk c, position q) -> its own 8 KB
-        blds16(b_lane, ur, (((p0 + q) * nchunk + c) * 2 * Cout) * 16, bl0 + q * 1024);
-    };
     const float* Bl = smem + (B_OFF + wave * 8192) / 4 + lane * 4;
     f32x16 acc[8];
-
-    stage(0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) stage_b(0, q);
     TRP(1);
     dma_wait();
     __syncthreads();
