@@ -50,7 +50,6 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--shapes", default="7,9,13")
     ap.add_argument("--no-time", action="store_true")
-    ap.add_argument("--dbg", type=int, default=0, help="timing ablation bits for the Winograd kernel (results are garbage): 2 no MFMA, 4 no stores, 8 no transform, 16 no epilogue")
     a = ap.parse_args()
     dev = "cuda:0"
     torch.manual_seed(0)
@@ -82,14 +81,11 @@ def main():
                         if i == 2:
                             e0.record()
                         if v == "wino":
-                            if a.dbg and i == 0:
-                                _lib.call("tmf_set_option", b"debug", a.dbg)
                             ops.conv3d_wino_raw(x, uf, ci, co, what == "fwd")
                         else:
                             ops.conv3d_raw(x, wp, ci, co, 3, what == "fwd")
                     e1.record()
                     e1.synchronize()
-                    _lib.call("tmf_set_option", b"debug", 0)
                     best[v] = min(best[v], e0.elapsed_time(e1) / a.reps)
             flop = 2.0 * a.B * s ** 3 * ci * co * 27
             for v in best:
