@@ -1,34 +1,40 @@
-// conv3d_wino.hip — 3x3x3 convolution (forward / data gradient) in the Winograd form F(2x2x2, 3x3x3), exact-fp32
-// arithmetic on v_mfma_f32_32x32x2_f32, for gfx950 (MI355X).
+// conv3d_wino.hip — the encoders' 3x3x3 convolutions (forward, data gradient, weight gradient, eval-mode block) in the
+// Winograd form F(2x2x2, 3x3x3), exact-fp32 arithmetic on v_mfma_f32_32x32x2_f32, for gfx950 (MI355X).  DESIGN.md 3.15.
 //
-// Why.  The fp32 train step is bound by the fp32 matrix pipe (0.78 / 0.83 busy over a whole step, every
-// vector instruction paid in matrix time), and the direct kernels of conv3d_mfma.hip already run at 0.72-0.86 of it: the
-// only thing left to remove is the matrix work itself.  With 2x2x2 output tiles a 3x3x3 convolution needs 64 products per
-// tile, input and output channel instead of 216 (x 3.375 less), at the price of 192 additions per (tile, input channel) and
-// 112 per (tile, output channel) — 10-15 % of the remaining matrix time at 32-64 channels.
+// Why.  The fp32 train step is bound by the fp32 matrix pipe (0.78 / 0.83 busy over a whole step, every vector instruction
+// paid in matrix time), and the direct kernels of conv3d_mfma.hip already run at 0.72-0.86 of it: the only thing left to
+// remove is the matrix work itself.  With 2x2x2 output tiles a 3x3x3 convolution needs 64 products per tile, input and
+// output channel instead of 216 (x 3.375 less), at the price of 192 additions per (tile, input channel) and 112 per (tile,
+// output channel).
 //
 //   y = A^T [ (G g G^T) .* (B^T d B) ] A   along each of the three axes,
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1].
 //
-// One workgroup (8 waves, one per CU: the accumulators are half the CU's register file) owns a 4x8x8 brick of output
-// voxels = 32 tiles and 32 output channels:
-//   * per chunk of 8 input channels the 6x10x10 halo goes global -> registers -> LDS (zero fill from the buffer range
-//     check), is transformed to V[64 positions][32 tiles][8 channels] in LDS (thread = (tile, channel pair, row pd of the
-//     d transform): 32 ds_read_b64, 48 packed adds, 16 ds_write_b64), and then multiplied: wave w owns the 8 positions
-//     (pd = w / 2, ph in {2 (w & 1), +1}, pw = 0..3) with one 32 x 32 accumulator each; A operand = one ds_read_b128 per
-//     position (the K permutation of conv3d_mfma.hip: lanes 0-31 channels 0-3, lanes 32-63 channels 4-7), B operand =
-//     the transformed weights straight from L2 (each position's weights are used by exactly one wave of the workgroup: a
-//     ring in LDS would share nothing), one buffer_load_b128 per position, requested before the transform phase;
-//   * epilogue: the w transform and this wave's half of the h transform in registers, one exchange through LDS (128 KB),
-//     the d transform on the reading side, 128-byte channel rows to z, BatchNorm statistic partials as in the direct
-//     kernels (fixed order: results are bit-reproducible run to run).
+// Forward / data gradient (conv3d_wino_kernel<MODE>).  One workgroup (8 waves, ONE per CU: its 64 x 32 x 32 accumulators
+// are half the CU's register file) owns a 4x8x8 brick of output voxels = 32 tiles and 32 output channels:
+//   * per chunk of 8 input channels the 6x10x10 halo comes in by LDS-DMA (zero fill from the buffer range check), double-
+//     buffered, in a parity-sorted slot map whose tile-strided ds_read_b128 is conflict-free (see RAW layout below);
+//   * wave w owns the 8 positions (pd = w / 2, ph in {2 (w & 1), +1}, pw = 0..3) of the transformed tile with one 32 x 32
+//     accumulator each; NO transformed tensor exists: the lane (tile, channel quad) computes the A operands of its tile for
+//     those positions in registers straight from the halo (24 ds_read_b128 + 64 packed adds per chunk); the K permutation is
+//     conv3d_mfma.hip's (lanes 0-31 channels 0-3, lanes 32-63 channels 4-7);
+//   * B operand = the transformed weights U[p][cin/8][2][cout][4] (tmf_pack_conv_weights_wino: fp64 inside, rounded once):
+//     each position's weights are used by exactly one wave, so they go global -> that wave's private 8 KB of LDS by DMA, the
+//     next chunk's copies issued right behind the reads of the running one;
+//   * the waves 0-3 transform a chunk and then multiply it while the waves 4-7 first multiply the previous chunk and then
+//     transform (w and w + 4 share a SIMD: one's loads / adds run beside the other's MFMAs); one barrier per chunk;
+//   * epilogue: the w transform and this wave's half of the h transform in registers, one exchange through LDS (128 KB), the
+//     other half and the d transform on the reading side, 128-byte channel rows to z, BatchNorm statistic partials as the
+//     direct kernels produce them (MODE 1) or the eval-mode affine + LeakyReLU + in-lane 2x2x2 max pool (MODE 2); fixed
+//     order everywhere: results are bit-reproducible run to run.
+// Weight gradient (conv3d_wino_wgrad_kernel): dU_p = V_p^T Z_p per position over all tiles, dW = G^T dU G — further down.
 //
-// The transformed weights U[p][cin/8][2][cout][4] come from tmf_pack_conv_weights_wino (computed in fp64, rounded once).
-// Numerics: transforms, products and sums in fp32; against the fp64 reference the error of z is about twice the direct
-// kernels' (cancellation in the output transform), measured on the fixtures in tools/winograd_numerics.py and gated by the
-// golden tests at the same tolerances as the direct path.
+// Numerics: transforms, products and sums in fp32 (U and the final G^T . G in fp64); against fp64 the error of z, dx and dw
+// is level with the direct kernels' (2-8e-7 of the maximum: Cin-long fp32 chains + the cancellation of the output transform
+// against 864..3456-term chains), measured in tools/wino_check.py / wino_wgrad_check.py and gated by the golden tests at the
+// same tolerances as the direct path.
 //
-// Replaces aten::conv3d / convolution_backward (input gradient) at /root/reference/models/networks.py:28,31,37,40,46.
+// Replaces aten::conv3d / convolution_backward at /root/reference/models/networks.py:28,31,37,40,46.
 #include <type_traits>
 #include "tmf_common.h"
 
