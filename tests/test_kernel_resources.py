@@ -60,3 +60,13 @@ def test_bf16_large_brick_kernels_fit_128_registers(kernels):
             assert k.get("scratch", 0) == 0, k
         else:
             assert k.get("scratch", 0) <= 64, k
+
+
+def test_winograd_kernels_fit_their_registers_without_scratch(kernels):
+    """conv3d_wino_kernel<0|1|2> runs ONE 8-wave workgroup per CU with 128 accumulator registers per wave: 256 registers is the
+    whole budget, and the compiler answers anything above it by spilling the address plan into the chunk loop (seen in this
+    round with three edits that looked harmless: -6 ... -22 % without any error).  The weight-gradient kernel likewise."""
+    ks = _find(kernels, "conv3d_wino.o", "conv3d_wino_kernelILi")
+    assert len(ks) == 3
+    for k in ks + _find(kernels, "conv3d_wino.o", "conv3d_wino_wgrad_kernel"):
+        assert k["vgpr"] <= 256 and k.get("scratch", 0) == 0, k
