@@ -244,6 +244,9 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
         "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
         "traffic_note": None if traffic is None else f"{traffic.get('note')} [{traffic.get('source')}]",
         "launch_ms": round(dom["ms"] / dom["launches"], 4),
+        "launch_note": ("a weight-gradient op is the kernel named here + its tmf_slab_reduce launch(es) (+ wino_wgrad_finish_kernel for "
+                        "the Winograd form): launch_ms times the op; in a rocprofv3 --stats summary the rows of those kernels add up to it"
+                        if "wgrad" in dom_name else "one launch of the kernel named here"),
         "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
         "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
         "mfma_frac": round(tf / peak_tf, 4), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
