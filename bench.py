@@ -79,6 +79,34 @@ def conv_bytes_per_pair(size, elem, dim=128):
     return 2 * tot
 
 
+def wino_exec_flops(kind, B, D, H, W, ci, co):
+    """Matrix flops a Winograd launch EXECUTES: 2 * 64 products per 2x2x2 tile, input and output channel, over the PADDED bricks
+    (forward / data gradient: 4x8x8 voxels = 32 tiles per brick; weight gradient: 4x4x8 half bricks = 16 tiles)."""
+    if kind == "wgrad":
+        return 2.0 * 64 * ci * co * 16 * B * -(-D // 4) * -(-H // 4) * -(-W // 8)
+    return 2.0 * 64 * ci * co * 32 * B * -(-D // 4) * -(-H // 8) * -(-W // 8)
+
+
+def exec_flops_per_pair(size, wino, dim=128, streams=2):
+    """EXECUTED matrix flops fwd+bwd per pair: the algorithmic count of conv_flops_per_pair with the Cin > 1 3x3x3 layers
+    priced by wino_exec_flops where the step runs them in the Winograd form (wino: 0 never, 1 data gradients, 2 + forward,
+    3 + weight gradients) — the denominator of `executed_mfma_frac` for the whole step."""
+    q, h, d, d2 = dim // 4, dim // 2, dim, dim * 2
+    layers = [(1, q, 3, 0), (q, q, 3, 1), (q, h, 3, 1), (h, h, 3, 2), (h, d, 3, 2), (d, d2, 3, 3), (d2, d, 1, 3)]
+    dims = (size, size, size) if isinstance(size, int) else tuple(size)
+    tot = 0.0
+    for i, (ci, co, k, lvl) in enumerate(layers):
+        D, H, W = (e >> lvl for e in dims)
+        f = 2.0 * ci * co * k ** 3 * D * H * W
+        if i == 0 or k == 1:
+            tot += f * (2 if i == 0 else 3)
+            continue
+        tot += wino_exec_flops("fwd", 1, D, H, W, ci, co) if wino >= 2 else f
+        tot += wino_exec_flops("dgrad", 1, D, H, W, co, ci) if wino >= 1 else f
+        tot += wino_exec_flops("wgrad", 1, D, H, W, ci, co) if wino >= 3 else f
+    return streams * tot
+
+
 def _pmc_traffic(kernel, precision, storage, B, vol):
     """HBM bytes per launch of a kernel instance from the committed rocprofv3 --pmc passes (counters cannot be read
     live): profiles/r03_pmc_traffic.json = {"precision|storage|B|DxHxW": {kernel instance: {"hbm_bytes_per_launch": ...}}};
@@ -128,6 +156,8 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
     output voxel; tensors read + written once, at the storage width the step really uses)."""
     dim = 128
     rows = []
+    # the forward / data-gradient kernel the library's default takes (conv3d_wino.hip: the persistent one-wave-per-SIMD form)
+    wino_fwd_name = "conv3d_wino_p_kernel" if os.environ.get("TMF_WINO_P", "1") != "0" else "conv3d_wino_kernel"
     b16 = precision == "bf16"
     s16 = b16 and storage == "bf16"
     adt = torch.bfloat16 if s16 else torch.float32
@@ -161,10 +191,10 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             wino = ops.conv_wino_mode() if precision == "fp32" else 0       # as the step runs them (snet_path.hip make_plan)
             if wino >= 2 and ops.wino_ok(ci, co):
                 uf, _ = ops.pack_weights_wino(w, True, False)
-                fns = (("fwd", "conv3d_wino_kernel<1>", lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
+                fns = (("fwd", wino_fwd_name + "<1>", lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
             if wino >= 1 and ops.wino_ok(co, ci):
                 _, ud = ops.pack_weights_wino(w, False, True)
-                fns = (fns[0], ("dgrad", "conv3d_wino_kernel<0>", lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
+                fns = (fns[0], ("dgrad", wino_fwd_name + "<0>", lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
             if wino >= 3 and ops.wgrad_wino_ok(ci, co):
                 fns = fns[:2] + (("wgrad", "conv3d_wino_wgrad_kernel", lambda: ops.conv3d_wgrad_wino(x, dz, ci, co)),)
             if precision == "fp32x":      # forward / data gradient as the step runs them: six bf16 partial products per fp32 product
@@ -178,9 +208,9 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             # of 4x8x8 voxels, padded); the direct kernels execute the algorithmic count
             ex = fl
             if kern.startswith("conv3d_wino_wgrad"):
-                ex = 2.0 * 64 * ci * co * 16 * B * -(-D // 4) * -(-H // 4) * -(-W // 8)
+                ex = wino_exec_flops("wgrad", B, D, H, W, ci, co)
             elif kern.startswith("conv3d_wino"):
-                ex = 2.0 * 64 * ci * co * 32 * B * -(-D // 4) * -(-H // 8) * -(-W // 8)
+                ex = wino_exec_flops(pas, B, D, H, W, ci, co)
             rows.append(dict(layer=name, **{"pass": pas}, kernel=kern, ms=ms, flops=fl, bytes=by, exec_flops=ex))
         del x, dz, w, wf, wd
     # fused first block: statistics + normalise/pool forward, backward reduce + weight gradient (z never stored)
@@ -204,12 +234,15 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
     return rows
 
 
-def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes_pair, B, vol):
-    """Fold the per-launch rows into the bench line's `roofline` object:
+def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes_pair, B, vol, exec_gf_pair=None):
+    """Fold the per-launch rows into the bench line's `roofline` object.  Every `frac` / `achieved` / `mfma_frac` is PHYSICAL:
+    the matrix flops the launches EXECUTE against the matrix peak (<= 1 by construction); the SURVEY 8d figure (algorithmic
+    flops: 2*27*Cin*Cout per output voxel, which a Winograd launch reaches with 64/216 of the products) sits beside it as
+    `algorithmic_*`.
       * main entry  = the time-dominant kernel instance of a step (all of its launches, FLOP-weighted);
       * step_conv   = FLOP-weighted over EVERY conv launch of one step (both encoders);
-      * whole_step  = the train step itself (pairs/s x algorithmic figure per pair) against both ceilings;
-      * best_launch = the single best launch (what round 1 quoted);  layers = the full table."""
+      * whole_step  = the train step itself (pairs/s x figure per pair) against both ceilings;
+      * best_launch = the single best launch;  layers = the full table."""
     peak_tf = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
     groups = {}
     for r in rows:
@@ -222,81 +255,94 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
     dom_name, dom = max(((k, g) for k, g in groups.items() if not k.startswith("conv1_fused_kernel<0..3>")),
                         key=lambda kv: kv[1]["ms"])
 
-    def entry(fl, by, ms):
-        tf, gbs = fl / ms / 1e9, by / ms / 1e6
-        t_mfma, t_hbm = fl / peak_tf / 1e9, by / PEAK_HBM_GBS / 1e6            # ms at either ceiling
-        return tf, gbs, ("mfma" if t_mfma >= t_hbm else "hbm")
-    tf, gbs, bound = entry(dom["flops"], dom["bytes"], dom["ms"])
+    def fracs(ex, fl, by, ms):
+        """executed TF, its fraction, algorithmic TF, its fraction, GB/s, its fraction"""
+        return (ex / ms / 1e9, ex / ms / 1e9 / peak_tf, fl / ms / 1e9, fl / ms / 1e9 / peak_tf, by / ms / 1e6, by / ms / 1e6 / PEAK_HBM_GBS)
+    etf, efr, atf, afr, gbs, hfr = fracs(dom["exec_flops"], dom["flops"], dom["bytes"], dom["ms"])
+    bound = "mfma" if dom["exec_flops"] / peak_tf / 1e9 >= dom["bytes"] / PEAK_HBM_GBS / 1e6 else "hbm"     # ms at either ceiling
     tot_ms = sum(r["ms"] for r in rows)
     tot_fl = sum(r["flops"] for r in rows)
+    tot_ex = sum(r.get("exec_flops", r["flops"]) for r in rows)
     tot_by = sum(r["bytes"] for r in rows)
-    best = max((r for r in rows if r["layer"] != "conv1.0"), key=lambda r: r["flops"] / r["ms"])
+    best = max((r for r in rows if r["layer"] != "conv1.0"), key=lambda r: r.get("exec_flops", r["flops"]) / r["ms"])
     traffic = _pmc_traffic(dom_name, precision, storage, B, vol)
+
+    def kern_entry(g):
+        e = fracs(g["exec_flops"], g["flops"], g["bytes"], g["ms"])
+        return {"launches_per_encoder_step": g["launches"], "ms": round(g["ms"], 4), "avg_launch_ms": round(g["ms"] / g["launches"], 4),
+                "tflops": round(e[0], 1), "mfma_frac": round(e[1], 4), "algorithmic_tflops": round(e[2], 1),
+                "algorithmic_frac": round(e[3], 4), "hbm_frac": round(e[5], 4)}
     roof = {
         "bound": bound,
         "kernel": dom_name,
         "scope": f"all {dom['launches']} launches of the time-dominant kernel instance in one encoder's train step "
                  f"({', '.join(dom['members'])}); B={B}, volume {'x'.join(map(str, vol))}",
-        "achieved": round(tf if bound == "mfma" else gbs, 2),
+        "achieved": round(etf if bound == "mfma" else gbs, 2),
         "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
         "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-        "frac": round((tf / peak_tf) if bound == "mfma" else (gbs / PEAK_HBM_GBS), 4),
+        "frac": round(efr if bound == "mfma" else hfr, 4),
         "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
         "traffic_note": None if traffic is None else f"{traffic.get('note')} [{traffic.get('source')}]",
         "launch_ms": round(dom["ms"] / dom["launches"], 4),
         "launch_note": ("a weight-gradient op is the kernel named here + its tmf_slab_reduce launch(es) (+ wino_wgrad_finish_kernel for "
                         "the Winograd form): launch_ms times the op; in a rocprofv3 --stats summary the rows of those kernels add up to it"
                         if "wgrad" in dom_name else "one launch of the kernel named here"),
+        "executed_flops_per_launch": dom["exec_flops"] / dom["launches"],
         "algorithmic_flops_per_launch": dom["flops"] / dom["launches"],
         "algorithmic_bytes_per_launch": dom["bytes"] / dom["launches"],
-        "mfma_frac": round(tf / peak_tf, 4), "hbm_frac": round(gbs / PEAK_HBM_GBS, 4),
-        "executed_mfma_frac": round(dom["exec_flops"] / dom["ms"] / 1e9 / peak_tf, 4),
+        "mfma_frac": round(efr, 4), "hbm_frac": round(hfr, 4),
+        "algorithmic_achieved": round(atf, 2), "algorithmic_frac": round(afr, 4),
+        "products_ratio": round(dom["exec_flops"] / dom["flops"], 4),
         "share_of_conv_time": round(dom["ms"] / tot_ms, 3),
-        "kernels": {k: {"launches_per_encoder_step": g["launches"], "ms": round(g["ms"], 4),
-                        "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                        "tflops": round(g["flops"] / g["ms"] / 1e9, 1),
-                        "mfma_frac": round(g["flops"] / g["ms"] / 1e9 / peak_tf, 4),
-                        "executed_mfma_frac": round(g["exec_flops"] / g["ms"] / 1e9 / peak_tf, 4),
-                        "hbm_frac": round(g["bytes"] / g["ms"] / 1e6 / PEAK_HBM_GBS, 4)} for k, g in groups.items()},
+        "kernels": {k: kern_entry(g) for k, g in groups.items()},
         "step_conv": {"what": "FLOP-weighted over every conv launch of one train step (fwd + dgrad + wgrad of the five "
                               "Cin>1 layers + the fused first block; x2 encoders), launches timed back to back",
-                      "ms_per_step": round(2 * tot_ms, 3), "tflops": round(tot_fl / tot_ms / 1e9, 2),
-                      "mfma_frac": round(tot_fl / tot_ms / 1e9 / peak_tf, 4),
-                      "executed_mfma_frac": round(sum(r.get("exec_flops", r["flops"]) for r in rows) / tot_ms / 1e9 / peak_tf, 4),
+                      "ms_per_step": round(2 * tot_ms, 3), "tflops": round(tot_ex / tot_ms / 1e9, 2),
+                      "mfma_frac": round(tot_ex / tot_ms / 1e9 / peak_tf, 4),
+                      "algorithmic_tflops": round(tot_fl / tot_ms / 1e9, 2),
+                      "algorithmic_frac": round(tot_fl / tot_ms / 1e9 / peak_tf, 4),
                       "hbm_frac": round(tot_by / tot_ms / 1e6 / PEAK_HBM_GBS, 4)},
         "best_launch": {"layer": best["layer"], "pass": best["pass"], "kernel": best["kernel"],
-                        "ms": round(best["ms"], 4), "tflops": round(best["flops"] / best["ms"] / 1e9, 2),
-                        "mfma_frac": round(best["flops"] / best["ms"] / 1e9 / peak_tf, 4)},
-        "layers": {f"{r['layer']} {r['pass']}": {"ms": round(r["ms"], 4), "tflops": round(r["flops"] / r["ms"] / 1e9, 1),
-                                                 "mfma_frac": round(r["flops"] / r["ms"] / 1e9 / peak_tf, 3),
+                        "ms": round(best["ms"], 4), "tflops": round(best.get("exec_flops", best["flops"]) / best["ms"] / 1e9, 2),
+                        "mfma_frac": round(best.get("exec_flops", best["flops"]) / best["ms"] / 1e9 / peak_tf, 4),
+                        "algorithmic_frac": round(best["flops"] / best["ms"] / 1e9 / peak_tf, 4)},
+        "layers": {f"{r['layer']} {r['pass']}": {"ms": round(r["ms"], 4),
+                                                 "tflops": round(r.get("exec_flops", r["flops"]) / r["ms"] / 1e9, 1),
+                                                 "mfma_frac": round(r.get("exec_flops", r["flops"]) / r["ms"] / 1e9 / peak_tf, 3),
+                                                 "algorithmic_frac": round(r["flops"] / r["ms"] / 1e9 / peak_tf, 3),
                                                  "hbm_frac": round(r["bytes"] / r["ms"] / 1e6 / PEAK_HBM_GBS, 3)}
                    for r in rows},
+        "peak_note": ("frac = achieved / peak with achieved = executed_flops_per_launch x launches / (launch_ms x launches): the matrix "
+                      "flops the launches EXECUTE.  A direct kernel executes the algorithmic count (SURVEY.md 8d: 2*27*Cin*Cout per "
+                      "output voxel); a Winograd F(2x2x2, 3x3x3) launch (conv3d_wino_*: exact-fp32 arithmetic on the same fp32 matrix "
+                      "pipe) executes 2*64*Cin*Cout per 2x2x2 tile over its PADDED bricks (4x8x8 voxels forward / data gradient, 4x4x8 "
+                      "weight gradient) — products_ratio of the algorithmic count; `algorithmic_*` is the 8d figure over the same time "
+                      "(may exceed 1 for a Winograd launch).  Reproduce from a rocprofv3 --kernel-trace --stats summary of "
+                      "`bench.py --roofline-only`: executed_flops_per_launch / AverageNs of the kernel named here / peak"),
     }
-    if any(k.startswith("conv3d_wino") for k in groups):
-        roof["peak_note"] = ("`achieved` / `frac` / `mfma_frac` are ALGORITHMIC flops (SURVEY.md 8d: 2*27*Cin*Cout per output voxel) "
-                             "against the fp32-MFMA peak; the launches named conv3d_wino_kernel / conv3d_wino_wgrad_kernel run the "
-                             "Winograd form F(2x2x2, 3x3x3) — 64 instead of 216 products per 2x2x2 tile, exact-fp32 arithmetic on the "
-                             "same matrix pipe — so their algorithmic figures may exceed 1; `executed_mfma_frac` prices the matrix "
-                             "flops a launch really executes against the same peak (always < 1)")
     if precision == "fp32x":
-        roof["peak_note"] = ("opt-in mode: fractions are ALGORITHMIC fp32 flops against the fp32-MFMA peak (157.3 TF); the "
-                             "forward / data-gradient kernel evaluates every fp32 product as six bf16 partial products, its own "
-                             f"ceiling is the bf16 peak / 6 = {PEAK_BF16_MFMA_TFLOPS / 6:.1f} TF, so its entries may exceed 1")
+        roof["peak_note"] = ("opt-in mode: the forward / data-gradient kernel evaluates every fp32 product as six bf16 partial products on "
+                             f"the bf16 matrix cores (its own ceiling: bf16 peak / 6 = {PEAK_BF16_MFMA_TFLOPS / 6:.1f} TF); fractions price "
+                             "the fp32 products against the fp32-MFMA peak (157.3 TF) and may exceed 1 for that kernel")
     if pairs_per_s is not None:
-        roof["whole_step"] = whole_step_entry(pairs_per_s, world, gf_pair, bytes_pair, precision)
+        roof["whole_step"] = whole_step_entry(pairs_per_s, world, gf_pair, bytes_pair, precision, exec_gf_pair)
     return roof
 
 
-def whole_step_entry(pairs_per_s, world, gf_pair, bytes_pair, precision):
-    """The train step itself against both ceilings: units/s per GPU x the algorithmic figure per unit."""
+def whole_step_entry(pairs_per_s, world, gf_pair, bytes_pair, precision, exec_gf_pair=None):
+    """The train step itself against both ceilings: units/s per GPU x the figure per unit — executed matrix flops (mfma_frac,
+    <= 1) and the algorithmic SURVEY.md 8d figure beside it."""
     peak_tf = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
     per_gpu = pairs_per_s / world
+    ex = gf_pair if exec_gf_pair is None else exec_gf_pair
     return {
-        "what": "the train step itself: pairs/s per GPU x algorithmic figure per pair (SURVEY.md 8d)",
-        "conv_tflops": round(per_gpu * gf_pair / 1e12, 2), "mfma_frac": round(per_gpu * gf_pair / 1e12 / peak_tf, 4),
+        "what": "the train step itself: pairs/s per GPU x figure per pair (executed matrix flops; algorithmic = SURVEY.md 8d)",
+        "conv_tflops": round(per_gpu * ex / 1e12, 2), "mfma_frac": round(per_gpu * ex / 1e12 / peak_tf, 4),
+        "algorithmic_tflops": round(per_gpu * gf_pair / 1e12, 2), "algorithmic_frac": round(per_gpu * gf_pair / 1e12 / peak_tf, 4),
         "hbm_GBps": round(per_gpu * bytes_pair / 1e9, 1), "hbm_frac": round(per_gpu * bytes_pair / 1e9 / PEAK_HBM_GBS, 4),
+        "executed_GFLOP_per_pair": round(ex / 1e9, 2),
         "algorithmic_GFLOP_per_pair": round(gf_pair / 1e9, 2), "algorithmic_GB_per_pair": round(bytes_pair / 1e9, 3),
-        "bound": "mfma" if gf_pair / peak_tf / 1e12 >= bytes_pair / PEAK_HBM_GBS / 1e9 else "hbm"}
+        "bound": "mfma" if ex / peak_tf / 1e12 >= bytes_pair / PEAK_HBM_GBS / 1e9 else "hbm"}
 
 
 def build_parser():
@@ -350,7 +396,7 @@ def build_parser():
 # default flags on one GPU (so that the driver's one run witnesses them): name -> argument overrides.
 ALSO = (
     ("configs[2]: 128^3, batch 8, bf16 MFMA 3D conv + bf16 activation storage",
-     dict(precision="bf16", storage="bf16", size=128, batch=8, model="ad", cpu_batch=2)),
+     dict(precision="bf16", storage="bf16", size=128, batch=8, model="ad", cpu_batch=2, also_kernel_roofline=True)),
     ("configs[4]: model_CNN_ad (dual-modality reading of --model CNN), batch 16, 96^3, fp32",
      dict(model="cnn", batch=16, cpu_batch=2)),
     ("configs[4]: model_single (MRI-only reading), batch 16, 96^3, fp32",
@@ -532,12 +578,40 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
         torch.cuda.synchronize()
 
     gate_gpu = None
+    gate_train = None
     if want_gate:
         net.eval()
         with torch.no_grad():
             lo_g, _dm_g, _dp_g = net(mri0, pet0)
             gate_gpu = (lo_g.cpu(), crit(lo_g, label0).item())
         net.train()
+        # train-mode gate (the metric is fwd + bwd): the FIRST train step on the initial parameters — forward, the reference's
+        # loss, backward through the very kernels the timed steps run — with fc_cls's two Dropout(0.5) keep-masks fixed to a
+        # regenerable pattern (RandomState(99), the pattern of the golden fixtures) so that the CPU leg below can repeat it
+        inner = net.module if hasattr(net, "module") else net
+        rs_m = np.random.RandomState(99)
+        keep = (rs_m.rand(B, 512) >= 0.5, rs_m.rand(B, 64) >= 0.5)
+
+        class _FixedMask(nn.Module):
+            def __init__(self, m):
+                super().__init__()
+                self.m = torch.from_numpy(m).float().to(dev)
+
+            def forward(self, x):
+                return x * self.m * 2.0
+
+            def tmf_keep_mask(self, training):      # lets model_ad take its one-launch heads with this fixed mask
+                return self.m * 2.0 if training else None
+        drops = (inner.fc_cls[3], inner.fc_cls[7])
+        inner.fc_cls[3], inner.fc_cls[7] = _FixedMask(keep[0]), _FixedMask(keep[1])
+        net.zero_grad(set_to_none=True)
+        lo_t, dm_t, dp_t = net(mri0, pet0)
+        loss_t = crit(lo_t, label0) + (crit(dm_t, ones) + crit(dp_t, zeros)) / 2
+        loss_t.backward()
+        gate_train = (lo_t.detach().cpu(), loss_t.item(), inner.mri_cnn.conv2[3].weight.grad.detach().cpu().clone(), keep)
+        net.zero_grad(set_to_none=True)
+        inner.fc_cls[3], inner.fc_cls[7] = drops
+        inner.load_state_dict({k: v.to(dev) for k, v in gate_state.items()})     # BatchNorm buffers back to the initial state
     loss = torch.zeros((), device=dev)
     if args.roofline_only:
         args.warmup, args.steps = 0, 0
@@ -613,23 +687,27 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
     # ---- roofline: every conv launch of a step timed live (HIP events on the launching stream), folded into the
     # time-dominant kernel instance (main entry), the FLOP-weighted step figure, and the whole-step fractions ----
     roof = None
-    gf_pair = conv_flops_per_pair(vol) * (0.5 if args.model == "single" else 1.0)
-    by_pair = conv_bytes_per_pair(vol, 2 if args.storage == "bf16" else 4) * (0.5 if args.model == "single" else 1.0)
+    half = 0.5 if args.model == "single" else 1.0
+    gf_pair = conv_flops_per_pair(vol) * half
+    by_pair = conv_bytes_per_pair(vol, 2 if args.storage == "bf16" else 4) * half
+    # executed matrix flops per pair: the Winograd layers at 64 products per tile in the fp32 mode; the bf16 / fp32x modes run the
+    # direct form (fp32x: six bf16 partial products per fp32 product, priced as ONE fp32 product each — see peak_note)
+    ex_pair = exec_flops_per_pair(vol, args.conv_wino if args.precision == "fp32" else 0) * half
     if rank == 0 and not args.eval:
-        if brief:
-            roof = {"whole_step": whole_step_entry(pairs_per_s, world, gf_pair, by_pair, args.precision)}
-            if args.precision == "fp32" and args.conv_wino:
-                roof["peak_note"] = ("ALGORITHMIC fp32 flops against the fp32-MFMA peak (157.3 TF); forward / data-gradient "
-                                     "convolutions in the Winograd form execute 64/216 of them")
+        if brief and not getattr(args, "also_kernel_roofline", False):
+            roof = {"whole_step": whole_step_entry(pairs_per_s, world, gf_pair, by_pair, args.precision, ex_pair)}
             if args.precision == "fp32x":
-                roof["peak_note"] = ("fractions are ALGORITHMIC fp32 flops against the fp32-MFMA peak (157.3 TF); the forward / "
+                roof["peak_note"] = ("fractions price fp32 products against the fp32-MFMA peak (157.3 TF); the forward / "
                                      "data-gradient kernel of this mode runs on the bf16 matrix cores (six partial products)")
         else:
             _spin_up(dev, float(os.environ.get("TMF_ROOF_SPIN_S", "0.5")))
             rows = measure_conv_launches(ops, _lib, dev, B, vol, args.precision, args.storage,
                                          reps=int(os.environ.get("TMF_ROOF_REPS", "10")))
             roof = roofline_report(rows, args.precision, args.storage, pairs_per_s if args.steps > 0 else None, world, gf_pair,
-                                   by_pair, B, vol)
+                                   by_pair, B, vol, ex_pair)
+            if brief:                       # an `also` record carries the dominant-kernel entry, not the full tables
+                for k in ("layers", "kernels", "best_launch"):
+                    roof.pop(k, None)
 
     cpu = None
     gate = None
@@ -663,9 +741,25 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
                 loss_c = torch.nn.functional.cross_entropy(lo_c, label0.cpu()).item()
             dl = (gate_gpu[0] - lo_c).abs().max().item()
             gate = {"what": "eval-mode forward of the product at the bench's initial parameters and inputs vs the CPU oracle "
-                            "(BASELINE.md section 3; the train-mode gates with injected Dropout masks are tests/test_gpu_model.py)",
+                            "(BASELINE.md section 3); `train`: the first train step (forward + reference loss + backward) with fixed "
+                            "fc_cls keep-masks vs the oracle's train step on the same inputs, parameters and masks",
                     "max_abs_dlogits": dl, "abs_dloss": abs(gate_gpu[1] - loss_c), "gpu_loss": gate_gpu[1], "cpu_loss": loss_c,
                     "tolerance": 1e-3, "pass": bool(dl <= 1e-3 and abs(gate_gpu[1] - loss_c) <= 1e-3)}
+            if gate_train is not None:
+                lo_t, loss_t, gw_t, keep = gate_train
+                S_tr = O.to_state({k: v.numpy() for k, v in gate_state.items()}, spec, requires_grad=True)
+                lo_c, dm_c, dp_c = O.model_ad_forward(S_tr, mri0.cpu(), pet0.cpu(), train=True,
+                                                      dropout_masks=(torch.from_numpy(keep[0]), torch.from_numpy(keep[1])))
+                loss_tc = O.adversarial_loss(lo_c, dm_c, dp_c, label0.cpu())
+                loss_tc.backward()
+                gw_c = S_tr["mri_cnn.conv2.3.weight"].grad
+                dlt = (lo_t - lo_c.detach()).abs().max().item()
+                gerr = ((gw_t - gw_c).abs().max() / gw_c.abs().max()).item()
+                gate["train"] = {"max_abs_dlogits": dlt, "abs_dloss": abs(loss_t - loss_tc.item()), "gpu_loss": loss_t,
+                                 "cpu_loss": loss_tc.item(), "conv2.3_weight_grad_rel_to_max": gerr,
+                                 "tolerance": {"logits": 1e-3, "loss": 1e-3, "weight_grad_rel_to_max": 2e-2},
+                                 "pass": bool(dlt <= 1e-3 and abs(loss_t - loss_tc.item()) <= 1e-3 and gerr <= 2e-2)}
+                gate["pass"] = bool(gate["pass"] and gate["train"]["pass"])
         unit_txt = "volumes" if args.model == "single" else "pairs"
         cpu = {"value": round(cpu_batch / sec, 4), "unit": "volumes/s" if args.model == "single" else "volume-pairs/s",
                "cores": threads, "kind": "port",
@@ -722,7 +816,8 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
                    "setup_steps_untimed": setup_steps,
                    "per_step_timing": "ms_per_step = wall clock of the K steps / K (the contract); _min / _median from one HIP "
                                       "event per step boundary on the issuing stream"},
-        "conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
+        "conv_tflops_whole_step": round(pairs_per_s / world * (ex_pair if not args.eval else gf) / 1e12, 2),
+        "algorithmic_conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
         "loss": round(final_loss, 6),
         "roofline": roof, "cpu_baseline": cpu,
     }

@@ -55,11 +55,14 @@ def _worker(rank, world, port, out_dir):
     net = GradAllReduce(_build(), bucket_mb=0.05)
     net.train()
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
-    for _ in range(2):                       # second pass: bucket reset, set_to_none grads, stream reuse
+    order = []
+    for _ in range(3):                       # later passes: bucket reset, set_to_none grads, stream reuse
         opt.zero_grad()
         _loss(net, rank).backward()
+        order.append((list(net.last_reduced_kinds), list(net.last_reduced_bytes)))
     torch.cuda.synchronize()
     torch.save([p.grad.cpu() for p in net.parameters()], os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save(order, os.path.join(out_dir, f"order{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,6 +79,11 @@ def test_two_ranks_one_gpu_gradient_average(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     got = [torch.load(tmp_path / f"rank{r}.pt") for r in range(world)]
+    # the ORDER of the collectives (kind and byte count of every all-reduce, in launch order) is what a 1-rank RCCL group
+    # cannot check: it must be the same on both ranks and from step to step, or the ranks would pair different buffers
+    order = [torch.load(tmp_path / f"order{r}.pt") for r in range(world)]
+    assert order[0] == order[1], (order[0], order[1])
+    assert order[0][0] == order[0][1] == order[0][2] and len(order[0][0][0]) >= 5, order[0]
     local = []
     for r in range(world):
         net = _build().train()
@@ -179,6 +187,42 @@ def test_wrapper_reduces_the_flat_buffers_in_place(tmp_path):
         if dist.is_initialized():
             dist.destroy_process_group()
         os.environ.pop("TMF_DDP_FORCE", None)
+
+
+def test_two_forwards_before_one_backward_are_refused(tmp_path):
+    """Two forwards before one backward: every whole-pass node produces a second gradient for parameters whose buffer is
+    already with the collective (AccumulateGrad would add into a buffer RCCL is reducing).  The wrapper refuses the pattern
+    when the backward starts — on the in-place path and on the end-of-backward path alike — and recovers for the next step."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", TMF_DDP_FORCE="1")
+    try:
+        from transmf_ad_amd.parallel import GradAllReduce
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        ref = _build().train()
+        _loss(ref, 0).backward()
+        torch.cuda.synchronize()
+        for inplace in ("1", "0"):
+            os.environ["TMF_DDP_INPLACE"] = inplace
+            net = GradAllReduce(_build(), bucket_mb=64.0).train()
+            with pytest.raises(RuntimeError, match="one forward per backward"):
+                (_loss(net, 0) + _loss(net, 1)).backward()
+            torch.cuda.synchronize()
+            net.zero_grad()
+            _loss(net, 0).backward()                             # a plain step afterwards is reduced as usual
+            torch.cuda.synchronize()
+            assert not net.unreduced_gradients()
+            assert (net.last_reduced_kinds.count("event") == 2) == (inplace == "1"), net.last_reduced_kinds
+            for (n, p), q in zip(net.module.named_parameters(), ref.parameters()):
+                assert torch.equal(p.grad, q.grad), (inplace, n)
+        # a backward over a graph built from the INNER module is not reduced, and the wrapper can tell
+        net.zero_grad()
+        net(*(torch.from_numpy(a).to("cuda:0") for a in P.make_inputs(2, SIZE, seed=3)[:2]))       # a forward through the wrapper ...
+        _loss(net.module, 0).backward()                                                           # ... but the graph of the inner one
+        assert net.unreduced_gradients()
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        os.environ.pop("TMF_DDP_FORCE", None)
+        os.environ.pop("TMF_DDP_INPLACE", None)
 
 
 def _nccl_one_rank_worker(_rank, port, out_dir, full):

@@ -79,7 +79,22 @@ def _worker(rank, world, port, out_dir):
     opt.zero_grad(set_to_none=False)
     O.adversarial_loss(*net(mri, pet), y).backward()
     g3 = [p.grad.clone() for p in m.ps]
-    torch.save(dict(grads=grads, p0=m.ps[0].detach().clone(), g2=g2, g3=g3), os.path.join(out_dir, f"rank{rank}.pt"))
+    # the collectives of a step: same kinds and byte counts, in the same order, on every rank and in every step
+    order3 = (list(net.last_reduced_kinds), list(net.last_reduced_bytes))
+    # two forwards before one backward are refused (both ranks raise: nothing is left half-reduced); a forward whose graph is
+    # simply dropped is fine, and the step after a refusal is reduced as usual
+    refused = False
+    opt.zero_grad()
+    try:
+        (O.adversarial_loss(*net(mri, pet), y) + O.adversarial_loss(*net(mri, pet), y)).backward()
+    except RuntimeError as e:
+        refused = "one forward per backward" in str(e)
+    opt.zero_grad()
+    net(mri, pet)                                                   # dropped graph
+    O.adversarial_loss(*net(mri, pet), y).backward()
+    g4 = [p.grad.clone() for p in m.ps]
+    torch.save(dict(grads=grads, p0=m.ps[0].detach().clone(), g2=g2, g3=g3, g4=g4, refused=refused, order3=order3,
+                    unreduced=net.unreduced_gradients()), os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -108,6 +123,11 @@ def test_two_rank_gradient_average(tmp_path):
     for a, b, c in zip(res[0]["g3"], res[1]["g3"], res[0]["g2"]):
         assert torch.equal(a, b)
         assert (a - c).abs().max() <= 1e-3 * c.abs().max().clamp_min(1e-6)     # same parameters, same data as step 2
+    assert res[0]["refused"] and res[1]["refused"] and not res[0]["unreduced"] and not res[1]["unreduced"]
+    assert res[0]["order3"] == res[1]["order3"] and set(res[0]["order3"][0]) == {"bucket"}
+    for a, b, c in zip(res[0]["g4"], res[1]["g4"], res[0]["g2"]):
+        assert torch.equal(a, b)
+        assert (a - c).abs().max() <= 1e-3 * c.abs().max().clamp_min(1e-6)
 
 
 def _plan_worker(rank, world, port, out_dir):

@@ -90,9 +90,12 @@ __device__ long long g_wino_blocks[8192 * 4];
 __device__ long long g_wino_phases[8 * 64];
 #define TRB(i, v) do { if (blockIdx.y == 0 && tid == 0 && blockIdx.x < 8192) g_wino_blocks[blockIdx.x * 4 + (i)] = (v); } while (0)
 #define TRP(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 1500 && blockIdx.y == 0 && lane == 0) g_wino_phases[wave * 64 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+// persistent kernel: phases of the SECOND item of one workgroup (steady state of the stream)
+#define TRQ(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 77 && it == 1 && lane == 0) g_wino_phases[wave * 64 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define TRB(i, v)
 #define TRP(i)
+#define TRQ(i)
 #endif
 
 // MODE 0: z only (data gradient, eval-mode z); 1: z + BatchNorm statistic partials (train forward); 2: the eval-mode block in
@@ -434,6 +437,550 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The same convolution as ONE WAVE PER SIMD and a persistent workgroup (conv3d_wino_p_kernel<MODE>; round 5).
+// Why: on gfx950 the fp32 matrix instructions execute on the vector ALU itself — a partner wave's VALU / LDS instructions
+// do not run beside them, they wait (tools/microbench/valu_cost.hip: a wave that only transforms beside a wave that only
+// multiplies costs BOTH, +35 % on the multiplier for 2 VALU per MFMA, where the same instructions interleaved in the
+// multiplying wave itself cost +9 %), so the half-period stagger of the kernel above hides nothing, and with one workgroup
+// per CU its prologue / epilogue (8 000 of 33 000 cycles per brick with all arithmetic removed) are exposed.  Here:
+//   * 4 waves, wave = pd (the d position of the 4x4x4 transformed tile): 16 positions x 32 tiles x 32 output channels =
+//     256 accumulator registers per lane (the AGPR half of the 512-register budget of a lone wave);
+//   * the workgroup walks a strided list of (brick, channel group) items as ONE continuous stream of 8-channel chunks:
+//     the halo of chunk g + 2 is in flight (LDS-DMA, two buffers), the A operands of chunk g + 1 are transformed and its
+//     weights loaded while chunk g is multiplied — across item boundaries too, so only the first item of a workgroup
+//     pays a prologue;
+//   * a chunk is two phases of 32 MFMAs: P0 multiplies the positions ph 1, 2 (they need only the halo rows 1, 2:
+//     u1 + u2, u2 - u1) while the rows 0, 3 are read and turned into ph 0, 3 (u0 - u2, u1 - u3); P1 multiplies ph 0, 3
+//     while the rows 1, 2 of the NEXT chunk are transformed — no second copy of the A operands, 32 ds_read_b128 and 96
+//     packed adds per 64 MFMAs (the two-waves-per-SIMD kernel: 64 and 128);
+//   * the transformed weights go global -> registers (one buffer_load_dwordx4 per position and chunk: the 16 bytes of a
+//     lane are its B operand of the four K steps), a phase ahead: no LDS traffic for them at all;
+//   * epilogue: w and h output transforms in registers (all 16 positions of a pd are in the wave), one 64 KB exchange
+//     for the d transform, stores and BatchNorm partials as above.
+#ifndef WINO_P_LATE_DMA
+#define WINO_P_LATE_DMA 0
+#endif
+#ifndef P_BSTAGE
+#define P_BSTAGE 2
+#endif
+#ifndef P_ABL               // timing ablations (tools/build_variant.py --flags=-DP_ABL=n; results are wrong with any bit set):
+#define P_ABL 0             // 1 no input transform, 2 no weight loads, 4 no halo copies, 8 no epilogue, 16 no MFMAs
+#endif
+static_assert(SLOTS / 256 == 6, "the vmcnt(6) of the late-copy form counts the six halo copies of a wave");
+constexpr int PN = 256;                                           // threads: 4 waves, wave = pd
+constexpr int PDMA = SLOTS / PN;                                  // 6 LDS-DMA instructions per wave and chunk
+constexpr int P_EX_OFF = 2 * RAW_BYTES;                           // bytes; exchange [pd 4][r pair 8][ho 2][lane 64] x 16 B
+constexpr int P_EX_BYTES = 4 * 8 * 2 * 64 * 16;
+constexpr int P_RED_OFF = P_EX_OFF + P_EX_BYTES;                  // statistic scratch [which 2][source 32][33] floats
+constexpr int P_TAB_OFF = P_RED_OFF + 2 * 32 * 33 * 4 + 64;             // item table [P_TAB] x 2 int4: {brick, channel group, sample, bd | bh << 10 | bw << 20},
+                                                                  // {halo corner byte offset, valid h | w << 16 coordinate mask, valid d range lo | hi << 8, -}
+constexpr int P_TAB = 768;                                        // items per workgroup and launch
+constexpr size_t P_LDS_BYTES = (size_t)P_TAB_OFF + P_TAB * 32;    // 145 KB
+
+__device__ __forceinline__ void bload16(f32x4& dst, int voff, i32x4 rsrc, int soff) {
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+// the loads above are invisible to the compiler's wait-count pass: the kernel waits itself (vmcnt(0)) and then re-defines
+// the registers, so that every use is ordered behind the wait
+__device__ __forceinline__ void bpin(f32x4 (&b)[8]) {
+    asm volatile("" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]));
+}
+
+// Packed fp32 adds as opaque instructions: beside MFMAs the compiler splits <2 x float> arithmetic into scalar instructions
+// (a post-RA peephole written for the bf16 matrix pipe, where VALU instructions run beside the matrix unit).  The fp32 matrix
+// instructions run ON the vector ALU and a lone wave issues one instruction per ~5 cycles: a packed add costs the matrix stream
+// what a scalar one costs (tools/microbench/valu_cost.hip: 5.4 against 5.3 cycles), i.e. half per channel.
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {          // a * b + c
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// one accumulator element AGPR -> VGPR, in program order (left to the compiler, the copies of all 256 elements are hoisted to
+// the top of the epilogue and the next item's operands are spilled to make room)
+__device__ __forceinline__ float acc_read(float a) {
+    float v;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+    return v;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
+    const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ z, float* __restrict__ stat_partial,
+    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int item0, int nitems,
+    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr, float slope = 0.f, int pool = 0) {
+    constexpr bool STATS = MODE == 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* ex = smem + P_EX_OFF / 4;
+    float* red = smem + P_RED_OFF / 4;
+    i32x4* tab = reinterpret_cast<i32x4*>(smem + P_TAB_OFF / 4);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int nchunk = Cin / CK;
+    constexpr int OOB = (int)0x80000000u;
+
+    // ---- this workgroup's items: item0 + jb + i G; within a window of G consecutive items every XCD (blockIdx % 8) takes a
+    // contiguous range (neighbouring bricks share their halo in that XCD's L2) ----
+    const int G = gridDim.x;
+    const int jb = (G & 7) == 0 ? (blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int my_items = jb < nitems ? (nitems - jb + G - 1) / G : 0;
+    if (my_items == 0) return;
+    for (int i = tid; i < my_items; i += PN) {
+        const int item = item0 + jb + i * G;
+        const int ng = item / nbricks;
+        int t = item - ng * nbricks;
+        const int brick = t;
+        const int bw = t % tilesW; t /= tilesW;
+        const int bh = t % tilesH; t /= tilesH;
+        const int bd = t % tilesD;
+        tab[2 * i] = i32x4{brick, ng, t / tilesD, bd | (bh << 10) | (bw << 20)};
+        // the halo of this brick: byte offset of its voxel (0, 0, 0) = (d0 - 1, h0 - 1, w0 - 1) in the sample (negative at the faces)
+        // and the valid coordinates [lo, hi) per axis (the volume's faces and a ragged last brick cut them)
+        const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
+        const int lo_d = d0 == 0 ? 1 : 0, hi_d = D - d0 + 1 < HD ? D - d0 + 1 : HD;
+        const int lo_h = h0 == 0 ? 1 : 0, hi_h = H - h0 + 1 < HH ? H - h0 + 1 : HH;
+        const int lo_w = w0 == 0 ? 1 : 0, hi_w = W - w0 + 1 < HW ? W - w0 + 1 : HW;
+        tab[2 * i + 1] = i32x4{(((d0 - 1) * H + (h0 - 1)) * W + (w0 - 1)) * Cin * 4,
+                               (((1 << hi_h) - 1) & ~((1 << lo_h) - 1)) | ((((1 << hi_w) - 1) & ~((1 << lo_w) - 1)) << 16), lo_d | (hi_d << 8), 0};
+    }
+    __syncthreads();
+    const int total = my_items * nchunk;                    // chunks of the whole stream
+
+    // ---- halo staging (the slot map of the kernel above): DMA instruction q of wave w fills the slots (q * 4 + w) * 64 + lane ----
+    // Per lane and instruction only what does not depend on the brick: the voxel's offset from the halo's corner and one-hot masks
+    // of its halo h / w coordinates; the brick's part sits in the item table; per item (dma_plan: every instruction of a lone wave
+    // is ~5 matrix cycles) the lanes outside the volume get the out-of-range offset by one AND + compare per copy.
+    const int sr = lane >> 1, sbb = sr / 6, sc = sr % 6;
+    const int squad = (lane & 1) ^ (sbb & 1);
+    const bool sreal = sbb < 5 && sc < 5;
+    int hrel[PDMA], hoff[PDMA];
+    int hmask[4];                                           // [h parity][w parity]: bit hh | bit (16 + hw); a padding slot: a bit no brick has
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) hmask[pp] = sreal ? (1 << (2 * sbb + (pp >> 1))) | (1 << (16 + 2 * sc + (pp & 1))) : (1 << 30);
+#pragma unroll
+    for (int q = 0; q < PDMA; ++q) {
+        const int g32 = q * 4 + wave, par = g32 / 3, a = g32 % 3;
+        const int hd = 2 * a + (par >> 2), hh = 2 * sbb + ((par >> 1) & 1), hw = 2 * sc + (par & 1);
+        hrel[q] = (((hd * H + hh) * W + hw) * Cin + squad * 4) * 4;
+    }
+    i32x4 xr;
+    int dm_i = 0, dm_c = 0;                                 // the (item, chunk) the next halo copy belongs to
+    auto dma_plan = [&](int i) {
+        const i32x4 e1 = tab[2 * i + 1];
+        const int b = __builtin_amdgcn_readfirstlane(tab[2 * i][2]);
+        const int corner = __builtin_amdgcn_readfirstlane(e1[0]), vm = __builtin_amdgcn_readfirstlane(e1[1]);
+        const int dr = __builtin_amdgcn_readfirstlane(e1[2]), lo_d = dr & 255, hi_d = dr >> 8;
+        xr = make_rsrc(x + (size_t)b * D * H * W * Cin, (unsigned)(D * H * W * Cin * 4));
+#pragma unroll
+        for (int q = 0; q < PDMA; ++q) {
+            const int g32 = q * 4 + wave, par = g32 / 3, a = g32 % 3;
+            const int hd = 2 * a + (par >> 2);
+            const int m = hmask[par & 3];
+            const int off = hrel[q] + corner;               // (absolute and non-negative where valid: the range check sees vector + scalar offset)
+            hoff[q] = (hd >= lo_d && hd < hi_d && (m & vm) == m) ? off : OOB;
+#if P_ABL & 32          // timing only: 8 / 16 cache lines per copy instruction instead of 32 (contiguous 1 KB / 16 x 64 B pieces)
+            hoff[q] = (q * 4 + wave) * 1024 + lane * 16;
+#elif P_ABL & 64
+            hoff[q] = ((q * 4 + wave) * 16 + (lane >> 2)) * Cin * 4 + (lane & 3) * 16;
+#endif
+        }
+    };
+    auto dma_issue = [&](int buf) {                         // halo of (dm_i, dm_c) -> buffer buf; advance the cursor
+        const unsigned base = lds0 + buf * RAW_BYTES + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < ((P_ABL & 4) ? 0 : PDMA); ++q) blds16(hoff[q], xr, dm_c * (CK * 4), base + q * 4096);
+        if (++dm_c == nchunk) {
+            dm_c = 0;
+            if (++dm_i < my_items) dma_plan(dm_i);
+        }
+    };
+
+    // ---- transformed weights: position p = (pd * 4 + ph) * 4 + pw, chunk c, channel group n0 -> this lane's 16 bytes ----
+    const i32x4 ur = make_rsrc(u, (unsigned)(64 * Cin * Cout * 4));
+    const int b_lane = (hsel * Cout + l31) * 16;
+    f32x4 B12[8], B03[8];                                   // [ph slot][pw]: ph 1, 2 / ph 0, 3
+    auto load_b = [&](f32x4 (&b)[8], int pha, int phb, int c, int n0) {
+        if (P_ABL & 2) return;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bload16(b[k], b_lane, ur, ((((wave * 4 + pha) * 4 + k) * nchunk + c) * 2 * Cout + n0) * 16);
+            bload16(b[4 + k], b_lane, ur, ((((wave * 4 + phb) * 4 + k) * nchunk + c) * 2 * Cout + n0) * 16);
+        }
+    };
+
+    // ---- input transform of this wave's pd: planes da, db (d row of B^T), all four h rows and w columns ----
+    const int da = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int db = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sgn = wave == 1 ? 1.f : -1.f;
+    const int td = l31 >> 4, th = (l31 >> 2) & 3, tw = l31 & 3;
+    const int g0 = td * 32 + th * 6 + tw;
+    const int e0 = hsel ^ (th & 1);
+    auto row_base = [&](int dd, int i) { return (2 * (g0 + ogd(dd) + ogh(i)) + (e0 ^ (i >> 1))) * 4; };
+    int rba[4], rbb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { rba[i] = row_base(da, i); rbb[i] = row_base(db, i); }
+    f32x4 A[16];                                            // [ph][pw]
+    f32x2 u1l[4], u1h[4], u2l[4], u2h[4];                   // the w-transformed rows 1, 2 (channels 0-1 / 2-3), kept for ph 0, 3
+    const f32x2 s2 = {sgn, sgn};
+    auto wrow = [&](const float* R, int i, f32x2 (&lo)[4], f32x2 (&hi)[4]) {      // h row i: d combination, then the w transform
+        f32x2 tl[4], th2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&R[rba[i] + ogw(k) * 8]), bq = *reinterpret_cast<const f32x4*>(&R[rbb[i] + ogw(k) * 8]);
+            tl[k] = f32x2{a[0], a[1]} + s2 * f32x2{bq[0], bq[1]};
+            th2[k] = f32x2{a[2], a[3]} + s2 * f32x2{bq[2], bq[3]};
+        }
+        lo[0] = tl[0] - tl[2]; lo[1] = tl[1] + tl[2]; lo[2] = tl[2] - tl[1]; lo[3] = tl[1] - tl[3];
+        hi[0] = th2[0] - th2[2]; hi[1] = th2[1] + th2[2]; hi[2] = th2[2] - th2[1]; hi[3] = th2[1] - th2[3];
+    };
+    auto pack4 = [](f32x2 l, f32x2 h) { return f32x4{l[0], l[1], h[0], h[1]}; };
+    // The transform of a phase is cut into four stages, one per group of 8 MFMAs (the compiler's scheduler is fenced between the
+    // groups: left alone it gathers the 32 MFMAs of a phase behind the barrier and waits for the LDS in front of it):
+    //   stage 0 reads one h row (8 ds_read_b128), stage 1 combines / transforms it and reads the second row, stages 2, 3 finish.
+    f32x4 ra[4], rb[4];                                     // the row in flight: planes da / db, the four w taps
+    auto row_read = [&](const float* R, int i) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ra[k] = *reinterpret_cast<const f32x4*>(&R[rba[i] + ogw(k) * 8]);
+            rb[k] = *reinterpret_cast<const f32x4*>(&R[rbb[i] + ogw(k) * 8]);
+        }
+    };
+    auto row_xform = [&](f32x2 (&lo)[4], f32x2 (&hi)[4]) {  // d combination, then the w transform
+        f32x2 tl[4], th2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tl[k] = pk_fma(s2, f32x2{rb[k][0], rb[k][1]}, f32x2{ra[k][0], ra[k][1]});
+            th2[k] = pk_fma(s2, f32x2{rb[k][2], rb[k][3]}, f32x2{ra[k][2], ra[k][3]});
+        }
+        lo[0] = pk_sub(tl[0], tl[2]); lo[1] = pk_add(tl[1], tl[2]); lo[2] = pk_sub(tl[2], tl[1]); lo[3] = pk_sub(tl[1], tl[3]);
+        hi[0] = pk_sub(th2[0], th2[2]); hi[1] = pk_add(th2[1], th2[2]); hi[2] = pk_sub(th2[2], th2[1]); hi[3] = pk_sub(th2[1], th2[3]);
+    };
+    f32x2 vl[4], vh[4];
+    // (the stage results are pinned where they are computed: they are used a barrier later, and the optimiser sinks pure
+    // arithmetic into the block of its first use otherwise — out of the MFMA shadow it was placed in)
+    auto pin2 = [](f32x2 (&a)[4], f32x2 (&b)[4]) {
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+    };
+    auto pin4 = [](f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); };
+    auto T1 = [&](int buf, int stage) {                     // rows 1, 2 -> ph 1 = u1 + u2, ph 2 = u2 - u1
+        if (P_ABL & 1) return;
+        const float* R = smem + buf * (RAW_BYTES / 4);
+        if (stage == 0) row_read(R, 1);
+        if (stage == 1) { row_xform(u1l, u1h); row_read(R, 2); pin2(u1l, u1h); }
+        if (stage == 2) { row_xform(u2l, u2h); pin2(u2l, u2h); }
+        if (stage == 3) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                A[4 + k] = pack4(pk_add(u1l[k], u2l[k]), pk_add(u1h[k], u2h[k]));
+                A[8 + k] = pack4(pk_sub(u2l[k], u1l[k]), pk_sub(u2h[k], u1h[k]));
+            }
+            pin4(A[4], A[5], A[6], A[7]);
+            pin4(A[8], A[9], A[10], A[11]);
+        }
+    };
+    auto T2 = [&](int buf, int stage) {                     // rows 0, 3 -> ph 0 = u0 - u2, ph 3 = u1 - u3
+        if (P_ABL & 1) return;
+        const float* R = smem + buf * (RAW_BYTES / 4);
+        if (stage == 0) row_read(R, 0);
+        if (stage == 1) {
+            row_xform(vl, vh);
+            row_read(R, 3);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) A[k] = pack4(pk_sub(vl[k], u2l[k]), pk_sub(vh[k], u2h[k]));
+            pin4(A[0], A[1], A[2], A[3]);
+        }
+        if (stage == 2) { row_xform(vl, vh); pin2(vl, vh); }
+        if (stage == 3) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) A[12 + k] = pack4(pk_sub(u1l[k], vl[k]), pk_sub(u1h[k], vh[k]));
+            pin4(A[12], A[13], A[14], A[15]);
+        }
+    };
+
+    f32x16 acc[16];
+    // 8 MFMAs: K step s (channels s and 4 + s of the chunk) of the phase's 8 positions — every accumulator once per group, so a
+    // dependent pair is 8 instructions apart
+    auto mfma_k = [&](int pha, int phb, const f32x4 (&b)[8], int s, auto first_c) {
+        constexpr bool FIRST = decltype(first_c)::value;
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#if P_ABL & 16
+            if (FIRST && s == 0) { acc[pha * 4 + k] = zero; acc[phb * 4 + k] = zero; }
+            acc[pha * 4 + k][s] += A[pha * 4 + k][s] * b[k][s]; acc[phb * 4 + k][s] += A[phb * 4 + k][s] * b[4 + k][s];
+#else
+            acc[pha * 4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[pha * 4 + k][s], b[k][s], (FIRST && s == 0) ? zero : acc[pha * 4 + k], 0, 0, 0);
+            acc[phb * 4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[phb * 4 + k][s], b[4 + k][s], (FIRST && s == 0) ? zero : acc[phb * 4 + k], 0, 0, 0);
+#endif
+        }
+    };
+
+    // store side of the epilogue (reader lanes: channel quad lane & 7, wo = lane >> 3 & 1, tile w = lane >> 4; tile d = wave >> 1,
+    // tile h = 2 (wave & 1) + j): this lane's byte offset inside a brick
+    const int st_lane = ((((2 * (wave >> 1)) * H + 4 * (wave & 1)) * W + 2 * (lane >> 4) + ((lane >> 3) & 1)) * Cout + 4 * (lane & 7)) * 4;
+    // ---- prologue of the stream: two halos in flight, the first weights, the first half transform ----
+    dma_plan(0);
+    dma_issue(0);
+    if (total > 1) dma_issue(1);
+    int ci_n0;                                              // channel group of the item being multiplied
+    {
+        const i32x4 e = tab[0];
+        ci_n0 = __builtin_amdgcn_readfirstlane(e[1]) * 32;
+    }
+    load_b(B12, 1, 2, 0, ci_n0);
+    dma_wait();
+    __syncthreads();
+    bpin(B12);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) T1(0, k);
+
+    int g = 0;                                              // chunk of the stream
+    for (int it = 0; it < my_items; ++it) {
+        const i32x4 ce = tab[2 * it];
+        const int brick = __builtin_amdgcn_readfirstlane(ce[0]), b = __builtin_amdgcn_readfirstlane(ce[2]);
+        const int cpk = __builtin_amdgcn_readfirstlane(ce[3]);
+        const int d0 = (cpk & 1023) * TD, h0 = ((cpk >> 10) & 1023) * TH, w0 = (cpk >> 20) * TW;
+        const int n0 = ci_n0;
+        TRQ(0);
+        auto chunk = [&](int c, auto first_c) {
+            // P0: ph 1, 2 of chunk g; meanwhile rows 0, 3 -> ph 0, 3 and their weights
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (k == P_BSTAGE) load_b(B03, 0, 3, c, n0);       // (half a phase ahead: their registers are free for the row in flight until here)
+                T2(g & 1, k);
+                mfma_k(1, 2, B12, k, first_c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TRQ(1 + 4 * (c & 3));
+            dma_wait();
+            __syncthreads();                                // every wave is done with the halo of chunk g; chunk g + 1's has landed
+            TRQ(2 + 4 * (c & 3));
+            bpin(B03);
+#if !WINO_P_LATE_DMA
+            if (dm_i < my_items) dma_issue(g & 1);          // halo of chunk g + 2
+#endif
+            // (behind the last chunk of the stream the "next chunk" is a repeat of valid addresses: its transform and weights are never used)
+            bool dma_now = false;
+            int nc = c + 1;
+            if (nc == nchunk) {
+                nc = 0;
+                const i32x4 e = tab[2 * (it + 1 < my_items ? it + 1 : it)];
+                ci_n0 = __builtin_amdgcn_readfirstlane(e[1]) * 32;
+            }
+            // P1: ph 0, 3 of chunk g; meanwhile rows 1, 2 of chunk g + 1 -> its ph 1, 2
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                __builtin_amdgcn_sched_barrier(0);
+#if WINO_P_LATE_DMA
+                // the halo of chunk g + 2 goes out BEHIND the weights of chunk g + 1: the wait at the end of this phase (the weights)
+                // then leaves the six copies in flight (the counter retires in order), they have until the next barrier
+                if (k == 2) {
+                    load_b(B12, 1, 2, nc, ci_n0);
+                    dma_now = dm_i < my_items;
+                    if (dma_now) dma_issue(g & 1);
+                }
+#else
+                if (k == P_BSTAGE) load_b(B12, 1, 2, nc, ci_n0);
+#endif
+                T1((g + 1) & 1, k);
+                mfma_k(0, 3, B03, k, first_c);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            TRQ(3 + 4 * (c & 3));
+#if WINO_P_LATE_DMA
+            if (dma_now) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else
+#endif
+            dma_wait();
+            TRQ(4 + 4 * (c & 3));
+            bpin(B12);
+            ++g;
+        };
+        chunk(0, std::true_type{});
+        for (int c = 1; c < nchunk; ++c) chunk(c, std::false_type{});
+
+#if P_ABL & 8
+        {
+            float sm = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sm += acc_read(acc[q][0]) + acc_read(acc[q][7]);
+            if (sm == 12345.678f) z[tid] = sm + (float)(b + d0 + h0 + w0 + brick + n0);
+            continue;
+        }
+#endif
+        // ---- output transform: w and h in registers (accumulator-row pairs), d through LDS ----
+        // The exchange is TRANSPOSED on the way: the writer lane (channel l31, row half hsel) stores single floats at
+        // ex[pd][tile][ho][wo][channel]; the reader lane (channel quad cq = lane & 7, wo = lane >> 3 & 1, vq = lane >> 4) reads float4s
+        // of 4 channels for its two tiles 8 w' + 4 j + vq: 16-byte stores to z (8 instead of 32 per lane; one instruction covers 8
+        // consecutive w voxels x 128 bytes) and a conflict-free ds_read_b128 (the two wo rows of a tile are 32 floats apart).
+        {
+            float* exw = ex + (wave * 32 + 4 * hsel) * 128 + l31;        // accumulator row r -> tile (r & 3) + 8 (r >> 2) + 4 hsel
+#pragma unroll
+            for (int rp = 0; rp < 8; ++rp) {
+                f32x2 y[4][2];
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    f32x2 m[4];
+#pragma unroll
+                    for (int pw = 0; pw < 4; ++pw) m[pw] = f32x2{acc_read(acc[ph * 4 + pw][2 * rp]), acc_read(acc[ph * 4 + pw][2 * rp + 1])};
+                    y[ph][0] = (m[0] + m[1]) + m[2];
+                    y[ph][1] = (m[1] - m[2]) - m[3];
+                }
+#pragma unroll
+                for (int ho = 0; ho < 2; ++ho)
+#pragma unroll
+                    for (int wo = 0; wo < 2; ++wo) {
+                        const f32x2 pv = ho == 0 ? (y[0][wo] + y[1][wo]) + y[2][wo] : (y[1][wo] - y[2][wo]) - y[3][wo];
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int r = 2 * rp + e, trow = (r & 3) + 8 * (r >> 2);
+                            exw[((trow * 2 + ho) * 2 + wo) * 32] = pv[e];
+                        }
+                    }
+                __builtin_amdgcn_sched_barrier(0);          // (one row pair at a time: the next item's operands stay in registers)
+            }
+        }
+        TRQ(20);
+        __syncthreads();
+        TRQ(21);
+        // reader: out[do 0] = S_0 + S_1 + S_2, out[do 1] = S_1 - S_2 - S_3 over the four pd
+        const int cq = lane & 7, rwo = (lane >> 3) & 1, vq = lane >> 4;
+        f32x4 outv[2][2][2];                                // [j][ho][do]: tile 8 w' + 4 j + vq, channels 4 cq .. 4 cq + 3
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ho = 0; ho < 2; ++ho) {
+                f32x4 S[4];
+#pragma unroll
+                for (int pd = 0; pd < 4; ++pd)
+                    S[pd] = *reinterpret_cast<const f32x4*>(&ex[((((pd * 32 + 8 * wave + 4 * j + vq) * 2 + ho) * 2 + rwo) * 32) + 4 * cq]);
+                outv[j][ho][0] = (S[0] + S[1]) + S[2];
+                outv[j][ho][1] = (S[1] - S[2]) - S[3];
+            }
+        TRQ(22);
+        // tile 8 w' + 4 j + vq: tile d = w' >> 1, tile h = 2 (w' & 1) + j, tile w = vq
+        const int co = n0 + 4 * cq;
+        const int gdb = d0 + 2 * (wave >> 1), ghb = h0 + 4 * (wave & 1), gw = w0 + 2 * vq + rwo;
+        if constexpr (MODE == 2) {
+            f32x4 sc, sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { sc[e] = aff_scale[co + e]; sh[e] = aff_shift[co + e]; }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ho = 0; ho < 2; ++ho)
+#pragma unroll
+                    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y = outv[j][ho][dd][e] * sc[e] + sh[e];
+                            outv[j][ho][dd][e] = y > 0.f ? y : y * slope;
+                        }
+            if (pool == TMF_POOL_MAX2) {
+                const int OD = D / 2, OH = H / 2, OW = W / 2;
+                float* yb = z + (size_t)b * OD * OH * OW * Cout;
+                const int od = gdb >> 1, ow = (w0 >> 1) + vq;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {                  // the window = the tile: d and h pairs in this lane, the w pair in lane ^ 8
+                    f32x4 m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = fmaxf(fmaxf(outv[j][0][0][e], outv[j][0][1][e]), fmaxf(outv[j][1][0][e], outv[j][1][1][e]));
+                        m[e] = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)));       // row_ror:8 = lane ^ 8
+                    }
+                    const int oh = (ghb >> 1) + j;
+                    if (rwo == 0 && od < OD && oh < OH && ow < OW) *reinterpret_cast<f32x4*>(&yb[((size_t)(od * OH + oh) * OW + ow) * Cout + co]) = m;
+                }
+            } else {
+                float* yb = z + (size_t)b * D * H * W * Cout;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ho = 0; ho < 2; ++ho)
+#pragma unroll
+                        for (int dd = 0; dd < 2; ++dd) {
+                            const int gd = gdb + dd, gh = ghb + 2 * j + ho;
+                            if (gd < D && gh < H && gw < W) *reinterpret_cast<f32x4*>(&yb[((size_t)(gd * H + gh) * W + gw) * Cout + co]) = outv[j][ho][dd];
+                        }
+            }
+        } else {
+            float* zb = z + (size_t)b * D * H * W * Cout;
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, D * H * W * Cout * 4, 0x00020000);
+            const bool full = d0 + TD <= D && h0 + TH <= H && w0 + TW <= W;
+            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2q = {0.f, 0.f, 0.f, 0.f};
+            // address = this lane's part (st_lane: tile and channel quad, fixed for the kernel) + the brick's corner and the row
+            // (d, h) of the store in the scalar offset: one s_add per store
+            const int st_item = (((d0 * H + h0) * W + w0) * Cout + n0) * 4;
+            auto put = [&](auto full_c) {
+                constexpr bool FULL = decltype(full_c)::value;
+                const bool w_ok = FULL || gw < W;
+                const int voff = w_ok ? st_lane : OOB;
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int ho = 0; ho < 2; ++ho)
+#pragma unroll
+                        for (int dd = 0; dd < 2; ++dd) {
+                            const int gd = gdb + dd, gh = ghb + 2 * j + ho;                    // (wave-uniform)
+                            const bool row_ok = FULL || (gd < D && gh < H);
+                            f32x4 v = outv[j][ho][dd];
+                            if (row_ok)
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tmf_u32x4, v), zr, voff, st_item + (dd * H + 2 * j + ho) * W * Cout * 4, 0);
+                            if (STATS) {
+                                if (!FULL) v = (row_ok && w_ok) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+                                s1 += v;
+                                s2q += v * v;
+                            }
+                        }
+            };
+            if (full) put(std::true_type{});
+            else put(std::false_type{});
+            TRQ(23);
+            if constexpr (STATS) {
+                if (stat_partial != nullptr) {
+                    // per-channel sums over the brick: every lane leaves its 4 + 4 partial sums in LDS, [which][source 32][channel 32 + 1]
+                    // (source = wave * 8 + lane >> 3); thread (which, channel, part) adds 8 sources in a fixed order and a quad of
+                    // lanes adds its four parts with two DPP steps — 24 ds_bpermute round trips were 1 100 cycles here
+                    {
+                        const int src = wave * 8 + (lane >> 3);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            red[src * 33 + 4 * cq + e] = s1[e];
+                            red[(32 + src) * 33 + 4 * cq + e] = s2q[e];
+                        }
+                    }
+                    __syncthreads();
+                    {
+                        const int part = tid & 3, ch = (tid >> 2) & 31, which = tid >> 7;
+                        float a = 0.f;
+#pragma unroll
+                        for (int m = 0; m < 8; ++m) a += red[(which * 32 + part * 8 + m) * 33 + ch];
+                        a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+                        a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+                        if (part == 0) stat_partial[((size_t)brick * 2 + which) * Cout + n0 + ch] = a;
+                    }
+                }
+            }
+        }
+        TRQ(24);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Weight gradient in the Winograd form.  y = A^T [(G g) .* (B^T d)] gives  dL/d(G g)_p = (B^T d)_p (A dy)_p: per position p of
 // the 4x4x4 transformed tile a plain product of the TRANSFORMED INPUT V (the forward's own input transform) and the
 // transformed output gradient Z = A dz A^T (1-D: z0 = y0, z1 = y0 + y1, z2 = y0 - y1, z3 = -y1), summed over all tiles:
@@ -704,8 +1251,55 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 }
 
 int g_conv_wino = -1;
+int g_wino_p = -1;          // forward / data gradient: 1 the persistent one-wave-per-SIMD kernel (default), 0 the two-waves-per-SIMD one
+
+int wino_p_mode() {
+    if (g_wino_p < 0) {
+        const char* e = getenv("TMF_WINO_P");
+        g_wino_p = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return g_wino_p;
+}
+
+int wino_cu_count() {
+    static thread_local int n[16] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 16) dev = 0;
+    if (n[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev] = v;
+    }
+    return n[dev];
+}
+
+template <int MODE>
+int launch_wino_p(const char* what, const float* x, const float* u, float* z, float* stat_partial, int B, int D, int H, int W,
+                  int cin, int cout, const float* scale, const float* shift, float slope, int pool, hipStream_t stream) {
+    const int tilesD = tmf_cdiv(D, TD), tilesH = tmf_cdiv(H, TH), tilesW = tmf_cdiv(W, TW);
+    TMF_REQUIRE(tilesD < 1024 && tilesH < 1024 && tilesW < 1024, TMF_E_SHAPE, "%s: more than 1023 bricks along one axis", what);
+    const long nbricks = (long)B * tilesD * tilesH * tilesW;
+    const long nitems = nbricks * (cout / 32);
+    TMF_REQUIRE(nitems < (1L << 30), TMF_E_SHAPE, "%s: too many bricks", what);
+    auto k = conv3d_wino_p_kernel<MODE>;
+    int rc;
+    if ((rc = tmf_allow_lds(k, P_LDS_BYTES, what))) return rc;
+    const int ncu = wino_cu_count();
+    const long per_launch = (long)ncu * P_TAB;              // a workgroup's item table holds P_TAB entries
+    for (long i0 = 0; i0 < nitems; i0 += per_launch) {
+        const long n = nitems - i0 < per_launch ? nitems - i0 : per_launch;
+        const int grid = (int)(n < ncu ? n : ncu);
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN), P_LDS_BYTES, stream, x, u, z, stat_partial, D, H, W, cin, cout,
+                           tilesD, tilesH, tilesW, (int)nbricks, (int)i0, (int)n, scale, shift, slope, pool);
+        if ((rc = tmf_launch_result(what))) return rc;
+    }
+    return TMF_OK;
+}
 
 }  // namespace
+
+int tmf_wino_p_set(int v) { g_wino_p = v ? 1 : 0; return TMF_OK; }
 
 #ifdef TMF_WINO_TRACE
 extern "C" int tmf_wino_trace_read(long long* blocks, long long* phases) {
@@ -760,6 +1354,11 @@ extern "C" int tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, flo
                 "tmf_conv3d_fwd_wino: one sample exceeds 2^29 elements (32-bit byte offsets inside a sample)");
     TMF_REQUIRE((long)64 * cin * cout < (1L << 29), TMF_E_SHAPE, "tmf_conv3d_fwd_wino: weight tensor exceeds 2^29 elements");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(u); TMF_REQUIRE_ALIGNED(z);
+    if (wino_p_mode()) {
+        if (stat_partial != nullptr)
+            return launch_wino_p<1>("tmf_conv3d_fwd_wino", x, u, z, stat_partial, B, D, H, W, cin, cout, nullptr, nullptr, 0.f, 0, (hipStream_t)stream);
+        return launch_wino_p<0>("tmf_conv3d_fwd_wino", x, u, z, nullptr, B, D, H, W, cin, cout, nullptr, nullptr, 0.f, 0, (hipStream_t)stream);
+    }
     const int tilesD = tmf_cdiv(D, TD), tilesH = tmf_cdiv(H, TH), tilesW = tmf_cdiv(W, TW);
     const int ntiles = B * tilesD * tilesH * tilesW;
     dim3 grid(ntiles, cout / 32), block(NTHR);
@@ -832,6 +1431,8 @@ extern "C" int tmf_conv3d_fwd_wino_affine(const float* x, const float* u, const 
     TMF_REQUIRE((long)64 * cin * cout < (1L << 29), TMF_E_SHAPE, "tmf_conv3d_fwd_wino_affine: weight tensor exceeds 2^29 elements");
     TMF_REQUIRE_ALIGNED(x); TMF_REQUIRE_ALIGNED(u); TMF_REQUIRE_ALIGNED(y);
     if (pool != TMF_POOL_NONE && (D / 2 == 0 || H / 2 == 0 || W / 2 == 0)) return TMF_OK;      // empty output
+    if (wino_p_mode())
+        return launch_wino_p<2>("tmf_conv3d_fwd_wino_affine", x, u, y, nullptr, B, D, H, W, cin, cout, scale, shift, slope, pool, (hipStream_t)stream);
     const int tilesD = tmf_cdiv(D, TD), tilesH = tmf_cdiv(H, TH), tilesW = tmf_cdiv(W, TW);
     const int ntiles = B * tilesD * tilesH * tilesW;
     auto k = conv3d_wino_kernel<2>;

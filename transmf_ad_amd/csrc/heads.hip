@@ -936,8 +936,11 @@ __global__ __launch_bounds__(256) void dropout_masks_kernel(MaskArgs a) {
         const long nq = (a.seg[s].n + 3) >> 2;
         if (q < nq) {
             unsigned r[4];
+            // key = torch's seed XOR a domain constant: torch / curand put the offset in c0, c1 and the thread in c2, c3 — the other way
+            // round — so with the bare seed as key the two counter spaces would intersect ((q = X, offset = O) here is torch's
+            // thread O at offset 4 X) and mask bits could coincide with numbers another torch kernel draws in the same run
             philox4x32_10((unsigned)q, (unsigned)(q >> 32) ^ ((unsigned)s << 24), (unsigned)a.offset, (unsigned)(a.offset >> 32),
-                          (unsigned)a.seed, (unsigned)(a.seed >> 32), r);
+                          (unsigned)a.seed ^ 0x746D666Du, (unsigned)(a.seed >> 32) ^ 0x6B736D5Fu, r);
             const float thr = a.seg[s].keep * 16777216.0f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -144,3 +144,7 @@ class Adam(torch.optim.Optimizer):
                         self.state[p]["step"] = cnt[2]
                 else:
                     cnt[0], cnt[1] = max(counts), dict(enumerate(counts))
+                    # diverged counts: EVERY parameter gets a step tensor of its own (one that loaded no state would otherwise keep
+                    # the chunk's shared tensor, and step() would advance it once per such parameter)
+                    for p, n in zip(sub, counts):
+                        self.state[p]["step"] = torch.tensor(float(n))

@@ -95,6 +95,12 @@ class GradAllReduce(nn.Module):
 
     >>> net = GradAllReduce(model_ad(...).to(device))      # after dist.init_process_group
     >>> out = net(mri, pet); loss.backward(); optimizer.step()
+
+    The forward MUST go through the wrapper (``net(...)``, not ``net.module(...)``): there are no per-parameter hooks, the
+    end-of-backward reduction is queued by a hook on the wrapper's outputs (or by a whole-pass node reporting its gradient
+    buffer).  A backward over a graph built from the inner module leaves the gradients un-reduced; ``unreduced_gradients()``
+    tells, ``reduce_gradients()`` reduces them explicitly.  ONE forward per backward: a second forward through the wrapper before
+    the backward raises there (the reference's train_step never does it; torch's DDP supports it, this wrapper does not).
     """
 
     def __init__(self, module: nn.Module, process_group=None, bucket_mb: float = 6.0,
@@ -161,6 +167,8 @@ class GradAllReduce(nn.Module):
         self._nodes = {}                        # parameter addresses of a node -> (its Parameters, their view offsets)
         self._covered = set()
         self._checked_steps = 0
+        self._fwd_seq = 0                       # forwards through the wrapper so far; _bw_seq: the one the running backward belongs to
+        self._bw_seq = None
         # RCCL / NCCL average inside the collective (ncclAvg): no division launch afterwards; gloo sums, the wrapper divides
         self._avg = dist.get_backend(process_group) == "nccl" and os.environ.get("TMF_DDP_AVG", "1") != "0"
         self._op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
@@ -192,12 +200,24 @@ class GradAllReduce(nn.Module):
             m = self._by_ptr = {p.data_ptr(): p for p in self._params}
         return m.get(ptr)
 
-    def _on_backward_start(self, _grad):
-        """Tensor hook on the wrapped module's outputs: the first gradient of a backward pass queues the end-of-backward
-        callback.  Nothing else happens per gradient."""
-        if self._live and self.require_sync and not self._callback_queued:
-            self._callback_queued = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
+    def _on_backward_start(self, _grad, seq=None):
+        """Tensor hook on the wrapped module's outputs (tagged with the number of the forward that produced them): the first
+        gradient of a backward pass queues the end-of-backward callback.  Nothing else happens per gradient."""
+        if self._live and self.require_sync:
+            if self._bw_seq is None:
+                self._bw_seq = seq
+            elif seq != self._bw_seq:
+                # Outputs of TWO forwards in one backward: the gradients of the two graphs are summed inside autograd's input
+                # buffers (in place, into the first node's flat buffer where it can) — the in-place path would hand a buffer to RCCL
+                # that is still being added to, and the end-of-backward path was seen to copy stale values on its first use in this
+                # pattern.  Not needed by the reference's train_step (one forward, one backward): refused loudly instead of reduced
+                # wrongly.  (A forward whose graph is simply dropped is fine: its hooks never fire.)
+                raise RuntimeError(
+                    "GradAllReduce: this backward spans two forwards through the wrapper — run one forward per backward "
+                    "(accumulate over micro-batches with zero_grad(set_to_none=False) between complete steps instead)")
+            if not self._callback_queued:
+                self._callback_queued = True
+                torch.autograd.Variable._execution_engine.queue_callback(self._finalize)
         return None
 
     def tmf_flat_grads(self, flat, param_ptrs, views, segments):
@@ -240,8 +260,20 @@ class GradAllReduce(nn.Module):
             return
         # autograd ADOPTS the views only where there is no .grad to accumulate into: zero_grad(set_to_none=False) keeps every
         # .grad, so the first and the last parameter of the node tell (a partly zeroed model takes the error of _finalize)
-        if plist[0].grad is not None or plist[-1].grad is not None or plist[0] in self._covered:
+        if plist[0].grad is not None and plist[0] not in self._covered:
             return                              # accumulation into existing .grad tensors: end-of-backward path
+        if plist[-1].grad is not None and plist[-1] not in self._covered:
+            return
+        if plist[0] in self._covered or plist[-1] in self._covered:
+            # A SECOND gradient for these parameters in ONE backward (a module used twice in one graph; two forwards are refused
+            # earlier, in _on_backward_start): their first buffer is already queued or in flight on the staging stream and
+            # AccumulateGrad is about to add this gradient into it in place on the producing stream — a race with RCCL that would
+            # leave avg(g1) + local g2.  The address check of _finalize cannot see it (in-place accumulation keeps the pointer),
+            # so it is an error here.
+            raise RuntimeError(
+                "GradAllReduce: a whole-pass node produced a second gradient for parameters whose gradient buffer was already "
+                "handed to the collective in this backward (the module is used twice in one graph) — not supported by the "
+                "in-place reduction")
         base = flat.data_ptr()
         params = (plist, offs, base)
         if not self._callback_queued:           # (a backward started from an output the wrapper never saw)
@@ -334,7 +366,23 @@ class GradAllReduce(nn.Module):
         self._finalize_impl()
         _PROF_T.setdefault("finalize", []).append(time.perf_counter() - t0)
 
+    def _reset_backward_state(self):
+        """Forget everything a backward pass left behind (also after one that threw): no stale work handles, no stale set of
+        in-place parameters, and the next backward queues its own end-of-backward callback."""
+        self._inplace = []
+        self._pending = []
+        self._covered = set()
+        self._callback_queued = False
+        self._bw_seq = None
+
     def _finalize_impl(self):
+        try:
+            self._finalize_body()
+            self._finalized_since_forward = True
+        finally:
+            self._reset_backward_state()
+
+    def _finalize_body(self):
         self._callback_queued = False
         first = self._params[0] if self._params else None
         dev = first.device if first is not None else torch.device("cpu")
@@ -399,12 +447,19 @@ class GradAllReduce(nn.Module):
             views = b.views()
             for i, p in todo:
                 p.grad = views[i]
-        self._inplace = []
-        self._covered = set()
 
     def _begin_backward_bookkeeping(self):
+        self._reset_backward_state()            # (a previous backward that threw mid-way must not leak into this one)
+        self._finalized_since_forward = False
         self.last_reduced_bytes = []
         self.last_reduced_kinds = []
+
+    def unreduced_gradients(self):
+        """True when gradients exist that no collective has seen since the last forward through the wrapper — a backward whose
+        graph was built by calling the INNER module (no output hook, no whole-pass node) never queues the end-of-backward
+        reduction.  ``reduce_gradients()`` is the explicit form for such callers; optimizers may assert on this."""
+        return (self._live and self.require_sync and not getattr(self, "_finalized_since_forward", True)
+                and any(p.grad is not None for p in self._params))
 
     def exposed_allreduce_ms(self):
         """Per recorded step: milliseconds between the end of backward's compute and the last collective being done and
@@ -445,9 +500,11 @@ class GradAllReduce(nn.Module):
         out = self.module(*args, **kwargs)
         if self._live and self.require_sync and torch.is_grad_enabled():
             self._begin_backward_bookkeeping()
+            self._fwd_seq += 1
+            seq = self._fwd_seq
             for t in (out if isinstance(out, (tuple, list)) else (out,)):
                 if isinstance(t, torch.Tensor) and t.requires_grad:
-                    t.register_hook(self._on_backward_start)
+                    t.register_hook(lambda g, seq=seq: self._on_backward_start(g, seq))
         return out
 
     def state_dict(self, *args, **kwargs):          # checkpoints interchange with the bare module
