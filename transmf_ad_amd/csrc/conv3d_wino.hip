@@ -457,16 +457,12 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
 //     lane are its B operand of the four K steps), a phase ahead: no LDS traffic for them at all;
 //   * epilogue: w and h output transforms in registers (all 16 positions of a pd are in the wave), one 64 KB exchange
 //     for the d transform, stores and BatchNorm partials as above.
-#ifndef WINO_P_LATE_DMA
-#define WINO_P_LATE_DMA 0
-#endif
 #ifndef P_BSTAGE
 #define P_BSTAGE 2
 #endif
 #ifndef P_ABL               // timing ablations (tools/build_variant.py --flags=-DP_ABL=n; results are wrong with any bit set):
 #define P_ABL 0             // 1 no input transform, 2 no weight loads, 4 no halo copies, 8 no epilogue, 16 no MFMAs
 #endif
-static_assert(SLOTS / 256 == 6, "the vmcnt(6) of the late-copy form counts the six halo copies of a wave");
 constexpr int PN = 256;                                           // threads: 4 waves, wave = pd
 constexpr int PDMA = SLOTS / PN;                                  // 6 LDS-DMA instructions per wave and chunk
 constexpr int P_EX_OFF = 2 * RAW_BYTES;                           // bytes; exchange [pd 4][r pair 8][ho 2][lane 64] x 16 B
@@ -504,6 +500,53 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {          //
     f32x2 d;
     asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
     return d;
+}
+
+// d combination + 1-D input transform of one row of four taps as ONE opaque block: t_k = a_k + s b_k (in place), then
+// u = [t0 - t2, t1 + t2, t2 - t1, t1 - t3].  (Between separate inline-asm instructions that depend on each other the compiler pads
+// with s_nop — an issue slot each, ~5 matrix cycles for a lone wave; inside a block there is nothing to pad: VALU results are
+// interlocked.)
+__device__ __forceinline__ void pk_row4(f32x2 (&u)[4], f32x2 (&a)[4], const f32x2 (&b)[4], f32x2 s) {
+    asm("v_pk_fma_f32 %4, %12, %8, %4\n\t"
+        "v_pk_fma_f32 %5, %12, %9, %5\n\t"
+        "v_pk_fma_f32 %6, %12, %10, %6\n\t"
+        "v_pk_fma_f32 %7, %12, %11, %7\n\t"
+        "v_pk_add_f32 %0, %4, %6 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %5, %6\n\t"
+        "v_pk_add_f32 %2, %6, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %3, %5, %7 neg_lo:[0,1] neg_hi:[0,1]"
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3])
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(s));
+}
+// o = [y0, y0 + y1, y0 - y1, y1] (the 1-D transform of Z without its last sign) for two rows at once
+__device__ __forceinline__ void pk_z2(f32x2& a1, f32x2& a2, f32x2& b1, f32x2& b2, f32x2 ya0, f32x2 ya1, f32x2 yb0, f32x2 yb1) {
+    asm("v_pk_add_f32 %0, %4, %5\n\t"
+        "v_pk_add_f32 %1, %4, %5 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %2, %6, %7\n\t"
+        "v_pk_add_f32 %3, %6, %7 neg_lo:[0,1] neg_hi:[0,1]"
+        : "=&v"(a1), "=&v"(a2), "=&v"(b1), "=&v"(b2) : "v"(ya0), "v"(ya1), "v"(yb0), "v"(yb1));
+}
+// d = a + b and e = a - b for four pairs (the h transform of two positions rows; operands may not alias the results)
+__device__ __forceinline__ void pk_addsub4(f32x2 (&d)[4], f32x2 (&e)[4], const f32x2 (&a)[4], const f32x2 (&b)[4]) {
+    asm("v_pk_add_f32 %0, %8, %12\n\t"
+        "v_pk_add_f32 %1, %9, %13\n\t"
+        "v_pk_add_f32 %2, %10, %14\n\t"
+        "v_pk_add_f32 %3, %11, %15\n\t"
+        "v_pk_add_f32 %4, %8, %12 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %5, %9, %13 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %6, %10, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %7, %11, %15 neg_lo:[0,1] neg_hi:[0,1]"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
+}
+// d = a - b for four pairs
+__device__ __forceinline__ void pk_sub4(f32x2 (&d)[4], const f32x2 (&a)[4], const f32x2 (&b)[4]) {
+    asm("v_pk_add_f32 %0, %4, %8 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %1, %5, %9 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %2, %6, %10 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %3, %7, %11 neg_lo:[0,1] neg_hi:[0,1]"
+        : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]));
 }
 
 // one accumulator element AGPR -> VGPR, in program order (left to the compiler, the copies of all 256 elements are hoisted to
@@ -598,14 +641,21 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
 #endif
         }
     };
-    auto dma_issue = [&](int buf) {                         // halo of (dm_i, dm_c) -> buffer buf; advance the cursor
+    // halo of (dm_i, dm_c) -> buffer buf in three parts of two copies (one part per group of MFMAs: six LDS-DMA instructions back
+    // to back wait for each other in the issue slot); the third part advances the cursor
+    auto dma_part = [&](int buf, int part) {
         const unsigned base = lds0 + buf * RAW_BYTES + wave * 1024;
 #pragma unroll
-        for (int q = 0; q < ((P_ABL & 4) ? 0 : PDMA); ++q) blds16(hoff[q], xr, dm_c * (CK * 4), base + q * 4096);
-        if (++dm_c == nchunk) {
+        for (int q = 0; q < ((P_ABL & 4) ? 0 : PDMA); ++q)
+            if (q / 2 == part) blds16(hoff[q], xr, dm_c * (CK * 4), base + q * 4096);
+        if (part == 2 && ++dm_c == nchunk) {
             dm_c = 0;
             if (++dm_i < my_items) dma_plan(dm_i);
         }
+    };
+    auto dma_issue = [&](int buf) {                         // all of it (prologue)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dma_part(buf, i);
     };
 
     // ---- transformed weights: position p = (pd * 4 + ph) * 4 + pw, chunk c, channel group n0 -> this lane's 16 bytes ----
@@ -658,15 +708,15 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
             rb[k] = *reinterpret_cast<const f32x4*>(&R[rbb[i] + ogw(k) * 8]);
         }
     };
-    auto row_xform = [&](f32x2 (&lo)[4], f32x2 (&hi)[4]) {  // d combination, then the w transform
-        f32x2 tl[4], th2[4];
+    auto row_xform = [&](f32x2 (&lo)[4], f32x2 (&hi)[4]) {  // d combination, then the w transform (channels 0-1 / 2-3 of the quad)
+        f32x2 al[4], ah[4], bl[4], bh[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            tl[k] = pk_fma(s2, f32x2{rb[k][0], rb[k][1]}, f32x2{ra[k][0], ra[k][1]});
-            th2[k] = pk_fma(s2, f32x2{rb[k][2], rb[k][3]}, f32x2{ra[k][2], ra[k][3]});
+            al[k] = f32x2{ra[k][0], ra[k][1]}; ah[k] = f32x2{ra[k][2], ra[k][3]};
+            bl[k] = f32x2{rb[k][0], rb[k][1]}; bh[k] = f32x2{rb[k][2], rb[k][3]};
         }
-        lo[0] = pk_sub(tl[0], tl[2]); lo[1] = pk_add(tl[1], tl[2]); lo[2] = pk_sub(tl[2], tl[1]); lo[3] = pk_sub(tl[1], tl[3]);
-        hi[0] = pk_sub(th2[0], th2[2]); hi[1] = pk_add(th2[1], th2[2]); hi[2] = pk_sub(th2[2], th2[1]); hi[3] = pk_sub(th2[1], th2[3]);
+        pk_row4(lo, al, bl, s2);
+        pk_row4(hi, ah, bh, s2);
     };
     f32x2 vl[4], vh[4];
     // (the stage results are pinned where they are computed: they are used a barrier later, and the optimiser sinks pure
@@ -682,10 +732,13 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
         if (stage == 1) { row_xform(u1l, u1h); row_read(R, 2); pin2(u1l, u1h); }
         if (stage == 2) { row_xform(u2l, u2h); pin2(u2l, u2h); }
         if (stage == 3) {
+            f32x2 sl[4], dl[4], sh[4], dh[4];
+            pk_addsub4(sl, dl, u2l, u1l);                   // ph 1 = u1 + u2, ph 2 = u2 - u1
+            pk_addsub4(sh, dh, u2h, u1h);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                A[4 + k] = pack4(pk_add(u1l[k], u2l[k]), pk_add(u1h[k], u2h[k]));
-                A[8 + k] = pack4(pk_sub(u2l[k], u1l[k]), pk_sub(u2h[k], u1h[k]));
+                A[4 + k] = pack4(sl[k], sh[k]);
+                A[8 + k] = pack4(dl[k], dh[k]);
             }
             pin4(A[4], A[5], A[6], A[7]);
             pin4(A[8], A[9], A[10], A[11]);
@@ -698,14 +751,24 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
         if (stage == 1) {
             row_xform(vl, vh);
             row_read(R, 3);
+            {
+                f32x2 dl[4], dh[4];
+                pk_sub4(dl, vl, u2l);
+                pk_sub4(dh, vh, u2h);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) A[k] = pack4(pk_sub(vl[k], u2l[k]), pk_sub(vh[k], u2h[k]));
+                for (int k = 0; k < 4; ++k) A[k] = pack4(dl[k], dh[k]);
+            }
             pin4(A[0], A[1], A[2], A[3]);
         }
         if (stage == 2) { row_xform(vl, vh); pin2(vl, vh); }
         if (stage == 3) {
+            {
+                f32x2 dl[4], dh[4];
+                pk_sub4(dl, u1l, vl);
+                pk_sub4(dh, u1h, vh);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) A[12 + k] = pack4(pk_sub(u1l[k], vl[k]), pk_sub(u1h[k], vh[k]));
+                for (int k = 0; k < 4; ++k) A[12 + k] = pack4(dl[k], dh[k]);
+            }
             pin4(A[12], A[13], A[14], A[15]);
         }
     };
@@ -770,11 +833,8 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
             __syncthreads();                                // every wave is done with the halo of chunk g; chunk g + 1's has landed
             TRQ(2 + 4 * (c & 3));
             bpin(B03);
-#if !WINO_P_LATE_DMA
-            if (dm_i < my_items) dma_issue(g & 1);          // halo of chunk g + 2
-#endif
+            const bool dma_go = dm_i < my_items;            // halo of chunk g + 2: two copies per group of MFMAs below
             // (behind the last chunk of the stream the "next chunk" is a repeat of valid addresses: its transform and weights are never used)
-            bool dma_now = false;
             int nc = c + 1;
             if (nc == nchunk) {
                 nc = 0;
@@ -785,26 +845,14 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 __builtin_amdgcn_sched_barrier(0);
-#if WINO_P_LATE_DMA
-                // the halo of chunk g + 2 goes out BEHIND the weights of chunk g + 1: the wait at the end of this phase (the weights)
-                // then leaves the six copies in flight (the counter retires in order), they have until the next barrier
-                if (k == 2) {
-                    load_b(B12, 1, 2, nc, ci_n0);
-                    dma_now = dm_i < my_items;
-                    if (dma_now) dma_issue(g & 1);
-                }
-#else
                 if (k == P_BSTAGE) load_b(B12, 1, 2, nc, ci_n0);
-#endif
+                if (k == 0 && dma_go) dma_issue(g & 1);   // (spread over the groups, two copies each, it measured 2 % slower here; the
+                                                          //  weight-gradient kernel's sixteen copies per stage gain 8 % from being spread)
                 T1((g + 1) & 1, k);
                 mfma_k(0, 3, B03, k, first_c);
             }
             __builtin_amdgcn_sched_barrier(0);
             TRQ(3 + 4 * (c & 3));
-#if WINO_P_LATE_DMA
-            if (dma_now) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else
-#endif
             dma_wait();
             TRQ(4 + 4 * (c & 3));
             bpin(B12);
@@ -1138,10 +1186,310 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_wgrad_kernel(
             out[q * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + l31] = acc[q][r];
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The weight gradient as ONE WAVE PER SIMD (conv3d_wino_wgrad_p_kernel; round 5) — the reasons of conv3d_wino_p_kernel:
+// the fp32 matrix instructions run on the vector ALU and a lone wave issues one instruction per ~5 cycles, so what counts is
+// the NUMBER of instructions beside the MFMAs.  The kernel above spends 9.6 of them per MFMA (one channel and one tile per
+// lane and instruction); here:
+//   * 4 waves, wave = pd: 16 positions x 32 ci x 32 co = 256 accumulator registers (AGPRs);
+//   * a lane (channel l31, tile parity hsel) transforms TWO tiles at once — w origins 4 apart, i.e. 512 bytes apart in the
+//     stage buffer: one ds_read2st64_b32 fetches both into a register pair and the transform runs on v_pk_*_f32
+//     (32 + 8 paired reads and ~64 packed adds per 32 MFMAs: 3.3 instructions per MFMA);
+//   * the minus signs of Z = A dz A^T (z3 = -y1 on every axis) are left out of the kernel: position p carries the sign
+//     (-1)^[pd = 3] (-1)^[ph = 3] (-1)^[pw = 3], applied by wino_wgrad_finish_kernel;
+//   * the step of four tiles is two phases of 16 MFMAs: P0 multiplies ph 1, 2 while the rows 0, 3 are read and turned into
+//     ph 0, 3; P1 multiplies ph 0, 3 while the rows 1, 2 of the NEXT step become its ph 1, 2 — no second copy of the operands,
+//     across stage boundaries too (one barrier per stage of 16 tiles, the stage after next in flight by LDS-DMA); every row
+//     is read a group of MFMAs before it is used.
+template <int C>
+__device__ __forceinline__ f32x2 lds_pair(unsigned base_even, unsigned base_odd) {      // floats at 128 C and 128 C + 512 bytes
+    f32x2 d;
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"((C & 1) ? base_odd : base_even), "n"(C >> 1), "n"((C >> 1) + 2));
+    return d;
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(std::integral_constant<int, N - 1>{});
+    }
+}
+constexpr int WPN = 256;                                          // threads: 4 waves, wave = pd
+constexpr int WP_XDMA = WX_SLOTS / WPN, WP_ZDMA = WZ_SLOTS / WPN; // 12 + 4 LDS-DMA instructions per wave and stage
+
+__global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
+    const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
+    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int per_split, int ncob) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hsel = lane >> 5;
+    const int split = blockIdx.x, blk = blockIdx.y;
+    const int ci0 = (blk / ncob) * 32, co0 = (blk % ncob) * 32;
+    const int st0 = split * per_split;
+    const int st1 = st0 + per_split < nbricks ? st0 + per_split : nbricks;
+    constexpr int OOB = (int)0x80000000u;
+
+    // ---- staging plan: per lane and instruction the voxel's offset from the stage's corner and one-hot masks of its coordinates;
+    // per stage one AND + compare + add + select per copy ----
+    int relx[WP_XDMA], mx[WP_XDMA], relz[WP_ZDMA], mz[WP_ZDMA];
+#pragma unroll
+    for (int q = 0; q < WP_XDMA; ++q) {
+        const int e = (q * 4 + wave) * 64 + lane, v = e >> 3, piece = e & 7;
+        const int hd = v / 60, hh = (v / 10) % 6, hw = v % 10;
+        relx[q] = ((hd * H + hh) * W + hw) * Cin * 4 + piece * 16;
+        mx[q] = e < WX_REAL ? (1 << hd) | (1 << (8 + hh)) | (1 << (16 + hw)) : (1 << 30);
+    }
+#pragma unroll
+    for (int q = 0; q < WP_ZDMA; ++q) {
+        const int e = (q * 4 + wave) * 64 + lane, v = e >> 3, piece = e & 7;
+        const int od = v >> 5, oh = (v >> 3) & 3, ow = v & 7;
+        relz[q] = ((od * H + oh) * W + ow) * Cout * 4 + piece * 16;
+        mz[q] = (1 << od) | (1 << (8 + oh)) | (1 << (16 + ow));
+    }
+    // the half brick the next copy belongs to: decoded once (stage_first), then advanced by one (stage_next: no divisions)
+    int sbw = 0, sbh = 0, sbd = 0, sb = 0;
+    auto stage_first = [&](int st) {
+        int t = st;
+        sbw = t % tilesW; t /= tilesW;
+        sbh = t % tilesH; t /= tilesH;
+        sbd = t % tilesD;
+        sb = t / tilesD;
+    };
+    auto stage_next = [&]() {
+        if (++sbw == tilesW) { sbw = 0; if (++sbh == tilesH) { sbh = 0; if (++sbd == tilesD) { sbd = 0; ++sb; } } }
+    };
+    // The 16 copies of a stage go out in four parts of four, one part per phase: sixteen back-to-back LDS-DMA instructions
+    // fill the CU's address queue and every further one waits in the issue slot (the whole plan issued at the barrier cost 15 %
+    // of the kernel).  stage_setup: the scalars of the half brick (sb, sbd, sbh, sbw); stage_part(i): copies 4 i .. 4 i + 3.
+    i32x4 s_xr, s_zr;
+    int s_xcorner = 0, s_zcorner = 0, s_vmx = 0, s_vmz = 0;
+    unsigned s_base = 0;
+    auto stage_setup = [&](int buf) {
+        const int b = sb, d0 = sbd * 4, h0 = sbh * 4, w0 = sbw * 8;
+        s_xr = make_rsrc(x + (size_t)b * D * H * W * Cin, (unsigned)(D * H * W * Cin * 4));
+        s_zr = make_rsrc(dz + (size_t)b * D * H * W * Cout, (unsigned)(D * H * W * Cout * 4));
+        s_xcorner = (((d0 - 1) * H + (h0 - 1)) * W + (w0 - 1)) * Cin * 4 + ci0 * 4;       // (negative at the faces)
+        s_zcorner = ((d0 * H + h0) * W + w0) * Cout * 4 + co0 * 4;
+        auto range = [](int lo, int hi) { return ((1 << hi) - 1) & ~((1 << lo) - 1); };
+        auto mn = [](int a, int b_) { return a < b_ ? a : b_; };
+        s_vmx = range(d0 == 0 ? 1 : 0, mn(6, D - d0 + 1)) | (range(h0 == 0 ? 1 : 0, mn(6, H - h0 + 1)) << 8) |
+                (range(w0 == 0 ? 1 : 0, mn(10, W - w0 + 1)) << 16);
+        s_vmz = range(0, mn(4, D - d0)) | (range(0, mn(4, H - h0)) << 8) | (range(0, mn(8, W - w0)) << 16);
+        s_base = lds0 + buf * WBUF_BYTES + wave * 1024;
+    };
+    auto stage_part = [&](int part) {
+        if (P_ABL & 4) return;
+#pragma unroll
+        for (int q = 0; q < WP_XDMA; ++q)
+            if (q / 4 == part) blds16((mx[q] & s_vmx) == mx[q] ? relx[q] + s_xcorner : OOB, s_xr, 0, s_base + q * 4096);
+#pragma unroll
+        for (int q = 0; q < WP_ZDMA; ++q)
+            if (3 == part) blds16((mz[q] & s_vmz) == mz[q] ? relz[q] + s_zcorner : OOB, s_zr, 0, s_base + WX_SLOTS * 16 + q * 4096);
+    };
+    auto stage_issue = [&](int buf) {               // the whole stage at once (prologue)
+        stage_setup(buf);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) stage_part(i);
+    };
+
+    // ---- this wave's d row of the transforms ----
+    const int da = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
+    const int db = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
+    const float sgn = wave == 1 ? 1.f : -1.f;
+    const f32x2 s2 = {sgn, sgn};
+    const float cz = wave == 1 ? 1.f : (wave == 2 ? -1.f : 0.f);
+    const f32x2 cz2 = {cz, cz};
+    const unsigned zfirst = wave == 3 ? 4 * 8 * 32 * 4 : 0;          // pd 3: the plane do 1 (4 x 8 voxels x 128 bytes further)
+    // LDS byte addresses of this lane's tile pair (w origins 2 hsel and 2 hsel + 4) in buffer 0: x plane da / db and dz
+    // (ds_read2st64 offsets count 256 bytes: the odd 128-byte rows go through a base 128 bytes further)
+    const unsigned lx = lds0 + (2 * hsel * 32 + l31) * 4;
+    const unsigned xa0 = lx + da * 60 * 128, xb0 = lx + db * 60 * 128, zz0 = lx + WX_SLOTS * 16;
+    f32x2 A[16], Bv[16];                            // [ph][pw] -> {tile set 0, tile set 1}
+#if P_ABL & 1
+    for (int i = 0; i < 16; ++i) { A[i] = f32x2{(float)tid, 1.f}; Bv[i] = f32x2{(float)lane, 2.f}; }
+#endif
+    f32x2 u1[4], u2[4], zd[2][2];                   // kept between the two halves of a step: w-transformed rows 1, 2; d-combined dz [ho][wo]
+    f32x16 acc[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+    auto pin4 = [](f32x2& a, f32x2& b, f32x2& c, f32x2& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); };
+    // one h row (2 th + i) of the step (td, th): planes da / db, the four w taps — issued a group of MFMAs ahead of its use
+    // (row_issue), then d combination -> w transform (row_finish).  The reads are opaque to the compiler: wait + pin before use.
+    f32x2 ra[4], rb[4];                             // the row in flight
+    auto row_issue = [&](unsigned ea, unsigned eb, auto c_c) {
+        constexpr int Cb = decltype(c_c)::value;    // row offset in 128-byte units: ((2 td) * 60 + (2 th + i) * 10)
+        static_for<4>([&](auto k_c) {
+            constexpr int K = decltype(k_c)::value;
+            ra[K] = lds_pair<Cb + K>(ea, ea + 128);
+            rb[K] = lds_pair<Cb + K>(eb, eb + 128);
+        });
+    };
+    auto row_finish = [&](f32x2 (&u)[4]) {
+        lds_wait();
+        pin4(ra[0], ra[1], ra[2], ra[3]);
+        pin4(rb[0], rb[1], rb[2], rb[3]);
+        pk_row4(u, ra, rb, s2);
+    };
+    // rows pha, phb of B = [y0, y0 + y1, y0 - y1, y1] each: the 1-D transform of Z without its last sign
+    auto zrows = [&](f32x2 ya0, f32x2 ya1, int pha, f32x2 yb0, f32x2 yb1, int phb) {
+        Bv[pha * 4 + 0] = ya0; Bv[pha * 4 + 3] = ya1; Bv[phb * 4 + 0] = yb0; Bv[phb * 4 + 3] = yb1;
+        pk_z2(Bv[pha * 4 + 1], Bv[pha * 4 + 2], Bv[phb * 4 + 1], Bv[phb * 4 + 2], ya0, ya1, yb0, yb1);
+    };
+    f32x2 yq[2][2][2];                              // dz in flight: [slot][ho][wo]
+    f32x2 v0[4];
+    // T1 (three parts, one per group of MFMAs of the phase it rides under): rows 1, 2 of step (td, th) in buffer `par` -> A, B of
+    // ph 1, 2; keeps u1, u2 and zd for T2.  dz: z_d = y[do 0] | y0 + y1 | y0 - y1 | y[do 1] for pd = 0 .. 3 = first + cz * second,
+    // where pd 3 reads the plane do 1 as its "first" (a wave-uniform address) and cz = 0, 1, -1, 0: no branch
+    auto T1 = [&](int par, auto step_c, int part) {
+        constexpr int STEP = decltype(step_c)::value, TDs = STEP >> 1, THs = STEP & 1;
+        if (P_ABL & 1) return;
+        const unsigned off = par * WBUF_BYTES;
+        if (part == 0) {
+            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * 60 + (2 * THs + 1) * 10>{});
+            static_for<2>([&](auto ho_c) {
+                static_for<2>([&](auto wo_c) {
+                    constexpr int HO = decltype(ho_c)::value, WO = decltype(wo_c)::value;
+                    constexpr int C0 = ((2 * TDs + 0) * 4 + (2 * THs + HO)) * 8 + WO, C1 = ((2 * TDs + 1) * 4 + (2 * THs + HO)) * 8 + WO;
+                    yq[0][HO][WO] = lds_pair<C0>(zz0 + zfirst + off, zz0 + zfirst + off + 128);
+                    yq[1][HO][WO] = lds_pair<C1>(zz0 + off, zz0 + off + 128);
+                });
+            });
+        } else if (part == 1) {
+            row_finish(u1);
+            pin4(yq[0][0][0], yq[0][0][1], yq[0][1][0], yq[0][1][1]);
+            pin4(yq[1][0][0], yq[1][0][1], yq[1][1][0], yq[1][1][1]);
+            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * 60 + (2 * THs + 2) * 10>{});
+#pragma unroll
+            for (int ho = 0; ho < 2; ++ho)
+#pragma unroll
+                for (int wo = 0; wo < 2; ++wo) zd[ho][wo] = pk_fma(cz2, yq[1][ho][wo], yq[0][ho][wo]);
+            {
+                f32x2 zs0, zdf0, zs1, zdf1;             // ho sum / difference per wo
+                pk_z2(zs0, zdf0, zs1, zdf1, zd[0][0], zd[1][0], zd[0][1], zd[1][1]);
+                zrows(zs0, zs1, 1, zdf0, zdf1, 2);
+            }
+            pin4(u1[0], u1[1], u1[2], u1[3]);
+            pin4(Bv[4], Bv[5], Bv[6], Bv[7]); pin4(Bv[8], Bv[9], Bv[10], Bv[11]);
+        } else {
+            row_finish(u2);
+            {
+                f32x2 sm[4], df[4];
+                pk_addsub4(sm, df, u2, u1);             // ph 1 = u1 + u2, ph 2 = u2 - u1
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { A[4 + k] = sm[k]; A[8 + k] = df[k]; }
+            }
+            pin4(A[4], A[5], A[6], A[7]); pin4(A[8], A[9], A[10], A[11]);
+        }
+    };
+    // T2: rows 0, 3 of the same step -> A, B of ph 0, 3
+    auto T2 = [&](int par, auto step_c, int part) {
+        constexpr int STEP = decltype(step_c)::value, TDs = STEP >> 1, THs = STEP & 1;
+        if (P_ABL & 1) return;
+        const unsigned off = par * WBUF_BYTES;
+        if (part == 0) {
+            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * 60 + (2 * THs + 0) * 10>{});
+            zrows(zd[0][0], zd[0][1], 0, zd[1][0], zd[1][1], 3);
+            pin4(Bv[0], Bv[1], Bv[2], Bv[3]); pin4(Bv[12], Bv[13], Bv[14], Bv[15]);
+        } else if (part == 1) {
+            row_finish(v0);
+            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * 60 + (2 * THs + 3) * 10>{});
+            {
+                f32x2 d[4];
+                pk_sub4(d, v0, u2);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) A[k] = d[k];
+            }
+            pin4(A[0], A[1], A[2], A[3]);
+        } else {
+            row_finish(v0);
+            {
+                f32x2 d[4];
+                pk_sub4(d, u1, v0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) A[12 + k] = d[k];
+            }
+            pin4(A[12], A[13], A[14], A[15]);
+        }
+    };
+    // a phase's 16 MFMAs (both tile sets of the 8 positions ph in {pha, phb}) in three groups of 4, 4, 8: part g of the other
+    // half's transform rides under group g
+    auto mfma_g = [&](int pha, int phb, int g) {
+        const int k0 = g == 2 ? 0 : 2 * g, k1 = g == 2 ? 4 : 2 * g + 2, s0 = g == 2 ? 1 : 0;
+#pragma unroll
+        for (int k = k0; k < k1; ++k) {
+#if P_ABL & 16
+            acc[pha * 4 + k][s0] += A[pha * 4 + k][s0] * Bv[pha * 4 + k][s0]; acc[phb * 4 + k][s0] += A[phb * 4 + k][s0] * Bv[phb * 4 + k][s0];
+#else
+            acc[pha * 4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[pha * 4 + k][s0], Bv[pha * 4 + k][s0], acc[pha * 4 + k], 0, 0, 0);
+            acc[phb * 4 + k] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[phb * 4 + k][s0], Bv[phb * 4 + k][s0], acc[phb * 4 + k], 0, 0, 0);
+#endif
+        }
+    };
+
+    if (st0 < st1) {
+        stage_first(st0);
+        stage_issue(0);
+        if (st0 + 1 < st1) { stage_next(); stage_issue(1); }
+        dma_wait();
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 3; ++g) T1(0, std::integral_constant<int, 0>{}, g);
+        bool pend = false;                              // a stage's copies are going out (parts 1 .. 3 in the phases behind the barrier's)
+        for (int st = st0; st < st1; ++st) {
+            const int par = (st - st0) & 1;
+            static_for<4>([&](auto step_c) {
+                constexpr int STEP = decltype(step_c)::value;
+                // P0: ph 1, 2 of this step; meanwhile rows 0, 3 -> ph 0, 3
+                __builtin_amdgcn_sched_barrier(0);
+                if (STEP < 2 && pend) { stage_part(1 + 2 * STEP); if (STEP == 1) pend = false; }
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    T2(par, step_c, g);
+                    mfma_g(1, 2, g);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (STEP == 3) {                        // the last read of this stage's buffer is done
+                    dma_wait();
+                    __syncthreads();                    // every wave is done with stage st; stage st + 1 has landed
+                    if (st + 2 < st1) { stage_next(); stage_setup(par); stage_part(0); pend = true; }
+                }
+                if (STEP == 0 && pend) stage_part(2);
+                // P1: ph 0, 3 of this step; meanwhile rows 1, 2 of the next step (the next stage's first step behind the last one;
+                // behind the last stage the "next step" re-reads valid LDS: its operands are never used)
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    T1(STEP < 3 ? par : par ^ 1, std::integral_constant<int, (STEP + 1) & 3>{}, g);
+                    mfma_g(0, 3, g);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        }
+    }
+
+    // ---- partial slab [split][blk][p][ci 32][co 32]: accumulator row r -> ci = (r & 3) + 8 (r >> 2) + 4 hsel, column co = l31 ----
+    float* out = partial + (((size_t)split * gridDim.y + blk) * 64 + wave * 16) * 1024;
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[q * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + l31] = acc[q][r];
+}
+
 // dU (reduced over the slabs) [blk][p][ci 32][co 32] -> dw = G^T dU G along the three axes, one thread per (ci, co), fp64:
 // 1-D: w0 = u0 + (u1 + u2) / 2, w1 = (u1 - u2) / 2, w2 = (u1 + u2) / 2 + u3.  dw_ref: nn.Conv3d's [co][ci][27], else [27][ci][co].
+// fold_signs: the slabs come from conv3d_wino_wgrad_p_kernel, whose Z transform leaves out the minus of the last row on every
+// axis: position (p, q, r) carries (-1)^[p = 3] (-1)^[q = 3] (-1)^[r = 3].
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ du, float* __restrict__ dw,
-                                                                int cin, int cout, int ncob, int dw_ref) {
+                                                                int cin, int cout, int ncob, int dw_ref, int fold_signs) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= cin * cout) return;
     const int co = e % cout, ci = e / cout;
@@ -1153,7 +1501,10 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) u[p][q][r] = (double)src[((p * 4 + q) * 4 + r) * 1024];
+            for (int r = 0; r < 4; ++r) {
+                const double v = (double)src[((p * 4 + q) * 4 + r) * 1024];
+                u[p][q][r] = (fold_signs && (((p == 3) + (q == 3) + (r == 3)) & 1)) ? -v : v;
+            }
     auto GT = [](double u0, double u1, double u2, double u3, int a) {
         return a == 0 ? u0 + 0.5 * (u1 + u2) : (a == 1 ? 0.5 * (u1 - u2) : 0.5 * (u1 + u2) + u3);
     };
@@ -1404,16 +1755,24 @@ extern "C" int tmf_conv3d_wgrad_wino(const float* x, const float* dz, float* dw,
     float* partial = (float*)workspace;
     const long n = (long)p.nblk * 64 * 1024;
     int rc;
-    auto k = conv3d_wino_wgrad_kernel;
-    if ((rc = tmf_allow_lds(k, WG_LDS_BYTES, "tmf_conv3d_wgrad_wino"))) return rc;
-    hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(NTHR), WG_LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,
-                       p.tilesD, p.tilesH, p.tilesW, p.nbricks, p.per, p.ncob);
+    const int one_wave = wino_p_mode();
+    if (one_wave) {
+        auto k = conv3d_wino_wgrad_p_kernel;
+        if ((rc = tmf_allow_lds(k, WG_LDS_BYTES, "tmf_conv3d_wgrad_wino"))) return rc;
+        hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(WPN), WG_LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,
+                           p.tilesD, p.tilesH, p.tilesW, p.nbricks, p.per, p.ncob);
+    } else {
+        auto k = conv3d_wino_wgrad_kernel;
+        if ((rc = tmf_allow_lds(k, WG_LDS_BYTES, "tmf_conv3d_wgrad_wino"))) return rc;
+        hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(NTHR), WG_LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,
+                           p.tilesD, p.tilesH, p.tilesW, p.nbricks, p.per, p.ncob);
+    }
     if ((rc = tmf_launch_result("tmf_conv3d_wgrad_wino"))) return rc;
     float* scratch = partial + (size_t)p.nsplit * n;
     float* du = scratch + (size_t)tmf_reduce_groups(p.nsplit) * n;
     if ((rc = tmf_reduce_slabs(partial, p.nsplit, n, scratch, du, s, "tmf_conv3d_wgrad_wino(reduce)"))) return rc;
     hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)tmf_cdiv((long)cin * cout, 256L)), dim3(256), 0, s,
-                       (const float*)du, dw, cin, cout, p.ncob, dw_layout == TMF_DW_REFERENCE ? 1 : 0);
+                       (const float*)du, dw, cin, cout, p.ncob, dw_layout == TMF_DW_REFERENCE ? 1 : 0, one_wave);
     return tmf_launch_result("tmf_conv3d_wgrad_wino(finish)");
 }
 
