@@ -79,18 +79,32 @@ def conv_bytes_per_pair(size, elem, dim=128):
     return 2 * tot
 
 
+def _cd(a, b):
+    return -(-a // b)
+
+
+def wino_fwd_bricks(B, D, H, W):
+    """Bricks (32 tiles each) of the Winograd forward / data-gradient launch: 4x8x8 voxels of one sample, or — where that
+    executes fewer tiles, the persistent kernel's choice (csrc/conv3d_wino.hip wino_p_geom) — 4x4x4 voxels of four samples."""
+    b0 = B * _cd(D, 4) * _cd(H, 8) * _cd(W, 8)
+    if os.environ.get("TMF_WINO_P", "1") == "0":
+        return b0
+    b1 = _cd(B, 4) * _cd(D, 4) * _cd(H, 4) * _cd(W, 4)
+    return b1 if b1 < b0 else b0
+
+
 def wino_exec_flops(kind, B, D, H, W, ci, co):
     """Matrix flops a Winograd launch EXECUTES: 2 * 64 products per 2x2x2 tile, input and output channel, over the PADDED bricks
-    (forward / data gradient: 4x8x8 voxels = 32 tiles per brick; weight gradient: 4x4x8 half bricks = 16 tiles)."""
+    (forward / data gradient: 32 tiles per brick, wino_fwd_bricks; weight gradient: 4x4x8 half bricks = 16 tiles)."""
     if kind == "wgrad":
-        return 2.0 * 64 * ci * co * 16 * B * -(-D // 4) * -(-H // 4) * -(-W // 8)
-    return 2.0 * 64 * ci * co * 32 * B * -(-D // 4) * -(-H // 8) * -(-W // 8)
+        return 2.0 * 64 * ci * co * 16 * B * _cd(D, 4) * _cd(H, 4) * _cd(W, 8)
+    return 2.0 * 64 * ci * co * 32 * wino_fwd_bricks(B, D, H, W)
 
 
-def exec_flops_per_pair(size, wino, dim=128, streams=2):
-    """EXECUTED matrix flops fwd+bwd per pair: the algorithmic count of conv_flops_per_pair with the Cin > 1 3x3x3 layers
-    priced by wino_exec_flops where the step runs them in the Winograd form (wino: 0 never, 1 data gradients, 2 + forward,
-    3 + weight gradients) — the denominator of `executed_mfma_frac` for the whole step."""
+def exec_flops_per_pair(size, wino, B, dim=128, streams=2):
+    """EXECUTED matrix flops fwd+bwd per pair at batch B: the algorithmic count of conv_flops_per_pair with the Cin > 1 3x3x3
+    layers priced by wino_exec_flops where the step runs them in the Winograd form (wino: 0 never, 1 data gradients, 2 + forward,
+    3 + weight gradients) — the denominator of the whole step's `mfma_frac`."""
     q, h, d, d2 = dim // 4, dim // 2, dim, dim * 2
     layers = [(1, q, 3, 0), (q, q, 3, 1), (q, h, 3, 1), (h, h, 3, 2), (h, d, 3, 2), (d, d2, 3, 3), (d2, d, 1, 3)]
     dims = (size, size, size) if isinstance(size, int) else tuple(size)
@@ -101,9 +115,9 @@ def exec_flops_per_pair(size, wino, dim=128, streams=2):
         if i == 0 or k == 1:
             tot += f * (2 if i == 0 else 3)
             continue
-        tot += wino_exec_flops("fwd", 1, D, H, W, ci, co) if wino >= 2 else f
-        tot += wino_exec_flops("dgrad", 1, D, H, W, co, ci) if wino >= 1 else f
-        tot += wino_exec_flops("wgrad", 1, D, H, W, ci, co) if wino >= 3 else f
+        tot += wino_exec_flops("fwd", B, D, H, W, ci, co) / B if wino >= 2 else f
+        tot += wino_exec_flops("dgrad", B, D, H, W, co, ci) / B if wino >= 1 else f
+        tot += wino_exec_flops("wgrad", B, D, H, W, ci, co) / B if wino >= 3 else f
     return streams * tot
 
 
@@ -692,7 +706,7 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
     by_pair = conv_bytes_per_pair(vol, 2 if args.storage == "bf16" else 4) * half
     # executed matrix flops per pair: the Winograd layers at 64 products per tile in the fp32 mode; the bf16 / fp32x modes run the
     # direct form (fp32x: six bf16 partial products per fp32 product, priced as ONE fp32 product each — see peak_note)
-    ex_pair = exec_flops_per_pair(vol, args.conv_wino if args.precision == "fp32" else 0) * half
+    ex_pair = exec_flops_per_pair(vol, args.conv_wino if args.precision == "fp32" else 0, B) * half
     if rank == 0 and not args.eval:
         if brief and not getattr(args, "also_kernel_roofline", False):
             roof = {"whole_step": whole_step_entry(pairs_per_s, world, gf_pair, by_pair, args.precision, ex_pair)}

@@ -144,6 +144,11 @@ int    tmf_conv3d_fwd_wino_affine(const float* x, const float* u, const float* s
 int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);
 size_t tmf_conv3d_wino_weight_bytes(int cin, int cout);             /* 64 * cin * cout floats */
 int    tmf_conv_wino_mode(void);
+/* tmf_wino_p_mode(): tmf_set_option("wino_p", 0 | 1) / TMF_WINO_P — 1 (default): the three Winograd entries run their persistent
+ * one-wave-per-SIMD kernels (conv3d_wino_p_kernel, conv3d_wino_wgrad_p_kernel; the forward picks per volume between 4x8x8
+ * bricks of one sample and 4x4x4 bricks of four samples — tmf_conv3d_wino_stat_blocks() follows it); 0: the two-waves-per-
+ * SIMD kernels of round 4.  Same results up to fp32 rounding of the output transform's order of additions. */
+int    tmf_wino_p_mode(void);
 /* Weight gradient in the same form: dU_p = V_p^T Z_p per position of the transformed tile (V = the forward's input transform of
  * x, Z = A dz A^T), summed over all tiles on the fp32 matrix pipe, then dw = G^T dU G (fp64) — replaces the weight gradient of
  * convolution_backward at networks.py:28,31,37,40,46 for cin % 32 == 0 and cout % 32 == 0.  Arguments as tmf_conv3d_wgrad. */

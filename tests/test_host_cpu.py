@@ -208,6 +208,37 @@ def test_winograd_halo_slot_map_is_a_conflict_free_bijection():
                         assert len(res) == 16, (dd, i, k, quad)
 
 
+def test_winograd_folded_brick_slot_map_is_a_conflict_free_bijection():
+    """The persistent kernel's second geometry (csrc/conv3d_wino.hip PGeom<1>): four samples x 2x2x2 tiles, the 4 x 6x6x6 halo of
+    a chunk as slot(sample, voxel, quad) = 2 G + (quad ^ ((hh >> 1) & 1)), G = parity class * 144 + sample * 36 + (hd >> 1) * 10 +
+    (hh >> 1) * 3 + (hw >> 1): injective into the 2 304 slots of a buffer, and for every tap the 32 tiles' ds_read_b128 (lane
+    l31 = sample * 8 + td * 4 + th * 2 + tw) is conflict-free in both 16-lane service groups."""
+    def slot(s, hd, hh, hw, quad):
+        g = ((hd & 1) * 4 + (hh & 1) * 2 + (hw & 1)) * 144 + s * 36 + (hd >> 1) * 10 + (hh >> 1) * 3 + (hw >> 1)
+        return 2 * g + (quad ^ ((hh >> 1) & 1))
+    seen = set()
+    for s in range(4):
+        for hd in range(6):
+            for hh in range(6):
+                for hw in range(6):
+                    a, b = slot(s, hd, hh, hw, 0), slot(s, hd, hh, hw, 1)
+                    assert a // 2 == b // 2 and a != b and 0 <= a < 2304 and 0 <= b < 2304
+                    assert a not in seen and b not in seen
+                    seen.update((a, b))
+    assert len(seen) == 2 * 4 * 216
+    groups = ([0, 1, 2, 3, 12, 13, 14, 15] + list(range(20, 28)), list(range(4, 12)) + [16, 17, 18, 19, 28, 29, 30, 31])
+    for dd in range(4):
+        for i in range(4):
+            for k in range(4):
+                for quad in range(2):
+                    for lanes in groups:
+                        res = set()
+                        for tile in lanes:
+                            s, td, th, tw = tile >> 3, (tile >> 2) & 1, (tile >> 1) & 1, tile & 1
+                            res.add(slot(s, 2 * td + dd, 2 * th + i, 2 * tw + k, quad) % 16)
+                        assert len(res) == 16, (dd, i, k, quad)
+
+
 def test_winograd_form_is_the_default_plan_of_the_encoder():
     """tmf_set_option("conv_wino", ..): default 3; the whole-encoder plan (tmf_snet_saved_bytes — host arithmetic, no GPU) carries
     the 64-position transformed weights (64 x cin x cout floats per layout) exactly for the layers and directions a mode puts on

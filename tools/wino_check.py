@@ -57,6 +57,9 @@ def main():
     worst = check(2, d, h, w, 8, 32, dev, "ragged")
     worst = max(worst, check(1, 4, 8, 8, 16, 32, dev, "one brick"))
     worst = max(worst, check(2, 6, 10, 12, 32, 64, dev, "even"))
+    worst = max(worst, check(8, 12, 12, 12, 32, 64, dev, "folded"))          # four samples x 4x4x4 bricks
+    worst = max(worst, check(7, 11, 13, 11, 16, 32, dev, "folded rag"))
+    worst = max(worst, check(3, 4, 4, 4, 8, 32, dev, "folded one"))
     tot = {"wino": 0.0, "direct": 0.0}
     for name, cin, cout, k, div in LAYERS:
         if k != 3 or (a.only and a.only not in name):

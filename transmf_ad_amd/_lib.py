@@ -46,6 +46,7 @@ PROTOTYPES = {
     "tmf_conv3d_wino_stat_blocks": (_i, [_i, _i, _i, _i]),
     "tmf_conv3d_wino_weight_bytes": (_z, [_i, _i]),
     "tmf_conv_wino_mode": (_i, []),
+    "tmf_wino_p_mode": (_i, []),
     "tmf_conv3d_wgrad_wino_ok": (_i, [_i, _i]),
     "tmf_conv3d_wgrad_wino_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad_wino": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -464,14 +464,30 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
 #define P_ABL 0             // 1 no input transform, 2 no weight loads, 4 no halo copies, 8 no epilogue, 16 no MFMAs
 #endif
 constexpr int PN = 256;                                           // threads: 4 waves, wave = pd
-constexpr int PDMA = SLOTS / PN;                                  // 6 LDS-DMA instructions per wave and chunk
-constexpr int P_EX_OFF = 2 * RAW_BYTES;                           // bytes; exchange [pd 4][r pair 8][ho 2][lane 64] x 16 B
-constexpr int P_EX_BYTES = 4 * 8 * 2 * 64 * 16;
-constexpr int P_RED_OFF = P_EX_OFF + P_EX_BYTES;                  // statistic scratch [which 2][source 32][33] floats
-constexpr int P_TAB_OFF = P_RED_OFF + 2 * 32 * 33 * 4 + 64;             // item table [P_TAB] x 2 int4: {brick, channel group, sample, bd | bh << 10 | bw << 20},
-                                                                  // {halo corner byte offset, valid h | w << 16 coordinate mask, valid d range lo | hi << 8, -}
-constexpr int P_TAB = 768;                                        // items per workgroup and launch
-constexpr size_t P_LDS_BYTES = (size_t)P_TAB_OFF + P_TAB * 32;    // 145 KB
+// The 32 tiles of an item, two geometries:
+//   GEOM 0: one sample, 2 x 4 x 4 tiles = the 4x8x8 brick and slot map of the kernel above (tile l31 = td * 16 + th * 4 + tw);
+//   GEOM 1: FOUR samples x 2 x 2 x 2 tiles = a 4x4x4 brick of each (tile l31 = s * 8 + td * 4 + th * 2 + tw) for the small deep
+//     volumes: 12^3 in 4x8x8 bricks pads to 12x16x16 (1.78 x the products), 11x13x11 likewise; 4x4x4 bricks fit exactly / pad
+//     to 12x16x12.  Slot map of its 4 x 6x6x6 halo: group = parity * 144 + s * 36 + (hd >> 1) * 10 + (hh >> 1) * 3 + (hw >> 1),
+//     slot = 2 group + (quad ^ (hh >> 1 & 1)) as in GEOM 0 — the strides 36 and 10 make the four lane quads of either service
+//     group of a ds_read_b128 start at the bank residues {0, 2, 4, 6} mod 8 (tests/test_host_cpu.py checks both maps
+//     exhaustively: bijective, every tap conflict-free).
+template <int GEOM> struct PGeom;
+template <> struct PGeom<0> { static constexpr int BS = 1, BD = 4, BH = 8, BW = 8, CP = 96, SS = 0, SD = 32, SH = 6, TAB = 768; };
+template <> struct PGeom<1> { static constexpr int BS = 4, BD = 4, BH = 4, BW = 4, CP = 144, SS = 36, SD = 10, SH = 3, TAB = 448; };
+template <int GEOM> struct PLds {
+    using GM = PGeom<GEOM>;
+    static constexpr int SLOTS_G = 16 * GM::CP;                   // 8 parity classes x 2 channel quads
+    static constexpr int RAWB = SLOTS_G * 16;                     // one halo buffer: 24 KB / 36 KB
+    static constexpr int NDMA_G = SLOTS_G / PN;                   // 6 / 9 LDS-DMA instructions per wave and chunk
+    static constexpr int EX_OFF = 2 * RAWB;                       // bytes; exchange [pd 4][tile 32][ho 2][wo 2][channel 32] floats
+    static constexpr int EX_BYTES = 4 * 32 * 4 * 32 * 4;
+    static constexpr int RED_OFF = EX_OFF + EX_BYTES;             // statistic scratch [which 2][source 32][33] floats
+    static constexpr int TAB_OFF = RED_OFF + 2 * 32 * 33 * 4 + 64;      // item table [TAB] x 2 int4: {brick, channel group, first sample,
+                                                                  // bd | bh << 10 | bw << 20}, {halo corner byte offset, valid-coordinate mask, -, -}
+    static constexpr size_t BYTES = (size_t)TAB_OFF + GM::TAB * 32;     // 145 KB / 155 KB
+    static_assert(SLOTS_G % PN == 0 && BYTES <= 160 * 1024, "LDS carving");
+};
 
 __device__ __forceinline__ void bload16(f32x4& dst, int voff, i32x4 rsrc, int soff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
@@ -557,16 +573,21 @@ __device__ __forceinline__ float acc_read(float a) {
     return v;
 }
 
-template <int MODE>
+template <int MODE, int GEOM>
 __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
     const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ z, float* __restrict__ stat_partial,
-    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int item0, int nitems,
+    int B, int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int item0, int nitems,
     const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr, float slope = 0.f, int pool = 0) {
     constexpr bool STATS = MODE == 1;
+    using GM = PGeom<GEOM>;
+    using PL = PLds<GEOM>;
+    constexpr int BS = GM::BS, BD = GM::BD, BH = GM::BH, BW = GM::BW;                 // samples and voxels of a brick
+    constexpr int CP = GM::CP, SS = GM::SS, SD = GM::SD, SH = GM::SH;                 // slot map strides (groups)
+    constexpr int RAWB = PL::RAWB, PDMA = PL::NDMA_G;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* ex = smem + P_EX_OFF / 4;
-    float* red = smem + P_RED_OFF / 4;
-    i32x4* tab = reinterpret_cast<i32x4*>(smem + P_TAB_OFF / 4);
+    float* ex = smem + PL::EX_OFF / 4;
+    float* red = smem + PL::RED_OFF / 4;
+    i32x4* tab = reinterpret_cast<i32x4*>(smem + PL::TAB_OFF / 4);
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -589,15 +610,17 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
         const int bw = t % tilesW; t /= tilesW;
         const int bh = t % tilesH; t /= tilesH;
         const int bd = t % tilesD;
-        tab[2 * i] = i32x4{brick, ng, t / tilesD, bd | (bh << 10) | (bw << 20)};
+        const int b0 = (t / tilesD) * BS;
+        tab[2 * i] = i32x4{brick, ng, b0, bd | (bh << 10) | (bw << 20)};
         // the halo of this brick: byte offset of its voxel (0, 0, 0) = (d0 - 1, h0 - 1, w0 - 1) in the sample (negative at the faces)
-        // and the valid coordinates [lo, hi) per axis (the volume's faces and a ragged last brick cut them)
-        const int d0 = bd * TD, h0 = bh * TH, w0 = bw * TW;
-        const int lo_d = d0 == 0 ? 1 : 0, hi_d = D - d0 + 1 < HD ? D - d0 + 1 : HD;
-        const int lo_h = h0 == 0 ? 1 : 0, hi_h = H - h0 + 1 < HH ? H - h0 + 1 : HH;
-        const int lo_w = w0 == 0 ? 1 : 0, hi_w = W - w0 + 1 < HW ? W - w0 + 1 : HW;
+        // and the valid halo coordinates [lo, hi) per axis (the volume's faces and a ragged last brick cut them; a last brick of
+        // fewer than BS samples cuts the sample range) as one mask: d bits 0-5, h bits 6-15, w bits 16-25, sample bits 26-29
+        const int d0 = bd * BD, h0 = bh * BH, w0 = bw * BW;
+        auto range = [](int lo, int hi) { return ((1 << hi) - 1) & ~((1 << lo) - 1); };
+        auto mn = [](int a, int b_) { return a < b_ ? a : b_; };
         tab[2 * i + 1] = i32x4{(((d0 - 1) * H + (h0 - 1)) * W + (w0 - 1)) * Cin * 4,
-                               (((1 << hi_h) - 1) & ~((1 << lo_h) - 1)) | ((((1 << hi_w) - 1) & ~((1 << lo_w) - 1)) << 16), lo_d | (hi_d << 8), 0};
+                               range(d0 == 0 ? 1 : 0, mn(BD + 2, D - d0 + 1)) | (range(h0 == 0 ? 1 : 0, mn(BH + 2, H - h0 + 1)) << 6) |
+                                   (range(w0 == 0 ? 1 : 0, mn(BW + 2, W - w0 + 1)) << 16) | (range(0, mn(BS, B - b0)) << 26), 0, 0};
     }
     __syncthreads();
     const int total = my_items * nchunk;                    // chunks of the whole stream
@@ -606,18 +629,18 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
     // Per lane and instruction only what does not depend on the brick: the voxel's offset from the halo's corner and one-hot masks
     // of its halo h / w coordinates; the brick's part sits in the item table; per item (dma_plan: every instruction of a lone wave
     // is ~5 matrix cycles) the lanes outside the volume get the out-of-range offset by one AND + compare per copy.
-    const int sr = lane >> 1, sbb = sr / 6, sc = sr % 6;
-    const int squad = (lane & 1) ^ (sbb & 1);
-    const bool sreal = sbb < 5 && sc < 5;
-    int hrel[PDMA], hoff[PDMA];
-    int hmask[4];                                           // [h parity][w parity]: bit hh | bit (16 + hw); a padding slot: a bit no brick has
-#pragma unroll
-    for (int pp = 0; pp < 4; ++pp) hmask[pp] = sreal ? (1 << (2 * sbb + (pp >> 1))) | (1 << (16 + 2 * sc + (pp & 1))) : (1 << 30);
+    int hrel[PDMA], hm[PDMA], hoff[PDMA];
 #pragma unroll
     for (int q = 0; q < PDMA; ++q) {
-        const int g32 = q * 4 + wave, par = g32 / 3, a = g32 % 3;
-        const int hd = 2 * a + (par >> 2), hh = 2 * sbb + ((par >> 1) & 1), hw = 2 * sc + (par & 1);
-        hrel[q] = (((hd * H + hh) * W + hw) * Cin + squad * 4) * 4;
+        const int e = (q * 4 + wave) * 64 + lane, gg = e >> 1, par = gg / CP, g = gg % CP;
+        int s_, a_, bb, c_;
+        bool real;
+        if (GEOM == 0) { s_ = 0; a_ = g / 32; bb = (g % 32) / 6; c_ = (g % 32) % 6; real = bb < 5 && c_ < 5; }
+        else { s_ = g / 36; a_ = (g % 36) / 10; bb = ((g % 36) % 10) / 3; c_ = ((g % 36) % 10) % 3; real = a_ < 3 && (g % 36) % 10 < 9; }
+        const int hd = 2 * a_ + (par >> 2), hh = 2 * bb + ((par >> 1) & 1), hw = 2 * c_ + (par & 1);
+        const int quad = (e & 1) ^ (bb & 1);
+        hrel[q] = ((((s_ * D + hd) * H + hh) * W + hw) * Cin + quad * 4) * 4;
+        hm[q] = real ? (1 << hd) | (1 << (6 + hh)) | (1 << (16 + hw)) | (1 << (26 + s_)) : (1 << 30);      // (bit 30: in no brick's mask)
     }
     i32x4 xr;
     int dm_i = 0, dm_c = 0;                                 // the (item, chunk) the next halo copy belongs to
@@ -625,15 +648,12 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
         const i32x4 e1 = tab[2 * i + 1];
         const int b = __builtin_amdgcn_readfirstlane(tab[2 * i][2]);
         const int corner = __builtin_amdgcn_readfirstlane(e1[0]), vm = __builtin_amdgcn_readfirstlane(e1[1]);
-        const int dr = __builtin_amdgcn_readfirstlane(e1[2]), lo_d = dr & 255, hi_d = dr >> 8;
-        xr = make_rsrc(x + (size_t)b * D * H * W * Cin, (unsigned)(D * H * W * Cin * 4));
+        const int ns = B - b < BS ? B - b : BS;
+        xr = make_rsrc(x + (size_t)b * D * H * W * Cin, (unsigned)(ns * D * H * W * Cin * 4));
 #pragma unroll
         for (int q = 0; q < PDMA; ++q) {
-            const int g32 = q * 4 + wave, par = g32 / 3, a = g32 % 3;
-            const int hd = 2 * a + (par >> 2);
-            const int m = hmask[par & 3];
             const int off = hrel[q] + corner;               // (absolute and non-negative where valid: the range check sees vector + scalar offset)
-            hoff[q] = (hd >= lo_d && hd < hi_d && (m & vm) == m) ? off : OOB;
+            hoff[q] = (hm[q] & vm) == hm[q] ? off : OOB;
 #if P_ABL & 32          // timing only: 8 / 16 cache lines per copy instruction instead of 32 (contiguous 1 KB / 16 x 64 B pieces)
             hoff[q] = (q * 4 + wave) * 1024 + lane * 16;
 #elif P_ABL & 64
@@ -641,13 +661,12 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
 #endif
         }
     };
-    // halo of (dm_i, dm_c) -> buffer buf in three parts of two copies (one part per group of MFMAs: six LDS-DMA instructions back
-    // to back wait for each other in the issue slot); the third part advances the cursor
+    // halo of (dm_i, dm_c) -> buffer buf in three parts (a third of the copies each); the third part advances the cursor
     auto dma_part = [&](int buf, int part) {
-        const unsigned base = lds0 + buf * RAW_BYTES + wave * 1024;
+        const unsigned base = lds0 + buf * RAWB + wave * 1024;
 #pragma unroll
         for (int q = 0; q < ((P_ABL & 4) ? 0 : PDMA); ++q)
-            if (q / 2 == part) blds16(hoff[q], xr, dm_c * (CK * 4), base + q * 4096);
+            if (q / (PDMA / 3) == part) blds16(hoff[q], xr, dm_c * (CK * 4), base + q * 4096);
         if (part == 2 && ++dm_c == nchunk) {
             dm_c = 0;
             if (++dm_i < my_items) dma_plan(dm_i);
@@ -675,27 +694,21 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
     const int da = wave == 0 ? 0 : (wave == 2 ? 2 : 1);
     const int db = wave == 0 ? 2 : (wave == 1 ? 2 : (wave == 2 ? 1 : 3));
     const float sgn = wave == 1 ? 1.f : -1.f;
-    const int td = l31 >> 4, th = (l31 >> 2) & 3, tw = l31 & 3;
-    const int g0 = td * 32 + th * 6 + tw;
+    const int ts = GEOM == 0 ? 0 : l31 >> 3, td = GEOM == 0 ? l31 >> 4 : (l31 >> 2) & 1;
+    const int th = GEOM == 0 ? (l31 >> 2) & 3 : (l31 >> 1) & 1, tw = GEOM == 0 ? l31 & 3 : l31 & 1;
+    const int g0 = ts * SS + td * SD + th * SH + tw;
     const int e0 = hsel ^ (th & 1);
-    auto row_base = [&](int dd, int i) { return (2 * (g0 + ogd(dd) + ogh(i)) + (e0 ^ (i >> 1))) * 4; };
+    // group offsets of a tap (dd, i, k) relative to the tile's own group
+    auto pgd = [](int dd) { return (dd & 1) * 4 * CP + (dd >> 1) * SD; };
+    auto pgh = [](int i) { return (i & 1) * 2 * CP + (i >> 1) * SH; };
+    auto pgw = [](int k) { return (k & 1) * CP + (k >> 1); };
+    auto row_base = [&](int dd, int i) { return (2 * (g0 + pgd(dd) + pgh(i)) + (e0 ^ (i >> 1))) * 4; };
     int rba[4], rbb[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { rba[i] = row_base(da, i); rbb[i] = row_base(db, i); }
     f32x4 A[16];                                            // [ph][pw]
     f32x2 u1l[4], u1h[4], u2l[4], u2h[4];                   // the w-transformed rows 1, 2 (channels 0-1 / 2-3), kept for ph 0, 3
     const f32x2 s2 = {sgn, sgn};
-    auto wrow = [&](const float* R, int i, f32x2 (&lo)[4], f32x2 (&hi)[4]) {      // h row i: d combination, then the w transform
-        f32x2 tl[4], th2[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(&R[rba[i] + ogw(k) * 8]), bq = *reinterpret_cast<const f32x4*>(&R[rbb[i] + ogw(k) * 8]);
-            tl[k] = f32x2{a[0], a[1]} + s2 * f32x2{bq[0], bq[1]};
-            th2[k] = f32x2{a[2], a[3]} + s2 * f32x2{bq[2], bq[3]};
-        }
-        lo[0] = tl[0] - tl[2]; lo[1] = tl[1] + tl[2]; lo[2] = tl[2] - tl[1]; lo[3] = tl[1] - tl[3];
-        hi[0] = th2[0] - th2[2]; hi[1] = th2[1] + th2[2]; hi[2] = th2[2] - th2[1]; hi[3] = th2[1] - th2[3];
-    };
     auto pack4 = [](f32x2 l, f32x2 h) { return f32x4{l[0], l[1], h[0], h[1]}; };
     // The transform of a phase is cut into four stages, one per group of 8 MFMAs (the compiler's scheduler is fenced between the
     // groups: left alone it gathers the 32 MFMAs of a phase behind the barrier and waits for the LDS in front of it):
@@ -704,8 +717,8 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
     auto row_read = [&](const float* R, int i) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            ra[k] = *reinterpret_cast<const f32x4*>(&R[rba[i] + ogw(k) * 8]);
-            rb[k] = *reinterpret_cast<const f32x4*>(&R[rbb[i] + ogw(k) * 8]);
+            ra[k] = *reinterpret_cast<const f32x4*>(&R[rba[i] + pgw(k) * 8]);
+            rb[k] = *reinterpret_cast<const f32x4*>(&R[rbb[i] + pgw(k) * 8]);
         }
     };
     auto row_xform = [&](f32x2 (&lo)[4], f32x2 (&hi)[4]) {  // d combination, then the w transform (channels 0-1 / 2-3 of the quad)
@@ -727,7 +740,7 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
     auto pin4 = [](f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); };
     auto T1 = [&](int buf, int stage) {                     // rows 1, 2 -> ph 1 = u1 + u2, ph 2 = u2 - u1
         if (P_ABL & 1) return;
-        const float* R = smem + buf * (RAW_BYTES / 4);
+        const float* R = smem + buf * (RAWB / 4);
         if (stage == 0) row_read(R, 1);
         if (stage == 1) { row_xform(u1l, u1h); row_read(R, 2); pin2(u1l, u1h); }
         if (stage == 2) { row_xform(u2l, u2h); pin2(u2l, u2h); }
@@ -746,7 +759,7 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
     };
     auto T2 = [&](int buf, int stage) {                     // rows 0, 3 -> ph 0 = u0 - u2, ph 3 = u1 - u3
         if (P_ABL & 1) return;
-        const float* R = smem + buf * (RAW_BYTES / 4);
+        const float* R = smem + buf * (RAWB / 4);
         if (stage == 0) row_read(R, 0);
         if (stage == 1) {
             row_xform(vl, vh);
@@ -791,9 +804,14 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
         }
     };
 
-    // store side of the epilogue (reader lanes: channel quad lane & 7, wo = lane >> 3 & 1, tile w = lane >> 4; tile d = wave >> 1,
-    // tile h = 2 (wave & 1) + j): this lane's byte offset inside a brick
-    const int st_lane = ((((2 * (wave >> 1)) * H + 4 * (wave & 1)) * W + 2 * (lane >> 4) + ((lane >> 3) & 1)) * Cout + 4 * (lane & 7)) * 4;
+    // store side of the epilogue: the reader lane (channel quad lane & 7, wo = lane >> 3 & 1, vq = lane >> 4) of wave w' holds the tiles
+    // 8 w' + 4 j + vq, j = 0, 1.  GEOM 0: tile d = w' >> 1, tile h = 2 (w' & 1) + j, tile w = vq;  GEOM 1: sample w', tile d = j,
+    // tile h = vq >> 1, tile w = vq & 1.  st_lane: this lane's (and wave's) byte offset inside a brick; st_j: the step of j
+    const int rvq = lane >> 4;
+    const int st_ts = GEOM == 0 ? 0 : wave, st_td = GEOM == 0 ? wave >> 1 : 0;                  // (+ j for GEOM 1)
+    const int st_th = GEOM == 0 ? 2 * (wave & 1) : rvq >> 1, st_tw = GEOM == 0 ? rvq : rvq & 1; // (+ j for GEOM 0)
+    const int st_lane = (((((st_ts * D + 2 * st_td) * H + 2 * st_th) * W + 2 * st_tw + ((lane >> 3) & 1)) * Cout + 4 * (lane & 7))) * 4;
+    const int st_j = (GEOM == 0 ? 2 * W : 2 * H * W) * Cout * 4;
     // ---- prologue of the stream: two halos in flight, the first weights, the first half transform ----
     dma_plan(0);
     dma_issue(0);
@@ -815,7 +833,7 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
         const i32x4 ce = tab[2 * it];
         const int brick = __builtin_amdgcn_readfirstlane(ce[0]), b = __builtin_amdgcn_readfirstlane(ce[2]);
         const int cpk = __builtin_amdgcn_readfirstlane(ce[3]);
-        const int d0 = (cpk & 1023) * TD, h0 = ((cpk >> 10) & 1023) * TH, w0 = (cpk >> 20) * TW;
+        const int d0 = (cpk & 1023) * BD, h0 = ((cpk >> 10) & 1023) * BH, w0 = (cpk >> 20) * BW;
         const int n0 = ci_n0;
         TRQ(0);
         auto chunk = [&](int c, auto first_c) {
@@ -920,9 +938,11 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
                 outv[j][ho][1] = (S[1] - S[2]) - S[3];
             }
         TRQ(22);
-        // tile 8 w' + 4 j + vq: tile d = w' >> 1, tile h = 2 (w' & 1) + j, tile w = vq
+        // voxel of (tile 8 w' + 4 j + vq, do, ho, wo): d = gdb + 2 j jd + do, h = ghb + 2 j jh + ho, w = gw (jd, jh: which axis j steps)
         const int co = n0 + 4 * cq;
-        const int gdb = d0 + 2 * (wave >> 1), ghb = h0 + 4 * (wave & 1), gw = w0 + 2 * vq + rwo;
+        constexpr int jd = GEOM == 0 ? 0 : 1, jh = GEOM == 0 ? 1 : 0;
+        const int gdb = d0 + 2 * st_td, ghb = h0 + 2 * st_th, gw = w0 + 2 * st_tw + rwo;
+        const int bs = b + st_ts;                           // this wave's sample
         if constexpr (MODE == 2) {
             f32x4 sc, sh;
 #pragma unroll
@@ -940,8 +960,8 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
                         }
             if (pool == TMF_POOL_MAX2) {
                 const int OD = D / 2, OH = H / 2, OW = W / 2;
-                float* yb = z + (size_t)b * OD * OH * OW * Cout;
-                const int od = gdb >> 1, ow = (w0 >> 1) + vq;
+                float* yb = z + (size_t)bs * OD * OH * OW * Cout;
+                const int ow = (w0 >> 1) + st_tw;
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {                  // the window = the tile: d and h pairs in this lane, the w pair in lane ^ 8
                     f32x4 m;
@@ -950,32 +970,34 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
                         float v = fmaxf(fmaxf(outv[j][0][0][e], outv[j][0][1][e]), fmaxf(outv[j][1][0][e], outv[j][1][1][e]));
                         m[e] = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true)));       // row_ror:8 = lane ^ 8
                     }
-                    const int oh = (ghb >> 1) + j;
-                    if (rwo == 0 && od < OD && oh < OH && ow < OW) *reinterpret_cast<f32x4*>(&yb[((size_t)(od * OH + oh) * OW + ow) * Cout + co]) = m;
+                    const int od = (gdb >> 1) + j * jd, oh = (ghb >> 1) + j * jh;
+                    if (rwo == 0 && bs < B && od < OD && oh < OH && ow < OW) *reinterpret_cast<f32x4*>(&yb[((size_t)(od * OH + oh) * OW + ow) * Cout + co]) = m;
                 }
             } else {
-                float* yb = z + (size_t)b * D * H * W * Cout;
+                float* yb = z + (size_t)bs * D * H * W * Cout;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
 #pragma unroll
                     for (int ho = 0; ho < 2; ++ho)
 #pragma unroll
                         for (int dd = 0; dd < 2; ++dd) {
-                            const int gd = gdb + dd, gh = ghb + 2 * j + ho;
-                            if (gd < D && gh < H && gw < W) *reinterpret_cast<f32x4*>(&yb[((size_t)(gd * H + gh) * W + gw) * Cout + co]) = outv[j][ho][dd];
+                            const int gd = gdb + 2 * j * jd + dd, gh = ghb + 2 * j * jh + ho;
+                            if (bs < B && gd < D && gh < H && gw < W) *reinterpret_cast<f32x4*>(&yb[((size_t)(gd * H + gh) * W + gw) * Cout + co]) = outv[j][ho][dd];
                         }
             }
         } else {
+            // (the resource covers the brick's samples that exist: a lane of a sample beyond the batch is out of range and dropped)
             float* zb = z + (size_t)b * D * H * W * Cout;
-            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, D * H * W * Cout * 4, 0x00020000);
-            const bool full = d0 + TD <= D && h0 + TH <= H && w0 + TW <= W;
+            const int ns = B - b < BS ? B - b : BS;
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, ns * D * H * W * Cout * 4, 0x00020000);
+            const bool full = d0 + BD <= D && h0 + BH <= H && w0 + BW <= W && b + BS <= B;
             f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2q = {0.f, 0.f, 0.f, 0.f};
             // address = this lane's part (st_lane: tile and channel quad, fixed for the kernel) + the brick's corner and the row
             // (d, h) of the store in the scalar offset: one s_add per store
             const int st_item = (((d0 * H + h0) * W + w0) * Cout + n0) * 4;
             auto put = [&](auto full_c) {
                 constexpr bool FULL = decltype(full_c)::value;
-                const bool w_ok = FULL || gw < W;
+                const bool w_ok = FULL || (gw < W && bs < B);
                 const int voff = w_ok ? st_lane : OOB;
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
@@ -983,11 +1005,15 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
                     for (int ho = 0; ho < 2; ++ho)
 #pragma unroll
                         for (int dd = 0; dd < 2; ++dd) {
-                            const int gd = gdb + dd, gh = ghb + 2 * j + ho;                    // (wave-uniform)
+                            const int gd = gdb + 2 * j * jd + dd, gh = ghb + 2 * j * jh + ho;      // (wave-uniform for GEOM 0; per lane for GEOM 1)
                             const bool row_ok = FULL || (gd < D && gh < H);
                             f32x4 v = outv[j][ho][dd];
-                            if (row_ok)
-                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tmf_u32x4, v), zr, voff, st_item + (dd * H + 2 * j + ho) * W * Cout * 4, 0);
+                            if (GEOM == 0) {
+                                if (row_ok)
+                                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tmf_u32x4, v), zr, voff, st_item + j * st_j + (dd * H + ho) * W * Cout * 4, 0);
+                            } else {
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tmf_u32x4, v), zr, row_ok ? voff : OOB, st_item + j * st_j + (dd * H + ho) * W * Cout * 4, 0);
+                            }
                             if (STATS) {
                                 if (!FULL) v = (row_ok && w_ok) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                                 s1 += v;
@@ -1625,32 +1651,53 @@ int wino_cu_count() {
     return n[dev];
 }
 
-template <int MODE>
-int launch_wino_p(const char* what, const float* x, const float* u, float* z, float* stat_partial, int B, int D, int H, int W,
-                  int cin, int cout, const float* scale, const float* shift, float slope, int pool, hipStream_t stream) {
-    const int tilesD = tmf_cdiv(D, TD), tilesH = tmf_cdiv(H, TH), tilesW = tmf_cdiv(W, TW);
+// Brick geometry of the persistent kernel for a volume: 1 (four samples x 4x4x4) where that executes fewer tiles than 0 (4x8x8)
+int wino_p_geom(int B, int D, int H, int W) {
+    const long t0 = (long)B * tmf_cdiv(D, 4) * tmf_cdiv(H, 8) * tmf_cdiv(W, 8);
+    const long t1 = (long)tmf_cdiv(B, 4) * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 4);
+    return t1 < t0 ? 1 : 0;
+}
+long wino_p_bricks(int geom, int B, int D, int H, int W) {
+    return geom ? (long)tmf_cdiv(B, 4) * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 4)
+                : (long)B * tmf_cdiv(D, 4) * tmf_cdiv(H, 8) * tmf_cdiv(W, 8);
+}
+
+template <int MODE, int GEOM>
+int launch_wino_p_g(const char* what, const float* x, const float* u, float* z, float* stat_partial, int B, int D, int H, int W,
+                    int cin, int cout, const float* scale, const float* shift, float slope, int pool, hipStream_t stream) {
+    using GM = PGeom<GEOM>;
+    const int tilesD = tmf_cdiv(D, GM::BD), tilesH = tmf_cdiv(H, GM::BH), tilesW = tmf_cdiv(W, GM::BW);
     TMF_REQUIRE(tilesD < 1024 && tilesH < 1024 && tilesW < 1024, TMF_E_SHAPE, "%s: more than 1023 bricks along one axis", what);
-    const long nbricks = (long)B * tilesD * tilesH * tilesW;
+    TMF_REQUIRE((long)GM::BS * D * H * W * (cin > cout ? cin : cout) < (1L << 29), TMF_E_SHAPE,
+                "%s: the samples of one brick exceed 2^29 elements (32-bit byte offsets)", what);
+    const long nbricks = wino_p_bricks(GEOM, B, D, H, W);
     const long nitems = nbricks * (cout / 32);
     TMF_REQUIRE(nitems < (1L << 30), TMF_E_SHAPE, "%s: too many bricks", what);
-    auto k = conv3d_wino_p_kernel<MODE>;
+    auto k = conv3d_wino_p_kernel<MODE, GEOM>;
     int rc;
-    if ((rc = tmf_allow_lds(k, P_LDS_BYTES, what))) return rc;
+    if ((rc = tmf_allow_lds(k, PLds<GEOM>::BYTES, what))) return rc;
     const int ncu = wino_cu_count();
-    const long per_launch = (long)ncu * P_TAB;              // a workgroup's item table holds P_TAB entries
+    const long per_launch = (long)ncu * GM::TAB;            // a workgroup's item table holds TAB entries
     for (long i0 = 0; i0 < nitems; i0 += per_launch) {
         const long n = nitems - i0 < per_launch ? nitems - i0 : per_launch;
         const int grid = (int)(n < ncu ? n : ncu);
-        hipLaunchKernelGGL(k, dim3(grid), dim3(PN), P_LDS_BYTES, stream, x, u, z, stat_partial, D, H, W, cin, cout,
+        hipLaunchKernelGGL(k, dim3(grid), dim3(PN), PLds<GEOM>::BYTES, stream, x, u, z, stat_partial, B, D, H, W, cin, cout,
                            tilesD, tilesH, tilesW, (int)nbricks, (int)i0, (int)n, scale, shift, slope, pool);
         if ((rc = tmf_launch_result(what))) return rc;
     }
     return TMF_OK;
 }
+template <int MODE>
+int launch_wino_p(const char* what, const float* x, const float* u, float* z, float* stat_partial, int B, int D, int H, int W,
+                  int cin, int cout, const float* scale, const float* shift, float slope, int pool, hipStream_t stream) {
+    if (wino_p_geom(B, D, H, W)) return launch_wino_p_g<MODE, 1>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
+    return launch_wino_p_g<MODE, 0>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
+}
 
 }  // namespace
 
 int tmf_wino_p_set(int v) { g_wino_p = v ? 1 : 0; return TMF_OK; }
+extern "C" int tmf_wino_p_mode(void) { return wino_p_mode(); }
 
 #ifdef TMF_WINO_TRACE
 extern "C" int tmf_wino_trace_read(long long* blocks, long long* phases) {
@@ -1675,8 +1722,10 @@ int tmf_conv_wino_set(int v) { g_conv_wino = v; return TMF_OK; }
 
 extern "C" int tmf_conv3d_wino_ok(int cin, int cout) { return cin > 0 && cout > 0 && cin % 8 == 0 && cout % 32 == 0; }
 
+// rows of the statistic partials = bricks of the forward kernel tmf_conv3d_fwd_wino takes for this volume
 extern "C" int tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (wino_p_mode()) return (int)wino_p_bricks(wino_p_geom(B, D, H, W), B, D, H, W);
     return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
 }
 

@@ -197,6 +197,12 @@ def conv3d_wino_raw(x, u, cin, cout, want_stats):
     return z, part, nblk
 
 
+def wino_p_mode() -> bool:
+    """True when the Winograd entries run their persistent one-wave-per-SIMD kernels (the default; TMF_WINO_P=0 or
+    tmf_set_option("wino_p", 0): the two-waves-per-SIMD kernels of round 4)."""
+    return bool(_lib.query("tmf_wino_p_mode"))
+
+
 def wgrad_wino_ok(cin: int, cout: int) -> bool:
     return bool(_lib.query("tmf_conv3d_wgrad_wino_ok", cin, cout))
 
