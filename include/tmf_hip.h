@@ -330,6 +330,9 @@ int tmf_pack_conv_weights_split3(const float* w, void* w3_fwd, void* w3_dgrad, i
  * u_dgrad[p][cout / 8][2][cin][4] (the flipped filter with the channel roles swapped).  Either may be NULL; the forward
  * form needs tmf_conv3d_wino_ok(cin, cout), the data-gradient form tmf_conv3d_wino_ok(cout, cin). */
 int tmf_pack_conv_weights_wino(const float* w, float* u_fwd, float* u_dgrad, int cout, int cin, void* stream);
+/* ... the same for up to 8 layers in one launch (an encoder's Winograd blocks: one launch per forward instead of one per block) */
+int tmf_pack_conv_weights_wino_multi(int n, const float* const* w, float* const* u_fwd, float* const* u_dgrad,
+                                     const int* cout, const int* cin, void* stream);
 
 /* Layout conversion between the reference's NCDHW tensors and the channels-last tensors every kernel here uses
  * (voxels = D*H*W).  The model itself never needs it — its input has C == 1 (same bytes either way) and its output

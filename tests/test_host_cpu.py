@@ -242,7 +242,8 @@ def test_winograd_folded_brick_slot_map_is_a_conflict_free_bijection():
 def test_winograd_form_is_the_default_plan_of_the_encoder():
     """tmf_set_option("conv_wino", ..): default 3; the whole-encoder plan (tmf_snet_saved_bytes — host arithmetic, no GPU) carries
     the 64-position transformed weights (64 x cin x cout floats per layout) exactly for the layers and directions a mode puts on
-    the Winograd kernels, and the weight-gradient workspace grows to the kernel's [splits + groups + 1][blocks][64][32][32] slabs."""
+    the Winograd kernels, and the weight-gradient workspace holds the kernel's slabs: dw's own [27][cin][cout] per split (+ the
+    first-stage sums of a two-stage reduction) with the one-wave-per-SIMD kernel, [splits + groups + 1][blocks][64][32][32] with the other."""
     from transmf_ad_amd import _lib
     lib = _lib.load()
     assert lib.tmf_conv_wino_mode() == 3
@@ -251,7 +252,13 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
     assert lib.tmf_conv3d_wino_stat_blocks(8, 48, 48, 48) == 8 * 12 * 6 * 6 and lib.tmf_conv3d_wino_stat_blocks(2, 7, 9, 13) == 2 * 2 * 2 * 2
     assert lib.tmf_conv3d_wino_weight_bytes(32, 64) == 64 * 32 * 64 * 4
     # conv2.0 at B = 8, 48^3: one (ci, co) block -> 256 slabs in 16 groups
+    assert lib.tmf_wino_p_mode() == 1
+    assert lib.tmf_conv3d_wino_stat_blocks(8, 12, 12, 12) == 2 * 3 * 3 * 3          # four samples x 4x4x4 bricks where that is fewer tiles
+    assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 32, 32) == (256 + 16) * 27 * 1024 * 4
+    assert lib.tmf_set_option(b"wino_p", 0) == 0
+    assert lib.tmf_conv3d_wino_stat_blocks(8, 12, 12, 12) == 8 * 3 * 2 * 2
     assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 32, 32) == (256 + 16 + 1) * 64 * 1024 * 4
+    assert lib.tmf_set_option(b"wino_p", 1) == 0
     assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 16, 32) == 0
     desc = _lib.SnetDesc(B=8, D=96, H=96, W=96, dim=128, precision=0, storage_bf16=0)
     desc.momentum[:] = [0.1] * 7
@@ -266,7 +273,8 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
         per_layout = sum((64 - 27) * ci * co * 4 for ci, co in layers)     # every size here is a multiple of 256
         assert size[1][0] - size[0][0] == per_layout                       # data-gradient layouts
         assert size[2][0] - size[1][0] == per_layout                       # + forward layouts
-        assert size[3][0] == size[2][0] and size[3][1] > size[2][1]        # + the weight-gradient slabs in backward's scratch
+        assert size[3][0] == size[2][0] and size[3][1] >= size[2][1]       # (the weight-gradient slabs in backward's scratch: dw-sized
+        #                                                                     per split with the one-wave kernel — no larger than the direct kernel's)
         assert lib.tmf_set_option(b"conv_wino", 4) != 0
     finally:
         lib.tmf_set_option(b"conv_wino", 3)

@@ -86,6 +86,7 @@ PROTOTYPES = {
     "tmf_pack_conv_weights_bf16": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "tmf_pack_conv_weights_split3": (_i, [_p, _p, _p, _i, _i, _i, _p]),
     "tmf_pack_conv_weights_wino": (_i, [_p, _p, _p, _i, _i, _p]),
+    "tmf_pack_conv_weights_wino_multi": (_i, [_i, _p, _p, _p, _p, _p, _p]),
     "tmf_layout_ncdhw_to_ndhwc": (_i, [_p, _p, _i, _i, _l, _p]),
     "tmf_layout_ndhwc_to_ncdhw": (_i, [_p, _p, _i, _i, _l, _p]),
     "tmf_tok_row_blocks": (_i, [_i]),

@@ -1221,8 +1221,8 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_wgrad_kernel(
 //   * a lane (channel l31, tile parity hsel) transforms TWO tiles at once — w origins 4 apart, i.e. 512 bytes apart in the
 //     stage buffer: one ds_read2st64_b32 fetches both into a register pair and the transform runs on v_pk_*_f32
 //     (32 + 8 paired reads and ~64 packed adds per 32 MFMAs: 3.3 instructions per MFMA);
-//   * the minus signs of Z = A dz A^T (z3 = -y1 on every axis) are left out of the kernel: position p carries the sign
-//     (-1)^[pd = 3] (-1)^[ph = 3] (-1)^[pw = 3], applied by wino_wgrad_finish_kernel;
+//   * the minus signs of Z = A dz A^T (z3 = -y1 on every axis) are left out of the main loop: position p carries the sign
+//     (-1)^[pd = 3] (-1)^[ph = 3] (-1)^[pw = 3], applied where the kernel turns its sums into dw (G^T dU G per workgroup, once);
 //   * the step of four tiles is two phases of 16 MFMAs: P0 multiplies ph 1, 2 while the rows 0, 3 are read and turned into
 //     ph 0, 3; P1 multiplies ph 0, 3 while the rows 1, 2 of the NEXT step become its ph 1, 2 — no second copy of the operands,
 //     across stage boundaries too (one barrier per stage of 16 tiles, the stage after next in flight by LDS-DMA); every row
@@ -1501,21 +1501,60 @@ __global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
         }
     }
 
-    // ---- partial slab [split][blk][p][ci 32][co 32]: accumulator row r -> ci = (r & 3) + 8 (r >> 2) + 4 hsel, column co = l31 ----
-    float* out = partial + (((size_t)split * gridDim.y + blk) * 64 + wave * 16) * 1024;
+    // ---- this workgroup's share of dw = G^T dU G, straight into its slab [split][27][cin][cout] (tap-major, the full tensor: the
+    // blocks of one split fill disjoint parts): G^T along w and h on this wave's 16 positions in registers, along d across the
+    // four waves through LDS (two halves of the accumulator rows: 72 KB each).  1-D: w0 = u0 + (u1 + u2) / 2, w1 = (u1 - u2) / 2,
+    // w2 = (u1 + u2) / 2 + u3, where u3 carries the sign the Z transform left out (so: ... - u3).  The slabs are 27 / 64 of the
+    // 64-position ones and tmf_reduce_slabs writes dw itself: no finish launch.
+    // accumulator row r -> ci = (r & 3) + 8 (r >> 2) + 4 hsel, column co = l31 ----
+    __syncthreads();                                    // (every wave is done with the stage buffers: the exchange re-uses them)
+    float* slab = partial + (size_t)split * 27 * Cin * Cout + (size_t)ci0 * Cout + co0 + l31;
+    auto gt3 = [](float u0, float u1, float u2, float u3, float (&o)[3]) {
+        const float sm = u1 + u2, df = u1 - u2;
+        o[0] = u0 + 0.5f * sm; o[1] = 0.5f * df; o[2] = 0.5f * sm - u3;
+    };
 #pragma unroll
-    for (int q = 0; q < 16; ++q)
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            out[q * 1024 + ((r & 3) + 8 * (r >> 2) + 4 * hsel) * 32 + l31] = acc[q][r];
+        for (int rr = 0; rr < 8; ++rr) {
+            const int r = half * 8 + rr;
+            float t[4][3], v[3][3];
+#pragma unroll
+            for (int ph = 0; ph < 4; ++ph)
+                gt3(acc_read(acc[ph * 4 + 0][r]), acc_read(acc[ph * 4 + 1][r]), acc_read(acc[ph * 4 + 2][r]), acc_read(acc[ph * 4 + 3][r]), t[ph]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float o[3];
+                gt3(t[0][j], t[1][j], t[2][j], t[3][j], o);
+                v[0][j] = o[0]; v[1][j] = o[1]; v[2][j] = o[2];
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) smem[((wave * 8 + rr) * 9 + i * 3 + j) * 64 + lane] = v[i][j];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        // wave w' combines the four pd of the (row, h-w tap) pairs e = 18 w' .. 18 w' + 17 of this half
+#pragma unroll
+        for (int q = 0; q < 18; ++q) {
+            const int e = wave * 18 + q, rr = e / 9, ij = e % 9;
+            float V[4], o[3];
+#pragma unroll
+            for (int pd = 0; pd < 4; ++pd) V[pd] = smem[((pd * 8 + rr) * 9 + ij) * 64 + lane];
+            gt3(V[0], V[1], V[2], V[3], o);
+            const int r = half * 8 + rr, ci = (r & 3) + 8 * (r >> 2) + 4 * hsel;
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) slab[((size_t)(kd * 9 + ij) * Cin + ci) * Cout] = o[kd];
+        }
+        __syncthreads();
+    }
 }
 
 // dU (reduced over the slabs) [blk][p][ci 32][co 32] -> dw = G^T dU G along the three axes, one thread per (ci, co), fp64:
 // 1-D: w0 = u0 + (u1 + u2) / 2, w1 = (u1 - u2) / 2, w2 = (u1 + u2) / 2 + u3.  dw_ref: nn.Conv3d's [co][ci][27], else [27][ci][co].
-// fold_signs: the slabs come from conv3d_wino_wgrad_p_kernel, whose Z transform leaves out the minus of the last row on every
-// axis: position (p, q, r) carries (-1)^[p = 3] (-1)^[q = 3] (-1)^[r = 3].
 __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __restrict__ du, float* __restrict__ dw,
-                                                                int cin, int cout, int ncob, int dw_ref, int fold_signs) {
+                                                                int cin, int cout, int ncob, int dw_ref) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= cin * cout) return;
     const int co = e % cout, ci = e / cout;
@@ -1527,10 +1566,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double v = (double)src[((p * 4 + q) * 4 + r) * 1024];
-                u[p][q][r] = (fold_signs && (((p == 3) + (q == 3) + (r == 3)) & 1)) ? -v : v;
-            }
+            for (int r = 0; r < 4; ++r) u[p][q][r] = (double)src[((p * 4 + q) * 4 + r) * 1024];
     auto GT = [](double u0, double u1, double u2, double u3, int a) {
         return a == 0 ? u0 + 0.5 * (u1 + u2) : (a == 1 ? 0.5 * (u1 - u2) : 0.5 * (u1 + u2) + u3);
     };
@@ -1579,9 +1615,8 @@ WinoWgPlan plan_wino_wgrad(int B, int D, int H, int W, int cin, int cout) {
 //   dgrad[p'][cout / 8][2][cin][4] = U_p(w[co][ci])        p' = p with every axis index mapped 0 <-> 3 (the flipped
 //                                                           kernel: G's rows 0 / 3 swap, rows 1 / 2 are symmetric),
 //                                                           input channel co, output channel ci
-__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ fwd,
-                                                        float* __restrict__ dgrad, int cout, int cin) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float* __restrict__ fwd, float* __restrict__ dgrad,
+                                              int cout, int cin, int e) {
     if (e >= cout * cin) return;
     const int co = e % cout, ci = e / cout;
     const float* src = w + ((size_t)co * cin + ci) * 27;
@@ -1625,6 +1660,18 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
                     dgrad[((((size_t)pos * (cout / 8) + co / 8) * 2 + (co >> 2 & 1)) * cin + ci) * 4 + (co & 3)] = v;
                 }
             }
+}
+
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ fwd,
+                                                        float* __restrict__ dgrad, int cout, int cin) {
+    wino_pack_one(w, fwd, dgrad, cout, cin, blockIdx.x * 256 + threadIdx.x);
+}
+// the transformed weights of several layers in ONE launch (blockIdx.y = layer): an encoder's five Winograd blocks need ten
+// of these small transforms per step, each its own ~10 us launch otherwise
+struct WinoPackMulti { const float* w[8]; float* fwd[8]; float* dgrad[8]; int cout[8], cin[8]; };
+__global__ __launch_bounds__(256) void wino_pack_multi_kernel(WinoPackMulti a) {
+    const int l = blockIdx.y;
+    wino_pack_one(a.w[l], a.fwd[l], a.dgrad[l], a.cout[l], a.cin[l], blockIdx.x * 256 + threadIdx.x);
 }
 
 int g_conv_wino = -1;
@@ -1744,6 +1791,26 @@ extern "C" int tmf_pack_conv_weights_wino(const float* w, float* u_fwd, float* u
     return tmf_launch_result("tmf_pack_conv_weights_wino");
 }
 
+extern "C" int tmf_pack_conv_weights_wino_multi(int n, const float* const* w, float* const* u_fwd, float* const* u_dgrad,
+                                                const int* cout, const int* cin, void* stream) {
+    TMF_REQUIRE(n > 0 && n <= 8, TMF_E_ARG, "tmf_pack_conv_weights_wino_multi: %d layers (1 .. 8)", n);
+    TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(u_fwd); TMF_REQUIRE_PTR(u_dgrad); TMF_REQUIRE_PTR(cout); TMF_REQUIRE_PTR(cin);
+    WinoPackMulti a;
+    long most = 0;
+    for (int l = 0; l < n; ++l) {
+        TMF_REQUIRE(w[l] != nullptr && (u_fwd[l] != nullptr || u_dgrad[l] != nullptr), TMF_E_NULL,
+                    "tmf_pack_conv_weights_wino_multi: layer %d: weight or both outputs NULL", l);
+        TMF_REQUIRE(cout[l] > 0 && cin[l] > 0 && (u_fwd[l] == nullptr || tmf_conv3d_wino_ok(cin[l], cout[l])) &&
+                    (u_dgrad[l] == nullptr || tmf_conv3d_wino_ok(cout[l], cin[l])), TMF_E_SHAPE,
+                    "tmf_pack_conv_weights_wino_multi: layer %d: cin=%d cout=%d", l, cin[l], cout[l]);
+        a.w[l] = w[l]; a.fwd[l] = u_fwd[l]; a.dgrad[l] = u_dgrad[l]; a.cout[l] = cout[l]; a.cin[l] = cin[l];
+        if ((long)cout[l] * cin[l] > most) most = (long)cout[l] * cin[l];
+    }
+    for (int l = n; l < 8; ++l) { a.w[l] = nullptr; a.fwd[l] = nullptr; a.dgrad[l] = nullptr; a.cout[l] = 0; a.cin[l] = 0; }
+    hipLaunchKernelGGL(wino_pack_multi_kernel, dim3((unsigned)tmf_cdiv(most, 256L), n), dim3(256), 0, (hipStream_t)stream, a);
+    return tmf_launch_result("tmf_pack_conv_weights_wino_multi");
+}
+
 extern "C" int tmf_conv3d_fwd_wino(const float* x, const float* u, float* z, float* stat_partial,
                                    int B, int D, int H, int W, int cin, int cout, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(u); TMF_REQUIRE_PTR(z);
@@ -1782,6 +1849,8 @@ extern "C" int tmf_conv3d_wgrad_wino_ok(int cin, int cout) { return cin > 0 && c
 extern "C" size_t tmf_conv3d_wgrad_wino_workspace_bytes(int B, int D, int H, int W, int cin, int cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || !tmf_conv3d_wgrad_wino_ok(cin, cout)) return 0;
     const WinoWgPlan p = plan_wino_wgrad(B, D, H, W, cin, cout);
+    if (wino_p_mode())                                      // slabs of dw itself [27][cin][cout] (+ the first-stage sums of a two-stage reduction)
+        return (size_t)(p.nsplit + tmf_reduce_groups(p.nsplit)) * 27 * cin * cout * 4;
     const size_t n = (size_t)p.nblk * 64 * 1024;
     return (size_t)(p.nsplit + tmf_reduce_groups(p.nsplit) + 1) * n * 4;
 }
@@ -1804,24 +1873,28 @@ extern "C" int tmf_conv3d_wgrad_wino(const float* x, const float* dz, float* dw,
     float* partial = (float*)workspace;
     const long n = (long)p.nblk * 64 * 1024;
     int rc;
-    const int one_wave = wino_p_mode();
-    if (one_wave) {
+    if (wino_p_mode()) {
         auto k = conv3d_wino_wgrad_p_kernel;
         if ((rc = tmf_allow_lds(k, WG_LDS_BYTES, "tmf_conv3d_wgrad_wino"))) return rc;
         hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(WPN), WG_LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,
                            p.tilesD, p.tilesH, p.tilesW, p.nbricks, p.per, p.ncob);
-    } else {
-        auto k = conv3d_wino_wgrad_kernel;
-        if ((rc = tmf_allow_lds(k, WG_LDS_BYTES, "tmf_conv3d_wgrad_wino"))) return rc;
-        hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(NTHR), WG_LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,
-                           p.tilesD, p.tilesH, p.tilesW, p.nbricks, p.per, p.ncob);
+        if ((rc = tmf_launch_result("tmf_conv3d_wgrad_wino"))) return rc;
+        // the slabs are dw's own [27][cin][cout]: the (fp64, fixed-order) reduction writes the result in either layout
+        const long nw = (long)27 * cin * cout;
+        const bool ref = dw_layout == TMF_DW_REFERENCE;
+        return tmf_reduce_slabs(partial, p.nsplit, nw, partial + (size_t)p.nsplit * nw, dw, s, "tmf_conv3d_wgrad_wino(reduce)",
+                                ref ? cin : 0, ref ? cout : 0);
     }
+    auto k = conv3d_wino_wgrad_kernel;
+    if ((rc = tmf_allow_lds(k, WG_LDS_BYTES, "tmf_conv3d_wgrad_wino"))) return rc;
+    hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(NTHR), WG_LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,
+                       p.tilesD, p.tilesH, p.tilesW, p.nbricks, p.per, p.ncob);
     if ((rc = tmf_launch_result("tmf_conv3d_wgrad_wino"))) return rc;
     float* scratch = partial + (size_t)p.nsplit * n;
     float* du = scratch + (size_t)tmf_reduce_groups(p.nsplit) * n;
     if ((rc = tmf_reduce_slabs(partial, p.nsplit, n, scratch, du, s, "tmf_conv3d_wgrad_wino(reduce)"))) return rc;
     hipLaunchKernelGGL(wino_wgrad_finish_kernel, dim3((unsigned)tmf_cdiv((long)cin * cout, 256L)), dim3(256), 0, s,
-                       (const float*)du, dw, cin, cout, p.ncob, dw_layout == TMF_DW_REFERENCE ? 1 : 0, one_wave);
+                       (const float*)du, dw, cin, cout, p.ncob, dw_layout == TMF_DW_REFERENCE ? 1 : 0);
     return tmf_launch_result("tmf_conv3d_wgrad_wino(finish)");
 }
 

@@ -171,6 +171,17 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
     float* part = (float*)(base + p.off_part);
     const bool b16 = d->precision == TMF_PREC_BF16;
     const void* x = vol;
+    {   // the transformed weights of every Winograd block (forward and data-gradient layouts) in one launch
+        const float* pw[8]; float* pf[8]; float* pd[8]; int pco[8], pci[8];
+        int n = 0;
+        for (int l = 0; l < NL; ++l) {
+            const LayerPlan& L = p.L[l];
+            if (l == 0 || L.bf || L.sp || !(L.wgf || L.wgd)) continue;
+            pw[n] = prm->weight[l]; pf[n] = L.wgf ? (float*)(base + L.off_wf) : nullptr; pd[n] = L.wgd ? (float*)(base + L.off_wd) : nullptr;
+            pco[n] = L.cout; pci[n] = L.cin; ++n;
+        }
+        if (n > 0) TMF_TRY(tmf_pack_conv_weights_wino_multi(n, pw, pf, pd, pco, pci, stream));
+    }
     for (int l = 0; l < NL; ++l) {
         const LayerPlan& L = p.L[l];
         const Vecs v = vecs_of(base, L);
@@ -197,10 +208,7 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
             nblk = tmf_conv3d_split_stat_blocks(d->B, L.D, L.H, L.W);
             TMF_TRY(tmf_conv3d_fwd_split((const float*)x, wf, (float*)z, part, d->B, L.D, L.H, L.W, L.cin, L.cout, stream));
         } else {
-            if (L.wgf || L.wgd)
-                TMF_TRY(tmf_pack_conv_weights_wino(prm->weight[l], L.wgf ? (float*)wf : nullptr, L.wgd ? (float*)wd : nullptr,
-                                                   L.cout, L.cin, stream));
-            if (!L.wgf || !L.wgd)
+            if (!L.wgf || !L.wgd)                           // (the Winograd layouts of this block: packed above, all blocks in one launch)
                 TMF_TRY(tmf_pack_conv_weights(prm->weight[l], L.wgf ? nullptr : (float*)wf, L.wgd ? nullptr : (float*)wd, L.cout,
                                               L.cin, L.k * L.k * L.k, stream));
             if (L.wgf) {
