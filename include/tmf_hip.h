@@ -141,12 +141,15 @@ int    tmf_conv3d_wino_ok(int cin, int cout);
  * y = LeakyReLU(scale * conv(x, w) + shift), pool TMF_POOL_NONE | TMF_POOL_MAX2 (floor mode) applied before the store. */
 int    tmf_conv3d_fwd_wino_affine(const float* x, const float* u, const float* scale, const float* shift, float* y,
                                   int B, int D, int H, int W, int cin, int cout, int pool, float slope, void* stream);
-int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);
+int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);       /* rows of stat_partial: one per workgroup of the persistent
+                                                                       * kernel (= compute units; all rows are written), one per
+                                                                       * 4x8x8 brick with "wino_p" 0 */
+int    tmf_conv3d_wino_bricks(int B, int D, int H, int W);            /* bricks the forward kernel walks per 32 output channels */
 size_t tmf_conv3d_wino_weight_bytes(int cin, int cout);             /* 64 * cin * cout floats */
 int    tmf_conv_wino_mode(void);
 /* tmf_wino_p_mode(): tmf_set_option("wino_p", 0 | 1) / TMF_WINO_P — 1 (default): the three Winograd entries run their persistent
  * one-wave-per-SIMD kernels (conv3d_wino_p_kernel, conv3d_wino_wgrad_p_kernel; the forward picks per volume between 4x8x8
- * bricks of one sample and 4x4x4 bricks of four samples — tmf_conv3d_wino_stat_blocks() follows it); 0: the two-waves-per-
+ * bricks of one sample and 4x4x4 bricks of four samples — tmf_conv3d_wino_bricks() follows it); 0: the two-waves-per-
  * SIMD kernels of round 4.  Same results up to fp32 rounding of the output transform's order of additions. */
 int    tmf_wino_p_mode(void);
 /* Weight gradient in the same form: dU_p = V_p^T Z_p per position of the transformed tile (V = the forward's input transform of

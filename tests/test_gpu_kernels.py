@@ -1257,9 +1257,14 @@ def test_conv3d_winograd_form(shape):
     zd, _, _ = ops.conv3d_raw(xg, ops.pack_weight(wg), cin, cout, 3, False)
     assert _relerr(z.cpu(), zd.cpu()) < 2e-6                                   # two fp32 roundings of the same sums
     n0_, n1_ = B * -(-D // 4) * -(-H // 8) * -(-W // 8), -(-B // 4) * -(-D // 4) * -(-H // 4) * -(-W // 4)
-    assert nblk == (n1_ if n1_ < n0_ and ops.wino_p_mode() else n0_) and tuple(part.shape) == (nblk, 2, cout)
+    from transmf_ad_amd import _lib
+    nbricks = _lib.query("tmf_conv3d_wino_bricks", B, D, H, W)
+    assert nbricks == (n1_ if n1_ < n0_ and ops.wino_p_mode() else n0_)
+    # one row of partials per workgroup of the persistent kernel (per compute unit), per brick with the other
+    assert nblk == (torch.cuda.get_device_properties(0).multi_processor_count if ops.wino_p_mode() else n0_)
+    assert tuple(part.shape) == (nblk, 2, cout)
     if shape[0] > 2:
-        assert nblk == n1_                                                      # (these shapes are here for the folded geometry)
+        assert nbricks == n1_                                                   # (these shapes are here for the folded geometry)
     s1, s2 = part[:, 0].double().sum(0).cpu(), part[:, 1].double().sum(0).cpu()
     zz = z.double().cpu()
     assert (s1 - zz.sum((0, 1, 2, 3))).abs().max().item() <= 2e-6 * zz.abs().sum((0, 1, 2, 3)).max().item()

@@ -249,14 +249,17 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
     assert lib.tmf_conv_wino_mode() == 3
     assert lib.tmf_conv3d_wino_ok(8, 32) and not lib.tmf_conv3d_wino_ok(8, 16) and not lib.tmf_conv3d_wino_ok(4, 32)
     assert lib.tmf_conv3d_wgrad_wino_ok(32, 64) and not lib.tmf_conv3d_wgrad_wino_ok(16, 32)
-    assert lib.tmf_conv3d_wino_stat_blocks(8, 48, 48, 48) == 8 * 12 * 6 * 6 and lib.tmf_conv3d_wino_stat_blocks(2, 7, 9, 13) == 2 * 2 * 2 * 2
+    assert lib.tmf_conv3d_wino_bricks(8, 48, 48, 48) == 8 * 12 * 6 * 6 and lib.tmf_conv3d_wino_bricks(2, 7, 9, 13) == 2 * 2 * 2 * 2
+    # statistic partials of the persistent kernel: one row per workgroup = compute unit, whatever the volume (256 without a device)
+    rows = lib.tmf_conv3d_wino_stat_blocks(8, 48, 48, 48)
+    assert 64 <= rows <= 1024 and lib.tmf_conv3d_wino_stat_blocks(2, 7, 9, 13) == rows and lib.tmf_conv3d_wino_stat_blocks(0, 4, 4, 4) == 0
     assert lib.tmf_conv3d_wino_weight_bytes(32, 64) == 64 * 32 * 64 * 4
     # conv2.0 at B = 8, 48^3: one (ci, co) block -> 256 slabs in 16 groups
     assert lib.tmf_wino_p_mode() == 1
-    assert lib.tmf_conv3d_wino_stat_blocks(8, 12, 12, 12) == 2 * 3 * 3 * 3          # four samples x 4x4x4 bricks where that is fewer tiles
+    assert lib.tmf_conv3d_wino_bricks(8, 12, 12, 12) == 2 * 3 * 3 * 3               # four samples x 4x4x4 bricks where that is fewer tiles
     assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 32, 32) == (256 + 16) * 27 * 1024 * 4
     assert lib.tmf_set_option(b"wino_p", 0) == 0
-    assert lib.tmf_conv3d_wino_stat_blocks(8, 12, 12, 12) == 8 * 3 * 2 * 2
+    assert lib.tmf_conv3d_wino_bricks(8, 12, 12, 12) == 8 * 3 * 2 * 2 and lib.tmf_conv3d_wino_stat_blocks(8, 12, 12, 12) == 8 * 3 * 2 * 2
     assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 32, 32) == (256 + 16 + 1) * 64 * 1024 * 4
     assert lib.tmf_set_option(b"wino_p", 1) == 0
     assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 16, 32) == 0
@@ -272,9 +275,34 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
             size[mode] = lib.tmf_snet_saved_bytes(ctypes.byref(desc)), lib.tmf_snet_bwd_scratch_bytes(ctypes.byref(desc))
         per_layout = sum((64 - 27) * ci * co * 4 for ci, co in layers)     # every size here is a multiple of 256
         assert size[1][0] - size[0][0] == per_layout                       # data-gradient layouts
-        assert size[2][0] - size[1][0] == per_layout                       # + forward layouts
+        # (the statistic partials — one buffer, sized for the block with the most: rows per workgroup instead of per tile)
+        vols = [48, 48, 24, 24, 12]
+        c1 = lib.tmf_c1_blocks(8, 96, 96, 96, 32) * 2 * 32 * 4
+        part_d = max([c1] + [lib.tmf_conv3d_stat_blocks(8, v, v, v, ci, co, 3) * 2 * co * 4 for v, (ci, co) in zip(vols, layers)])
+        part_w = max([c1] + [lib.tmf_conv3d_wino_stat_blocks(8, v, v, v) * 2 * co * 4 for v, (ci, co) in zip(vols, layers)])
+        assert size[2][0] - size[1][0] == per_layout + part_w - part_d     # + forward layouts
         assert size[3][0] == size[2][0] and size[3][1] >= size[2][1]       # (the weight-gradient slabs in backward's scratch: dw-sized
         #                                                                     per split with the one-wave kernel — no larger than the direct kernel's)
         assert lib.tmf_set_option(b"conv_wino", 4) != 0
     finally:
         lib.tmf_set_option(b"conv_wino", 3)
+
+
+def test_winograd_listing_has_no_use_of_registers_in_flight_and_no_store_data_overwrite(tmp_path):
+    """tools/asm_checks.py on a fresh gfx950 listing of conv3d_wino.hip (the library's own flags): the weight loads the
+    persistent kernels keep in flight to registers are not touched before their wait, and no wide store's data registers are
+    overwritten in the slot behind it (the MI355X stores a wrong value there; LLVM exempts the SGPR-soffset form)."""
+    import subprocess
+    import sys
+    from transmf_ad_amd import build
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import asm_checks
+    out = str(tmp_path / "wino.s")
+    flags = [f for f in build.FLAGS if f != "-fPIC"]
+    subprocess.run([build._hipcc(), "-x", "hip", "-S", "--cuda-device-only", os.path.join(build.CSRC, "conv3d_wino.hip"), "-o", out] + flags,
+                   check=True, capture_output=True, timeout=600)
+    loads, uses = asm_checks.inflight_uses(out, "wino")
+    stores, overwrites = asm_checks.store_data_overwrites(out, "wino")
+    assert loads >= 100 and stores >= 40                                   # (the check has seen the kernels)
+    assert not uses, uses[:5]
+    assert not overwrites, overwrites[:5]

@@ -83,6 +83,15 @@ __device__ __forceinline__ void blds16(int voff, i32x4 rsrc, int soff, unsigned 
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base) : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// A buffer_store_dwordx4 reads its data registers AFTER it has issued: a v_pk_* that overwrites them in the very next slot
+// corrupted the second register of the pair in lanes 12-15 of every row of 16 (measured on gfx950 with an SGPR soffset, the
+// case LLVM's hazard recognizer exempts; tools/asm_checks.py finds the pattern in a listing).  One wait state after a store
+// whose data dies right behind it:
+__device__ __forceinline__ void store_guard() {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 0");
+    __builtin_amdgcn_sched_barrier(0);
+}
 
 #ifdef TMF_WINO_TRACE
 // instrumented build (tools/wino_trace.py): shader-clock stamps of every block (start, end, hardware ids) and of the phases of one
@@ -577,7 +586,8 @@ template <int MODE, int GEOM>
 __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
     const float* __restrict__ x, const float* __restrict__ u, float* __restrict__ z, float* __restrict__ stat_partial,
     int B, int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int item0, int nitems,
-    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr, float slope = 0.f, int pool = 0) {
+    const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr, float slope = 0.f, int pool = 0,
+    int stat_rows = 0, int stat_accum = 0) {
     constexpr bool STATS = MODE == 1;
     using GM = PGeom<GEOM>;
     using PL = PLds<GEOM>;
@@ -828,6 +838,37 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) T1(0, k);
 
+    // BatchNorm statistic partials (MODE 1): ONE row [2][Cout] per workgroup.  A lane keeps its 4 + 4 sums over the items of a
+    // channel group in registers; the LDS reduction over the workgroup and the store happen only where the group changes (the
+    // items of a workgroup are ordered by group) and at the end — per item this is 32 packed adds, no barrier.
+    f32x4 st1 = {0.f, 0.f, 0.f, 0.f}, st2 = {0.f, 0.f, 0.f, 0.f};
+    int st_n0 = -1;                                         // channel group the sums belong to (-1: none yet)
+    unsigned st_seen = 0;                                   // groups this workgroup has written
+    auto stat_flush = [&]() {                               // sums of group st_n0 -> this workgroup's row
+        const int cq_ = lane & 7, src = wave * 8 + (lane >> 3);
+        __syncthreads();                                    // (red may still be read by the previous flush)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[src * 33 + 4 * cq_ + e] = st1[e];
+            red[(32 + src) * 33 + 4 * cq_ + e] = st2[e];
+        }
+        __syncthreads();
+        // thread (which, channel, part) adds 8 sources in a fixed order, a quad of lanes its four parts with two DPP steps
+        const int part = tid & 3, ch = (tid >> 2) & 31, which = tid >> 7;
+        float a = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) a += red[(which * 32 + part * 8 + m) * 33 + ch];
+        a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+        a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+        if (part == 0) {
+            float* dst = stat_partial + ((size_t)blockIdx.x * 2 + which) * Cout + st_n0 + ch;
+            *dst = (stat_accum || ((st_seen >> (st_n0 >> 5)) & 1)) ? *dst + a : a;
+        }
+        st_seen |= 1u << (st_n0 >> 5);
+        st1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        st2 = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+
     int g = 0;                                              // chunk of the stream
     for (int it = 0; it < my_items; ++it) {
         const i32x4 ce = tab[2 * it];
@@ -991,7 +1032,10 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
             const int ns = B - b < BS ? B - b : BS;
             const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, ns * D * H * W * Cout * 4, 0x00020000);
             const bool full = d0 + BD <= D && h0 + BH <= H && w0 + BW <= W && b + BS <= B;
-            f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2q = {0.f, 0.f, 0.f, 0.f};
+            if (STATS && stat_partial != nullptr && st_n0 != n0) {    // a new channel group: the previous one's sums leave
+                if (st_n0 >= 0) stat_flush();
+                st_n0 = n0;
+            }
             // address = this lane's part (st_lane: tile and channel quad, fixed for the kernel) + the brick's corner and the row
             // (d, h) of the store in the scalar offset: one s_add per store
             const int st_item = (((d0 * H + h0) * W + w0) * Cout + n0) * 4;
@@ -1015,42 +1059,30 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tmf_u32x4, v), zr, row_ok ? voff : OOB, st_item + j * st_j + (dd * H + ho) * W * Cout * 4, 0);
                             }
                             if (STATS) {
+                                store_guard();
                                 if (!FULL) v = (row_ok && w_ok) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-                                s1 += v;
-                                s2q += v * v;
+                                st1 += v;
+                                st2 += v * v;
                             }
                         }
             };
             if (full) put(std::true_type{});
             else put(std::false_type{});
             TRQ(23);
-            if constexpr (STATS) {
-                if (stat_partial != nullptr) {
-                    // per-channel sums over the brick: every lane leaves its 4 + 4 partial sums in LDS, [which][source 32][channel 32 + 1]
-                    // (source = wave * 8 + lane >> 3); thread (which, channel, part) adds 8 sources in a fixed order and a quad of
-                    // lanes adds its four parts with two DPP steps — 24 ds_bpermute round trips were 1 100 cycles here
-                    {
-                        const int src = wave * 8 + (lane >> 3);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            red[src * 33 + 4 * cq + e] = s1[e];
-                            red[(32 + src) * 33 + 4 * cq + e] = s2q[e];
-                        }
-                    }
-                    __syncthreads();
-                    {
-                        const int part = tid & 3, ch = (tid >> 2) & 31, which = tid >> 7;
-                        float a = 0.f;
-#pragma unroll
-                        for (int m = 0; m < 8; ++m) a += red[(which * 32 + part * 8 + m) * 33 + ch];
-                        a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-                        a += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, a), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-                        if (part == 0) stat_partial[((size_t)brick * 2 + which) * Cout + n0 + ch] = a;
-                    }
-                }
-            }
         }
         TRQ(24);
+    }
+    if constexpr (STATS) {
+        if (stat_partial != nullptr) {
+            if (st_n0 >= 0) stat_flush();
+            if (!stat_accum) {
+                // the channel groups this workgroup never saw, and (workgroup 0) the rows no workgroup owns: zeros
+                for (int ng = 0; ng < Cout / 32; ++ng)
+                    if (!((st_seen >> ng) & 1) && tid < 64) stat_partial[((size_t)blockIdx.x * 2 + (tid >> 5)) * Cout + ng * 32 + (tid & 31)] = 0.f;
+                if (blockIdx.x == 0)
+                    for (int i = (int)gridDim.x * 2 * Cout + tid; i < stat_rows * 2 * Cout; i += PN) stat_partial[i] = 0.f;
+            }
+        }
     }
 }
 
@@ -1720,6 +1752,7 @@ int launch_wino_p_g(const char* what, const float* x, const float* u, float* z, 
     const long nbricks = wino_p_bricks(GEOM, B, D, H, W);
     const long nitems = nbricks * (cout / 32);
     TMF_REQUIRE(nitems < (1L << 30), TMF_E_SHAPE, "%s: too many bricks", what);
+    TMF_REQUIRE(cout <= 1024, TMF_E_SHAPE, "%s: more than 32 groups of output channels", what);
     auto k = conv3d_wino_p_kernel<MODE, GEOM>;
     int rc;
     if ((rc = tmf_allow_lds(k, PLds<GEOM>::BYTES, what))) return rc;
@@ -1729,7 +1762,7 @@ int launch_wino_p_g(const char* what, const float* x, const float* u, float* z, 
         const long n = nitems - i0 < per_launch ? nitems - i0 : per_launch;
         const int grid = (int)(n < ncu ? n : ncu);
         hipLaunchKernelGGL(k, dim3(grid), dim3(PN), PLds<GEOM>::BYTES, stream, x, u, z, stat_partial, B, D, H, W, cin, cout,
-                           tilesD, tilesH, tilesW, (int)nbricks, (int)i0, (int)n, scale, shift, slope, pool);
+                           tilesD, tilesH, tilesW, (int)nbricks, (int)i0, (int)n, scale, shift, slope, pool, ncu, i0 > 0 ? 1 : 0);
         if ((rc = tmf_launch_result(what))) return rc;
     }
     return TMF_OK;
@@ -1769,8 +1802,16 @@ int tmf_conv_wino_set(int v) { g_conv_wino = v; return TMF_OK; }
 
 extern "C" int tmf_conv3d_wino_ok(int cin, int cout) { return cin > 0 && cout > 0 && cin % 8 == 0 && cout % 32 == 0; }
 
-// rows of the statistic partials = bricks of the forward kernel tmf_conv3d_fwd_wino takes for this volume
+// rows of the statistic partials of tmf_conv3d_fwd_wino: one per workgroup of the persistent kernel (= compute units of the
+// device: every row is written, those of workgroups a small launch does not have with zeros), one per brick with the
+// two-waves-per-SIMD kernel
 extern "C" int tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (wino_p_mode()) return wino_cu_count();
+    return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
+}
+// bricks (items per group of 32 output channels) of the persistent forward kernel for a volume
+extern "C" int tmf_conv3d_wino_bricks(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     if (wino_p_mode()) return (int)wino_p_bricks(wino_p_geom(B, D, H, W), B, D, H, W);
     return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
