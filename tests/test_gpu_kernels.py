@@ -1299,6 +1299,9 @@ WINO_WGRAD_SHAPES = [
     (2, 6, 10, 12, 64, 32),         # two input-channel blocks
     (3, 12, 12, 12, 128, 64),       # more (ci, co) blocks than slabs per block
     (2, 24, 24, 24, 32, 32),        # 256 slabs -> two-stage reduction
+    (8, 12, 12, 12, 128, 256),      # conv4.0 of the 96^3 input: stages of two samples x 4x4x4 voxels (27 per pair instead of 36)
+    (5, 6, 7, 12, 32, 32),          # ... an odd batch (the last pair holds one sample), ragged d and h
+    (4, 9, 5, 4, 32, 64),           # ... a volume one such brick wide
 ]
 
 

@@ -258,6 +258,8 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
     assert lib.tmf_wino_p_mode() == 1
     assert lib.tmf_conv3d_wino_bricks(8, 12, 12, 12) == 2 * 3 * 3 * 3               # four samples x 4x4x4 bricks where that is fewer tiles
     assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 32, 32) == (256 + 16) * 27 * 1024 * 4
+    # conv4.0 (12^3): 4 pairs of samples x 27 bricks = 108 stages in 8 slabs of 14 per (ci, co) block (18 half bricks per sample: 144 in 8 of 18)
+    assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 12, 12, 12, 128, 256) == (8 + 1) * 27 * 128 * 256 * 4
     assert lib.tmf_set_option(b"wino_p", 0) == 0
     assert lib.tmf_conv3d_wino_bricks(8, 12, 12, 12) == 8 * 3 * 2 * 2 and lib.tmf_conv3d_wino_stat_blocks(8, 12, 12, 12) == 8 * 3 * 2 * 2
     assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 32, 32) == (256 + 16 + 1) * 64 * 1024 * 4

@@ -1259,10 +1259,10 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_wgrad_kernel(
 //     ph 0, 3; P1 multiplies ph 0, 3 while the rows 1, 2 of the NEXT step become its ph 1, 2 — no second copy of the operands,
 //     across stage boundaries too (one barrier per stage of 16 tiles, the stage after next in flight by LDS-DMA); every row
 //     is read a group of MFMAs before it is used.
-template <int C>
-__device__ __forceinline__ f32x2 lds_pair(unsigned base_even, unsigned base_odd) {      // floats at 128 C and 128 C + 512 bytes
+template <int C, int PAIR = 2>
+__device__ __forceinline__ f32x2 lds_pair(unsigned base_even, unsigned base_odd) {      // floats at 128 C and 128 C + 256 PAIR bytes
     f32x2 d;
-    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"((C & 1) ? base_odd : base_even), "n"(C >> 1), "n"((C >> 1) + 2));
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"((C & 1) ? base_odd : base_even), "n"(C >> 1), "n"((C >> 1) + PAIR));
     return d;
 }
 __device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -1274,11 +1274,28 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 constexpr int WPN = 256;                                          // threads: 4 waves, wave = pd
-constexpr int WP_XDMA = WX_SLOTS / WPN, WP_ZDMA = WZ_SLOTS / WPN; // 12 + 4 LDS-DMA instructions per wave and stage
+// The stage of 16 tiles (a lane's pair = two tiles one ds_read2st64 apart) in two geometries, as in the forward:
+//   GEOM 0: 2 x 2 x 4 tiles of one sample — a 4x4x8 half brick, halo [6][6][10] voxels, the pair 4 voxels apart in w;
+//   GEOM 1: 2 x 2 x 2 tiles of TWO samples — a 4x4x4 brick of each, halo [6][6][sample 2][6] (the pair = the two samples, 6 voxel
+//           rows apart), dz [4][4][sample 2][4]: a 12^3 volume is 27 such bricks instead of 18 half bricks a third of whose w
+//           range lies outside (conv4.0 of the 96^3 input).  The main loop differs in three constants.
+template <int GEOM> struct WGeomP {
+    static constexpr int ROWW = GEOM == 0 ? 10 : 12, PLANE = 6 * ROWW, PAIR = GEOM == 0 ? 2 : 3, BW = GEOM == 0 ? 8 : 4, BS = GEOM == 0 ? 1 : 2;
+    static constexpr int XREAL = 36 * ROWW * 8;                           // 16-byte pieces of the halo
+    static constexpr int XDMA = (XREAL + 4 * 64 - 1) / (4 * 64);          // LDS-DMA instructions per wave and stage: 12 / 14 (+ 4 for dz)
+    static constexpr int XSLOTS = XDMA * WPN;
+    static constexpr int BUF_BYTES = (XSLOTS + WZ_SLOTS) * 16;            // 64 KB / 72 KB per stage buffer
+    static constexpr size_t LDS_BYTES = 2 * (size_t)BUF_BYTES;
+};
+constexpr int WP_ZDMA = WZ_SLOTS / WPN;
 
+template <int GEOM>
 __global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
     const float* __restrict__ x, const float* __restrict__ dz, float* __restrict__ partial,
-    int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int per_split, int ncob) {
+    int B, int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int per_split, int ncob) {
+    using WG = WGeomP<GEOM>;
+    constexpr int WP_XDMA = WG::XDMA, WX_SLOTS = WG::XSLOTS, WX_REAL = WG::XREAL, WBUF_BYTES = WG::BUF_BYTES;
+    constexpr int ROWW = WG::ROWW, PLANE = WG::PLANE, PAIR = WG::PAIR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
     const int tid = threadIdx.x;
@@ -1297,16 +1314,16 @@ __global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
 #pragma unroll
     for (int q = 0; q < WP_XDMA; ++q) {
         const int e = (q * 4 + wave) * 64 + lane, v = e >> 3, piece = e & 7;
-        const int hd = v / 60, hh = (v / 10) % 6, hw = v % 10;
-        relx[q] = ((hd * H + hh) * W + hw) * Cin * 4 + piece * 16;
-        mx[q] = e < WX_REAL ? (1 << hd) | (1 << (8 + hh)) | (1 << (16 + hw)) : (1 << 30);
+        const int hd = v / PLANE, hh = (v / ROWW) % 6, hr = v % ROWW, s_ = GEOM == 0 ? 0 : hr / 6, hw = GEOM == 0 ? hr : hr % 6;
+        relx[q] = (((s_ * D + hd) * H + hh) * W + hw) * Cin * 4 + piece * 16;
+        mx[q] = e < WX_REAL ? (1 << hd) | (1 << (8 + hh)) | (1 << (16 + hw)) | (1 << (26 + s_)) : (1 << 30);
     }
 #pragma unroll
     for (int q = 0; q < WP_ZDMA; ++q) {
         const int e = (q * 4 + wave) * 64 + lane, v = e >> 3, piece = e & 7;
-        const int od = v >> 5, oh = (v >> 3) & 3, ow = v & 7;
-        relz[q] = ((od * H + oh) * W + ow) * Cout * 4 + piece * 16;
-        mz[q] = (1 << od) | (1 << (8 + oh)) | (1 << (16 + ow));
+        const int od = v >> 5, oh = (v >> 3) & 3, s_ = GEOM == 0 ? 0 : (v >> 2) & 1, ow = GEOM == 0 ? v & 7 : v & 3;
+        relz[q] = (((s_ * D + od) * H + oh) * W + ow) * Cout * 4 + piece * 16;
+        mz[q] = (1 << od) | (1 << (8 + oh)) | (1 << (16 + ow)) | (1 << (26 + s_));
     }
     // the half brick the next copy belongs to: decoded once (stage_first), then advanced by one (stage_next: no divisions)
     int sbw = 0, sbh = 0, sbd = 0, sb = 0;
@@ -1327,23 +1344,24 @@ __global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
     int s_xcorner = 0, s_zcorner = 0, s_vmx = 0, s_vmz = 0;
     unsigned s_base = 0;
     auto stage_setup = [&](int buf) {
-        const int b = sb, d0 = sbd * 4, h0 = sbh * 4, w0 = sbw * 8;
-        s_xr = make_rsrc(x + (size_t)b * D * H * W * Cin, (unsigned)(D * H * W * Cin * 4));
-        s_zr = make_rsrc(dz + (size_t)b * D * H * W * Cout, (unsigned)(D * H * W * Cout * 4));
+        const int b = sb * WG::BS, d0 = sbd * 4, h0 = sbh * 4, w0 = sbw * WG::BW;
+        const int ns = B - b < WG::BS ? B - b : WG::BS;                  // (a last pair of one sample: the other's lanes are masked)
+        s_xr = make_rsrc(x + (size_t)b * D * H * W * Cin, (unsigned)(ns * D * H * W * Cin * 4));
+        s_zr = make_rsrc(dz + (size_t)b * D * H * W * Cout, (unsigned)(ns * D * H * W * Cout * 4));
         s_xcorner = (((d0 - 1) * H + (h0 - 1)) * W + (w0 - 1)) * Cin * 4 + ci0 * 4;       // (negative at the faces)
         s_zcorner = ((d0 * H + h0) * W + w0) * Cout * 4 + co0 * 4;
         auto range = [](int lo, int hi) { return ((1 << hi) - 1) & ~((1 << lo) - 1); };
         auto mn = [](int a, int b_) { return a < b_ ? a : b_; };
         s_vmx = range(d0 == 0 ? 1 : 0, mn(6, D - d0 + 1)) | (range(h0 == 0 ? 1 : 0, mn(6, H - h0 + 1)) << 8) |
-                (range(w0 == 0 ? 1 : 0, mn(10, W - w0 + 1)) << 16);
-        s_vmz = range(0, mn(4, D - d0)) | (range(0, mn(4, H - h0)) << 8) | (range(0, mn(8, W - w0)) << 16);
+                (range(w0 == 0 ? 1 : 0, mn(WG::BW + 2, W - w0 + 1)) << 16) | (range(0, ns) << 26);
+        s_vmz = range(0, mn(4, D - d0)) | (range(0, mn(4, H - h0)) << 8) | (range(0, mn(WG::BW, W - w0)) << 16) | (range(0, ns) << 26);
         s_base = lds0 + buf * WBUF_BYTES + wave * 1024;
     };
     auto stage_part = [&](int part) {
         if (P_ABL & 4) return;
 #pragma unroll
         for (int q = 0; q < WP_XDMA; ++q)
-            if (q / 4 == part) blds16((mx[q] & s_vmx) == mx[q] ? relx[q] + s_xcorner : OOB, s_xr, 0, s_base + q * 4096);
+            if (q * 3 / WP_XDMA == part) blds16((mx[q] & s_vmx) == mx[q] ? relx[q] + s_xcorner : OOB, s_xr, 0, s_base + q * 4096);
 #pragma unroll
         for (int q = 0; q < WP_ZDMA; ++q)
             if (3 == part) blds16((mz[q] & s_vmz) == mz[q] ? relz[q] + s_zcorner : OOB, s_zr, 0, s_base + WX_SLOTS * 16 + q * 4096);
@@ -1365,7 +1383,7 @@ __global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
     // LDS byte addresses of this lane's tile pair (w origins 2 hsel and 2 hsel + 4) in buffer 0: x plane da / db and dz
     // (ds_read2st64 offsets count 256 bytes: the odd 128-byte rows go through a base 128 bytes further)
     const unsigned lx = lds0 + (2 * hsel * 32 + l31) * 4;
-    const unsigned xa0 = lx + da * 60 * 128, xb0 = lx + db * 60 * 128, zz0 = lx + WX_SLOTS * 16;
+    const unsigned xa0 = lx + da * PLANE * 128, xb0 = lx + db * PLANE * 128, zz0 = lx + WX_SLOTS * 16;
     f32x2 A[16], Bv[16];                            // [ph][pw] -> {tile set 0, tile set 1}
 #if P_ABL & 1
     for (int i = 0; i < 16; ++i) { A[i] = f32x2{(float)tid, 1.f}; Bv[i] = f32x2{(float)lane, 2.f}; }
@@ -1382,11 +1400,11 @@ __global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
     // (row_issue), then d combination -> w transform (row_finish).  The reads are opaque to the compiler: wait + pin before use.
     f32x2 ra[4], rb[4];                             // the row in flight
     auto row_issue = [&](unsigned ea, unsigned eb, auto c_c) {
-        constexpr int Cb = decltype(c_c)::value;    // row offset in 128-byte units: ((2 td) * 60 + (2 th + i) * 10)
+        constexpr int Cb = decltype(c_c)::value;    // row offset in 128-byte units: ((2 td) * PLANE + (2 th + i) * ROWW)
         static_for<4>([&](auto k_c) {
             constexpr int K = decltype(k_c)::value;
-            ra[K] = lds_pair<Cb + K>(ea, ea + 128);
-            rb[K] = lds_pair<Cb + K>(eb, eb + 128);
+            ra[K] = lds_pair<Cb + K, PAIR>(ea, ea + 128);
+            rb[K] = lds_pair<Cb + K, PAIR>(eb, eb + 128);
         });
     };
     auto row_finish = [&](f32x2 (&u)[4]) {
@@ -1410,7 +1428,7 @@ __global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
         if (P_ABL & 1) return;
         const unsigned off = par * WBUF_BYTES;
         if (part == 0) {
-            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * 60 + (2 * THs + 1) * 10>{});
+            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * PLANE + (2 * THs + 1) * ROWW>{});
             static_for<2>([&](auto ho_c) {
                 static_for<2>([&](auto wo_c) {
                     constexpr int HO = decltype(ho_c)::value, WO = decltype(wo_c)::value;
@@ -1423,7 +1441,7 @@ __global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
             row_finish(u1);
             pin4(yq[0][0][0], yq[0][0][1], yq[0][1][0], yq[0][1][1]);
             pin4(yq[1][0][0], yq[1][0][1], yq[1][1][0], yq[1][1][1]);
-            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * 60 + (2 * THs + 2) * 10>{});
+            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * PLANE + (2 * THs + 2) * ROWW>{});
 #pragma unroll
             for (int ho = 0; ho < 2; ++ho)
 #pragma unroll
@@ -1452,12 +1470,12 @@ __global__ __launch_bounds__(WPN) void conv3d_wino_wgrad_p_kernel(
         if (P_ABL & 1) return;
         const unsigned off = par * WBUF_BYTES;
         if (part == 0) {
-            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * 60 + (2 * THs + 0) * 10>{});
+            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * PLANE + (2 * THs + 0) * ROWW>{});
             zrows(zd[0][0], zd[0][1], 0, zd[1][0], zd[1][1], 3);
             pin4(Bv[0], Bv[1], Bv[2], Bv[3]); pin4(Bv[12], Bv[13], Bv[14], Bv[15]);
         } else if (part == 1) {
             row_finish(v0);
-            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * 60 + (2 * THs + 3) * 10>{});
+            row_issue(xa0 + off, xb0 + off, std::integral_constant<int, (2 * TDs) * PLANE + (2 * THs + 3) * ROWW>{});
             {
                 f32x2 d[4];
                 pk_sub4(d, v0, u2);
@@ -1628,11 +1646,22 @@ __global__ __launch_bounds__(256) void wino_wgrad_finish_kernel(const float* __r
             }
 }
 
-struct WinoWgPlan { int tilesD, tilesH, tilesW, nbricks, nblk, ncob, nsplit, per; };
+int wino_p_mode();
+struct WinoWgPlan { int geom, tilesD, tilesH, tilesW, nbricks, nblk, ncob, nsplit, per; };
 WinoWgPlan plan_wino_wgrad(int B, int D, int H, int W, int cin, int cout) {
     WinoWgPlan p;
     p.tilesD = tmf_cdiv(D, 4); p.tilesH = tmf_cdiv(H, 4); p.tilesW = tmf_cdiv(W, 8);
     p.nbricks = B * p.tilesD * p.tilesH * p.tilesW;
+    p.geom = 0;
+    // the persistent kernel's second geometry (stages of two samples x 4x4x4 voxels) where that is fewer stages; both samples sit
+    // behind one buffer resource with 32-bit byte offsets
+    const long two = 2L * D * H * W * (cin > cout ? cin : cout) * 4;
+    const int nb1 = tmf_cdiv(B, 2) * p.tilesD * p.tilesH * tmf_cdiv(W, 4);
+    if (wino_p_mode() && nb1 < p.nbricks && two < (1L << 31)) {
+        p.geom = 1;
+        p.tilesW = tmf_cdiv(W, 4);
+        p.nbricks = nb1;
+    }
     p.ncob = cout / 32;
     p.nblk = (cin / 32) * p.ncob;
     int ns = p.nblk >= 256 ? 1 : 256 / p.nblk;             // one round of workgroups over the 256 CUs
@@ -1915,9 +1944,10 @@ extern "C" int tmf_conv3d_wgrad_wino(const float* x, const float* dz, float* dw,
     const long n = (long)p.nblk * 64 * 1024;
     int rc;
     if (wino_p_mode()) {
-        auto k = conv3d_wino_wgrad_p_kernel;
-        if ((rc = tmf_allow_lds(k, WG_LDS_BYTES, "tmf_conv3d_wgrad_wino"))) return rc;
-        hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(WPN), WG_LDS_BYTES, s, x, dz, partial, D, H, W, cin, cout,
+        auto k = p.geom ? conv3d_wino_wgrad_p_kernel<1> : conv3d_wino_wgrad_p_kernel<0>;
+        const size_t lds = p.geom ? WGeomP<1>::LDS_BYTES : WGeomP<0>::LDS_BYTES;
+        if ((rc = tmf_allow_lds(k, lds, "tmf_conv3d_wgrad_wino"))) return rc;
+        hipLaunchKernelGGL(k, dim3(p.nsplit, p.nblk), dim3(WPN), lds, s, x, dz, partial, B, D, H, W, cin, cout,
                            p.tilesD, p.tilesH, p.tilesW, p.nbricks, p.per, p.ncob);
         if ((rc = tmf_launch_result("tmf_conv3d_wgrad_wino"))) return rc;
         // the slabs are dw's own [27][cin][cout]: the (fp64, fixed-order) reduction writes the result in either layout
