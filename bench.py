@@ -95,9 +95,14 @@ def wino_fwd_bricks(B, D, H, W):
 
 def wino_exec_flops(kind, B, D, H, W, ci, co):
     """Matrix flops a Winograd launch EXECUTES: 2 * 64 products per 2x2x2 tile, input and output channel, over the PADDED bricks
-    (forward / data gradient: 32 tiles per brick, wino_fwd_bricks; weight gradient: 4x4x8 half bricks = 16 tiles)."""
+    (forward / data gradient: 32 tiles per brick, wino_fwd_bricks; weight gradient: stages of 16 tiles — 4x4x8 voxels of one
+    sample or, where that is fewer stages, 4x4x4 voxels of two samples: csrc/conv3d_wino.hip plan_wino_wgrad)."""
     if kind == "wgrad":
-        return 2.0 * 64 * ci * co * 16 * B * _cd(D, 4) * _cd(H, 4) * _cd(W, 8)
+        s0 = B * _cd(D, 4) * _cd(H, 4) * _cd(W, 8)
+        s1 = _cd(B, 2) * _cd(D, 4) * _cd(H, 4) * _cd(W, 4)
+        if os.environ.get("TMF_WINO_P", "1") != "0" and s1 < s0:
+            s0 = s1
+        return 2.0 * 64 * ci * co * 16 * s0
     return 2.0 * 64 * ci * co * 32 * wino_fwd_bricks(B, D, H, W)
 
 
@@ -125,7 +130,7 @@ def _pmc_traffic(kernel, precision, storage, B, vol):
     """HBM bytes per launch of a kernel instance from the committed rocprofv3 --pmc passes (counters cannot be read
     live): profiles/r03_pmc_traffic.json = {"precision|storage|B|DxHxW": {kernel instance: {"hbm_bytes_per_launch": ...}}};
     None for configurations that were not profiled."""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):          # newest committed pass first
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):          # newest committed pass first
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 tab = json.load(f).get(f"{precision}|{storage}|{B}|{'x'.join(map(str, vol))}", {})
@@ -170,8 +175,10 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
     output voxel; tensors read + written once, at the storage width the step really uses)."""
     dim = 128
     rows = []
-    # the forward / data-gradient kernel the library's default takes (conv3d_wino.hip: the persistent one-wave-per-SIMD form)
-    wino_fwd_name = "conv3d_wino_p_kernel" if os.environ.get("TMF_WINO_P", "1") != "0" else "conv3d_wino_kernel"
+    # the Winograd instances as a kernel trace names them (conv3d_wino.hip: the persistent one-wave-per-SIMD kernels and their
+    # brick geometry per volume)
+    def wino_name(D, H, W, stats):
+        return _lib.query("tmf_conv3d_wino_kernel_name", B, D, H, W, stats).decode()
     b16 = precision == "bf16"
     s16 = b16 and storage == "bf16"
     adt = torch.bfloat16 if s16 else torch.float32
@@ -205,12 +212,13 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             wino = ops.conv_wino_mode() if precision == "fp32" else 0       # as the step runs them (snet_path.hip make_plan)
             if wino >= 2 and ops.wino_ok(ci, co):
                 uf, _ = ops.pack_weights_wino(w, True, False)
-                fns = (("fwd", wino_fwd_name + "<1>", lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
+                fns = (("fwd", wino_name(D, H, W, 1), lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
             if wino >= 1 and ops.wino_ok(co, ci):
                 _, ud = ops.pack_weights_wino(w, False, True)
-                fns = (fns[0], ("dgrad", wino_fwd_name + "<0>", lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
+                fns = (fns[0], ("dgrad", wino_name(D, H, W, 0), lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
             if wino >= 3 and ops.wgrad_wino_ok(ci, co):
-                fns = fns[:2] + (("wgrad", "conv3d_wino_wgrad_kernel", lambda: ops.conv3d_wgrad_wino(x, dz, ci, co)),)
+                fns = fns[:2] + (("wgrad", _lib.query("tmf_conv3d_wgrad_wino_kernel_name", B, D, H, W, ci, co).decode(),
+                                 lambda: ops.conv3d_wgrad_wino(x, dz, ci, co)),)
             if precision == "fp32x":      # forward / data gradient as the step runs them: six bf16 partial products per fp32 product
                 w3f = ops.split3_bf16(w.permute(2, 3, 4, 0, 1).contiguous())
                 w3d = ops.split3_bf16(w.flip(2, 3, 4).permute(2, 3, 4, 1, 0).contiguous())

@@ -145,6 +145,8 @@ int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);       /* rows of
                                                                        * kernel (= compute units; all rows are written), one per
                                                                        * 4x8x8 brick with "wino_p" 0 */
 int    tmf_conv3d_wino_bricks(int B, int D, int H, int W);            /* bricks the forward kernel walks per 32 output channels */
+const char* tmf_conv3d_wino_kernel_name(int B, int D, int H, int W, int stats);        /* the instance a kernel trace shows (as */
+const char* tmf_conv3d_wgrad_wino_kernel_name(int B, int D, int H, int W, int cin, int cout);   /* tmf_conv3d_fwd_kernel_name) */
 size_t tmf_conv3d_wino_weight_bytes(int cin, int cout);             /* 64 * cin * cout floats */
 int    tmf_conv_wino_mode(void);
 /* tmf_wino_p_mode(): tmf_set_option("wino_p", 0 | 1) / TMF_WINO_P — 1 (default): the three Winograd entries run their persistent

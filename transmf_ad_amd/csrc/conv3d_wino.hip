@@ -470,7 +470,7 @@ __global__ __launch_bounds__(NTHR) void conv3d_wino_kernel(
 #define P_BSTAGE 2
 #endif
 #ifndef P_ABL               // timing ablations (tools/build_variant.py --flags=-DP_ABL=n; results are wrong with any bit set):
-#define P_ABL 0             // 1 no input transform, 2 no weight loads, 4 no halo copies, 8 no epilogue, 16 no MFMAs
+#define P_ABL 0             // 1 no input transform, 2 no weight loads, 4 no halo copies, 8 no epilogue, 16 no MFMAs, 128 no statistic sums, 256 no store_guard
 #endif
 constexpr int PN = 256;                                           // threads: 4 waves, wave = pd
 // The 32 tiles of an item, two geometries:
@@ -1058,8 +1058,8 @@ __global__ __launch_bounds__(PN) void conv3d_wino_p_kernel(
                             } else {
                                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tmf_u32x4, v), zr, row_ok ? voff : OOB, st_item + j * st_j + (dd * H + ho) * W * Cout * 4, 0);
                             }
-                            if (STATS) {
-                                store_guard();
+                            if (STATS && !(P_ABL & 128)) {
+                                if (!(P_ABL & 256)) store_guard();
                                 if (!FULL) v = (row_ok && w_ok) ? v : f32x4{0.f, 0.f, 0.f, 0.f};
                                 st1 += v;
                                 st2 += v * v;
@@ -1844,6 +1844,19 @@ extern "C" int tmf_conv3d_wino_bricks(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     if (wino_p_mode()) return (int)wino_p_bricks(wino_p_geom(B, D, H, W), B, D, H, W);
     return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
+}
+
+// the kernel instance tmf_conv3d_fwd_wino (stats: with statistic partials) / tmf_conv3d_wgrad_wino launch for a volume, as a kernel
+// trace prints it (bench.py's roofline rows and tools/pmc_traffic.py's keys)
+extern "C" const char* tmf_conv3d_wino_kernel_name(int B, int D, int H, int W, int stats) {
+    if (!wino_p_mode()) return stats ? "conv3d_wino_kernel<1>" : "conv3d_wino_kernel<0>";
+    const int g = (B > 0 && D > 0 && H > 0 && W > 0) ? wino_p_geom(B, D, H, W) : 0;
+    return stats ? (g ? "conv3d_wino_p_kernel<1, 1>" : "conv3d_wino_p_kernel<1, 0>") : (g ? "conv3d_wino_p_kernel<0, 1>" : "conv3d_wino_p_kernel<0, 0>");
+}
+extern "C" const char* tmf_conv3d_wgrad_wino_kernel_name(int B, int D, int H, int W, int cin, int cout) {
+    if (!wino_p_mode()) return "conv3d_wino_wgrad_kernel";
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return "conv3d_wino_wgrad_p_kernel<0>";
+    return plan_wino_wgrad(B, D, H, W, cin, cout).geom ? "conv3d_wino_wgrad_p_kernel<1>" : "conv3d_wino_wgrad_p_kernel<0>";
 }
 
 extern "C" size_t tmf_conv3d_wino_weight_bytes(int cin, int cout) { return (size_t)64 * cin * cout * 4; }
