@@ -174,13 +174,20 @@ int    tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* wor
  * Fused first block: Conv3d(1->C,3x3x3) -> BatchNorm3d -> LeakyReLU -> MaxPool3d(2) (networks.py:21-26)
  * without materialising the conv output: every pass recomputes it from x (28 MB) instead of
  * reading/writing the 906 MB tensor.  x[b][d][h][w], w[27][C], pooled/dpool [b][D/2][H/2][W/2][C].
- *   tmf_c1_stats        -> stat_partial [tmf_c1_blocks()][2][C]  (reduce with tmf_bn_finalize)
+ *   tmf_c1_stats        -> stat_partial [tmf_c1_blocks()][2][C]  (reduce with tmf_bn_finalize over tmf_c1_stat_rows() rows).
+ *                          tmf_set_option("c1_gram", 0 | 1) / TMF_C1_GRAM, default 1: where the buffer holds its scratch the two
+ *                          sums come from the 63 pair sums of the INPUT volume (fp64) minus the directly evaluated one-voxel shell
+ *                          around it (csrc/conv1_gram.hip) — no convolution; rows 0 / 1 then hold the high / low float halves of
+ *                          the sums and tmf_c1_stat_rows() = 2.  0: one row per workgroup of the recomputing pass.
  *   tmf_c1_bn_pool_fwd  -> pooled
  *   tmf_c1_bwd_reduce   -> partial [tmf_c1_blocks()][2][C]       (reduce with tmf_bn_bwd_finalize)
  *   tmf_c1_bwd_wgrad    -> dw[27][C]   (coef from tmf_bn_bwd_finalize)
  * ---------------------------------------------------------------------------- */
 int    tmf_c1_blocks(int B, int D, int H, int W, int C);
 int    tmf_c1_stats(const float* x, const float* w, float* stat_partial, int B, int D, int H, int W, int C, void* stream);
+int    tmf_c1_stat_rows(int B, int D, int H, int W, int C, int nblk);    /* rows of stat_partial that carry the sums (nblk = tmf_c1_blocks()) */
+int    tmf_c1_stats_direct(const float* x, const float* w, float* stat_partial, int B, int D, int H, int W, int C, void* stream);   /* always
+                                                                          * the recomputing pass: all tmf_c1_blocks() rows (the fp32x mode) */
 int    tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* scale, const float* shift, float* pooled,
                           int B, int D, int H, int W, int C, float slope, void* stream);
 int    tmf_c1_bwd_reduce(const float* x, const float* w, const float* scale, const float* shift,

@@ -1360,3 +1360,61 @@ def test_conv3d_winograd_eval_block_in_one_pass(shape, pool):
     if pool:
         ref = F.max_pool3d(ref, 2, 2)
     assert _relerr(_ncdhw(y.cpu()), ref) < 3e-6
+
+
+C1_GRAM_SHAPES = [(2, 16, 24, 40, 32), (1, 9, 13, 35, 32), (3, 8, 8, 32, 16), (8, 48, 48, 48, 32), (2, 20, 17, 21, 8)]
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("shape", C1_GRAM_SHAPES)
+def test_first_block_statistics_from_input_pair_sums(shape, bf16):
+    """tmf_c1_stats with "c1_gram" 1 (csrc/conv1_gram.hip: sum z and sum z^2 of the Cin = 1 convolution from the 63 pair sums of the
+    input volume minus the directly evaluated shell) against the direct pass ("c1_gram" 0: conv1_fused_kernel<0>) and against fp64
+    torch: mean and 1 / std after tmf_bn_finalize, on a smooth volume with an offset (wide filters cancel there) and on noise;
+    two runs are bit-identical."""
+    from transmf_ad_amd import _lib
+    ops = _ops()
+    B, D, H, W, C = shape
+    g = torch.Generator().manual_seed(5)
+    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    smooth = (3.0 + torch.sin(0.21 * zz + 0.13 * yy) * torch.cos(0.17 * xx)).float()
+    for kind in ("smooth", "noise"):
+        x = (smooth.expand(B, D, H, W) + 0.01 * torch.rand((B, D, H, W), generator=g)) if kind == "smooth" else torch.rand((B, D, H, W), generator=g)
+        x = x.contiguous()
+        w = torch.randn((C, 1, 3, 3, 3), generator=g) * 0.3
+        xg = x.to(DEV)
+        wp = ops.pack_weight(w.to(DEV)).view(27, C)
+        nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
+        gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+        res = {}
+        for gram in (1, 0, 1):
+            _lib.call("tmf_set_option", b"c1_gram", gram)
+            try:
+                part = torch.full((nblk, 2, C), float("nan"), device=DEV)
+                _lib.call("tmf_c1_stats" + ("_bf16" if bf16 else ""), xg.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, ops._stream())
+                mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
+                rows = _lib.query("tmf_c1_stat_rows", B, D, H, W, C, nblk)
+                _lib.call("tmf_bn_finalize", part.data_ptr(), rows, C, float(B * D * H * W), gamma.data_ptr(), beta.data_ptr(), None, None, None,
+                          0.1, 1e-5, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), ops._stream())
+                torch.cuda.synchronize()
+            finally:
+                _lib.call("tmf_set_option", b"c1_gram", 1)
+            assert torch.isfinite(part[:rows]).all()
+            res.setdefault(gram, []).append((mean.cpu(), invstd.cpu(), part[:rows].cpu(), rows))
+        (m1, i1, p1, r1), (m1b, i1b, p1b, _r) = res[1]
+        m0, i0, _, r0 = res[0][0]
+        assert torch.equal(p1, p1b) and torch.equal(m1, m1b) and torch.equal(i1, i1b)
+        # the path is taken where the partial buffer holds its scratch (a volume of a few bricks keeps the direct pass)
+        ngram = min(256, B * -(-D // 8) * -(-H // 8) * -(-W // 32))
+        fits = nblk * 2 * C * 4 >= -(-16 * C // 256) * 256 + ngram * 512 + 2 * C * 4
+        assert r0 == nblk and r1 == (2 if fits else nblk) and (fits or shape == C1_GRAM_SHAPES[-1])
+        xr, wr = (x.bfloat16().double(), w.bfloat16().double()) if bf16 else (x.double(), w.double())
+        z = F.conv3d(xr.unsqueeze(1), wr, None, 1, 1)
+        mref, vref = z.mean((0, 2, 3, 4)), z.var((0, 2, 3, 4), unbiased=False)
+        iref = (vref + 1e-5).rsqrt()
+        sc = z.abs().mean().item()
+        assert (m1.double() - mref).abs().max().item() <= 2e-6 * sc, (kind, (m1.double() - mref).abs().max().item(), sc)
+        assert ((i1.double() - iref).abs() / iref).max().item() <= 2e-5, (kind, ((i1.double() - iref).abs() / iref).max().item())
+        # ... and no further from fp64 than the direct pass is (up to a floor)
+        e1, e0 = ((i1.double() - iref).abs() / iref).max().item(), ((i0.double() - iref).abs() / iref).max().item()
+        assert e1 <= max(2.0 * e0, 2e-6), (kind, e1, e0)

@@ -464,8 +464,13 @@ class Conv1BnPool(torch.autograd.Function):
         if training:
             nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
             part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
-            _lib.call("tmf_c1_stats" + sfx, x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
-            _lib.call("tmf_bn_finalize", part.data_ptr(), nblk, C, float(B * D * H * W),
+            if mode == "fp32x":        # this mode keeps the recomputing pass
+                _lib.call("tmf_c1_stats_direct", x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
+                rows = nblk
+            else:
+                _lib.call("tmf_c1_stats" + sfx, x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
+                rows = _lib.query("tmf_c1_stat_rows", B, D, H, W, C, nblk)  # 2 where the sums come from pair sums of the input
+            _lib.call("tmf_bn_finalize", part.data_ptr(), rows, C, float(B * D * H * W),
                       gamma.data_ptr(), beta.data_ptr(), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                       float(momentum), float(eps), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
                       shift.data_ptr(), s)
