@@ -178,7 +178,8 @@ int    tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* wor
  *                          tmf_set_option("c1_gram", 0 | 1) / TMF_C1_GRAM, default 1: where the buffer holds its scratch the two
  *                          sums come from the 63 pair sums of the INPUT volume (fp64) minus the directly evaluated one-voxel shell
  *                          around it (csrc/conv1_gram.hip) — no convolution; rows 0 / 1 then hold the high / low float halves of
- *                          the sums and tmf_c1_stat_rows() = 2.  0: one row per workgroup of the recomputing pass.
+ *                          the sums and tmf_c1_stat_rows() = 2.  0: one row per workgroup of the recomputing pass.  (fp32 entry
+ *                          only: tmf_c1_stats_bf16 and tmf_c1_stats_direct always recompute and fill all tmf_c1_blocks() rows.)
  *   tmf_c1_bn_pool_fwd  -> pooled
  *   tmf_c1_bwd_reduce   -> partial [tmf_c1_blocks()][2][C]       (reduce with tmf_bn_bwd_finalize)
  *   tmf_c1_bwd_wgrad    -> dw[27][C]   (coef from tmf_bn_bwd_finalize)

@@ -1393,7 +1393,7 @@ def test_first_block_statistics_from_input_pair_sums(shape, bf16):
                 part = torch.full((nblk, 2, C), float("nan"), device=DEV)
                 _lib.call("tmf_c1_stats" + ("_bf16" if bf16 else ""), xg.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, ops._stream())
                 mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
-                rows = _lib.query("tmf_c1_stat_rows", B, D, H, W, C, nblk)
+                rows = nblk if bf16 else _lib.query("tmf_c1_stat_rows", B, D, H, W, C, nblk)
                 _lib.call("tmf_bn_finalize", part.data_ptr(), rows, C, float(B * D * H * W), gamma.data_ptr(), beta.data_ptr(), None, None, None,
                           0.1, 1e-5, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), ops._stream())
                 torch.cuda.synchronize()
@@ -1407,7 +1407,10 @@ def test_first_block_statistics_from_input_pair_sums(shape, bf16):
         # the path is taken where the partial buffer holds its scratch (a volume of a few bricks keeps the direct pass)
         ngram = min(256, B * -(-D // 8) * -(-H // 8) * -(-W // 32))
         fits = nblk * 2 * C * 4 >= -(-16 * C // 256) * 256 + ngram * 512 + 2 * C * 4
-        assert r0 == nblk and r1 == (2 if fits else nblk) and (fits or shape == C1_GRAM_SHAPES[-1])
+        assert fits or shape == C1_GRAM_SHAPES[-1]
+        if bf16:        # (the bf16 entry keeps its own recomputing pass — 2 MFMAs per tile —: the option does not reach it)
+            fits = False
+        assert r0 == nblk and r1 == (2 if fits else nblk)
         xr, wr = (x.bfloat16().double(), w.bfloat16().double()) if bf16 else (x.double(), w.double())
         z = F.conv3d(xr.unsqueeze(1), wr, None, 1, 1)
         mref, vref = z.mean((0, 2, 3, 4)), z.var((0, 2, 3, 4), unbiased=False)

@@ -442,7 +442,10 @@ EwPlan plan_ew(long nwork, int C, bool wide = false) {
     p.rows = 256 / p.cq;
     if (p.rows < 1) p.rows = 0;      // C/vec > 256 unsupported
     long nb = p.rows ? (nwork + p.rows - 1) / p.rows : 0;
-    if (nb > 4096) nb = 4096;        // 16 workgroups per CU, grid-stride over the rest
+#ifndef TMF_EW_MAX_BLOCKS
+#define TMF_EW_MAX_BLOCKS 4096
+#endif
+    if (nb > TMF_EW_MAX_BLOCKS) nb = TMF_EW_MAX_BLOCKS;        // 16 workgroups per CU, grid-stride over the rest
     if (nb < 1) nb = 1;
     p.nblk = (int)nb;
     return p;

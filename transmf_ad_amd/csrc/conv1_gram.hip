@@ -17,7 +17,8 @@
 //                     all other rows zero: tmf_bn_finalize (fp64 sum over the rows) needs no change.
 // The statistics then differ from "the sums of the fp32 z the forward pass produces" by fp32 rounding of z (1e-7 relative).
 // Scratch: the tail of stat_partial itself ([tmf_c1_blocks()][2][C] floats); a volume whose partial buffer is too small for it
-// (a few bricks) keeps the direct pass.  bf16 mode: x and w rounded to bf16 first, as conv1_fused_kernel<.., true> sees them.
+// (a few bricks) keeps the direct pass.  The bf16 mode keeps its own pass too: there the convolution is 2 MFMAs per tile instead
+// of 14 (92 us at 128^3 against 184 us for these three kernels, whose fp64 work does not depend on the operand type).
 // tmf_set_option("c1_gram", 0 | 1) / TMF_C1_GRAM (default 1).
 #include "tmf_common.h"
 
@@ -27,8 +28,6 @@ constexpr int GT_D = 8, GT_H = 8, GT_W = 32;                       // voxels per
 constexpr int GP_D = GT_D + 2, GP_H = GT_H + 4, GP_W = GT_W + 4;   // tile: d 0 .. +2, h -2 .. +2, w -2 .. +2 (the half space of offsets)
 constexpr int GTHR = 512, GWG = 256, SWG = 256, NACC = 64;         // 63 offsets + S
 
-__device__ __forceinline__ float rbf(float v) { return __uint_as_float(tmf_pack_bf16(v, 0.f) << 16); }
-
 // index of an offset of the half space {d > 0} u {d = 0, h > 0} u {d = h = 0, w >= 0}
 __host__ __device__ constexpr int kidx(int dd, int dh, int dw) {
     return dd == 0 ? (dh == 0 ? dw : 3 + (dh - 1) * 5 + (dw + 2)) : 13 + ((dd - 1) * 5 + (dh + 2)) * 5 + (dw + 2);
@@ -37,7 +36,6 @@ static_assert(kidx(2, 2, 2) == 62, "63 offsets");
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 
-template <bool BF16>
 __global__ __launch_bounds__(GTHR) void c1_gram_kernel(const float* __restrict__ x, double* __restrict__ part,
                                                         int D, int H, int W, int tilesD, int tilesH, int tilesW, int ntiles) {
     // the tile as DOUBLES (converted once where it is written: one conversion per voxel instead of one per use), 34 KB;
@@ -82,7 +80,7 @@ __global__ __launch_bounds__(GTHR) void c1_gram_kernel(const float* __restrict__
         __syncthreads();                                            // (the previous brick's reads are done)
 #pragma unroll
         for (int j = 0; j < NE; ++j)
-            if (pe[j] >= 0) tile[tid + j * GTHR] = (double)(BF16 ? rbf(pre[j]) : pre[j]);
+            if (pe[j] >= 0) tile[tid + j * GTHR] = (double)pre[j];
         __syncthreads();
         if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
         // this thread's voxels: (d0 + dd0, h0 + 2 + hh, w0 + 2 + 4 g + i), i = 0 .. 3; a row = the 8 values w - 2 .. w + 5
@@ -153,7 +151,6 @@ __device__ __forceinline__ void shell_voxel(int r, int D, int H, int W, int& vd,
 }
 
 constexpr int STHR = 1024;                                         // shell: few rows of partials, many waves per workgroup
-template <bool BF16>
 __global__ __launch_bounds__(STHR) void c1_shell_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ part,
                                                          int B, int D, int H, int W, int C) {
     __shared__ __attribute__((aligned(16))) float wl[27 * 32];
@@ -162,7 +159,6 @@ __global__ __launch_bounds__(STHR) void c1_shell_kernel(const float* __restrict_
     for (int e = tid; e < 27 * 32; e += STHR) {
         const int c = n0 + (e & 31);
         float v = c < C ? w[(e >> 5) * C + c] : 0.f;
-        if (BF16) v = rbf(v);
         wl[e] = v;
     }
     __syncthreads();
@@ -184,7 +180,6 @@ __global__ __launch_bounds__(STHR) void c1_shell_kernel(const float* __restrict_
             const int ud = vd + tap / 9 - 1, uh = vh + (tap / 3) % 3 - 1, uw = vw + tap % 3 - 1;
             if (ud >= 0 && ud < D && uh >= 0 && uh < H && uw >= 0 && uw < W) {      // (a shell voxel sees at most 9 taps inside)
                 float xv = xb[((size_t)ud * H + uh) * W + uw];
-                if (BF16) xv = rbf(xv);
                 const f32x4* wr = reinterpret_cast<const f32x4*>(wl + tap * 32);
 #pragma unroll
                 for (int c4 = 0; c4 < 8; ++c4) {
@@ -217,7 +212,6 @@ __global__ __launch_bounds__(STHR) void c1_shell_kernel(const float* __restrict_
 
 constexpr int GMAXC = 64;                                          // channels of the first block this path takes (sNet: dim / 4 = 32)
 
-template <bool BF16>
 __global__ __launch_bounds__(1024) void c1_gram_finish_kernel(const float* __restrict__ w, const double* __restrict__ gram, int ngram,
                                                                const float* __restrict__ shell, int nshell, float* __restrict__ out,
                                                                int C) {
@@ -236,7 +230,6 @@ __global__ __launch_bounds__(1024) void c1_gram_finish_kernel(const float* __res
     }
     for (int e = tid; e < 27 * C; e += 1024) {
         float v = w[e];
-        if (BF16) v = rbf(v);
         wsh[e] = v;
     }
     __shared__ double shp[8 * 2 * GMAXC];
@@ -323,22 +316,16 @@ extern "C" int tmf_c1_stat_rows(int B, int D, int H, int W, int C, int nblk) {
 
 // -> 1: the statistics are enqueued (rows 0, 1 of stat_partial: tmf_c1_stat_rows() = 2); 0: not taken (option off, C > 64, or the
 // partial buffer too small for the scratch) — the caller runs the direct pass; < 0: an error code
-int tmf_c1_stats_gram(bool bf16, const float* x, const float* w, float* stat_partial, int nblk,
+int tmf_c1_stats_gram(const float* x, const float* w, float* stat_partial, int nblk,
                       int B, int D, int H, int W, int C, void* stream) {
     int tilesD, tilesH, tilesW, ngram, nshell; long ntiles; size_t off;
     if (!gram_plan(nblk, B, D, H, W, C, tilesD, tilesH, tilesW, ntiles, ngram, nshell, off)) return 0;
     double* gram = (double*)((char*)stat_partial + off);
     float* shell = (float*)(gram + (size_t)ngram * NACC);
     hipStream_t s = (hipStream_t)stream;
-    if (bf16) {
-        hipLaunchKernelGGL(c1_gram_kernel<true>, dim3(ngram), dim3(GTHR), 0, s, x, gram, D, H, W, tilesD, tilesH, tilesW, (int)ntiles);
-        hipLaunchKernelGGL(c1_shell_kernel<true>, dim3(nshell, tmf_cdiv(C, 32)), dim3(STHR), 0, s, x, w, shell, B, D, H, W, C);
-        hipLaunchKernelGGL(c1_gram_finish_kernel<true>, dim3(1), dim3(1024), 0, s, w, (const double*)gram, ngram, (const float*)shell, nshell, stat_partial, C);
-    } else {
-        hipLaunchKernelGGL(c1_gram_kernel<false>, dim3(ngram), dim3(GTHR), 0, s, x, gram, D, H, W, tilesD, tilesH, tilesW, (int)ntiles);
-        hipLaunchKernelGGL(c1_shell_kernel<false>, dim3(nshell, tmf_cdiv(C, 32)), dim3(STHR), 0, s, x, w, shell, B, D, H, W, C);
-        hipLaunchKernelGGL(c1_gram_finish_kernel<false>, dim3(1), dim3(1024), 0, s, w, (const double*)gram, ngram, (const float*)shell, nshell, stat_partial, C);
-    }
+    hipLaunchKernelGGL(c1_gram_kernel, dim3(ngram), dim3(GTHR), 0, s, x, gram, D, H, W, tilesD, tilesH, tilesW, (int)ntiles);
+    hipLaunchKernelGGL(c1_shell_kernel, dim3(nshell, tmf_cdiv(C, 32)), dim3(STHR), 0, s, x, w, shell, B, D, H, W, C);
+    hipLaunchKernelGGL(c1_gram_finish_kernel, dim3(1), dim3(1024), 0, s, w, (const double*)gram, ngram, (const float*)shell, nshell, stat_partial, C);
     const int rc = tmf_launch_result("tmf_c1_stats(gram)");
     return rc ? rc : 1;
 }

@@ -469,7 +469,8 @@ class Conv1BnPool(torch.autograd.Function):
                 rows = nblk
             else:
                 _lib.call("tmf_c1_stats" + sfx, x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
-                rows = _lib.query("tmf_c1_stat_rows", B, D, H, W, C, nblk)  # 2 where the sums come from pair sums of the input
+                # fp32: 2 rows where the sums come from pair sums of the input; the bf16 pass writes one row per workgroup
+                rows = nblk if sfx else _lib.query("tmf_c1_stat_rows", B, D, H, W, C, nblk)
             _lib.call("tmf_bn_finalize", part.data_ptr(), rows, C, float(B * D * H * W),
                       gamma.data_ptr(), beta.data_ptr(), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                       float(momentum), float(eps), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
