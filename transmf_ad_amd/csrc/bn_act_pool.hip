@@ -442,10 +442,12 @@ EwPlan plan_ew(long nwork, int C, bool wide = false) {
     p.rows = 256 / p.cq;
     if (p.rows < 1) p.rows = 0;      // C/vec > 256 unsupported
     long nb = p.rows ? (nwork + p.rows - 1) / p.rows : 0;
+    // 8 workgroups per CU, grid-stride over the rest.  (Round 5, five alternating processes of 30 steps per variant on one box: 4096 ->
+    // 923 pairs/s, 2048 -> 939, 1024 -> 938: half the rows for the finalize kernels, the passes themselves level.)
 #ifndef TMF_EW_MAX_BLOCKS
-#define TMF_EW_MAX_BLOCKS 4096
+#define TMF_EW_MAX_BLOCKS 2048
 #endif
-    if (nb > TMF_EW_MAX_BLOCKS) nb = TMF_EW_MAX_BLOCKS;        // 16 workgroups per CU, grid-stride over the rest
+    if (nb > TMF_EW_MAX_BLOCKS) nb = TMF_EW_MAX_BLOCKS;
     if (nb < 1) nb = 1;
     p.nblk = (int)nb;
     return p;
