@@ -1754,6 +1754,8 @@ int wino_cu_count() {
     if (n[dev] == 0) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        const char* e = getenv("TMF_WINO_CUS");             // experiments: fewer persistent workgroups than compute units
+        if (e && atoi(e) > 0 && atoi(e) < v) v = atoi(e);
         n[dev] = v;
     }
     return n[dev];
