@@ -1,4 +1,5 @@
-"""Two checks of a gfx950 assembly listing (hipcc -S --cuda-device-only) that the compiler does not make for us.
+"""Two checks of a gfx950 assembly listing (hipcc -S --cuda-device-only, or the disassembly of a built object:
+tools/resources.disassembly_of) that the compiler does not make for us.
 
 1. in flight: the persistent Winograd kernels (csrc/conv3d_wino.hip: load_b / bpin) keep weight loads to REGISTERS
    (buffer_load_dwordx4 from inline asm) in flight across a phase on purpose.  The compiler believes the asm's outputs are ready,
@@ -9,7 +10,7 @@
    the Winograd forward's statistics, fixed with store_guard()).
 
     python tools/asm_checks.py listing.s [kernel-name-substring]         exit code 1 when something is found
-tests/test_host_cpu.py runs both on a fresh listing of conv3d_wino.hip.
+tests/test_host_cpu.py runs the store check on the disassembly of EVERY built object and the in-flight check on conv3d_wino.o.
 """
 import re
 import sys

@@ -39,6 +39,30 @@ def kernels_of(obj):
     return [k for k in out if "vgpr" in k]
 
 
+def disassembly_of(obj, out_path):
+    """llvm-objdump -d of the gfx950 code object embedded in a host object, rewritten into the shape of a `hipcc -S` listing
+    (kernel labels `_Z...:`, one instruction per line, no encodings) for tools/asm_checks.py.  False for host-only objects."""
+    with tempfile.TemporaryDirectory() as td:
+        fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+        rc = subprocess.call([f"{LLVM}/llvm-objcopy", f"--dump-section=.hip_fatbin={fat}", obj, os.path.join(td, "x.o")],
+                             stderr=subprocess.DEVNULL)
+        if rc != 0 or not os.path.exists(fat) or os.path.getsize(fat) == 0:
+            return False
+        subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}",
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], stderr=subprocess.DEVNULL)
+        text = subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", co], text=True)
+    with open(out_path, "w") as f:
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\w+)>:", line)
+            if m:
+                f.write(m.group(1) + ":\n")
+                continue
+            t = line.split("//")[0].rstrip()
+            if t.startswith("\t") or t.startswith("  "):
+                f.write("\t" + t.strip() + "\n")
+    return True
+
+
 def all_kernels():
     res = {}
     for f in sorted(os.listdir(CSRC)):
