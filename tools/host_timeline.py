@@ -24,10 +24,19 @@ ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--setup", type=int, default=40)
 ap.add_argument("--B", type=int, default=8)
 ap.add_argument("--S", type=int, default=96)
+ap.add_argument("--ddp", action="store_true", help="wrap the model in GradAllReduce over a 1-rank RCCL group (the N > 1 machinery on one GPU)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 net = model_ad(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512, dropout=0.0).to(dev)
+if a.ddp:
+    import os
+    import torch.distributed as dist
+    from transmf_ad_amd.parallel import GradAllReduce
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    net = GradAllReduce(net)
 opt = Adam(net.parameters(), lr=1e-4)
 crit = nn.CrossEntropyLoss()
 rs = np.random.RandomState(0)

@@ -164,6 +164,10 @@ class GradAllReduce(nn.Module):
         self._inplace = []
         self._pending = []
         self._events = []
+        # "now" reports (an encoder's deep range, final at an event in the middle of its backward) seen in this backward / in
+        # the previous one: the host enqueues nothing until the LAST expected one has come in (see _tmf_flat_grads)
+        self._now_seen = 0
+        self._now_expected = 1
         self._nodes = {}                        # parameter addresses of a node -> (its Parameters, their view offsets)
         self._covered = set()
         self._checked_steps = 0
@@ -290,17 +294,31 @@ class GradAllReduce(nn.Module):
         # encoder's whole backward, milliseconds of GPU work, is queued and the host is free —, or at the end of backward.  An
         # "end" range (an encoder's shallow blocks) would make the in-order staging stream wait for this encoder's whole backward
         # with the OTHER encoder's deep range queued behind it: it goes out at the end of backward.
-        if any(when == "now" for _a, _b, _e, when in segments) and self._early:
-            self._flush_pending(st)
+        #
+        # ... and with TWO encoders the first one's report comes BETWEEN the two backward calls: three collective enqueues there
+        # (heads, fusion, its own deep range: ~0.3 ms of host time) keep the second encoder's kernels — the other stream of the
+        # step — from being launched, and the GPU runs one stream for that long (round 5, 1-rank RCCL group: +4 % on an 8.5 ms
+        # step, more than the end-of-backward buckets cost).  So a "now" range that is not the LAST one expected (as many as the
+        # previous backward had: the same on every rank) only joins `_pending` with its event; the last one flushes everything.
+        has_now = self._early and any(when == "now" and ev is not None and stop > start for start, stop, ev, when in segments)
+        last_now = False
+        if has_now:
+            self._now_seen += 1
+            last_now = self._now_seen >= self._now_expected
+            if last_now:
+                self._flush_pending(st)
         for start, stop, ev, when in segments:
             if stop <= start:
                 continue
             if when == "now" and ev is not None and self._early:
-                st.wait_event(ev)
-                with torch.cuda.stream(st):
-                    works.append(self._all_reduce(flat[start:stop]))
-                self.last_reduced_bytes.append((stop - start) * flat.element_size())
-                self.last_reduced_kinds.append("event")
+                if last_now:
+                    st.wait_event(ev)
+                    with torch.cuda.stream(st):
+                        works.append(self._all_reduce(flat[start:stop]))
+                    self.last_reduced_bytes.append((stop - start) * flat.element_size())
+                    self.last_reduced_kinds.append("event")
+                else:
+                    self._pending.append((flat, start, stop, ev, works, "event"))
             elif when == "next":
                 if ev is None:                                   # final behind what the current stream holds now
                     k = len(self._pending)                      # (events are re-used from step to step: creating one is ~10 us)
@@ -308,7 +326,7 @@ class GradAllReduce(nn.Module):
                         self._events.append(torch.cuda.Event())
                     ev = self._events[k]
                     ev.record(torch.cuda.current_stream(dev))
-                self._pending.append((flat, start, stop, ev, works))
+                self._pending.append((flat, start, stop, ev, works, "stream"))
             else:                                               # "end" (and "now" with TMF_DDP_EVENTS=0)
                 deferred.append((start, stop))
         # (no record_stream on the buffer: it lives until the next zero_grad — .grad holds views of it — and by then the
@@ -323,12 +341,12 @@ class GradAllReduce(nn.Module):
     def _flush_pending(self, st):
         """Start the collectives of the buffers that reported in without an event range (heads, fusion), each behind the
         event recorded at the end of its backward."""
-        for flat, start, stop, done, works in self._pending:
+        for flat, start, stop, done, works, kind in self._pending:
             st.wait_event(done)
             with torch.cuda.stream(st):
                 works.append(self._all_reduce(flat[start:stop]))
             self.last_reduced_bytes.append((stop - start) * flat.element_size())
-            self.last_reduced_kinds.append("stream")
+            self.last_reduced_kinds.append(kind)
         self._pending = []
 
     def _reduce_rest(self, st):
@@ -374,6 +392,9 @@ class GradAllReduce(nn.Module):
         self._covered = set()
         self._callback_queued = False
         self._bw_seq = None
+        if self._now_seen:                       # (what the next backward may expect; a backward without such a report changes nothing)
+            self._now_expected = self._now_seen
+        self._now_seen = 0
 
     def _finalize_impl(self):
         try:
@@ -395,7 +416,7 @@ class GradAllReduce(nn.Module):
                 for s_ in self._known_streams(dev):
                     st.wait_stream(s_)
         if cuda:
-            self._flush_pending(st)              # (no encoder reported in: a module without one)
+            self._flush_pending(st)              # (no encoder reported in — a module without one —, or fewer than the last backward had)
         with ctx:
             rest = self._reduce_rest(st)
             ev0 = ev1 = None
