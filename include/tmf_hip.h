@@ -187,6 +187,21 @@ int    tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* wor
 int    tmf_c1_blocks(int B, int D, int H, int W, int C);
 int    tmf_c1_stats(const float* x, const float* w, float* stat_partial, int B, int D, int H, int W, int C, void* stream);
 int    tmf_c1_stat_rows(int B, int D, int H, int W, int C, int nblk);    /* rows of stat_partial that carry the sums (nblk = tmf_c1_blocks()) */
+/* Round 5, second half: the statistics AND the exact 27 x 27 tap Gram matrix G of the volume (+ the 27 shifted sums S_t) in one go —
+ * gram: tmf_c1_gram_bytes() bytes (0: not available — option "c1_gram" off or C > 64), doubles [0,729) G, [729,756) S_t, 756 S, then
+ * scratch; stat_partial rows 0 / 1 as above (tmf_bn_finalize over 2 rows).  With it the backward of the block is ONE pass over the
+ * volume: tmf_c1_bwd_fused = tmf_c1_bwd_reduce + tmf_bn_bwd_finalize + tmf_c1_bwd_wgrad (train mode, fp32):
+ *   dw[t][c] = scale_c [ D[t][c] - c0_c S_t - c1_c invstd_c (sum_t' w[t'][c] G[t][t'] - mean_c S_t) ],  D = sum_v x(v + t) dy_c(v)
+ * (dy is one element per pooling window: 27 multiply-adds per window beside the BatchNorm sums).  workspace:
+ * tmf_c1_bwd_fused_workspace_bytes(). */
+size_t tmf_c1_gram_bytes(int B, int D, int H, int W, int C);
+int    tmf_c1_stats_g(const float* x, const float* w, float* stat_partial, void* gram, size_t gram_bytes,
+                      int B, int D, int H, int W, int C, void* stream);
+size_t tmf_c1_bwd_fused_workspace_bytes(int B, int D, int H, int W, int C);
+int    tmf_c1_bwd_fused(const float* x, const float* w, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, const float* dpool, const void* gram, float* dw, float* dgamma, float* dbeta,
+                        void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, float slope,
+                        int dw_layout, void* stream);
 int    tmf_c1_stats_direct(const float* x, const float* w, float* stat_partial, int B, int D, int H, int W, int C, void* stream);   /* always
                                                                           * the recomputing pass: all tmf_c1_blocks() rows (the fp32x mode) */
 int    tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* scale, const float* shift, float* pooled,

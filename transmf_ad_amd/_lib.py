@@ -63,6 +63,10 @@ PROTOTYPES = {
     "tmf_c1_stats": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tmf_c1_stat_rows": (_i, [_i, _i, _i, _i, _i, _i]),
     "tmf_c1_stats_direct": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "tmf_c1_gram_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "tmf_c1_stats_g": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
+    "tmf_c1_bwd_fused_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "tmf_c1_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _i, _p]),
     "tmf_c1_bn_pool_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_c1_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_c1_stats_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

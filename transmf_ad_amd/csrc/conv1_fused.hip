@@ -32,7 +32,10 @@ constexpr int NTI = TD / 2;                           // M-tiles per wave and br
 constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int NHALO = HD * HH * HW;
 
-enum { MODE_STATS = 0, MODE_FWD = 1, MODE_REDUCE = 2, MODE_WGRAD = 3 };
+enum { MODE_STATS = 0, MODE_FWD = 1, MODE_REDUCE = 2, MODE_WGRAD = 3, MODE_RD = 4 };
+// MODE_RD (round 5): MODE_REDUCE plus D[tap][c] = sum_voxel x[voxel + tap] dy[voxel][c] — dy is ONE element per pooling window, so D is 27
+// reads and multiply-adds per window; with the tap Gram matrix of the forward (conv1_gram.hip) the weight gradient follows without
+// a second pass (tmf_c1_bwd_fused).
 
 // bf16 passes: the halo brick lives in LDS as bf16, TWICE — copy c stores element e at index e + c — so that the pair
 // (x[w], x[w + 1]) is one aligned dword for every w (even w: copy 0, odd w: copy 1).  A lane then fetches two taps per
@@ -64,7 +67,8 @@ struct Args {
     const float* coef;     // [2][C] (WGRAD)
     const void* dpool;     // [B][D/2][H/2][W/2][C] (REDUCE, WGRAD); float, or bf16 when P16
     void* pooled;          // (FWD)
-    float* partial;        // STATS/REDUCE: [nblk][2][C];  WGRAD: [nblk][27][C]
+    float* partial;        // STATS/REDUCE/RD: [nblk][2][C];  WGRAD: [nblk][27][C]
+    float* partial2;       // RD: [nblk][27][C]
     int D, H, W, C;
     int tilesD, tilesH, tilesW, ntiles, tiles_per_block;
     float slope;
@@ -118,10 +122,13 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
     }
     float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f, c0 = 0.f, c1 = 0.f;
     if (MODE != MODE_STATS && cv) { sc = a.scale[co]; sh = a.shift[co]; }
-    if ((MODE == MODE_REDUCE || MODE == MODE_WGRAD) && cv) { mu = a.mean[co]; is = a.invstd[co]; }
+    if ((MODE == MODE_REDUCE || MODE == MODE_WGRAD || MODE == MODE_RD) && cv) { mu = a.mean[co]; is = a.invstd[co]; }
     if (MODE == MODE_WGRAD && cv) { c0 = a.coef[co]; c1 = a.coef[a.C + co]; }
 
-    float s1 = 0.f, s2 = 0.f;               // STATS: sum z, sum z^2;  REDUCE: sum dy, sum dy*xhat
+    float s1 = 0.f, s2 = 0.f;               // STATS: sum z, sum z^2;  REDUCE / RD: sum dy, sum dy*xhat
+    float dacc[MODE == MODE_RD ? 27 : 1];   // RD: D[tap][this lane's channel]
+#pragma unroll
+    for (int t = 0; t < (MODE == MODE_RD ? 27 : 1); ++t) dacc[t] = 0.f;
     f32x16 accw;                            // WGRAD: dw[tap = row][co = column]
 #pragma unroll
     for (int r = 0; r < 16; ++r) accw[r] = 0.f;
@@ -359,12 +366,21 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
                     g = P16 ? __builtin_bit_cast(float, (unsigned int)__builtin_amdgcn_raw_buffer_load_b16(pr, pv, psoff, 0) << 16)
                             : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(pr, pv, psoff, 0));
                 const float gl = g * lrm;                       // dLoss/dy at the routed element
-                if (MODE == MODE_REDUCE) {
+                if (MODE == MODE_REDUCE || MODE == MODE_RD) {
                     float zs = z[8 * q + 7];                    // z of the first maximum (a pooled window is all-valid)
 #pragma unroll
                     for (int k = 6; k >= 0; --k) zs = (y[k] == ymax) ? z[8 * q + k] : zs;
                     s1 += gl;
                     s2 += gl * ((zs - mu) * is);
+                    if (MODE == MODE_RD) {
+                        // the routed voxel's 27 input taps (halo index of fragment row r = 8 q + k: row_off(r) + the lane half's rows)
+                        int arg = 7;
+#pragma unroll
+                        for (int k = 6; k >= 0; --k) arg = (y[k] == ymax) ? k : arg;
+                        const int vx = org + hsel * 2 * HW + ((arg >> 2) & 1) * HH * HW + ((arg >> 1) & 1) * HW + 2 * q + (arg & 1);
+#pragma unroll
+                        for (int t = 0; t < 27; ++t) dacc[t] = fmaf(halo[vx + tapoff(t)], gl, dacc[t]);
+                    }
                 } else {
                     int arg = 7;
 #pragma unroll
@@ -416,7 +432,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
     }
 
     // ---- workgroup reduction and partial slab ----
-    if (MODE == MODE_STATS || MODE == MODE_REDUCE) {
+    if (MODE == MODE_STATS || MODE == MODE_REDUCE || MODE == MODE_RD) {
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         __syncthreads();
@@ -428,6 +444,23 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
             for (int m = 0; m < 4; ++m) { t1 += red[(m * 32 + tid) * 2]; t2 += red[(m * 32 + tid) * 2 + 1]; }
             a.partial[((size_t)blockIdx.x * 2 + 0) * a.C + n0 + tid] = t1;
             a.partial[((size_t)blockIdx.x * 2 + 1) * a.C + n0 + tid] = t2;
+        }
+    }
+    if (MODE == MODE_RD) {                  // D: the two lane halves, then the four waves
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            const float v = dacc[t] + __shfl_xor(dacc[t], 32);
+            if (hsel == 0) red[(wave * 32 + t) * 32 + l31] = v;
+        }
+        __syncthreads();
+        for (int e = tid; e < 27 * 32; e += 256) {
+            const int tap = e >> 5, c = e & 31;
+            if (n0 + c < a.C) {
+                const float v = red[(0 * 32 + tap) * 32 + c] + red[(1 * 32 + tap) * 32 + c] +
+                                red[(2 * 32 + tap) * 32 + c] + red[(3 * 32 + tap) * 32 + c];
+                a.partial2[((size_t)blockIdx.x * 27 + tap) * a.C + n0 + c] = v;
+            }
         }
     } else if (MODE == MODE_WGRAD) {
         __syncthreads();
@@ -624,4 +657,43 @@ extern "C" int tmf_c1_bwd_wgrad_bf16(const float* x, const float* w, const float
                                      void* stream) {
     return c1_bwd_wgrad(true, pooled_bf16 != 0, x, w, scale, shift, mean, invstd, coef, dpool, dw, workspace, workspace_bytes,
                         B, D, H, W, C, slope, dw_layout, stream);
+}
+
+// ---- reduce + weight gradient in ONE pass over the volume (fp32; needs the Gram data tmf_c1_stats_g left in `gram`) ----
+// workspace: [nblk][2][C] sums | [nblk][27][C] D slabs | their reduction scratch | [27][C] reduced D
+int tmf_c1_bwd_fused_finish(const float* part, int nblk, const float* dred, const float* w, const void* gram, const float* scale,
+                            const float* mean, const float* invstd, double count, float* dgamma, float* dbeta, float* dw, int C,
+                            int dw_ref, void* stream);
+extern "C" size_t tmf_c1_bwd_fused_workspace_bytes(int B, int D, int H, int W, int C) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
+    return ((size_t)p.nblk * 2 * C + (size_t)(p.nblk + tmf_reduce_groups(p.nblk) + 1) * 27 * C) * 4;
+}
+extern "C" int tmf_c1_bwd_fused(const float* x, const float* w, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, const float* dpool, const void* gram, float* dw, float* dgamma, float* dbeta,
+                                void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, float slope,
+                                int dw_layout, void* stream) {
+    TMF_REQUIRE(dw_layout == TMF_DW_TAPMAJOR || dw_layout == TMF_DW_REFERENCE, TMF_E_ARG, "tmf_c1_bwd_fused: unknown dw_layout %d", dw_layout);
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(invstd);
+    TMF_REQUIRE_PTR(dpool); TMF_REQUIRE_PTR(gram); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
+    int rc = check("tmf_c1_bwd_fused", B, D, H, W, C);
+    if (rc) return rc;
+    TMF_REQUIRE(C <= 64, TMF_E_SHAPE, "tmf_c1_bwd_fused: C = %d > 64", C);
+    const size_t need = tmf_c1_bwd_fused_workspace_bytes(B, D, H, W, C);
+    TMF_REQUIRE(workspace_bytes >= need, TMF_E_WORKSPACE, "tmf_c1_bwd_fused: workspace %zu B < required %zu B", workspace_bytes, need);
+    const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
+    Args a = base_args(x, w, D, H, W, C, p, slope);
+    a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.dpool = dpool;
+    float* part = (float*)workspace;
+    float* slabs = part + (size_t)p.nblk * 2 * C;
+    const long n = 27L * C;
+    float* scratch = slabs + (size_t)p.nblk * n;
+    float* dred = scratch + (size_t)tmf_reduce_groups(p.nblk) * n;
+    a.partial = part; a.partial2 = slabs;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((conv1_fused_kernel<MODE_RD, false>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    if ((rc = tmf_launch_result("tmf_c1_bwd_fused"))) return rc;
+    if ((rc = tmf_reduce_slabs(slabs, p.nblk, n, scratch, dred, s, "tmf_c1_bwd_fused(reduce)"))) return rc;
+    return tmf_c1_bwd_fused_finish(part, p.nblk, dred, w, gram, scale, mean, invstd, (double)B * D * H * W, dgamma, dbeta, dw, C,
+                                   dw_layout == TMF_DW_REFERENCE ? 1 : 0, stream);
 }

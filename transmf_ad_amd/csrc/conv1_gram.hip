@@ -279,6 +279,219 @@ __global__ __launch_bounds__(1024) void c1_gram_finish_kernel(const float* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The exact tap Gram matrix of the volume, for the BACKWARD of the block as well (round 5, second half):
+//     G[t][t'] = sum_{v in V} x~(v + t) x~(v + t')  = R(t' - t) - Hs[t][t'],      S_t = sum_{v in V} x~(v + t) = S - Es[t],
+// Hs / Es = the same sums over the one-voxel shell V+ \ V.  A shell voxel of the face class (axis a, side) sees only the 9 taps with
+// t_a pointing inward: 81 pair sums and 9 sums per class.  With G and S_t the statistics are quadratic / linear forms of the
+// weights (sum z_c^2 = w_c^T G w_c, sum z_c = sum_t w[t][c] S_t), and the weight gradient of the block needs NO second pass over
+// the volume: with dz = s (dy - c0 - xhat c1), xhat = (z - mu) / sigma,
+//     dw[t][c] = s_c [ D[t][c] - c0_c S_t - c1_c / sigma_c ( V[t][c] - mu_c S_t ) ],   V[t][c] = sum_{t'} w[t'][c] G[t][t'],
+// where D[t][c] = sum_v x~(v + t) dy_c(v) is the only term that needs dy — and dy is ONE element per pooling window: 27 reads and
+// multiply-adds per window in the pass that already computes the BatchNorm sums (conv1_fused_kernel<MODE_RD>).
+// Layout of the caller's buffer (doubles): [0, 729) G, [729, 756) S_t, 756 S, 757 spare, then the scratch of the three kernels.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int NGRAM = 760;                                         // doubles ahead of the scratch
+constexpr int HWG = 64, HTHR = 256, HNB = 288, HPART = 96;          // shell classes: 6 x HWG workgroups, batches of 288 voxels
+constexpr int HNE = (HNB * 9 + HTHR - 1) / HTHR;                   // tile elements per thread and batch          // shell classes: 6 x HWG workgroups; 90 numbers per partial row
+
+// tap index of in-class tap j (0 .. 8) of face class cls: the axis cls / 2 is fixed at +1 (side 0: v = -1) or -1 (side 1: v = n)
+__host__ __device__ constexpr int class_tap(int cls, int j) {
+    const int ax = cls >> 1, fixed = (cls & 1) ? 0 : 2, a = j / 3, b = j % 3;
+    return ax == 0 ? fixed * 9 + a * 3 + b : (ax == 1 ? a * 9 + fixed * 3 + b : a * 9 + b * 3 + fixed);
+}
+
+__global__ __launch_bounds__(HTHR) void c1_shell_gram_kernel(const float* __restrict__ x, double* __restrict__ part, int B, int D, int H, int W) {
+    __shared__ double xs[HNB * 9];                              // (converted once where it is written)
+    __shared__ int vbase[HNB], vcrd[HNB];                      // per voxel of the batch: sample offset, packed (vd + 1, vh + 1, vw + 1) or -1
+    __shared__ double red[3 * 81];
+    const int tid = threadIdx.x, cls = blockIdx.y, ax = cls >> 1, side = cls & 1;
+    const int n1 = ax == 0 ? H + 2 : D, n2 = ax == 2 ? H : W + 2;          // the face as an n1 x n2 grid per sample
+    const int per = n1 * n2, total = B * per;                  // (< 2^31: checked by the caller)
+    const int p = tid % 81, slice = tid / 81, pi = p / 9, pj = p % 9;
+    // this thread's copies of a batch: elements e = tid + 256 k -> (voxel e / 9, in-class tap e % 9): the tap's offset is fixed
+    int cv_[HNE], cdd[HNE], cdh[HNE], cdw[HNE];
+#pragma unroll
+    for (int k = 0; k < HNE; ++k) {
+        const int e = tid + k * HTHR, vi = e / 9, j = e - vi * 9, tap = class_tap(cls, j);
+        cv_[k] = e < HNB * 9 ? vi : -1;
+        cdd[k] = tap / 9 - 2; cdh[k] = (tap / 3) % 3 - 2; cdw[k] = tap % 3 - 2;      // (relative to the +1-biased coordinates)
+    }
+    double acc = 0.0, eacc = 0.0;
+    for (int base = blockIdx.x * HNB; base < total; base += gridDim.x * HNB) {
+        __syncthreads();
+        for (int vt = tid; vt < HNB; vt += HTHR) {
+            const int s_ = base + vt;
+            int c = -1, off = 0;
+            if (s_ < total) {
+                const int b = s_ / per, q = s_ - b * per, q1 = q / n2, q2 = q - q1 * n2;
+                int vd, vh, vw;
+                if (ax == 0) { vd = side ? D : -1; vh = q1 - 1; vw = q2 - 1; }
+                else if (ax == 1) { vh = side ? H : -1; vd = q1; vw = q2 - 1; }
+                else { vw = side ? W : -1; vd = q1; vh = q2; }
+                c = (vd + 1) | (vh + 1) << 10 | (vw + 1) << 20;
+                off = b * D * H * W;
+            }
+            vcrd[vt] = c; vbase[vt] = off;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < HNE; ++k) {
+            if (cv_[k] < 0) continue;
+            const int c = vcrd[cv_[k]];
+            float v = 0.f;
+            if (c >= 0) {
+                const int ud = (c & 1023) + cdd[k], uh = ((c >> 10) & 1023) + cdh[k], uw = (c >> 20) + cdw[k];
+                if (ud >= 0 && ud < D && uh >= 0 && uh < H && uw >= 0 && uw < W) v = x[(size_t)vbase[cv_[k]] + ((size_t)ud * H + uh) * W + uw];
+            }
+            xs[tid + k * HTHR] = (double)v;
+        }
+        __syncthreads();
+        if (slice < 3) {                                           // (the threads of column j = 0 also sum their tap: E_i)
+#pragma unroll 8
+            for (int vi = slice * (HNB / 3); vi < (slice + 1) * (HNB / 3); ++vi) {
+                const double xa = xs[vi * 9 + pi];
+                acc = fma(xa, xs[vi * 9 + pj], acc);
+                eacc += pj == 0 ? xa : 0.0;
+            }
+        }
+    }
+    __shared__ double rede[3 * 9];
+    __syncthreads();
+    if (slice < 3) {
+        red[slice * 81 + p] = acc;
+        if (pj == 0) rede[slice * 9 + pi] = eacc;
+    }
+    __syncthreads();
+    double* row = part + ((size_t)cls * gridDim.x + blockIdx.x) * HPART;
+    if (tid < 81) row[tid] = (red[tid] + red[81 + tid]) + red[162 + tid];
+    else if (tid < 90) row[tid] = (rede[tid - 81] + rede[9 + tid - 81]) + rede[18 + tid - 81];
+}
+
+// G, S_t, S -> gram[0 .. 756]; statistic rows 0 / 1 of stat_partial (high / low halves) from them
+__global__ __launch_bounds__(1024) void c1_gram2_finish_kernel(const float* __restrict__ w, const double* __restrict__ rpart, int ngram,
+                                                                const double* __restrict__ hpart, int nh, double* __restrict__ gram,
+                                                                float* __restrict__ out, int C) {
+    __shared__ double ra[16 * NACC];
+    __shared__ double R[NACC];
+    __shared__ double Hc[6 * HPART];
+    __shared__ double G[27 * 27 + 27];
+    __shared__ float wsh[27 * GMAXC];
+    __shared__ double rows[27 * GMAXC];
+    const int tid = threadIdx.x;
+    {
+        const int k = tid & 63, rg = tid >> 6;
+        double s = 0.0;
+#pragma unroll 8
+        for (int i = rg; i < ngram; i += 16) s += rpart[(size_t)i * NACC + k];
+        ra[rg * NACC + k] = s;
+    }
+    for (int e = tid; e < 27 * C; e += 1024) wsh[e] = w[e];
+    for (int e = tid; e < 6 * HPART; e += 1024) {                    // class cls, number k: fixed-order sum over the class's workgroups
+        const int cls = e / HPART, k = e - cls * HPART;
+        double s0 = 0.0, s1_ = 0.0, s2_ = 0.0, s3 = 0.0;
+        if (k < 90) {
+            int i = 0;
+            for (; i + 3 < nh; i += 4) {
+                s0 += hpart[((size_t)cls * nh + i) * HPART + k]; s1_ += hpart[((size_t)cls * nh + i + 1) * HPART + k];
+                s2_ += hpart[((size_t)cls * nh + i + 2) * HPART + k]; s3 += hpart[((size_t)cls * nh + i + 3) * HPART + k];
+            }
+            for (; i < nh; ++i) s0 += hpart[((size_t)cls * nh + i) * HPART + k];
+        }
+        Hc[e] = (s0 + s1_) + (s2_ + s3);
+    }
+    __syncthreads();
+    if (tid < NACC) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += ra[i * NACC + tid];
+        R[tid] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < 27 * 27 + 27; e += 1024) {
+        double v;
+        if (e < 729) {
+            const int t = e / 27, u = e - t * 27;
+            int dd = u / 9 - t / 9, dh = (u / 3) % 3 - (t / 3) % 3, dw = u % 3 - t % 3;
+            if (dd < 0 || (dd == 0 && (dh < 0 || (dh == 0 && dw < 0)))) { dd = -dd; dh = -dh; dw = -dw; }
+            v = R[kidx(dd, dh, dw)];
+            for (int cls = 0; cls < 6; ++cls)                       // the classes both taps belong to
+                for (int i = 0; i < 9; ++i) {
+                    if (class_tap(cls, i) != t) continue;
+                    for (int j = 0; j < 9; ++j)
+                        if (class_tap(cls, j) == u) v -= Hc[cls * HPART + i * 9 + j];
+                }
+        } else {
+            const int t = e - 729;
+            v = R[63];
+            for (int cls = 0; cls < 6; ++cls)
+                for (int i = 0; i < 9; ++i)
+                    if (class_tap(cls, i) == t) v -= Hc[cls * HPART + 81 + i];
+        }
+        G[e] = v;
+        gram[e] = v;
+    }
+    if (tid == 0) { gram[756] = R[63]; gram[757] = 0.0; }
+    __syncthreads();
+    for (int e = tid; e < 27 * C; e += 1024) {                       // rows[t][c] = w[t][c] * sum_u w[u][c] G[t][u]
+        const int t = e / C, c = e - t * C;
+        double row = 0.0;
+        for (int u = 0; u < 27; ++u) row = fma((double)wsh[u * C + c], G[t * 27 + u], row);
+        rows[e] = (double)wsh[e] * row;
+    }
+    __syncthreads();
+    if (tid < C) {
+        double q = 0.0, s1 = 0.0;
+        for (int t = 0; t < 27; ++t) { q += rows[t * C + tid]; s1 = fma((double)wsh[t * C + tid], G[729 + t], s1); }
+        const float h1 = (float)s1, h2 = (float)q;
+        out[0 * C + tid] = h1;
+        out[1 * C + tid] = h2;
+        out[2 * C + tid] = (float)(s1 - (double)h1);
+        out[3 * C + tid] = (float)(q - (double)h2);
+    }
+}
+
+// dw, dgamma, dbeta of the first block from the sums of conv1_fused_kernel<MODE_RD>: part [nblk][2][C] (sum dy, sum dy xhat),
+// dred [27][C] (D, reduced over the workgroups), G / S_t of the forward
+__global__ __launch_bounds__(1024) void c1_bwd_fused_finish_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ dred,
+                                                                    const float* __restrict__ w, const double* __restrict__ gram,
+                                                                    const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                    const float* __restrict__ invstd, double count,
+                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                    float* __restrict__ dw, int C, int dw_ref) {
+    __shared__ double pa[16 * 2 * GMAXC];
+    __shared__ double c01[2 * GMAXC];
+    __shared__ float wsh[27 * GMAXC];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < 16 * 2 * C; e += 1024) {                   // column j = which * C + c, 16 row groups
+        const int j = e % (2 * C), rg = e / (2 * C);
+        double s = 0.0;
+#pragma unroll 8
+        for (int i = rg; i < nblk; i += 16) s += (double)part[(size_t)i * 2 * C + j];
+        pa[e] = s;
+    }
+    for (int e = tid; e < 27 * C; e += 1024) wsh[e] = w[e];
+    __syncthreads();
+    for (int j = tid; j < 2 * C; j += 1024) {
+        double s = 0.0;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) s += pa[rg * 2 * C + j];
+        c01[j] = s / count;
+        if (j < C) { if (dbeta) dbeta[j] = (float)s; }
+        else if (dgamma) dgamma[j - C] = (float)s;
+    }
+    __syncthreads();
+    for (int e = tid; e < 27 * C; e += 1024) {
+        const int t = e / C, c = e - t * C;
+        double v = 0.0;                                             // V[t][c] = sum_u w[u][c] G[t][u]
+        for (int u = 0; u < 27; ++u) v = fma((double)wsh[u * C + c], gram[t * 27 + u], v);
+        const double st = gram[729 + t], mu = mean[c], is = invstd[c];
+        const double r = (double)scale[c] * ((double)dred[e] - c01[c] * st - c01[C + c] * is * (v - mu * st));
+        if (dw_ref) dw[(size_t)c * 27 + t] = (float)r;
+        else dw[e] = (float)r;
+    }
+}
+
 int g_c1_gram = -1;
 int c1_gram_mode() {
     if (g_c1_gram < 0) {
@@ -328,4 +541,41 @@ int tmf_c1_stats_gram(const float* x, const float* w, float* stat_partial, int n
     hipLaunchKernelGGL(c1_gram_finish_kernel, dim3(1), dim3(1024), 0, s, w, (const double*)gram, ngram, (const float*)shell, nshell, stat_partial, C);
     const int rc = tmf_launch_result("tmf_c1_stats(gram)");
     return rc ? rc : 1;
+}
+
+// ---- the statistics + Gram data of the forward, and the one-pass backward (fp32; conv1_fused.hip launches the MODE_RD kernel) ----
+extern "C" size_t tmf_c1_gram_bytes(int B, int D, int H, int W, int C) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || !c1_gram_mode() || C > GMAXC) return 0;
+    return ((size_t)NGRAM + (size_t)GWG * NACC + (size_t)6 * HWG * HPART) * 8;
+}
+
+extern "C" int tmf_c1_stats_g(const float* x, const float* w, float* stat_partial, void* gram, size_t gram_bytes,
+                              int B, int D, int H, int W, int C, void* stream) {
+    TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(stat_partial); TMF_REQUIRE_PTR(gram);
+    const size_t need = tmf_c1_gram_bytes(B, D, H, W, C);
+    TMF_REQUIRE(need > 0, TMF_E_SHAPE, "tmf_c1_stats_g: not available for this shape / option (tmf_c1_gram_bytes() = 0)");
+    TMF_REQUIRE(gram_bytes >= need, TMF_E_WORKSPACE, "tmf_c1_stats_g: gram buffer %zu B < required %zu B", gram_bytes, need);
+    TMF_REQUIRE((long)B * D * H * W < (1L << 31) && D < 1022 && H < 1022 && W < 1022, TMF_E_SHAPE,
+                "tmf_c1_stats_g: the batch exceeds 2^31 voxels or an axis 1021");
+    const int tilesD = tmf_cdiv(D, GT_D), tilesH = tmf_cdiv(H, GT_H), tilesW = tmf_cdiv(W, GT_W);
+    const long ntiles = (long)B * tilesD * tilesH * tilesW;
+    TMF_REQUIRE(ntiles < (1L << 31), TMF_E_SHAPE, "tmf_c1_stats_g: too many bricks");
+    const int ngram = (int)(ntiles < GWG ? ntiles : GWG);
+    double* g = (double*)gram;
+    double* rpart = g + NGRAM;
+    double* hpart = rpart + (size_t)GWG * NACC;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(c1_gram_kernel, dim3(ngram), dim3(GTHR), 0, s, x, rpart, D, H, W, tilesD, tilesH, tilesW, (int)ntiles);
+    hipLaunchKernelGGL(c1_shell_gram_kernel, dim3(HWG, 6), dim3(HTHR), 0, s, x, hpart, B, D, H, W);
+    hipLaunchKernelGGL(c1_gram2_finish_kernel, dim3(1), dim3(1024), 0, s, w, (const double*)rpart, ngram, (const double*)hpart, HWG, g,
+                       stat_partial, C);
+    return tmf_launch_result("tmf_c1_stats_g");
+}
+
+int tmf_c1_bwd_fused_finish(const float* part, int nblk, const float* dred, const float* w, const void* gram, const float* scale,
+                            const float* mean, const float* invstd, double count, float* dgamma, float* dbeta, float* dw, int C,
+                            int dw_ref, void* stream) {
+    hipLaunchKernelGGL(c1_bwd_fused_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, nblk, dred, w, (const double*)gram,
+                       scale, mean, invstd, count, dgamma, dbeta, dw, C, dw_ref);
+    return tmf_launch_result("tmf_c1_bwd_fused(finish)");
 }

@@ -37,6 +37,7 @@ struct LayerPlan {
 struct Plan {
     LayerPlan L[NL];
     size_t off_part;        // forward statistics partials (max over the blocks)
+    size_t off_c1gram = 0, c1gram_bytes = 0;    // fp32: Gram data of the first block (statistics forward, one-pass backward)
     size_t saved_bytes;
     // backward scratch
     size_t off_bpart, off_coef, off_dz, off_gA, off_gB, off_ws, scratch_bytes, ws_bytes;
@@ -104,6 +105,12 @@ Plan make_plan(const tmf_snet_desc& d) {
             nblk = tmf_c1_blocks(d.B, L.D, L.H, L.W, L.cout);
             nb2 = nblk;
             ws = tmf_c1_bwd_wgrad_workspace_bytes(d.B, L.D, L.H, L.W, L.cout);
+            // fp32: pair-sum statistics + the tap Gram matrix of the volume, kept for the one-pass backward (conv1_gram.hip)
+            p.c1gram_bytes = d.precision == TMF_PREC_FP32 ? tmf_c1_gram_bytes(d.B, L.D, L.H, L.W, L.cout) : 0;
+            if (p.c1gram_bytes) {
+                const size_t wf_ = tmf_c1_bwd_fused_workspace_bytes(d.B, L.D, L.H, L.W, L.cout);
+                if (wf_ > ws) ws = wf_;
+            }
         } else {
             nblk = L.bf ? tmf_conv3d_bf16_stat_blocks(d.B, L.D, L.H, L.W)
                    : L.sp ? tmf_conv3d_split_stat_blocks(d.B, L.D, L.H, L.W)
@@ -122,6 +129,7 @@ Plan make_plan(const tmf_snet_desc& d) {
         if (ws > ws_max) ws_max = ws;
     }
     p.off_part = off; off += up256(part_max);
+    p.off_c1gram = off; off += up256(p.c1gram_bytes);
     p.saved_bytes = off;
     size_t so = 0;
     p.off_bpart = so; so += up256(bpart_max);
@@ -197,10 +205,13 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
             TMF_TRY(tmf_pack_conv_weights(prm->weight[l], (float*)wf, nullptr, L.cout, 1, 27, stream));
             nblk = tmf_c1_blocks(d->B, L.D, L.H, L.W, L.cout);
             // (the fp32x mode keeps the recomputing pass — DESIGN 3.16: its margin on the ill-conditioned batch-2 fixture; the bf16 mode its own)
-            if (b16) TMF_TRY(tmf_c1_stats_bf16(vol, (const float*)wf, part, d->B, L.D, L.H, L.W, L.cout, stream));
+            if (p.c1gram_bytes) {
+                TMF_TRY(tmf_c1_stats_g(vol, (const float*)wf, part, base + p.off_c1gram, p.c1gram_bytes, d->B, L.D, L.H, L.W, L.cout, stream));
+                nblk = 2;
+            } else if (b16) TMF_TRY(tmf_c1_stats_bf16(vol, (const float*)wf, part, d->B, L.D, L.H, L.W, L.cout, stream));
             else if (d->precision == TMF_PREC_FP32X) TMF_TRY(tmf_c1_stats_direct(vol, (const float*)wf, part, d->B, L.D, L.H, L.W, L.cout, stream));
             else     TMF_TRY(tmf_c1_stats(vol, (const float*)wf, part, d->B, L.D, L.H, L.W, L.cout, stream));
-            if (d->precision == TMF_PREC_FP32)
+            if (d->precision == TMF_PREC_FP32 && !p.c1gram_bytes)
                 nblk = tmf_c1_stat_rows(d->B, L.D, L.H, L.W, L.cout, nblk);   // (2 where the sums come from the input's pair sums)
         } else if (L.bf) {
             TMF_TRY(tmf_pack_conv_weights_bf16(prm->weight[l], wf, wd, L.cout, L.cin, 27, stream));
@@ -365,6 +376,13 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
             TMF_REQUIRE(e == hipSuccess, (int)e, "tmf_snet_train_bwd: memset failed: %s", hipGetErrorString(e));
         }
         if ((size_t)L.oD * L.oH * L.oW == 0) continue;
+        if (l == 0 && p.c1gram_bytes && g->dweight[l] != nullptr) {
+            // one pass over the volume: BatchNorm sums and D = x (*) dy together; dw from the forward's Gram data (conv1_gram.hip)
+            TMF_TRY(tmf_c1_bwd_fused(vol, (const float*)wf, v.scale, v.shift, v.mean, v.invstd, (const float*)go, base + p.off_c1gram,
+                                     g->dweight[l], g->dgamma[l], g->dbeta[l], ws, p.ws_bytes, d->B, L.D, L.H, L.W, L.cout, d->slope[l],
+                                     TMF_DW_REFERENCE, stream));
+            break;
+        }
         if (l == 0) {
             const int nblk = tmf_c1_blocks(d->B, L.D, L.H, L.W, L.cout);
             if (b16) TMF_TRY(tmf_c1_bwd_reduce_bf16(vol, (const float*)wf, v.scale, v.shift, v.mean, v.invstd, go, part, d->B, L.D,

@@ -461,10 +461,16 @@ class Conv1BnPool(torch.autograd.Function):
         shift = torch.empty(C, device=dev, dtype=_f32)
         s = _stream()
         sfx = "_bf16" if mode == "bf16" else ""            # both products on the bf16 matrix cores (opt-in mode)
+        gram = None
         if training:
             nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
             part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
-            if mode == "fp32x":        # this mode keeps the recomputing pass
+            gbytes = _lib.query("tmf_c1_gram_bytes", B, D, H, W, C) if mode == "fp32" else 0
+            if gbytes:                 # pair sums + the tap Gram matrix of the volume: backward then needs one pass
+                gram = torch.empty(gbytes // 8, device=dev, dtype=torch.float64)
+                _lib.call("tmf_c1_stats_g", x.data_ptr(), wp.data_ptr(), part.data_ptr(), gram.data_ptr(), gbytes, B, D, H, W, C, s)
+                rows = 2
+            elif mode == "fp32x":      # this mode keeps the recomputing pass
                 _lib.call("tmf_c1_stats_direct", x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
                 rows = nblk
             else:
@@ -489,6 +495,7 @@ class Conv1BnPool(torch.autograd.Function):
                       out.data_ptr(), B, D, H, W, C, float(slope), *p16, s)
         ctx.save_for_backward(x, wp, scale, shift, mean, invstd)
         ctx.cfg = (training, float(slope), C, bias is not None, sfx, p16)
+        ctx.gram = gram
         return out
 
     @staticmethod
@@ -502,6 +509,18 @@ class Conv1BnPool(torch.autograd.Function):
         want16 = bool(p16 and p16[0])
         if (dout.dtype == _b16) != want16:
             dout = dout.to(_b16 if want16 else _f32)
+        if ctx.gram is not None and training and ctx.needs_input_grad[1] and not ctx.needs_input_grad[0]:
+            # one pass over the volume: BatchNorm sums and D = x (*) dy together, dw from the forward's Gram data
+            nbytes = _lib.query("tmf_c1_bwd_fused_workspace_bytes", B, D, H, W, C)
+            ws = torch.empty((max(nbytes, 16) // 4,), device=dev, dtype=_f32)
+            dweight = torch.empty((C, 1, 3, 3, 3), device=dev, dtype=_f32)
+            dgamma = torch.empty(C, device=dev, dtype=_f32)
+            dbeta = torch.empty(C, device=dev, dtype=_f32)
+            _lib.call("tmf_c1_bwd_fused", x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+                      invstd.data_ptr(), dout.data_ptr(), ctx.gram.data_ptr(), dweight.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
+                      ws.data_ptr(), nbytes, B, D, H, W, C, slope, _lib.DW_REFERENCE, s)
+            dbias = torch.zeros(C, device=dev, dtype=_f32) if has_bias else None
+            return (None, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None)
         nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
         part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
         _lib.call("tmf_c1_bwd_reduce" + sfx, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(),
