@@ -174,22 +174,20 @@ int    tmf_conv3d_c1_wgrad(const float* x, const float* dz, float* dw, void* wor
  * Fused first block: Conv3d(1->C,3x3x3) -> BatchNorm3d -> LeakyReLU -> MaxPool3d(2) (networks.py:21-26)
  * without materialising the conv output: every pass recomputes it from x (28 MB) instead of
  * reading/writing the 906 MB tensor.  x[b][d][h][w], w[27][C], pooled/dpool [b][D/2][H/2][W/2][C].
- *   tmf_c1_stats        -> stat_partial [tmf_c1_blocks()][2][C]  (reduce with tmf_bn_finalize over tmf_c1_stat_rows() rows).
- *                          tmf_set_option("c1_gram", 0 | 1) / TMF_C1_GRAM, default 1: where the buffer holds its scratch the two
- *                          sums come from the 63 pair sums of the INPUT volume (fp64) minus the directly evaluated one-voxel shell
- *                          around it (csrc/conv1_gram.hip) — no convolution; rows 0 / 1 then hold the high / low float halves of
- *                          the sums and tmf_c1_stat_rows() = 2.  0: one row per workgroup of the recomputing pass.  (fp32 entry
- *                          only: tmf_c1_stats_bf16 and tmf_c1_stats_direct always recompute and fill all tmf_c1_blocks() rows.)
+ *   tmf_c1_stats        -> stat_partial [tmf_c1_blocks()][2][C]  (reduce with tmf_bn_finalize)
  *   tmf_c1_bn_pool_fwd  -> pooled
  *   tmf_c1_bwd_reduce   -> partial [tmf_c1_blocks()][2][C]       (reduce with tmf_bn_bwd_finalize)
  *   tmf_c1_bwd_wgrad    -> dw[27][C]   (coef from tmf_bn_bwd_finalize)
  * ---------------------------------------------------------------------------- */
 int    tmf_c1_blocks(int B, int D, int H, int W, int C);
 int    tmf_c1_stats(const float* x, const float* w, float* stat_partial, int B, int D, int H, int W, int C, void* stream);
-int    tmf_c1_stat_rows(int B, int D, int H, int W, int C, int nblk);    /* rows of stat_partial that carry the sums (nblk = tmf_c1_blocks()) */
-/* Round 5, second half: the statistics AND the exact 27 x 27 tap Gram matrix G of the volume (+ the 27 shifted sums S_t) in one go —
+/* Round 5: the first block through the tap Gram matrix of its INPUT (csrc/conv1_gram.hip; tmf_set_option("c1_gram", 0 | 1) /
+ * TMF_C1_GRAM, default 1; fp32).  tmf_c1_stats_g: the statistics WITHOUT a convolution pass and the exact 27 x 27 matrix
+ * G[t][t'] = sum_v x~(v + t) x~(v + t') of the zero-padded volume (+ the 27 shifted sums S_t), from 63 offset pair sums of the
+ * volume minus per-face-class sums over the one-voxel shell around it, all in fp64 —
  * gram: tmf_c1_gram_bytes() bytes (0: not available — option "c1_gram" off or C > 64), doubles [0,729) G, [729,756) S_t, 756 S, then
- * scratch; stat_partial rows 0 / 1 as above (tmf_bn_finalize over 2 rows).  With it the backward of the block is ONE pass over the
+ * scratch; stat_partial rows 0 / 1 = the high / low float halves of sum z, sum z^2 (tmf_bn_finalize over 2 rows).  With G the
+ * backward of the block is ONE pass over the
  * volume: tmf_c1_bwd_fused = tmf_c1_bwd_reduce + tmf_bn_bwd_finalize + tmf_c1_bwd_wgrad (train mode, fp32):
  *   dw[t][c] = scale_c [ D[t][c] - c0_c S_t - c1_c invstd_c (sum_t' w[t'][c] G[t][t'] - mean_c S_t) ],  D = sum_v x(v + t) dy_c(v)
  * (dy is one element per pooling window: 27 multiply-adds per window beside the BatchNorm sums).  workspace:
@@ -202,8 +200,6 @@ int    tmf_c1_bwd_fused(const float* x, const float* w, const float* scale, cons
                         const float* invstd, const float* dpool, const void* gram, float* dw, float* dgamma, float* dbeta,
                         void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, float slope,
                         int dw_layout, void* stream);
-int    tmf_c1_stats_direct(const float* x, const float* w, float* stat_partial, int B, int D, int H, int W, int C, void* stream);   /* always
-                                                                          * the recomputing pass: all tmf_c1_blocks() rows (the fp32x mode) */
 int    tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* scale, const float* shift, float* pooled,
                           int B, int D, int H, int W, int C, float slope, void* stream);
 int    tmf_c1_bwd_reduce(const float* x, const float* w, const float* scale, const float* shift,

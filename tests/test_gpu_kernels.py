@@ -1362,62 +1362,105 @@ def test_conv3d_winograd_eval_block_in_one_pass(shape, pool):
     assert _relerr(_ncdhw(y.cpu()), ref) < 3e-6
 
 
-C1_GRAM_SHAPES = [(2, 16, 24, 40, 32), (1, 9, 13, 35, 32), (3, 8, 8, 32, 16), (8, 48, 48, 48, 32), (2, 20, 17, 21, 8)]
+C1_FUSED_SHAPES = [(2, 16, 24, 40, 32), (1, 9, 13, 35, 32), (3, 8, 10, 33, 16), (5, 17, 16, 19, 8), (8, 48, 48, 48, 32)]
 
 
-@pytest.mark.parametrize("bf16", [False, True])
-@pytest.mark.parametrize("shape", C1_GRAM_SHAPES)
-def test_first_block_statistics_from_input_pair_sums(shape, bf16):
-    """tmf_c1_stats with "c1_gram" 1 (csrc/conv1_gram.hip: sum z and sum z^2 of the Cin = 1 convolution from the 63 pair sums of the
-    input volume minus the directly evaluated shell) against the direct pass ("c1_gram" 0: conv1_fused_kernel<0>) and against fp64
-    torch: mean and 1 / std after tmf_bn_finalize, on a smooth volume with an offset (wide filters cancel there) and on noise;
-    two runs are bit-identical."""
+@pytest.mark.parametrize("shape", C1_FUSED_SHAPES)
+def test_first_block_gram_data_and_one_pass_backward(shape):
+    """tmf_c1_stats_g (csrc/conv1_gram.hip): the exact tap Gram matrix G[t][t'] = sum_v x~(v + t) x~(v + t') and the shifted sums S_t
+    of the zero-padded volume against an explicit fp64 evaluation; tmf_c1_bwd_fused (BatchNorm sums and D = x (*) dy in ONE
+    recomputing pass, dw from G) against the two-pass backward (tmf_c1_bwd_reduce + tmf_bn_bwd_finalize + tmf_c1_bwd_wgrad) and
+    against fp64 torch through the whole block; bit-identical run to run."""
     from transmf_ad_amd import _lib
     ops = _ops()
     B, D, H, W, C = shape
-    g = torch.Generator().manual_seed(5)
-    zz, yy, xx = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
-    smooth = (3.0 + torch.sin(0.21 * zz + 0.13 * yy) * torch.cos(0.17 * xx)).float()
-    for kind in ("smooth", "noise"):
-        x = (smooth.expand(B, D, H, W) + 0.01 * torch.rand((B, D, H, W), generator=g)) if kind == "smooth" else torch.rand((B, D, H, W), generator=g)
-        x = x.contiguous()
-        w = torch.randn((C, 1, 3, 3, 3), generator=g) * 0.3
-        xg = x.to(DEV)
-        wp = ops.pack_weight(w.to(DEV)).view(27, C)
-        nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
-        gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
-        res = {}
-        for gram in (1, 0, 1):
-            _lib.call("tmf_set_option", b"c1_gram", gram)
-            try:
-                part = torch.full((nblk, 2, C), float("nan"), device=DEV)
-                _lib.call("tmf_c1_stats" + ("_bf16" if bf16 else ""), xg.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, ops._stream())
-                mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
-                rows = nblk if bf16 else _lib.query("tmf_c1_stat_rows", B, D, H, W, C, nblk)
-                _lib.call("tmf_bn_finalize", part.data_ptr(), rows, C, float(B * D * H * W), gamma.data_ptr(), beta.data_ptr(), None, None, None,
-                          0.1, 1e-5, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), ops._stream())
-                torch.cuda.synchronize()
-            finally:
-                _lib.call("tmf_set_option", b"c1_gram", 1)
-            assert torch.isfinite(part[:rows]).all()
-            res.setdefault(gram, []).append((mean.cpu(), invstd.cpu(), part[:rows].cpu(), rows))
-        (m1, i1, p1, r1), (m1b, i1b, p1b, _r) = res[1]
-        m0, i0, _, r0 = res[0][0]
-        assert torch.equal(p1, p1b) and torch.equal(m1, m1b) and torch.equal(i1, i1b)
-        # the path is taken where the partial buffer holds its scratch (a volume of a few bricks keeps the direct pass)
-        ngram = min(256, B * -(-D // 8) * -(-H // 8) * -(-W // 32))
-        fits = nblk * 2 * C * 4 >= -(-16 * C // 256) * 256 + ngram * 512 + 2 * C * 4
-        assert fits or shape == C1_GRAM_SHAPES[-1]
-        if bf16:        # (the bf16 entry keeps its own recomputing pass — 2 MFMAs per tile —: the option does not reach it)
-            fits = False
-        assert r0 == nblk and r1 == (2 if fits else nblk)
-        xr, wr = (x.bfloat16().double(), w.bfloat16().double()) if bf16 else (x.double(), w.double())
-        z = F.conv3d(xr.unsqueeze(1), wr, None, 1, 1)
-        mref, vref = z.mean((0, 2, 3, 4)), z.var((0, 2, 3, 4), unbiased=False)
-        iref = (vref + 1e-5).rsqrt()
-        sc = z.abs().mean().item()
-        assert (m1.double() - mref).abs().max().item() <= 2e-6 * sc, (kind, (m1.double() - mref).abs().max().item(), sc)
-        assert ((i1.double() - iref).abs() / iref).max().item() <= 2e-5, (kind, ((i1.double() - iref).abs() / iref).max().item())
-        # ... and no further from fp64 than the direct pass is (up to a floor)
-        e1, e0 = ((i1.double() - iref).abs() / iref).max().item(), ((i0.double() - iref).abs() / iref).max().item()
-        assert e1 <= max(2.0 * e0, 2e-6), (kind, e1, e0)
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand((B, D, H, W), generator=g) * 0.8 + 0.1
+    w = torch.randn((C, 1, 3, 3, 3), generator=g) * 0.3
+    xg = x.to(DEV)
+    wp = ops.pack_weight(w.to(DEV)).view(27, C)
+    nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
+    gbytes = _lib.query("tmf_c1_gram_bytes", B, D, H, W, C)
+    assert gbytes > 0
+    part = torch.full((nblk, 2, C), float("nan"), device=DEV)
+    gram = torch.empty(gbytes // 8, device=DEV, dtype=torch.float64)
+    _lib.call("tmf_c1_stats_g", xg.data_ptr(), wp.data_ptr(), part.data_ptr(), gram.data_ptr(), gbytes, B, D, H, W, C, ops._stream())
+    torch.cuda.synchronize()
+    xp = F.pad(x.double(), (2, 2, 2, 2, 2, 2))                                    # shifted copies of the zero-padded volume over V
+    sh = torch.stack([xp[:, 1 + t // 9:1 + t // 9 + D, 1 + (t // 3) % 3:1 + (t // 3) % 3 + H, 1 + t % 3:1 + t % 3 + W].reshape(-1)
+                      for t in range(27)])
+    G_ref, S_ref = sh @ sh.t(), sh.sum(1)
+    G = gram[:729].cpu().view(27, 27)
+    assert (G - G_ref).abs().max().item() <= 1e-12 * G_ref.abs().max().item()
+    assert (gram[729:756].cpu() - S_ref).abs().max().item() <= 1e-12 * S_ref.abs().max().item()
+    assert abs(gram[756].item() - x.double().sum().item()) <= 1e-12 * x.double().sum().item()
+    # statistics rows 0 / 1 (high + low halves) = the sums of the exactly computed z
+    z = F.conv3d(x.double().unsqueeze(1), w.double(), None, 1, 1)
+    s1 = (part[0, 0].double() + part[1, 0].double()).cpu()
+    s2 = (part[0, 1].double() + part[1, 1].double()).cpu()
+    assert (s1 - z.sum((0, 2, 3, 4))).abs().max().item() <= 1e-9 * z.abs().sum((0, 2, 3, 4)).max().item()
+    assert ((s2 - (z * z).sum((0, 2, 3, 4))).abs() / (z * z).sum((0, 2, 3, 4))).max().item() <= 1e-9
+    # ... and on a smooth volume with an offset (wide filters cancel there): mean and 1 / sigma after tmf_bn_finalize against fp64
+    # and against the recomputing pass ("c1_gram" 0: tmf_c1_gram_bytes() = 0, callers run conv1_fused_kernel<0>)
+    zz_, yy_, xx_ = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    xs = ((3.0 + torch.sin(0.21 * zz_ + 0.13 * yy_) * torch.cos(0.17 * xx_)).float().expand(B, D, H, W) + 0.01 * torch.rand((B, D, H, W), generator=g)).contiguous()
+    xsg = xs.to(DEV)
+    gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+
+    def finalize(p_, rows):
+        mean, invstd, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
+        _lib.call("tmf_bn_finalize", p_.data_ptr(), rows, C, float(B * D * H * W), gamma.data_ptr(), beta.data_ptr(), None, None, None,
+                  0.1, 1e-5, mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(), shift.data_ptr(), ops._stream())
+        torch.cuda.synchronize()
+        return mean.cpu().double(), invstd.cpu().double()
+    _lib.call("tmf_c1_stats_g", xsg.data_ptr(), wp.data_ptr(), part.data_ptr(), gram.data_ptr(), gbytes, B, D, H, W, C, ops._stream())
+    m1, i1 = finalize(part, 2)
+    pd = torch.empty((nblk, 2, C), device=DEV)
+    _lib.call("tmf_c1_stats", xsg.data_ptr(), wp.data_ptr(), pd.data_ptr(), B, D, H, W, C, ops._stream())
+    m0, i0 = finalize(pd, nblk)
+    zs = F.conv3d(xs.double().unsqueeze(1), w.double(), None, 1, 1)
+    mref, iref = zs.mean((0, 2, 3, 4)), (zs.var((0, 2, 3, 4), unbiased=False) + 1e-5).rsqrt()
+    assert (m1 - mref).abs().max().item() <= 2e-6 * zs.abs().mean().item()
+    e1, e0 = ((i1 - iref).abs() / iref).max().item(), ((i0 - iref).abs() / iref).max().item()
+    assert e1 <= 2e-5 and e1 <= max(2.0 * e0, 2e-6), (e1, e0)
+    _lib.call("tmf_set_option", b"c1_gram", 0)
+    try:
+        assert _lib.query("tmf_c1_gram_bytes", B, D, H, W, C) == 0
+    finally:
+        _lib.call("tmf_set_option", b"c1_gram", 1)
+    # the whole block, both backward forms
+    conv = torch.nn.Conv3d(1, C, 3, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm3d(C).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w.to(DEV))
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.2, 0.2)
+    go = torch.randn((B, D // 2, H // 2, W // 2, C), generator=g).to(DEV)
+    res = {}
+    for gram_opt in (1, 0, 1):
+        _lib.call("tmf_set_option", b"c1_gram", gram_opt)
+        try:
+            for p_ in (conv.weight, bn.weight, bn.bias):
+                p_.grad = None
+            y = ops.conv_bn_act_pool(xg.unsqueeze(-1), conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean.clone(),
+                                     bn.running_var.clone(), True, pool="max")
+            y.backward(go)
+            torch.cuda.synchronize()
+        finally:
+            _lib.call("tmf_set_option", b"c1_gram", 1)
+        res.setdefault(gram_opt, []).append((y.detach().cpu(), conv.weight.grad.cpu().clone(), bn.weight.grad.cpu().clone(), bn.bias.grad.cpu().clone()))
+    a, a2 = res[1]
+    b = res[0][0]
+    assert all(torch.equal(u, v) for u, v in zip(a, a2))
+    for u, v in zip(a[1:], b[1:]):
+        assert (u - v).abs().max().item() <= 2e-5 * v.abs().max().item()
+    if B * D * H * W <= 40000:
+        w64 = w.double().requires_grad_(True)
+        g64, b64 = bn.weight.detach().double().cpu().requires_grad_(True), bn.bias.detach().double().cpu().requires_grad_(True)
+        zz = F.conv3d(x.double().unsqueeze(1), w64, conv.bias.detach().double().cpu(), padding=1)
+        yy = F.max_pool3d(F.leaky_relu(F.batch_norm(zz, None, None, g64, b64, True, 0.1, 1e-5), 0.01), 2)
+        yy.backward(go.double().permute(0, 4, 1, 2, 3).cpu())
+        e1 = (a[1].double() - w64.grad).abs().max().item() / w64.grad.abs().max().item()
+        e0 = (b[1].double() - w64.grad).abs().max().item() / w64.grad.abs().max().item()
+        assert e1 <= max(3.0 * e0, 5e-6), (e1, e0)
+        assert (a[2].double() - g64.grad).abs().max().item() <= 5e-6 * g64.grad.abs().max().item()

@@ -75,13 +75,16 @@ def test_winograd_kernels_fit_their_registers_without_scratch(kernels):
 def test_persistent_winograd_and_pair_sum_kernels_do_not_spill(kernels):
     """Round 5's kernels: conv3d_wino_p_kernel<0|1|2, 0|1> and conv3d_wino_wgrad_p_kernel<0|1> hold 256 accumulators in AGPRs and
     everything else in the 256 VGPRs (a spill lands in the chunk loop of a kernel that pays ~5 matrix cycles per instruction);
-    the three kernels of conv1_gram.hip keep their accumulators (63 doubles per thread in c1_gram_kernel) in registers."""
+    the kernels of conv1_gram.hip keep their accumulators (63 doubles per thread in c1_gram_kernel) in registers, and so does the
+    one-pass backward of the first block (conv1_fused_kernel<4>: 27 more accumulators per lane)."""
     ks = _find(kernels, "conv3d_wino.o", "conv3d_wino_p_kernelILi")
     assert len(ks) == 6
     kw = _find(kernels, "conv3d_wino.o", "conv3d_wino_wgrad_p_kernelILi")
     assert len(kw) == 2
     for k in ks + kw:                               # (the code object counts VGPRs + AGPRs: 512 = the whole file of a one-wave SIMD)
         assert k["vgpr"] <= 512 and k.get("scratch", 0) == 0, k
-    for needle in ("c1_gram_kernel", "c1_shell_kernel", "c1_gram_finish_kernel"):
+    for needle in ("c1_gram_kernel", "c1_shell_gram_kernel", "c1_gram2_finish_kernel", "c1_bwd_fused_finish_kernel"):
         for k in _find(kernels, "conv1_gram.o", needle):
             assert k.get("scratch", 0) == 0, k
+    for k in _find(kernels, "conv1_fused.o", "conv1_fused_kernelILi4E"):
+        assert k["vgpr"] <= 256 and k.get("scratch", 0) == 0, k

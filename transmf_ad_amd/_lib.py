@@ -61,8 +61,6 @@ PROTOTYPES = {
     "tmf_conv3d_c1_wgrad": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _i, _p]),
     "tmf_c1_blocks": (_i, [_i, _i, _i, _i, _i]),
     "tmf_c1_stats": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "tmf_c1_stat_rows": (_i, [_i, _i, _i, _i, _i, _i]),
-    "tmf_c1_stats_direct": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tmf_c1_gram_bytes": (_z, [_i, _i, _i, _i, _i]),
     "tmf_c1_stats_g": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
     "tmf_c1_bwd_fused_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),

@@ -525,17 +525,12 @@ extern "C" int tmf_c1_blocks(int B, int D, int H, int W, int C) {
     return make_plan(B, D, H, W, C, SLAB_BLOCKS).nblk;
 }
 
-static int c1_stats(bool bf16, bool pair_sums, const float* x, const float* w, float* stat_partial,
+static int c1_stats(bool bf16, const float* x, const float* w, float* stat_partial,
                     int B, int D, int H, int W, int C, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(stat_partial);
     int rc = check("tmf_c1_stats", B, D, H, W, C);
     if (rc) return rc;
     const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
-    // the sums from pair sums of the input (conv1_gram.hip) where the partial buffer holds that path's scratch: no convolution
-    if (pair_sums) {
-        rc = tmf_c1_stats_gram(x, w, stat_partial, p.nblk, B, D, H, W, C, stream);
-        if (rc != 0) return rc < 0 ? rc : TMF_OK;
-    }
     Args a = base_args(x, w, D, H, W, C, p, 0.f);
     a.partial = stat_partial;
     if (bf16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_STATS, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
@@ -544,17 +539,11 @@ static int c1_stats(bool bf16, bool pair_sums, const float* x, const float* w, f
 }
 extern "C" int tmf_c1_stats(const float* x, const float* w, float* stat_partial,
                             int B, int D, int H, int W, int C, void* stream) {
-    return c1_stats(false, true, x, w, stat_partial, B, D, H, W, C, stream);
+    return c1_stats(false, x, w, stat_partial, B, D, H, W, C, stream);
 }
 extern "C" int tmf_c1_stats_bf16(const float* x, const float* w, float* stat_partial,
                                  int B, int D, int H, int W, int C, void* stream) {
-    return c1_stats(true, false, x, w, stat_partial, B, D, H, W, C, stream);       // (2 bf16 MFMAs per tile: cheaper than the pair sums)
-}
-// always the recomputing pass (one row per workgroup: tmf_bn_finalize over all tmf_c1_blocks() rows) — what the fp32x mode keeps
-// (tmf_c1_stats_bf16 is always its own recomputing pass as well)
-extern "C" int tmf_c1_stats_direct(const float* x, const float* w, float* stat_partial,
-                                   int B, int D, int H, int W, int C, void* stream) {
-    return c1_stats(false, false, x, w, stat_partial, B, D, H, W, C, stream);
+    return c1_stats(true, x, w, stat_partial, B, D, H, W, C, stream);
 }
 
 static int c1_bn_pool_fwd(bool bf16, bool p16, const float* x, const float* w, const float* scale, const float* shift,

@@ -204,15 +204,12 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
             // fused first block: the conv output is never stored (csrc/conv1_fused.hip)
             TMF_TRY(tmf_pack_conv_weights(prm->weight[l], (float*)wf, nullptr, L.cout, 1, 27, stream));
             nblk = tmf_c1_blocks(d->B, L.D, L.H, L.W, L.cout);
-            // (the fp32x mode keeps the recomputing pass — DESIGN 3.16: its margin on the ill-conditioned batch-2 fixture; the bf16 mode its own)
+            // fp32: pair sums + the tap Gram matrix; the fp32x and bf16 modes keep their recomputing passes
             if (p.c1gram_bytes) {
                 TMF_TRY(tmf_c1_stats_g(vol, (const float*)wf, part, base + p.off_c1gram, p.c1gram_bytes, d->B, L.D, L.H, L.W, L.cout, stream));
                 nblk = 2;
             } else if (b16) TMF_TRY(tmf_c1_stats_bf16(vol, (const float*)wf, part, d->B, L.D, L.H, L.W, L.cout, stream));
-            else if (d->precision == TMF_PREC_FP32X) TMF_TRY(tmf_c1_stats_direct(vol, (const float*)wf, part, d->B, L.D, L.H, L.W, L.cout, stream));
             else     TMF_TRY(tmf_c1_stats(vol, (const float*)wf, part, d->B, L.D, L.H, L.W, L.cout, stream));
-            if (d->precision == TMF_PREC_FP32 && !p.c1gram_bytes)
-                nblk = tmf_c1_stat_rows(d->B, L.D, L.H, L.W, L.cout, nblk);   // (2 where the sums come from the input's pair sums)
         } else if (L.bf) {
             TMF_TRY(tmf_pack_conv_weights_bf16(prm->weight[l], wf, wd, L.cout, L.cin, 27, stream));
             nblk = tmf_conv3d_bf16_stat_blocks(d->B, L.D, L.H, L.W);

@@ -88,9 +88,7 @@ extern int tmf_g_wgrad_tr;       // conv3d_bf16.hip: bf16 weight-gradient kernel
 int tmf_conv3d_fwd_mode(const float* x, const float* w, float* z, float* stat_partial, int B, int D, int H, int W, int cin,
                         int cout, int ksize, int rt_min, void* stream);
 int tmf_conv3d_stat_blocks_mode(int B, int D, int H, int W, int cin, int cout, int ksize, int rt_min);
-int tmf_c1_gram_set(int v);      // conv1_gram.hip: tmf_set_option("c1_gram", 0 | 1): first-block statistics from pair sums of the input
-// conv1_gram.hip: -> 1 enqueued (stat_partial written in full), 0 not taken (the caller runs the direct pass), < 0 error
-int tmf_c1_stats_gram(const float* x, const float* w, float* stat_partial, int nblk, int B, int D, int H, int W, int C, void* stream);
+int tmf_c1_gram_set(int v);      // conv1_gram.hip: tmf_set_option("c1_gram", 0 | 1): the first block through the tap Gram matrix of its input
 int tmf_wino_p_set(int v);       // conv3d_wino.hip: tmf_set_option("wino_p", 0 | 1): two-waves-per-SIMD / persistent one-wave-per-SIMD forward kernel
 int tmf_conv_wino_set(int v);    // conv3d_wino.hip: tmf_set_option("conv_wino", 0 | 1 | 2)
 extern int tmf_g_bf16_dma;       // conv3d_bf16.hip: LDS-DMA form of the large-brick bf16 forward kernel (tmf_set_option("bf16_dma", 0 | 1))

@@ -470,13 +470,9 @@ class Conv1BnPool(torch.autograd.Function):
                 gram = torch.empty(gbytes // 8, device=dev, dtype=torch.float64)
                 _lib.call("tmf_c1_stats_g", x.data_ptr(), wp.data_ptr(), part.data_ptr(), gram.data_ptr(), gbytes, B, D, H, W, C, s)
                 rows = 2
-            elif mode == "fp32x":      # this mode keeps the recomputing pass
-                _lib.call("tmf_c1_stats_direct", x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
-                rows = nblk
-            else:
+            else:                      # the recomputing pass (bf16: its own; fp32x keeps it: DESIGN 3.16)
                 _lib.call("tmf_c1_stats" + sfx, x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
-                # fp32: 2 rows where the sums come from pair sums of the input; the bf16 pass writes one row per workgroup
-                rows = nblk if sfx else _lib.query("tmf_c1_stat_rows", B, D, H, W, C, nblk)
+                rows = nblk
             _lib.call("tmf_bn_finalize", part.data_ptr(), rows, C, float(B * D * H * W),
                       gamma.data_ptr(), beta.data_ptr(), _ptr(bias), _ptr(running_mean), _ptr(running_var),
                       float(momentum), float(eps), mean.data_ptr(), invstd.data_ptr(), scale.data_ptr(),
