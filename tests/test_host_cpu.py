@@ -317,3 +317,22 @@ def test_built_kernels_have_no_use_of_registers_in_flight_and_no_store_data_over
             assert loads >= 100 and stores >= 40                            # (the check has seen the kernels)
             assert not uses and not uses2, (uses + uses2)[:5]
     assert seen >= 300
+
+
+def test_first_block_gram_path_is_offered_only_inside_its_limits():
+    """tmf_c1_gram_bytes (csrc/conv1_gram.hip): 0 — the callers then take the recomputing passes — beyond 64 channels, beyond the
+    32-bit voxel offsets / 10-bit coordinates of its kernels, and with the option off; the backward workspace covers the sums, the
+    D slabs, their reduction scratch and the reduced D."""
+    from transmf_ad_amd import _lib
+    lib = _lib.load()
+    n = lib.tmf_c1_gram_bytes(8, 96, 96, 96, 32)
+    assert n == (760 + 256 * 64 + 6 * 64 * 96) * 8
+    assert lib.tmf_c1_gram_bytes(8, 96, 96, 96, 128) == 0 and lib.tmf_c1_gram_bytes(1, 1100, 64, 64, 32) == 0
+    assert lib.tmf_c1_gram_bytes(64, 400, 400, 400, 32) == 0 and lib.tmf_c1_gram_bytes(0, 96, 96, 96, 32) == 0
+    assert lib.tmf_set_option(b"c1_gram", 0) == 0
+    try:
+        assert lib.tmf_c1_gram_bytes(8, 96, 96, 96, 32) == 0
+    finally:
+        lib.tmf_set_option(b"c1_gram", 1)
+    nblk = lib.tmf_c1_blocks(8, 96, 96, 96, 32)
+    assert lib.tmf_c1_bwd_fused_workspace_bytes(8, 96, 96, 96, 32) >= (nblk * 2 * 32 + (nblk + 1) * 27 * 32) * 4

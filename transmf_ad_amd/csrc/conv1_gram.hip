@@ -361,6 +361,9 @@ int tmf_c1_gram_set(int v) { g_c1_gram = v ? 1 : 0; return TMF_OK; }
 // ---- the statistics + Gram data of the forward, and the one-pass backward (fp32; conv1_fused.hip launches the MODE_RD kernel) ----
 extern "C" size_t tmf_c1_gram_bytes(int B, int D, int H, int W, int C) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0 || !c1_gram_mode() || C > GMAXC) return 0;
+    // (32-bit voxel offsets and 10-bit packed coordinates in the shell kernel: larger volumes take the recomputing passes)
+    if ((long)B * D * H * W >= (1L << 31) || D >= 1022 || H >= 1022 || W >= 1022) return 0;
+    if ((long)B * tmf_cdiv(D, GT_D) * tmf_cdiv(H, GT_H) * tmf_cdiv(W, GT_W) >= (1L << 31)) return 0;
     return ((size_t)NGRAM + (size_t)GWG * NACC + (size_t)6 * HWG * HPART) * 8;
 }
 
