@@ -1791,7 +1791,14 @@ int launch_wino_p_g(const char* what, const float* x, const float* u, float* z, 
     const long per_launch = (long)ncu * GM::TAB;            // a workgroup's item table holds TAB entries
     for (long i0 = 0; i0 < nitems; i0 += per_launch) {
         const long n = nitems - i0 < per_launch ? nitems - i0 : per_launch;
-        const int grid = (int)(n < ncu ? n : ncu);
+        // as many workgroups as the launch needs for its number of ROUNDS (864 items on 256 CUs are 4 rounds: 216 workgroups
+        // of exactly 4 items take as long as 256 of 3 or 4 and leave 40 CUs to the other encoder's stream)
+        int grid = (int)(n < ncu ? n : ncu);
+        static const bool even = !(getenv("TMF_WINO_EVEN") && atoi(getenv("TMF_WINO_EVEN")) == 0);
+        if (even && n > ncu) {
+            const long rounds = (n + ncu - 1) / ncu;
+            grid = (int)((n + rounds - 1) / rounds);
+        }
         hipLaunchKernelGGL(k, dim3(grid), dim3(PN), PLds<GEOM>::BYTES, stream, x, u, z, stat_partial, B, D, H, W, cin, cout,
                            tilesD, tilesH, tilesW, (int)nbricks, (int)i0, (int)n, scale, shift, slope, pool, ncu, i0 > 0 ? 1 : 0);
         if ((rc = tmf_launch_result(what))) return rc;
