@@ -1,5 +1,5 @@
 # One GPU-box pass that regenerates what profiles/ holds for the round (fp32 headline + configs[2] bf16 report).
-# Run through gpurun from the repo root:  gpurun --timeout 2400 -- 'bash tools/scripts/refresh_profiles.sh r04'
+# Run through gpurun from the repo root:  gpurun --timeout 2400 -- 'bash tools/scripts/refresh_profiles.sh <tag>'
 # then copy gpurun_out/refresh/* into profiles/.
 TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
