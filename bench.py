@@ -2,6 +2,7 @@
 """bench.py — volume-pairs/s of the TransMF_AD train step (fwd + bwd + Adam) on MI355X.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N --steps K --warmup W          (starts the N ranks itself, as child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -436,15 +437,49 @@ def _is_default_workload(args):
             and not args.no_cpu_baseline and args.steps > 0 and args.dropout == 0.0 and args.conv_wino == 3)
 
 
+def launch_command(argv, n_gpus, port, python=None):
+    """The command `python bench.py --gpus N ...` turns itself into when it was started WITHOUT a torchrun environment:
+    one rank per GPU of this node over RCCL, exactly the driver's own multi-GPU launch line (rendezvous on 127.0.0.1)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py")] + list(argv)
+
+
+def visible_gpu_error(n_gpus, visible):
+    """None when `n_gpus` ranks fit on this node, else the message bench.py exits with."""
+    if n_gpus <= visible:
+        return None
+    return (f"bench.py --gpus {n_gpus}: {n_gpus} GPUs requested, {visible} visible on this node "
+            f"(one rank per GPU; no oversubscription in the benchmark)")
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) without WORLD_SIZE: start the N ranks as CHILD processes — before this process has
+    made any GPU call (torch.cuda.device_count() does not initialise the device on this image; a process that has must never
+    exec another program) —, relay their output (rank 0 prints the ONE JSON line) and return the child's exit code."""
+    import socket
+    import subprocess
+    err = visible_gpu_error(args.gpus, torch.cuda.device_count())
+    if err:
+        raise SystemExit(err)
+    with socket.socket() as s:                       # a free rendezvous port
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    return subprocess.call(launch_command(argv, args.gpus, port), env=env)
+
+
 def main():
     import copy
     args = build_parser().parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     from transmf_ad_amd.parallel import init_from_env
 
     rank, local, world = init_from_env()
     if world != args.gpus:
         if args.gpus != 1 or world != 1:
-            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback in the product path)")
     torch.cuda.set_device(local)

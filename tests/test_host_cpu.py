@@ -336,3 +336,31 @@ def test_first_block_gram_path_is_offered_only_inside_its_limits():
         lib.tmf_set_option(b"c1_gram", 1)
     nblk = lib.tmf_c1_blocks(8, 96, 96, 96, 32)
     assert lib.tmf_c1_bwd_fused_workspace_bytes(8, 96, 96, 96, 32) >= (nblk * 2 * 32 + (nblk + 1) * 27 * 32) * 4
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a torchrun environment composes the driver's launch line and starts it as a CHILD
+    process before any GPU call; with fewer GPUs than ranks it says so."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launch_command(["--gpus", "4", "--steps", "7", "--warmup", "2"], 4, 29611, python="python3")
+    assert cmd[:3] == ["python3", "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29611"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]          # the same arguments, after the script
+    assert bench.visible_gpu_error(2, 8) is None and bench.visible_gpu_error(8, 8) is None
+    assert "2 GPUs requested, 1 visible" in bench.visible_gpu_error(2, 1)
+    # end to end on this box (no GPU): the self-launch path is taken and refuses before any child is started
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "2 GPUs requested, 0 visible" in r.stderr and "launch with torch.distributed.run" not in r.stderr
+    # inside a launcher's environment a mismatch is still an error of its own
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True,
+                        text=True, timeout=300)
+    assert r2.returncode != 0 and "--nproc-per-node must equal --gpus" in r2.stderr
