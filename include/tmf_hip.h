@@ -147,7 +147,16 @@ int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);       /* rows of
 int    tmf_conv3d_wino_bricks(int B, int D, int H, int W);            /* bricks the forward kernel walks per 32 output channels */
 const char* tmf_conv3d_wino_kernel_name(int B, int D, int H, int W, int stats);        /* the instance a kernel trace shows (as */
 const char* tmf_conv3d_wgrad_wino_kernel_name(int B, int D, int H, int W, int cin, int cout);   /* tmf_conv3d_fwd_kernel_name) */
-size_t tmf_conv3d_wino_weight_bytes(int cin, int cout);             /* 64 * cin * cout floats */
+const char* tmf_conv3d_wino_kernel_name2(int B, int D, int H, int W, int cin, int cout, int stats);   /* ... with the channel counts: the
+                                                                       * split kernel conv3d_winox_kernel where it takes the launch */
+size_t tmf_conv3d_wino_weight_bytes(int cin, int cout);             /* 64 * cin * cout floats + the same numbers as three bf16 parts
+                                                                       * (6 bytes each) behind them */
+/* tmf_wino_x_mode(): tmf_set_option("wino_x", 0 | 1) / TMF_WINO_X — 1 (default): tmf_conv3d_fwd_wino (train forward and data gradient)
+ * runs csrc/conv3d_winox.hip where cin % 32 == 0, cout % 32 == 0 and the volume takes 4x8x8 bricks: the SAME fp32 products, each
+ * operand split exactly into three bf16 numbers (no rounding: 8 + 8 + 8 significand bits), six of the nine partial products on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation — the dropped three are below 2^-24 of the product, under the rounding of the
+ * fp32 product itself.  0: the fp32 matrix pipe (conv3d_wino_p_kernel) everywhere. */
+int    tmf_wino_x_mode(void);
 int    tmf_conv_wino_mode(void);
 /* tmf_wino_p_mode(): tmf_set_option("wino_p", 0 | 1) / TMF_WINO_P — 1 (default): the three Winograd entries run their persistent
  * one-wave-per-SIMD kernels (conv3d_wino_p_kernel, conv3d_wino_wgrad_p_kernel; the forward picks per volume between 4x8x8

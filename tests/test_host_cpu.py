@@ -253,7 +253,7 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
     # statistic partials of the persistent kernel: one row per workgroup = compute unit, whatever the volume (256 without a device)
     rows = lib.tmf_conv3d_wino_stat_blocks(8, 48, 48, 48)
     assert 64 <= rows <= 1024 and lib.tmf_conv3d_wino_stat_blocks(2, 7, 9, 13) == rows and lib.tmf_conv3d_wino_stat_blocks(0, 4, 4, 4) == 0
-    assert lib.tmf_conv3d_wino_weight_bytes(32, 64) == 64 * 32 * 64 * 4
+    assert lib.tmf_conv3d_wino_weight_bytes(32, 64) == 64 * 32 * 64 * (4 + 6)      # the fp32 tensor + its 3-way bf16 split
     # conv2.0 at B = 8, 48^3: one (ci, co) block -> 256 slabs in 16 groups
     assert lib.tmf_wino_p_mode() == 1
     assert lib.tmf_conv3d_wino_bricks(8, 12, 12, 12) == 2 * 3 * 3 * 3               # four samples x 4x4x4 bricks where that is fewer tiles
@@ -275,7 +275,8 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
         for mode in (0, 1, 2, 3):
             assert lib.tmf_set_option(b"conv_wino", mode) == 0
             size[mode] = lib.tmf_snet_saved_bytes(ctypes.byref(desc)), lib.tmf_snet_bwd_scratch_bytes(ctypes.byref(desc))
-        per_layout = sum((64 - 27) * ci * co * 4 for ci, co in layers)     # every size here is a multiple of 256
+        # (a Winograd layout = the fp32 tensor + its exact 3-way bf16 split behind it, 4 + 6 bytes per transformed weight)
+        per_layout = sum((64 * 10 - 27 * 4) * ci * co for ci, co in layers)     # every size here is a multiple of 256
         assert size[1][0] - size[0][0] == per_layout                       # data-gradient layouts
         # (the statistic partials — one buffer, sized for the block with the most: rows per workgroup instead of per tile)
         vols = [48, 48, 24, 24, 12]
@@ -316,6 +317,14 @@ def test_built_kernels_have_no_use_of_registers_in_flight_and_no_store_data_over
             loads2, uses2 = asm_checks.inflight_uses(out, "wino_wgrad_p_kernel")
             assert loads >= 100 and stores >= 40                            # (the check has seen the kernels)
             assert not uses and not uses2, (uses + uses2)[:5]
+        if f == "conv3d_winox.o":
+            # counted waits (s_waitcnt vmcnt(n), loads / LDS-DMA copies / stores retire in order): a model of the queue walks every
+            # control-flow edge of the kernels and finds no access to a register whose load is still outstanding
+            import asm_inflight
+            res = asm_inflight.check_object(os.path.join(R.CSRC, f), "winox_kernel")
+            assert len(res) == 2
+            for name, bad, loads, depth in res:
+                assert loads >= 40 and depth <= 63 and not bad, (name, bad[:5])
     assert seen >= 300
 
 

@@ -1655,6 +1655,7 @@ extern "C" int tmf_set_option(const char* name, int value) {
         return TMF_OK;
     }
     if (strcmp(name, "wino_p") == 0) return tmf_wino_p_set(value);
+    if (strcmp(name, "wino_x") == 0) return tmf_wino_x_set(value);
     if (strcmp(name, "c1_gram") == 0) return tmf_c1_gram_set(value);
     if (strcmp(name, "conv_wino") == 0) {
         TMF_REQUIRE(value >= 0 && value <= 3, TMF_E_ARG, "tmf_set_option: conv_wino must be 0, 1, 2 or 3, got %d", value);

@@ -1712,13 +1712,33 @@ __device__ __forceinline__ void wino_pack_one(const float* __restrict__ w, float
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float v = (float)G(t2[p][q][0], t2[p][q][1], t2[p][q][2], r);
+                // the same number as three bf16 parts (exact: 8 + 8 + 8 significand bits) for conv3d_winox.hip, behind the fp32 tensor:
+                //   [p][K / 16][part h, m, l][K half 2][N][8] bf16,  K index 16 c + 8 s + 4 half + e  ->  element s * 4 + e of its half
+                const unsigned uv = __builtin_bit_cast(unsigned, v);
+                const float r1 = v - __builtin_bit_cast(float, uv & 0xFFFF0000u);
+                const unsigned ur1 = __builtin_bit_cast(unsigned, r1);
+                const float r2 = r1 - __builtin_bit_cast(float, ur1 & 0xFFFF0000u);
+                const unsigned short part[3] = {(unsigned short)(uv >> 16), (unsigned short)(ur1 >> 16),
+                                                (unsigned short)(__builtin_bit_cast(unsigned, r2) >> 16)};
                 if (fwd != nullptr) {
                     const int pos = (p * 4 + q) * 4 + r;
                     fwd[((((size_t)pos * (cin / 8) + ci / 8) * 2 + (ci >> 2 & 1)) * cout + co) * 4 + (ci & 3)] = v;
+                    if (cin % 32 == 0) {
+                        unsigned short* f3 = reinterpret_cast<unsigned short*>(fwd + (size_t)64 * cin * cout);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            f3[(((((size_t)pos * (cin / 16) + ci / 16) * 3 + t) * 2 + (ci >> 2 & 1)) * cout + co) * 8 + (ci >> 3 & 1) * 4 + (ci & 3)] = part[t];
+                    }
                 }
                 if (dgrad != nullptr) {
                     const int pos = (fl[p] * 4 + fl[q]) * 4 + fl[r];
                     dgrad[((((size_t)pos * (cout / 8) + co / 8) * 2 + (co >> 2 & 1)) * cin + ci) * 4 + (co & 3)] = v;
+                    if (cout % 32 == 0) {
+                        unsigned short* d3 = reinterpret_cast<unsigned short*>(dgrad + (size_t)64 * cin * cout);
+#pragma unroll
+                        for (int t = 0; t < 3; ++t)
+                            d3[(((((size_t)pos * (cout / 16) + co / 16) * 3 + t) * 2 + (co >> 2 & 1)) * cin + ci) * 8 + (co >> 3 & 1) * 4 + (co & 3)] = part[t];
+                    }
                 }
             }
 }
@@ -1808,6 +1828,10 @@ int launch_wino_p_g(const char* what, const float* x, const float* u, float* z, 
 template <int MODE>
 int launch_wino_p(const char* what, const float* x, const float* u, float* z, float* stat_partial, int B, int D, int H, int W,
                   int cin, int cout, const float* scale, const float* shift, float slope, int pool, hipStream_t stream) {
+    // train forward / data gradient on the bf16 matrix pipe through exact 3-way splits (conv3d_winox.hip) where it takes the launch
+    if (MODE != 2 && tmf_winox_takes(B, D, H, W, cin, cout, wino_p_geom(B, D, H, W)))
+        return tmf_winox_launch(what, x, reinterpret_cast<const unsigned short*>(u + (size_t)64 * cin * cout), z, stat_partial, B, D, H, W,
+                                cin, cout, wino_cu_count(), stream);
     if (wino_p_geom(B, D, H, W)) return launch_wino_p_g<MODE, 1>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
     return launch_wino_p_g<MODE, 0>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
 }
@@ -1857,6 +1881,11 @@ extern "C" int tmf_conv3d_wino_bricks(int B, int D, int H, int W) {
 
 // the kernel instance tmf_conv3d_fwd_wino (stats: with statistic partials) / tmf_conv3d_wgrad_wino launch for a volume, as a kernel
 // trace prints it (bench.py's roofline rows and tools/pmc_traffic.py's keys)
+extern "C" const char* tmf_conv3d_wino_kernel_name2(int B, int D, int H, int W, int cin, int cout, int stats) {
+    if (wino_p_mode() && B > 0 && D > 0 && H > 0 && W > 0 && tmf_winox_takes(B, D, H, W, cin, cout, wino_p_geom(B, D, H, W)))
+        return stats ? "conv3d_winox_kernel<1>" : "conv3d_winox_kernel<0>";
+    return tmf_conv3d_wino_kernel_name(B, D, H, W, stats);
+}
 extern "C" const char* tmf_conv3d_wino_kernel_name(int B, int D, int H, int W, int stats) {
     if (!wino_p_mode()) return stats ? "conv3d_wino_kernel<1>" : "conv3d_wino_kernel<0>";
     const int g = (B > 0 && D > 0 && H > 0 && W > 0) ? wino_p_geom(B, D, H, W) : 0;
@@ -1868,7 +1897,9 @@ extern "C" const char* tmf_conv3d_wgrad_wino_kernel_name(int B, int D, int H, in
     return plan_wino_wgrad(B, D, H, W, cin, cout).geom ? "conv3d_wino_wgrad_p_kernel<1>" : "conv3d_wino_wgrad_p_kernel<0>";
 }
 
-extern "C" size_t tmf_conv3d_wino_weight_bytes(int cin, int cout) { return (size_t)64 * cin * cout * 4; }
+// the fp32 tensor U[64][cin][cout] and, behind it, its exact 3-way bf16 split (conv3d_winox.hip; written when the K dimension is a
+// multiple of 32, reserved always: which kernel reads the buffer is decided per launch)
+extern "C" size_t tmf_conv3d_wino_weight_bytes(int cin, int cout) { return (size_t)64 * cin * cout * (4 + 6); }
 
 extern "C" int tmf_pack_conv_weights_wino(const float* w, float* u_fwd, float* u_dgrad, int cout, int cin, void* stream) {
     TMF_REQUIRE_PTR(w);

@@ -90,6 +90,10 @@ int tmf_conv3d_fwd_mode(const float* x, const float* w, float* z, float* stat_pa
 int tmf_conv3d_stat_blocks_mode(int B, int D, int H, int W, int cin, int cout, int ksize, int rt_min);
 int tmf_c1_gram_set(int v);      // conv1_gram.hip: tmf_set_option("c1_gram", 0 | 1): the first block through the tap Gram matrix of its input
 int tmf_wino_p_set(int v);       // conv3d_wino.hip: tmf_set_option("wino_p", 0 | 1): two-waves-per-SIMD / persistent one-wave-per-SIMD forward kernel
+int tmf_wino_x_set(int v);       // conv3d_winox.hip: tmf_set_option("wino_x", 0 | 1): Winograd forward / data gradient as exact 3-way bf16 splits on the bf16 matrix pipe
+int tmf_winox_takes(int B, int D, int H, int W, int cin, int cout, int geom);
+int tmf_winox_launch(const char* what, const float* x, const unsigned short* u3, float* z, float* stat_partial, int B, int D, int H,
+                     int W, int cin, int cout, int ncu, hipStream_t stream);
 int tmf_conv_wino_set(int v);    // conv3d_wino.hip: tmf_set_option("conv_wino", 0 | 1 | 2)
 extern int tmf_g_bf16_dma;       // conv3d_bf16.hip: LDS-DMA form of the large-brick bf16 forward kernel (tmf_set_option("bf16_dma", 0 | 1))
 extern int tmf_g_bf16_v2;        // conv3d_bf16.hip: kernel choice of the bf16 forward (tmf_set_option("bf16_v2", ..))

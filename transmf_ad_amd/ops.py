@@ -179,8 +179,12 @@ def pack_weights_wino(weight: torch.Tensor, want_fwd: bool = True, want_dgrad: b
     """Winograd-transformed weights of one (cout, cin, 3, 3, 3) tensor in ONE launch: u_fwd [64][cin/8][2][cout][4] and
     u_dgrad [64][cout/8][2][cin][4] (flipped filter, channel roles swapped); None for a form that is not asked for."""
     cout, cin = weight.shape[0], weight.shape[1]
-    uf = torch.empty((64, cin // 8, 2, cout, 4), device=weight.device, dtype=_f32) if want_fwd else None
-    ud = torch.empty((64, cout // 8, 2, cin, 4), device=weight.device, dtype=_f32) if want_dgrad else None
+    # (the library's buffer is the fp32 tensor plus, behind it, its exact 3-way bf16 split for conv3d_winox.hip: the returned
+    #  tensors are views of the fp32 part, the storage carries both)
+    n = 64 * cin * cout
+    nb = _lib.query("tmf_conv3d_wino_weight_bytes", cin, cout) // 4
+    uf = torch.empty((nb,), device=weight.device, dtype=_f32)[:n].view(64, cin // 8, 2, cout, 4) if want_fwd else None
+    ud = torch.empty((nb,), device=weight.device, dtype=_f32)[:n].view(64, cout // 8, 2, cin, 4) if want_dgrad else None
     _lib.call("tmf_pack_conv_weights_wino", weight.data_ptr(), _ptr(uf), _ptr(ud), cout, cin, _stream())
     return uf, ud
 
