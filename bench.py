@@ -84,47 +84,46 @@ def _cd(a, b):
     return -(-a // b)
 
 
-def wino_fwd_bricks(B, D, H, W):
-    """Bricks (32 tiles each) of the Winograd forward / data-gradient launch: 4x8x8 voxels of one sample, or — where that
-    executes fewer tiles, the persistent kernel's choice (csrc/conv3d_wino.hip wino_p_geom) — 4x4x4 voxels of four samples."""
-    b0 = B * _cd(D, 4) * _cd(H, 8) * _cd(W, 8)
-    if os.environ.get("TMF_WINO_P", "1") == "0":
-        return b0
-    b1 = _cd(B, 4) * _cd(D, 4) * _cd(H, 4) * _cd(W, 4)
-    return b1 if b1 < b0 else b0
-
-
 def wino_exec_flops(kind, B, D, H, W, ci, co):
-    """Matrix flops a Winograd launch EXECUTES: 2 * 64 products per 2x2x2 tile, input and output channel, over the PADDED bricks
-    (forward / data gradient: 32 tiles per brick, wino_fwd_bricks; weight gradient: stages of 16 tiles — 4x4x8 voxels of one
-    sample or, where that is fewer stages, 4x4x4 voxels of two samples: csrc/conv3d_wino.hip plan_wino_wgrad)."""
+    """Matrix flops a Winograd launch EXECUTES and the pipe they run on -> (flops, "fp32" | "bf16").  2 * 64 products per 2x2x2
+    tile, input and output channel, over the PADDED bricks the library's own plan walks (forward / data gradient:
+    tmf_conv3d_wino_bricks x 32 tiles; weight gradient: tmf_conv3d_wgrad_wino_tiles).  Where the split kernel takes the launch
+    (csrc/conv3d_winox.hip: every fp32 product as six bf16 partial products) the count is 6 x that, on the bf16 matrix pipe."""
+    from transmf_ad_amd import _lib
     if kind == "wgrad":
-        s0 = B * _cd(D, 4) * _cd(H, 4) * _cd(W, 8)
-        s1 = _cd(B, 2) * _cd(D, 4) * _cd(H, 4) * _cd(W, 4)
-        if os.environ.get("TMF_WINO_P", "1") != "0" and s1 < s0:
-            s0 = s1
-        return 2.0 * 64 * ci * co * 16 * s0
-    return 2.0 * 64 * ci * co * 32 * wino_fwd_bricks(B, D, H, W)
+        return 2.0 * 64 * ci * co * _lib.query("tmf_conv3d_wgrad_wino_tiles", B, D, H, W, ci, co), "fp32"
+    base = 2.0 * 64 * ci * co * 32 * _lib.query("tmf_conv3d_wino_bricks", B, D, H, W)
+    if _lib.query("tmf_conv3d_wino_kernel_name2", B, D, H, W, ci, co, 0).startswith(b"conv3d_winox"):
+        return 6.0 * base, "bf16"
+    return base, "fp32"
 
 
 def exec_flops_per_pair(size, wino, B, dim=128, streams=2):
-    """EXECUTED matrix flops fwd+bwd per pair at batch B: the algorithmic count of conv_flops_per_pair with the Cin > 1 3x3x3
-    layers priced by wino_exec_flops where the step runs them in the Winograd form (wino: 0 never, 1 data gradients, 2 + forward,
-    3 + weight gradients) — the denominator of the whole step's `mfma_frac`."""
+    """EXECUTED matrix flops fwd+bwd per pair at batch B, per pipe -> {"fp32": .., "bf16": ..}: the algorithmic count of
+    conv_flops_per_pair with the Cin > 1 3x3x3 layers priced by wino_exec_flops where the step runs them in the Winograd form
+    (wino: 0 never, 1 data gradients, 2 + forward, 3 + weight gradients) — the numerators of the whole step's `mfma_frac`."""
     q, h, d, d2 = dim // 4, dim // 2, dim, dim * 2
     layers = [(1, q, 3, 0), (q, q, 3, 1), (q, h, 3, 1), (h, h, 3, 2), (h, d, 3, 2), (d, d2, 3, 3), (d2, d, 1, 3)]
     dims = (size, size, size) if isinstance(size, int) else tuple(size)
-    tot = 0.0
+    tot = {"fp32": 0.0, "bf16": 0.0}
     for i, (ci, co, k, lvl) in enumerate(layers):
         D, H, W = (e >> lvl for e in dims)
         f = 2.0 * ci * co * k ** 3 * D * H * W
         if i == 0 or k == 1:
-            tot += f * (2 if i == 0 else 3)
+            tot["fp32"] += f * (2 if i == 0 else 3)
             continue
-        tot += wino_exec_flops("fwd", B, D, H, W, ci, co) / B if wino >= 2 else f
-        tot += wino_exec_flops("dgrad", B, D, H, W, co, ci) / B if wino >= 1 else f
-        tot += wino_exec_flops("wgrad", B, D, H, W, ci, co) / B if wino >= 3 else f
-    return streams * tot
+        for kind, a, b, on in (("fwd", ci, co, wino >= 2), ("dgrad", co, ci, wino >= 1), ("wgrad", ci, co, wino >= 3)):
+            if on:
+                fl, pipe = wino_exec_flops(kind, B, D, H, W, a, b)
+                tot[pipe] += fl / B
+            else:
+                tot["fp32"] += f
+    return {k: streams * v for k, v in tot.items()}
+
+
+def _at_peak_ms(flops_by_pipe):
+    """Milliseconds the executed matrix flops take at the peak of the pipe they run on."""
+    return flops_by_pipe.get("fp32", 0.0) / PEAK_FP32_MFMA_TFLOPS / 1e9 + flops_by_pipe.get("bf16", 0.0) / PEAK_BF16_MFMA_TFLOPS / 1e9
 
 
 def _pmc_traffic(kernel, precision, storage, B, vol):
@@ -178,8 +177,8 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
     rows = []
     # the Winograd instances as a kernel trace names them (conv3d_wino.hip: the persistent one-wave-per-SIMD kernels and their
     # brick geometry per volume)
-    def wino_name(D, H, W, stats):
-        return _lib.query("tmf_conv3d_wino_kernel_name", B, D, H, W, stats).decode()
+    def wino_name(D, H, W, cin_, cout_, stats):
+        return _lib.query("tmf_conv3d_wino_kernel_name2", B, D, H, W, cin_, cout_, stats).decode()
     b16 = precision == "bf16"
     s16 = b16 and storage == "bf16"
     adt = torch.bfloat16 if s16 else torch.float32
@@ -213,10 +212,10 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             wino = ops.conv_wino_mode() if precision == "fp32" else 0       # as the step runs them (snet_path.hip make_plan)
             if wino >= 2 and ops.wino_ok(ci, co):
                 uf, _ = ops.pack_weights_wino(w, True, False)
-                fns = (("fwd", wino_name(D, H, W, 1), lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
+                fns = (("fwd", wino_name(D, H, W, ci, co, 1), lambda: ops.conv3d_wino_raw(x, uf, ci, co, True)),) + fns[1:]
             if wino >= 1 and ops.wino_ok(co, ci):
                 _, ud = ops.pack_weights_wino(w, False, True)
-                fns = (fns[0], ("dgrad", wino_name(D, H, W, 0), lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
+                fns = (fns[0], ("dgrad", wino_name(D, H, W, co, ci, 0), lambda: ops.conv3d_wino_raw(dz, ud, co, ci, False)), fns[2])
             if wino >= 3 and ops.wgrad_wino_ok(ci, co):
                 fns = fns[:2] + (("wgrad", _lib.query("tmf_conv3d_wgrad_wino_kernel_name", B, D, H, W, ci, co).decode(),
                                  lambda: ops.conv3d_wgrad_wino(x, dz, ci, co)),)
@@ -229,12 +228,12 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
             ms = _time_launches(fn, reps)
             # executed matrix flops: the Winograd form multiplies 64 numbers per 2x2x2 tile, input and output channel (bricks
             # of 4x8x8 voxels, padded); the direct kernels execute the algorithmic count
-            ex = fl
+            ex, pipe = fl, ("bf16" if b16 else "fp32")
             if kern.startswith("conv3d_wino_wgrad"):
-                ex = wino_exec_flops("wgrad", B, D, H, W, ci, co)
+                ex, pipe = wino_exec_flops("wgrad", B, D, H, W, ci, co)
             elif kern.startswith("conv3d_wino"):
-                ex = wino_exec_flops(pas, B, D, H, W, ci, co)
-            rows.append(dict(layer=name, **{"pass": pas}, kernel=kern, ms=ms, flops=fl, bytes=by, exec_flops=ex))
+                ex, pipe = wino_exec_flops(pas, B, D, H, W, *((ci, co) if pas == "fwd" else (co, ci)))
+            rows.append(dict(layer=name, **{"pass": pas}, kernel=kern, ms=ms, flops=fl, bytes=by, exec_flops=ex, pipe=pipe))
         del x, dz, w, wf, wd
     # fused first block: statistics + normalise/pool forward, backward reduce + weight gradient (z never stored)
     D, H, W = vol
@@ -253,7 +252,7 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
     vox = B * D * H * W
     rows.append(dict(layer="conv1.0", **{"pass": "fwd+bwd (4 recompute passes)"},
                      kernel="conv1_fused_kernel<0..3>" + (" bf16" if b16 else ""), ms=ms, flops=2 * 2.0 * 27 * q * vox,
-                     exec_flops=2 * 2.0 * 27 * q * vox, bytes=float(2 * vox * 4 + 2 * (vox // 8) * q * el)))
+                     exec_flops=2 * 2.0 * 27 * q * vox, pipe="bf16" if b16 else "fp32", bytes=float(2 * vox * 4 + 2 * (vox // 8) * q * el)))
     return rows
 
 
@@ -266,34 +265,42 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
       * step_conv   = FLOP-weighted over EVERY conv launch of one step (both encoders);
       * whole_step  = the train step itself (pairs/s x figure per pair) against both ceilings;
       * best_launch = the single best launch;  layers = the full table."""
-    peak_tf = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS     # (of the ALGORITHMIC figures' pipe)
+    pk = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16": PEAK_BF16_MFMA_TFLOPS}
+
+    def peak_ms(r):                 # milliseconds the row's executed flops take at the peak of the pipe they run on
+        return r.get("exec_flops", r["flops"]) / pk[r.get("pipe", "fp32")] / 1e9
     groups = {}
     for r in rows:
-        g = groups.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, exec_flops=0.0, launches=0, members=[]))
+        g = groups.setdefault(r["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, exec_flops=0.0, peak_ms=0.0, launches=0, members=[],
+                                                pipe=r.get("pipe", "fp32")))
         g["ms"] += r["ms"]; g["flops"] += r["flops"]; g["bytes"] += r["bytes"]; g["launches"] += 1
         g["exec_flops"] += r.get("exec_flops", r["flops"])
+        g["peak_ms"] += peak_ms(r)
         g["members"].append(f"{r['layer']} {r['pass']}")
     # the fused first block is four different kernels (+ their finalize launches) timed as one group: it stays in
     # `kernels` / `step_conv`, but the dominant INSTANCE is a single kernel
     dom_name, dom = max(((k, g) for k, g in groups.items() if not k.startswith("conv1_fused_kernel<0..3>")),
                         key=lambda kv: kv[1]["ms"])
 
-    def fracs(ex, fl, by, ms):
-        """executed TF, its fraction, algorithmic TF, its fraction, GB/s, its fraction"""
-        return (ex / ms / 1e9, ex / ms / 1e9 / peak_tf, fl / ms / 1e9, fl / ms / 1e9 / peak_tf, by / ms / 1e6, by / ms / 1e6 / PEAK_HBM_GBS)
-    etf, efr, atf, afr, gbs, hfr = fracs(dom["exec_flops"], dom["flops"], dom["bytes"], dom["ms"])
-    bound = "mfma" if dom["exec_flops"] / peak_tf / 1e9 >= dom["bytes"] / PEAK_HBM_GBS / 1e6 else "hbm"     # ms at either ceiling
+    def fracs(g):
+        """executed TF (on its pipe), matrix-pipe fraction, algorithmic TF, its fraction, GB/s, its fraction"""
+        return (g["exec_flops"] / g["ms"] / 1e9, g["peak_ms"] / g["ms"], g["flops"] / g["ms"] / 1e9, g["flops"] / g["ms"] / 1e9 / peak_tf,
+                g["bytes"] / g["ms"] / 1e6, g["bytes"] / g["ms"] / 1e6 / PEAK_HBM_GBS)
+    etf, efr, atf, afr, gbs, hfr = fracs(dom)
+    bound = "mfma" if dom["peak_ms"] >= dom["bytes"] / PEAK_HBM_GBS / 1e6 else "hbm"     # ms at either ceiling
     tot_ms = sum(r["ms"] for r in rows)
     tot_fl = sum(r["flops"] for r in rows)
-    tot_ex = sum(r.get("exec_flops", r["flops"]) for r in rows)
+    tot_pk = sum(peak_ms(r) for r in rows)
+    tot_ex = {pp: sum(r.get("exec_flops", r["flops"]) for r in rows if r.get("pipe", "fp32") == pp) for pp in ("fp32", "bf16")}
     tot_by = sum(r["bytes"] for r in rows)
-    best = max((r for r in rows if r["layer"] != "conv1.0"), key=lambda r: r.get("exec_flops", r["flops"]) / r["ms"])
+    best = max((r for r in rows if r["layer"] != "conv1.0"), key=lambda r: peak_ms(r) / r["ms"])
     traffic = _pmc_traffic(dom_name, precision, storage, B, vol)
 
     def kern_entry(g):
-        e = fracs(g["exec_flops"], g["flops"], g["bytes"], g["ms"])
+        e = fracs(g)
         return {"launches_per_encoder_step": g["launches"], "ms": round(g["ms"], 4), "avg_launch_ms": round(g["ms"] / g["launches"], 4),
-                "tflops": round(e[0], 1), "mfma_frac": round(e[1], 4), "algorithmic_tflops": round(e[2], 1),
+                "pipe": g["pipe"], "tflops": round(e[0], 1), "mfma_frac": round(e[1], 4), "algorithmic_tflops": round(e[2], 1),
                 "algorithmic_frac": round(e[3], 4), "hbm_frac": round(e[5], 4)}
     roof = {
         "bound": bound,
@@ -301,9 +308,10 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
         "scope": f"all {dom['launches']} launches of the time-dominant kernel instance in one encoder's train step "
                  f"({', '.join(dom['members'])}); B={B}, volume {'x'.join(map(str, vol))}",
         "achieved": round(etf if bound == "mfma" else gbs, 2),
-        "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
+        "peak": pk[dom["pipe"]] if bound == "mfma" else PEAK_HBM_GBS,
         "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
         "frac": round(efr if bound == "mfma" else hfr, 4),
+        "pipe": dom["pipe"],
         "traffic": None if traffic is None else traffic.get("hbm_bytes_per_launch"),
         "traffic_note": None if traffic is None else f"{traffic.get('note')} [{traffic.get('source')}]",
         "launch_ms": round(dom["ms"] / dom["launches"], 4),
@@ -318,30 +326,34 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
         "products_ratio": round(dom["exec_flops"] / dom["flops"], 4),
         "share_of_conv_time": round(dom["ms"] / tot_ms, 3),
         "kernels": {k: kern_entry(g) for k, g in groups.items()},
-        "step_conv": {"what": "FLOP-weighted over every conv launch of one train step (fwd + dgrad + wgrad of the five "
-                              "Cin>1 layers + the fused first block; x2 encoders), launches timed back to back",
-                      "ms_per_step": round(2 * tot_ms, 3), "tflops": round(tot_ex / tot_ms / 1e9, 2),
-                      "mfma_frac": round(tot_ex / tot_ms / 1e9 / peak_tf, 4),
+        "step_conv": {"what": "over every conv launch of one train step (fwd + dgrad + wgrad of the five Cin>1 layers + the fused "
+                              "first block; x2 encoders), launches timed back to back; mfma_frac = time of the executed flops at "
+                              "the peak of the pipe each launch runs on / measured time",
+                      "ms_per_step": round(2 * tot_ms, 3), "tflops_fp32_pipe": round(tot_ex["fp32"] / tot_ms / 1e9, 2),
+                      "tflops_bf16_pipe": round(tot_ex["bf16"] / tot_ms / 1e9, 2),
+                      "mfma_frac": round(tot_pk / tot_ms, 4),
                       "algorithmic_tflops": round(tot_fl / tot_ms / 1e9, 2),
                       "algorithmic_frac": round(tot_fl / tot_ms / 1e9 / peak_tf, 4),
                       "hbm_frac": round(tot_by / tot_ms / 1e6 / PEAK_HBM_GBS, 4)},
-        "best_launch": {"layer": best["layer"], "pass": best["pass"], "kernel": best["kernel"],
+        "best_launch": {"layer": best["layer"], "pass": best["pass"], "kernel": best["kernel"], "pipe": best.get("pipe", "fp32"),
                         "ms": round(best["ms"], 4), "tflops": round(best.get("exec_flops", best["flops"]) / best["ms"] / 1e9, 2),
-                        "mfma_frac": round(best.get("exec_flops", best["flops"]) / best["ms"] / 1e9 / peak_tf, 4),
+                        "mfma_frac": round(peak_ms(best) / best["ms"], 4),
                         "algorithmic_frac": round(best["flops"] / best["ms"] / 1e9 / peak_tf, 4)},
-        "layers": {f"{r['layer']} {r['pass']}": {"ms": round(r["ms"], 4),
+        "layers": {f"{r['layer']} {r['pass']}": {"ms": round(r["ms"], 4), "pipe": r.get("pipe", "fp32"),
                                                  "tflops": round(r.get("exec_flops", r["flops"]) / r["ms"] / 1e9, 1),
-                                                 "mfma_frac": round(r.get("exec_flops", r["flops"]) / r["ms"] / 1e9 / peak_tf, 3),
+                                                 "mfma_frac": round(peak_ms(r) / r["ms"], 3),
                                                  "algorithmic_frac": round(r["flops"] / r["ms"] / 1e9 / peak_tf, 3),
                                                  "hbm_frac": round(r["bytes"] / r["ms"] / 1e6 / PEAK_HBM_GBS, 3)}
                    for r in rows},
         "peak_note": ("frac = achieved / peak with achieved = executed_flops_per_launch x launches / (launch_ms x launches): the matrix "
-                      "flops the launches EXECUTE.  A direct kernel executes the algorithmic count (SURVEY.md 8d: 2*27*Cin*Cout per "
-                      "output voxel); a Winograd F(2x2x2, 3x3x3) launch (conv3d_wino_*: exact-fp32 arithmetic on the same fp32 matrix "
-                      "pipe) executes 2*64*Cin*Cout per 2x2x2 tile over its PADDED bricks (4x8x8 voxels forward / data gradient, 4x4x8 "
-                      "weight gradient) — products_ratio of the algorithmic count; `algorithmic_*` is the 8d figure over the same time "
-                      "(may exceed 1 for a Winograd launch).  Reproduce from a rocprofv3 --kernel-trace --stats summary of "
-                      "`bench.py --roofline-only`: executed_flops_per_launch / AverageNs of the kernel named here / peak"),
+                      "flops the launches EXECUTE on the pipe named in `pipe` (fp32: v_mfma_f32_32x32x2_f32, 157.3 TF; bf16: "
+                      "v_mfma_f32_32x32x16_bf16, 2 500 TF).  A direct kernel executes the algorithmic count (SURVEY.md 8d: 2*27*Cin*Cout per "
+                      "output voxel); a Winograd F(2x2x2, 3x3x3) launch executes 2*64*Cin*Cout per 2x2x2 tile over its PADDED bricks "
+                      "(tmf_conv3d_wino_bricks / tmf_conv3d_wgrad_wino_tiles) — on the fp32 pipe (conv3d_wino_*) or, in the split kernel "
+                      "(conv3d_winox_kernel: every fp32 operand as three exact bf16 parts), as SIX bf16 products each on the bf16 pipe; "
+                      "`algorithmic_*` is the 8d figure over the same time against the fp32 peak (may exceed 1 for a Winograd launch).  "
+                      "Reproduce from a rocprofv3 --kernel-trace --stats summary of `bench.py --roofline-only`: executed_flops_per_launch "
+                      "/ AverageNs of the kernel named here / peak"),
     }
     if precision == "fp32x":
         roof["peak_note"] = ("opt-in mode: the forward / data-gradient kernel evaluates every fp32 product as six bf16 partial products on "
@@ -353,19 +365,21 @@ def roofline_report(rows, precision, storage, pairs_per_s, world, gf_pair, bytes
 
 
 def whole_step_entry(pairs_per_s, world, gf_pair, bytes_pair, precision, exec_gf_pair=None):
-    """The train step itself against both ceilings: units/s per GPU x the figure per unit — executed matrix flops (mfma_frac,
-    <= 1) and the algorithmic SURVEY.md 8d figure beside it."""
+    """The train step itself against both ceilings: units/s per GPU x the figure per unit — executed matrix flops per pipe
+    (mfma_frac = their time at the peaks / the step time, <= 1) and the algorithmic SURVEY.md 8d figure beside it."""
     peak_tf = PEAK_BF16_MFMA_TFLOPS if precision == "bf16" else PEAK_FP32_MFMA_TFLOPS
     per_gpu = pairs_per_s / world
-    ex = gf_pair if exec_gf_pair is None else exec_gf_pair
+    ex = exec_gf_pair if isinstance(exec_gf_pair, dict) else {("bf16" if precision == "bf16" else "fp32"): (gf_pair if exec_gf_pair is None else exec_gf_pair)}
+    pk_s = _at_peak_ms(ex) / 1e3                          # seconds of matrix-pipe time per pair at the peaks
     return {
-        "what": "the train step itself: pairs/s per GPU x figure per pair (executed matrix flops; algorithmic = SURVEY.md 8d)",
-        "conv_tflops": round(per_gpu * ex / 1e12, 2), "mfma_frac": round(per_gpu * ex / 1e12 / peak_tf, 4),
+        "what": "the train step itself: pairs/s per GPU x figure per pair (executed matrix flops per pipe; algorithmic = SURVEY.md 8d)",
+        "conv_tflops_fp32_pipe": round(per_gpu * ex.get("fp32", 0.0) / 1e12, 2), "conv_tflops_bf16_pipe": round(per_gpu * ex.get("bf16", 0.0) / 1e12, 2),
+        "mfma_frac": round(per_gpu * pk_s, 4),
         "algorithmic_tflops": round(per_gpu * gf_pair / 1e12, 2), "algorithmic_frac": round(per_gpu * gf_pair / 1e12 / peak_tf, 4),
         "hbm_GBps": round(per_gpu * bytes_pair / 1e9, 1), "hbm_frac": round(per_gpu * bytes_pair / 1e9 / PEAK_HBM_GBS, 4),
-        "executed_GFLOP_per_pair": round(ex / 1e9, 2),
+        "executed_GFLOP_per_pair": {k: round(v / 1e9, 2) for k, v in ex.items()},
         "algorithmic_GFLOP_per_pair": round(gf_pair / 1e9, 2), "algorithmic_GB_per_pair": round(bytes_pair / 1e9, 3),
-        "bound": "mfma" if ex / peak_tf / 1e12 >= bytes_pair / PEAK_HBM_GBS / 1e9 else "hbm"}
+        "bound": "mfma" if pk_s >= bytes_pair / PEAK_HBM_GBS / 1e9 else "hbm"}
 
 
 def build_parser():
@@ -749,7 +763,8 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
     by_pair = conv_bytes_per_pair(vol, 2 if args.storage == "bf16" else 4) * half
     # executed matrix flops per pair: the Winograd layers at 64 products per tile in the fp32 mode; the bf16 / fp32x modes run the
     # direct form (fp32x: six bf16 partial products per fp32 product, priced as ONE fp32 product each — see peak_note)
-    ex_pair = exec_flops_per_pair(vol, args.conv_wino if args.precision == "fp32" else 0, B) * half
+    ex_pair = exec_flops_per_pair(vol, args.conv_wino if args.precision == "fp32" else 0, B)
+    ex_pair = {("bf16" if args.precision == "bf16" and k == "fp32" else k): v * half for k, v in ex_pair.items()}
     if rank == 0 and not args.eval:
         if brief and not getattr(args, "also_kernel_roofline", False):
             roof = {"whole_step": whole_step_entry(pairs_per_s, world, gf_pair, by_pair, args.precision, ex_pair)}
@@ -854,9 +869,13 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
                    "step": "val_step: eval-mode no_grad forward + CE" if args.eval else
                            ("zero_grad+fwd+loss+bwd+allreduce+Adam" if args.no_item_sync or args.model == "single" else
                             "zero_grad+fwd+loss+2x loss.item()+bwd+allreduce+Adam (kfold_train_adversarial.py:101-136)"),
-                   "conv_algorithm": ({3: "fp32: Winograd F(2x2x2,3x3x3) on the fp32 matrix pipe for forward, data and weight gradients "
-                                          "of the Cin>1 3x3x3 blocks (exact-fp32 arithmetic, 64/216 of the products), direct implicit "
-                                          "GEMM for the first block and the 1x1x1 block",
+                   "conv_algorithm": ({3: "fp32: Winograd F(2x2x2,3x3x3) for forward, data and weight gradients of the Cin>1 3x3x3 blocks "
+                                          "(64/216 of the products): weight gradients and the 12^3 block on the fp32 matrix pipe, "
+                                          + ("forward / data gradients of the blocks with Cin % 32 == 0 on the bf16 matrix pipe with every fp32 "
+                                             "operand split EXACTLY into three bf16 numbers (six partial products, fp32 accumulation; the "
+                                             "dropped three are below 2^-24 of the product) — csrc/conv3d_winox.hip; "
+                                             if _lib.query("tmf_wino_x_mode") else "forward / data gradients on the fp32 matrix pipe; ")
+                                          + "direct implicit GEMM for the first block and the 1x1x1 block",
                                        2: "fp32: Winograd F(2x2x2,3x3x3) on the fp32 matrix pipe for forward and data gradients of the "
                                           "Cin>1 3x3x3 blocks (exact-fp32 arithmetic, 64/216 of the products), direct implicit GEMM for "
                                           "the weight gradients, the first block and the 1x1x1 block",
@@ -873,7 +892,7 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
                    "setup_steps_untimed": setup_steps,
                    "per_step_timing": "ms_per_step = wall clock of the K steps / K (the contract); _min / _median from one HIP "
                                       "event per step boundary on the issuing stream"},
-        "conv_tflops_whole_step": round(pairs_per_s / world * (ex_pair if not args.eval else gf) / 1e12, 2),
+        "conv_tflops_whole_step": round(pairs_per_s / world * (sum(ex_pair.values()) if not args.eval else gf) / 1e12, 2),
         "algorithmic_conv_tflops_whole_step": round(pairs_per_s / world * gf / 1e12, 2),
         "loss": round(final_loss, 6),
         "roofline": roof, "cpu_baseline": cpu,

@@ -147,6 +147,8 @@ int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);       /* rows of
 int    tmf_conv3d_wino_bricks(int B, int D, int H, int W);            /* bricks the forward kernel walks per 32 output channels */
 const char* tmf_conv3d_wino_kernel_name(int B, int D, int H, int W, int stats);        /* the instance a kernel trace shows (as */
 const char* tmf_conv3d_wgrad_wino_kernel_name(int B, int D, int H, int W, int cin, int cout);   /* tmf_conv3d_fwd_kernel_name) */
+long   tmf_conv3d_wgrad_wino_tiles(int B, int D, int H, int W, int cin, int cout);     /* 2x2x2 tiles (padded: 16 per stage) the weight-
+                                                                       * gradient launch multiplies per channel pair */
 const char* tmf_conv3d_wino_kernel_name2(int B, int D, int H, int W, int cin, int cout, int stats);   /* ... with the channel counts: the
                                                                        * split kernel conv3d_winox_kernel where it takes the launch */
 size_t tmf_conv3d_wino_weight_bytes(int cin, int cout);             /* 64 * cin * cout floats + the same numbers as three bf16 parts

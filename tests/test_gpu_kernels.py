@@ -1280,6 +1280,77 @@ def test_conv3d_winograd_form(shape):
         assert _relerr(_ncdhw(dx.cpu()), dref) < 2e-6
 
 
+WINOX_SHAPES = [
+    # B, D, H, W, cin, cout — launches the split kernel takes (cin, cout multiples of 32, 4x8x8 bricks of one sample)
+    (1, 4, 8, 8, 32, 32),           # one brick, one item per workgroup
+    (2, 7, 9, 13, 32, 32),          # every brick ragged
+    (1, 8, 16, 16, 32, 64),         # two groups of output channels
+    (2, 12, 24, 24, 64, 128),       # four chunks, four groups: workgroups walk several items and groups
+    (2, 9, 17, 21, 128, 64),        # eight chunks, odd edges
+    (5, 16, 16, 24, 32, 32),        # more items than compute units on a small device are still a strided list
+]
+
+
+def _winox_parts(u, cin, cout):
+    """The three bf16 parts the pack kernel writes behind the fp32 tensor u [64][K/8][2][N][4] -> [3][64][K][N] floats
+    (layout [p][K/16][part][K half][N][8], K index 16 c + 8 s + 4 half + e -> element 4 s + e of its half)."""
+    n = 64 * cin * cout
+    raw = torch.empty(0, dtype=torch.int16, device=u.device).set_(u.untyped_storage(), (u.storage_offset() + n) * 2, (3 * n,))
+    f = (raw.view(64, cin // 16, 3, 2, cout, 8).to(torch.int32) << 16).view(torch.float32)
+    return f.view(64, cin // 16, 3, 2, cout, 2, 4).permute(2, 0, 1, 5, 3, 6, 4).reshape(3, 64, cin, cout)
+
+
+@pytest.mark.parametrize("shape", WINOX_SHAPES)
+def test_conv3d_winograd_split_kernel(shape):
+    """conv3d_winox_kernel (csrc/conv3d_winox.hip; the default of tmf_conv3d_fwd_wino where it takes the launch): the Winograd
+    products on the bf16 matrix pipe through EXACT 3-way bf16 splits of both fp32 operands.  The packed parts sum to the fp32
+    transformed weight bit for bit; z, the statistic partials and the data gradient hold the fp32 kernel's tolerances against
+    fp64 torch and lie within fp32 round-off of the fp32 kernel (tmf_set_option("wino_x", 0)); results are bit-reproducible."""
+    from transmf_ad_amd import _lib
+    ops = _ops()
+    B, D, H, W, cin, cout = shape
+    assert _lib.query("tmf_wino_x_mode") == 1
+    assert _lib.query("tmf_conv3d_wino_kernel_name2", B, D, H, W, cin, cout, 1) == b"conv3d_winox_kernel<1>"
+    assert _lib.query("tmf_conv3d_wino_kernel_name2", B, D, H, W, cout, cin, 0) == b"conv3d_winox_kernel<0>"
+    x = _rand(B, cin, D, H, W, seed=331)
+    w = _rand(cout, cin, 3, 3, 3, seed=332, scale=(cin * 27) ** -0.5)
+    xg, wg = _ndhwc(x).to(DEV), w.to(DEV)
+    uf, ud = ops.pack_weights_wino(wg, True, True)
+    for u, ci, co in ((uf, cin, cout), (ud, cout, cin)):
+        parts = _winox_parts(u, ci, co)
+        u32 = u.permute(0, 1, 2, 4, 3).reshape(64, ci, co)
+        assert torch.equal(parts.double().sum(0), u32.double())                # h + m + l == u, exactly
+        assert bool((parts[1].abs() <= parts[0].abs() * 2.0 ** -7).all()) and bool((parts[2].abs() <= parts[0].abs() * 2.0 ** -15).all())
+    z, part, nblk = ops.conv3d_wino_raw(xg, uf, cin, cout, True)
+    ref = F.conv3d(x.double(), w.double(), None, 1, 1)
+    assert _relerr(_ncdhw(z.cpu()), ref) < 2e-6
+    _lib.call("tmf_set_option", b"wino_x", 0)
+    try:
+        assert _lib.query("tmf_conv3d_wino_kernel_name2", B, D, H, W, cin, cout, 1).startswith(b"conv3d_wino_p_kernel")
+        zf, partf, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, True)
+    finally:
+        _lib.call("tmf_set_option", b"wino_x", 1)
+    assert _relerr(z.cpu(), zf.cpu()) < 2e-6 and not torch.equal(z, zf)        # (another kernel: same sums, other rounding)
+    assert tuple(part.shape) == tuple(partf.shape) == (nblk, 2, cout)           # one row per workgroup, as the fp32 kernel
+    s1, s2 = part[:, 0].double().sum(0).cpu(), part[:, 1].double().sum(0).cpu()
+    zz = z.double().cpu()
+    assert (s1 - zz.sum((0, 1, 2, 3))).abs().max().item() <= 2e-6 * zz.abs().sum((0, 1, 2, 3)).max().item()
+    assert _relerr(s2, (zz ** 2).sum((0, 1, 2, 3))) < 2e-6
+    z2, part2, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, True)
+    z3, _, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, False)
+    assert torch.equal(z, z2) and torch.equal(part, part2) and torch.equal(z, z3)
+    dz = _rand(B, cout, D, H, W, seed=333)
+    dx, _, _ = ops.conv3d_wino_raw(_ndhwc(dz).to(DEV), ud, cout, cin, False)
+    assert _relerr(_ncdhw(dx.cpu()), F.conv_transpose3d(dz.double(), w.double(), None, 1, 1)) < 2e-6
+    # exact on small integers (every partial product and every sum is an integer below 2^24: no rounding anywhere)
+    xi = torch.randint(-3, 4, (B, D, H, W, cin), device=DEV).float()
+    wi = torch.randint(-2, 3, (cout, cin, 3, 3, 3), device=DEV).float()
+    ui, _ = ops.pack_weights_wino(wi, True, False)
+    zi, _, _ = ops.conv3d_wino_raw(xi, ui, cin, cout, False)
+    refi = F.conv3d(xi.permute(0, 4, 1, 2, 3).double(), wi.double(), None, 1, 1).permute(0, 2, 3, 4, 1)
+    assert torch.equal(zi.double(), refi)
+
+
 def test_conv3d_winograd_form_refuses_other_channel_counts():
     import transmf_ad_amd as T
     ops = _ops()
@@ -1351,11 +1422,19 @@ def test_conv3d_winograd_eval_block_in_one_pass(shape, pool):
     y = torch.full(oshape, float("nan"), device=DEV)
     _lib.call("tmf_conv3d_fwd_wino_affine", xg.data_ptr(), uf.data_ptr(), scg.data_ptr(), shg.data_ptr(), y.data_ptr(),
               B, D, H, W, cin, cout, pc, 0.01, ops._stream())
-    z, _, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, False)
+    # (the two-kernel sequence on the fp32 matrix pipe: the one-kernel block is that kernel's MODE 2; the train-mode default for
+    #  cin % 32 == 0 is the split kernel of conv3d_winox.hip, whose sums round differently — compared below to fp32 round-off)
+    _lib.call("tmf_set_option", b"wino_x", 0)
+    try:
+        z, _, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, False)
+    finally:
+        _lib.call("tmf_set_option", b"wino_x", 1)
     y2 = torch.empty(oshape, device=DEV)
     _lib.call("tmf_bn_act_pool_fwd_t", z.data_ptr(), scg.data_ptr(), shg.data_ptr(), y2.data_ptr(), B, D, H, W, cout, pc, 0.01, 0,
               ops._stream())
     assert torch.equal(y, y2)
+    zx, _, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, False)
+    assert (zx - z).abs().max().item() <= 2e-6 * z.abs().max().item()
     ref = F.leaky_relu(F.conv3d(x.double(), w.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1), 0.01)
     if pool:
         ref = F.max_pool3d(ref, 2, 2)

@@ -111,7 +111,20 @@ CASES = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid", 
 # models are quoted on; model_single's encoder asks for the register-tiled conv kernel per call (TMF_SNET_ALONE), so
 # `single_full_b16` is also that kernel's full-size golden.
 LOGIT_TOL = {"ad_full_b2_blobs": 2e-4, "cnn_full_b2": 2e-4, "single_full_b2": 2e-4, "cnn_full_b16": 2e-4,
-             "single_full_b16": 2e-4}
+             "single_full_b16": 2e-4,
+             # `ad_full_b2` is the deliberately ILL-CONDITIONED fixture: two uniform-noise samples whose pooled features differ by
+             # ~1e-6, a train-mode BatchNorm1d over that batch of two.  Its head turns a difference of 3e-7 in the 512-d `cls`
+             # vector into 1e-3 on the logits (x 3 500, measured: profiles/r06_parity_report.txt), so the logit error of ANY fp32
+             # implementation is a draw that re-rolls with every change of summation order — 8.4e-6, 3.2e-4, 8.9e-4, 1.0e-3 over
+             # rounds 1-5, 7.6e-4 with the fp32 Winograd kernels and 1.2e-3 with the split kernel of round 6, whose
+             # `cls` is CLOSER to the fp64 reference (3.2e-7 against 5.1e-7).  What is held tight for this fixture is what is
+             # well-posed: `cls` and the encoder outputs (CLS_TOL below, 17 x tighter than for the others) and the head evaluated
+             # by the fp64 oracle on OUR cls (the north-star 1e-3).  The benchmark configuration itself (`ad_full_b8`) and every
+             # other fixture keep the 1e-3 / 2e-4 gates (measured 2.6e-5 / <= 2.5e-4).
+             "ad_full_b2": 3e-3}
+# bound on the sampled `cls` / encoder-output probes against the reference's fp64 run, relative to the tensor's scale (5e-5 where a
+# fixture states nothing; measured on ad_full_b2: 0.3-1.0e-6 with the Winograd kernels, 0.6-1.7e-6 with the direct ones)
+CLS_TOL = {"ad_full_b2": 3e-6}
 # gradient-probe tolerance (16 sampled elements, relative to the reference tensor's max-abs) of the golden train step
 GRAD_PROBE_TOL = {"ad_full_b2_blobs": 2e-2}
 
@@ -185,7 +198,7 @@ def _golden_train_step(name):
         h.remove()
     for k, t in seen.items():          # well-conditioned intermediate results vs the reference's fp64 probes
         ref = g[f"f64/probe/{k}"]
-        assert np.abs(probe(t) - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max()), (k, probe(t) - ref)
+        assert np.abs(probe(t) - ref).max() <= CLS_TOL.get(name, 5e-5) * max(1.0, np.abs(ref).max()), (k, probe(t) - ref)
     if "cls" in seen:                  # the head on OUR cls vector, evaluated by the oracle in fp64
         from oracle import tmf_oracle as O
         S = O.to_state(g.arrays(), g.spec, dtype=torch.float64, requires_grad=False)
@@ -219,7 +232,7 @@ def _golden_train_step(name):
         ref = g[f"f32/buf/{k}"]
         # fc_cls.5 sits BEHIND the first train-mode BatchNorm1d of the head (batch of 2 in most fixtures: that layer
         # amplifies fp32 noise, see GATE) — its statistics get the gate, everything else 1e-4
-        btol = GATE if k.startswith("fc_cls.5.") else 1e-4
+        btol = max(GATE, LOGIT_TOL.get(name, GATE)) if k.startswith("fc_cls.5.") else 1e-4
         assert np.abs(b.detach().double().cpu().numpy() - ref).max() <= btol * max(1.0, np.abs(ref).max()), k
 
 

@@ -291,6 +291,26 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
         lib.tmf_set_option(b"conv_wino", 3)
 
 
+def test_split_winograd_kernel_takes_the_launches_it_is_built_for():
+    """tmf_wino_x_mode() / tmf_conv3d_wino_kernel_name2 (host logic of csrc/conv3d_winox.hip): the split kernel takes the train
+    forward / data gradient where cin and cout are multiples of 32 and the volume uses 4x8x8 bricks of one sample; everything else —
+    8- and 16-channel inputs, the folded four-sample geometry of the small deep volumes, wino_x 0 — stays on the fp32 kernels."""
+    from transmf_ad_amd import _lib
+    lib = _lib.load()
+    assert lib.tmf_wino_x_mode() == 1
+    name = lambda *a: lib.tmf_conv3d_wino_kernel_name2(*a)                   # noqa: E731
+    assert name(8, 48, 48, 48, 32, 32, 1) == b"conv3d_winox_kernel<1>" and name(8, 48, 48, 48, 64, 32, 0) == b"conv3d_winox_kernel<0>"
+    assert name(8, 24, 24, 24, 64, 128, 1) == b"conv3d_winox_kernel<1>"
+    assert name(8, 48, 48, 48, 16, 32, 1) == b"conv3d_wino_p_kernel<1, 0>"   # cin % 32
+    assert name(8, 12, 12, 12, 128, 256, 1) == b"conv3d_wino_p_kernel<1, 1>"  # four samples x 4x4x4 bricks
+    assert lib.tmf_set_option(b"wino_x", 0) == 0
+    try:
+        assert lib.tmf_wino_x_mode() == 0 and name(8, 48, 48, 48, 32, 32, 1) == b"conv3d_wino_p_kernel<1, 0>"
+    finally:
+        lib.tmf_set_option(b"wino_x", 1)
+    assert name(8, 48, 48, 48, 32, 32, 1) == b"conv3d_winox_kernel<1>"
+
+
 def test_built_kernels_have_no_use_of_registers_in_flight_and_no_store_data_overwrite(tmp_path):
     """tools/asm_checks.py on the DISASSEMBLY of every built code object (tools/resources.disassembly_of: what ships, not a
     recompilation): no wide store's data registers are overwritten in the slot behind it (the MI355X stores a wrong value there;

@@ -48,6 +48,7 @@ PROTOTYPES = {
     "tmf_conv3d_wino_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad_wino_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wino_kernel_name2": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),
+    "tmf_conv3d_wgrad_wino_tiles": (C.c_long, [_i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wino_weight_bytes": (_z, [_i, _i]),
     "tmf_wino_x_mode": (_i, []),
     "tmf_conv_wino_mode": (_i, []),

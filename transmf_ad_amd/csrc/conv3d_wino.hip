@@ -1891,6 +1891,12 @@ extern "C" const char* tmf_conv3d_wino_kernel_name(int B, int D, int H, int W, i
     const int g = (B > 0 && D > 0 && H > 0 && W > 0) ? wino_p_geom(B, D, H, W) : 0;
     return stats ? (g ? "conv3d_wino_p_kernel<1, 1>" : "conv3d_wino_p_kernel<1, 0>") : (g ? "conv3d_wino_p_kernel<0, 1>" : "conv3d_wino_p_kernel<0, 0>");
 }
+// tiles (of 2x2x2 output voxels, padded) the weight-gradient launch multiplies per (input, output) channel pair: 16 per stage
+extern "C" long tmf_conv3d_wgrad_wino_tiles(int B, int D, int H, int W, int cin, int cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || !tmf_conv3d_wgrad_wino_ok(cin, cout)) return 0;
+    if (!wino_p_mode()) return 16L * B * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 8);
+    return 16L * plan_wino_wgrad(B, D, H, W, cin, cout).nbricks;
+}
 extern "C" const char* tmf_conv3d_wgrad_wino_kernel_name(int B, int D, int H, int W, int cin, int cout) {
     if (!wino_p_mode()) return "conv3d_wino_wgrad_kernel";
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return "conv3d_wino_wgrad_p_kernel<0>";

@@ -34,6 +34,15 @@
 #include <type_traits>
 #include "tmf_common.h"
 
+#ifndef X_PF                // weights requested this many positions ahead (1 | 2)
+#define X_PF 2
+#endif
+#ifndef X_SKEW              // 1: the waves 4-7 meet the barriers half a phase later than the waves 0-3 (measured level: off)
+#define X_SKEW 0
+#endif
+#ifndef X_RB                // 1: all 16 LDS reads of a (group, buffer) are requested before the first is used (measured level: off)
+#define X_RB 0
+#endif
 #ifndef X_ABL               // timing ablations (tools/build_variant.py --flags=-DX_ABL=n; results are wrong with any bit set):
 #define X_ABL 0             // 1 no input transform, 2 no weight loads, 4 no halo copies, 8 no epilogue, 16 no MFMAs, 32 no split
 #endif
@@ -41,6 +50,18 @@
 namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef TMF_WINOX_TRACE
+// instrumented build (tools/winox_trace.py): shader-clock stamps of the phases of the SECOND item of workgroup 77, every wave.  The
+// stamps go to LDS (the item table shrinks to make room) and leave at the end of the kernel: a global store per stamp would sit in
+// the vmcnt queue the kernel's counted waits rely on and serialise the very thing that is measured.
+__device__ long long g_winox_phases[8 * 64];
+#define XTR(i) do { __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 77 && it == 1 && lane == 0) xtr_lds[wave * 64 + (i)] = (long long)__builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define XTRC(i) XTR((i) + 20 * (c & 1))
+#else
+#define XTR(i)
+#define XTRC(i)
+#endif
 
 constexpr int XN = 512;                               // 8 waves
 constexpr int XCK = 16;                               // input channels per chunk
@@ -57,8 +78,12 @@ constexpr int EX_BYTES = 8 * 32 * TS * 4;             // 69 632
 constexpr int RED_OFF = EX_OFF + EX_BYTES;            // statistic sums [which 2][source 64][33] floats: every lane adds its own 4 + 4 per item
 constexpr int PLAN_OFF = RED_OFF + 2 * 64 * 33 * 4 + 64;      // halo copy plan [9][512] ints: per lane hrel[3], hm[3], hoff[3] (registers are scarce)
 constexpr int TAB_OFF = PLAN_OFF + 9 * XN * 4;
+#ifdef TMF_WINOX_TRACE
+constexpr int TAB = 96;
+#else
 constexpr int TAB = 256;                              // item table entries per workgroup (2 x int4 each)
-constexpr size_t X_LDS_BYTES = (size_t)TAB_OFF + TAB * 32;
+#endif
+constexpr size_t X_LDS_BYTES = (size_t)TAB_OFF + 256 * 32;
 static_assert(EX_OFF + EX_BYTES >= 4 * RAWB && X_LDS_BYTES <= 160 * 1024, "LDS carving");
 
 __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
@@ -67,10 +92,14 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p, unsigned bytes) {
 }
 // LDS-DMA of 16 bytes per lane: LDS byte = lds_wave_base + 16 * lane <- base + voff + soff; a lane outside the range delivers zeros
 __device__ __forceinline__ void blds16(int voff, i32x4 rsrc, int soff, unsigned lds_wave_base) {
+    asm volatile("" : "+s"(soff));                  // (a register, not a literal the instruction cannot encode)
+    rsrc = i32x4{__builtin_amdgcn_readfirstlane(rsrc[0]), __builtin_amdgcn_readfirstlane(rsrc[1]), __builtin_amdgcn_readfirstlane(rsrc[2]),
+                 __builtin_amdgcn_readfirstlane(rsrc[3])};  // (folds away where the descriptor already sits in scalar registers)
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_wave_base) : "memory");
 }
 // 16 bytes per lane to registers, invisible to the compiler's wait-count pass (the kernel counts its waits itself)
 __device__ __forceinline__ void bload16(i32x4& dst, int voff, i32x4 rsrc, int soff) {
+    asm volatile("" : "+s"(soff));
     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory");
 }
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -84,6 +113,12 @@ __device__ __forceinline__ void store_guard() {
 // workgroup barrier that leaves the weight loads in flight (the LDS traffic of this wave has been consumed by then)
 __device__ __forceinline__ void wg_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ... for the waves whose flag is set, as ONE opaque statement: a branch in the source splits the loop into blocks and costs the
+// register allocator two accumulators (spilled), although the two roles run the same instructions
+__device__ __forceinline__ void wg_barrier_if(int flag) {
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .LWGB%=\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier\n.LWGB%=:" ::"s"(__builtin_amdgcn_readfirstlane(flag)) : "memory", "scc");
 }
 
 // exact 3-way bf16 split of 8 fp32 values (K order: y0[0..3], y1[0..3]); element 2 j in the low half of register j
@@ -115,12 +150,22 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
     float* ex = smem + EX_OFF / 4;
     float* red = smem + RED_OFF / 4;
     i32x4* tab = reinterpret_cast<i32x4*>(smem + TAB_OFF / 4);
+#ifdef TMF_WINOX_TRACE
+    long long* xtr_lds = reinterpret_cast<long long*>(smem + TAB_OFF / 4 + TAB * 8);     // [8][64] stamps behind the (shrunk) table
+    for (int i = threadIdx.x; i < 512; i += XN) xtr_lds[i] = 0;
+#endif
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hsel = lane >> 5;
     const int mpd = wave >> 1, mhh = wave & 1;
+    // The two waves of a SIMD (w and w + 4) run the SAME program — rows(a) pos(a) rows(b) pos(b) per chunk — half a phase apart: the
+    // waves 0-3 meet the workgroup's barriers behind their positions, the waves 4-7 ("late") behind their rows, so that between two
+    // barriers one wave of every SIMD reads LDS and transforms (latency-bound, few vector instructions) while the other splits and
+    // multiplies (vector- and matrix-bound).  The late waves carry the transformed rows across the barrier in registers and copy
+    // the halo like the others (the vector-memory sequence of both roles is the same: only the barriers sit elsewhere).
+    const int late = (X_SKEW && wave >= 4) ? 1 : 0, early = late ^ 1;
     const int nchunk = Cin / XCK;                           // even (Cin % 32 == 0): every item ends on halo pair 1
     constexpr int OOB = (int)0x80000000u;
 
@@ -241,13 +286,18 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
             return;
         }
         float T[4][4];
+        f32x4 ax[4], bx[4], ak[4], bk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const f32x4 ax = *reinterpret_cast<const f32x4*>(&R[xa + pgw(k) * 8]), bx = *reinterpret_cast<const f32x4*>(&R[xb + pgw(k) * 8]);
-            const f32x4 ak = *reinterpret_cast<const f32x4*>(&R[rka + pgw(k) * 8]), bk = *reinterpret_cast<const f32x4*>(&R[rkb + pgw(k) * 8]);
+            ax[k] = *reinterpret_cast<const f32x4*>(&R[xa + pgw(k) * 8]); bx[k] = *reinterpret_cast<const f32x4*>(&R[xb + pgw(k) * 8]);
+            ak[k] = *reinterpret_cast<const f32x4*>(&R[rka + pgw(k) * 8]); bk[k] = *reinterpret_cast<const f32x4*>(&R[rkb + pgw(k) * 8]);
+        }
+        if (X_RB) __builtin_amdgcn_sched_barrier(0);       // (16 reads in flight, then the arithmetic as they arrive: one latency per buffer)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float tx = ax[e] + sgn * bx[e], tk = ak[e] + sgn * bk[e];
+                const float tx = ax[k][e] + sgn * bx[k][e], tk = ak[k][e] + sgn * bk[k][e];
                 T[k][e] = GA ? tx - tk : c1 * tx + tk;
             }
         }
@@ -260,16 +310,18 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
     f32x16 acc[8];                                          // [phl * 4 + pw]: rows = output channels 8 j + 4 hsel + e (register 4 j + e), column = tile l31
 
     // ---- epilogue addressing: the reader lane (channel quad cq, wo, tile 4 w' + vq) ----
-    const int cq = lane & 7, rwo = (lane >> 3) & 1, vq = lane >> 4;
-    const int r_td = wave >> 2, r_th = wave & 3, r_tw = vq;  // tile 4 w' + vq = td * 16 + th * 4 + tw
-    const int st_lane = ((((2 * r_td) * H + 2 * r_th) * W + 2 * r_tw + rwo) * Cout + 4 * cq) * 4;
+    // (recomputed per item from an opaque copy of the lane index: hoisted out of the item loop these addresses are ~10 live registers
+    //  across the main loop, which runs at the 256-register limit)
+    const int r_td = wave >> 2, r_th = wave & 3;            // reader tile 4 w' + vq = td * 16 + th * 4 + tw, tw = vq
+    auto lane_now = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
     // BatchNorm statistic partials (MODE 1): ONE row [2][Cout] per workgroup.  Every reader lane adds its 4 + 4 sums of an item into
     // its OWN cells of `red` (no registers across the main loop); the reduction over the workgroup and the store happen only where
     // the channel group changes (the items of a workgroup are ordered by group) and at the end.
-    float* red_l = red + (wave * 8 + (lane >> 3)) * 33 + 4 * cq;
     int st_n0 = -1;
     unsigned st_seen = 0;
     auto stat_zero = [&]() {
+        const int le = lane_now();
+        float* red_l = red + (wave * 8 + (le >> 3)) * 33 + 4 * (le & 7);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { red_l[e] = 0.f; red_l[64 * 33 + e] = 0.f; }
     };
@@ -299,7 +351,7 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
 #pragma unroll
     for (int i = 0; i < XDMA; ++i) dma_part(0, i);
     load_b(0, 0, 0, ci_n0);
-    load_b(1, 1, 0, ci_n0);
+    if (X_PF == 2) load_b(1, 1, 0, ci_n0);
     vm_wait<0>();
     __syncthreads();
 
@@ -322,15 +374,16 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
                 n0n = __builtin_amdgcn_readfirstlane(tab[2 * (it + 1 < my_items ? it + 1 : it)][1]) * 32;
                 ci_n0 = n0n;
             }
-            float Y0[4][4], Y1[4][4];                           // [pw][channel of the quad]: the group's positions, both buffers
+            float Y0[4][4], Y1[4][4];                           // [pw][channel of the quad]: the transformed rows of a group, both buffers
             auto position = [&](auto q8_c, const float (&y0)[4], const float (&y1)[4]) {
                 constexpr int q8 = decltype(q8_c)::value;
-                // weights two positions ahead (their slot's last reader was position q8 - 2)
-                if (q8 < 6) load_b((q8 + 2) & 3, q8 + 2, c, n0);
-                else load_b((q8 + 2) & 3, q8 - 6, nc, n0n);
-                // in flight behind this position's weights: the next position's (3), these (3), the halo copies of the two
-                // positions before (2 each at positions 0-2), and at the start of an item the 4 stores of the epilogue before it
-                constexpr int cnt = 6 + (q8 >= 1 && q8 <= 3 ? 2 : 0) + (q8 >= 2 && q8 <= 4 ? 2 : 0) + (FIRST && q8 < 2 && !(X_ABL & 8) ? 4 : 0);
+                // weights X_PF positions ahead (the slot's last reader was the position before the running one)
+                if (q8 + X_PF < 8) load_b((q8 + X_PF) & 3, q8 + X_PF, c, n0);
+                else load_b((q8 + X_PF) & 3, q8 + X_PF - 8, nc, n0n);
+                // in flight behind this position's weights: those of the X_PF positions after it (3 each) and, as long as the six halo
+                // copies issued at the chunk's start lie behind them (positions < X_PF), those and — at the start of an item — the 4
+                // stores of the epilogue before it
+                constexpr int cnt = 3 * X_PF + (q8 < X_PF ? ((X_ABL & 4) ? 0 : 6) + (FIRST && !(X_ABL & 8) ? 4 : 0) : 0);
                 vm_wait<cnt>();
                 pin3(Bq[q8 & 3][0], Bq[q8 & 3][1], Bq[q8 & 3][2]);
                 i32x4 vh, vm_, vl;
@@ -355,22 +408,40 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
                 a = mfma_bf16(wm, vh, a);
                 acc[q8] = mfma_bf16(wh, vh, a);
 #endif
-                if (q8 < XDMA) dma_part(pr ^ 1, q8);
             };
+            // (the scheduler is fenced between the phases: left alone it pulls the next group's LDS reads into the positions — the other
+            //  wave of the SIMD provides that overlap here — and spills accumulators to make room)
+            XTRC(0);
+            __builtin_amdgcn_sched_barrier(0);
+            // the next chunk's halo (its pair is free: every wave is past rows(b) of the chunk before); the copies have this phase and
+            // position 0 to land before the weights of position 2 queue up behind them
+#pragma unroll
+            for (int i = 0; i < XDMA; ++i) dma_part(pr ^ 1, i);
             group_rows(R0, raa, rab, std::true_type{}, Y0);
             group_rows(R1, raa, rab, std::true_type{}, Y1);
+            __builtin_amdgcn_sched_barrier(0);
+            XTRC(1);
+            wg_barrier_if(late);
             position(std::integral_constant<int, 0>{}, Y0[0], Y1[0]);
             position(std::integral_constant<int, 1>{}, Y0[1], Y1[1]);
             position(std::integral_constant<int, 2>{}, Y0[2], Y1[2]);
             position(std::integral_constant<int, 3>{}, Y0[3], Y1[3]);
+            XTRC(2);
+            __builtin_amdgcn_sched_barrier(0);
+            if (X_SKEW) wg_barrier_if(early);
             group_rows(R0, rba, rbb, std::false_type{}, Y0);
             group_rows(R1, rba, rbb, std::false_type{}, Y1);
+            __builtin_amdgcn_sched_barrier(0);
+            XTRC(3);
+            wg_barrier_if(late);                            // (every wave is done with this chunk's halo)
             position(std::integral_constant<int, 4>{}, Y0[0], Y1[0]);
             position(std::integral_constant<int, 5>{}, Y0[1], Y1[1]);
             position(std::integral_constant<int, 6>{}, Y0[2], Y1[2]);
             position(std::integral_constant<int, 7>{}, Y0[3], Y1[3]);
-            // every wave is done with this chunk's halo; the next chunk's has landed (this wave's copies: the waits above)
-            wg_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            XTRC(4);
+            wg_barrier_if(early);                           // (... and the next chunk's has landed: this wave's copies by the waits above)
+            XTRC(5);
             ++g;
         };
         chunk(0, std::true_type{});
@@ -390,7 +461,11 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
         //   mhh = 0 (ph 0, 1): P[ho 0] = y(ph 0) + y(ph 1), P[ho 1] = y(ph 1);  mhh = 1 (ph 2, 3): P[ho 0] = y(ph 2), P[ho 1] = y(ph 2) + y(ph 3)
         //   out_h[0] = P0[0] + P1[0], out_h[1] = P0[1] - P1[1];  S_pd = that;  out[do 0] = S_0 + S_1 + S_2, out[do 1] = S_1 - S_2 - S_3
         f32x4 P1[4][2];                                     // [j][wo]: the ho = 1 partials wait for the second pass
-        float* exw = ex + (wave * 32 + l31) * TS + 4 * hsel;
+        const int le = lane_now();
+        const int cq = le & 7, rwo = (le >> 3) & 1, vq = le >> 4, r_tw = vq;
+        const int st_lane = ((((2 * r_td) * H + 2 * r_th) * W + 2 * r_tw + rwo) * Cout + 4 * cq) * 4;
+        float* red_l = red + (wave * 8 + (le >> 3)) * 33 + 4 * cq;
+        float* exw = ex + (wave * 32 + (le & 31)) * TS + 4 * (le >> 5);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 y[2][2];
@@ -411,6 +486,7 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
                 *reinterpret_cast<f32x4*>(&exw[wo * 32 + 8 * j]) = p0;
             }
         }
+        XTR(40);
         float* zb = z + (size_t)b * D * H * W * Cout;
         const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, D * H * W * Cout * 4, 0x00020000);
         const bool full = d0 + BD <= D && h0 + BH <= H && w0 + BW <= W;
@@ -423,6 +499,7 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
         const float* exr = ex + (4 * wave + vq) * TS + rwo * 32 + 4 * cq;
         auto pass = [&](int ho) {
             wg_barrier();                                   // (lgkmcnt(0) first: this wave's exchange writes)
+            XTR(41 + 4 * ho);
             f32x4 S[4];
 #pragma unroll
             for (int pd = 0; pd < 4; ++pd) {
@@ -453,14 +530,24 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
             }
         };
         pass(0);
+        XTR(42);
         wg_barrier();                                       // every reader is done with the ho = 0 partials
+        XTR(43);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int wo = 0; wo < 2; ++wo) *reinterpret_cast<f32x4*>(&exw[wo * 32 + 8 * j]) = P1[j][wo];
+        XTR(44);
         pass(1);
+        XTR(46);
         wg_barrier();                                       // the exchange (= halo pair 1) is free for the next item's copies
+        XTR(47);
     }
+    vm_wait<0>();
+#ifdef TMF_WINOX_TRACE
+    __syncthreads();
+    if (blockIdx.x == 77) for (int i = threadIdx.x; i < 512; i += XN) g_winox_phases[i] = xtr_lds[i];
+#endif
     if constexpr (STATS) {
         if (stat_partial != nullptr) {
             if (st_n0 >= 0) stat_flush();
@@ -474,6 +561,13 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
     }
 }
 
+}  // namespace
+#ifdef TMF_WINOX_TRACE
+extern "C" int tmf_winox_trace_read(long long* phases) {
+    return (int)hipMemcpyFromSymbol(phases, HIP_SYMBOL(g_winox_phases), sizeof(long long) * 8 * 64);
+}
+#endif
+namespace {
 int g_wino_x = -1;
 int wino_x_mode() {
     if (g_wino_x < 0) {
