@@ -446,6 +446,17 @@ int    tmf_scale_flip(const float* src, float* dst, const float* minmax, const u
  * of those layers take the register-tiled kernel (as tmf_set_option("conv_rt", 1) would, for this call only; same results
  * up to fp32 summation order).  model_single at B = 16: 13.72 -> 13.51 ms per step. */
 #define TMF_SNET_ALONE 1
+/* The ALGORITHM of a call travels in its descriptor (round 6): with TMF_SNET_ALGO set, the fields below decide which kernels the
+ * call's fp32 convolutions take — for this call only, whatever tmf_set_option says, so that two models with different settings
+ * live in one process and a forward / backward pair cannot disagree about the plan of the `saved` workspace (the backward gets
+ * the descriptor of its forward).  Without the bit the process options (tmf_set_option / TMF_* environment) are the default.
+ * tmf_snet_algo_flags() encodes the process options of the moment into such a word (the Python binding pins them at forward). */
+#define TMF_SNET_ALGO          0x100
+#define TMF_SNET_ALGO_WINO(m)  (((m) & 3) << 9)   /* conv_wino: 0 direct kernels .. 3 forward, data and weight gradients in the Winograd form */
+#define TMF_SNET_ALGO_WINO_P   0x800              /* wino_p: the persistent one-wave-per-SIMD Winograd kernels */
+#define TMF_SNET_ALGO_WINO_X   0x1000             /* wino_x: forward / data gradient as exact 3-way bf16 splits (conv3d_winox.hip) */
+#define TMF_SNET_ALGO_C1_GRAM  0x2000             /* c1_gram: the first block through the tap Gram matrix of its input */
+int  tmf_snet_algo_flags(void);
 typedef struct tmf_snet_desc {
     int   B, D, H, W;                /* input volumes (B, 1, D, H, W) */
     int   dim;                       /* sNet(dim) */
@@ -454,7 +465,8 @@ typedef struct tmf_snet_desc {
     float momentum[TMF_SNET_BLOCKS]; /* BatchNorm3d.momentum, .eps and LeakyReLU.negative_slope per block */
     float eps[TMF_SNET_BLOCKS];
     float slope[TMF_SNET_BLOCKS];
-    int   flags;                     /* TMF_SNET_ALONE: no other encoder runs beside this one (model_single, TMF_STREAMS=1) */
+    int   flags;                     /* TMF_SNET_ALONE: no other encoder runs beside this one (model_single, TMF_STREAMS=1);
+                                      * TMF_SNET_ALGO | ...: this call's algorithm choice (above) */
 } tmf_snet_desc;
 typedef struct tmf_snet_params {
     const float* weight[TMF_SNET_BLOCKS];

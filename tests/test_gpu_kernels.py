@@ -1441,6 +1441,52 @@ def test_conv3d_winograd_eval_block_in_one_pass(shape, pool):
     assert _relerr(_ncdhw(y.cpu()), ref) < 3e-6
 
 
+@pytest.mark.parametrize("scale", [1.0, 1000.0])
+def test_first_block_one_pass_backward_on_uncentred_input(scale):
+    """tmf_c1_bwd_fused on a volume that is NOT centred (a smooth field around 3, and the same at raw-intensity scale): in
+    dw = s [D - c0 S_t - c1 / sigma ((G w)_t - mu S_t)] the fp32 sum D and c0 S_t nearly cancel there, a step the two-pass form avoids
+    by forming the mean-free dz per voxel first (the advisor's finding, round 5).  dw / dgamma / dbeta of the whole block against fp64
+    torch and against the two-pass backward (c1_gram 0): the one-pass form is no further from fp64 than 3 x the two-pass one."""
+    from transmf_ad_amd import _lib
+    ops = _ops()
+    B, D, H, W, C = 2, 16, 24, 40, 32
+    g = torch.Generator().manual_seed(23)
+    zz_, yy_, xx_ = torch.meshgrid(torch.arange(D), torch.arange(H), torch.arange(W), indexing="ij")
+    x = ((3.0 + torch.sin(0.21 * zz_ + 0.13 * yy_) * torch.cos(0.17 * xx_)).float().expand(B, D, H, W)
+         + 0.05 * torch.rand((B, D, H, W), generator=g)).contiguous() * scale
+    w = torch.randn((C, 1, 3, 3, 3), generator=g) * 0.3 / scale
+    conv = torch.nn.Conv3d(1, C, 3, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm3d(C).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w.to(DEV))
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.2, 0.2)
+    go = torch.randn((B, D // 2, H // 2, W // 2, C), generator=g).to(DEV)
+    xg = x.to(DEV)
+    res = {}
+    for gram_opt in (1, 0):
+        _lib.call("tmf_set_option", b"c1_gram", gram_opt)
+        try:
+            for p_ in (conv.weight, bn.weight, bn.bias):
+                p_.grad = None
+            y = ops.conv_bn_act_pool(xg.unsqueeze(-1), conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean.clone(),
+                                     bn.running_var.clone(), True, pool="max")
+            y.backward(go)
+            torch.cuda.synchronize()
+        finally:
+            _lib.call("tmf_set_option", b"c1_gram", 1)
+        res[gram_opt] = (conv.weight.grad.cpu().clone(), bn.weight.grad.cpu().clone(), bn.bias.grad.cpu().clone())
+    w64 = w.double().requires_grad_(True)
+    g64, b64 = bn.weight.detach().double().cpu().requires_grad_(True), bn.bias.detach().double().cpu().requires_grad_(True)
+    zz = F.conv3d(x.double().unsqueeze(1), w64, conv.bias.detach().double().cpu(), padding=1)
+    yy = F.max_pool3d(F.leaky_relu(F.batch_norm(zz, None, None, g64, b64, True, 0.1, 1e-5), 0.01), 2)
+    yy.backward(go.double().permute(0, 4, 1, 2, 3).cpu())
+    for i, ref in enumerate((w64.grad, g64.grad, b64.grad)):
+        e1 = (res[1][i].double() - ref).abs().max().item() / ref.abs().max().item()
+        e0 = (res[0][i].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert e1 <= max(3.0 * e0, 2e-5), (i, e1, e0)
+
+
 C1_FUSED_SHAPES = [(2, 16, 24, 40, 32), (1, 9, 13, 35, 32), (3, 8, 10, 33, 16), (5, 17, 16, 19, 8), (8, 48, 48, 48, 32)]
 
 

@@ -398,8 +398,10 @@ def test_full_size_properties_b8_96():
             if not g.has(f"{prec}/train/logits"):
                 continue
             for k, v in outs.items():
-                assert np.abs(v.detach().double().cpu().numpy() - g[f"{prec}/train/{k}"]).max() <= (GATE if k == "logits" else TOL), (k, prec)
-            assert abs(loss.item() - float(g[f"{prec}/train/loss"])) <= GATE
+                # (the benchmark configuration: logits 2.1-2.6e-5 and loss <= 9e-6 measured over rounds 4-6, profiles/r06_parity_report.txt;
+                #  the bounds are 8 x that, a fifth of the north-star gate)
+                assert np.abs(v.detach().double().cpu().numpy() - g[f"{prec}/train/{k}"]).max() <= 2e-4, (k, prec)
+            assert abs(loss.item() - float(g[f"{prec}/train/loss"])) <= 2e-4
         prec = "f64" if g.has("f64/grad/fc_cls.8.weight") else "f32"
         for k, row in _grad_probe_errors(net, g, prec).items():
             if row[0] == "zero":
@@ -1138,6 +1140,70 @@ def test_two_precisions_live_side_by_side():
     assert not torch.equal(both[0][0][0], both[1][0][0])          # the two precisions do differ
     default = _adam_run([(None, None)], 1, g)[0]                  # no setting of its own: the process default (fp32)
     assert torch.equal(default[0][0], solo_a[0][0])
+
+
+def _algo_run(settings, steps, g, toggle=None):
+    """_adam_run with a per-encoder algorithm setting (sNet.set_algorithm) per model; toggle(): called between forward and backward."""
+    import transmf_ad_amd as T
+    mri, pet, y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
+    nets, opts, outs = [], [], []
+    for algo in settings:
+        net = build(g)
+        if algo is not None:
+            for enc in (net.mri_cnn, net.pet_cnn):
+                enc.set_algorithm(**algo)
+        nets.append(net)
+        opts.append(T.optim.Adam(net.parameters(), lr=1e-3))
+        outs.append([])
+    ce = torch.nn.CrossEntropyLoss()
+    for _ in range(steps):
+        for net, opt, out in zip(nets, opts, outs):
+            net.train()
+            opt.zero_grad()
+            lo, dm, dp = net(mri, pet)
+            loss = (ce(dm, torch.ones_like(y)) + ce(dp, torch.zeros_like(y))) / 2 + ce(lo, y)
+            if toggle is not None:
+                toggle(True)
+            try:
+                loss.backward()
+            finally:
+                if toggle is not None:
+                    toggle(False)
+            opt.step()
+            out.append(lo.detach().clone())
+    torch.cuda.synchronize()
+    return [(o, [p.detach().clone() for p in n.parameters()]) for o, n in zip(outs, nets)]
+
+
+def test_two_algorithm_settings_live_side_by_side():
+    """The ALGORITHM of an encoder call travels in its descriptor (tmf_snet_desc.flags, TMF_SNET_ALGO; sNet.set_algorithm), not in
+    process state: a model on the direct fp32 kernels without the Gram path and a model on the defaults (Winograd, split kernel),
+    stepping alternately in one process, each produce BITWISE what the same setting produces as the process option; and the
+    descriptor of a forward pins the plan of its backward — flipping the process options between the two changes nothing."""
+    from transmf_ad_amd import _lib
+    g = Golden("ad_mid")
+    direct = dict(conv_wino=0, c1_gram=0, wino_x=0)
+    both = _algo_run([direct, None], 2, g)
+    for k, v in direct.items():
+        _lib.call("tmf_set_option", k.encode(), v)
+    try:
+        solo_direct = _algo_run([None], 2, g)[0]
+    finally:
+        _lib.call("tmf_set_option", b"conv_wino", 3)
+        _lib.call("tmf_set_option", b"c1_gram", 1)
+        _lib.call("tmf_set_option", b"wino_x", 1)
+    solo_default = _algo_run([None], 2, g)[0]
+    for (lo_t, p_t), (lo_s, p_s) in zip(both, (solo_direct, solo_default)):
+        assert all(torch.equal(a, b) for a, b in zip(lo_t, lo_s)) and all(torch.equal(a, b) for a, b in zip(p_t, p_s))
+    assert not torch.equal(both[0][0][0], both[1][0][0])          # (the two settings do round differently)
+
+    def flip(on):                                                  # other options between forward and backward
+        _lib.call("tmf_set_option", b"conv_wino", 0 if on else 3)
+        _lib.call("tmf_set_option", b"c1_gram", 0 if on else 1)
+        _lib.call("tmf_set_option", b"wino_p", 0 if on else 1)
+    flipped = _algo_run([None], 2, g, toggle=flip)[0]
+    assert all(torch.equal(a, b) for a, b in zip(flipped[0], solo_default[0]))
+    assert all(torch.equal(a, b) for a, b in zip(flipped[1], solo_default[1]))
 
 
 # Measured on MI355X (round 3; 30 Adam steps at the reference's lr 1e-4 and batch 8 from the fixture-style parameters, fixed

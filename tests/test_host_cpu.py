@@ -257,6 +257,9 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
     # conv2.0 at B = 8, 48^3: one (ci, co) block -> 256 slabs in 16 groups
     assert lib.tmf_wino_p_mode() == 1
     assert lib.tmf_conv3d_wino_bricks(8, 12, 12, 12) == 2 * 3 * 3 * 3               # four samples x 4x4x4 bricks where that is fewer tiles
+    # ... but not for a large ragged volume (four samples behind one 32-bit buffer resource): 8 x 81x85x83 would be 2 x 21 x 22 x 21
+    # folded bricks against 8 x 21 x 11 x 11 — it keeps the one-sample bricks, which the kernel can address
+    assert lib.tmf_conv3d_wino_bricks(8, 81, 85, 83) == 8 * 21 * 11 * 11 and lib.tmf_conv3d_wino_bricks(8, 33, 36, 35) == 2 * 9 * 9 * 9
     assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 48, 48, 48, 32, 32) == (256 + 16) * 27 * 1024 * 4
     # conv4.0 (12^3): 4 pairs of samples x 27 bricks = 108 stages in 8 slabs of 14 per (ci, co) block (18 half bricks per sample: 144 in 8 of 18)
     assert lib.tmf_conv3d_wgrad_wino_workspace_bytes(8, 12, 12, 12, 128, 256) == (8 + 1) * 27 * 128 * 256 * 4
@@ -289,6 +292,44 @@ def test_winograd_form_is_the_default_plan_of_the_encoder():
         assert lib.tmf_set_option(b"conv_wino", 4) != 0
     finally:
         lib.tmf_set_option(b"conv_wino", 3)
+
+
+def test_algorithm_choice_travels_in_the_descriptor():
+    """tmf_snet_desc.flags with TMF_SNET_ALGO: the plan of a call (here: the size of its `saved` workspace, host arithmetic)
+    follows the descriptor, not the process options — and without the bit it follows the options; tmf_snet_algo_flags() is the
+    options of the moment as such a word (ops.snet_algo_flags: a module's own dict on top)."""
+    from transmf_ad_amd import _lib, ops
+    lib = _lib.load()
+
+    def saved(flags):
+        desc = _lib.SnetDesc(B=8, D=96, H=96, W=96, dim=128, precision=0, storage_bf16=0, flags=flags)
+        desc.momentum[:] = [0.1] * 7
+        desc.eps[:] = [1e-5] * 7
+        desc.slope[:] = [0.01] * 7
+        return lib.tmf_snet_saved_bytes(ctypes.byref(desc))
+    ALGO, P, X, G = 0x100, 0x800, 0x1000, 0x2000
+    assert lib.tmf_snet_algo_flags() == ALGO | (3 << 9) | P | X | G
+    default = saved(0)
+    assert saved(lib.tmf_snet_algo_flags()) == default
+    by_flags = {m: saved(ALGO | (m << 9) | P | X | G) for m in (0, 1, 2, 3)}
+    no_gram = saved(ALGO | (3 << 9) | P | X)
+    assert by_flags[3] == default and len(set(by_flags.values())) >= 3 and no_gram < default
+    try:
+        for m in (0, 1, 2):
+            assert lib.tmf_set_option(b"conv_wino", m) == 0
+            assert saved(0) == by_flags[m]                                    # the process option ...
+            assert saved(ALGO | (3 << 9) | P | X | G) == default              # ... does not reach a call that carries its own
+            assert lib.tmf_snet_algo_flags() == ALGO | (m << 9) | P | X | G
+        assert lib.tmf_set_option(b"conv_wino", 3) == 0 and lib.tmf_set_option(b"c1_gram", 0) == 0
+        assert saved(0) == no_gram and saved(ALGO | (3 << 9) | P | X | G) == default
+    finally:
+        lib.tmf_set_option(b"conv_wino", 3)
+        lib.tmf_set_option(b"c1_gram", 1)
+    assert ops.snet_algo_flags() == ALGO | (3 << 9) | P | X | G
+    assert ops.snet_algo_flags(dict(conv_wino=0, wino_x=0)) == ALGO | P | G
+    with pytest.raises(ValueError):
+        ops.snet_algo_flags(dict(winograd=1))
+    assert lib.tmf_conv_wino_mode() == 3 and lib.tmf_wino_x_mode() == 1      # (no override leaks out of a call)
 
 
 def test_split_winograd_kernel_takes_the_launches_it_is_built_for():

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "tmf_conv3d_wgrad_wino_tiles": (C.c_long, [_i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wino_weight_bytes": (_z, [_i, _i]),
     "tmf_wino_x_mode": (_i, []),
+    "tmf_snet_algo_flags": (_i, []),
     "tmf_conv_wino_mode": (_i, []),
     "tmf_wino_p_mode": (_i, []),
     "tmf_conv3d_wgrad_wino_ok": (_i, [_i, _i]),

@@ -347,6 +347,7 @@ __global__ __launch_bounds__(1024) void c1_bwd_fused_finish_kernel(const float* 
 
 int g_c1_gram = -1;
 int c1_gram_mode() {
+    if (const int o = tmf_algo_override()) return (o & TMF_SNET_ALGO_C1_GRAM) ? 1 : 0;
     if (g_c1_gram < 0) {
         const char* e = getenv("TMF_C1_GRAM");
         g_c1_gram = (e && atoi(e) == 0) ? 0 : 1;
@@ -357,6 +358,7 @@ int c1_gram_mode() {
 }  // namespace
 
 int tmf_c1_gram_set(int v) { g_c1_gram = v ? 1 : 0; return TMF_OK; }
+int tmf_c1_gram_mode(void) { return c1_gram_mode(); }
 
 // ---- the statistics + Gram data of the forward, and the one-pass backward (fp32; conv1_fused.hip launches the MODE_RD kernel) ----
 extern "C" size_t tmf_c1_gram_bytes(int B, int D, int H, int W, int C) {

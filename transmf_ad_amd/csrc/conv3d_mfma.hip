@@ -1641,6 +1641,15 @@ C1Plan plan_c1(int B, int D, int H, int W, int cout) {
 // ------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------
+static thread_local int t_algo_override = 0;
+int tmf_algo_override(void) { return t_algo_override; }
+void tmf_algo_override_set(int flags) { t_algo_override = (flags & TMF_SNET_ALGO) ? flags : 0; }
+int tmf_c1_gram_mode(void);      // conv1_gram.hip
+extern "C" int tmf_snet_algo_flags(void) {
+    return TMF_SNET_ALGO | TMF_SNET_ALGO_WINO(tmf_conv_wino_mode()) | (tmf_wino_p_mode() ? TMF_SNET_ALGO_WINO_P : 0) |
+           (tmf_wino_x_mode() ? TMF_SNET_ALGO_WINO_X : 0) | (tmf_c1_gram_mode() ? TMF_SNET_ALGO_C1_GRAM : 0);
+}
+
 extern "C" int tmf_set_option(const char* name, int value) {
     TMF_REQUIRE_PTR(name);
     if (strcmp(name, "conv_waves") == 0) {

@@ -1759,6 +1759,7 @@ int g_conv_wino = -1;
 int g_wino_p = -1;          // forward / data gradient: 1 the persistent one-wave-per-SIMD kernel (default), 0 the two-waves-per-SIMD one
 
 int wino_p_mode() {
+    if (const int o = tmf_algo_override()) return (o & TMF_SNET_ALGO_WINO_P) ? 1 : 0;
     if (g_wino_p < 0) {
         const char* e = getenv("TMF_WINO_P");
         g_wino_p = (e && atoi(e) == 0) ? 0 : 1;
@@ -1782,10 +1783,14 @@ int wino_cu_count() {
 }
 
 // Brick geometry of the persistent kernel for a volume: 1 (four samples x 4x4x4) where that executes fewer tiles than 0 (4x8x8)
+// (... and only for volumes below 2^17 voxels: the four samples of such a brick sit behind ONE buffer resource with 32-bit byte
+//  offsets, 4 x D x H x W x channels x 4 B < 2^31 for up to 1 024 channels — a large ragged volume keeps the one-sample bricks, which
+//  only need one sample below 2^29 elements; the advisor's finding, round 5.  The geometry depends on the volume alone, so every
+//  query — bricks, kernel names, statistic rows — and the launch agree.)
 int wino_p_geom(int B, int D, int H, int W) {
     const long t0 = (long)B * tmf_cdiv(D, 4) * tmf_cdiv(H, 8) * tmf_cdiv(W, 8);
     const long t1 = (long)tmf_cdiv(B, 4) * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 4);
-    return t1 < t0 ? 1 : 0;
+    return (t1 < t0 && (long)D * H * W < (1L << 17)) ? 1 : 0;
 }
 long wino_p_bricks(int geom, int B, int D, int H, int W) {
     return geom ? (long)tmf_cdiv(B, 4) * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 4)
@@ -1832,7 +1837,7 @@ int launch_wino_p(const char* what, const float* x, const float* u, float* z, fl
     if (MODE != 2 && tmf_winox_takes(B, D, H, W, cin, cout, wino_p_geom(B, D, H, W)))
         return tmf_winox_launch(what, x, reinterpret_cast<const unsigned short*>(u + (size_t)64 * cin * cout), z, stat_partial, B, D, H, W,
                                 cin, cout, wino_cu_count(), stream);
-    if (wino_p_geom(B, D, H, W)) return launch_wino_p_g<MODE, 1>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
+    if (wino_p_geom(B, D, H, W) && (long)4 * D * H * W * (cin > cout ? cin : cout) < (1L << 29)) return launch_wino_p_g<MODE, 1>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
     return launch_wino_p_g<MODE, 0>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
 }
 
@@ -1853,6 +1858,7 @@ extern "C" int tmf_wino_trace_read(long long* blocks, long long* phases) {
 // data gradients / (default) for forward, data and weight gradients of the encoder's 3x3x3 blocks that qualify (tmf_conv3d_wino_ok); consulted by the whole-encoder entries
 // (snet_path.hip) and, through tmf_conv_wino_mode(), by the op-by-op path (ops.py)
 extern "C" int tmf_conv_wino_mode(void) {
+    if (const int o = tmf_algo_override()) return (o >> 9) & 3;
     if (g_conv_wino < 0) {
         const char* e = getenv("TMF_CONV_WINO");
         const int v = e ? atoi(e) : 3;

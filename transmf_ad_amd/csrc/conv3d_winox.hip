@@ -570,6 +570,7 @@ extern "C" int tmf_winox_trace_read(long long* phases) {
 namespace {
 int g_wino_x = -1;
 int wino_x_mode() {
+    if (const int o = tmf_algo_override()) return (o & TMF_SNET_ALGO_WINO_X) ? 1 : 0;
     if (g_wino_x < 0) {
         const char* e = getenv("TMF_WINO_X");
         g_wino_x = (e && atoi(e) == 0) ? 0 : 1;

@@ -155,17 +155,20 @@ inline Vecs vecs_of(char* base, const LayerPlan& L) {
 
 extern "C" size_t tmf_snet_saved_bytes(const tmf_snet_desc* d) {
     if (check_desc("tmf_snet_saved_bytes", d) != TMF_OK) return 0;
+    const TmfAlgoScope algo_scope(d->flags);
     return make_plan(*d).saved_bytes;
 }
 
 extern "C" size_t tmf_snet_bwd_scratch_bytes(const tmf_snet_desc* d) {
     if (check_desc("tmf_snet_bwd_scratch_bytes", d) != TMF_OK) return 0;
+    const TmfAlgoScope algo_scope(d->flags);
     return make_plan(*d).scratch_bytes;
 }
 
 extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, const tmf_snet_params* prm,
                                   void* saved, size_t saved_bytes, float* out, void* stream) {
     TMF_TRY(check_desc("tmf_snet_train_fwd", d));
+    const TmfAlgoScope algo_scope(d->flags);          // this call's algorithm choice, if the descriptor carries one
     TMF_REQUIRE_PTR(vol); TMF_REQUIRE_PTR(prm); TMF_REQUIRE_PTR(saved); TMF_REQUIRE_PTR(out);
     TMF_REQUIRE_ALIGNED(vol); TMF_REQUIRE_ALIGNED(saved); TMF_REQUIRE_ALIGNED(out);
     const Plan p = make_plan(*d);
@@ -259,6 +262,7 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
 // (bit-identical, tested), issued by one call as well.
 extern "C" size_t tmf_snet_eval_workspace_bytes(const tmf_snet_desc* d) {
     if (check_desc("tmf_snet_eval_workspace_bytes", d) != TMF_OK) return 0;
+    const TmfAlgoScope algo_scope(d->flags);
     tmf_snet_desc e = *d;
     if (e.precision == TMF_PREC_FP32X) { e.precision = TMF_PREC_FP32; e.storage_bf16 = 0; }
     return make_plan(e).saved_bytes;            // same carving: raw conv outputs (bf16 modes), block outputs, vectors, packed weights
@@ -267,6 +271,7 @@ extern "C" size_t tmf_snet_eval_workspace_bytes(const tmf_snet_desc* d) {
 extern "C" int tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const tmf_snet_params* prm,
                                  void* workspace, size_t workspace_bytes, float* out, void* stream) {
     TMF_TRY(check_desc("tmf_snet_eval_fwd", d));
+    const TmfAlgoScope algo_scope(d->flags);
     TMF_REQUIRE(d->precision == TMF_PREC_FP32 || d->precision == TMF_PREC_BF16, TMF_E_ARG,
                 "tmf_snet_eval_fwd: fp32 and bf16 precisions only");
     TMF_REQUIRE_PTR(vol); TMF_REQUIRE_PTR(prm); TMF_REQUIRE_PTR(workspace); TMF_REQUIRE_PTR(out);
@@ -323,6 +328,7 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
                                   const float* dout, const tmf_snet_grads* g, void* scratch, size_t scratch_bytes,
                                   void* stream) {
     TMF_TRY(check_desc("tmf_snet_train_bwd", d));
+    const TmfAlgoScope algo_scope(d->flags);          // (the forward's: the plan of `saved` is the one the forward laid out)
     TMF_REQUIRE_PTR(vol); TMF_REQUIRE_PTR(saved); TMF_REQUIRE_PTR(dout); TMF_REQUIRE_PTR(g); TMF_REQUIRE_PTR(scratch);
     TMF_REQUIRE_ALIGNED(vol); TMF_REQUIRE_ALIGNED(saved); TMF_REQUIRE_ALIGNED(dout); TMF_REQUIRE_ALIGNED(scratch);
     const Plan p = make_plan(*d);

@@ -90,6 +90,17 @@ int tmf_conv3d_fwd_mode(const float* x, const float* w, float* z, float* stat_pa
 int tmf_conv3d_stat_blocks_mode(int B, int D, int H, int W, int cin, int cout, int ksize, int rt_min);
 int tmf_c1_gram_set(int v);      // conv1_gram.hip: tmf_set_option("c1_gram", 0 | 1): the first block through the tap Gram matrix of its input
 int tmf_wino_p_set(int v);       // conv3d_wino.hip: tmf_set_option("wino_p", 0 | 1): two-waves-per-SIMD / persistent one-wave-per-SIMD forward kernel
+// per-call algorithm choice (tmf_snet_desc.flags & TMF_SNET_ALGO): the whole-encoder entries set it for the calling thread while they
+// plan and enqueue; the option getters (tmf_conv_wino_mode, wino_p_mode, wino_x_mode, c1_gram_mode) look here first
+int  tmf_algo_override(void);            // 0, or a flags word with TMF_SNET_ALGO set
+void tmf_algo_override_set(int flags);
+struct TmfAlgoScope {
+    int prev;
+    explicit TmfAlgoScope(int flags) : prev(tmf_algo_override()) { if (flags & TMF_SNET_ALGO) tmf_algo_override_set(flags); }
+    ~TmfAlgoScope() { tmf_algo_override_set(prev); }
+    TmfAlgoScope(const TmfAlgoScope&) = delete;
+    TmfAlgoScope& operator=(const TmfAlgoScope&) = delete;
+};
 int tmf_wino_x_set(int v);       // conv3d_winox.hip: tmf_set_option("wino_x", 0 | 1): Winograd forward / data gradient as exact 3-way bf16 splits on the bf16 matrix pipe
 int tmf_winox_takes(int B, int D, int H, int W, int cin, int cout, int geom);
 int tmf_winox_launch(const char* what, const float* x, const unsigned short* u3, float* z, float* stat_partial, int B, int D, int H,

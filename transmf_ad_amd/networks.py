@@ -70,12 +70,20 @@ class sNet(nn.Module):
             p.tmf_bucket_group = ("sNet deep", id(self)) if name.startswith(("conv3", "conv4")) else ("sNet shallow",)
         self.tmf_precision = None           # None: follow the process default (ops.set_conv_precision / set_activation_storage)
         self.tmf_alone = False              # True: nothing runs beside this encoder (model_single): tmf_snet_desc.flags = TMF_SNET_ALONE
+        self.tmf_algo = None                # None: the process options; a dict: this encoder's own kernels (set_algorithm)
 
     def set_precision(self, conv="fp32", storage="fp32"):
         """Precision of THIS encoder's convolution products ("fp32" | "bf16" | "fp32x") and of the activations between its
         blocks ("fp32" | "bf16", the latter with conv "bf16" only) — independent of any other module in the process;
         conv=None returns to the process default."""
         self.tmf_precision = None if conv is None else ops.make_precision(conv, storage)
+        return self
+
+    def set_algorithm(self, **algo):
+        """Kernels of THIS encoder's fp32 convolutions in its whole-pass calls (tmf_snet_desc.flags, TMF_SNET_ALGO): conv_wino 0..3,
+        wino_p, wino_x, c1_gram 0 | 1 — independent of tmf_set_option and of any other module; no arguments: the process options."""
+        ops.snet_algo_flags(algo)            # (validates)
+        self.tmf_algo = dict(algo) or None
         return self
 
     @device_guard
@@ -97,7 +105,8 @@ class sNet(nn.Module):
             return ops.snet_eval_one_call(
                 vol, blocks[-1][0].out_channels, tuple(float(bn.eps) for _c, bn, _a in blocks),
                 tuple(float(a.negative_slope) for _c, _b, a in blocks),
-                [(c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var) for c, bn, _a in blocks], prec)
+                [(c.weight, c.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var) for c, bn, _a in blocks], prec,
+                getattr(self, "tmf_algo", None))
         if self._one_call_ok(vol, blocks, prec=prec):
             params, buffers = [], []
             for conv, bn, _act in blocks:
@@ -105,7 +114,7 @@ class sNet(nn.Module):
                 buffers.append((bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None))
             cfg = (blocks[-1][0].out_channels, tuple(float(bn.momentum) for _c, bn, _a in blocks),
                    tuple(float(bn.eps) for _c, bn, _a in blocks), tuple(float(a.negative_slope) for _c, _b, a in blocks), prec,
-                   bool(getattr(self, "tmf_alone", False)))
+                   bool(getattr(self, "tmf_alone", False)), getattr(self, "tmf_algo", None))
             return ops.SNetTrain.apply(vol, cfg, buffers, *params)
         store16 = prec[1]
         for n_blk, (seq_name, i, pool) in enumerate(self._PLAN):

@@ -611,7 +611,7 @@ def snet_one_call_supported(B, D, H, W, dim, precision=None):
             and min(D, H, W) >= 16 and B > 0)
 
 
-def snet_eval_one_call(vol, dim, eps, slope, blocks, precision=None):
+def snet_eval_one_call(vol, dim, eps, slope, blocks, precision=None, algo=None):
     """Eval-mode sNet forward as ONE library call (tmf_snet_eval_fwd): no autograd graph (val_step runs under no_grad).
     blocks: 7 x (conv weight, conv bias | None, bn weight, bn bias, running_mean, running_var); precision: fp32 (a block is
     one kernel) or bf16 [+ bf16 storage] (the block-by-block launches, enqueued by one call)."""
@@ -619,7 +619,8 @@ def snet_eval_one_call(vol, dim, eps, slope, blocks, precision=None):
     vol = _chk(vol, "vol")
     B, _, D, H, W = vol.shape
     mode, act16 = resolve_precision(precision)
-    desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision={"fp32": 0, "bf16": 1}[mode], storage_bf16=int(act16))
+    desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision={"fp32": 0, "bf16": 1}[mode], storage_bf16=int(act16),
+                         flags=snet_algo_flags(algo))
     prm = _lib.SnetParams()
     for l, (w, b, g, be, rm, rv) in enumerate(blocks):
         desc.eps[l], desc.slope[l], desc.momentum[l] = eps[l], slope[l], 0.0
@@ -664,6 +665,26 @@ def _publish_flat_grads(flat, param_ptrs, views, segments) -> None:
         c.tmf_flat_grads(flat, param_ptrs, views, segments)
 
 
+def snet_algo_flags(algo=None) -> int:
+    """The algorithm word of a tmf_snet_desc (include/tmf_hip.h: TMF_SNET_ALGO | ...).  algo None: the process options of the
+    moment (tmf_set_option / TMF_* environment), pinned for the call — a backward then runs the plan its forward laid out whatever
+    happens to the options in between; a dict {conv_wino: 0..3, wino_p: 0|1, wino_x: 0|1, c1_gram: 0|1} (missing keys: the process
+    option) is ONE module's own choice (sNet.set_algorithm): two models with different settings live side by side."""
+    f = _lib.query("tmf_snet_algo_flags")
+    if algo:
+        bad = set(algo) - {"conv_wino", "wino_p", "wino_x", "c1_gram"}
+        if bad:
+            raise ValueError(f"unknown algorithm option(s) {sorted(bad)}")
+        if "conv_wino" in algo:
+            if algo["conv_wino"] not in (0, 1, 2, 3):
+                raise ValueError("conv_wino must be 0, 1, 2 or 3")
+            f = (f & ~(3 << 9)) | (int(algo["conv_wino"]) << 9)
+        for key, bit in (("wino_p", 0x800), ("wino_x", 0x1000), ("c1_gram", 0x2000)):
+            if key in algo:
+                f = (f | bit) if algo[key] else (f & ~bit)
+    return f
+
+
 class SNetTrain(torch.autograd.Function):
     """Train-mode sNet forward / backward as ONE library call each (tmf_snet_train_fwd / _bwd: csrc/snet_path.hip): the
     same kernels in the same order as the block-by-block path, every intermediate tensor inside one workspace tensor,
@@ -678,7 +699,7 @@ class SNetTrain(torch.autograd.Function):
         mode, act16 = resolve_precision(cfg[4] if len(cfg) > 4 else None)
         B, _, D, H, W = vol.shape
         desc = _lib.SnetDesc(B=B, D=D, H=H, W=W, dim=dim, precision={"fp32": 0, "bf16": 1, "fp32x": 2}[mode], storage_bf16=int(act16),
-                             flags=_lib.SNET_ALONE if (len(cfg) > 5 and cfg[5]) else 0)
+                             flags=(_lib.SNET_ALONE if (len(cfg) > 5 and cfg[5]) else 0) | snet_algo_flags(cfg[6] if len(cfg) > 6 else None))
         prm = _lib.SnetParams()
         for l in range(7):
             desc.momentum[l], desc.eps[l], desc.slope[l] = momentum[l], eps[l], slope[l]

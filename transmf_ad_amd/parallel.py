@@ -99,8 +99,14 @@ class GradAllReduce(nn.Module):
     The forward MUST go through the wrapper (``net(...)``, not ``net.module(...)``): there are no per-parameter hooks, the
     end-of-backward reduction is queued by a hook on the wrapper's outputs (or by a whole-pass node reporting its gradient
     buffer).  A backward over a graph built from the inner module leaves the gradients un-reduced; ``unreduced_gradients()``
-    tells, ``reduce_gradients()`` reduces them explicitly.  ONE forward per backward: a second forward through the wrapper before
-    the backward raises there (the reference's train_step never does it; torch's DDP supports it, this wrapper does not).
+    tells, ``reduce_gradients()`` reduces them explicitly.  ONE forward per backward (the reference's train_step never does
+    anything else; torch's DDP supports more, this wrapper does not).  What is refused and what is not: a SINGLE backward that
+    spans the graphs of two forwards (``(f(net(a)) + f(net(b))).backward()``) raises — inside that backward, when the hook of
+    the older forward's outputs fires, i.e. after the younger forward's graph has run and its ranges have been handed to the
+    reduction: the gradients left behind by that exception are PARTLY REDUCED and must be zeroed (``zero_grad()``) before the
+    next step.  Two forwards whose backwards run one after the other (f1, f2, backward(f1), backward(f2)) are not detected: each
+    backward reduces its own graph's gradients, and the second one ACCUMULATES into ``.grad`` tensors that are already
+    rank-averaged — the result is the sum of two averaged gradients (as with torch's DDP), through the bucket path.
     """
 
     def __init__(self, module: nn.Module, process_group=None, bucket_mb: float = 6.0,
