@@ -130,7 +130,7 @@ def _pmc_traffic(kernel, precision, storage, B, vol):
     """HBM bytes per launch of a kernel instance from the committed rocprofv3 --pmc passes (counters cannot be read
     live): profiles/r03_pmc_traffic.json = {"precision|storage|B|DxHxW": {kernel instance: {"hbm_bytes_per_launch": ...}}};
     None for configurations that were not profiled."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):          # newest committed pass first
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):          # newest committed pass first
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 tab = json.load(f).get(f"{precision}|{storage}|{B}|{'x'.join(map(str, vol))}", {})

@@ -1,7 +1,7 @@
 # One GPU-box pass that regenerates what profiles/ holds for the round (fp32 headline + configs[2] bf16 report).
 # Run through gpurun from the repo root:  gpurun --timeout 2400 -- 'bash tools/scripts/refresh_profiles.sh <tag>'
 # then copy gpurun_out/refresh/* into profiles/.
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/refresh
