@@ -1404,10 +1404,11 @@ def test_conv3d_winograd_weight_gradient_refuses_other_channel_counts():
 
 
 @pytest.mark.parametrize("shape,pool", [((2, 7, 9, 13, 8, 32), "max"), ((2, 7, 9, 13, 8, 32), None), ((2, 12, 16, 16, 32, 64), "max"),
-                                        ((1, 24, 24, 24, 64, 64), None)])
+                                        ((1, 24, 24, 24, 64, 64), None), ((3, 9, 15, 21, 32, 32), "max"), ((2, 7, 10, 13, 64, 96), None)])
 def test_conv3d_winograd_eval_block_in_one_pass(shape, pool):
     """tmf_conv3d_fwd_wino_affine: the eval-mode block (conv + folded BatchNorm + LeakyReLU + max pool) in ONE Winograd kernel —
-    bitwise what the two-kernel sequence (Winograd conv, then tmf_bn_act_pool_fwd) gives, and fp32-close to fp64 torch."""
+    conv3d_winox_kernel<2 | 3> where the split kernel takes the launch, conv3d_wino_p_kernel<2> otherwise — bitwise what the
+    two-kernel sequence of the same family (Winograd conv, then tmf_bn_act_pool_fwd) gives, and fp32-close to fp64 torch."""
     from transmf_ad_amd import _lib
     ops = _ops()
     B, D, H, W, cin, cout = shape
@@ -1419,22 +1420,25 @@ def test_conv3d_winograd_eval_block_in_one_pass(shape, pool):
     scg, shg = sc.to(DEV), sh.to(DEV)
     pc = _lib.pool_code(pool)
     oshape = (B, D // 2, H // 2, W // 2, cout) if pool else (B, D, H, W, cout)
-    y = torch.full(oshape, float("nan"), device=DEV)
-    _lib.call("tmf_conv3d_fwd_wino_affine", xg.data_ptr(), uf.data_ptr(), scg.data_ptr(), shg.data_ptr(), y.data_ptr(),
-              B, D, H, W, cin, cout, pc, 0.01, ops._stream())
-    # (the two-kernel sequence on the fp32 matrix pipe: the one-kernel block is that kernel's MODE 2; the train-mode default for
-    #  cin % 32 == 0 is the split kernel of conv3d_winox.hip, whose sums round differently — compared below to fp32 round-off)
-    _lib.call("tmf_set_option", b"wino_x", 0)
-    try:
-        z, _, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, False)
-    finally:
-        _lib.call("tmf_set_option", b"wino_x", 1)
-    y2 = torch.empty(oshape, device=DEV)
-    _lib.call("tmf_bn_act_pool_fwd_t", z.data_ptr(), scg.data_ptr(), shg.data_ptr(), y2.data_ptr(), B, D, H, W, cout, pc, 0.01, 0,
-              ops._stream())
-    assert torch.equal(y, y2)
-    zx, _, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, False)
-    assert (zx - z).abs().max().item() <= 2e-6 * z.abs().max().item()
+    ys = {}
+    for xmode in (1, 0):        # the split kernel's eval modes (where it takes the launch) and the fp32 kernel's: each against ITS two-kernel sequence
+        _lib.call("tmf_set_option", b"wino_x", xmode)
+        try:
+            y = torch.full(oshape, float("nan"), device=DEV)
+            _lib.call("tmf_conv3d_fwd_wino_affine", xg.data_ptr(), uf.data_ptr(), scg.data_ptr(), shg.data_ptr(), y.data_ptr(),
+                      B, D, H, W, cin, cout, pc, 0.01, ops._stream())
+            z, _, _ = ops.conv3d_wino_raw(xg, uf, cin, cout, False)
+        finally:
+            _lib.call("tmf_set_option", b"wino_x", 1)
+        y2 = torch.empty(oshape, device=DEV)
+        _lib.call("tmf_bn_act_pool_fwd_t", z.data_ptr(), scg.data_ptr(), shg.data_ptr(), y2.data_ptr(), B, D, H, W, cout, pc, 0.01, 0,
+                  ops._stream())
+        assert torch.equal(y, y2), xmode
+        ys[xmode] = y
+    y = ys[1]
+    assert (ys[1] - ys[0]).abs().max().item() <= 3e-6 * ys[0].abs().max().item()
+    if cin % 32 == 0:
+        assert not torch.equal(ys[1], ys[0])                                    # (the split kernel did take it)
     ref = F.leaky_relu(F.conv3d(x.double(), w.double(), None, 1, 1) * sc.double().view(1, -1, 1, 1, 1) + sh.double().view(1, -1, 1, 1, 1), 0.01)
     if pool:
         ref = F.max_pool3d(ref, 2, 2)

@@ -1871,9 +1871,9 @@ template <int MODE>
 int launch_wino_p(const char* what, const float* x, const float* u, float* z, float* stat_partial, int B, int D, int H, int W,
                   int cin, int cout, const float* scale, const float* shift, float slope, int pool, hipStream_t stream) {
     // train forward / data gradient on the bf16 matrix pipe through exact 3-way splits (conv3d_winox.hip) where it takes the launch
-    if (MODE != 2 && tmf_winox_takes(B, D, H, W, cin, cout, wino_p_geom(B, D, H, W)))
+    if (tmf_winox_takes(B, D, H, W, cin, cout, wino_p_geom(B, D, H, W)))
         return tmf_winox_launch(what, x, reinterpret_cast<const unsigned short*>(u + (size_t)64 * cin * cout), z, stat_partial, B, D, H, W,
-                                cin, cout, wino_cu_count(), stream);
+                                cin, cout, wino_cu_count(), stream, MODE == 2 ? scale : nullptr, MODE == 2 ? shift : nullptr, slope, pool);
     if (wino_p_geom(B, D, H, W) && (long)4 * D * H * W * (cin > cout ? cin : cout) < (1L << 29)) return launch_wino_p_g<MODE, 1>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
     return launch_wino_p_g<MODE, 0>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
 }

@@ -139,13 +139,18 @@ __device__ __forceinline__ f32x16 mfma_bf16(i32x4 a, i32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tmf_bf16x8, a), __builtin_bit_cast(tmf_bf16x8, b), c, 0, 0, 0);
 }
 
-// MODE 0: z only (data gradient); 1: z + BatchNorm statistic partials (train forward)
+// MODE 0: z only (data gradient); 1: z + BatchNorm statistic partials (train forward); 2 / 3: the eval-mode block in ONE pass —
+// y = LeakyReLU(scale z + shift) (BatchNorm is affine in eval mode), 3: 2x2x2 max-pooled (floor mode) before anything is stored: the
+// window's d pair sits in one reader lane, its h pair in the two passes of the epilogue, its w pair in lane ^ 8
 template <int MODE>
 __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ u3, float* __restrict__ z, float* __restrict__ stat_partial,
     int B, int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int item0, int nitems,
-    int stat_rows, int stat_accum) {
+    int stat_rows, int stat_accum, const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr,
+    float slope = 0.f) {
     constexpr bool STATS = MODE == 1;
+    constexpr bool AFFINE = MODE >= 2, POOL = MODE == 3;
+    constexpr int EPI_STORES = POOL ? 1 : 4;                // vector-memory stores of an item's epilogue (static: the counted waits)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* ex = smem + EX_OFF / 4;
     float* red = smem + RED_OFF / 4;
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
                 // in flight behind this position's weights: those of the X_PF positions after it (3 each) and, as long as the six halo
                 // copies issued at the chunk's start lie behind them (positions < X_PF), those and — at the start of an item — the 4
                 // stores of the epilogue before it
-                constexpr int cnt = 3 * X_PF + (q8 < X_PF ? ((X_ABL & 4) ? 0 : 6) + (FIRST && !(X_ABL & 8) ? 4 : 0) : 0);
+                constexpr int cnt = 3 * X_PF + (q8 < X_PF ? ((X_ABL & 4) ? 0 : 6) + (FIRST && !(X_ABL & 8) ? EPI_STORES : 0) : 0);
                 vm_wait<cnt>();
                 pin3(Bq[q8 & 3][0], Bq[q8 & 3][1], Bq[q8 & 3][2]);
                 i32x4 vh, vm_, vl;
@@ -487,12 +492,24 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
             }
         }
         XTR(40);
-        float* zb = z + (size_t)b * D * H * W * Cout;
-        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, D * H * W * Cout * 4, 0x00020000);
+        const int OD = D / 2, OH = H / 2, OW = W / 2;        // (MODE 3: the pooled tensor)
+        float* zb = z + (size_t)b * (POOL ? OD * OH * OW : D * H * W) * Cout;
+        const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc(zb, 0, (POOL ? OD * OH * OW : D * H * W) * Cout * 4, 0x00020000);
         const bool full = d0 + BD <= D && h0 + BH <= H && w0 + BW <= W;
         if (STATS && stat_partial != nullptr && st_n0 != n0) {
             if (st_n0 >= 0) stat_flush();
             st_n0 = n0;
+        }
+        if (AFFINE && st_n0 != n0) {                         // a new channel group: its scale / shift into LDS (the statistics' cells are free here)
+            __syncthreads();
+            if (tid < 64) red[tid] = tid < 32 ? aff_scale[n0 + tid] : aff_shift[n0 + tid - 32];
+            __syncthreads();
+            st_n0 = n0;
+        }
+        f32x4 a_sc = {1.f, 1.f, 1.f, 1.f}, a_sh = {0.f, 0.f, 0.f, 0.f}, pmax = {0.f, 0.f, 0.f, 0.f};
+        if (AFFINE) {
+            a_sc = *reinterpret_cast<const f32x4*>(&red[4 * cq]);
+            a_sh = *reinterpret_cast<const f32x4*>(&red[32 + 4 * cq]);
         }
         const int gd0 = d0 + 2 * r_td, gh0 = h0 + 2 * r_th, gw = w0 + 2 * r_tw + rwo;
         const int st_item = (((d0 * H + h0) * W + w0) * Cout + n0) * 4;
@@ -511,6 +528,42 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
             o[0] = (S[0] + S[1]) + S[2];
             o[1] = (S[1] - S[2]) - S[3];
             const int gh = gh0 + ho;
+            if (AFFINE) {
+#pragma unroll
+                for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yv = o[dd][e] * a_sc[e] + a_sh[e];
+                        o[dd][e] = yv > 0.f ? yv : yv * slope;
+                    }
+            }
+            if (POOL) {
+                // the window = the tile: d pair here, h pair = the two passes, w pair = lane ^ 8; ONE store per item (pass 1, wo = 0 lanes)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = fmaxf(o[0][e], o[1][e]);
+                    pmax[e] = ho == 0 ? v : fmaxf(pmax[e], v);
+                }
+                if (ho == 1) {
+                    f32x4 m;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // row_ror:8 = lane ^ 8, as assembly: with the builtin (mov_dpp and update_dpp alike) the compiler emitted ONE
+                        // v_mov_b32_dpp and used its result for all four channels.  (s_nop: a DPP read needs two wait states behind the
+                        // VALU write of its source, which the hazard pass does not see inside an asm block.)
+                        float other;
+                        asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=&v"(other) : "v"(pmax[e]));
+                        m[e] = fmaxf(pmax[e], other);
+                    }
+                    const int od = (d0 >> 1) + r_td, oh = (h0 >> 1) + r_th, ow = (w0 >> 1) + r_tw;
+                    const bool okp = rwo == 0 && od < OD && oh < OH && ow < OW;
+                    const int voff = (((r_td * OH + r_th) * OW + r_tw) * Cout + 4 * cq) * 4;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tmf_u32x4, m), zr, okp ? voff : OOB,
+                                                           ((((d0 >> 1) * OH + (h0 >> 1)) * OW + (w0 >> 1)) * Cout + n0) * 4, 0);
+                    store_guard();
+                }
+                return;
+            }
 #pragma unroll
             for (int dd = 0; dd < 2; ++dd) {
                 const bool ok = full || (gd0 + dd < D && gh < H && gw < W);
@@ -590,7 +643,7 @@ int tmf_winox_takes(int B, int D, int H, int W, int cin, int cout, int geom) {
 }
 
 int tmf_winox_launch(const char* what, const float* x, const unsigned short* u3, float* z, float* stat_partial, int B, int D, int H,
-                     int W, int cin, int cout, int ncu, hipStream_t stream) {
+                     int W, int cin, int cout, int ncu, hipStream_t stream, const float* scale, const float* shift, float slope, int pool) {
     const int tilesD = tmf_cdiv(D, BD), tilesH = tmf_cdiv(H, BH), tilesW = tmf_cdiv(W, BW);
     TMF_REQUIRE(tilesD < 1024 && tilesH < 1024 && tilesW < 1024, TMF_E_SHAPE, "%s: more than 1023 bricks along one axis", what);
     TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 29), TMF_E_SHAPE,
@@ -611,11 +664,12 @@ int tmf_winox_launch(const char* what, const float* x, const unsigned short* u3,
                 grid = (int)((n + rounds - 1) / rounds);
             }
             hipLaunchKernelGGL(k, dim3(grid), dim3(XN), X_LDS_BYTES, stream, x, u3, z, stat_partial, B, D, H, W, cin, cout,
-                               tilesD, tilesH, tilesW, (int)nbricks, (int)i0, (int)n, ncu, i0 > 0 ? 1 : 0);
+                               tilesD, tilesH, tilesW, (int)nbricks, (int)i0, (int)n, ncu, i0 > 0 ? 1 : 0, scale, shift, slope);
             if ((rc = tmf_launch_result(what))) return rc;
         }
         return TMF_OK;
     };
+    if (scale != nullptr) return pool == TMF_POOL_MAX2 ? launch(conv3d_winox_kernel<3>, 3) : launch(conv3d_winox_kernel<2>, 2);
     if (stat_partial != nullptr) return launch(conv3d_winox_kernel<1>, 1);
     return launch(conv3d_winox_kernel<0>, 0);
 }

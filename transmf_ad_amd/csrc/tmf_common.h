@@ -104,7 +104,8 @@ struct TmfAlgoScope {
 int tmf_wino_x_set(int v);       // conv3d_winox.hip: tmf_set_option("wino_x", 0 | 1): Winograd forward / data gradient as exact 3-way bf16 splits on the bf16 matrix pipe
 int tmf_winox_takes(int B, int D, int H, int W, int cin, int cout, int geom);
 int tmf_winox_launch(const char* what, const float* x, const unsigned short* u3, float* z, float* stat_partial, int B, int D, int H,
-                     int W, int cin, int cout, int ncu, hipStream_t stream);
+                     int W, int cin, int cout, int ncu, hipStream_t stream, const float* scale = nullptr, const float* shift = nullptr,
+                     float slope = 0.f, int pool = 0);     // scale != NULL: the eval-mode block (y = LeakyReLU(scale z + shift), pool none | max)
 int tmf_conv_wino_set(int v);    // conv3d_wino.hip: tmf_set_option("conv_wino", 0 | 1 | 2)
 extern int tmf_g_bf16_dma;       // conv3d_bf16.hip: LDS-DMA form of the large-brick bf16 forward kernel (tmf_set_option("bf16_dma", 0 | 1))
 extern int tmf_g_bf16_v2;        // conv3d_bf16.hip: kernel choice of the bf16 forward (tmf_set_option("bf16_v2", ..))
