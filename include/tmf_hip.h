@@ -204,6 +204,7 @@ int    tmf_c1_stats(const float* x, const float* w, float* stat_partial, int B, 
  * (dy is one element per pooling window: 27 multiply-adds per window beside the BatchNorm sums).  workspace:
  * tmf_c1_bwd_fused_workspace_bytes(). */
 size_t tmf_c1_gram_bytes(int B, int D, int H, int W, int C);
+size_t tmf_c1_gram_bytes_bf16(int B, int D, int H, int W, int C);   /* what a bf16-mode caller asks: 0 unless "c1_gram" is 2 */
 int    tmf_c1_stats_g(const float* x, const float* w, float* stat_partial, void* gram, size_t gram_bytes,
                       int B, int D, int H, int W, int C, void* stream);
 size_t tmf_c1_bwd_fused_workspace_bytes(int B, int D, int H, int W, int C);
@@ -211,6 +212,15 @@ int    tmf_c1_bwd_fused(const float* x, const float* w, const float* scale, cons
                         const float* invstd, const float* dpool, const void* gram, float* dw, float* dgamma, float* dbeta,
                         void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, float slope,
                         int dw_layout, void* stream);
+/* Round 6: the same two entries for the bf16 mode (TMF_PREC_BF16; conv1_fused_kernel<.., true> multiplies the volume and the taps
+ * ROUNDED to bf16): G, S_t of the rounded volume, forms in the rounded taps — the exact statistics of that kernel's z; the backward
+ * pass accumulates D from the rounded volume and the unrounded dy (pooled_bf16: dpool is a bf16 tensor). */
+int    tmf_c1_stats_g_bf16(const float* x, const float* w, float* stat_partial, void* gram, size_t gram_bytes,
+                           int B, int D, int H, int W, int C, void* stream);
+int    tmf_c1_bwd_fused_bf16(const float* x, const float* w, const float* scale, const float* shift, const float* mean,
+                             const float* invstd, const void* dpool, const void* gram, float* dw, float* dgamma, float* dbeta,
+                             void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, float slope,
+                             int pooled_bf16, int dw_layout, void* stream);
 int    tmf_c1_bn_pool_fwd(const float* x, const float* w, const float* scale, const float* shift, float* pooled,
                           int B, int D, int H, int W, int C, float slope, void* stream);
 int    tmf_c1_bwd_reduce(const float* x, const float* w, const float* scale, const float* shift,
@@ -456,7 +466,10 @@ int    tmf_scale_flip(const float* src, float* dst, const float* minmax, const u
 #define TMF_SNET_ALGO_WINO_P   0x800              /* wino_p: the persistent one-wave-per-SIMD Winograd kernels */
 #define TMF_SNET_ALGO_WINO_X   0x1000             /* wino_x: forward / data gradient as exact 3-way bf16 splits (conv3d_winox.hip) */
 #define TMF_SNET_ALGO_C1_GRAM  0x2000             /* c1_gram: the first block through the tap Gram matrix of its input */
+#define TMF_SNET_ALGO_C1_GRAM_BF16 0x4000         /* c1_gram 2: in the bf16 mode as well (off by default: slower there) */
+#define TMF_SNET_ALGO_C1_SPLIT 0x8000             /* c1_split: z of the first block (fp32) as exact 3-way bf16 splits on the bf16 pipe */
 int  tmf_snet_algo_flags(void);
+int  tmf_c1_split_mode(void);                     /* the process option "c1_split" (TMF_C1_SPLIT, default 1) or the calling entry's flags */
 typedef struct tmf_snet_desc {
     int   B, D, H, W;                /* input volumes (B, 1, D, H, W) */
     int   dim;                       /* sNet(dim) */

@@ -1491,6 +1491,149 @@ def test_first_block_one_pass_backward_on_uncentred_input(scale):
         assert e1 <= max(3.0 * e0, 2e-5), (i, e1, e0)
 
 
+@pytest.mark.parametrize("out_bf16", [False, True])
+@pytest.mark.parametrize("shape", [(2, 16, 24, 40, 32), (1, 9, 13, 35, 32), (3, 8, 10, 33, 16)])
+def test_first_block_gram_path_in_the_bf16_mode(shape, out_bf16):
+    """Round 6: tmf_c1_stats_g_bf16 / tmf_c1_bwd_fused_bf16 — the bf16 mode multiplies the volume and the taps ROUNDED to bf16
+    (conv1_fused_kernel<.., true>), so G, S_t are those of the rounded volume and the forms use the rounded taps: G / S_t against an
+    explicit fp64 evaluation on the rounded volume, the statistic rows against the sums of the exactly computed z of the rounded
+    operands; the whole block (one pass) against the bf16 mode's two-pass backward ("c1_gram" 0) and against fp64 torch on the rounded
+    operands — no further from it than the two-pass form, which rounds dz to bf16 once more; bit-identical run to run.  The mode takes
+    the path under "c1_gram" 2 only (it is slower there: DESIGN 3.16), so that is what the one-pass runs set."""
+    from transmf_ad_amd import _lib
+    ops = _ops()
+    B, D, H, W, C = shape
+    g = torch.Generator().manual_seed(12)
+    x = torch.rand((B, D, H, W), generator=g) * 0.8 + 0.1
+    w = torch.randn((C, 1, 3, 3, 3), generator=g) * 0.3
+    xb, wb = x.bfloat16().double(), w.bfloat16().double()
+    xg = x.to(DEV)
+    wp = ops.pack_weight(w.to(DEV)).view(27, C)
+    gbytes = _lib.query("tmf_c1_gram_bytes", B, D, H, W, C)
+    assert gbytes > 0
+    part = torch.full((2, 2, C), float("nan"), device=DEV)
+    gram = torch.empty(gbytes // 8, device=DEV, dtype=torch.float64)
+    _lib.call("tmf_c1_stats_g_bf16", xg.data_ptr(), wp.data_ptr(), part.data_ptr(), gram.data_ptr(), gbytes, B, D, H, W, C, ops._stream())
+    torch.cuda.synchronize()
+    xp = F.pad(xb, (2, 2, 2, 2, 2, 2))
+    sh = torch.stack([xp[:, 1 + t // 9:1 + t // 9 + D, 1 + (t // 3) % 3:1 + (t // 3) % 3 + H, 1 + t % 3:1 + t % 3 + W].reshape(-1)
+                      for t in range(27)])
+    G_ref, S_ref = sh @ sh.t(), sh.sum(1)
+    assert (gram[:729].cpu().view(27, 27) - G_ref).abs().max().item() <= 1e-12 * G_ref.abs().max().item()
+    assert (gram[729:756].cpu() - S_ref).abs().max().item() <= 1e-12 * S_ref.abs().max().item()
+    z = F.conv3d(xb.unsqueeze(1), wb, None, 1, 1)
+    s1 = (part[0, 0].double() + part[1, 0].double()).cpu()
+    s2 = (part[0, 1].double() + part[1, 1].double()).cpu()
+    assert (s1 - z.sum((0, 2, 3, 4))).abs().max().item() <= 1e-9 * z.abs().sum((0, 2, 3, 4)).max().item()
+    assert ((s2 - (z * z).sum((0, 2, 3, 4))).abs() / (z * z).sum((0, 2, 3, 4))).max().item() <= 1e-9
+    # the whole block in the bf16 mode, both backward forms
+    prec = ops.make_precision("bf16", "bf16" if out_bf16 else "fp32")
+    conv = torch.nn.Conv3d(1, C, 3, padding=1).to(DEV)
+    bn = torch.nn.BatchNorm3d(C).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(w.to(DEV))
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.2, 0.2)
+    go = torch.randn((B, D // 2, H // 2, W // 2, C), generator=g)
+    if out_bf16:
+        go = go.bfloat16()
+    gog = go.to(DEV)
+    res = {}
+    assert _lib.query("tmf_c1_gram_bytes_bf16", B, D, H, W, C) == 0                  # the default: fp32 only
+    for gram_opt in (2, 1, 2):
+        _lib.call("tmf_set_option", b"c1_gram", gram_opt)
+        try:
+            assert (_lib.query("tmf_c1_gram_bytes_bf16", B, D, H, W, C) > 0) == (gram_opt == 2)
+            for p_ in (conv.weight, bn.weight, bn.bias):
+                p_.grad = None
+            y = ops.conv_bn_act_pool(xg.unsqueeze(-1), conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean.clone(),
+                                     bn.running_var.clone(), True, pool="max", out_bf16=out_bf16, precision=prec)
+            assert y.dtype == (torch.bfloat16 if out_bf16 else torch.float32)
+            y.backward(gog)
+            torch.cuda.synchronize()
+        finally:
+            _lib.call("tmf_set_option", b"c1_gram", 1)
+        res.setdefault(gram_opt, []).append((y.detach().float().cpu(), conv.weight.grad.cpu().clone(), bn.weight.grad.cpu().clone(),
+                                             bn.bias.grad.cpu().clone()))
+    a, a2 = res[2]
+    b = res[1][0]
+    assert all(torch.equal(u, v) for u, v in zip(a, a2))
+    w64 = wb.clone().requires_grad_(True)
+    g64, b64 = bn.weight.detach().double().cpu().requires_grad_(True), bn.bias.detach().double().cpu().requires_grad_(True)
+    zz = F.conv3d(xb.unsqueeze(1), w64, conv.bias.detach().double().cpu(), padding=1)
+    yy = F.max_pool3d(F.leaky_relu(F.batch_norm(zz, None, None, g64, b64, True, 0.1, 1e-5), 0.01), 2)
+    yy.backward(go.double().permute(0, 4, 1, 2, 3))
+    assert _relerr(_ncdhw(a[0]), yy.detach()) < (1e-2 if out_bf16 else 2e-5)
+    for i, ref in enumerate((w64.grad, g64.grad, b64.grad)):
+        e1 = (a[1 + i].double() - ref).abs().max().item() / ref.abs().max().item()
+        e0 = (b[1 + i].double() - ref).abs().max().item() / ref.abs().max().item()
+        assert e1 <= max(1.5 * e0, 2e-5), (i, e1, e0)
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 24, 40, 32), (1, 9, 13, 35, 32), (3, 8, 10, 33, 16), (2, 17, 16, 19, 8)])
+def test_first_block_z_as_exact_bf16_splits(shape):
+    """Round 6, "c1_split" (default 1): the fp32 passes of the first block compute z on the bf16 matrix pipe from EXACT 3-way bf16
+    splits of the volume and the taps (six partial products; conv1_fused_kernel<.., SPLIT>).  Against the fp32-MFMA passes
+    ("c1_split" 0) and fp64: the block's output, statistics and all three gradients — no further from fp64 than the fp32 form (x 1.5)
+    —, EXACT equality with it on small integers (every product and sum representable), and bit-identical results run to run."""
+    from transmf_ad_amd import _lib
+    ops = _ops()
+    B, D, H, W, C = shape
+    g = torch.Generator().manual_seed(31)
+    assert _lib.query("tmf_c1_split_mode") == 1
+
+    def block(x, w, gamma, beta, go, split, gram):
+        _lib.call("tmf_set_option", b"c1_split", split)
+        _lib.call("tmf_set_option", b"c1_gram", gram)
+        try:
+            conv = torch.nn.Conv3d(1, C, 3, padding=1).to(DEV)
+            bn = torch.nn.BatchNorm3d(C).to(DEV)
+            with torch.no_grad():
+                conv.weight.copy_(w.to(DEV)); bn.weight.copy_(gamma.to(DEV)); bn.bias.copy_(beta.to(DEV))
+                conv.bias.fill_(0.25)
+            y = ops.conv_bn_act_pool(x.to(DEV).unsqueeze(-1), conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean,
+                                     bn.running_var, True, pool="max")
+            y.backward(go.to(DEV))
+            torch.cuda.synchronize()
+            return [t.detach().cpu().clone() for t in (y, conv.weight.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)]
+        finally:
+            _lib.call("tmf_set_option", b"c1_split", 1)
+            _lib.call("tmf_set_option", b"c1_gram", 1)
+
+    x = torch.rand((B, D, H, W), generator=g) * 3.0 + 0.1
+    w = torch.randn((C, 1, 3, 3, 3), generator=g) * 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.rand(C, generator=g) * 0.4 - 0.2
+    go = torch.randn((B, D // 2, H // 2, W // 2, C), generator=g)
+    w64 = w.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    zz = F.conv3d(x.double().unsqueeze(1), w64, None, padding=1)
+    yy = F.max_pool3d(F.leaky_relu(F.batch_norm(zz, None, None, g64, b64, True, 0.1, 1e-5), 0.01), 2)
+    yy.backward(go.double().permute(0, 4, 1, 2, 3))
+    ref = [yy.detach(), w64.grad, g64.grad, b64.grad]
+    for gram in (1, 0):                                   # the one-pass (Gram) and the recomputing passes: all five kernel modes
+        a, a2, b = block(x, w, gamma, beta, go, 1, gram), block(x, w, gamma, beta, go, 1, gram), block(x, w, gamma, beta, go, 0, gram)
+        assert all(torch.equal(u, v) for u, v in zip(a, a2))
+        assert _relerr(_ncdhw(a[0]), ref[0]) < 3e-6
+        for i in (1, 2, 3):
+            e1 = (a[i].double() - ref[i]).abs().max().item() / ref[i].abs().max().item()
+            e0 = (b[i].double() - ref[i]).abs().max().item() / ref[i].abs().max().item()
+            assert e1 <= max(1.5 * e0, 5e-6), (gram, i, e1, e0)
+        for u, v in zip(a[4:], b[4:]):
+            assert (u - v).abs().max().item() <= 2e-6 * max(1.0, v.abs().max().item())
+    # small integers: every partial product and every sum is exact in both forms -> the same z bit for bit, hence the same block
+    xi = torch.randint(-4, 5, (B, D, H, W), generator=g).float()
+    wi = torch.randint(-3, 4, (C, 1, 3, 3, 3), generator=g).float()
+    a, b = block(xi, wi, gamma, beta, go, 1, 0), block(xi, wi, gamma, beta, go, 0, 0)
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+    # ... and values that NEED all three parts (24 significant bits)
+    xf = (torch.randint(1 << 23, 1 << 24, (B, D, H, W), generator=g).float() * 2.0 ** -20)
+    wf = (torch.randint(1 << 23, 1 << 24, (C, 1, 3, 3, 3), generator=g).float() * 2.0 ** -26) * (torch.randint(0, 2, (C, 1, 3, 3, 3), generator=g) * 2 - 1)
+    a = block(xf, wf, gamma, beta, go, 1, 1)
+    zz = F.conv3d(xf.double().unsqueeze(1), wf.double(), None, padding=1)
+    yy = F.max_pool3d(F.leaky_relu(F.batch_norm(zz, None, None, gamma.double(), beta.double(), True, 0.1, 1e-5), 0.01), 2)
+    assert _relerr(_ncdhw(a[0]), yy) < 3e-6
+
+
 C1_FUSED_SHAPES = [(2, 16, 24, 40, 32), (1, 9, 13, 35, 32), (3, 8, 10, 33, 16), (5, 17, 16, 19, 8), (8, 48, 48, 48, 32)]
 
 

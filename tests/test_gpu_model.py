@@ -806,7 +806,7 @@ def test_one_call_fusion_is_taken_by_default():
     assert type(cls.grad_fn).__name__.startswith("FusionTrain"), cls.grad_fn
 
 
-def _bf16_mode_errors(mode, B=4, size=(48, 48, 48)):
+def _bf16_mode_errors(mode, B=4, size=(48, 48, 48), c1_gram=1):
     """HIP path in a bf16 mode against the oracle's restatement of THAT mode (oracle/tmf_oracle.py conv_mode: the same
     algorithm with the kernels' rounding points, evaluated in fp64) on structured volumes.  Returns error figures."""
     import transmf_ad_amd as T
@@ -827,8 +827,10 @@ def _bf16_mode_errors(mode, B=4, size=(48, 48, 48)):
     loss_ref.backward()
     gref = O.grads_of(S, spec)
     # HIP path
+    from transmf_ad_amd import _lib
     T.set_conv_precision("bf16")
     T.set_activation_storage("bf16" if mode == "bf16s" else "fp32")
+    _lib.call("tmf_set_option", b"c1_gram", c1_gram)
     try:
         net = T.model_ad(dropout=0., **kw)
         net.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in arrs.items()}, strict=True)
@@ -846,6 +848,7 @@ def _bf16_mode_errors(mode, B=4, size=(48, 48, 48)):
         loss.backward()
         torch.cuda.synchronize()
     finally:
+        _lib.call("tmf_set_option", b"c1_gram", 1)
         T.set_activation_storage("fp32")
         T.set_conv_precision("fp32")
     err = {"loss": abs(loss.item() - loss_ref.item()),
@@ -884,6 +887,18 @@ def test_bf16_modes_match_their_own_oracle(mode):
     against the un-rounded fp32 reference; what is left are bf16 rounding-boundary flips (a value within fp32 round-off of
     a bf16 rounding boundary goes the other way: one 2^-8 step in one element) and discrete pool / LeakyReLU decisions."""
     e = _bf16_mode_errors(mode)
+    tol = BF16_ORACLE_TOL[mode]
+    assert max(e["cls"], e["mri_cnn.conv4.3"], e["pet_cnn.conv4.3"]) <= tol["act"], e
+    assert e["logits"] <= tol["logits"] and e["d"] <= tol["d"] and e["loss"] <= tol["loss"], e
+    assert e["grad_l2_conv"] <= tol["gconv"] and e["grad_l2_rest"] <= tol["grest"], e
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16s"])
+def test_bf16_modes_with_the_first_block_through_the_gram_matrix(mode):
+    """Round 6, "c1_gram" 2: the bf16 modes' first block takes its statistics from the tap Gram matrix of the bf16-ROUNDED volume and
+    its backward in one pass (tmf_c1_stats_g_bf16 / tmf_c1_bwd_fused_bf16 inside tmf_snet_train_fwd / _bwd) — the same oracle, the
+    same tolerances as the recomputing passes (off by default: slower in this mode)."""
+    e = _bf16_mode_errors(mode, c1_gram=2)
     tol = BF16_ORACLE_TOL[mode]
     assert max(e["cls"], e["mri_cnn.conv4.3"], e["pet_cnn.conv4.3"]) <= tol["act"], e
     assert e["logits"] <= tol["logits"] and e["d"] <= tol["d"] and e["loss"] <= tol["loss"], e

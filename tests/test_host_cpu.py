@@ -307,29 +307,34 @@ def test_algorithm_choice_travels_in_the_descriptor():
         desc.eps[:] = [1e-5] * 7
         desc.slope[:] = [0.01] * 7
         return lib.tmf_snet_saved_bytes(ctypes.byref(desc))
-    ALGO, P, X, G = 0x100, 0x800, 0x1000, 0x2000
-    assert lib.tmf_snet_algo_flags() == ALGO | (3 << 9) | P | X | G
+    ALGO, P, X, G, S = 0x100, 0x800, 0x1000, 0x2000, 0x8000      # (S: c1_split, the first block's z as exact bf16 splits)
+    assert lib.tmf_snet_algo_flags() == ALGO | (3 << 9) | P | X | G | S
     default = saved(0)
     assert saved(lib.tmf_snet_algo_flags()) == default
-    by_flags = {m: saved(ALGO | (m << 9) | P | X | G) for m in (0, 1, 2, 3)}
-    no_gram = saved(ALGO | (3 << 9) | P | X)
+    by_flags = {m: saved(ALGO | (m << 9) | P | X | G | S) for m in (0, 1, 2, 3)}
+    no_gram = saved(ALGO | (3 << 9) | P | X | S)
     assert by_flags[3] == default and len(set(by_flags.values())) >= 3 and no_gram < default
+    assert saved(ALGO | (3 << 9) | P | X | G) == default                      # (c1_split changes kernels, not the plan)
     try:
         for m in (0, 1, 2):
             assert lib.tmf_set_option(b"conv_wino", m) == 0
             assert saved(0) == by_flags[m]                                    # the process option ...
-            assert saved(ALGO | (3 << 9) | P | X | G) == default              # ... does not reach a call that carries its own
-            assert lib.tmf_snet_algo_flags() == ALGO | (m << 9) | P | X | G
+            assert saved(ALGO | (3 << 9) | P | X | G | S) == default          # ... does not reach a call that carries its own
+            assert lib.tmf_snet_algo_flags() == ALGO | (m << 9) | P | X | G | S
         assert lib.tmf_set_option(b"conv_wino", 3) == 0 and lib.tmf_set_option(b"c1_gram", 0) == 0
-        assert saved(0) == no_gram and saved(ALGO | (3 << 9) | P | X | G) == default
+        assert saved(0) == no_gram and saved(ALGO | (3 << 9) | P | X | G | S) == default
+        assert lib.tmf_set_option(b"c1_split", 0) == 0 and lib.tmf_c1_split_mode() == 0
+        assert lib.tmf_snet_algo_flags() == ALGO | (3 << 9) | P | X
     finally:
         lib.tmf_set_option(b"conv_wino", 3)
         lib.tmf_set_option(b"c1_gram", 1)
-    assert ops.snet_algo_flags() == ALGO | (3 << 9) | P | X | G
-    assert ops.snet_algo_flags(dict(conv_wino=0, wino_x=0)) == ALGO | P | G
+        lib.tmf_set_option(b"c1_split", 1)
+    assert ops.snet_algo_flags() == ALGO | (3 << 9) | P | X | G | S
+    assert ops.snet_algo_flags(dict(conv_wino=0, wino_x=0)) == ALGO | P | G | S
+    assert ops.snet_algo_flags(dict(c1_split=0, c1_gram=2)) == ALGO | (3 << 9) | P | X | G | 0x4000
     with pytest.raises(ValueError):
         ops.snet_algo_flags(dict(winograd=1))
-    assert lib.tmf_conv_wino_mode() == 3 and lib.tmf_wino_x_mode() == 1      # (no override leaks out of a call)
+    assert lib.tmf_conv_wino_mode() == 3 and lib.tmf_wino_x_mode() == 1 and lib.tmf_c1_split_mode() == 1   # (no override leaks out of a call)
 
 
 def test_split_winograd_kernel_takes_the_launches_it_is_built_for():
@@ -399,6 +404,15 @@ def test_first_block_gram_path_is_offered_only_inside_its_limits():
     assert n == (760 + 256 * 64 + 6 * 64 * 96) * 8
     assert lib.tmf_c1_gram_bytes(8, 96, 96, 96, 128) == 0 and lib.tmf_c1_gram_bytes(1, 1100, 64, 64, 32) == 0
     assert lib.tmf_c1_gram_bytes(64, 400, 400, 400, 32) == 0 and lib.tmf_c1_gram_bytes(0, 96, 96, 96, 32) == 0
+    lib.tmf_c1_gram_bytes_bf16.restype = ctypes.c_size_t
+    assert lib.tmf_c1_gram_bytes_bf16(8, 96, 96, 96, 32) == 0           # the bf16 mode: under "c1_gram" 2 only
+    assert lib.tmf_set_option(b"c1_gram", 2) == 0
+    try:
+        assert lib.tmf_c1_gram_bytes_bf16(8, 96, 96, 96, 32) == n and lib.tmf_c1_gram_bytes(8, 96, 96, 96, 32) == n
+        assert lib.tmf_snet_algo_flags() & 0x6000 == 0x6000
+    finally:
+        lib.tmf_set_option(b"c1_gram", 1)
+    assert lib.tmf_snet_algo_flags() & 0x6000 == 0x2000
     assert lib.tmf_set_option(b"c1_gram", 0) == 0
     try:
         assert lib.tmf_c1_gram_bytes(8, 96, 96, 96, 32) == 0

@@ -51,6 +51,7 @@ PROTOTYPES = {
     "tmf_conv3d_wgrad_wino_tiles": (C.c_long, [_i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wino_weight_bytes": (_z, [_i, _i]),
     "tmf_wino_x_mode": (_i, []),
+    "tmf_c1_split_mode": (_i, []),
     "tmf_snet_algo_flags": (_i, []),
     "tmf_conv_wino_mode": (_i, []),
     "tmf_wino_p_mode": (_i, []),
@@ -66,9 +67,12 @@ PROTOTYPES = {
     "tmf_c1_blocks": (_i, [_i, _i, _i, _i, _i]),
     "tmf_c1_stats": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "tmf_c1_gram_bytes": (_z, [_i, _i, _i, _i, _i]),
+    "tmf_c1_gram_bytes_bf16": (_z, [_i, _i, _i, _i, _i]),
     "tmf_c1_stats_g": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
     "tmf_c1_bwd_fused_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "tmf_c1_bwd_fused": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _i, _p]),
+    "tmf_c1_stats_g_bf16": (_i, [_p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _p]),
+    "tmf_c1_bwd_fused_bf16": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _z, _i, _i, _i, _i, _i, _f, _i, _i, _p]),
     "tmf_c1_bn_pool_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_c1_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_c1_stats_bf16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),

@@ -33,6 +33,11 @@ constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int NHALO = HD * HH * HW;
 
 enum { MODE_STATS = 0, MODE_FWD = 1, MODE_REDUCE = 2, MODE_WGRAD = 3, MODE_RD = 4 };
+#ifndef TMF_C1X_LAZY
+#define TMF_C1X_LAZY 0x12          // bit MODE: the SPLIT form of that pass computes one M-tile's z at a time — the one-pass backward
+                                   // needs it to stay below 256 registers (226), the forward drops to 128 (4 waves per SIMD:
+                                   // 111.6 -> 105.0 us at B = 8, 96^3; requesting the next image's rows ahead of the MFMAs: no gain)
+#endif
 // MODE_RD (round 5): MODE_REDUCE plus D[tap][c] = sum_voxel x[voxel + tap] dy[voxel][c] — dy is ONE element per pooling window, so D is 27
 // reads and multiply-adds per window; with the tap Gram matrix of the forward (conv1_gram.hip) the weight gradient follows without
 // a second pass (tmf_c1_bwd_fused).
@@ -81,12 +86,33 @@ __device__ __forceinline__ tmf_bf16x8 pack8(const float (&v)[8]) {
     return __builtin_bit_cast(tmf_bf16x8, p);
 }
 
+// x = h + m + l exactly, each part a bf16 number (low 16 bits zero): h / m by truncation, l = the remaining <= 8 bits
+__device__ __forceinline__ void split3(float x, float& h, float& m, float& l) {
+    h = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & 0xFFFF0000u);
+    const float r = x - h;
+    m = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, r) & 0xFFFF0000u);
+    l = r - m;
+}
+
 // BF16 = true: both products run on v_mfma_f32_32x32x16_bf16 (operands rounded to bf16, fp32 accumulation) — the
 // 27-tap convolution is 2 MFMAs instead of 14 and the tap-gradient product 2 instead of 16, which turns the four
 // passes from matrix-bound into LDS / HBM-bound (the opt-in bf16 mode of BASELINE configs[2]).
-template <int MODE, bool BF16, bool P16 = false>     // P16: pooled / dpool are bf16 tensors (bf16 activation storage)
-__global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Args a) {   // <= 256 registers: MFMA results in VGPRs (no v_accvgpr_read copies)
-    __shared__ float halo[BF16 ? NHB_DW : NHALO];
+//
+// SPLIT = true (round 6, fp32 mode): z of the fp32 precision on the bf16 matrix pipe — the volume and the taps as EXACT sums of three
+// bf16 parts each (h = the top 8 mantissa bits, m = the next 8, l = the rest; three bf16 halo images in the layout above), z = the six
+// partial products wh xl + wl xh + wm xm + wh xm + wm xh + wh xh, accumulated in fp32 from the small terms up: 18 MFMAs of 32 cycles per
+// 32 voxels x 32 channels instead of 14 of 64, the dropped products are below 2^-24 of |w||x| (conv3d_winox.hip has the same
+// arithmetic), and — what counts as much — the bf16 MFMAs do not share the vector ALU's issue port, so the BatchNorm / pooling /
+// routing arithmetic of these passes runs beside them instead of in between.  The fp32 halo stays next to the images for the passes
+// that multiply the inputs themselves (D of MODE_RD, the tap-gradient product of MODE_WGRAD: fp32 as before).
+template <int MODE, bool BF16, bool P16 = false, bool SPLIT = false>     // P16: pooled / dpool are bf16 tensors (bf16 activation storage)
+__global__ __launch_bounds__(256, MODE == 3 && !SPLIT ? 4 : 2) void conv1_fused_kernel(Args a) {   // <= 256 registers: MFMA results in VGPRs (no v_accvgpr_read copies)
+    static_assert(!(BF16 && SPLIT), "SPLIT is the fp32 mode's variant");
+    constexpr bool B16L = BF16 || SPLIT;                    // bf16 halo image(s) in LDS
+    constexpr int NIMG = SPLIT ? 3 : 1;
+    constexpr bool KEEP32 = SPLIT && (MODE == MODE_RD || MODE == MODE_WGRAD);
+    __shared__ float halo[B16L ? NIMG * NHB_DW : NHALO];
+    __shared__ float halo32[KEEP32 ? NHALO : 1];
     const unsigned hb_base = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)halo;   // LDS byte address of the bf16 copies (BF16)
     __shared__ float red[4 * 32 * 32];      // cross-wave reduction scratch (16 KB)
     const int tid = threadIdx.x;
@@ -98,11 +124,11 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
     const bool cv = co < a.C;
     const int OD = a.D / 2, OH = a.H / 2, OW = a.W / 2;
 
-    float bw[BF16 ? 1 : 14];
+    float bw[B16L ? 1 : 14];
     // BF16: K = 48 = 3 MFMAs x (2 lane halves x 4 tap rows x 2 taps): k = 16 m + 8 hsel + 2 s + t is tap row r = 4 m + s
     // (= 3 dz + dy), dx = 2 hsel + t — the lane half picks the pair (dx 0, 1) or (dx 2, pad); rows >= 9 and dx = 3 are zero
-    tmf_bf16x8 bwb[3];
-    if (BF16) {
+    tmf_bf16x8 bwb[NIMG][3];                // [part h / m / l][MFMA]
+    if (B16L) {
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             float v[8];
@@ -111,7 +137,14 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
                 const int r = 4 * m + (j >> 1), dx = 2 * hsel + (j & 1);
                 v[j] = (r < 9 && dx < 3 && cv) ? a.w[(3 * r + dx) * a.C + co] : 0.f;
             }
-            bwb[m] = pack8(v);
+            if (SPLIT) {
+                float vh[8], vm[8], vl[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) split3(v[j], vh[j], vm[j], vl[j]);
+                bwb[0][m] = pack8(vh); bwb[NIMG > 1 ? 1 : 0][m] = pack8(vm); bwb[NIMG > 2 ? 2 : 0][m] = pack8(vl);
+            } else {
+                bwb[0][m] = pack8(v);
+            }
         }
     } else {
 #pragma unroll
@@ -160,8 +193,8 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
         hcrd[q] = hd | hh << 8 | hw << 16;
         hdst[q] = hd * BPLANE + hh * BROW + hw;          // BF16: element index in copy 0
     }
-    if (BF16) {                                          // pad elements (row tails, plane gaps) are read against zero weights
-        for (int e = tid; e < NHB_DW; e += 256) halo[e] = 0.f;
+    if (B16L) {                                          // pad elements (row tails, plane gaps) are read against zero weights
+        for (int e = tid; e < NIMG * NHB_DW; e += 256) halo[e] = 0.f;
         __syncthreads();
     }
     auto min_i = [](int x_, int y_) { return x_ < y_ ? x_ : y_; };
@@ -235,7 +268,22 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
 #pragma unroll
         for (int q = 0; q < HVN; ++q) {
             const int e = tid + q * 256;
-            if (BF16) {
+            if (SPLIT) {
+                if (e < NHALO) {
+                    float ph, pm, pl;
+                    split3(hv[q], ph, pm, pl);
+                    const unsigned short p16[3] = {(unsigned short)(__builtin_bit_cast(unsigned, ph) >> 16),
+                                                   (unsigned short)(__builtin_bit_cast(unsigned, pm) >> 16),
+                                                   (unsigned short)(__builtin_bit_cast(unsigned, pl) >> 16)};
+#pragma unroll
+                    for (int im = 0; im < 3; ++im) {
+                        unsigned short* dst = reinterpret_cast<unsigned short*>(halo) + im * (2 * NHB_DW) + hdst[q];
+                        dst[0] = p16[im];
+                        dst[BCOPY + 1] = p16[im];
+                    }
+                    if (KEEP32) halo32[e] = hv[q];
+                }
+            } else if (BF16) {
                 if (e < NHALO) {
                     const unsigned short h16 = (unsigned short)(tmf_pack_bf16(hv[q], 0.f) & 0xFFFFu);
                     unsigned short* dst = reinterpret_cast<unsigned short*>(halo) + hdst[q];
@@ -254,28 +302,40 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
         // ---- z = conv(x) for BOTH M-tiles of this wave, interleaved (two independent MFMA chains) ----
         //      A[i = voxel][k = tap], voxel i = lane & 31 in fragment-row order
         f32x16 zt[NTI];
-        constexpr bool LAZY = BF16 && MODE == MODE_WGRAD;      // 128-register budget: one M-tile's z at a time
+        constexpr bool LAZY = (BF16 && MODE == MODE_WGRAD) || (SPLIT && ((TMF_C1X_LAZY >> MODE) & 1));   // register budget: one M-tile's z at a time
         const int i = l31;
         // BF16: A[i = voxel][k]: per MFMA four dwords = the lane half's tap pair of four tap rows (rows >= 9 repeat row 8
         // against zero weights); the lane's byte address is loop-invariant up to the M-tile origin
         const unsigned lane_b = hb_base + 2u * (unsigned)(((i >> 3) & 1) * BPLANE + (2 * ((i >> 2) & 1) + ((i >> 1) & 1)) * BROW +
                                                         2 * ((i >> 4) & 1) + 2 * (i & 1) + (i & 1) * BCOPY + 2 * hsel);
-        auto load_rows = [&](int ti, unsigned (&pr)[9]) {
+        auto load_rows = [&](int ti, unsigned (&pr)[9], int img = 0) {
             const int mt = wave * NTI + ti;
-            const unsigned tb = lane_b + 2u * (unsigned)((2 * (mt >> 2)) * BPLANE + 4 * ((mt >> 1) & 1) * BROW + 4 * (mt & 1));
+            const unsigned tb = lane_b + 2u * (unsigned)((2 * (mt >> 2)) * BPLANE + 4 * ((mt >> 1) & 1) * BROW + 4 * (mt & 1)) +
+                                (unsigned)(img * NHB_DW * 4);
 #pragma unroll
             for (int r = 0; r < 9; ++r)
                 pr[r] = *reinterpret_cast<const __attribute__((address_space(3))) unsigned*>((size_t)(tb + 2u * (unsigned)brow_off(r)));
         };
-        auto mma = [&](int ti, int m, const unsigned (&pr)[9]) {
+        auto mma = [&](int ti, int m, const unsigned (&pr)[9], int wpart = 0) {
             const u32x4 av = {pr[4 * m < 9 ? 4 * m : 8], pr[4 * m + 1 < 9 ? 4 * m + 1 : 8],
                               pr[4 * m + 2 < 9 ? 4 * m + 2 : 8], pr[4 * m + 3 < 9 ? 4 * m + 3 : 8]};
-            zt[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tmf_bf16x8, av), bwb[m], zt[ti], 0, 0, 0);
+            zt[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tmf_bf16x8, av), bwb[wpart < NIMG ? wpart : 0][m], zt[ti], 0, 0, 0);
         };
         auto conv_one = [&](int ti) {
             unsigned pr[9];
 #pragma unroll
             for (int r = 0; r < 16; ++r) zt[ti][r] = 0.f;
+            if (SPLIT) {                                    // (the order of the interleaved form below: bit-identical z)
+#pragma unroll
+                for (int img = 2; img >= 0; --img) {
+                    load_rows(ti, pr, img);
+#pragma unroll
+                    for (int wp = 2 - img; wp >= 0; --wp)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m) mma(ti, m, pr, wp);
+                }
+                return;
+            }
             load_rows(ti, pr);
 #pragma unroll
             for (int m = 0; m < 3; ++m) mma(ti, m, pr);
@@ -290,7 +350,21 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
 #pragma unroll
                 for (int r = 0; r < 16; ++r) zt[ti][r] = 0.f;
             }
-            if (BF16) {
+            if (SPLIT) {
+                // image l, then m, then h — the products in ascending size: wh xl | wm xm, wh xm | wl xh, wm xh, wh xh
+#pragma unroll
+                for (int img = 2; img >= 0; --img) {
+                    unsigned pr[NTI][9];
+#pragma unroll
+                    for (int ti = 0; ti < NTI; ++ti) load_rows(ti, pr[ti], img);
+#pragma unroll
+                    for (int wp = 2 - img; wp >= 0; --wp)
+#pragma unroll
+                        for (int m = 0; m < 3; ++m)
+#pragma unroll
+                            for (int ti = 0; ti < NTI; ++ti) mma(ti, m, pr[ti], wp);
+                }
+            } else if (BF16) {
                 unsigned pr[NTI][9];
 #pragma unroll
                 for (int ti = 0; ti < NTI; ++ti) load_rows(ti, pr[ti]);
@@ -377,9 +451,22 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
                         int arg = 7;
 #pragma unroll
                         for (int k = 6; k >= 0; --k) arg = (y[k] == ymax) ? k : arg;
-                        const int vx = org + hsel * 2 * HW + ((arg >> 2) & 1) * HH * HW + ((arg >> 1) & 1) * HW + 2 * q + (arg & 1);
+                        if (BF16) {
+                            // the bf16 halo (copy 0: element index = hd * BPLANE + hh * BROW + hw): the inputs as the MFMAs of z saw them
+                            const int hd = 2 * (mt >> 2) + ((arg >> 2) & 1), hh = 4 * ((mt >> 1) & 1) + 2 * hsel + ((arg >> 1) & 1);
+                            const unsigned short* hb = reinterpret_cast<const unsigned short*>(halo) + hd * BPLANE + hh * BROW +
+                                                       4 * (mt & 1) + 2 * q + (arg & 1);
 #pragma unroll
-                        for (int t = 0; t < 27; ++t) dacc[t] = fmaf(halo[vx + tapoff(t)], gl, dacc[t]);
+                            for (int t = 0; t < 27; ++t) {
+                                const float xv = __builtin_bit_cast(float, (unsigned int)hb[(t / 9) * BPLANE + ((t / 3) % 3) * BROW + t % 3] << 16);
+                                dacc[t] = fmaf(xv, gl, dacc[t]);
+                            }
+                        } else {
+                        const int vx = org + hsel * 2 * HW + ((arg >> 2) & 1) * HH * HW + ((arg >> 1) & 1) * HW + 2 * q + (arg & 1);
+                        const float* h32 = KEEP32 ? halo32 : halo;
+#pragma unroll
+                        for (int t = 0; t < 27; ++t) dacc[t] = fmaf(h32[vx + tapoff(t)], gl, dacc[t]);
+                        }
                     }
                 } else {
                     int arg = 7;
@@ -420,7 +507,7 @@ __global__ __launch_bounds__(256, MODE == 3 ? 4 : 2) void conv1_fused_kernel(Arg
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        accw = __builtin_amdgcn_mfma_f32_32x32x2f32(halo[a_row + row_off(r)], z[r], accw, 0, 0, 0);
+                        accw = __builtin_amdgcn_mfma_f32_32x32x2f32((KEEP32 ? halo32 : halo)[a_row + row_off(r)], z[r], accw, 0, 0, 0);
                 }
             }
         }
@@ -518,7 +605,21 @@ Args base_args(const float* x, const float* w, int D, int H, int W, int C, const
     return a;
 }
 
+int g_c1_split = -1;
+// tmf_set_option("c1_split", 0 | 1) / TMF_C1_SPLIT (default 1): the fp32 passes compute z as exact 3-way bf16 splits (SPLIT above)
+int c1_split_mode() {
+    if (const int o = tmf_algo_override()) return (o & TMF_SNET_ALGO_C1_SPLIT) ? 1 : 0;
+    if (g_c1_split < 0) {
+        const char* e = getenv("TMF_C1_SPLIT");
+        g_c1_split = (e && atoi(e) == 0) ? 0 : 1;
+    }
+    return g_c1_split;
+}
+
 }  // namespace
+
+int tmf_c1_split_set(int v) { g_c1_split = v ? 1 : 0; return TMF_OK; }
+extern "C" int tmf_c1_split_mode(void) { return c1_split_mode(); }
 
 extern "C" int tmf_c1_blocks(int B, int D, int H, int W, int C) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
@@ -534,6 +635,7 @@ static int c1_stats(bool bf16, const float* x, const float* w, float* stat_parti
     Args a = base_args(x, w, D, H, W, C, p, 0.f);
     a.partial = stat_partial;
     if (bf16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_STATS, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else if (c1_split_mode()) hipLaunchKernelGGL((conv1_fused_kernel<MODE_STATS, false, false, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     else      hipLaunchKernelGGL((conv1_fused_kernel<MODE_STATS, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_c1_stats");
 }
@@ -558,6 +660,7 @@ static int c1_bn_pool_fwd(bool bf16, bool p16, const float* x, const float* w, c
     TMF_REQUIRE(bf16 || !p16, TMF_E_ARG, "tmf_c1_bn_pool_fwd: bf16 tensors only with the bf16 kernels");
     if (bf16 && p16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, true, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     else if (bf16)   hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else if (c1_split_mode()) hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, false, false, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     else             hipLaunchKernelGGL((conv1_fused_kernel<MODE_FWD, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_c1_bn_pool_fwd");
 }
@@ -584,6 +687,7 @@ static int c1_bwd_reduce(bool bf16, bool p16, const float* x, const float* w, co
     TMF_REQUIRE(bf16 || !p16, TMF_E_ARG, "tmf_c1_bwd_reduce: bf16 tensors only with the bf16 kernels");
     if (bf16 && p16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, true, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     else if (bf16)   hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
+    else if (c1_split_mode()) hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, false, false, true>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     else             hipLaunchKernelGGL((conv1_fused_kernel<MODE_REDUCE, false>), dim3(p.nblk, p.nby), dim3(256), 0, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_c1_bwd_reduce");
 }
@@ -625,6 +729,7 @@ static int c1_bwd_wgrad(bool bf16, bool p16, const float* x, const float* w, con
     TMF_REQUIRE(bf16 || !p16, TMF_E_ARG, "tmf_c1_bwd_wgrad: bf16 tensors only with the bf16 kernels");
     if (bf16 && p16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, true, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
     else if (bf16)   hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    else if (c1_split_mode()) hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, false, false, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
     else             hipLaunchKernelGGL((conv1_fused_kernel<MODE_WGRAD, false>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
     if ((rc = tmf_launch_result("tmf_c1_bwd_wgrad"))) return rc;
     const long n = 27L * C;
@@ -652,16 +757,16 @@ extern "C" int tmf_c1_bwd_wgrad_bf16(const float* x, const float* w, const float
 // workspace: [nblk][2][C] sums | [nblk][27][C] D slabs | their reduction scratch | [27][C] reduced D
 int tmf_c1_bwd_fused_finish(const float* part, int nblk, const float* dred, const float* w, const void* gram, const float* scale,
                             const float* mean, const float* invstd, double count, float* dgamma, float* dbeta, float* dw, int C,
-                            int dw_ref, void* stream);
+                            int dw_ref, int round16, void* stream);
 extern "C" size_t tmf_c1_bwd_fused_workspace_bytes(int B, int D, int H, int W, int C) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
     const Plan p = make_plan(B, D, H, W, C, SLAB_BLOCKS);
     return ((size_t)p.nblk * 2 * C + (size_t)(p.nblk + tmf_reduce_groups(p.nblk) + 1) * 27 * C) * 4;
 }
-extern "C" int tmf_c1_bwd_fused(const float* x, const float* w, const float* scale, const float* shift, const float* mean,
-                                const float* invstd, const float* dpool, const void* gram, float* dw, float* dgamma, float* dbeta,
-                                void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, float slope,
-                                int dw_layout, void* stream) {
+static int c1_bwd_fused(bool bf16, bool p16, const float* x, const float* w, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, const void* dpool, const void* gram, float* dw, float* dgamma, float* dbeta,
+                        void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, float slope,
+                        int dw_layout, void* stream) {
     TMF_REQUIRE(dw_layout == TMF_DW_TAPMAJOR || dw_layout == TMF_DW_REFERENCE, TMF_E_ARG, "tmf_c1_bwd_fused: unknown dw_layout %d", dw_layout);
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(scale); TMF_REQUIRE_PTR(shift); TMF_REQUIRE_PTR(mean); TMF_REQUIRE_PTR(invstd);
     TMF_REQUIRE_PTR(dpool); TMF_REQUIRE_PTR(gram); TMF_REQUIRE_PTR(dw); TMF_REQUIRE_PTR(workspace);
@@ -680,9 +785,29 @@ extern "C" int tmf_c1_bwd_fused(const float* x, const float* w, const float* sca
     float* dred = scratch + (size_t)tmf_reduce_groups(p.nblk) * n;
     a.partial = part; a.partial2 = slabs;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((conv1_fused_kernel<MODE_RD, false>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    TMF_REQUIRE(bf16 || !p16, TMF_E_ARG, "tmf_c1_bwd_fused: bf16 tensors only with the bf16 kernels");
+    if (bf16 && p16) hipLaunchKernelGGL((conv1_fused_kernel<MODE_RD, true, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    else if (bf16)   hipLaunchKernelGGL((conv1_fused_kernel<MODE_RD, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    else if (c1_split_mode()) hipLaunchKernelGGL((conv1_fused_kernel<MODE_RD, false, false, true>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
+    else             hipLaunchKernelGGL((conv1_fused_kernel<MODE_RD, false>), dim3(p.nblk, p.nby), dim3(256), 0, s, a);
     if ((rc = tmf_launch_result("tmf_c1_bwd_fused"))) return rc;
     if ((rc = tmf_reduce_slabs(slabs, p.nblk, n, scratch, dred, s, "tmf_c1_bwd_fused(reduce)"))) return rc;
     return tmf_c1_bwd_fused_finish(part, p.nblk, dred, w, gram, scale, mean, invstd, (double)B * D * H * W, dgamma, dbeta, dw, C,
-                                   dw_layout == TMF_DW_REFERENCE ? 1 : 0, stream);
+                                   dw_layout == TMF_DW_REFERENCE ? 1 : 0, bf16 ? 1 : 0, stream);
+}
+extern "C" int tmf_c1_bwd_fused(const float* x, const float* w, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, const float* dpool, const void* gram, float* dw, float* dgamma, float* dbeta,
+                                void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, float slope,
+                                int dw_layout, void* stream) {
+    return c1_bwd_fused(false, false, x, w, scale, shift, mean, invstd, dpool, gram, dw, dgamma, dbeta, workspace, workspace_bytes,
+                        B, D, H, W, C, slope, dw_layout, stream);
+}
+// the bf16 mode's form (gram from tmf_c1_stats_g_bf16): z and D from the volume and the taps rounded to bf16, dy unrounded — the
+// weight gradient is that of the bf16 forward WITHOUT the second rounding of dz that tmf_c1_bwd_wgrad_bf16's product performs
+extern "C" int tmf_c1_bwd_fused_bf16(const float* x, const float* w, const float* scale, const float* shift, const float* mean,
+                                     const float* invstd, const void* dpool, const void* gram, float* dw, float* dgamma, float* dbeta,
+                                     void* workspace, size_t workspace_bytes, int B, int D, int H, int W, int C, float slope,
+                                     int pooled_bf16, int dw_layout, void* stream) {
+    return c1_bwd_fused(true, pooled_bf16 != 0, x, w, scale, shift, mean, invstd, dpool, gram, dw, dgamma, dbeta, workspace,
+                        workspace_bytes, B, D, H, W, C, slope, dw_layout, stream);
 }

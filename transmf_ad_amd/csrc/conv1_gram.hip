@@ -32,9 +32,12 @@ __host__ __device__ constexpr int kidx(int dd, int dh, int dw) {
 static_assert(kidx(2, 2, 2) == 62, "63 offsets");
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+// the bf16 mode (conv1_fused_kernel<.., true>) multiplies the volume and the taps ROUNDED to bf16 (round-to-nearest-even): the same
+// rounding here makes G, S_t and the forms in them the exact statistics of what that kernel computes
+__device__ __forceinline__ float rbf16(float v) { return __builtin_bit_cast(float, tmf_pack_bf16(v, 0.f) << 16); }
 
 __global__ __launch_bounds__(GTHR) void c1_gram_kernel(const float* __restrict__ x, double* __restrict__ part,
-                                                        int D, int H, int W, int tilesD, int tilesH, int tilesW, int ntiles) {
+                                                        int D, int H, int W, int tilesD, int tilesH, int tilesW, int ntiles, int round16) {
     // the tile as DOUBLES (converted once where it is written: one conversion per voxel instead of one per use), 34 KB;
     // the reduction scratch of the epilogue shares the allocation
     constexpr int NT = GP_D * GP_H * GP_W, NS = NT > 8 * GTHR ? NT : 8 * GTHR;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(GTHR) void c1_gram_kernel(const float* __restrict__
             const int gd = d0 + (pe[j] >> 16), gh = h0 + ((pe[j] >> 8) & 255), gw = w0 + (pe[j] & 255);
             float v = 0.f;
             if (pe[j] >= 0 && gd < D && gh >= 0 && gh < H && gw >= 0 && gw < W) v = xb[((size_t)gd * H + gh) * W + gw];
-            pre[j] = v;
+            pre[j] = round16 ? rbf16(v) : v;
         }
     };
     if ((int)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -154,7 +157,8 @@ __host__ __device__ constexpr int class_tap(int cls, int j) {
     return ax == 0 ? fixed * 9 + a * 3 + b : (ax == 1 ? a * 9 + fixed * 3 + b : a * 9 + b * 3 + fixed);
 }
 
-__global__ __launch_bounds__(HTHR) void c1_shell_gram_kernel(const float* __restrict__ x, double* __restrict__ part, int B, int D, int H, int W) {
+__global__ __launch_bounds__(HTHR) void c1_shell_gram_kernel(const float* __restrict__ x, double* __restrict__ part, int B, int D, int H, int W,
+                                                              int round16) {
     __shared__ double xs[HNB * 9];                              // (converted once where it is written)
     __shared__ int vbase[HNB], vcrd[HNB];                      // per voxel of the batch: sample offset, packed (vd + 1, vh + 1, vw + 1) or -1
     __shared__ double red[3 * 81];
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(HTHR) void c1_shell_gram_kernel(const float* __rest
                 const int ud = (c & 1023) + cdd[k], uh = ((c >> 10) & 1023) + cdh[k], uw = (c >> 20) + cdw[k];
                 if (ud >= 0 && ud < D && uh >= 0 && uh < H && uw >= 0 && uw < W) v = x[(size_t)vbase[cv_[k]] + ((size_t)ud * H + uh) * W + uw];
             }
-            xs[tid + k * HTHR] = (double)v;
+            xs[tid + k * HTHR] = (double)(round16 ? rbf16(v) : v);
         }
         __syncthreads();
         if (slice < 3) {                                           // (the threads of column j = 0 also sum their tap: E_i)
@@ -224,7 +228,7 @@ __global__ __launch_bounds__(HTHR) void c1_shell_gram_kernel(const float* __rest
 // G, S_t, S -> gram[0 .. 756]; statistic rows 0 / 1 of stat_partial (high / low halves) from them
 __global__ __launch_bounds__(1024) void c1_gram2_finish_kernel(const float* __restrict__ w, const double* __restrict__ rpart, int ngram,
                                                                 const double* __restrict__ hpart, int nh, double* __restrict__ gram,
-                                                                float* __restrict__ out, int C) {
+                                                                float* __restrict__ out, int C, int round16) {
     __shared__ double ra[16 * NACC];
     __shared__ double R[NACC];
     __shared__ double Hc[6 * HPART];
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(1024) void c1_gram2_finish_kernel(const float* __re
         for (int i = rg; i < ngram; i += 16) s += rpart[(size_t)i * NACC + k];
         ra[rg * NACC + k] = s;
     }
-    for (int e = tid; e < 27 * C; e += 1024) wsh[e] = w[e];
+    for (int e = tid; e < 27 * C; e += 1024) wsh[e] = round16 ? rbf16(w[e]) : w[e];
     for (int e = tid; e < 6 * HPART; e += 1024) {                    // class cls, number k: fixed-order sum over the class's workgroups
         const int cls = e / HPART, k = e - cls * HPART;
         double s0 = 0.0, s1_ = 0.0, s2_ = 0.0, s3 = 0.0;
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(1024) void c1_bwd_fused_finish_kernel(const float* 
                                                                     const float* __restrict__ scale, const float* __restrict__ mean,
                                                                     const float* __restrict__ invstd, double count,
                                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                    float* __restrict__ dw, int C, int dw_ref) {
+                                                                    float* __restrict__ dw, int C, int dw_ref, int round16) {
     __shared__ double pa[16 * 2 * GMAXC];
     __shared__ double c01[2 * GMAXC];
     __shared__ float wsh[27 * GMAXC];
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(1024) void c1_bwd_fused_finish_kernel(const float* 
         for (int i = rg; i < nblk; i += 16) s += (double)part[(size_t)i * 2 * C + j];
         pa[e] = s;
     }
-    for (int e = tid; e < 27 * C; e += 1024) wsh[e] = w[e];
+    for (int e = tid; e < 27 * C; e += 1024) wsh[e] = round16 ? rbf16(w[e]) : w[e];
     __syncthreads();
     for (int j = tid; j < 2 * C; j += 1024) {
         double s = 0.0;
@@ -347,17 +351,17 @@ __global__ __launch_bounds__(1024) void c1_bwd_fused_finish_kernel(const float* 
 
 int g_c1_gram = -1;
 int c1_gram_mode() {
-    if (const int o = tmf_algo_override()) return (o & TMF_SNET_ALGO_C1_GRAM) ? 1 : 0;
+    if (const int o = tmf_algo_override()) return (o & TMF_SNET_ALGO_C1_GRAM) ? ((o & TMF_SNET_ALGO_C1_GRAM_BF16) ? 2 : 1) : 0;
     if (g_c1_gram < 0) {
         const char* e = getenv("TMF_C1_GRAM");
-        g_c1_gram = (e && atoi(e) == 0) ? 0 : 1;
+        g_c1_gram = e ? (atoi(e) <= 0 ? 0 : atoi(e) >= 2 ? 2 : 1) : 1;
     }
     return g_c1_gram;
 }
 
 }  // namespace
 
-int tmf_c1_gram_set(int v) { g_c1_gram = v ? 1 : 0; return TMF_OK; }
+int tmf_c1_gram_set(int v) { g_c1_gram = v <= 0 ? 0 : (v >= 2 ? 2 : 1); return TMF_OK; }
 int tmf_c1_gram_mode(void) { return c1_gram_mode(); }
 
 // ---- the statistics + Gram data of the forward, and the one-pass backward (fp32; conv1_fused.hip launches the MODE_RD kernel) ----
@@ -368,11 +372,16 @@ extern "C" size_t tmf_c1_gram_bytes(int B, int D, int H, int W, int C) {
     if ((long)B * tmf_cdiv(D, GT_D) * tmf_cdiv(H, GT_H) * tmf_cdiv(W, GT_W) >= (1L << 31)) return 0;
     return ((size_t)NGRAM + (size_t)GWG * NACC + (size_t)6 * HWG * HPART) * 8;
 }
+// the bf16 mode takes this path only under "c1_gram" 2 (measured, round 6: its recomputing passes run two bf16 MFMAs per 32 voxels
+// and are bound by the pooled tensors they read and write — the fp64 pair sums cost more than the statistics pass they replace)
+extern "C" size_t tmf_c1_gram_bytes_bf16(int B, int D, int H, int W, int C) {
+    return c1_gram_mode() == 2 ? tmf_c1_gram_bytes(B, D, H, W, C) : 0;
+}
 
-extern "C" int tmf_c1_stats_g(const float* x, const float* w, float* stat_partial, void* gram, size_t gram_bytes,
-                              int B, int D, int H, int W, int C, void* stream) {
+static int c1_stats_g(int round16, const float* x, const float* w, float* stat_partial, void* gram, size_t gram_bytes,
+                      int B, int D, int H, int W, int C, void* stream) {
     TMF_REQUIRE_PTR(x); TMF_REQUIRE_PTR(w); TMF_REQUIRE_PTR(stat_partial); TMF_REQUIRE_PTR(gram);
-    const size_t need = tmf_c1_gram_bytes(B, D, H, W, C);
+    const size_t need = tmf_c1_gram_bytes(B, D, H, W, C);       // (a direct call in the bf16 mode needs "c1_gram" >= 1 only)
     TMF_REQUIRE(need > 0, TMF_E_SHAPE, "tmf_c1_stats_g: not available for this shape / option (tmf_c1_gram_bytes() = 0)");
     TMF_REQUIRE(gram_bytes >= need, TMF_E_WORKSPACE, "tmf_c1_stats_g: gram buffer %zu B < required %zu B", gram_bytes, need);
     TMF_REQUIRE((long)B * D * H * W < (1L << 31) && D < 1022 && H < 1022 && W < 1022, TMF_E_SHAPE,
@@ -385,17 +394,26 @@ extern "C" int tmf_c1_stats_g(const float* x, const float* w, float* stat_partia
     double* rpart = g + NGRAM;
     double* hpart = rpart + (size_t)GWG * NACC;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(c1_gram_kernel, dim3(ngram), dim3(GTHR), 0, s, x, rpart, D, H, W, tilesD, tilesH, tilesW, (int)ntiles);
-    hipLaunchKernelGGL(c1_shell_gram_kernel, dim3(HWG, 6), dim3(HTHR), 0, s, x, hpart, B, D, H, W);
+    hipLaunchKernelGGL(c1_gram_kernel, dim3(ngram), dim3(GTHR), 0, s, x, rpart, D, H, W, tilesD, tilesH, tilesW, (int)ntiles, round16);
+    hipLaunchKernelGGL(c1_shell_gram_kernel, dim3(HWG, 6), dim3(HTHR), 0, s, x, hpart, B, D, H, W, round16);
     hipLaunchKernelGGL(c1_gram2_finish_kernel, dim3(1), dim3(1024), 0, s, w, (const double*)rpart, ngram, (const double*)hpart, HWG, g,
-                       stat_partial, C);
+                       stat_partial, C, round16);
     return tmf_launch_result("tmf_c1_stats_g");
+}
+extern "C" int tmf_c1_stats_g(const float* x, const float* w, float* stat_partial, void* gram, size_t gram_bytes,
+                              int B, int D, int H, int W, int C, void* stream) {
+    return c1_stats_g(0, x, w, stat_partial, gram, gram_bytes, B, D, H, W, C, stream);
+}
+// the bf16 mode's form: the volume and the taps rounded to bf16 first, as conv1_fused_kernel<.., true> multiplies them
+extern "C" int tmf_c1_stats_g_bf16(const float* x, const float* w, float* stat_partial, void* gram, size_t gram_bytes,
+                                   int B, int D, int H, int W, int C, void* stream) {
+    return c1_stats_g(1, x, w, stat_partial, gram, gram_bytes, B, D, H, W, C, stream);
 }
 
 int tmf_c1_bwd_fused_finish(const float* part, int nblk, const float* dred, const float* w, const void* gram, const float* scale,
                             const float* mean, const float* invstd, double count, float* dgamma, float* dbeta, float* dw, int C,
-                            int dw_ref, void* stream) {
+                            int dw_ref, int round16, void* stream) {
     hipLaunchKernelGGL(c1_bwd_fused_finish_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, nblk, dred, w, (const double*)gram,
-                       scale, mean, invstd, count, dgamma, dbeta, dw, C, dw_ref);
+                       scale, mean, invstd, count, dgamma, dbeta, dw, C, dw_ref, round16);
     return tmf_launch_result("tmf_c1_bwd_fused(finish)");
 }

@@ -1647,7 +1647,8 @@ void tmf_algo_override_set(int flags) { t_algo_override = (flags & TMF_SNET_ALGO
 int tmf_c1_gram_mode(void);      // conv1_gram.hip
 extern "C" int tmf_snet_algo_flags(void) {
     return TMF_SNET_ALGO | TMF_SNET_ALGO_WINO(tmf_conv_wino_mode()) | (tmf_wino_p_mode() ? TMF_SNET_ALGO_WINO_P : 0) |
-           (tmf_wino_x_mode() ? TMF_SNET_ALGO_WINO_X : 0) | (tmf_c1_gram_mode() ? TMF_SNET_ALGO_C1_GRAM : 0);
+           (tmf_wino_x_mode() ? TMF_SNET_ALGO_WINO_X : 0) | (tmf_c1_gram_mode() ? TMF_SNET_ALGO_C1_GRAM : 0) |
+           (tmf_c1_gram_mode() == 2 ? TMF_SNET_ALGO_C1_GRAM_BF16 : 0) | (tmf_c1_split_mode() ? TMF_SNET_ALGO_C1_SPLIT : 0);
 }
 
 extern "C" int tmf_set_option(const char* name, int value) {
@@ -1666,6 +1667,7 @@ extern "C" int tmf_set_option(const char* name, int value) {
     if (strcmp(name, "wino_p") == 0) return tmf_wino_p_set(value);
     if (strcmp(name, "wino_x") == 0) return tmf_wino_x_set(value);
     if (strcmp(name, "c1_gram") == 0) return tmf_c1_gram_set(value);
+    if (strcmp(name, "c1_split") == 0) return tmf_c1_split_set(value);
     if (strcmp(name, "conv_wino") == 0) {
         TMF_REQUIRE(value >= 0 && value <= 3, TMF_E_ARG, "tmf_set_option: conv_wino must be 0, 1, 2 or 3, got %d", value);
         return tmf_conv_wino_set(value);

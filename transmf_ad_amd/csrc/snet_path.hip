@@ -105,8 +105,9 @@ Plan make_plan(const tmf_snet_desc& d) {
             nblk = tmf_c1_blocks(d.B, L.D, L.H, L.W, L.cout);
             nb2 = nblk;
             ws = tmf_c1_bwd_wgrad_workspace_bytes(d.B, L.D, L.H, L.W, L.cout);
-            // fp32: pair-sum statistics + the tap Gram matrix of the volume, kept for the one-pass backward (conv1_gram.hip)
-            p.c1gram_bytes = d.precision == TMF_PREC_FP32 ? tmf_c1_gram_bytes(d.B, L.D, L.H, L.W, L.cout) : 0;
+            // fp32 and bf16: pair-sum statistics + the tap Gram matrix of the volume, kept for the one-pass backward (conv1_gram.hip)
+            p.c1gram_bytes = d.precision == TMF_PREC_FP32 ? tmf_c1_gram_bytes(d.B, L.D, L.H, L.W, L.cout)
+                             : b16 ? tmf_c1_gram_bytes_bf16(d.B, L.D, L.H, L.W, L.cout) : 0;   // (bf16: under "c1_gram" 2 only)
             if (p.c1gram_bytes) {
                 const size_t wf_ = tmf_c1_bwd_fused_workspace_bytes(d.B, L.D, L.H, L.W, L.cout);
                 if (wf_ > ws) ws = wf_;
@@ -207,9 +208,12 @@ extern "C" int tmf_snet_train_fwd(const tmf_snet_desc* d, const float* vol, cons
             // fused first block: the conv output is never stored (csrc/conv1_fused.hip)
             TMF_TRY(tmf_pack_conv_weights(prm->weight[l], (float*)wf, nullptr, L.cout, 1, 27, stream));
             nblk = tmf_c1_blocks(d->B, L.D, L.H, L.W, L.cout);
-            // fp32: pair sums + the tap Gram matrix; the fp32x and bf16 modes keep their recomputing passes
+            // fp32, bf16: pair sums + the tap Gram matrix (bf16: of the rounded volume); fp32x keeps its recomputing passes
             if (p.c1gram_bytes) {
-                TMF_TRY(tmf_c1_stats_g(vol, (const float*)wf, part, base + p.off_c1gram, p.c1gram_bytes, d->B, L.D, L.H, L.W, L.cout, stream));
+                if (b16) TMF_TRY(tmf_c1_stats_g_bf16(vol, (const float*)wf, part, base + p.off_c1gram, p.c1gram_bytes, d->B, L.D, L.H, L.W,
+                                                     L.cout, stream));
+                else     TMF_TRY(tmf_c1_stats_g(vol, (const float*)wf, part, base + p.off_c1gram, p.c1gram_bytes, d->B, L.D, L.H, L.W, L.cout,
+                                                stream));
                 nblk = 2;
             } else if (b16) TMF_TRY(tmf_c1_stats_bf16(vol, (const float*)wf, part, d->B, L.D, L.H, L.W, L.cout, stream));
             else     TMF_TRY(tmf_c1_stats(vol, (const float*)wf, part, d->B, L.D, L.H, L.W, L.cout, stream));
@@ -381,9 +385,12 @@ extern "C" int tmf_snet_train_bwd(const tmf_snet_desc* d, const float* vol, cons
         if ((size_t)L.oD * L.oH * L.oW == 0) continue;
         if (l == 0 && p.c1gram_bytes && g->dweight[l] != nullptr) {
             // one pass over the volume: BatchNorm sums and D = x (*) dy together; dw from the forward's Gram data (conv1_gram.hip)
-            TMF_TRY(tmf_c1_bwd_fused(vol, (const float*)wf, v.scale, v.shift, v.mean, v.invstd, (const float*)go, base + p.off_c1gram,
-                                     g->dweight[l], g->dgamma[l], g->dbeta[l], ws, p.ws_bytes, d->B, L.D, L.H, L.W, L.cout, d->slope[l],
-                                     TMF_DW_REFERENCE, stream));
+            if (b16) TMF_TRY(tmf_c1_bwd_fused_bf16(vol, (const float*)wf, v.scale, v.shift, v.mean, v.invstd, go, base + p.off_c1gram,
+                                                   g->dweight[l], g->dgamma[l], g->dbeta[l], ws, p.ws_bytes, d->B, L.D, L.H, L.W, L.cout,
+                                                   d->slope[l], L.o16 ? 1 : 0, TMF_DW_REFERENCE, stream));
+            else     TMF_TRY(tmf_c1_bwd_fused(vol, (const float*)wf, v.scale, v.shift, v.mean, v.invstd, (const float*)go,
+                                              base + p.off_c1gram, g->dweight[l], g->dgamma[l], g->dbeta[l], ws, p.ws_bytes, d->B, L.D,
+                                              L.H, L.W, L.cout, d->slope[l], TMF_DW_REFERENCE, stream));
             break;
         }
         if (l == 0) {

@@ -88,6 +88,7 @@ extern int tmf_g_wgrad_tr;       // conv3d_bf16.hip: bf16 weight-gradient kernel
 int tmf_conv3d_fwd_mode(const float* x, const float* w, float* z, float* stat_partial, int B, int D, int H, int W, int cin,
                         int cout, int ksize, int rt_min, void* stream);
 int tmf_conv3d_stat_blocks_mode(int B, int D, int H, int W, int cin, int cout, int ksize, int rt_min);
+int tmf_c1_split_set(int v);     // conv1_fused.hip: tmf_set_option("c1_split", 0 | 1): z of the first block (fp32) as exact 3-way bf16 splits
 int tmf_c1_gram_set(int v);      // conv1_gram.hip: tmf_set_option("c1_gram", 0 | 1): the first block through the tap Gram matrix of its input
 int tmf_wino_p_set(int v);       // conv3d_wino.hip: tmf_set_option("wino_p", 0 | 1): two-waves-per-SIMD / persistent one-wave-per-SIMD forward kernel
 // per-call algorithm choice (tmf_snet_desc.flags & TMF_SNET_ALGO): the whole-encoder entries set it for the calling thread while they

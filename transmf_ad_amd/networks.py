@@ -81,7 +81,7 @@ class sNet(nn.Module):
 
     def set_algorithm(self, **algo):
         """Kernels of THIS encoder's fp32 convolutions in its whole-pass calls (tmf_snet_desc.flags, TMF_SNET_ALGO): conv_wino 0..3,
-        wino_p, wino_x, c1_gram 0 | 1 — independent of tmf_set_option and of any other module; no arguments: the process options."""
+        wino_p, wino_x 0 | 1, c1_gram 0 | 1 | 2 (2: in the bf16 mode as well) — independent of tmf_set_option and of any other module; no arguments: the process options."""
         ops.snet_algo_flags(algo)            # (validates)
         self.tmf_algo = dict(algo) or None
         return self

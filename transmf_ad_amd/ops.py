@@ -469,10 +469,10 @@ class Conv1BnPool(torch.autograd.Function):
         if training:
             nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
             part = torch.empty((nblk, 2, C), device=dev, dtype=_f32)
-            gbytes = _lib.query("tmf_c1_gram_bytes", B, D, H, W, C) if mode == "fp32" else 0
+            gbytes = _lib.query("tmf_c1_gram_bytes" + sfx, B, D, H, W, C) if mode in ("fp32", "bf16") else 0   # (bf16: "c1_gram" 2 only)
             if gbytes:                 # pair sums + the tap Gram matrix of the volume: backward then needs one pass
-                gram = torch.empty(gbytes // 8, device=dev, dtype=torch.float64)
-                _lib.call("tmf_c1_stats_g", x.data_ptr(), wp.data_ptr(), part.data_ptr(), gram.data_ptr(), gbytes, B, D, H, W, C, s)
+                gram = torch.empty(gbytes // 8, device=dev, dtype=torch.float64)   # (bf16: of the volume rounded to bf16)
+                _lib.call("tmf_c1_stats_g" + sfx, x.data_ptr(), wp.data_ptr(), part.data_ptr(), gram.data_ptr(), gbytes, B, D, H, W, C, s)
                 rows = 2
             else:                      # the recomputing pass (bf16: its own; fp32x keeps it: DESIGN 3.16)
                 _lib.call("tmf_c1_stats" + sfx, x.data_ptr(), wp.data_ptr(), part.data_ptr(), B, D, H, W, C, s)
@@ -516,9 +516,9 @@ class Conv1BnPool(torch.autograd.Function):
             dweight = torch.empty((C, 1, 3, 3, 3), device=dev, dtype=_f32)
             dgamma = torch.empty(C, device=dev, dtype=_f32)
             dbeta = torch.empty(C, device=dev, dtype=_f32)
-            _lib.call("tmf_c1_bwd_fused", x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
+            _lib.call("tmf_c1_bwd_fused" + sfx, x.data_ptr(), wp.data_ptr(), scale.data_ptr(), shift.data_ptr(), mean.data_ptr(),
                       invstd.data_ptr(), dout.data_ptr(), ctx.gram.data_ptr(), dweight.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                      ws.data_ptr(), nbytes, B, D, H, W, C, slope, _lib.DW_REFERENCE, s)
+                      ws.data_ptr(), nbytes, B, D, H, W, C, slope, *p16, _lib.DW_REFERENCE, s)
             dbias = torch.zeros(C, device=dev, dtype=_f32) if has_bias else None
             return (None, dweight, dbias, dgamma, dbeta, None, None, None, None, None, None, None, None)
         nblk = _lib.query("tmf_c1_blocks", B, D, H, W, C)
@@ -668,20 +668,22 @@ def _publish_flat_grads(flat, param_ptrs, views, segments) -> None:
 def snet_algo_flags(algo=None) -> int:
     """The algorithm word of a tmf_snet_desc (include/tmf_hip.h: TMF_SNET_ALGO | ...).  algo None: the process options of the
     moment (tmf_set_option / TMF_* environment), pinned for the call — a backward then runs the plan its forward laid out whatever
-    happens to the options in between; a dict {conv_wino: 0..3, wino_p: 0|1, wino_x: 0|1, c1_gram: 0|1} (missing keys: the process
+    happens to the options in between; a dict {conv_wino: 0..3, wino_p: 0|1, wino_x: 0|1, c1_gram: 0|1|2, c1_split: 0|1} (missing keys: the process
     option) is ONE module's own choice (sNet.set_algorithm): two models with different settings live side by side."""
     f = _lib.query("tmf_snet_algo_flags")
     if algo:
-        bad = set(algo) - {"conv_wino", "wino_p", "wino_x", "c1_gram"}
+        bad = set(algo) - {"conv_wino", "wino_p", "wino_x", "c1_gram", "c1_split"}
         if bad:
             raise ValueError(f"unknown algorithm option(s) {sorted(bad)}")
         if "conv_wino" in algo:
             if algo["conv_wino"] not in (0, 1, 2, 3):
                 raise ValueError("conv_wino must be 0, 1, 2 or 3")
             f = (f & ~(3 << 9)) | (int(algo["conv_wino"]) << 9)
-        for key, bit in (("wino_p", 0x800), ("wino_x", 0x1000), ("c1_gram", 0x2000)):
+        for key, bit in (("wino_p", 0x800), ("wino_x", 0x1000), ("c1_gram", 0x2000), ("c1_split", 0x8000)):
             if key in algo:
                 f = (f | bit) if algo[key] else (f & ~bit)
+        if "c1_gram" in algo:                            # 2: the bf16 mode's first block through the Gram matrix as well
+            f = (f | 0x4000) if algo["c1_gram"] == 2 else (f & ~0x4000)
     return f
 
 
