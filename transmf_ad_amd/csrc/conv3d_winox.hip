@@ -37,6 +37,9 @@
 #ifndef X_PF                // weights requested this many positions ahead (1 | 2)
 #define X_PF 2
 #endif
+#ifndef X_NGFAST
+#define X_NGFAST 1
+#endif
 #ifndef X_SKEW              // 1: the waves 4-7 meet the barriers half a phase later than the waves 0-3 (measured level: off)
 #define X_SKEW 0
 #endif
@@ -181,8 +184,16 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
     if (my_items == 0) return;
     for (int i = tid; i < my_items; i += XN) {
         const int item = item0 + jb + i * G;
+#if X_NGFAST
+        // the channel group is the FAST index: the groups of one brick are neighbouring items, i.e. workgroups of one XCD at about the
+        // same time (jb above), and share the brick's halo through that XCD's L2 instead of fetching it again a whole pass later
+        const int ngroups = Cout >> 5;
+        int t = item / ngroups;
+        const int ng = item - t * ngroups;
+#else
         const int ng = item / nbricks;
         int t = item - ng * nbricks;
+#endif
         const int bw = t % tilesW; t /= tilesW;
         const int bh = t % tilesH; t /= tilesH;
         const int bd = t % tilesD;
