@@ -33,6 +33,9 @@ constexpr int HD = TD + 2, HH = TH + 2, HW = TW + 2;
 constexpr int NHALO = HD * HH * HW;
 
 enum { MODE_STATS = 0, MODE_FWD = 1, MODE_REDUCE = 2, MODE_WGRAD = 3, MODE_RD = 4 };
+#ifndef TMF_C1X_ABL
+#define TMF_C1X_ABL 0              // timing ablations of the SPLIT forward (wrong results): 1 = no stores, 2 = no MFMAs
+#endif
 #ifndef TMF_C1X_LAZY
 #define TMF_C1X_LAZY 0x12          // bit MODE: the SPLIT form of that pass computes one M-tile's z at a time — the one-pass backward
                                    // needs it to stay below 256 registers (226), the forward drops to 128 (4 waves per SIMD:
@@ -48,9 +51,11 @@ enum { MODE_STATS = 0, MODE_FWD = 1, MODE_REDUCE = 2, MODE_WGRAD = 3, MODE_RD = 
 // were bound by the LDS port (PMC: half of all LDS cycles bank conflicts; no gather at all: 99 -> 37 us, stats, 128^3).
 // Pitches (dwords) are chosen so that the five lane bits of a fragment row land on five different address bits:
 //   w0 -> copy offset + 1 = 2 (mod 32), w1 -> 1, h0 -> 8, h1 -> 16, d0 -> 100 = 4 (mod 32): conflict-free ds_read_b32.
-constexpr int BROW = 16, BPLANE = 200, BCOPY = 2 * 609;         // elements: row, plane, copy pitch (609 = 19 * 32 + 1 dwords)
-constexpr int NHB_DW = 2 * 609;                                 // dwords of LDS for both copies (copy 1 ends at 609 + 600 + 1)
-static_assert(HD * BPLANE / 2 + 1 <= 609 && HH * BROW <= BPLANE && HW + 2 <= BROW, "bf16 halo layout");
+constexpr int BROW = 16, BPLANE = 200;                          // elements: row, plane
+constexpr int BCP_DW = (HD * BPLANE / 2 + 1 + 31) / 32 * 32 + 1;    // copy pitch in dwords: = 1 (mod 32); TD = 4: 609 = 19 * 32 + 1
+constexpr int BCOPY = 2 * BCP_DW;                               // ... in elements
+constexpr int NHB_DW = 2 * BCP_DW;                              // dwords of LDS for both copies (copy 1 ends at 609 + 600 + 1)
+static_assert(HD * BPLANE / 2 + 1 <= BCP_DW && HH * BROW <= BPLANE && HW + 2 <= BROW, "bf16 halo layout");
 __device__ __forceinline__ constexpr int brow_off(int r) { return (r / 3) * BPLANE + (r % 3) * BROW; }   // tap row r = 3 dz + dy
 
 __device__ __forceinline__ constexpr int tapoff(int tap) {
@@ -319,7 +324,12 @@ __global__ __launch_bounds__(256, MODE == 3 && !SPLIT ? 4 : 2) void conv1_fused_
         auto mma = [&](int ti, int m, const unsigned (&pr)[9], int wpart = 0) {
             const u32x4 av = {pr[4 * m < 9 ? 4 * m : 8], pr[4 * m + 1 < 9 ? 4 * m + 1 : 8],
                               pr[4 * m + 2 < 9 ? 4 * m + 2 : 8], pr[4 * m + 3 < 9 ? 4 * m + 3 : 8]};
+#if TMF_C1X_ABL & 2
+            asm volatile("" :: "v"(av));
+            zt[ti][m] += __builtin_bit_cast(float, av[0]);
+#else
             zt[ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(tmf_bf16x8, av), bwb[wpart < NIMG ? wpart : 0][m], zt[ti], 0, 0, 0);
+#endif
         };
         auto conv_one = [&](int ti) {
             unsigned pr[9];
@@ -429,7 +439,8 @@ __global__ __launch_bounds__(256, MODE == 3 && !SPLIT ? 4 : 2) void conv1_fused_
                 const float lrm = ymax > 0.f ? 1.f : a.slope;
                 if (MODE == MODE_FWD) {
                     const float best = ymax * lrm;
-                    if (win_u) {
+                    if ((TMF_C1X_ABL & 1) && best == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, best), pr, pv, psoff, 0);
+                    if (win_u && !(TMF_C1X_ABL & 1)) {
                         if (P16) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(tmf_pack_bf16(best, 0.f) & 0xFFFFu), pr, pv, psoff, 0);
                         else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, best), pr, pv, psoff, 0);
                     }
