@@ -98,7 +98,16 @@ def wino_exec_flops(kind, B, D, H, W, ci, co):
     return base, "fp32"
 
 
-def exec_flops_per_pair(size, wino, B, dim=128, streams=2):
+# the first block's z as exact bf16 splits: K = 27 taps padded to 48, six partial products per fp32 product
+C1_SPLIT_FLOP_RATIO = 6.0 * 48.0 / 27.0
+
+
+def c1_split_on():
+    from transmf_ad_amd import _lib
+    return bool(_lib.query("tmf_c1_split_mode"))
+
+
+def exec_flops_per_pair(size, wino, B, dim=128, streams=2, c1_split=False):
     """EXECUTED matrix flops fwd+bwd per pair at batch B, per pipe -> {"fp32": .., "bf16": ..}: the algorithmic count of
     conv_flops_per_pair with the Cin > 1 3x3x3 layers priced by wino_exec_flops where the step runs them in the Winograd form
     (wino: 0 never, 1 data gradients, 2 + forward, 3 + weight gradients) — the numerators of the whole step's `mfma_frac`."""
@@ -109,6 +118,9 @@ def exec_flops_per_pair(size, wino, B, dim=128, streams=2):
     for i, (ci, co, k, lvl) in enumerate(layers):
         D, H, W = (e >> lvl for e in dims)
         f = 2.0 * ci * co * k ** 3 * D * H * W
+        if i == 0 and c1_split:              # csrc/conv1_fused.hip SPLIT: 18 bf16 MFMAs of K = 16 per 32 voxels x 32 channels,
+            tot["bf16"] += 2 * f * C1_SPLIT_FLOP_RATIO     # two evaluations of z per step (forward, one-pass backward)
+            continue
         if i == 0 or k == 1:
             tot["fp32"] += f * (2 if i == 0 else 3)
             continue
@@ -250,9 +262,13 @@ def measure_conv_launches(ops, _lib, dev, B, vol, precision, storage, reps=10):
         y.backward(go)
     ms = _time_launches(first_block, reps)
     vox = B * D * H * W
-    rows.append(dict(layer="conv1.0", **{"pass": "fwd+bwd (4 recompute passes)"},
-                     kernel="conv1_fused_kernel<0..3>" + (" bf16" if b16 else ""), ms=ms, flops=2 * 2.0 * 27 * q * vox,
-                     exec_flops=2 * 2.0 * 27 * q * vox, pipe="bf16" if b16 else "fp32", bytes=float(2 * vox * 4 + 2 * (vox // 8) * q * el)))
+    # (fp32: Gram statistics, forward and the one-pass backward = two evaluations of z; "c1_split": on the bf16 pipe, 6 x 48 / 27 of
+    # the algorithmic products.  The kernel label keeps its historic spelling: roofline_report excludes the block by it.)
+    c1x = precision == "fp32" and c1_split_on()
+    rows.append(dict(layer="conv1.0", **{"pass": "fwd+bwd (Gram statistics + 2 recomputing passes)" if not b16 else "fwd+bwd (4 recompute passes)"},
+                     kernel="conv1_fused_kernel<0..3>" + (" bf16" if b16 else " split" if c1x else ""), ms=ms, flops=2 * 2.0 * 27 * q * vox,
+                     exec_flops=2 * 2.0 * 27 * q * vox * (C1_SPLIT_FLOP_RATIO if c1x else 1.0), pipe="bf16" if (b16 or c1x) else "fp32",
+                     bytes=float(2 * vox * 4 + 2 * (vox // 8) * q * el)))
     return rows
 
 
@@ -763,7 +779,8 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
     by_pair = conv_bytes_per_pair(vol, 2 if args.storage == "bf16" else 4) * half
     # executed matrix flops per pair: the Winograd layers at 64 products per tile in the fp32 mode; the bf16 / fp32x modes run the
     # direct form (fp32x: six bf16 partial products per fp32 product, priced as ONE fp32 product each — see peak_note)
-    ex_pair = exec_flops_per_pair(vol, args.conv_wino if args.precision == "fp32" else 0, B)
+    ex_pair = exec_flops_per_pair(vol, args.conv_wino if args.precision == "fp32" else 0, B,
+                                  c1_split=args.precision in ("fp32", "fp32x") and c1_split_on())
     ex_pair = {("bf16" if args.precision == "bf16" and k == "fp32" else k): v * half for k, v in ex_pair.items()}
     if rank == 0 and not args.eval:
         if brief and not getattr(args, "also_kernel_roofline", False):
@@ -875,7 +892,9 @@ def run(args, rank, local, world, dev, cpu_cache, brief=False):
                                              "operand split EXACTLY into three bf16 numbers (six partial products, fp32 accumulation; the "
                                              "dropped three are below 2^-24 of the product) — csrc/conv3d_winox.hip; "
                                              if _lib.query("tmf_wino_x_mode") else "forward / data gradients on the fp32 matrix pipe; ")
-                                          + "direct implicit GEMM for the first block and the 1x1x1 block",
+                                          + ("the first block's z from exact 3-way bf16 splits of the volume and the taps on the bf16 pipe "
+                                             "(csrc/conv1_fused.hip SPLIT), " if c1_split_on() else "direct implicit GEMM for the first block, ")
+                                          + "direct implicit GEMM for the 1x1x1 block",
                                        2: "fp32: Winograd F(2x2x2,3x3x3) on the fp32 matrix pipe for forward and data gradients of the "
                                           "Cin>1 3x3x3 blocks (exact-fp32 arithmetic, 64/216 of the products), direct implicit GEMM for "
                                           "the weight gradients, the first block and the 1x1x1 block",
