@@ -528,7 +528,7 @@ int    tmf_snet_eval_fwd(const tmf_snet_desc* d, const float* vol, const tmf_sne
 #define TMF_FUSION_MAX_DEPTH 16
 /* flags: TMF_FUSION_PER_OP = enqueue one launch per Linear / attention / LayerNorm (token_gemm.hip, attention.hip,
  * token_ops.hip: 7 forward + 13 backward launches per instance) even where the fused per-instance kernels of
- * csrc/xformer_fused.hip apply (dim 128, 4 heads of 32, mlp 512, N <= 512: 1 forward + 2 backward launches per instance,
+ * csrc/xformer_fused.hip apply (dim 128, 4 heads of 32 or — round 6 — 8 heads of 16, mlp 512, N <= 512: 1 forward + 2 backward launches per instance,
  * all weight gradients in one launch at the end).  Forward and backward of one pass must see the same desc. */
 #define TMF_FUSION_PER_OP 1
 typedef struct tmf_fusion_desc { int B, N, dim, heads, dim_head, mlp, depth, flags; } tmf_fusion_desc;
@@ -551,6 +551,7 @@ typedef struct tmf_xformer_grads {
  * (shader clock) to fwd / bwd_q / bwd_kv, each [workgroups][4][16] uint64.  NULL (the default) turns it off. */
 void   tmf_debug_xf_trace(void* fwd, void* bwd_q, void* bwd_kv);
 size_t tmf_fusion_saved_bytes(const tmf_fusion_desc* d);
+int    tmf_fusion_uses_fused(const tmf_fusion_desc* d);     /* 1: this descriptor's calls run the fused per-instance kernels */
 size_t tmf_fusion_bwd_scratch_bytes(const tmf_fusion_desc* d);
 int    tmf_fusion_train_fwd(const tmf_fusion_desc* d, const float* mri_tok, const float* pet_tok,
                             const tmf_xformer_params* inst, void* saved, size_t saved_bytes, float* cls, void* stream);

@@ -49,6 +49,8 @@ CASES = {
     # Dropout ACTIVE in the fusion block (options/option.py:39 --dropout; networks.py:131,133,153): the reference is built with
     # dropout=0.3 and every Transformer Dropout module is forced to the regenerable masks of oracle/params.make_fusion_masks
     "ad_mid_drop": ("model_ad", dict(dim=128, depth=3, heads=4, dim_head=32, mlp_dim=512), (48, 48, 48), 2, True, "blobs", 0.3),
+    # the head geometry of the reference's OTHER entry script (train_adversarial.py:30-31: heads=8, dim_head=dim // 8)
+    "ad_mid_h8": ("model_ad", dict(dim=128, depth=3, heads=8, dim_head=16, mlp_dim=512), (48, 48, 48), 2, True, "blobs"),
     "cnn_tiny":   ("model_CNN_ad", dict(dim=32), (32, 32, 32), 2, True),
     "cnn_mid":    ("model_CNN_ad", dict(dim=128), (48, 40, 48), 2, True),
     "single_mid": ("model_single", dict(dim=128), (48, 48, 48), 3, True),

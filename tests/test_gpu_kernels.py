@@ -938,19 +938,23 @@ def _fusion64(fz, mri, pet):
     return torch.cat([mri.mean(dim=1), pet.mean(dim=1), mri.max(dim=1).values, pet.max(dim=1).values], dim=1)
 
 
+@pytest.mark.parametrize("heads", [4, 8], ids=["4x32", "8x16"])
 @pytest.mark.parametrize("B,N,depth,drop", [(2, 27, 2, False), (3, 216, 3, False), (2, 150, 1, True), (1, 512, 1, False),
                                             (2, 16, 1, False), (8, 216, 3, True), (2, 5, 2, True)])
-def test_fused_fusion_kernels_match_fp64_formula(B, N, depth, drop):
+def test_fused_fusion_kernels_match_fp64_formula(B, N, depth, drop, heads):
     """The whole fusion block on the fused per-instance kernels (csrc/xformer_fused.hip: 1 forward + 2 backward launches
     per Transformer instance, all weight gradients in one launch) against an fp64 evaluation of the reference formula
     (networks.py:114-175, 215-230, 272-281): cls, the gradients of both token tensors and of every parameter; ragged
     token counts (partial 16-row tiles), one to 32 key tiles, and — `drop` — fixed Dropout keep-masks at the three
-    Dropout sites of every instance.  Also against the one-launch-per-Linear path of the same entry point (1e-5)."""
+    Dropout sites of every instance.  Also against the one-launch-per-Linear path of the same entry point (1e-5).  Both head
+    geometries of the reference's scripts: 4 heads of 32 (kfold_train_adversarial.py:78-79) and — round 6, the H2 instances of the
+    fused kernels — 8 heads of 16 (train_adversarial.py:30-31)."""
     import copy
     ops = _ops()
     from transmf_ad_amd import networks
     torch.manual_seed(7)
-    fz = networks.CrossTransformer_MOD_AVG(128, depth, 4, 32, 512, 0.).to(DEV).train()
+    fz = networks.CrossTransformer_MOD_AVG(128, depth, heads, 128 // heads, 512, 0.).to(DEV).train()
+    assert ops.fusion_fused_supported(N, 128, heads, 128 // heads, 512)
     with torch.no_grad():
         for p in fz.parameters():
             p.add_(torch.randn_like(p) * 0.05)
@@ -994,14 +998,15 @@ def test_fused_fusion_kernels_match_fp64_formula(B, N, depth, drop):
             assert _relerr(a, b) < 1e-5, (name, _relerr(a, b))
 
 
-def test_fused_fusion_kernels_are_deterministic_and_leave_no_trace():
+@pytest.mark.parametrize("heads", [4, 8], ids=["4x32", "8x16"])
+def test_fused_fusion_kernels_are_deterministic_and_leave_no_trace(heads):
     """Two passes over the same inputs are bitwise equal (no atomics, fixed summation orders), also when the saved /
     scratch workspaces start out filled with NaN (nothing uninitialised is read: padded token rows, transposed-copy
     padding)."""
     ops = _ops()
     from transmf_ad_amd import networks
     torch.manual_seed(9)
-    fz = networks.CrossTransformer_MOD_AVG(128, 2, 4, 32, 512, 0.).to(DEV).train()
+    fz = networks.CrossTransformer_MOD_AVG(128, 2, heads, 128 // heads, 512, 0.).to(DEV).train()
     m0, p0 = _rand(3, 27, 128, seed=211).to(DEV), _rand(3, 27, 128, seed=212).to(DEV)
     go = _rand(3, 512, seed=213).to(DEV)
     outs = []

@@ -100,7 +100,7 @@ def step(net, g: Golden, train=True):
 
 
 CASES = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid", "ad_full_b2", "ad_full_b2_blobs",
-         "ad_adni_b2", "ad_mid_drop", "cnn_full_b2", "single_full_b2", "cnn_full_b16", "single_full_b16"]
+         "ad_adni_b2", "ad_mid_drop", "ad_mid_h8", "cnn_full_b2", "single_full_b2", "cnn_full_b16", "single_full_b16"]
 # Logit tolerance per fixture.  Default: the north-star gate.  The structured-volume fixtures (oracle/params.
 # make_inputs_blobs: per-sample blobs, so the pooled features of the two samples differ by O(0.1) and the train-mode
 # BatchNorm1d heads are well conditioned) are held 5x tighter: they are the full-size B=2 cases the gate really
@@ -797,13 +797,22 @@ def test_one_call_fusion_matches_instance_by_instance(name):
         assert err <= 1e-5, (k, err)
 
 
-def test_one_call_fusion_is_taken_by_default():
+@pytest.mark.parametrize("name", ["ad_mid", "ad_mid_h8"])
+def test_one_call_fusion_is_taken_by_default(name):
+    """... with the FUSED per-instance kernels, for both head geometries of the reference's scripts: 4 heads of 32
+    (kfold_train_adversarial.py:78-79) and 8 heads of 16 (train_adversarial.py:30-31; `ad_mid_h8`, round 6)."""
     import transmf_ad_amd as T
-    g = Golden("ad_mid")
+    from transmf_ad_amd import ops
+    g = Golden(name)
     net = build(g).train()
     mri, pet, _y = (torch.from_numpy(a).to(DEV) for a in g.inputs())
     cls, _dm, _dp = net.forward_features(mri, pet)
     assert type(cls.grad_fn).__name__.startswith("FusionTrain"), cls.grad_fn
+    kw = g.kw
+    assert ops.fusion_fused_supported(27, kw["dim"], kw["heads"], kw["dim_head"], kw["mlp_dim"])
+    import ctypes
+    from transmf_ad_amd import _lib
+    assert _lib.query("tmf_fusion_uses_fused", ctypes.byref(cls.grad_fn.desc)) == 1     # the fused kernels took it
 
 
 def _bf16_mode_errors(mode, B=4, size=(48, 48, 48), c1_gram=1):

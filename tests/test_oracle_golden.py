@@ -6,7 +6,7 @@ import torch
 
 from _golden import Golden, available, gprobe, probe, run_oracle, zero_grad_keys
 
-FAST = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid", "ad_mid_drop"]
+FAST = ["ad_tiny", "ad_ragged", "cnn_tiny", "single_mid", "cnn_mid", "ad_mid", "ad_mid_drop", "ad_mid_h8"]
 SLOW = ["ad_full_b2", "ad_full_b2_blobs", "ad_adni_b2", "cnn_full_b2", "single_full_b2", "cnn_full_b16", "single_full_b16"]
 
 

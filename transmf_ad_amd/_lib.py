@@ -173,6 +173,7 @@ class XformerGrads(C.Structure):
 PROTOTYPES.update({
     "tmf_debug_xf_trace": (None, [_p, _p, _p]),
     "tmf_fusion_saved_bytes": (_z, [C.POINTER(FusionDesc)]),
+    "tmf_fusion_uses_fused": (_i, [C.POINTER(FusionDesc)]),
     "tmf_fusion_bwd_scratch_bytes": (_z, [C.POINTER(FusionDesc)]),
     "tmf_fusion_train_fwd": (_i, [C.POINTER(FusionDesc), _p, _p, C.POINTER(XformerParams), _p, _z, _p, _p]),
     "tmf_fusion_train_bwd": (_i, [C.POINTER(FusionDesc), _p, _p, C.POINTER(XformerParams), _p, _z, _p,

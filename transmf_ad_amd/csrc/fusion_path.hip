@@ -32,8 +32,8 @@ int tmf_xf_part_stride(void);
 int tmf_xf_pack_floats(void);
 int tmf_xf_pack_kv_offset(void);
 int tmf_xf_launch_pack(int n_inst, const tmf_xformer_params* inst, float* const* pk_fwd, float* const* pk_bwd, hipStream_t s);
-int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fwd_io* io, float scale, int only_kv, hipStream_t s);
-int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bwd_io* io, float scale, hipStream_t s);
+int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fwd_io* io, float scale, int only_kv, int h2, hipStream_t s);
+int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bwd_io* io, float scale, int h2, hipStream_t s);
 int tmf_xf_launch_colsum(int n_inst, const float* const* part, float* const* small, float* const* lnf, int nblk, hipStream_t s);
 
 namespace {
@@ -145,6 +145,12 @@ extern "C" size_t tmf_fusion_saved_bytes(const tmf_fusion_desc* d) {
     return make_plan(*d).saved_bytes;
 }
 
+// 1: the calls of this descriptor run the fused per-instance kernels (csrc/xformer_fused.hip); 0: one launch per op
+extern "C" int tmf_fusion_uses_fused(const tmf_fusion_desc* d) {
+    if (check_desc("tmf_fusion_uses_fused", d) != TMF_OK) return 0;
+    return make_plan(*d).fused ? 1 : 0;
+}
+
 extern "C" size_t tmf_fusion_bwd_scratch_bytes(const tmf_fusion_desc* d) {
     if (check_desc("tmf_fusion_bwd_scratch_bytes", d) != TMF_OK) return 0;
     return make_plan(*d).scratch_bytes;
@@ -197,7 +203,7 @@ extern "C" int tmf_fusion_train_fwd(const tmf_fusion_desc* d, const float* mri_t
     const float* q = pet_tok;
     for (int i = 0; i < 2 * d->depth; ++i)
         TMF_REQUIRE(p.fused || (!inst[i].mask_o && !inst[i].mask_g && !inst[i].mask_f), TMF_E_SHAPE,
-                    "tmf_fusion_train_fwd: Dropout masks need the fused kernels (dim 128, 4 heads of 32, mlp 512, N <= 512)");
+                    "tmf_fusion_train_fwd: Dropout masks need the fused kernels (dim 128, 4 heads of 32 or 8 of 16, mlp 512, N <= 512)");
     if (p.fused && d->depth > 0) {
         const float scale = 1.0f / sqrtf((float)d->dim_head);
         hipStream_t s = (hipStream_t)stream;
@@ -213,7 +219,7 @@ extern "C" int tmf_fusion_train_fwd(const tmf_fusion_desc* d, const float* mri_t
             tmf_xf_fwd_io io = {};
             io.x = pet_tok; io.pkv_next = F(base, I.pkf) + tmf_xf_pack_kv_offset();
             io.KRn = F(base, I.KR); io.KCn = F(base, I.KC); io.VRn = F(base, I.VR); io.VCn = F(base, I.VC);
-            TMF_TRY(tmf_xf_launch_fwd(d->B, d->N, nullptr, &io, scale, 1, s));
+            TMF_TRY(tmf_xf_launch_fwd(d->B, d->N, nullptr, &io, scale, 1, d->heads == 8, s));
         }
         for (int i = 0; i < n_inst; ++i) {
             char* sv = base + (size_t)i * I.total;
@@ -229,7 +235,7 @@ extern "C" int tmf_fusion_train_fwd(const tmf_fusion_desc* d, const float* mri_t
                 io.pkv_next = F(sn, I.pkf) + tmf_xf_pack_kv_offset();
                 io.KRn = F(sn, I.KR); io.KCn = F(sn, I.KC); io.VRn = F(sn, I.VR); io.VCn = F(sn, I.VC);
             }
-            TMF_TRY(tmf_xf_launch_fwd(d->B, d->N, &inst[i], &io, scale, 0, s));
+            TMF_TRY(tmf_xf_launch_fwd(d->B, d->N, &inst[i], &io, scale, 0, d->heads == 8, s));
             if (i & 1) q = F(sv, I.y); else m = F(sv, I.y);
         }
         return tmf_token_pool_fwd(m, q, cls, (int32_t*)(base + p.off_arg), d->B, d->N, d->dim, stream);
@@ -301,7 +307,7 @@ static int instance_bwd_fused(const tmf_fusion_desc& d, const Plan& p, const tmf
     io.part = F(si, p.s_part);
     io.DR = F(sc, p.s_DR); io.DC = F(sc, p.s_DC); io.delta = F(sc, p.s_delta);
     io.dx = dx_out; io.dctx = dctx_out; io.dctx_acc = dctx_acc;
-    return tmf_xf_launch_bwd(d.B, d.N, &w, &io, 1.0f / sqrtf((float)d.dim_head), (hipStream_t)stream);
+    return tmf_xf_launch_bwd(d.B, d.N, &w, &io, 1.0f / sqrtf((float)d.dim_head), d.heads == 8, (hipStream_t)stream);
 }
 
 extern "C" int tmf_fusion_train_bwd(const tmf_fusion_desc* d, const float* mri_tok, const float* pet_tok,

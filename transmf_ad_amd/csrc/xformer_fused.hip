@@ -266,7 +266,10 @@ __device__ __forceinline__ f32x4 ln_row(const f32x4 v, const float* __restrict__
 // MT: key tiles held in registers (16 MT >= N).  EXACT: the launch has exactly MT key tiles — the attention loops then
 // carry no run-time guards; guarded loops make the compiler drain every outstanding load at each branch join, which
 // turned the operand rings into one L2 round trip per tile (measured: 890 cycles per 16-key tile against 320 of MFMA).
-template <int MT, bool EXACT>
+// H2 (round 6): EIGHT heads of 16 features (train_adversarial.py:30-31) — a wave owns the two heads 2 wave, 2 wave + 1, which are
+// exactly the two 16-feature blocks s = 0, 1 of its 32 features: the fragment panels are the same memory (head' = 2 h + s), only
+// the contractions change (a head's scores sum ONE block, its output is ONE dt tile), lse / delta are [B][8][Npad].
+template <int MT, bool EXACT, bool H2>
 __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                       // input rows
@@ -351,10 +354,12 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
             zero_acc<2>(acc);
             gq.run(acc, As, XP, lane);
             // the attention's first key tiles are requested ahead of this epilogue's stores
+            if constexpr (!H2) {
 #pragma unroll
-            for (int t = 0; t < RD - 1; ++t) {
-                kr[t][0] = kr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (EXACT || t < ntiles) load_k(t < ntiles ? t : 0, kr[t]);
+                for (int t = 0; t < RD - 1; ++t) {
+                    kr[t][0] = kr[t][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (EXACT || t < ntiles) load_k(t < ntiles ? t : 0, kr[t]);
+                }
             }
             const int c0 = 32 * wave + 2 * m;
 #pragma unroll
@@ -367,7 +372,91 @@ __global__ __launch_bounds__(XTHR, 1) void xf_fwd_kernel(const XfFwdArgs p) {
         XF_STAMP(2);
         // ---- P2: attention, head = wave.  S^T[key][query] = K Q^T: a lane holds 4 keys per 16-key tile of ONE query ----
         Gemm<2, 8> go;
-        {
+        if constexpr (H2) {
+            // two heads of 16 features, one after the other (the scores of ONE head's keys in registers at a time)
+            const float c = p.scale * XLOG2E;
+#pragma unroll
+            for (int hs = 0; hs < 2; ++hs) {
+                f32x4 k1[RD], v1[RD];
+                auto load_k1 = [&](int t, f32x4& dst) { dst = ld4(Kb + t * 512 + hs * 256); };
+                auto load_v1 = [&](int t, f32x4& dst) { dst = ld4(Vt + (size_t)(hs * ntiles + t) * 256); };
+#pragma unroll
+                for (int t = 0; t < RD - 1; ++t) {
+                    k1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (EXACT || t < ntiles) load_k1(t < ntiles ? t : 0, k1[t]);
+                }
+                float qreg[4];
+                {
+                    const f32x4 v = ld4(Qs + m * XP + XDH * h + 16 * hs + 4 * kb);
+                    qreg[0] = v[0] * c; qreg[1] = v[1] * c; qreg[2] = v[2] * c; qreg[3] = v[3] * c;
+                }
+                f32x4 sT[MT];
+                float mx = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    if (EXACT || t < ntiles) {
+                        if (t + RD - 1 < MT && (EXACT || t + RD - 1 < ntiles)) {
+                            load_k1(t + RD - 1, k1[(t + RD - 1) % RD]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        const f32x4 k0 = k1[t % RD];
+                        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(k0[j], qreg[j], sc, 0, 0, 0);
+                        sT[t] = sc;
+                    } else {
+                        sT[t] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < RD - 1; ++t) {
+                    v1[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (EXACT || t < ntiles) load_v1(t < ntiles ? t : 0, v1[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = 16 * t + 4 * kb + r;
+                        sT[t][r] = key < N ? sT[t][r] : -INFINITY;
+                        mx = fmaxf(mx, sT[t][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                float l = 0.f;
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = exp2f(sT[t][r] - mx);
+                        sT[t][r] = e;
+                        l += e;
+                    }
+                }
+                l += __shfl_xor(l, 16);
+                l += __shfl_xor(l, 32);
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    if (EXACT || t < ntiles) {
+                        if (t + RD - 1 < MT && (EXACT || t + RD - 1 < ntiles)) {
+                            load_v1(t + RD - 1, v1[(t + RD - 1) % RD]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        const f32x4 v0 = v1[t % RD];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(v0[r], sT[t][r], o, 0, 0, 0);
+                    }
+                }
+                if (hs == 1) go.prime(p.po, wave, lane);
+                const float inv = 1.f / l;
+                const f32x4 w4 = {o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv};
+                const int cc = XDH * h + 16 * hs + 4 * kb;
+                st4(Os + m * XP + cc, w4);
+                if (m < nv) st4(p.out + (row0 + m) * XD + cc, w4);
+                if (kb == 0) p.lse[((size_t)bz * (2 * XH) + 2 * h + hs) * Npad + t0 + m] = m < nv ? mx + log2f(l) : INFINITY;
+            }
+        } else {
             const float c = p.scale * XLOG2E;
             float qreg[2][4];
 #pragma unroll
@@ -619,6 +708,7 @@ struct XfBwdQArgs {
     unsigned long long* trace;
 };
 
+template <bool H2>                      // H2: eight heads of 16 (see xf_fwd_kernel)
 __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* DY = smem;                       // dy
@@ -848,7 +938,7 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
         const int h = wave;
         const float c = p.scale * XLOG2E;
         float qreg[2][4], doreg[2][4];
-        float delta = 0.f;
+        float delta = 0.f, delta_b[2] = {0.f, 0.f};                 // (delta_b / lse_b: per 16-feature block = per head of H2)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int cc = XDH * h + 16 * s + 4 * kb;
@@ -856,18 +946,56 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_q_kernel(const XfBwdQArgs p) {
             const f32x4 ov = o_r[s];
             const f32x4 dv = ld4(DO + m * XP + cc);                 // zero rows past nv
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { qreg[s][j] = qv[j] * c; doreg[s][j] = dv[j]; delta += dv[j] * ov[j]; }
+            for (int j = 0; j < 4; ++j) { qreg[s][j] = qv[j] * c; doreg[s][j] = dv[j]; delta_b[s] += dv[j] * ov[j]; }
         }
-        delta += __shfl_xor(delta, 16);
-        delta += __shfl_xor(delta, 32);
+        float lse_b[2] = {0.f, 0.f};
+        if constexpr (H2) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                delta_b[s] += __shfl_xor(delta_b[s], 16);
+                delta_b[s] += __shfl_xor(delta_b[s], 32);
+                const size_t si = ((size_t)bz * (2 * XH) + 2 * h + s) * Npad + t0 + m;
+                if (kb == 0) p.delta[si] = delta_b[s];
+                lse_b[s] = p.lse[si];
+            }
+        } else {
+            delta = delta_b[0] + delta_b[1];
+            delta += __shfl_xor(delta, 16);
+            delta += __shfl_xor(delta, 32);
+        }
         const size_t sidx = ((size_t)bz * XH + h) * Npad + t0 + m;
-        if (kb == 0) p.delta[sidx] = delta;
-        const float lse2 = p.lse[sidx];                             // +inf past nv: p = 0 there
+        if (!H2 && kb == 0) p.delta[sidx] = delta;
+        const float lse2 = H2 ? 0.f : p.lse[sidx];                  // +inf past nv: p = 0 there
         f32x4 dqT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         auto step = [&](int t, const f32x4 (&cur)[6], f32x4 (&nxt)[6]) {
             load_t(t + 2, nxt);
             __builtin_amdgcn_sched_barrier(0);
             const bool on = t < ntiles;                             // the last group of three may overhang: zero weight
+            if constexpr (H2) {
+                f32x4 sb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dpb[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sb[hs] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[hs][j], qreg[hs][j], sb[hs], 0, 0, 0);
+                        dpb[hs] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[2 + hs][j], doreg[hs][j], dpb[hs], 0, 0, 0);
+                    }
+                f32x4 dsb[2];
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = 16 * t + 4 * kb + r;
+                        const float pr = (on && key < N) ? exp2f(sb[hs][r] - lse_b[hs]) : 0.f;
+                        dsb[hs][r] = pr * (dpb[hs][r] - delta_b[hs]) * p.scale;
+                    }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dqT[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[4][r], dsb[0][r], dqT[0], 0, 0, 0);
+                    dqT[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[5][r], dsb[1][r], dqT[1], 0, 0, 0);
+                }
+                return;
+            }
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -970,6 +1098,7 @@ struct XfBwdKvArgs {
 
 constexpr int XKP = 2 * XD + 4;
 
+template <bool H2>                      // H2: eight heads of 16 (see xf_fwd_kernel)
 __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* DKV = smem;                      // [16][XKP]
@@ -990,18 +1119,21 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
     const float* Db = p.DR + frag_r(bz, h, 0, 0, ntiles) + lane * 4;
     const float* Qt = p.QC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
     const float* Dt = p.DC + frag_c(bz, h, 0, 0, ntiles) + lane * 4;
-    const float* Ls = p.lse + ((size_t)bz * XH + h) * Npad + 4 * kb;
-    const float* Dl = p.delta + ((size_t)bz * XH + h) * Npad + 4 * kb;
-    // operands of query tile t: Q row (2), dO row (2), Q^T columns (2), dO^T columns (2), lse, delta — three buffers in
-    // fixed roles, a tile is requested two tiles before its use (see xf_bwd_q_kernel)
-    f32x4 A0[10], A1[10], A2[10];
-    auto load_t = [&](int t, f32x4 (&d)[10]) {
+    // (H2: the wave's two heads 2 h, 2 h + 1 of eight: rows of lse / delta Npad apart)
+    const float* Ls = p.lse + ((size_t)bz * (H2 ? 2 * XH : XH) + (H2 ? 2 * h : h)) * Npad + 4 * kb;
+    const float* Dl = p.delta + ((size_t)bz * (H2 ? 2 * XH : XH) + (H2 ? 2 * h : h)) * Npad + 4 * kb;
+    // operands of query tile t: Q row (2), dO row (2), Q^T columns (2), dO^T columns (2), lse, delta (H2: of both heads) — three
+    // buffers in fixed roles, a tile is requested two tiles before its use (see xf_bwd_q_kernel)
+    constexpr int NOP = H2 ? 12 : 10;
+    f32x4 A0[NOP], A1[NOP], A2[NOP];
+    auto load_t = [&](int t, f32x4 (&d)[NOP]) {
         t = t < ntiles ? t : ntiles - 1;
         d[0] = ld4(Qb + t * 512); d[1] = ld4(Qb + t * 512 + 256);
         d[2] = ld4(Db + t * 512); d[3] = ld4(Db + t * 512 + 256);
         d[4] = ld4(Qt + t * 256); d[5] = ld4(Qt + (size_t)(ntiles + t) * 256);
         d[6] = ld4(Dt + t * 256); d[7] = ld4(Dt + (size_t)(ntiles + t) * 256);
         d[8] = ld4(Ls + 16 * t); d[9] = ld4(Dl + 16 * t);
+        if constexpr (H2) { d[10] = ld4(Ls + Npad + 16 * t); d[11] = ld4(Dl + Npad + 16 * t); }
     };
     // this lane's key (B operand column j = m): K row scaled, V row
     float kreg[2][4], vreg[2][4];
@@ -1028,10 +1160,33 @@ __global__ __launch_bounds__(XTHR, 1) void xf_bwd_kv_kernel(const XfBwdKvArgs p)
     Gemm<2, 16> gkv;
     {
         f32x4 dkT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, dvT[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        auto step = [&](int t, const f32x4 (&cur)[10], f32x4 (&nxt)[10]) {
+        auto step = [&](int t, const f32x4 (&cur)[NOP], f32x4 (&nxt)[NOP]) {
             load_t(t + 2, nxt);
             __builtin_amdgcn_sched_barrier(0);
             const bool on = t < ntiles;                             // the last group of three may overhang: zero weight
+            if constexpr (H2) {
+#pragma unroll
+                for (int hs = 0; hs < 2; ++hs) {
+                    f32x4 sb = {0.f, 0.f, 0.f, 0.f}, dpb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        sb = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[hs][j], kreg[hs][j], sb, 0, 0, 0);
+                        dpb = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[2 + hs][j], vreg[hs][j], dpb, 0, 0, 0);
+                    }
+                    f32x4 prb, dsb;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        prb[r] = on ? exp2f(sb[r] - cur[hs ? (NOP - 2) : 8][r]) : 0.f;
+                        dsb[r] = prb[r] * (dpb[r] - cur[hs ? (NOP - 1) : 9][r]) * p.scale;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        dvT[hs] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[6 + hs][r], prb[r], dvT[hs], 0, 0, 0);
+                        dkT[hs] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[4 + hs][r], dsb[r], dkT[hs], 0, 0, 0);
+                    }
+                }
+                return;
+            }
             // s[r] = S[query 16 t + 4 kb + r][key m];  dp likewise
             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1177,7 +1332,8 @@ extern "C" void tmf_debug_xf_trace(void* fwd, void* bwd_q, void* bwd_kv) {
 }
 
 bool tmf_xf_supported(int N, int dim, int heads, int dim_head, int mlp) {
-    return dim == XD && heads == XH && dim_head == XDH && mlp == XMLP && N >= 1 && N <= 512;
+    // 4 heads of 32 (kfold_train_adversarial.py:78-79), or 8 heads of 16 (train_adversarial.py:30-31: the H2 instances)
+    return dim == XD && ((heads == XH && dim_head == XDH) || (heads == 2 * XH && dim_head == XDH / 2)) && mlp == XMLP && N >= 1 && N <= 512;
 }
 int tmf_xf_npad(int N) { return (N + XT - 1) / XT * XT; }
 int tmf_xf_tiles(int N) { return (N + XT - 1) / XT; }
@@ -1223,7 +1379,7 @@ struct tmf_xf_fwd_io {
     float *a, *QR, *QC, *out, *lse, *x1, *f, *h, *g, *x2, *y, *m1, *r1, *m2, *r2, *mf, *rf, *KRn, *KCn, *VRn, *VCn;
 };
 
-int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fwd_io* io, float scale, int only_kv,
+int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fwd_io* io, float scale, int only_kv, int h2,
                       hipStream_t s) {
     XfFwdArgs a = {};
     a.x = io->x; a.KR = io->KR; a.VC = io->VC; a.pkv_next = io->pkv_next;
@@ -1245,7 +1401,7 @@ int tmf_xf_launch_fwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_fw
     int rc;
 #define XF_LAUNCH(MT, EX)                                                                     \
     {                                                                                         \
-        auto kf = xf_fwd_kernel<MT, EX>;                                                      \
+        auto kf = h2 ? xf_fwd_kernel<MT, EX, true> : xf_fwd_kernel<MT, EX, false>;            \
         if ((rc = tmf_allow_lds(kf, XF_FWD_LDS, "tmf_fusion_train_fwd(fused)"))) return rc;   \
         hipLaunchKernelGGL(kf, grid, block, XF_FWD_LDS, s, a);                                \
     }
@@ -1267,7 +1423,7 @@ struct tmf_xf_bwd_io {
     const float* dctx_acc;
 };
 
-int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bwd_io* io, float scale, hipStream_t s) {
+int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bwd_io* io, float scale, int h2, hipStream_t s) {
     int rc;
     const int grid = 8 * tmf_xf_tiles(N) * ((B + 7) / 8);
     {
@@ -1283,7 +1439,7 @@ int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bw
         a.dx = io->dx; a.part = io->part; a.stride = tmf_xf_part_stride();
         a.B = B; a.N = N; a.Npad = tmf_xf_npad(N); a.tiles = tmf_xf_tiles(N);
         a.trace = g_xf_trace[1];
-        auto kf = xf_bwd_q_kernel;
+        auto kf = h2 ? xf_bwd_q_kernel<true> : xf_bwd_q_kernel<false>;
         if ((rc = tmf_allow_lds(kf, XF_BWDQ_LDS, "tmf_fusion_train_bwd(fused q)"))) return rc;
         hipLaunchKernelGGL(kf, dim3(grid), dim3(XTHR), XF_BWDQ_LDS, s, a);
         if ((rc = tmf_launch_result("tmf_fusion_train_bwd(fused q)"))) return rc;
@@ -1294,7 +1450,8 @@ int tmf_xf_launch_bwd(int B, int N, const tmf_xformer_params* w, const tmf_xf_bw
         a.bkv = io->pk + XF_BK_KV; a.dctx_acc = io->dctx_acc; a.scale = scale; a.dkv = io->dkv; a.dctx = io->dctx;
         a.B = B; a.N = N; a.Npad = tmf_xf_npad(N); a.tiles = tmf_xf_tiles(N);
         a.trace = g_xf_trace[2];
-        hipLaunchKernelGGL(xf_bwd_kv_kernel, dim3(grid), dim3(XTHR), XF_BWDKV_LDS, s, a);
+        auto kkv = h2 ? xf_bwd_kv_kernel<true> : xf_bwd_kv_kernel<false>;
+        hipLaunchKernelGGL(kkv, dim3(grid), dim3(XTHR), XF_BWDKV_LDS, s, a);
         if ((rc = tmf_launch_result("tmf_fusion_train_bwd(fused kv)"))) return rc;
     }
     return TMF_OK;

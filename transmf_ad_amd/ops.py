@@ -1021,7 +1021,7 @@ FUSION_FUSED_KERNELS = os.environ.get("TMF_FUSION_FUSED", "1") != "0"
 
 def fusion_fused_supported(N, dim, heads, dim_head, mlp):
     """Shapes the fused per-instance kernels take (tmf_xf_supported, csrc/xformer_fused.hip)."""
-    return (FUSION_ONE_CALL and FUSION_FUSED_KERNELS and dim == 128 and heads == 4 and dim_head == 32 and mlp == 512
+    return (FUSION_ONE_CALL and FUSION_FUSED_KERNELS and dim == 128 and (heads, dim_head) in ((4, 32), (8, 16)) and mlp == 512
             and 1 <= N <= 512)
 
 
