@@ -92,7 +92,7 @@ def wino_exec_flops(kind, B, D, H, W, ci, co):
     from transmf_ad_amd import _lib
     if kind == "wgrad":
         return 2.0 * 64 * ci * co * _lib.query("tmf_conv3d_wgrad_wino_tiles", B, D, H, W, ci, co), "fp32"
-    base = 2.0 * 64 * ci * co * 32 * _lib.query("tmf_conv3d_wino_bricks", B, D, H, W)
+    base = 2.0 * 64 * ci * co * 32 * _lib.query("tmf_conv3d_wino_bricks2", B, D, H, W, ci, co)
     if _lib.query("tmf_conv3d_wino_kernel_name2", B, D, H, W, ci, co, 0).startswith(b"conv3d_winox"):
         return 6.0 * base, "bf16"
     return base, "fp32"

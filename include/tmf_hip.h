@@ -145,6 +145,9 @@ int    tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W);       /* rows of
                                                                        * kernel (= compute units; all rows are written), one per
                                                                        * 4x8x8 brick with "wino_p" 0 */
 int    tmf_conv3d_wino_bricks(int B, int D, int H, int W);            /* bricks the forward kernel walks per 32 output channels */
+int    tmf_conv3d_wino_bricks2(int B, int D, int H, int W, int cin, int cout);   /* ... of a launch with these channel counts: where the split
+                                                                         kernel can take it, the one-sample bricks are kept unless the folded
+                                                                         geometry saves more than 15 % of them (round 6) */
 const char* tmf_conv3d_wino_kernel_name(int B, int D, int H, int W, int stats);        /* the instance a kernel trace shows (as */
 const char* tmf_conv3d_wgrad_wino_kernel_name(int B, int D, int H, int W, int cin, int cout);   /* tmf_conv3d_fwd_kernel_name) */
 long   tmf_conv3d_wgrad_wino_tiles(int B, int D, int H, int W, int cin, int cout);     /* 2x2x2 tiles (padded: 16 per stage) the weight-

@@ -349,9 +349,18 @@ def test_split_winograd_kernel_takes_the_launches_it_is_built_for():
     assert name(8, 24, 24, 24, 64, 128, 1) == b"conv3d_winox_kernel<1>"
     assert name(8, 48, 48, 48, 16, 32, 1) == b"conv3d_wino_p_kernel<1, 0>"   # cin % 32
     assert name(8, 12, 12, 12, 128, 256, 1) == b"conv3d_wino_p_kernel<1, 1>"  # four samples x 4x4x4 bricks
+    # the geometry is chosen WITH the channel counts (round 6): 22x27x22 at B = 8 — the reference's 91x109x91 two levels down — is
+    # 576 one-sample bricks against 504 folded ones; the split kernel on 576 beats the fp32 kernel on 504, so it keeps the launch where
+    # it can take it, and only there (the folded geometry must save more than 15 %)
+    assert lib.tmf_conv3d_wino_bricks(8, 22, 27, 22) == 504 and lib.tmf_conv3d_wino_bricks2(8, 22, 27, 22, 64, 128) == 576
+    assert name(8, 22, 27, 22, 64, 128, 1) == b"conv3d_winox_kernel<1>" and name(8, 22, 27, 22, 128, 64, 0) == b"conv3d_winox_kernel<0>"
+    assert lib.tmf_conv3d_wino_bricks2(8, 22, 27, 22, 16, 64) == 504 and name(8, 22, 27, 22, 16, 64, 1) == b"conv3d_wino_p_kernel<1, 1>"
+    assert lib.tmf_conv3d_wino_bricks2(8, 11, 13, 11, 128, 256) == 72 and name(8, 11, 13, 11, 128, 256, 1) == b"conv3d_wino_p_kernel<1, 1>"
+    assert lib.tmf_conv3d_wino_bricks2(8, 48, 48, 48, 32, 64) == lib.tmf_conv3d_wino_bricks(8, 48, 48, 48)
     assert lib.tmf_set_option(b"wino_x", 0) == 0
     try:
         assert lib.tmf_wino_x_mode() == 0 and name(8, 48, 48, 48, 32, 32, 1) == b"conv3d_wino_p_kernel<1, 0>"
+        assert lib.tmf_conv3d_wino_bricks2(8, 22, 27, 22, 64, 128) == 504 and name(8, 22, 27, 22, 64, 128, 1) == b"conv3d_wino_p_kernel<1, 1>"
     finally:
         lib.tmf_set_option(b"wino_x", 1)
     assert name(8, 48, 48, 48, 32, 32, 1) == b"conv3d_winox_kernel<1>"

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "tmf_conv3d_fwd_wino_affine": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _p]),
     "tmf_conv3d_wino_stat_blocks": (_i, [_i, _i, _i, _i]),
     "tmf_conv3d_wino_bricks": (_i, [_i, _i, _i, _i]),
+    "tmf_conv3d_wino_bricks2": (_i, [_i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wino_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i]),
     "tmf_conv3d_wgrad_wino_kernel_name": (C.c_char_p, [_i, _i, _i, _i, _i, _i]),
     "tmf_conv3d_wino_kernel_name2": (C.c_char_p, [_i, _i, _i, _i, _i, _i, _i]),

@@ -1829,6 +1829,16 @@ int wino_p_geom(int B, int D, int H, int W) {
     const long t1 = (long)tmf_cdiv(B, 4) * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 4);
     return (t1 < t0 && (long)D * H * W < (1L << 17)) ? 1 : 0;
 }
+// ... and with the channel counts (round 6): where the split kernel (conv3d_winox.hip: one-sample bricks only, ~1.2 x the fp32
+// kernel per brick) can take the launch, the folded geometry must save more than that to be chosen — 22x27x22 at B = 8 (the
+// reference's 91x109x91 volume two levels down): 576 one-sample bricks against 504 folded ones, and the split kernel on 576 is faster
+int wino_fwd_geom(int B, int D, int H, int W, int cin, int cout) {
+    const int g = wino_p_geom(B, D, H, W);
+    if (g == 0 || !tmf_winox_takes(B, D, H, W, cin, cout, 0)) return g;
+    const long t0 = (long)B * tmf_cdiv(D, 4) * tmf_cdiv(H, 8) * tmf_cdiv(W, 8);
+    const long t1 = (long)tmf_cdiv(B, 4) * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 4);
+    return 100 * t0 <= 115 * t1 ? 0 : 1;
+}
 long wino_p_bricks(int geom, int B, int D, int H, int W) {
     return geom ? (long)tmf_cdiv(B, 4) * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 4)
                 : (long)B * tmf_cdiv(D, 4) * tmf_cdiv(H, 8) * tmf_cdiv(W, 8);
@@ -1871,10 +1881,11 @@ template <int MODE>
 int launch_wino_p(const char* what, const float* x, const float* u, float* z, float* stat_partial, int B, int D, int H, int W,
                   int cin, int cout, const float* scale, const float* shift, float slope, int pool, hipStream_t stream) {
     // train forward / data gradient on the bf16 matrix pipe through exact 3-way splits (conv3d_winox.hip) where it takes the launch
-    if (tmf_winox_takes(B, D, H, W, cin, cout, wino_p_geom(B, D, H, W)))
+    const int geom = wino_fwd_geom(B, D, H, W, cin, cout);
+    if (tmf_winox_takes(B, D, H, W, cin, cout, geom))
         return tmf_winox_launch(what, x, reinterpret_cast<const unsigned short*>(u + (size_t)64 * cin * cout), z, stat_partial, B, D, H, W,
                                 cin, cout, wino_cu_count(), stream, MODE == 2 ? scale : nullptr, MODE == 2 ? shift : nullptr, slope, pool);
-    if (wino_p_geom(B, D, H, W) && (long)4 * D * H * W * (cin > cout ? cin : cout) < (1L << 29)) return launch_wino_p_g<MODE, 1>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
+    if (geom && (long)4 * D * H * W * (cin > cout ? cin : cout) < (1L << 29)) return launch_wino_p_g<MODE, 1>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
     return launch_wino_p_g<MODE, 0>(what, x, u, z, stat_partial, B, D, H, W, cin, cout, scale, shift, slope, pool, stream);
 }
 
@@ -1916,6 +1927,12 @@ extern "C" int tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W) {
     return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
 }
 // bricks (items per group of 32 output channels) of the persistent forward kernel for a volume
+// ... of a launch with these channel counts (the split kernel's eligibility enters the choice of the geometry: wino_fwd_geom)
+extern "C" int tmf_conv3d_wino_bricks2(int B, int D, int H, int W, int cin, int cout) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    if (wino_p_mode()) return (int)wino_p_bricks(wino_fwd_geom(B, D, H, W, cin, cout), B, D, H, W);
+    return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
+}
 extern "C" int tmf_conv3d_wino_bricks(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     if (wino_p_mode()) return (int)wino_p_bricks(wino_p_geom(B, D, H, W), B, D, H, W);
@@ -1925,7 +1942,7 @@ extern "C" int tmf_conv3d_wino_bricks(int B, int D, int H, int W) {
 // the kernel instance tmf_conv3d_fwd_wino (stats: with statistic partials) / tmf_conv3d_wgrad_wino launch for a volume, as a kernel
 // trace prints it (bench.py's roofline rows and tools/pmc_traffic.py's keys)
 extern "C" const char* tmf_conv3d_wino_kernel_name2(int B, int D, int H, int W, int cin, int cout, int stats) {
-    if (wino_p_mode() && B > 0 && D > 0 && H > 0 && W > 0 && tmf_winox_takes(B, D, H, W, cin, cout, wino_p_geom(B, D, H, W)))
+    if (wino_p_mode() && B > 0 && D > 0 && H > 0 && W > 0 && tmf_winox_takes(B, D, H, W, cin, cout, wino_fwd_geom(B, D, H, W, cin, cout)))
         return stats ? "conv3d_winox_kernel<1>" : "conv3d_winox_kernel<0>";
     return tmf_conv3d_wino_kernel_name(B, D, H, W, stats);
 }
