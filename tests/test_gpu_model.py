@@ -440,8 +440,10 @@ def test_full_size_properties_b8_96():
 # within 2^-8 — the |.|-sum per tensor is bounded, element-wise agreement is not expected (measured: 0.28 / 0.18).
 # (logits, D logits, loss, cls / sNet-output probes relative to scale, conv-side |grad| sum, fusion+head |grad| sum)
 CFG3_TOL = {"fp32": dict(logits=2e-4, d=2e-4, loss=2e-4, act=5e-5, gconv=2e-2, gtok=1e-3),
-            "bf16": dict(logits=0.3, d=3e-2, loss=6e-2, act=3e-2, gconv=0.6, gtok=0.35),
-            "bf16s": dict(logits=0.35, d=3e-2, loss=6e-2, act=4e-2, gconv=0.6, gtok=0.5)}
+            # (round 6: 1.5-1.8 x what the round's final code measures — bf16: logits 0.108, D 0.009, loss 0.020, activations 0.008,
+            #  conv |grad| sum 0.32, fusion + heads 0.12; bf16 storage: 0.137, 0.009, 0.022, 0.011, 0.25, 0.23 — instead of 2-4 x)
+            "bf16": dict(logits=0.2, d=2e-2, loss=4e-2, act=1.5e-2, gconv=0.5, gtok=0.2),
+            "bf16s": dict(logits=0.25, d=2e-2, loss=4e-2, act=2e-2, gconv=0.45, gtok=0.4)}
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16", "bf16s"])
