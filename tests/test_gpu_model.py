@@ -767,7 +767,7 @@ def test_one_call_eval_encoder_is_bit_identical_to_block_by_block(name, mode):
     assert toks[0][0].abs().max().item() > 0 and toks[0][0].dtype == torch.float32
 
 
-@pytest.mark.parametrize("name", ["ad_mid", "ad_full_b2_blobs"])
+@pytest.mark.parametrize("name", ["ad_mid", "ad_full_b2_blobs", "ad_mid_h8"])
 def test_one_call_fusion_matches_instance_by_instance(name):
     """tmf_fusion_train_fwd / _bwd (one library call per pass for the whole CrossTransformer_MOD_AVG,
     csrc/fusion_path.hip) against the per-Transformer autograd path: the forward is the same launch sequence (bitwise
