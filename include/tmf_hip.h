@@ -568,7 +568,7 @@ int    tmf_fusion_train_bwd(const tmf_fusion_desc* d, const float* mri_tok, cons
  * `self.D(D_PET_inp)` on the reversed-gradient token means and `self.fc_cls(fused_embeds)` (models/mymodel.py:209-215,
  * 221; modules :190-194) and their backward.  fc_cls = Linear(4*dim, H1)-BatchNorm1d-ReLU-Dropout-Linear(H1, H2)-
  * BatchNorm1d-ReLU-Dropout-Linear(H2, NC);  D = Linear(dim, HD)-BatchNorm1d-ReLU-Linear(HD, NC), applied to the MRI then
- * the PET mean with separate batch statistics (running statistics updated twice, in that order).  B <= 16.
+ * the PET mean with separate batch statistics (running statistics updated twice, in that order).  B <= 32 (round 6; instances holding 16 / 32 batch rows in registers).
  *   cls [B][4*dim]; mri_tok / pet_tok [B][N][dim] (their means over N are D's inputs); mask1 [B][H1], mask2 [B][H2]:
  *   Dropout keep-masks ALREADY scaled by 1 / (1 - p), NULL = no dropout (eval, or p = 0); the random draw stays with the
  *   caller.  training != 0: batch statistics + running update (momentum / eps index 0 = fc_cls.1, 1 = fc_cls.5, 2 = D.1);
@@ -609,7 +609,7 @@ int    tmf_dropout_keep_masks(int nseg, float* const* out, const long* numel, co
  * cat[gap(mri), gap(pet)] and `D` (as in model_ad) on revgrad(gap(mri), 2), revgrad(gap(pet), 2): M = 2, HD = 128;
  * models/mymodel.py:13-41 model_single — `fc` = Linear(dim, H)-ReLU-Linear(H, NC) on avgpool(cnn(img)): M = 1, HD = 0
  * (pet_tok, the D parameters / outputs / gradients are then NULL).  Tokens [B][N][dim] = the encoder output, channels last;
- * gap == mean over N.  B <= 16, dim % 16 == 0, M dim <= 512.  momentum / eps are D's BatchNorm1d's. */
+ * gap == mean over N.  B <= 32, dim % 16 == 0, M dim <= 512.  momentum / eps are D's BatchNorm1d's. */
 typedef struct tmf_heads_cnn_desc { int B, N, dim, M, H, HD, NC, training; float momentum, eps; } tmf_heads_cnn_desc;
 typedef struct tmf_heads_cnn_params {
     const float *fc0_w, *fc0_b, *fc2_w, *fc2_b;              /* [H][M dim], [H], [NC][H], [NC] */

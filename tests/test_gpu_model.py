@@ -916,12 +916,14 @@ def test_bf16_modes_with_the_first_block_through_the_gram_matrix(mode):
     assert e["grad_l2_conv"] <= tol["gconv"] and e["grad_l2_rest"] <= tol["grest"], e
 
 
+@pytest.mark.parametrize("B", [6, 16, 17, 32])
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("name", ["ad_tiny", "ad_mid"])
-def test_one_launch_heads_match_stock_modules(name, train):
+def test_one_launch_heads_match_stock_modules(name, train, B):
     """ops.HeadsAD (fc_cls and both discriminator calls as one kernel per direction, csrc/heads.hip) against the stock
     torch modules it stands in for, on the same inputs: outputs, the gradients of cls / both token tensors / all 16 head
-    parameters, and the BatchNorm1d buffers (D's updated twice)."""
+    parameters, and the BatchNorm1d buffers (D's updated twice).  Batches up to 16 run the instances that hold 16 rows in
+    registers, 17 .. 32 (options/option.py:30 --batch_size is free; round 6) the 32-row ones."""
     import copy
     import transmf_ad_amd as T
     from transmf_ad_amd import revgrad
@@ -929,7 +931,7 @@ def test_one_launch_heads_match_stock_modules(name, train):
     net = build(g).train(train)
     ref = copy.deepcopy(net).train(train)
     dim = g.kw["dim"]
-    B, N = 6, 27
+    N = 27
     gen = torch.Generator(device=DEV).manual_seed(3)
     k1 = (torch.rand((B, 512), device=DEV, generator=gen) > 0.5).float()
     k2 = (torch.rand((B, 64), device=DEV, generator=gen) > 0.5).float()
@@ -975,7 +977,7 @@ def test_one_launch_heads_match_stock_modules(name, train):
 
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("kind,dim,B,N", [("cnn_ad", 128, 16, 216), ("cnn_ad", 32, 3, 8), ("single", 128, 16, 216),
-                                          ("single", 128, 1, 27)])
+                                          ("single", 128, 1, 27), ("cnn_ad", 128, 32, 27), ("single", 128, 24, 64)])
 def test_one_launch_cnn_heads_match_stock_modules(kind, dim, B, N, train):
     """ops.HeadsCNN (csrc/heads.hip: the heads of model_CNN_ad / model_single as one kernel per direction) against the
     stock torch modules it stands in for, on the same token tensors: outputs, token gradients, every head parameter's

@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int HT = 512;          // threads
-constexpr int MAXB = 16;
+constexpr int MAXB = 32;          // batch rows the kernels hold in registers: instances MB = 16 (B <= 16) and MB = 32
 constexpr int ND = 4;            // workgroups of the discriminator's backward (j-ranges of D.0)
 
 struct HeadsArgs {
@@ -61,17 +61,18 @@ __host__ __device__ inline SavedPlan saved_plan(int B, int dim, int H1, int H2, 
 }
 
 // BatchNorm1d of one feature over the batch held in acc[0..B): returns xhat in place, writes y = gamma*xhat + beta to yv
-__device__ __forceinline__ void bn1d(float (&acc)[MAXB], float (&yv)[MAXB], int B, bool training, float g, float be,
+template <int MB>
+__device__ __forceinline__ void bn1d(float (&acc)[MB], float (&yv)[MB], int B, bool training, float g, float be,
                                      float* rmean, float* rvar, float mom, float eps, float& invstd, bool update) {
     float mean, var;
     if (training) {
         float s = 0.f;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < B) s += acc[b];
+        for (int b = 0; b < MB; ++b) if (b < B) s += acc[b];
         mean = s / B;
         float q = 0.f;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < B) { const float d = acc[b] - mean; q += d * d; }
+        for (int b = 0; b < MB; ++b) if (b < B) { const float d = acc[b] - mean; q += d * d; }
         var = q / B;
         if (update && rmean != nullptr) {
             *rmean = (1.f - mom) * *rmean + mom * mean;
@@ -83,7 +84,7 @@ __device__ __forceinline__ void bn1d(float (&acc)[MAXB], float (&yv)[MAXB], int 
     }
     invstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
-    for (int b = 0; b < MAXB; ++b)
+    for (int b = 0; b < MB; ++b)
         if (b < B) {
             acc[b] = (acc[b] - mean) * invstd;
             yv[b] = acc[b] * g + be;
@@ -121,6 +122,7 @@ __global__ __launch_bounds__(HT) void token_mean_kernel(const float* __restrict_
 // fc_cls.0 / .1 / .2 / .3 on H1 / 32 workgroups: 32 output features per workgroup, 16 threads per feature split K in
 // interleaved 16-byte pieces (the 16 threads of a feature read 256 contiguous bytes of its weight row per step; all of a
 // thread's loads are in flight at once).  A feature's batch column ends up in one thread: BatchNorm1d is register-local.
+template <int MB>
 __global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
     extern __shared__ float lds[];
     const int t = threadIdx.x, B = a.B;
@@ -128,16 +130,16 @@ __global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
     for (int e = t; e < B * a.C4; e += HT) lds[e] = a.cls[e];
     __syncthreads();
     const int j = blockIdx.x * 32 + (t >> 4), part = t & 15;
-    float acc[MAXB], y[MAXB];
+    float acc[MB], y[MB];
 #pragma unroll
-    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+    for (int b = 0; b < MB; ++b) acc[b] = 0.f;
     if (j < a.H1) {
         const float* wr = a.w0 + (size_t)j * a.C4;
 #pragma unroll 8
         for (int k = part * 4; k < a.C4; k += 64) {
             const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b)
+            for (int b = 0; b < MB; ++b)
                 if (b < B) {
                     const float* x = lds + b * a.C4 + k;
                     acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
         }
     }
 #pragma unroll
-    for (int b = 0; b < MAXB; ++b) {
+    for (int b = 0; b < MB; ++b) {
         acc[b] += __shfl_xor(acc[b], 1);
         acc[b] += __shfl_xor(acc[b], 2);
         acc[b] += __shfl_xor(acc[b], 4);
@@ -155,13 +157,13 @@ __global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
     if (j < a.H1 && part == 0) {
         const float bias = a.b0[j];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) acc[b] += bias;
+        for (int b = 0; b < MB; ++b) acc[b] += bias;
         float is;
-        bn1d(acc, y, B, a.training != 0, a.g1[j], a.be1[j], a.rm1 ? a.rm1 + j : nullptr, a.rv1 ? a.rv1 + j : nullptr, a.mom1,
+        bn1d<MB>(acc, y, B, a.training != 0, a.g1[j], a.be1[j], a.rm1 ? a.rm1 + j : nullptr, a.rv1 ? a.rv1 + j : nullptr, a.mom1,
              a.eps1, is, true);
         a.saved[sp.is1 + j] = is;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b)
+        for (int b = 0; b < MB; ++b)
             if (b < B) {
                 a.saved[sp.xh1 + b * a.H1 + j] = acc[b];
                 float r = y[b] > 0.f ? y[b] : 0.f;
@@ -175,6 +177,7 @@ __global__ __launch_bounds__(HT) void heads_fc0_kernel(HeadsArgs a) {
 // workgroup (mymodel.py:150-153 / :209-215: two calls, each with its own batch statistics, the running statistics updated
 // MRI call first, then PET).  l_r [2][B][HD], l_st [2][HD][2], l_w3 [NC][HD] are LDS scratch; o_isD / o_xhD = offsets of
 // the saved inverse standard deviations / normalised pre-activations in a.saved.
+template <int MB>
 __device__ __forceinline__ void disc_fwd(const HeadsArgs& a, int o_isD, int o_xhD, const float* l_v, float* l_r, float* l_st,
                                          float* l_w3) {
     const int t = threadIdx.x, B = a.B;
@@ -183,9 +186,9 @@ __device__ __forceinline__ void disc_fwd(const HeadsArgs& a, int o_isD, int o_xh
         const int e = e0 + (t >> 1), part = t & 1;
         const bool live = e < 2 * a.HD;
         const int j = live ? e % a.HD : 0, m = live ? e / a.HD : 0;
-        float acc[MAXB], y[MAXB];
+        float acc[MB], y[MB];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+        for (int b = 0; b < MB; ++b) acc[b] = 0.f;
         if (live) {
             const float* wr = a.dw0 + (size_t)j * a.dim;
             const int kper = a.dim / 2;                       // dim % 8 == 0: whole float4s
@@ -193,7 +196,7 @@ __device__ __forceinline__ void disc_fwd(const HeadsArgs& a, int o_isD, int o_xh
             for (int k = part * kper; k < (part + 1) * kper; k += 4) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b)
+                for (int b = 0; b < MB; ++b)
                     if (b < B) {
                         const float* x = l_v + (m * B + b) * a.dim + k;
                         acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
@@ -202,30 +205,30 @@ __device__ __forceinline__ void disc_fwd(const HeadsArgs& a, int o_isD, int o_xh
             }
         }
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) acc[b] += __shfl_xor(acc[b], 1);
+        for (int b = 0; b < MB; ++b) acc[b] += __shfl_xor(acc[b], 1);
         if (!live || part != 0) continue;
         {
             const float bias = a.db0[j];
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) acc[b] += bias;
+            for (int b = 0; b < MB; ++b) acc[b] += bias;
         }
         // batch statistics of THIS call; the running buffers are updated below, MRI call first, then PET
         float mean = 0.f, q = 0.f;
         if (a.training) {
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) if (b < B) mean += acc[b];
+            for (int b = 0; b < MB; ++b) if (b < B) mean += acc[b];
             mean /= B;
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) if (b < B) { const float d = acc[b] - mean; q += d * d; }
+            for (int b = 0; b < MB; ++b) if (b < B) { const float d = acc[b] - mean; q += d * d; }
             l_st[(m * a.HD + j) * 2] = mean;
             l_st[(m * a.HD + j) * 2 + 1] = B > 1 ? q / (B - 1) : q / B;
         }
         float is;
-        bn1d(acc, y, B, a.training != 0, a.dg1[j], a.dbe1[j], a.drm1 ? a.drm1 + j : nullptr, a.drv1 ? a.drv1 + j : nullptr,
+        bn1d<MB>(acc, y, B, a.training != 0, a.dg1[j], a.dbe1[j], a.drm1 ? a.drm1 + j : nullptr, a.drv1 ? a.drv1 + j : nullptr,
              a.dmom, a.deps, is, false);
         a.saved[o_isD + m * a.HD + j] = is;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b)
+        for (int b = 0; b < MB; ++b)
             if (b < B) {
                 a.saved[o_xhD + (m * B + b) * a.HD + j] = acc[b];
                 l_r[(m * B + b) * a.HD + j] = y[b] > 0.f ? y[b] : 0.f;
@@ -254,17 +257,19 @@ __device__ __forceinline__ void disc_fwd(const HeadsArgs& a, int o_isD, int o_xh
     }
 }
 
+template <int MB>
 __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
     extern __shared__ float lds[];
     const int t = threadIdx.x;
     const int B = a.B;
     const SavedPlan sp = saved_plan(B, a.dim, a.H1, a.H2, a.HD);
-    float* l_cls = lds;                          // [B][C4]
-    float* l_a1 = l_cls + B * a.C4;              // [B][H1]
-    float* l_a2 = l_a1 + B * a.H1;               // [B][H2]
-    float* l_v = l_a2 + B * a.H2;                // [2][B][dim]
-    float* l_r = l_v + 2 * B * a.dim;            // [2][B][HD]  (ReLU output of D's hidden layer)
-    float* l_st = l_r + 2 * B * a.HD;            // [2][HD][2]  batch mean / unbiased var of the two D calls
+    // (the two roles run in different workgroups and share the allocation: fwd_lds() = the larger plan)
+    float* l_a1 = lds;                           // fc role: [B][H1]            D role: D.3's weights [NC][HD]
+    float* l_a2 = l_a1 + B * a.H1;               //          [B][H2]
+    const int wD = a.NC * a.HD;
+    float* l_v = lds + wD;                       // D role:  [2][B][dim]
+    float* l_r = l_v + 2 * B * a.dim;            //          [2][B][HD]  (ReLU output of D's hidden layer)
+    float* l_st = l_r + 2 * B * a.HD;            //          [2][HD][2]  batch mean / unbiased var of the two D calls
     // two workgroups, two independent chains: block 0 = fc_cls.4 .. fc_cls.8 (logits), block 1 = D on both token means
     const bool fc_role = blockIdx.x == 0;
     // ---- token means (token_mean_kernel) and the first hidden layer's output (heads_fc0_kernel) from `saved` ----
@@ -275,9 +280,9 @@ __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
     // ---- fc_cls.4 / .5 / .6 / .7 : 8 threads per output feature split K ----
     for (int j0 = 0; j0 < a.H2; j0 += HT / 8) {
         const int j = j0 + (t >> 3), part = t & 7;
-        float acc[MAXB], y[MAXB];
+        float acc[MB], y[MB];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+        for (int b = 0; b < MB; ++b) acc[b] = 0.f;
         if (j < a.H2) {
             const int kper = (a.H1 + 7) / 8;
             const int k0 = part * kper, k1 = k0 + kper < a.H1 ? k0 + kper : a.H1;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
             for (int k = k0; k < k1; k += 4) {                  // H1 % 32 == 0: every part is a whole number of float4s
                 const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b)
+                for (int b = 0; b < MB; ++b)
                     if (b < B) {
                         const float* x = l_a1 + b * a.H1 + k;
                         acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
@@ -295,7 +300,7 @@ __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
             }
         }
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
+        for (int b = 0; b < MB; ++b) {
             acc[b] += __shfl_xor(acc[b], 1);
             acc[b] += __shfl_xor(acc[b], 2);
             acc[b] += __shfl_xor(acc[b], 4);
@@ -303,13 +308,13 @@ __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
         if (j < a.H2 && part == 0) {
             const float bias = a.b4[j];
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) acc[b] += bias;
+            for (int b = 0; b < MB; ++b) acc[b] += bias;
             float is;
-            bn1d(acc, y, B, a.training != 0, a.g5[j], a.be5[j], a.rm5 ? a.rm5 + j : nullptr, a.rv5 ? a.rv5 + j : nullptr,
+            bn1d<MB>(acc, y, B, a.training != 0, a.g5[j], a.be5[j], a.rm5 ? a.rm5 + j : nullptr, a.rv5 ? a.rv5 + j : nullptr,
                  a.mom5, a.eps5, is, true);
             a.saved[sp.is2 + j] = is;
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b)
+            for (int b = 0; b < MB; ++b)
                 if (b < B) {
                     a.saved[sp.xh2 + b * a.H2 + j] = acc[b];
                     float r = y[b] > 0.f ? y[b] : 0.f;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(HT) void heads_fwd_kernel(HeadsArgs a) {
         }
         return;
     }
-    disc_fwd(a, sp.isD, sp.xhD, l_v, l_r, l_st, l_a1);           // block 1 (l_a1 is unused by this block: D.3's weights)
+    disc_fwd<MB>(a, sp.isD, sp.xhD, l_v, l_r, l_st, l_a1);           // block 1 (l_a1 is unused by this block: D.3's weights)
 }
 
 struct HeadsBwdArgs {
@@ -352,12 +357,13 @@ struct HeadsBwdArgs {
 
 // backward of y = gamma*xhat + beta followed by ReLU (and an optional scaled keep-mask) for one feature:
 // in: dr[b] = gradient w.r.t. the masked ReLU output; out: dz[b] w.r.t. the BatchNorm input; dgamma, dbeta
-__device__ __forceinline__ void bn1d_relu_bwd(float (&dr)[MAXB], const float* xhat, int stride, const float* mask, int B,
+template <int MB>
+__device__ __forceinline__ void bn1d_relu_bwd(float (&dr)[MB], const float* xhat, int stride, const float* mask, int B,
                                               bool training, float g, float be, float invstd, float& dgamma, float& dbeta) {
     float sg = 0.f, sx = 0.f;
-    float xh[MAXB];
+    float xh[MB];
 #pragma unroll
-    for (int b = 0; b < MAXB; ++b)
+    for (int b = 0; b < MB; ++b)
         if (b < B) {
             xh[b] = xhat[b * stride];
             const float y = xh[b] * g + be;
@@ -371,7 +377,7 @@ __device__ __forceinline__ void bn1d_relu_bwd(float (&dr)[MAXB], const float* xh
     dbeta = sg;
     const float k = g * invstd;
 #pragma unroll
-    for (int b = 0; b < MAXB; ++b)
+    for (int b = 0; b < MB; ++b)
         if (b < B) dr[b] = training ? k * (dr[b] - sg / B - xh[b] * (sx / B)) : k * dr[b];
 }
 
@@ -379,6 +385,7 @@ __device__ __forceinline__ void bn1d_relu_bwd(float (&dr)[MAXB], const float* xh
 // recomputes the D.3 / BatchNorm1d(HD) part, then takes the dq-th j-range of the D.0 backward — its rows of dW0 and its
 // partial of the token-mean gradient, a.s_dv[dq][2][B][dim] (summed, scaled by -alpha / N and broadcast over the tokens by the
 // caller's second launch).  l_dzD [2][B][HD]; l_x: LDS scratch of max(6 HD, 2 B dim NS) floats.
+template <int MB>
 __device__ __forceinline__ void disc_bwd(const HeadsBwdArgs& a, int o_xhD, int o_isD, int o_v, bool first, int dq, float* l_dzD,
                                          float* l_x) {
     const HeadsArgs& f = a.f;
@@ -404,19 +411,19 @@ __device__ __forceinline__ void disc_bwd(const HeadsBwdArgs& a, int o_xhD, int o
     __syncthreads();                                     // l_x (cls) is free from here on
     for (int e = t; e < 2 * f.HD; e += HT) {
         const int j = e % f.HD, m = e / f.HD;
-        float dr[MAXB];
+        float dr[MB];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
+        for (int b = 0; b < MB; ++b) {
             float s = 0.f;
             if (b < B) for (int c = 0; c < f.NC; ++c) s = fmaf(a.d_dlog[m][b * f.NC + c], f.dw3[c * f.HD + j], s);
             dr[b] = s;
         }
         float dg, db;
-        bn1d_relu_bwd(dr, f.saved + o_xhD + m * B * f.HD + j, f.HD, nullptr, B, tr, f.dg1[j], f.dbe1[j],
+        bn1d_relu_bwd<MB>(dr, f.saved + o_xhD + m * B * f.HD + j, f.HD, nullptr, B, tr, f.dg1[j], f.dbe1[j],
                       f.saved[o_isD + m * f.HD + j], dg, db);
         float sb = 0.f;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dzD[(m * B + b) * f.HD + j] = dr[b]; sb += dr[b]; }
+        for (int b = 0; b < MB; ++b) if (b < B) { l_dzD[(m * B + b) * f.HD + j] = dr[b]; sb += dr[b]; }
         l_pg[(m * f.HD + j) * 3] = dg;
         l_pg[(m * f.HD + j) * 3 + 1] = db;
         l_pg[(m * f.HD + j) * 3 + 2] = sb;
@@ -435,10 +442,10 @@ __device__ __forceinline__ void disc_bwd(const HeadsBwdArgs& a, int o_xhD, int o
         const int NS = HT / f.dim >= 2 ? 2 : 1;
         const int i = t % f.dim, sl = t / f.dim;
         if (sl < NS && t < NS * f.dim) {
-            float v[2 * MAXB], dv[2 * MAXB];
+            float v[2 * MB], dv[2 * MB];
 #pragma unroll
-            for (int q = 0; q < 2 * MAXB; ++q) {
-                const int m = q / MAXB, b = q % MAXB;
+            for (int q = 0; q < 2 * MB; ++q) {
+                const int m = q / MB, b = q % MB;
                 v[q] = b < B ? f.saved[o_v + (m * B + b) * f.dim + i] : 0.f;
                 dv[q] = 0.f;
             }
@@ -451,8 +458,8 @@ __device__ __forceinline__ void disc_bwd(const HeadsBwdArgs& a, int o_xhD, int o
                 const float w = f.dw0[(size_t)j * f.dim + i];
                 float s = 0.f;
 #pragma unroll
-                for (int q = 0; q < 2 * MAXB; ++q) {
-                    const int m = q / MAXB, b = q % MAXB;
+                for (int q = 0; q < 2 * MB; ++q) {
+                    const int m = q / MB, b = q % MB;
                     if (b < B) {
                         const float dz = l_dzD[(m * B + b) * f.HD + j];
                         s = fmaf(dz, v[q], s);
@@ -462,8 +469,8 @@ __device__ __forceinline__ void disc_bwd(const HeadsBwdArgs& a, int o_xhD, int o
                 a.gdw0[(size_t)j * f.dim + i] = s;
             }
 #pragma unroll
-            for (int q = 0; q < 2 * MAXB; ++q) {
-                const int m = q / MAXB, b = q % MAXB;
+            for (int q = 0; q < 2 * MB; ++q) {
+                const int m = q / MB, b = q % MB;
                 if (b < B) l_dvp[((sl * 2 + m) * B + b) * f.dim + i] = dv[q];
             }
         }
@@ -481,6 +488,7 @@ __device__ __forceinline__ void disc_bwd(const HeadsBwdArgs& a, int o_xhD, int o
 // so that a thread's chain of dependent weight loads is H2 / 8 long instead of H2); blocks nA .. nA + ND - 1 run the D path
 // (every one recomputes the small D.3 / BatchNorm1d(HD) part, the first stores its results; block q takes the q-th j-range
 // of the D.0 backward and writes its partial of the token-mean gradient, summed by heads_bwd_outer_kernel).
+template <int MB>
 __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
     extern __shared__ float lds[];
     const HeadsArgs& f = a.f;
@@ -491,11 +499,10 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
     const int blk = blockIdx.x;
     const bool d_role = blk >= nA, first = blk == 0 || blk == nA;
     const int dq = blk - nA;                             // D role: which j-range of D.0
-    float* l_dz1 = lds;                       // [B][H1]
-    float* l_dz2 = l_dz1 + B * f.H1;          // [B][H2]
-    float* l_dzD = l_dz2 + B * f.H2;          // [2][B][HD]
-    float* l_dv = l_dzD + 2 * B * f.HD;       // [2][B][dim]
-    float* l_x = l_dv + 2 * B * f.dim;        // [B][max(C4, H1)]  cls, later reused
+    // (the two roles run in different workgroups and share the allocation: bwd_lds() = the larger plan)
+    float* l_dz2 = lds;                                            // fc role: [B][H2], then l_x = the j-slice partials [8][B][64]
+    float* l_dzD = lds;                                            // D role:  [2][B][HD], then l_x = disc_bwd's scratch
+    float* l_x = d_role ? l_dzD + 2 * B * f.HD : l_dz2 + B * f.H2;
     if (!d_role) {
     // ---- fc_cls.8 backward, then through Dropout / ReLU / BatchNorm1d(H2) ----
     for (int e = t; first && e < f.NC * f.H2; e += HT) { // dW8[c][k] = sum_b dlogits[b][c] a2[b][k]
@@ -510,25 +517,25 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
         a.gb8[c] = s;
     }
     for (int j = t; j < f.H2; j += HT) {
-        float dr[MAXB];
+        float dr[MB];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
+        for (int b = 0; b < MB; ++b) {
             float s = 0.f;
             if (b < B) for (int c = 0; c < f.NC; ++c) s = fmaf(a.d_logits[b * f.NC + c], f.w8[c * f.H2 + j], s);
             dr[b] = s;
         }
         float dg, db;
-        bn1d_relu_bwd(dr, f.saved + sp.xh2 + j, f.H2, f.mask2 ? f.mask2 + j : nullptr, B, tr, f.g5[j], f.be5[j],
+        bn1d_relu_bwd<MB>(dr, f.saved + sp.xh2 + j, f.H2, f.mask2 ? f.mask2 + j : nullptr, B, tr, f.g5[j], f.be5[j],
                       f.saved[sp.is2 + j], dg, db);
         float sb = 0.f;
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < B) { l_dz2[b * f.H2 + j] = dr[b]; sb += dr[b]; }
+        for (int b = 0; b < MB; ++b) if (b < B) { l_dz2[b * f.H2 + j] = dr[b]; sb += dr[b]; }
         if (first) {
             a.gg5[j] = dg;
             a.gbe5[j] = db;
             a.gb4[j] = sb;
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) if (b < B) a.s_dz2[b * f.H2 + j] = dr[b];
+            for (int b = 0; b < MB; ++b) if (b < B) a.s_dz2[b * f.H2 + j] = dr[b];
         }
     }
     __syncthreads();
@@ -541,23 +548,23 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
         const int kk = t & 63, sl = t >> 6, k = kc + kk;
         const int jper = (f.H2 + 7) / 8;
         const int j0 = sl * jper, j1 = j0 + jper < f.H2 ? j0 + jper : f.H2;
-        float dr[MAXB];
+        float dr[MB];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) dr[b] = 0.f;
+        for (int b = 0; b < MB; ++b) dr[b] = 0.f;
         if (k < kend) {
 #pragma unroll 8
             for (int j = j0; j < j1; ++j) {
                 const float w = f.w4[(size_t)j * f.H1 + k];
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b) if (b < B) dr[b] = fmaf(l_dz2[b * f.H2 + j], w, dr[b]);
+                for (int b = 0; b < MB; ++b) if (b < B) dr[b] = fmaf(l_dz2[b * f.H2 + j], w, dr[b]);
             }
         }
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < B) l_part[(sl * B + b) * 64 + kk] = dr[b];
+        for (int b = 0; b < MB; ++b) if (b < B) l_part[(sl * B + b) * 64 + kk] = dr[b];
         __syncthreads();
         if (sl == 0 && k < kend) {
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b)
+            for (int b = 0; b < MB; ++b)
                 if (b < B) {
                     float sum = 0.f;
 #pragma unroll
@@ -565,13 +572,13 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
                     dr[b] = sum;
                 }
             float dg, db;
-            bn1d_relu_bwd(dr, f.saved + sp.xh1 + k, f.H1, f.mask1 ? f.mask1 + k : nullptr, B, tr, f.g1[k], f.be1[k],
+            bn1d_relu_bwd<MB>(dr, f.saved + sp.xh1 + k, f.H1, f.mask1 ? f.mask1 + k : nullptr, B, tr, f.g1[k], f.be1[k],
                           f.saved[sp.is1 + k], dg, db);
             a.gg1[k] = dg;
             a.gbe1[k] = db;
             float sb = 0.f;
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) if (b < B) { a.s_dz1[b * f.H1 + k] = dr[b]; sb += dr[b]; }
+            for (int b = 0; b < MB; ++b) if (b < B) { a.s_dz1[b * f.H1 + k] = dr[b]; sb += dr[b]; }
             a.gb0[k] = sb;
         }
         __syncthreads();
@@ -579,7 +586,7 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
     return;
     }
     // (fc_cls.0 backward — dcls = dz1 W0 and dW0 = dz1^T cls — runs on many workgroups: heads_bwd_outer_kernel)
-    disc_bwd(a, sp.xhD, sp.isD, sp.v, first, dq, l_dzD, l_x);       // blocks nA .. nA + ND - 1
+    disc_bwd<MB>(a, sp.xhD, sp.isD, sp.v, first, dq, l_dzD, l_x);       // blocks nA .. nA + ND - 1
 }
 
 // The wide parts of the backward on many workgroups:
@@ -587,8 +594,9 @@ __global__ __launch_bounds__(HT) void heads_bwd_kernel(HeadsBwdArgs a, int nA) {
 //   next nb0 blocks        : dW0[j][k] = sum_b dz1[b][j] cls[b][k]        (8 rows j per block, a thread per column k)
 //   next nb4 blocks        : dW4[j][k] = sum_b dz2[b][j] a1[b][k]
 //   the rest               : mean over tokens + gradient reversal: d tok[m][b][n][c] = -alpha * dv[m][b][c] / N
+template <int MB>
 __global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int nb0, int nb4, int nbc) {
-    __shared__ float part[16][MAXB][32];
+    __shared__ float part[16][MB][32];
     const HeadsArgs& f = a.f;
     const int t = threadIdx.x, B = f.B;
     int blk = blockIdx.x;
@@ -596,9 +604,9 @@ __global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int
         // dcls[b][k] = sum_j dz1[b][j] W0[j][k]: 32 columns per workgroup, 16 j-slices of H1 / 16 rows each (a thread's
         // chain of dependent weight loads is what this launch waits for)
         const int kk = t & 31, sl = t >> 5, k = blk * 32 + kk;
-        float dc[MAXB];
+        float dc[MB];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) dc[b] = 0.f;
+        for (int b = 0; b < MB; ++b) dc[b] = 0.f;
         const int jper = (f.H1 + 15) / 16;
         const int j0 = sl * jper, j1 = j0 + jper < f.H1 ? j0 + jper : f.H1;
         if (k < f.C4) {
@@ -606,11 +614,11 @@ __global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int
             for (int j = j0; j < j1; ++j) {
                 const float w = f.w0[(size_t)j * f.C4 + k];
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b) if (b < B) dc[b] = fmaf(a.s_dz1[b * f.H1 + j], w, dc[b]);
+                for (int b = 0; b < MB; ++b) if (b < B) dc[b] = fmaf(a.s_dz1[b * f.H1 + j], w, dc[b]);
             }
         }
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) part[sl][b][kk] = dc[b];
+        for (int b = 0; b < MB; ++b) part[sl][b][kk] = dc[b];
         __syncthreads();
         for (int e = t; e < B * 32; e += HT) {
             const int b = e >> 5, c = e & 31;
@@ -633,16 +641,16 @@ __global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int
         const float* x = first ? f.cls : f.saved + sp.a1;                    // [B][cols]
         float* gw = first ? a.gw0 : a.gw4;
         for (int k = t; k < cols; k += HT) {
-            float xv[MAXB];
+            float xv[MB];
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b) xv[b] = b < B ? x[b * cols + k] : 0.f;
+            for (int b = 0; b < MB; ++b) xv[b] = b < B ? x[b * cols + k] : 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) {
                 const int j = blk * 8 + r;
                 if (j < rows) {
                     float s = 0.f;
 #pragma unroll
-                    for (int b = 0; b < MAXB; ++b) if (b < B) s = fmaf(dz[b * rows + j], xv[b], s);
+                    for (int b = 0; b < MB; ++b) if (b < B) s = fmaf(dz[b * rows + j], xv[b], s);
                     gw[(size_t)j * cols + k] = s;
                 }
             }
@@ -675,6 +683,7 @@ __global__ __launch_bounds__(HT) void heads_bwd_outer_kernel(HeadsBwdArgs a, int
 // HeadsArgs is reused: tok[], w0 / b0 = the hidden layer [H1][C4] with C4 = M dim, w8 / b8 = the output layer [NC][H1], the
 // d* fields = D; saved = saved_plan(B, dim, H1, 0, HD) with `a1` = the ReLU output and `v` = the token means.
 // ------------------------------------------------------------------------------------------------------------
+template <int MB>
 __global__ __launch_bounds__(HT) void cnn_heads_fwd_kernel(HeadsArgs a) {
     extern __shared__ float lds[];
     const int t = threadIdx.x, B = a.B, M = a.C4 / a.dim;
@@ -686,13 +695,13 @@ __global__ __launch_bounds__(HT) void cnn_heads_fwd_kernel(HeadsArgs a) {
     float* l_st = l_w + a.NC * wide;             // [2][HD][2]
     for (int e = t; e < M * B * a.dim; e += HT) l_v[e] = a.saved[sp.v + e];
     __syncthreads();
-    if (blockIdx.x == 1) { disc_fwd(a, sp.isD, sp.xhD, l_v, l_h, l_st, l_w); return; }
+    if (blockIdx.x == 1) { disc_fwd<MB>(a, sp.isD, sp.xhD, l_v, l_h, l_st, l_w); return; }
     // ---- hidden layer + ReLU: 4 threads per feature split K; x[b][k] = v[k / dim][b][k % dim] is the concatenation ----
     for (int j0 = 0; j0 < a.H1; j0 += HT / 4) {
         const int j = j0 + (t >> 2), part = t & 3;
-        float acc[MAXB];
+        float acc[MB];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+        for (int b = 0; b < MB; ++b) acc[b] = 0.f;
         if (j < a.H1) {
             const float* wr = a.w0 + (size_t)j * a.C4;
             const int kper = a.C4 / 4;                          // C4 % 16 == 0: whole float4s, none straddles a modality
@@ -701,7 +710,7 @@ __global__ __launch_bounds__(HT) void cnn_heads_fwd_kernel(HeadsArgs a) {
                 const f32x4 w = *reinterpret_cast<const f32x4*>(wr + k);
                 const float* xm = l_v + (size_t)(k / a.dim) * B * a.dim + k % a.dim;
 #pragma unroll
-                for (int b = 0; b < MAXB; ++b)
+                for (int b = 0; b < MB; ++b)
                     if (b < B) {
                         const float* x = xm + b * a.dim;
                         acc[b] = fmaf(w[0], x[0], acc[b]); acc[b] = fmaf(w[1], x[1], acc[b]);
@@ -710,14 +719,14 @@ __global__ __launch_bounds__(HT) void cnn_heads_fwd_kernel(HeadsArgs a) {
             }
         }
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
+        for (int b = 0; b < MB; ++b) {
             acc[b] += __shfl_xor(acc[b], 1);
             acc[b] += __shfl_xor(acc[b], 2);
         }
         if (j < a.H1 && part == 0) {
             const float bias = a.b0[j];
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b)
+            for (int b = 0; b < MB; ++b)
                 if (b < B) {
                     const float r = acc[b] + bias > 0.f ? acc[b] + bias : 0.f;
                     l_h[b * a.H1 + j] = r;
@@ -738,6 +747,7 @@ __global__ __launch_bounds__(HT) void cnn_heads_fwd_kernel(HeadsArgs a) {
 
 // block 0: the fc chain (output layer, ReLU, hidden layer: its weight gradient and the gradient of the concatenated means,
 // a.s_dz1 [B][C4]); blocks 1 .. ND: disc_bwd.  cnn_heads_bwd_tok_kernel then spreads both over the tokens.
+template <int MB>
 __global__ __launch_bounds__(HT) void cnn_heads_bwd_kernel(HeadsBwdArgs a) {
     extern __shared__ float lds[];
     const HeadsArgs& f = a.f;
@@ -746,7 +756,7 @@ __global__ __launch_bounds__(HT) void cnn_heads_bwd_kernel(HeadsBwdArgs a) {
     float* l_dz = lds;                        // [B][H1]
     float* l_dzD = l_dz + B * f.H1;           // [2][B][HD]
     float* l_x = l_dzD + 2 * B * f.HD;        // scratch: [NS][B][C4] | disc_bwd's
-    if (blockIdx.x > 0) { disc_bwd(a, sp.xhD, sp.isD, sp.v, blockIdx.x == 1, (int)blockIdx.x - 1, l_dzD, l_x); return; }
+    if (blockIdx.x > 0) { disc_bwd<MB>(a, sp.xhD, sp.isD, sp.v, blockIdx.x == 1, (int)blockIdx.x - 1, l_dzD, l_x); return; }
     const float* h = f.saved + sp.a1;
     for (int e = t; e < f.NC * f.H1; e += HT) {          // dW2[c][k] = sum_b dlogits[b][c] h[b][k]
         const int k = e % f.H1, c = e / f.H1;
@@ -775,9 +785,9 @@ __global__ __launch_bounds__(HT) void cnn_heads_bwd_kernel(HeadsBwdArgs a) {
     const int NS = HT / f.C4 >= 2 ? 2 : 1;
     const int i = t % f.C4, sl = t / f.C4;
     if (sl < NS) {
-        float x[MAXB], dx[MAXB];
+        float x[MB], dx[MB];
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) {
+        for (int b = 0; b < MB; ++b) {
             x[b] = b < B ? f.saved[sp.v + ((size_t)(i / f.dim) * B + b) * f.dim + i % f.dim] : 0.f;
             dx[b] = 0.f;
         }
@@ -788,7 +798,7 @@ __global__ __launch_bounds__(HT) void cnn_heads_bwd_kernel(HeadsBwdArgs a) {
             const float w = f.w0[(size_t)k * f.C4 + i];
             float s = 0.f;
 #pragma unroll
-            for (int b = 0; b < MAXB; ++b)
+            for (int b = 0; b < MB; ++b)
                 if (b < B) {
                     const float dz = l_dz[b * f.H1 + k];
                     s = fmaf(dz, x[b], s);
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(HT) void cnn_heads_bwd_kernel(HeadsBwdArgs a) {
             a.gw0[(size_t)k * f.C4 + i] = s;
         }
 #pragma unroll
-        for (int b = 0; b < MAXB; ++b) if (b < B) l_x[(sl * B + b) * f.C4 + i] = dx[b];
+        for (int b = 0; b < MB; ++b) if (b < B) l_x[(sl * B + b) * f.C4 + i] = dx[b];
     }
     __syncthreads();
     for (int e = t; e < B * f.C4; e += HT) {
@@ -833,6 +843,9 @@ __global__ __launch_bounds__(HT) void cnn_heads_bwd_tok_kernel(HeadsBwdArgs a) {
         *reinterpret_cast<f32x4*>(a.d_tok[m] + o) = r;
     }
 }
+
+// the kernel instance for a batch: 16 rows in registers where that is enough, 32 above
+#define HEADS_K(K, B) ((B) <= 16 ? K<16> : K<32>)
 
 int check_cnn_heads(const char* fn, const tmf_heads_cnn_desc* d) {
     TMF_REQUIRE_PTR(d);
@@ -878,13 +891,19 @@ int check_heads(const char* fn, const tmf_heads_desc* d) {
     return TMF_OK;
 }
 size_t fwd_lds(const tmf_heads_desc& d) {
-    return (size_t)(d.B * 4 * d.dim + d.B * d.H1 + d.B * d.H2 + 2 * d.B * d.dim + 2 * d.B * d.HD + 4 * d.HD) * 4;
+    const size_t fc = (size_t)d.B * d.H1 + (size_t)d.B * d.H2;
+    const size_t fc8 = (size_t)d.NC * d.H2;                                     // fc_cls.8's weights re-use l_a1
+    const size_t dd = (size_t)d.NC * d.HD + 2 * d.B * d.dim + 2 * d.B * d.HD + 4 * d.HD;
+    size_t n = fc > dd ? fc : dd;
+    if (n < fc8) n = fc8;
+    return n * 4;
 }
 size_t bwd_lds(const tmf_heads_desc& d) {
-    const int c4 = 4 * d.dim;
-    int lx = d.B * (c4 > d.H1 ? c4 : d.H1) > 6 * d.HD ? d.B * (c4 > d.H1 ? c4 : d.H1) : 6 * d.HD;
-    if (lx < 8 * d.B * 64) lx = 8 * d.B * 64;          // the j-slice partials of the fc_cls.4 backward
-    return (size_t)(d.B * d.H1 + d.B * d.H2 + 2 * d.B * d.HD + 2 * d.B * d.dim + lx) * 4;
+    const size_t fc = (size_t)d.B * d.H2 + (size_t)8 * d.B * 64;               // dz2 + the j-slice partials of the fc_cls.4 backward
+    size_t dx = (size_t)2 * 2 * d.B * d.dim;                                    // disc_bwd: [NS <= 2][2][B][dim] partial dv ...
+    if (dx < (size_t)6 * d.HD) dx = (size_t)6 * d.HD;                           // ... after the per-call partials [2][HD][3]
+    const size_t dd = (size_t)2 * d.B * d.HD + dx;
+    return (fc > dd ? fc : dd) * 4;
 }
 HeadsArgs make_args(const tmf_heads_desc& d, const float* cls, const float* mri_tok, const float* pet_tok, const float* mask1,
                     const float* mask2, const tmf_heads_params& p, float* saved) {
@@ -996,15 +1015,15 @@ extern "C" int tmf_heads_fwd(const tmf_heads_desc* d, const float* cls, const fl
     a.logits = logits; a.dlog[0] = d_mri_logits; a.dlog[1] = d_pet_logits;
     const size_t lds = fwd_lds(*d);
     TMF_REQUIRE(lds <= 150 * 1024, TMF_E_SHAPE, "tmf_heads_fwd: %zu B of LDS needed (batch x widths too large)", lds);
-    if ((rc = tmf_allow_lds(heads_fwd_kernel, lds, "tmf_heads_fwd"))) return rc;
+    if ((rc = tmf_allow_lds(HEADS_K(heads_fwd_kernel, d->B), lds, "tmf_heads_fwd"))) return rc;
     hipLaunchKernelGGL(token_mean_kernel, dim3(2 * d->B), dim3(HT), 0, (hipStream_t)stream, mri_tok, pet_tok,
                        (float*)saved + saved_plan(d->B, d->dim, d->H1, d->H2, d->HD).v, d->B, d->N, d->dim);
     if ((rc = tmf_launch_result("tmf_heads_fwd(token mean)"))) return rc;
     const size_t lds0 = (size_t)d->B * 4 * d->dim * 4;
-    if ((rc = tmf_allow_lds(heads_fc0_kernel, lds0, "tmf_heads_fwd(fc0)"))) return rc;
-    hipLaunchKernelGGL(heads_fc0_kernel, dim3(tmf_cdiv(d->H1, 32)), dim3(HT), lds0, (hipStream_t)stream, a);
+    if ((rc = tmf_allow_lds(HEADS_K(heads_fc0_kernel, d->B), lds0, "tmf_heads_fwd(fc0)"))) return rc;
+    hipLaunchKernelGGL(HEADS_K(heads_fc0_kernel, d->B), dim3(tmf_cdiv(d->H1, 32)), dim3(HT), lds0, (hipStream_t)stream, a);
     if ((rc = tmf_launch_result("tmf_heads_fwd(fc0)"))) return rc;
-    hipLaunchKernelGGL(heads_fwd_kernel, dim3(2), dim3(HT), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(HEADS_K(heads_fwd_kernel, d->B), dim3(2), dim3(HT), lds, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_heads_fwd");
 }
 
@@ -1042,16 +1061,16 @@ extern "C" int tmf_heads_bwd(const tmf_heads_desc* d, const float* cls, const fl
     a.s_dz1 = (float*)scratch; a.s_dz2 = a.s_dz1 + (size_t)d->B * d->H1; a.s_dv = a.s_dz2 + (size_t)d->B * d->H2;
     const size_t lds = bwd_lds(*d);
     TMF_REQUIRE(lds <= 150 * 1024, TMF_E_SHAPE, "tmf_heads_bwd: %zu B of LDS needed (batch x widths too large)", lds);
-    if ((rc = tmf_allow_lds(heads_bwd_kernel, lds, "tmf_heads_bwd"))) return rc;
+    if ((rc = tmf_allow_lds(HEADS_K(heads_bwd_kernel, d->B), lds, "tmf_heads_bwd"))) return rc;
     const int nA = d->H1 % 64 == 0 ? d->H1 / 64 : 1;              // workgroups of the fc_cls chain (+ one for the D path)
-    hipLaunchKernelGGL(heads_bwd_kernel, dim3(nA + ND), dim3(HT), lds, (hipStream_t)stream, a, nA);
+    hipLaunchKernelGGL(HEADS_K(heads_bwd_kernel, d->B), dim3(nA + ND), dim3(HT), lds, (hipStream_t)stream, a, nA);
     if ((rc = tmf_launch_result("tmf_heads_bwd"))) return rc;
     const int nb0 = tmf_cdiv(d->H1, 8), nb4 = tmf_cdiv(d->H2, 8);
     int nbt = tmf_cdiv((long)2 * d->B * d->N * d->dim, (long)HT * 4 * 4);
     if (nbt > 256) nbt = 256;
     if (nbt < 1) nbt = 1;
     const int nbc = tmf_cdiv(4 * d->dim, 32);
-    hipLaunchKernelGGL(heads_bwd_outer_kernel, dim3(nbc + nb0 + nb4 + nbt), dim3(HT), 0, (hipStream_t)stream, a, nb0, nb4, nbc);
+    hipLaunchKernelGGL(HEADS_K(heads_bwd_outer_kernel, d->B), dim3(nbc + nb0 + nb4 + nbt), dim3(HT), 0, (hipStream_t)stream, a, nb0, nb4, nbc);
     return tmf_launch_result("tmf_heads_bwd(outer)");
 }
 
@@ -1086,11 +1105,11 @@ extern "C" int tmf_heads_cnn_fwd(const tmf_heads_cnn_desc* d, const float* mri_t
     a.logits = logits; a.dlog[0] = d_mri_logits; a.dlog[1] = d_pet_logits;
     const size_t lds = cnn_fwd_lds(*d);
     TMF_REQUIRE(lds <= 150 * 1024, TMF_E_SHAPE, "tmf_heads_cnn_fwd: %zu B of LDS needed (batch x widths too large)", lds);
-    if ((rc = tmf_allow_lds(cnn_heads_fwd_kernel, lds, "tmf_heads_cnn_fwd"))) return rc;
+    if ((rc = tmf_allow_lds(HEADS_K(cnn_heads_fwd_kernel, d->B), lds, "tmf_heads_cnn_fwd"))) return rc;
     hipLaunchKernelGGL(token_mean_kernel, dim3(d->M * d->B), dim3(HT), 0, (hipStream_t)stream, mri_tok, pet_tok,
                        (float*)saved + saved_plan(d->B, d->dim, d->H, 0, d->HD).v, d->B, d->N, d->dim);
     if ((rc = tmf_launch_result("tmf_heads_cnn_fwd(token mean)"))) return rc;
-    hipLaunchKernelGGL(cnn_heads_fwd_kernel, dim3(d->HD > 0 ? 2 : 1), dim3(HT), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(HEADS_K(cnn_heads_fwd_kernel, d->B), dim3(d->HD > 0 ? 2 : 1), dim3(HT), lds, (hipStream_t)stream, a);
     return tmf_launch_result("tmf_heads_cnn_fwd");
 }
 
@@ -1127,8 +1146,8 @@ extern "C" int tmf_heads_cnn_bwd(const tmf_heads_cnn_desc* d, const tmf_heads_cn
     a.s_dz1 = (float*)scratch; a.s_dv = a.s_dz1 + (size_t)d->B * d->M * d->dim;
     const size_t lds = cnn_bwd_lds(*d);
     TMF_REQUIRE(lds <= 150 * 1024, TMF_E_SHAPE, "tmf_heads_cnn_bwd: %zu B of LDS needed (batch x widths too large)", lds);
-    if ((rc = tmf_allow_lds(cnn_heads_bwd_kernel, lds, "tmf_heads_cnn_bwd"))) return rc;
-    hipLaunchKernelGGL(cnn_heads_bwd_kernel, dim3(d->HD > 0 ? 1 + ND : 1), dim3(HT), lds, (hipStream_t)stream, a);
+    if ((rc = tmf_allow_lds(HEADS_K(cnn_heads_bwd_kernel, d->B), lds, "tmf_heads_cnn_bwd"))) return rc;
+    hipLaunchKernelGGL(HEADS_K(cnn_heads_bwd_kernel, d->B), dim3(d->HD > 0 ? 1 + ND : 1), dim3(HT), lds, (hipStream_t)stream, a);
     if ((rc = tmf_launch_result("tmf_heads_cnn_bwd"))) return rc;
     int nbt = tmf_cdiv((long)d->M * d->B * d->N * d->dim, (long)HT * 4 * 4);
     if (nbt > 256) nbt = 256;

@@ -134,7 +134,7 @@ def _cnn_heads_one_call_ok(model, fc, D, tok, M):
     M concatenated token means, D = Linear-BatchNorm1d-ReLU-Linear or None — then they are one launch per direction
     (ops.HeadsCNN); anything else takes the module path."""
     from . import ops
-    if not (ops.HEADS_ONE_CALL and tok.is_cuda and tok.dtype == torch.float32 and tok.shape[0] <= 16):
+    if not (ops.HEADS_ONE_CALL and tok.is_cuda and tok.dtype == torch.float32 and tok.shape[0] <= 32):
         return False
     dim = tok.shape[-1]
     if not (isinstance(fc, nn.Sequential) and [type(m) for m in fc] == [nn.Linear, nn.ReLU, nn.Linear]):
@@ -247,7 +247,7 @@ class model_ad(_FastModeSwitch, nn.Module):
         """The heads as the reference builds them (mymodel.py:190-194), nobody hooked into them, a batch the kernel
         holds in registers: fc_cls and both D calls are one launch per direction (ops.HeadsAD)."""
         from . import ops
-        if not (ops.HEADS_ONE_CALL and tok.is_cuda and tok.dtype == torch.float32 and tok.shape[0] <= 16):
+        if not (ops.HEADS_ONE_CALL and tok.is_cuda and tok.dtype == torch.float32 and tok.shape[0] <= 32):
             return False
         fc, D = self.fc_cls, self.D
         if not (isinstance(fc, nn.Sequential) and len(fc) == 9 and isinstance(D, nn.Sequential) and len(D) == 4):
