@@ -1293,6 +1293,11 @@ WINOX_SHAPES = [
     (2, 12, 24, 24, 64, 128),       # four chunks, four groups: workgroups walk several items and groups
     (2, 9, 17, 21, 128, 64),        # eight chunks, odd edges
     (5, 16, 16, 24, 32, 32),        # more items than compute units on a small device are still a strided list
+    # round 6: volumes whose items lie better with the 4-voxel side along h — the kernel then runs TRANSPOSED (its d axis = the
+    # tensor's h axis; strides and weight positions trade places)
+    (2, 22, 27, 22, 64, 64),        # the reference's 91x109x91 two levels down: 63 instead of 72 items per sample
+    (1, 8, 4, 8, 32, 32),           # one transposed item
+    (3, 15, 21, 9, 32, 64),         # ragged on every axis, two channel groups
 ]
 
 
@@ -1409,7 +1414,8 @@ def test_conv3d_winograd_weight_gradient_refuses_other_channel_counts():
 
 
 @pytest.mark.parametrize("shape,pool", [((2, 7, 9, 13, 8, 32), "max"), ((2, 7, 9, 13, 8, 32), None), ((2, 12, 16, 16, 32, 64), "max"),
-                                        ((1, 24, 24, 24, 64, 64), None), ((3, 9, 15, 21, 32, 32), "max"), ((2, 7, 10, 13, 64, 96), None)])
+                                        ((1, 24, 24, 24, 64, 64), None), ((3, 9, 15, 21, 32, 32), "max"), ((2, 7, 10, 13, 64, 96), None),
+                                        ((2, 22, 27, 22, 64, 64), "max"), ((1, 8, 12, 8, 32, 32), None)])     # (transposed items)
 def test_conv3d_winograd_eval_block_in_one_pass(shape, pool):
     """tmf_conv3d_fwd_wino_affine: the eval-mode block (conv + folded BatchNorm + LeakyReLU + max pool) in ONE Winograd kernel —
     conv3d_winox_kernel<2 | 3> where the split kernel takes the launch, conv3d_wino_p_kernel<2> otherwise — bitwise what the

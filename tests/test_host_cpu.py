@@ -350,9 +350,10 @@ def test_split_winograd_kernel_takes_the_launches_it_is_built_for():
     assert name(8, 48, 48, 48, 16, 32, 1) == b"conv3d_wino_p_kernel<1, 0>"   # cin % 32
     assert name(8, 12, 12, 12, 128, 256, 1) == b"conv3d_wino_p_kernel<1, 1>"  # four samples x 4x4x4 bricks
     # the geometry is chosen WITH the channel counts (round 6): 22x27x22 at B = 8 — the reference's 91x109x91 two levels down — is
-    # 576 one-sample bricks against 504 folded ones; the split kernel on 576 beats the fp32 kernel on 504, so it keeps the launch where
-    # it can take it, and only there (the folded geometry must save more than 15 %)
-    assert lib.tmf_conv3d_wino_bricks(8, 22, 27, 22) == 504 and lib.tmf_conv3d_wino_bricks2(8, 22, 27, 22, 64, 128) == 576
+    # 576 (504 transposed) one-sample bricks against 504 folded ones; the split kernel beats the fp32 kernel on that many, so it keeps
+    # the launch where it can take it, and only there (the folded geometry must save more than 15 %)
+    # (... and the split kernel lays its items with the 4-voxel side along h there: 7 x 3 x 3 = 63 per sample instead of 6 x 4 x 3 = 72)
+    assert lib.tmf_conv3d_wino_bricks(8, 22, 27, 22) == 504 and lib.tmf_conv3d_wino_bricks2(8, 22, 27, 22, 64, 128) == 8 * 63
     assert name(8, 22, 27, 22, 64, 128, 1) == b"conv3d_winox_kernel<1>" and name(8, 22, 27, 22, 128, 64, 0) == b"conv3d_winox_kernel<0>"
     assert lib.tmf_conv3d_wino_bricks2(8, 22, 27, 22, 16, 64) == 504 and name(8, 22, 27, 22, 16, 64, 1) == b"conv3d_wino_p_kernel<1, 1>"
     assert lib.tmf_conv3d_wino_bricks2(8, 11, 13, 11, 128, 256) == 72 and name(8, 11, 13, 11, 128, 256, 1) == b"conv3d_wino_p_kernel<1, 1>"

@@ -1835,7 +1835,7 @@ int wino_p_geom(int B, int D, int H, int W) {
 int wino_fwd_geom(int B, int D, int H, int W, int cin, int cout) {
     const int g = wino_p_geom(B, D, H, W);
     if (g == 0 || !tmf_winox_takes(B, D, H, W, cin, cout, 0)) return g;
-    const long t0 = (long)B * tmf_cdiv(D, 4) * tmf_cdiv(H, 8) * tmf_cdiv(W, 8);
+    const long t0 = (long)B * tmf_winox_items(D, H, W, nullptr);       // (the better of the split kernel's two item orientations)
     const long t1 = (long)tmf_cdiv(B, 4) * tmf_cdiv(D, 4) * tmf_cdiv(H, 4) * tmf_cdiv(W, 4);
     return 100 * t0 <= 115 * t1 ? 0 : 1;
 }
@@ -1930,7 +1930,11 @@ extern "C" int tmf_conv3d_wino_stat_blocks(int B, int D, int H, int W) {
 // ... of a launch with these channel counts (the split kernel's eligibility enters the choice of the geometry: wino_fwd_geom)
 extern "C" int tmf_conv3d_wino_bricks2(int B, int D, int H, int W, int cin, int cout) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    if (wino_p_mode()) return (int)wino_p_bricks(wino_fwd_geom(B, D, H, W, cin, cout), B, D, H, W);
+    if (wino_p_mode()) {
+        const int g = wino_fwd_geom(B, D, H, W, cin, cout);
+        if (tmf_winox_takes(B, D, H, W, cin, cout, g)) return (int)(B * tmf_winox_items(D, H, W, nullptr));
+        return (int)wino_p_bricks(g, B, D, H, W);
+    }
     return B * tmf_cdiv(D, TD) * tmf_cdiv(H, TH) * tmf_cdiv(W, TW);
 }
 extern "C" int tmf_conv3d_wino_bricks(int B, int D, int H, int W) {

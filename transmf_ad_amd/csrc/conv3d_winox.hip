@@ -150,7 +150,11 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
     const float* __restrict__ x, const unsigned short* __restrict__ u3, float* __restrict__ z, float* __restrict__ stat_partial,
     int B, int D, int H, int W, int Cin, int Cout, int tilesD, int tilesH, int tilesW, int nbricks, int item0, int nitems,
     int stat_rows, int stat_accum, const float* __restrict__ aff_scale = nullptr, const float* __restrict__ aff_shift = nullptr,
-    float slope = 0.f) {
+    float slope = 0.f, int swap = 0) {
+    // swap (round 6): the kernel's d axis is the TENSOR's h axis and vice versa — D, H, tilesD, tilesH arrive in kernel space, the
+    // voxel strides of the two axes trade places and so do pd / ph in the weight positions (U is separable: U_k[pd][ph] = U[ph][pd]).
+    // The items' 4-voxel side then lies along the tensor's h: 22x27x22 is 7 x 3 x 3 = 63 items per sample instead of 6 x 4 x 3 = 72.
+    const int sd = swap ? W : H * W, sh = swap ? D * W : W;                 // voxel strides of the kernel's d and h axes
     constexpr bool STATS = MODE == 1;
     constexpr bool AFFINE = MODE >= 2, POOL = MODE == 3;
     constexpr int EPI_STORES = POOL ? 1 : 4;                // vector-memory stores of an item's epilogue (static: the counted waits)
@@ -203,7 +207,7 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
         auto range = [](int lo, int hi) { return ((1 << hi) - 1) & ~((1 << lo) - 1); };
         auto mn = [](int a, int b_) { return a < b_ ? a : b_; };
         // byte offset of the halo's voxel (0, 0, 0) = (d0 - 1, h0 - 1, w0 - 1) in the sample and the valid halo coordinates per axis
-        tab[2 * i + 1] = i32x4{(((d0 - 1) * H + (h0 - 1)) * W + (w0 - 1)) * Cin * 4,
+        tab[2 * i + 1] = i32x4{((d0 - 1) * sd + (h0 - 1) * sh + (w0 - 1)) * Cin * 4,
                                range(d0 == 0 ? 1 : 0, mn(BD + 2, D - d0 + 1)) | (range(h0 == 0 ? 1 : 0, mn(BH + 2, H - h0 + 1)) << 6) |
                                    (range(w0 == 0 ? 1 : 0, mn(BW + 2, W - w0 + 1)) << 16), 0, 0};
     }
@@ -219,7 +223,7 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
         const bool real = bb < 5 && c_ < 5;
         const int hd = 2 * a_ + (par >> 2), hh = 2 * bb + ((par >> 1) & 1), hw = 2 * c_ + (par & 1);
         const int quad = (e & 1) ^ (bb & 1);
-        plan[q * XN] = (((hd * H + hh) * W + hw) * Cin + quad * 4) * 4;
+        plan[q * XN] = ((hd * sd + hh * sh + hw) * Cin + quad * 4) * 4;
         plan[(3 + q) * XN] = real ? (1 << hd) | (1 << (6 + hh)) | (1 << (16 + hw)) : (1 << 30);
     }
     i32x4 xr = make_rsrc(x, 0);
@@ -261,11 +265,13 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
     const i32x4 ur = make_rsrc(u3, (unsigned)(64 * Cin * Cout * 6));
     const int b_lane = (hsel * Cout + l31) * 16;
     const int part_b = 2 * Cout * 16, chunk_b = 3 * part_b, pos_b = nchunk * chunk_b;
-    const int p_first = ((mpd * 4 + 2 * mhh) * 4) * pos_b;   // this wave's positions: p_first + (phl * 4 + pw) * pos_b
+    // this wave's positions: p_first + (phl * 4 + pw) * pos_b; swap: the tensor's position (ph, pd, pw) = p_first + (phl * 16 + pw) * pos_b
+    const int p_first = (swap ? (2 * mhh * 4 + mpd) * 4 : (mpd * 4 + 2 * mhh) * 4) * pos_b;
+    const int q_hi = swap ? 16 : 4;
     i32x4 Bq[4][3];                                         // [stream position & 3][part h, m, l]
     auto load_b = [&](int slot, int q8, int c, int n0) {
         if (X_ABL & 2) return;
-        const int so = p_first + q8 * pos_b + c * chunk_b + n0 * 16;
+        const int so = p_first + ((q8 >> 2) * q_hi + (q8 & 3)) * pos_b + c * chunk_b + n0 * 16;
         bload16(Bq[slot][0], b_lane, ur, so);
         bload16(Bq[slot][1], b_lane, ur, so + part_b);
         bload16(Bq[slot][2], b_lane, ur, so + 2 * part_b);
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
         f32x4 P1[4][2];                                     // [j][wo]: the ho = 1 partials wait for the second pass
         const int le = lane_now();
         const int cq = le & 7, rwo = (le >> 3) & 1, vq = le >> 4, r_tw = vq;
-        const int st_lane = ((((2 * r_td) * H + 2 * r_th) * W + 2 * r_tw + rwo) * Cout + 4 * cq) * 4;
+        const int st_lane = ((2 * r_td * sd + 2 * r_th * sh + 2 * r_tw + rwo) * Cout + 4 * cq) * 4;
         float* red_l = red + (wave * 8 + (le >> 3)) * 33 + 4 * cq;
         float* exw = ex + (wave * 32 + (le & 31)) * TS + 4 * (le >> 5);
 #pragma unroll
@@ -523,7 +529,7 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
             a_sh = *reinterpret_cast<const f32x4*>(&red[32 + 4 * cq]);
         }
         const int gd0 = d0 + 2 * r_td, gh0 = h0 + 2 * r_th, gw = w0 + 2 * r_tw + rwo;
-        const int st_item = (((d0 * H + h0) * W + w0) * Cout + n0) * 4;
+        const int st_item = ((d0 * sd + h0 * sh + w0) * Cout + n0) * 4;
         const float* exr = ex + (4 * wave + vq) * TS + rwo * 32 + 4 * cq;
         auto pass = [&](int ho) {
             wg_barrier();                                   // (lgkmcnt(0) first: this wave's exchange writes)
@@ -568,9 +574,10 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
                     }
                     const int od = (d0 >> 1) + r_td, oh = (h0 >> 1) + r_th, ow = (w0 >> 1) + r_tw;
                     const bool okp = rwo == 0 && od < OD && oh < OH && ow < OW;
-                    const int voff = (((r_td * OH + r_th) * OW + r_tw) * Cout + 4 * cq) * 4;
+                    const int osd = swap ? OW : OH * OW, osh = swap ? OD * OW : OW;
+                    const int voff = ((r_td * osd + r_th * osh + r_tw) * Cout + 4 * cq) * 4;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tmf_u32x4, m), zr, okp ? voff : OOB,
-                                                           ((((d0 >> 1) * OH + (h0 >> 1)) * OW + (w0 >> 1)) * Cout + n0) * 4, 0);
+                                                           (((d0 >> 1) * osd + (h0 >> 1) * osh + (w0 >> 1)) * Cout + n0) * 4, 0);
                     store_guard();
                 }
                 return;
@@ -581,7 +588,7 @@ __global__ __launch_bounds__(XN) void conv3d_winox_kernel(
                 // (always issued — the counted waits of the next item rely on exactly four stores per epilogue; a lane outside the
                 // volume is out of the resource's range and dropped)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(tmf_u32x4, o[dd]), zr, ok ? st_lane : OOB,
-                                                       st_item + ((dd * H + ho) * W) * Cout * 4, 0);
+                                                       st_item + (dd * sd + ho * sh) * Cout * 4, 0);
                 store_guard();                              // (its data registers die right behind the store)
                 if (STATS) {
 #pragma unroll
@@ -653,8 +660,21 @@ int tmf_winox_takes(int B, int D, int H, int W, int cin, int cout, int geom) {
     return wino_x_mode() && geom == 0 && cin % 32 == 0 && cout % 32 == 0 && cout <= 1024;
 }
 
-int tmf_winox_launch(const char* what, const float* x, const unsigned short* u3, float* z, float* stat_partial, int B, int D, int H,
+// items per sample of a volume, and whether the transposed form (4-voxel side along the tensor's h) has fewer
+long tmf_winox_items(int D, int H, int W, int* swap) {
+    const long t_n = (long)tmf_cdiv(D, BD) * tmf_cdiv(H, BH) * tmf_cdiv(W, BW);
+    const long t_s = (long)tmf_cdiv(H, BD) * tmf_cdiv(D, BH) * tmf_cdiv(W, BW);
+    static const bool allow = !(getenv("TMF_WINOX_SWAP") && atoi(getenv("TMF_WINOX_SWAP")) == 0);
+    const int sw = allow && t_s < t_n ? 1 : 0;
+    if (swap) *swap = sw;
+    return sw ? t_s : t_n;
+}
+
+int tmf_winox_launch(const char* what, const float* x, const unsigned short* u3, float* z, float* stat_partial, int B, int Dt, int Ht,
                      int W, int cin, int cout, int ncu, hipStream_t stream, const float* scale, const float* shift, float slope, int pool) {
+    int swap = 0;
+    tmf_winox_items(Dt, Ht, W, &swap);
+    const int D = swap ? Ht : Dt, H = swap ? Dt : Ht;        // kernel space
     const int tilesD = tmf_cdiv(D, BD), tilesH = tmf_cdiv(H, BH), tilesW = tmf_cdiv(W, BW);
     TMF_REQUIRE(tilesD < 1024 && tilesH < 1024 && tilesW < 1024, TMF_E_SHAPE, "%s: more than 1023 bricks along one axis", what);
     TMF_REQUIRE((long)D * H * W * (cin > cout ? cin : cout) < (1L << 29), TMF_E_SHAPE,
@@ -675,7 +695,7 @@ int tmf_winox_launch(const char* what, const float* x, const unsigned short* u3,
                 grid = (int)((n + rounds - 1) / rounds);
             }
             hipLaunchKernelGGL(k, dim3(grid), dim3(XN), X_LDS_BYTES, stream, x, u3, z, stat_partial, B, D, H, W, cin, cout,
-                               tilesD, tilesH, tilesW, (int)nbricks, (int)i0, (int)n, ncu, i0 > 0 ? 1 : 0, scale, shift, slope);
+                               tilesD, tilesH, tilesW, (int)nbricks, (int)i0, (int)n, ncu, i0 > 0 ? 1 : 0, scale, shift, slope, swap);
             if ((rc = tmf_launch_result(what))) return rc;
         }
         return TMF_OK;

@@ -104,6 +104,7 @@ struct TmfAlgoScope {
 };
 int tmf_wino_x_set(int v);       // conv3d_winox.hip: tmf_set_option("wino_x", 0 | 1): Winograd forward / data gradient as exact 3-way bf16 splits on the bf16 matrix pipe
 int tmf_winox_takes(int B, int D, int H, int W, int cin, int cout, int geom);
+long tmf_winox_items(int D, int H, int W, int* swap);     // items per sample (the better of the two item orientations)
 int tmf_winox_launch(const char* what, const float* x, const unsigned short* u3, float* z, float* stat_partial, int B, int D, int H,
                      int W, int cin, int cout, int ncu, hipStream_t stream, const float* scale = nullptr, const float* shift = nullptr,
                      float slope = 0.f, int pool = 0);     // scale != NULL: the eval-mode block (y = LeakyReLU(scale z + shift), pool none | max)
